@@ -1,0 +1,354 @@
+"""CPU oracle for the KV-Compress eviction/compaction hot path.
+
+TEST INFRASTRUCTURE ONLY.  This module is the *checker*: a NumPy restatement of
+the reference algorithm, function by function, each citing the reference
+file:line it follows.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it.  The product
+(``vllm_kvcompress_amd``) never does and has no CPU fallback.
+
+Parity pinning: every function here is checked in ``tests/test_oracle_golden.py``
+against golden vectors under ``tests/golden/`` that were produced by importing
+the reference's own Python (``vllm/_custom_ops.py`` ``ref_*`` twins and
+``vllm/kvcompress/metrics.py::CompressionMetrics.schedule_evictions``) in the
+build container with ``oracle/gen_golden.py`` (committed).  The native kernels
+(`count_block_evictions_kernel`, `single_tier_schedule_cache_moves_kernel`,
+`execute_cache_moves_kernel`) are CUDA and cannot be built here (no nvcc; a
+hipify would be a port, which this repo must not contain), so for those the
+anchor is the reference's Python twins, which the reference's own test asserts
+equal to the kernels (tests/kernels/test_kvcompress_eviction.py:900-901,967).
+
+Tie order.  The reference sorts float metrics with ``torch.sort`` (unstable);
+its result on tied metrics is implementation defined.  The oracle (and the HIP
+path) define the canonical order as *stable by masked flat index* ``f``
+(SURVEY.md section 8(a) step 3), chunk thresholds tie-break by
+(head, chunk).  On tie-free inputs this is irrelevant and the oracle is
+bit-identical to the reference (all golden vectors are tie-free).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+MAX_INT = 2147483000  # vllm/kvcompress/metrics.py:12
+
+INF32 = np.float32(np.inf)
+
+
+# --------------------------------------------------------------------------------------
+# KVHeadBias.get_bias_for_position        vllm/kvcompress/metrics.py:54-81
+# --------------------------------------------------------------------------------------
+def bias_for_position(bias, position_bins, positions, layer_idx, head_idx):
+    """bias [L,H,nbins] f32, position_bins [nbins] i32, positions [nb,bs] i32,
+    layer_idx/head_idx [nb] -> [nb,bs] f32."""
+    nbins = position_bins.shape[0]
+    # number of bins with position >= bin, minus one; -1 wraps to the last bin
+    # (Python negative indexing in the reference gather, metrics.py:72-77)
+    cnt = (positions[..., None] >= position_bins[None, None, :]).sum(-1) - 1
+    cnt = np.where(cnt < 0, cnt + nbins, cnt)
+    out = bias[layer_idx[:, None], head_idx[:, None], cnt].astype(np.float32)
+    out = np.where(positions < 0, np.float32(0), out)
+    return out.astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# count_block_evictions_kernel            csrc/kvcompress_eviction_kernels.cu:190-221
+# --------------------------------------------------------------------------------------
+def count_block_evictions(evicted_block_count, evicted_logical_indices, evicted_kv_offsets,
+                          hanging_token_count, block_size, null_value):
+    """In place on ``evicted_block_count`` and ``evicted_logical_indices``."""
+    offs = evicted_kv_offsets.reshape(-1)
+    hang = hanging_token_count.reshape(-1)
+    out = evicted_block_count.reshape(-1)
+    total_heads = offs.shape[0]
+    total_kvs = evicted_logical_indices.shape[0]
+    for g in range(total_heads):
+        start = int(offs[g])
+        end = total_kvs if g + 1 >= total_heads else int(offs[g + 1])
+        n = 0
+        i = start
+        while i < end:
+            if evicted_logical_indices[i] != null_value:
+                n += 1
+            else:
+                break
+            i += block_size
+        out[g] = n
+        if n > 0:
+            last_end = start + n * block_size
+            evicted_logical_indices[last_end - block_size + int(hang[g]):last_end] = null_value
+
+
+# --------------------------------------------------------------------------------------
+# CompressionMetrics.schedule_evictions   vllm/kvcompress/metrics.py:441-847
+# --------------------------------------------------------------------------------------
+def schedule_evictions(
+    *,
+    metrics, token_positions, seq_index_by_block, layer_index_by_block,
+    head_index_by_block, logical_block_num_by_block,
+    block_size, num_layers, num_kv_heads,
+    seq_indices, seq_positions, evicted_blocks_per_seq,
+    context_lens, hanging_token_count, evicted_kv_offsets, num_protected,
+    use_average=False, num_sinks=0,
+    bias=None, position_bins=None, bias_weight=0.0,
+    mode="reference",
+):
+    """Returns (evicted_logical_indices [N] i32, evicted_kv_count [B,L,H] i32,
+    evicted_block_count [B,L,H] i32).
+
+    mode="reference"     bit-exact to the reference including its batch>1
+                         inf-count quirk (metrics.py:718-721).
+    mode="per_sequence"  every sequence scheduled as if it were alone (== the
+                         reference called with B=1 per sequence).
+    """
+    bs, L, H = block_size, num_layers, num_kv_heads
+    seq_indices = [int(s) for s in seq_indices]
+    assert sorted(seq_indices) == seq_indices          # metrics.py:459
+    B = len(seq_indices)
+    seq_positions = np.asarray(seq_positions, dtype=np.int32).reshape(-1)
+    num_protected = np.asarray(num_protected, dtype=np.int32).reshape(-1)
+    evicted_blocks_per_seq = [int(x) for x in np.asarray(evicted_blocks_per_seq).reshape(-1)]
+
+    # candidate blocks in ascending physical order            metrics.py:465-493
+    slot_of_seq = np.full(max(seq_indices) + 1, -1, dtype=np.int64)
+    for i, s in enumerate(seq_indices):
+        slot_of_seq[s] = i
+    sib = seq_index_by_block.astype(np.int64)
+    seq_mask = (sib >= 0) & (sib <= max(seq_indices))
+    seq_mask &= slot_of_seq[np.clip(sib, 0, max(seq_indices))] >= 0
+    blocks = np.nonzero(seq_mask)[0]
+    m = metrics[blocks].astype(np.float32).reshape(-1).copy()
+    pos = token_positions[blocks].astype(np.int32)              # [nb,bs]
+    lay = layer_index_by_block[blocks].astype(np.int64)
+    head = head_index_by_block[blocks].astype(np.int64)
+    lbn = logical_block_num_by_block[blocks].astype(np.int64)
+    bslot = slot_of_seq[sib[blocks]]                             # batch slot i
+    lam = (lbn[:, None] * bs + np.arange(bs)[None, :]).astype(np.int32)
+
+    if use_average:                                              # metrics.py:495-501
+        qcount = (seq_positions[bslot][:, None] - pos).astype(np.float32).reshape(-1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            m = (m / qcount).astype(np.float32)
+    if bias is not None:                                         # metrics.py:503-506
+        b = bias_for_position(bias, position_bins, pos, lay, head).reshape(-1)
+        m = (m + (b * np.float32(bias_weight)).astype(np.float32)).astype(np.float32)
+
+    slh = bslot * (L * H) + lay * H + head                       # metrics.py:520-524
+    ctx_of = context_lens.transpose(1, 0, 2).reshape(-1)[slh].astype(np.int64)
+    max_in_range = (seq_positions - num_protected)[bslot]        # metrics.py:513-515
+    in_range = ((lbn < (ctx_of + bs - 1) // bs)[:, None]
+                & (pos <= max_in_range[:, None])
+                & (pos >= num_sinks))                            # metrics.py:539-543
+    m[~in_range.reshape(-1)] = INF32
+
+    # 1. order by (head, metric, flat index f)                   metrics.py:562-570
+    nslots = m.shape[0]
+    f = np.arange(nslots)
+    slh_slot = np.repeat(slh, bs)
+    order = np.lexsort((f, m, slh_slot))
+    sorted_m = m[order]
+    sorted_slh = slh_slot[order]
+
+    # 2. chunk thresholds                                        metrics.py:583-596
+    chunk_head = sorted_slh.reshape(-1, bs)[:, 0]
+    hang_chunk = hanging_token_count.reshape(-1)[chunk_head].astype(np.int64)
+    nchunks = chunk_head.shape[0]
+    thr = sorted_m.reshape(-1, bs)[np.arange(nchunks), hang_chunk - 1]
+
+    # 3. per-sequence selection                                  metrics.py:604-755
+    sorted_lam = lam.reshape(-1)[order].reshape(-1, bs).copy()
+    total_blocks_per_seq = ((context_lens.astype(np.int64) + bs - 1) // bs).sum(0).sum(-1)
+    # seq of a chunk: reference takes it from the first slot's block (metrics.py:672-677)
+    chunk_seq = bslot[order.reshape(-1, bs)[:, 0] // bs]
+    corder = np.lexsort((np.arange(nchunks), thr, chunk_seq))    # (seq, thr, position)
+    seq_sorted_thr = thr[corder]
+    keep_mask_sorted = np.zeros(nchunks, dtype=bool)             # True = NOT evicted
+    offset = 0
+    for i, k in enumerate(evicted_blocks_per_seq):
+        end_offset = offset + int(total_blocks_per_seq[i])
+        un = offset + k
+        if mode == "reference":
+            ninf = int(np.count_nonzero(seq_sorted_thr[:un] == INF32))       # :718 (from 0)
+        elif mode == "per_sequence":
+            ninf = int(np.count_nonzero(seq_sorted_thr[offset:un] == INF32))
+        else:
+            raise ValueError(mode)
+        un -= ninf
+        assert un >= 0
+        keep_mask_sorted[un:end_offset] = True                   # :723
+        assert np.all(seq_sorted_thr[offset:un] < INF32)         # :725
+        offset = end_offset
+    keep_chunk = np.zeros(nchunks, dtype=bool)
+    keep_chunk[corder] = keep_mask_sorted                        # :755 (remap)
+    sorted_lam[keep_chunk, :] = MAX_INT
+    flat = sorted_lam.reshape(-1).astype(np.int32)
+
+    # count leading evicted chunks per head, truncate hanging tail   metrics.py:773-792
+    evicted_block_count = np.empty_like(evicted_kv_offsets, dtype=np.int32)
+    count_block_evictions(evicted_block_count, flat, evicted_kv_offsets,
+                          hanging_token_count, bs, MAX_INT)
+    evicted_kv_count = np.where(
+        evicted_block_count > 0,
+        (evicted_block_count - 1) * bs + hanging_token_count, 0).astype(np.int32)
+    assert np.all(context_lens.transpose(1, 0, 2) >= evicted_kv_count)   # :798
+
+    # 4. per head ascending logical index                        metrics.py:822-834
+    final = np.lexsort((flat, sorted_slh))
+    return flat[final].astype(np.int32), evicted_kv_count, evicted_block_count
+
+
+# --------------------------------------------------------------------------------------
+# single_tier_schedule_cache_moves_kernel  csrc/kvcompress_eviction_kernels.cu:223-289
+# (Python twin: vllm/_custom_ops.py:1108-1154; wrapper zero-fill :1168)
+# --------------------------------------------------------------------------------------
+def schedule_cache_moves(out_cache_moves_idx, out_cache_moves_count, evicted_logical_indices,
+                         evicted_kv_count, evicted_kv_offsets, block_tables, context_lens,
+                         block_size):
+    """In place. ``out_cache_moves_idx [R,2]`` is zero-filled first like the wrapper."""
+    out_cache_moves_idx[...] = 0
+    B, L, H = evicted_kv_count.shape
+    bs = block_size
+    E = evicted_logical_indices
+    for b in range(B):
+        for l in range(L):
+            for h in range(H):
+                cnt = int(evicted_kv_count[b, l, h])
+                off = int(evicted_kv_offsets[b, l, h])
+                ctx = int(context_lens[l, b, h])
+                bt = block_tables[l, b, h]
+                mc = 0
+                ec = 0
+                for i in range(cnt):
+                    src = ctx - 1 - i
+                    stop = int(E[off + cnt - 1 - ec])
+                    dst = int(E[off + mc])
+                    if dst >= src:
+                        break
+                    if src <= stop:
+                        ec += 1
+                        continue
+                    out_cache_moves_idx[off + mc, 0] = int(bt[dst // bs]) * bs + dst % bs
+                    out_cache_moves_idx[off + mc, 1] = int(bt[src // bs]) * bs + src % bs
+                    mc += 1
+                out_cache_moves_count[b, l, h] = mc
+
+
+# --------------------------------------------------------------------------------------
+# execute_cache_moves_kernel               csrc/kvcompress_eviction_kernels.cu:359-435
+# (Python twin: vllm/_custom_ops.py:1182-1216)
+# --------------------------------------------------------------------------------------
+def execute_cache_moves(k_cache, v_cache, kv_metrics, kv_position, cache_moves_idx,
+                        cache_moves_count, evicted_kv_offsets):
+    """k_cache [NB, hd/x, bs, x], v_cache [NB, hd, bs] (any dtype; byte copy),
+    kv_metrics [NB,bs] f32, kv_position [NB,bs] i32.  In place."""
+    bs = v_cache.shape[2]
+    cnt = cache_moves_count.reshape(-1)
+    off = evicted_kv_offsets.reshape(-1)
+    met = kv_metrics.reshape(-1)
+    posv = kv_position.reshape(-1)
+    for g in range(cnt.shape[0]):
+        o = int(off[g])
+        for j in range(int(cnt[g])):
+            dst = int(cache_moves_idx[o + j, 0])
+            src = int(cache_moves_idx[o + j, 1])
+            db, do = divmod(dst, bs)
+            sb, so = divmod(src, bs)
+            met[dst] = met[src]
+            posv[dst] = posv[src]
+            k_cache[db, :, do, :] = k_cache[sb, :, so, :]
+            v_cache[db, :, do] = v_cache[sb, :, so]
+
+
+def execute_cache_moves_vectorized(k_cache, v_cache, kv_metrics, kv_position, cache_moves_idx,
+                                   cache_moves_count, evicted_kv_offsets):
+    """Same result as :func:`execute_cache_moves` for independent moves (no dst is
+    also a src, dsts distinct) -- the only case the reference kernel defines
+    (csrc/kvcompress_eviction_kernels.cu:358).  Used at sizes where the scalar loop
+    is too slow."""
+    bs = v_cache.shape[2]
+    cnt = cache_moves_count.reshape(-1).astype(np.int64)
+    off = evicted_kv_offsets.reshape(-1).astype(np.int64)
+    rows = np.concatenate([np.arange(o, o + c) for o, c in zip(off, cnt)]) if cnt.sum() else \
+        np.zeros(0, dtype=np.int64)
+    dst = cache_moves_idx[rows, 0].astype(np.int64)
+    src = cache_moves_idx[rows, 1].astype(np.int64)
+    assert np.intersect1d(dst, src).size == 0 and np.unique(dst).size == dst.size
+    kv_metrics.reshape(-1)[dst] = kv_metrics.reshape(-1)[src]
+    kv_position.reshape(-1)[dst] = kv_position.reshape(-1)[src]
+    k_cache[dst // bs, :, dst % bs, :] = k_cache[src // bs, :, src % bs, :]
+    v_cache[dst // bs, :, dst % bs] = v_cache[src // bs, :, src % bs]
+
+
+# --------------------------------------------------------------------------------------
+# aggregation                               vllm/kvcompress/metrics.py:337-342,396-439
+# --------------------------------------------------------------------------------------
+def aggregate_decode(metrics, temp_metrics, use_l2=True):
+    """metrics [NB,bs] f32 += sum_q temp^2 (or temp); float32, sum over the last
+    (qpk) axis in index order (torch sum over a contiguous last dim of 4)."""
+    t = temp_metrics.astype(np.float32)
+    if use_l2:
+        t = (t * t).astype(np.float32)
+    acc = np.zeros(t.shape[:-1], dtype=np.float32)
+    for q in range(t.shape[-1]):
+        acc = (acc + t[..., q]).astype(np.float32)
+    metrics += acc
+
+
+def aggregate_prefill(metrics, prefill_metrics, slot_mapping, num_kv_heads):
+    """prefill_metrics [T, H*qpk] f32, slot_mapping [T,H] i64 (unique slots)."""
+    T = prefill_metrics.shape[0]
+    v = prefill_metrics.astype(np.float32).reshape(T, num_kv_heads, -1)
+    acc = np.zeros((T, num_kv_heads), dtype=np.float32)
+    for q in range(v.shape[-1]):
+        acc = (acc + v[..., q]).astype(np.float32)
+    flat = metrics.reshape(-1)
+    slots = slot_mapping.reshape(-1).astype(np.int64)
+    flat[slots] = (flat[slots] + acc.reshape(-1)).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# prefill metric epilogue   vllm/attention/backends/flash_attn.py:1147-1211
+# (square -> mask -> column sum -> [avg scale] -> maxpool7), per q-block, then accumulate
+# --------------------------------------------------------------------------------------
+def prefill_metric_epilogue(out_kh, probs_hqk, q_offset, buffer_len, use_l2=True,
+                            use_average=False, use_maxpool=True):
+    """out_kh [K,Hq] f32 += epilogue(probs_hqk [Hq,qb,K] f32).  ``q_offset`` is the
+    absolute position (within the sequence) of the first query row of the tile."""
+    Hq, qb, K = probs_hqk.shape
+    p = probs_hqk.astype(np.float32)
+    if use_l2:
+        p = (p * p).astype(np.float32)
+    q = np.arange(qb)[:, None]
+    k = np.arange(K)[None, :]
+    mask = (k - q) <= (q_offset - int(buffer_len))      # tril(diagonal=q_offset-buffer_len)
+    colsum = (p * mask[None].astype(np.float32)).sum(axis=1, dtype=np.float32)   # [Hq,K]
+    if use_average:
+        scale = (np.arange(1, K + 1, dtype=np.float32) / np.float32(qb)).astype(np.float32)
+        colsum = (colsum * scale[None]).astype(np.float32)
+    if use_maxpool:
+        pad = np.full((Hq, 3), -np.inf, dtype=np.float32)
+        ext = np.concatenate([pad, colsum, pad], axis=1)
+        win = np.stack([ext[:, i:i + K] for i in range(7)], axis=0)
+        colsum = win.max(axis=0)
+    out_kh += colsum.T.astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# single_tier_reshape_and_cache_kernel     csrc/kvcompress_cache_kernels.cu:27-89
+# --------------------------------------------------------------------------------------
+def reshape_and_cache_kvc(key, value, key_cache, value_cache, kv_metrics, slot_mapping,
+                          kv_metric_head_bias):
+    """key/value [T,H,hd] (same dtype as the caches: "auto" path), key_cache
+    [NB,hd/x,bs,x], value_cache [NB,hd,bs], slot_mapping [T*H] i64 (<0 = skip)."""
+    T, H, hd = key.shape
+    bs = value_cache.shape[2]
+    x = key_cache.shape[3]
+    sm = slot_mapping.reshape(T, H)
+    met = kv_metrics.reshape(-1)
+    for t in range(T):
+        for h in range(H):
+            s = int(sm[t, h])
+            if s < 0:
+                continue
+            met[s] = kv_metric_head_bias[h]
+            b, o = divmod(s, bs)
+            key_cache[b, :, o, :] = key[t, h].reshape(hd // x, x)
+            value_cache[b, :, o] = value[t, h]

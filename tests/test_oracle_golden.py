@@ -1,0 +1,79 @@
+"""Pin the oracle: every function of oracle/kvc_oracle.py against the golden
+vectors produced by the reference's own Python (oracle/gen_golden.py)."""
+import numpy as np
+import pytest
+
+from oracle import kvc_oracle as orc
+from tests.conftest import golden_cases
+from tests.helpers import golden_caches, load_golden, sched_kwargs, sha
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_schedule_evictions_matches_reference(name):
+    g = load_golden(name)
+    eli, ekc, ebc = orc.schedule_evictions(**sched_kwargs(g), mode="reference")
+    np.testing.assert_array_equal(eli, g["ref_evicted_logical_indices"])
+    np.testing.assert_array_equal(ekc, g["ref_evicted_kv_count"])
+    np.testing.assert_array_equal(ebc, g["ref_evicted_block_count"])
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_schedule_and_execute_moves_match_reference(name):
+    g = load_golden(name)
+    bs = int(g["block_size"])
+    eli, ekc = g["ref_evicted_logical_indices"], g["ref_evicted_kv_count"]
+    cmi = np.full_like(g["ref_cache_moves_idx"], 77)         # wrapper must zero-fill
+    cmc = np.zeros_like(g["ref_cache_moves_count"])
+    orc.schedule_cache_moves(cmi, cmc, eli, ekc, g["evicted_kv_offsets"], g["block_tables"],
+                             g["context_lens"], bs)
+    np.testing.assert_array_equal(cmi, g["ref_cache_moves_idx"])
+    np.testing.assert_array_equal(cmc, g["ref_cache_moves_count"])
+
+    k, v = golden_caches(g)
+    m, p = g["metrics"].copy(), g["token_positions"].copy()
+    k1, v1, m1, p1 = k.copy(), v.copy(), m.copy(), p.copy()
+    orc.execute_cache_moves(k, v, m, p, cmi, cmc, g["evicted_kv_offsets"])
+    np.testing.assert_array_equal(sha(k), g["ref_k_sha256"])
+    np.testing.assert_array_equal(sha(v), g["ref_v_sha256"])
+    np.testing.assert_array_equal(m, g["ref_metrics"])
+    np.testing.assert_array_equal(p, g["ref_positions"])
+    if "ref_k_cache" in g:
+        np.testing.assert_array_equal(k, g["ref_k_cache"])
+        np.testing.assert_array_equal(v, g["ref_v_cache"])
+    # the vectorised form (used at large sizes) is the same function
+    orc.execute_cache_moves_vectorized(k1, v1, m1, p1, cmi, cmc, g["evicted_kv_offsets"])
+    np.testing.assert_array_equal(k1, k)
+    np.testing.assert_array_equal(v1, v)
+    np.testing.assert_array_equal(m1, m)
+    np.testing.assert_array_equal(p1, p)
+
+
+def test_per_sequence_mode_equals_reference_at_b1():
+    """mode="per_sequence" is defined as the reference run with B=1 per sequence."""
+    for name in golden_cases():
+        g = load_golden(name)
+        if len(g["seq_indices"]) != 1:
+            continue
+        a = orc.schedule_evictions(**sched_kwargs(g), mode="reference")
+        b = orc.schedule_evictions(**sched_kwargs(g), mode="per_sequence")
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+
+
+def test_count_block_evictions_hand_cases():
+    """count_block_evictions_kernel (csrc/kvcompress_eviction_kernels.cu:190-221) by hand:
+    leading run of chunk heads != null, then the hanging tail of the last chunk is nulled."""
+    NUL = 99
+    bs = 4
+    idx = np.array([1, 2, 3, 4, 5, 6, 7, 8, NUL, NUL, NUL, NUL,      # head0: 2 chunks
+                    NUL, 1, 1, 1,                                   # head1: 0 (first is null)
+                    3, 3, 3, 3, NUL, 2, 2, 2, 9, 9, 9, 9],          # head2: 1 (run stops)
+                   dtype=np.int32)
+    offs = np.array([[[0, 12, 16]]], dtype=np.int32)
+    hang = np.array([[[3, 4, 1]]], dtype=np.int32)
+    out = np.zeros((1, 1, 3), dtype=np.int32)
+    orc.count_block_evictions(out, idx, offs, hang, bs, NUL)
+    assert out.reshape(-1).tolist() == [2, 0, 1]
+    assert idx.tolist() == [1, 2, 3, 4, 5, 6, 7, NUL, NUL, NUL, NUL, NUL,
+                            NUL, 1, 1, 1,
+                            3, NUL, NUL, NUL, NUL, 2, 2, 2, 9, 9, 9, 9]
