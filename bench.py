@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""Hot-path benchmark: KV slots evicted+compacted per second on MI355X.
+
+A "step" is one full pass of the eviction/compaction hot path over one compression
+batch of synthetic paged-cache state resident in HBM:
+
+    S1  CompressionMetrics.schedule_evictions   (A3, includes A4's count)
+    S2  schedule_cache_moves                     (A5)
+    S3  execute_cache_moves                      (A6, the K/V compaction)
+
+Default workload = BASELINE.json configs[1]: Llama-3-8B shape (32 layers, 8 KV heads,
+hd 128), 32k-token cache, block_size 16, batch 1, compress_once to half the cache
+(max_cache_tokens = T/2), fp16 K/V, tie-free permutation metrics.  Scheduling always
+reads the pristine metric store; compaction writes working copies, so every step does
+identical work (the moves never touch their own sources).
+
+Multi GPU (launched by torch.distributed.run): sequences are sharded, every rank owns a
+private cache and runs the same per-rank workload (weak scaling); the only collective is
+the reduction of the throughput scalars.
+
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--kv-heads", type=int, default=8)
+    ap.add_argument("--head-size", type=int, default=128)
+    ap.add_argument("--block-size", type=int, default=16)
+    ap.add_argument("--seq-len", type=int, default=32768, help="cached tokens per sequence")
+    ap.add_argument("--batch", type=int, default=1, help="sequences per GPU")
+    ap.add_argument("--keep", type=float, default=0.5, help="max_cache_tokens / seq_len")
+    ap.add_argument("--protected", type=int, default=32)
+    ap.add_argument("--metric-shape", default="perm", choices=["perm", "decay"])
+    ap.add_argument("--mode", default="per_sequence", choices=["per_sequence", "reference"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-json", default=os.path.join(REPO, "profiles", "traffic.json"),
+                    help="PMC-derived HBM bytes per launch of the compaction kernel, if collected")
+    return ap.parse_args()
+
+
+def alg_bytes_per_move(head_size: int, elem_bytes: int) -> int:
+    """K and V, read+write, + metric r/w + position r/w + move pair read."""
+    return 4 * head_size * elem_bytes + 24
+
+
+def build_workload(args, seed, device):
+    import torch
+    from vllm_kvcompress_amd.harness import device as hdev
+    from vllm_kvcompress_amd.harness import synth
+    L, H, bs, hd = args.layers, args.kv_heads, args.block_size, args.head_size
+    # seq_len counts the freshly sampled token whose KV is not cached yet
+    st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs,
+                          seq_lens=[args.seq_len + 1] * args.batch, seed=seed,
+                          protected=args.protected, metric_shape=args.metric_shape,
+                          spare_block_frac=0.02)
+    evicted = [synth.evict_block_count(context_lens_lh=st.context_lens[:, b, :],
+                                       seq_len=args.seq_len + 1, block_size=bs,
+                                       protected_window_size=args.protected,
+                                       max_cache_tokens=int(args.seq_len * args.keep))
+               for b in range(args.batch)]
+    ds = hdev.upload(st, device, num_queries_per_kv=1, mode=args.mode)
+    g = torch.Generator(device=device)
+    g.manual_seed(1234 + seed)
+    kv = torch.randint(-32768, 32767, (2, st.num_blocks, bs * hd), dtype=torch.int16,
+                       device=device, generator=g).view(torch.float16)
+    k_cache, v_cache = hdev.split_kv_cache(kv, hd)
+    return st, ds, evicted, k_cache, v_cache
+
+
+def cpu_baseline(args):
+    """The oracle (a port of the reference algorithm) on the host, bounded sample:
+    BASELINE.json configs[0] (4k-token cache, one sequence), one full S1+S2+S3 pass."""
+    from oracle import kvc_oracle as orc
+    from oracle import kvc_oracle_c as orc_c
+    from vllm_kvcompress_amd.harness import synth
+    L, H, bs, hd = args.layers, args.kv_heads, args.block_size, args.head_size
+    T = 4096
+    st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs, seq_lens=[T + 1], seed=0,
+                          protected=args.protected, spare_block_frac=0.02)
+    evicted = [synth.evict_block_count(context_lens_lh=st.context_lens[:, 0, :], seq_len=T + 1,
+                                       block_size=bs, protected_window_size=args.protected,
+                                       max_cache_tokens=int(T * args.keep))]
+    k, v = synth.make_caches_u16(0, st.num_blocks, hd, bs)
+    k, v = np.ascontiguousarray(k), np.ascontiguousarray(v)
+    m, p = st.metrics.copy(), st.token_positions.copy()
+    t0 = time.perf_counter()
+    eli, ekc, ebc = orc.schedule_evictions(
+        metrics=st.metrics, token_positions=st.token_positions,
+        seq_index_by_block=st.seq_index_by_block, layer_index_by_block=st.layer_index_by_block,
+        head_index_by_block=st.head_index_by_block,
+        logical_block_num_by_block=st.logical_block_num_by_block, block_size=bs, num_layers=L,
+        num_kv_heads=H, seq_indices=st.seq_indices, seq_positions=st.seq_positions,
+        evicted_blocks_per_seq=evicted, context_lens=st.context_lens,
+        hanging_token_count=st.hanging_token_count, evicted_kv_offsets=st.evicted_kv_offsets,
+        num_protected=st.protected, mode="reference")
+    t1 = time.perf_counter()
+    cmi = np.zeros((st.total_slots, 2), np.int32)
+    cmc = np.zeros(ekc.shape, np.int32)
+    orc_c.schedule_cache_moves(cmi, cmc, eli, ekc, st.evicted_kv_offsets,
+                               np.ascontiguousarray(st.block_tables),
+                               np.ascontiguousarray(st.context_lens), bs)
+    t2 = time.perf_counter()
+    orc_c.execute_cache_moves(k, v, m, p, cmi, cmc, st.evicted_kv_offsets)
+    t3 = time.perf_counter()
+    units = int(ekc.sum()) + int(cmc.sum())
+    return {
+        "value": units / (t3 - t0), "unit": "KV slots/s", "cores": 1, "kind": "port",
+        "sample": f"Llama-3-8B shape, {T}-token cache, bs{bs}, B=1, keep={args.keep}: one "
+                  f"S1+S2+S3 pass of the oracle (NumPy schedule_evictions + C move/compaction "
+                  f"loops), {units} slots in {t3 - t0:.2f} s",
+        "stage_seconds": {"S1_schedule": t1 - t0, "S2_moves": t2 - t1, "S3_compact": t3 - t2},
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    from vllm_kvcompress_amd import _custom_ops as ops
+    import vllm_kvcompress_amd
+    vllm_kvcompress_amd.load()      # fail loudly if the HIP extension is missing
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device(device))
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    st, ds, evicted, k_cache, v_cache = build_workload(args, seed=rank, device=device)
+    bs = args.block_size
+    N = st.total_slots
+    work_metrics = ds.cm.metrics.clone()
+    work_pos = ds.cm.token_positions.clone()
+    cmi = torch.empty((N, 2), dtype=torch.int32, device=device)
+    cmc = torch.empty((st.num_seqs, st.num_layers, st.num_kv_heads), dtype=torch.int32, device=device)
+    evicted_t = torch.tensor(evicted, dtype=torch.int32, device=device)
+    seq_idx = list(st.seq_indices)
+    prot = list(st.protected)
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    marks = [[ev() for _ in range(4)] for _ in range(args.steps)]
+    out = {}
+
+    def step(i=None):
+        if i is not None: marks[i][0].record()
+        eli, ekc, ebc = ds.cm.schedule_evictions(seq_idx, ds.seq_positions, evicted_t,
+                                                 ds.context_lens, ds.hanging_token_count,
+                                                 ds.evicted_kv_offsets, prot, total_slots=N)
+        if i is not None: marks[i][1].record()
+        ops.schedule_cache_moves(cmi, cmc, eli, ekc, ds.evicted_kv_offsets, ds.block_tables,
+                                 ds.context_lens, bs)
+        if i is not None: marks[i][2].record()
+        ops.execute_cache_moves(k_cache, v_cache, work_metrics, work_pos, cmi, cmc,
+                                ds.evicted_kv_offsets, 1, 16)
+        if i is not None: marks[i][3].record()
+        out["ekc"], out["ebc"] = ekc, ebc
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+
+    evicted_slots = int(out["ekc"].sum().item())
+    moved_slots = int(cmc.sum().item())
+    freed_blocks = int(out["ebc"].sum().item())
+    assert freed_blocks == sum(evicted), (freed_blocks, sum(evicted))
+    s1 = sum(m[0].elapsed_time(m[1]) for m in marks) / args.steps
+    s2 = sum(m[1].elapsed_time(m[2]) for m in marks) / args.steps
+    s3 = sum(m[2].elapsed_time(m[3]) for m in marks) / args.steps
+
+    units_local = float((evicted_slots + moved_slots) * args.steps)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        u = torch.tensor([units_local, float(moved_slots), s3], dtype=torch.float64, device=device)
+        gathered = [torch.zeros_like(u) for _ in range(world)]
+        dist.all_gather(gathered, u)
+        elapsed = float(t.item())
+        units = sum(float(g[0]) for g in gathered)
+        per_rank = [{"moves": int(g[1]), "s3_ms": float(g[2])} for g in gathered]
+    else:
+        units = units_local
+        per_rank = None
+
+    if rank == 0:
+        e = 2
+        bpm = alg_bytes_per_move(args.head_size, e)
+        alg_bytes = moved_slots * bpm + 8 * st.total_heads
+        achieved = alg_bytes / (s3 * 1e-3) / 1e9
+        traffic = None
+        if os.path.exists(args.traffic_json):
+            try:
+                traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "KV slots evicted+compacted/sec and HBM GB/s, Llama-3-8B 32k cache blk16",
+            "value": units / elapsed,
+            "unit": "KV slots/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16 bytes / int32 indices / f32 metric compare",
+            "data": "synthetic (seeded paged cache, tie-free permutation metrics, random K/V bits)",
+            "config": {
+                "workload": f"Llama-3-8B shape L{args.layers} H{args.kv_heads} hd{args.head_size}, "
+                            f"{args.seq_len}-token cache, block_size {bs}, batch {args.batch}/GPU, "
+                            f"compress_once keep={args.keep}, protected_window={args.protected}, "
+                            f"metrics={args.metric_shape}, schedule mode={args.mode}",
+                "candidate_slots": N, "evicted_slots": evicted_slots, "moved_slots": moved_slots,
+                "freed_blocks": freed_blocks,
+            },
+            "stages_ms": {"S1_schedule_evictions": s1, "S2_schedule_moves": s2, "S3_execute_moves": s3},
+            "stage_rates": {
+                "S1_candidate_slots_per_s": N / (s1 * 1e-3),
+                "S2_moves_per_s": moved_slots / (s2 * 1e-3),
+                "S3_moved_slots_per_s": moved_slots / (s3 * 1e-3),
+            },
+            "roofline": {
+                "kernel": "compact_rows_kernel (execute_cache_moves)",
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_move": bpm,
+                "avg_launch_ms": s3,
+            },
+        }
+        if per_rank:
+            res["per_rank"] = per_rank
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,209 @@
+/*
+ * kvc_mi355x.h -- C ABI of libkvc_mi355x.so
+ *
+ * MI355X (gfx950) implementation of the KV-Compress eviction + compaction hot path.
+ * Every entry point takes plain device pointers, sizes and a HIP stream (passed as
+ * void*, i.e. hipStream_t); no torch types.  All calls are asynchronous on `stream`,
+ * never synchronise, never allocate: scratch memory is passed in by the caller (query
+ * the size with the matching *_workspace_bytes function).  All index tensors are
+ * int32 (reference: vllm/kvcompress/README.md:27, kernels reinterpret_cast<int*>,
+ * csrc/kvcompress_eviction_kernels.cu:527-542).
+ *
+ * Return value: 0 = ok, 1 = invalid argument / unsupported shape (the reference's
+ * TORCH_CHECK(false, "Unsupported block size: ...") -> RuntimeError), 2 = HIP error.
+ * kvc_last_error() returns the message for the calling thread.
+ *
+ * Each function cites the reference interface it replaces (paths relative to the
+ * reference repo IsaacRe/vllm-kvcompress @ 2024-12-20).
+ *
+ * Head order: "g" always enumerates heads in (seq, layer, kv_head) order,
+ * g = b*L*H + l*H + h, which is the order of evicted_kv_offsets / hanging_token_count /
+ * evicted_kv_count / cache_moves_count ([B,L,H]).  context_lens and block_tables are
+ * layer-major ([L,B,H] / [L,B,H,M]) exactly as in the reference.
+ */
+#ifndef KVC_MI355X_H
+#define KVC_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* kvc_stream_t; /* hipStream_t */
+
+int kvc_abi_version(void);
+const char* kvc_last_error(void);
+
+/* ---------------------------------------------------------------------------------
+ * A4  count_block_evictions
+ * replaces torch.ops._C_kvc_ops.count_block_evictions
+ *   (csrc/torch_bindings.cpp:388-394, csrc/kvcompress_eviction_kernels.cu:190-221,640-664,
+ *    Python wrapper vllm/_custom_ops.py:1065-1086)
+ * In place: evicted_block_count[g] = length of the leading run of chunks whose first
+ * entry != null_value; the [hanging..block_size) tail of the last such chunk is set to
+ * null_value.  The segment of the last head ends at total_kvs.
+ * Any block_size >= 1 is accepted (the reference: {1,2,4,16}).
+ * --------------------------------------------------------------------------------- */
+int kvc_count_block_evictions(int32_t* evicted_block_count,      /* [G] out */
+                              int32_t* evicted_logical_indices,  /* [total_kvs] in/out */
+                              const int32_t* evicted_kv_offsets, /* [G] */
+                              const int32_t* hanging_token_count,/* [G] */
+                              int32_t total_heads, int64_t total_kvs, int32_t block_size,
+                              int32_t null_value, kvc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * A5  schedule_t1_cache_moves  (+ the wrapper's zero fill of the whole workspace)
+ * replaces torch.ops._C_kvc_ops.schedule_t1_cache_moves and the
+ *   out_cache_moves_indices.fill_(0) in front of it
+ *   (csrc/torch_bindings.cpp:396-402, csrc/kvcompress_eviction_kernels.cu:223-289,698-726,
+ *    vllm/_custom_ops.py:1158-1179)
+ * cache_moves_idx rows [off_g, off_g+count_g) = (dst_physical_slot, src_physical_slot);
+ * if zero_fill != 0 every other row of the [cache_moves_rows,2] workspace is written 0
+ * (the observable result of the reference wrapper); with zero_fill == 0 rows that hold
+ * no move are left untouched (what the bare reference op does).
+ * --------------------------------------------------------------------------------- */
+int kvc_schedule_t1_cache_moves(int32_t* cache_moves_idx,            /* [rows,2] out */
+                                int64_t cache_moves_rows,
+                                int32_t* cache_moves_count,          /* [B,L,H] out */
+                                const int32_t* evicted_logical_indices, /* [>=N] */
+                                const int32_t* evicted_kv_count,     /* [B,L,H] */
+                                const int32_t* evicted_kv_offsets,   /* [B,L,H] */
+                                const int32_t* block_tables,         /* [L,B,H,M] */
+                                const int32_t* context_lens,         /* [L,B,H] */
+                                int32_t num_seqs, int32_t num_layers, int32_t num_kv_heads,
+                                int32_t max_num_blocks_per_seq, int32_t block_size,
+                                int32_t zero_fill, kvc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * A6  execute_cache_moves  (the K/V gather/scatter compaction)
+ * replaces torch.ops._C_kvc_ops.execute_cache_moves
+ *   (csrc/torch_bindings.cpp:410-418, csrc/kvcompress_eviction_kernels.cu:359-435,858-929,
+ *    vllm/_custom_ops.py:1220-1256, caller vllm/worker/cache_engine.py:139-151)
+ * k_cache [NB, head_size/x, block_size, x], v_cache [NB, head_size, block_size]; x =
+ * vec_size = k_cache.size(3) (16/elem_bytes in the engine: KVCAttention.split_kv_cache,
+ * vllm/attention/ops/paged_attn.py:272-284); pure byte copy, elem_bytes in {1,2,4}.
+ * Any block_size/head_size/vec_size combination works (reference: bs {1,2,4,16}, hd
+ * {1,2,4,128}, x {1,2,8}); hd 64/128/256 with x*elem_bytes == 16 take the row-wise path.  For every head g and
+ * every j < cache_moves_count[g]: (dst,src) = cache_moves_idx[evicted_kv_offsets[g]+j];
+ * K row, V row, kv_metrics and kv_position of slot src are copied to slot dst.  Source
+ * slots are left untouched.  Moves must be independent (no dst is a src, dsts distinct),
+ * the only case the reference defines (kvcompress_eviction_kernels.cu:358).
+ * blocks_per_head / threads_per_head of the reference signature are launch hints of the
+ * CUDA kernel and have no meaning here (the Python wrapper accepts and ignores them).
+ * workspace: kvc_execute_cache_moves_workspace_bytes(total_heads) bytes of device memory.
+ * --------------------------------------------------------------------------------- */
+size_t kvc_execute_cache_moves_workspace_bytes(int32_t total_heads);
+int kvc_execute_cache_moves(void* k_cache, void* v_cache, float* kv_metrics,
+                            int32_t* kv_position,
+                            const int32_t* cache_moves_idx,    /* [rows,2] */
+                            const int32_t* cache_moves_count,  /* [G] */
+                            const int32_t* evicted_kv_offsets, /* [G] */
+                            int32_t total_heads, int64_t num_blocks, int32_t block_size,
+                            int32_t head_size, int32_t elem_bytes, int32_t vec_size,
+                            void* workspace, size_t workspace_bytes, kvc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * A3  CompressionMetrics.schedule_evictions  (mask -> select -> count -> emit)
+ * replaces the torch-op pipeline of vllm/kvcompress/metrics.py:441-847 (six device
+ * sorts + a host loop) including its call of count_block_evictions (:774).
+ * Outputs are bit-identical to the reference on tie-free metrics; ties are ordered
+ * "stable by masked flat index" (physical block, offset) -- see DESIGN.md.
+ *
+ * mode 0 = "reference": reproduces the reference's batch>1 inf-count quirk
+ *          (metrics.py:718-721); mode 1 = "per_sequence": every sequence scheduled as
+ *          if alone (== reference called with B=1 per sequence).
+ * seq_slot_of_seq[s] = batch slot of sequence index s, or -1 (size seq_slot_len).
+ * bias may be NULL (== the reference's default zero bias, metrics.py:166-173).
+ * total_slots N = sum over heads of ceil(ctx/bs)*bs (== size of evicted_logical_indices).
+ * --------------------------------------------------------------------------------- */
+typedef struct kvc_schedule_params {
+  /* CompressionMetrics state (metrics.py:220-275) */
+  const float* metrics;                       /* [NB, bs] */
+  const int32_t* token_positions;             /* [NB, bs] */
+  const int32_t* seq_index_by_block;          /* [NB] (-1 = unallocated) */
+  const int32_t* layer_index_by_block;        /* [NB] */
+  const int32_t* head_index_by_block;         /* [NB] */
+  const int32_t* logical_block_num_by_block;  /* [NB] */
+  int64_t num_blocks;                         /* NB */
+  int32_t block_size, num_layers, num_kv_heads, num_seqs;
+  /* per batch */
+  const int32_t* seq_slot_of_seq;             /* [seq_slot_len] */
+  int32_t seq_slot_len;
+  const int32_t* seq_positions;               /* [B] */
+  const int32_t* num_protected;               /* [B] */
+  const int32_t* evicted_blocks_per_seq;      /* [B] */
+  const int32_t* context_lens;                /* [L,B,H] */
+  const int32_t* hanging_token_count;         /* [B,L,H] */
+  const int32_t* evicted_kv_offsets;          /* [B,L,H] */
+  int64_t total_slots;                        /* N */
+  /* options */
+  int32_t use_average;                        /* metrics.py:495-501 */
+  int32_t num_sinks;                          /* metrics.py:542 */
+  const float* bias;                          /* [L,H,num_bins] or NULL */
+  const int32_t* position_bins;               /* [num_bins] */
+  int32_t num_bins;
+  float bias_weight;
+  int32_t mode;                               /* 0 reference, 1 per_sequence */
+  int32_t null_value;                         /* MAX_INT = 2147483000 (metrics.py:12) */
+  /* outputs */
+  int32_t* evicted_logical_indices;           /* [N] */
+  int32_t* evicted_kv_count;                  /* [B,L,H] */
+  int32_t* evicted_block_count;               /* [B,L,H] */
+} kvc_schedule_params;
+
+size_t kvc_schedule_evictions_workspace_bytes(int64_t total_slots, int32_t total_heads,
+                                              int32_t num_seqs, int32_t block_size);
+int kvc_schedule_evictions(const kvc_schedule_params* p, void* workspace,
+                           size_t workspace_bytes, kvc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * A2a  aggregate_decode (+ clear_temp_metrics fused)
+ * replaces CompressionMetrics.aggregate_decode / clear_temp_metrics
+ *   (vllm/kvcompress/metrics.py:429-439, 337-342)
+ * metrics[s] += sum_q temp[s,q]^2 (use_l2) or sum_q temp[s,q]; float32, q summed in
+ * index order.  If clear_temp != 0 temp_metrics is zeroed in the same pass.
+ * --------------------------------------------------------------------------------- */
+int kvc_aggregate_decode(float* metrics, float* temp_metrics, int64_t num_slots,
+                         int32_t num_queries_per_kv, int32_t use_l2, int32_t clear_temp,
+                         kvc_stream_t stream);
+
+/* A2b  aggregate_prefill  (vllm/kvcompress/metrics.py:396-427)
+ * metrics.flat[slot_mapping[t,h]] += sum_q prefill_metrics[t, h*qpk + q]; slots unique. */
+int kvc_aggregate_prefill(float* metrics, const float* prefill_metrics,
+                          const int64_t* slot_mapping, int64_t num_tokens,
+                          int32_t num_kv_heads, int32_t num_queries_per_kv,
+                          kvc_stream_t stream);
+
+/* A2c  prefill metric epilogue: square -> causal-buffer mask -> column sum -> (avg
+ * scale) -> maxpool(7) -> accumulate, for one query block of softmax probabilities
+ *   (vllm/attention/backends/flash_attn.py:1147-1161, 1189-1211)
+ * out_kh [K, Hq] += f(probs [Hq, qb, K]);  q_offset = position of the tile's first query
+ * row inside the sequence. */
+int kvc_prefill_metric_epilogue(float* out_kh, const float* probs_hqk, int32_t num_q_heads,
+                                int32_t q_block, int32_t num_keys, int32_t q_offset,
+                                int32_t buffer_len, int32_t use_l2, int32_t use_average,
+                                int32_t use_maxpool, void* workspace, size_t workspace_bytes,
+                                kvc_stream_t stream);
+size_t kvc_prefill_metric_epilogue_workspace_bytes(int32_t num_q_heads, int32_t num_keys);
+
+/* ---------------------------------------------------------------------------------
+ * A7  kvcompress_reshape_and_cache  ("auto" cache dtype: byte-identical store)
+ * replaces torch.ops._C_cache_ops.kvcompress_reshape_and_cache
+ *   (csrc/torch_bindings.cpp:353-362, csrc/kvcompress_cache_kernels.cu:27-139,
+ *    vllm/_custom_ops.py:641-658)
+ * key/value [T, H, head_size] with token strides key_stride/value_stride (elements);
+ * slot_mapping [T*H] int64 (<0 = padding, skipped); kv_metrics[slot] = bias[h].
+ * --------------------------------------------------------------------------------- */
+int kvc_reshape_and_cache(const void* key, const void* value, void* key_cache,
+                          void* value_cache, float* kv_metrics, const int64_t* slot_mapping,
+                          const float* kv_metric_head_bias, int64_t num_tokens,
+                          int32_t num_heads, int32_t head_size, int32_t block_size,
+                          int32_t elem_bytes, int64_t key_stride, int64_t value_stride,
+                          kvc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KVC_MI355X_H */

@@ -1,0 +1,89 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every
+symbol include/kvc_mi355x.h declares; the Python surface mirrors the reference names;
+the ops refuse to run without a HIP device (no silent fallback)."""
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+import vllm_kvcompress_amd as kvc
+from vllm_kvcompress_amd import _custom_ops as ops
+from vllm_kvcompress_amd import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(REPO, "include", "kvc_mi355x.h")).read()
+    declared = set(re.findall(r"\b(kvc_[a-z0-9_]+)\s*\(", header))
+    declared -= {"kvc_schedule_params"}
+    assert declared, "no declarations found"
+    lib = kvc.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    assert lib.kvc_abi_version() == 1
+
+
+def test_python_surface_matches_reference_signatures():
+    """positional order of the reference wrappers (vllm/_custom_ops.py:1065,1158,1220,641)"""
+    want = {
+        "count_block_evictions": ["evicted_block_count", "evicted_logical_indices",
+                                  "evicted_kv_offsets", "hanging_token_count", "block_size",
+                                  "null_value", "evicted_blocks_per_seq"],
+        "schedule_cache_moves": ["out_cache_moves_indices", "out_cache_moves_count",
+                                 "evicted_logical_indices", "evicted_kv_count",
+                                 "evicted_kv_offsets", "block_tables", "context_lens",
+                                 "block_size"],
+        "execute_cache_moves": ["k_cache", "v_cache", "kv_metrics", "kv_position",
+                                "cache_moves_indices", "cache_moves_count", "evicted_kv_offsets",
+                                "blocks_per_head", "threads_per_head"],
+        "reshape_and_cache_kvc": ["key", "value", "key_cache", "value_cache", "kv_metrics",
+                                  "slot_mapping", "kv_metric_head_bias", "kv_cache_dtype",
+                                  "k_scale", "v_scale"],
+    }
+    for fn, params in want.items():
+        assert list(inspect.signature(getattr(ops, fn)).parameters) == params
+    from vllm_kvcompress_amd.kvcompress.metrics import CompressionMetrics
+    init = list(inspect.signature(CompressionMetrics.__init__).parameters)[1:]
+    assert init == ["block_size", "num_layers", "num_kv_heads", "num_queries_per_kv",
+                    "max_kv_per_sort", "kv_head_bias_file", "kv_head_bias_weight", "device",
+                    "random", "even_layer_evict", "use_l2", "use_average",
+                    "record_decoding_metrics", "num_attention_sinks"]
+    sched = list(inspect.signature(CompressionMetrics.schedule_evictions).parameters)[1:8]
+    assert sched == ["seq_indices", "seq_positions", "evicted_blocks_per_seq", "context_lens",
+                     "hanging_token_count", "evicted_kv_offsets", "num_protected"]
+    for m in ("init_kv_metadata", "clear_temp_metrics", "insert_metadata", "remove_metadata",
+              "aggregate_prefill", "aggregate_decode", "profile_schedule_evictions"):
+        assert callable(getattr(CompressionMetrics, m))
+
+
+def test_dispatcher_names_registered():
+    from vllm_kvcompress_amd import torch_ops
+    torch_ops.register()
+    torch_ops.register()          # idempotent
+    for name in ("count_block_evictions", "schedule_t1_cache_moves", "execute_cache_moves"):
+        assert hasattr(torch.ops._C_kvc_ops, name)
+    assert hasattr(torch.ops._C_cache_ops, "kvcompress_reshape_and_cache")
+
+
+def test_no_cpu_fallback():
+    t = torch.zeros(4, dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        ops.count_block_evictions(t, t, t, t, 4, 99)
+    from vllm_kvcompress_amd.kvcompress.metrics import CompressionMetrics
+    with pytest.raises(RuntimeError, match="HIP device"):
+        CompressionMetrics(16, 2, 2, 1, 1000, None, 0.0, device="cpu")
+
+
+def test_product_never_imports_oracle():
+    """the oracle is test infrastructure; the package must not reference it"""
+    pkg = os.path.join(REPO, "vllm_kvcompress_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".sh")):
+                src = open(os.path.join(root, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+                assert "kvc_oracle" not in src.replace("oracle/kvc_oracle.py", ""), f

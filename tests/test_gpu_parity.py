@@ -1,0 +1,363 @@
+"""GPU parity tests: the HIP path (called through the reference-shaped Python surface and
+the C ABI underneath) against the oracle and the committed golden vectors.
+
+Bars: bit-exact for every index / count / move table; bitwise equal K/V, metrics and
+positions after compaction (pure copies); float32 aggregation bit-equal to the oracle's
+sequential float32 restatement (tolerance vs torch reference: 1e-6 relative).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kvc_oracle as orc
+from tests.conftest import golden_cases
+from tests.helpers import golden_caches, load_golden, oracle_pipeline, sha
+from vllm_kvcompress_amd import _custom_ops as ops
+from vllm_kvcompress_amd.harness import device as hdev
+from vllm_kvcompress_amd.harness import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _state_from_golden(g):
+    return synth.PagedState(
+        block_size=int(g["block_size"]), num_layers=int(g["num_layers"]),
+        num_kv_heads=int(g["num_kv_heads"]), num_seqs=len(g["seq_indices"]),
+        num_blocks=int(g["num_blocks"]), metrics=g["metrics"],
+        token_positions=g["token_positions"], seq_index_by_block=g["seq_index_by_block"],
+        layer_index_by_block=g["layer_index_by_block"],
+        head_index_by_block=g["head_index_by_block"],
+        logical_block_num_by_block=g["logical_block_num_by_block"],
+        context_lens=g["context_lens"], block_tables=g["block_tables"],
+        hanging_token_count=g["hanging_token_count"],
+        evicted_kv_offsets=g["evicted_kv_offsets"],
+        seq_indices=[int(s) for s in g["seq_indices"]], seq_positions=g["seq_positions"],
+        protected=[int(p) for p in g["protected"]])
+
+
+def _gpu_pipeline(st, evicted, k_np=None, v_np=None, mode="reference", **kw):
+    ds = hdev.upload(st, DEV, mode=mode, **kw)
+    eli, ekc, ebc, cmi, cmc = hdev.schedule(ds, st, evicted)
+    out = dict(eli=eli.cpu().numpy(), ekc=ekc.cpu().numpy(), ebc=ebc.cpu().numpy(),
+               cmi=cmi.cpu().numpy(), cmc=cmc.cpu().numpy())
+    if k_np is not None:
+        k = torch.from_numpy(k_np.copy()).to(DEV)
+        v = torch.from_numpy(v_np.copy()).to(DEV)
+        ops.execute_cache_moves(k, v, ds.cm.metrics, ds.cm.token_positions, cmi, cmc,
+                                ds.evicted_kv_offsets, 1, 16)
+        out.update(k=k.cpu().numpy(), v=v.cpu().numpy(), metrics=ds.cm.metrics.cpu().numpy(),
+                   positions=ds.cm.token_positions.cpu().numpy())
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", golden_cases())
+def test_golden_end_to_end(name):
+    """A3 -> A5 -> A6 on the reference-generated fixtures (bit-exact)."""
+    g = load_golden(name)
+    st = _state_from_golden(g)
+    kw = dict(use_average=bool(int(g["use_average"])), num_sinks=int(g["num_sinks"]))
+    if "bias" in g:
+        kw.update(bias=g["bias"], position_bins=g["position_bins"],
+                  bias_weight=float(g["bias_weight"]))
+    k, v = golden_caches(g)
+    out = _gpu_pipeline(st, g["evicted_blocks_per_seq"], k, v, **kw)
+    np.testing.assert_array_equal(out["eli"], g["ref_evicted_logical_indices"])
+    np.testing.assert_array_equal(out["ekc"], g["ref_evicted_kv_count"])
+    np.testing.assert_array_equal(out["ebc"], g["ref_evicted_block_count"])
+    np.testing.assert_array_equal(out["cmi"], g["ref_cache_moves_idx"])
+    np.testing.assert_array_equal(out["cmc"], g["ref_cache_moves_count"])
+    np.testing.assert_array_equal(sha(out["k"]), g["ref_k_sha256"])
+    np.testing.assert_array_equal(sha(out["v"]), g["ref_v_sha256"])
+    np.testing.assert_array_equal(out["metrics"], g["ref_metrics"])
+    np.testing.assert_array_equal(out["positions"], g["ref_positions"])
+
+
+def _limit(st, frac):
+    bs = st.block_size
+    nblk = ((st.context_lens.astype(np.int64) + bs - 1) // bs).sum(0).sum(-1)
+    TH = st.num_layers * st.num_kv_heads
+    return [int(max(int(nblk[b]) - (st.protected[b] + bs - 1) // bs * TH, 0) * frac)
+            for b in range(st.num_seqs)]
+
+
+RANDOM_CASES = [
+    # (L, H, bs, seq_lens, protected, compressed, hd, frac, tie_levels)
+    (2, 2, 4, [37], 1, False, 8, 0.5, None),
+    (3, 2, 4, [37, 12, 55], [1, 3, 8], False, 8, 0.6, None),
+    (2, 4, 16, [300, 171], 32, False, 128, 0.5, None),
+    (2, 4, 16, [300, 171, 90], [32, 5, 17], True, 128, 0.7, None),
+    (4, 8, 16, [700], 32, False, 128, 0.875, None),
+    (2, 2, 32, [260, 100], 33, False, 128, 0.5, None),
+    (2, 2, 1, [40, 9], 2, False, 8, 0.5, None),
+    (2, 3, 2, [41, 23], 3, True, 8, 0.4, None),
+    (2, 2, 16, [2100], 16, False, 64, 0.5, None),       # heads longer than one histogram tile
+    (1, 1, 16, [5000], 1, False, 128, 0.9, None),
+    # ties: canonical order (metric, physical block, offset) / (threshold, head, chunk)
+    (2, 2, 4, [37, 50], 2, False, 8, 0.5, 3),
+    (2, 4, 16, [300, 171], 20, True, 128, 0.6, 5),
+    (2, 2, 16, [400], 7, False, 128, 0.5, 1),
+]
+
+
+@pytest.mark.parametrize("mode", ["reference", "per_sequence"])
+@pytest.mark.parametrize("case", range(len(RANDOM_CASES)))
+def test_random_states_vs_oracle(case, mode):
+    L, H, bs, seq_lens, prot, compressed, hd, frac, ties = RANDOM_CASES[case]
+    for seed in (0, 1):
+        st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs, seq_lens=seq_lens,
+                              seed=seed, protected=prot, compressed=compressed, tie_levels=ties)
+        evicted = _limit(st, frac)
+        k, v = synth.make_caches_u16(seed, st.num_blocks, hd, bs)
+        want = oracle_pipeline(st, evicted, k, v, mode=mode)
+        got = _gpu_pipeline(st, evicted, k, v, mode=mode)
+        for key in ("eli", "ekc", "ebc", "cmi", "cmc", "k", "v", "metrics", "positions"):
+            np.testing.assert_array_equal(got[key], want[key], err_msg=f"{key} seed={seed}")
+
+
+def test_overask_and_zero_evictions():
+    st = synth.make_state(num_layers=2, num_kv_heads=2, block_size=4, seq_lens=[33, 21, 40],
+                          seed=3, protected=[5, 2, 7])
+    nblk = ((st.context_lens.astype(np.int64) + 3) // 4).sum(0).sum(-1)
+    for evicted in ([int(n) for n in nblk], [0, 0, 0], [int(nblk[0]), 0, 3]):
+        for mode in ("reference", "per_sequence"):
+            want = oracle_pipeline(st, evicted, mode=mode)
+            got = _gpu_pipeline(st, evicted, mode=mode)
+            for key in ("eli", "ekc", "ebc", "cmi", "cmc"):
+                np.testing.assert_array_equal(got[key], want[key], err_msg=f"{key} {evicted} {mode}")
+
+
+def test_options_average_sinks_bias():
+    st = synth.make_state(num_layers=2, num_kv_heads=3, block_size=4, seq_lens=[45, 30], seed=5,
+                          protected=3)
+    evicted = _limit(st, 0.5)
+    bins = np.array([0, 6, 19], dtype=np.int32)
+    bias = (np.random.default_rng(4).normal(size=(2, 3, 3)) * 30).astype(np.float32)
+    for kw in (dict(use_average=True), dict(num_sinks=4),
+               dict(bias=bias, position_bins=bins, bias_weight=0.25),
+               dict(use_average=True, num_sinks=2, bias=bias, position_bins=bins, bias_weight=1.5)):
+        want = oracle_pipeline(st, evicted, **kw)
+        got = _gpu_pipeline(st, evicted, **kw)
+        for key in ("eli", "ekc", "ebc", "cmi", "cmc"):
+            np.testing.assert_array_equal(got[key], want[key], err_msg=f"{key} {list(kw)}")
+
+
+def test_protected_zero_quirk_moves():
+    """with protected=0 the first empty tail slot is evictable and the move walk
+    then drops a real KV.  The move schedule must still equal the serial kernel's."""
+    st = synth.make_state(num_layers=2, num_kv_heads=2, block_size=4, seq_lens=[31], seed=8,
+                          protected=0)
+    evicted = [6]
+    want = oracle_pipeline(st, evicted)
+    got = _gpu_pipeline(st, evicted)
+    for key in ("eli", "ekc", "ebc", "cmi", "cmc"):
+        np.testing.assert_array_equal(got[key], want[key], err_msg=key)
+
+
+# ---------------------------------------------------------------------------------------
+def test_count_block_evictions_op():
+    rng = np.random.default_rng(0)
+    for bs in (1, 2, 4, 16, 32):
+        G = 37
+        nchunks = rng.integers(0, 200, size=G)
+        nchunks[3] = 0
+        offs = np.concatenate([[0], np.cumsum(nchunks * bs)[:-1]]).astype(np.int32).reshape(1, 1, G)
+        total = int((nchunks * bs).sum())
+        idx = rng.integers(0, 50, size=total).astype(np.int32)
+        # leading runs of random length, then nulls sprinkled
+        for g in range(G):
+            s = int(offs.reshape(-1)[g])
+            run = rng.integers(0, nchunks[g] + 1)
+            idx[s + run * bs: s + nchunks[g] * bs][rng.random((nchunks[g] - run) * bs) < 0.5] = 99
+            if run < nchunks[g]:
+                idx[s + run * bs] = 99
+        hang = rng.integers(1, bs + 1, size=(1, 1, G)).astype(np.int32)
+        want_idx, want = idx.copy(), np.zeros((1, 1, G), np.int32)
+        orc.count_block_evictions(want, want_idx, offs, hang, bs, 99)
+        d_idx = torch.from_numpy(idx).to(DEV)
+        d_out = torch.zeros((1, 1, G), dtype=torch.int32, device=DEV)
+        ops.count_block_evictions(d_out, d_idx, torch.from_numpy(offs).to(DEV),
+                                  torch.from_numpy(hang).to(DEV), bs, 99)
+        np.testing.assert_array_equal(d_out.cpu().numpy(), want)
+        np.testing.assert_array_equal(d_idx.cpu().numpy(), want_idx)
+
+
+def _random_moves(rng, nb, bs, G, max_moves, sort_dst):
+    """independent moves: disjoint dst/src slot sets; per head a random count"""
+    slots = rng.permutation(nb * bs)
+    counts = rng.integers(0, max_moves + 1, size=G)
+    seg = rng.integers(0, 5, size=G) + counts          # segment >= count
+    offs = np.concatenate([[0], np.cumsum(seg)[:-1]]).astype(np.int32)
+    rows = int(seg.sum()) + 3
+    moves = np.zeros((rows, 2), dtype=np.int32)
+    cur = 0
+    for g in range(G):
+        c = int(counts[g])
+        dst = slots[cur:cur + c]
+        src = slots[cur + c:cur + 2 * c]
+        cur += 2 * c
+        if sort_dst:
+            dst = np.sort(dst)
+        moves[offs[g]:offs[g] + c, 0] = dst
+        moves[offs[g]:offs[g] + c, 1] = src
+    return moves, counts.astype(np.int32).reshape(1, 1, G), offs.reshape(1, 1, G)
+
+
+@pytest.mark.parametrize("dtype,hd,bs", [
+    (torch.float16, 128, 16), (torch.bfloat16, 128, 16), (torch.uint8, 128, 32),
+    (torch.uint8, 128, 16), (torch.float16, 128, 32), (torch.float32, 128, 16),
+    (torch.float16, 64, 16), (torch.float16, 256, 16),
+    (torch.float16, 8, 4), (torch.float16, 16, 2), (torch.float32, 4, 1), (torch.uint8, 16, 4),
+    (torch.float16, 80, 16), (torch.float16, 128, 8),
+])
+@pytest.mark.parametrize("sort_dst", [True, False])
+def test_execute_cache_moves_general(dtype, hd, bs, sort_dst):
+    """arbitrary independent move lists, all dtypes/shapes: fast row path (sorted dst),
+    element-wise fallback (unsorted dst) and the generic kernel (odd shapes)."""
+    rng = np.random.default_rng(hd * 1000 + bs)
+    nb, G = 96, 9
+    e = torch.empty((), dtype=dtype).element_size()
+    x = 16 // e
+    npdt = {1: np.uint8, 2: np.uint16, 4: np.uint32}[e]
+    k_np = rng.integers(0, 256, size=(nb, hd // x, bs, x * e), dtype=np.uint8).view(npdt)
+    v_np = rng.integers(0, 256, size=(nb, hd, bs * e), dtype=np.uint8).view(npdt)
+    m_np = rng.random((nb, bs)).astype(np.float32)
+    p_np = rng.integers(0, 10 ** 6, size=(nb, bs)).astype(np.int32)
+    moves, counts, offs = _random_moves(rng, nb, bs, G, min(40, nb * bs // (2 * G)), sort_dst)
+    wk, wv, wm, wp = k_np.copy(), v_np.copy(), m_np.copy(), p_np.copy()
+    orc.execute_cache_moves(wk, wv, wm, wp, moves, counts, offs)
+    k = torch.from_numpy(k_np.view(np.uint8)).to(DEV).view(dtype).view(nb, hd // x, bs, x)
+    v = torch.from_numpy(v_np.view(np.uint8)).to(DEV).view(dtype).view(nb, hd, bs)
+    m = torch.from_numpy(m_np).to(DEV)
+    p = torch.from_numpy(p_np).to(DEV)
+    ops.execute_cache_moves(k, v, m, p, torch.from_numpy(moves).to(DEV),
+                            torch.from_numpy(counts).to(DEV), torch.from_numpy(offs).to(DEV), 1, 16)
+    np.testing.assert_array_equal(k.view(torch.uint8).cpu().numpy().reshape(-1), wk.view(np.uint8).reshape(-1))
+    np.testing.assert_array_equal(v.view(torch.uint8).cpu().numpy().reshape(-1), wv.view(np.uint8).reshape(-1))
+    np.testing.assert_array_equal(m.cpu().numpy(), wm)
+    np.testing.assert_array_equal(p.cpu().numpy(), wp)
+
+
+def test_unsupported_shapes_raise():
+    k = torch.zeros((4, 2, 4, 8), dtype=torch.float64, device=DEV)
+    v = torch.zeros((4, 16, 4), dtype=torch.float64, device=DEV)
+    m = torch.zeros((4, 4), dtype=torch.float32, device=DEV)
+    p = torch.zeros((4, 4), dtype=torch.int32, device=DEV)
+    z = torch.zeros((1, 1, 1), dtype=torch.int32, device=DEV)
+    with pytest.raises(RuntimeError, match="Unsupported"):
+        ops.execute_cache_moves(k, v, m, p, torch.zeros((4, 2), dtype=torch.int32, device=DEV), z, z, 1, 1)
+    with pytest.raises(RuntimeError, match="Unsupported block size"):
+        ops.count_block_evictions(z, z.view(-1), z, z, 0, 99)
+
+
+def test_dispatcher_path():
+    """the fork's own call form: torch.ops._C_kvc_ops.* (vllm/_custom_ops.py:1074,1169,1247)"""
+    from vllm_kvcompress_amd import torch_ops
+    torch_ops.register()
+    st = synth.make_state(num_layers=2, num_kv_heads=2, block_size=16, seq_lens=[200, 90], seed=2,
+                          protected=16)
+    evicted = _limit(st, 0.5)
+    k, v = synth.make_caches_u16(2, st.num_blocks, 128, 16)
+    want = oracle_pipeline(st, evicted, k, v)
+    ds = hdev.upload(st, DEV)
+    eli, ekc, ebc = ds.cm.schedule_evictions(list(st.seq_indices), ds.seq_positions, evicted,
+                                             ds.context_lens, ds.hanging_token_count,
+                                             ds.evicted_kv_offsets, list(st.protected))
+    cmi = torch.zeros((st.total_slots, 2), dtype=torch.int32, device=DEV)
+    cmc = torch.empty_like(ekc)
+    torch.ops._C_kvc_ops.schedule_t1_cache_moves(cmi, cmc, eli, ekc, ds.evicted_kv_offsets,
+                                                 ds.block_tables, ds.context_lens, 16)
+    kd, vd = torch.from_numpy(k.copy()).to(DEV), torch.from_numpy(v.copy()).to(DEV)
+    torch.ops._C_kvc_ops.execute_cache_moves(kd, vd, ds.cm.metrics, ds.cm.token_positions, cmi, cmc,
+                                             ds.evicted_kv_offsets, 1, 16)
+    np.testing.assert_array_equal(cmi.cpu().numpy(), want["cmi"])
+    np.testing.assert_array_equal(kd.cpu().numpy(), want["k"])
+    np.testing.assert_array_equal(vd.cpu().numpy(), want["v"])
+
+
+# ---------------------------------------------------------------------------------------
+def test_aggregate_decode_and_clear():
+    from vllm_kvcompress_amd.kvcompress.metrics import CompressionMetrics
+    rng = np.random.default_rng(1)
+    for qpk, l2 in ((4, True), (4, False), (1, True), (8, True), (3, False)):
+        cm = CompressionMetrics(16, 2, 2, qpk, 1000, None, 0.0, device=DEV, use_l2=l2)
+        cm.init_kv_metadata(50)
+        m0 = rng.random((50, 16)).astype(np.float32)
+        t0 = rng.random((50, 16, qpk)).astype(np.float32)
+        cm.metrics.copy_(torch.from_numpy(m0))
+        cm.temp_metrics.copy_(torch.from_numpy(t0))
+        want = m0.copy()
+        orc.aggregate_decode(want, t0, use_l2=l2)
+        cm.aggregate_decode()
+        np.testing.assert_array_equal(cm.metrics.cpu().numpy(), want)
+        # float32 tolerance against the torch formulation of the reference (metrics.py:436-439)
+        tt = torch.from_numpy(t0)
+        ref = torch.from_numpy(m0) + ((tt ** 2) if l2 else tt).sum(dim=-1)
+        np.testing.assert_allclose(cm.metrics.cpu().numpy(), ref.numpy(), rtol=1e-6, atol=0)
+        assert float(cm._temp_metrics.abs().max()) == 0.0      # fused clear
+        cm.clear_temp_metrics()                                # free; contract: zeros
+        assert float(cm.temp_metrics.abs().max()) == 0.0
+        cm.temp_metrics.fill_(1.0)                             # attention wrote into it
+        cm.clear_temp_metrics()
+        assert float(cm._temp_metrics.abs().max()) == 0.0
+
+
+def test_aggregate_prefill():
+    from vllm_kvcompress_amd.kvcompress.metrics import CompressionMetrics
+    rng = np.random.default_rng(2)
+    H, qpk, T, NB, bs = 4, 4, 70, 40, 16
+    cm = CompressionMetrics(bs, 2, H, qpk, 1000, None, 0.0, device=DEV)
+    cm.init_kv_metadata(NB)
+    m0 = rng.random((NB, bs)).astype(np.float32)
+    pm = rng.random((T, H * qpk)).astype(np.float32)
+    slots = rng.permutation(NB * bs)[:T * H].astype(np.int64).reshape(T, H)
+    cm.metrics.copy_(torch.from_numpy(m0))
+    want = m0.copy()
+    orc.aggregate_prefill(want, pm, slots, H)
+    cm.aggregate_prefill(torch.from_numpy(pm).to(DEV), torch.from_numpy(slots).to(DEV))
+    np.testing.assert_array_equal(cm.metrics.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("l2", [True, False])
+@pytest.mark.parametrize("avg", [True, False])
+@pytest.mark.parametrize("pool", [True, False])
+def test_prefill_metric_epilogue(l2, avg, pool):
+    from vllm_kvcompress_amd.kvcompress.prefill import accumulate_prefill_tile
+    rng = np.random.default_rng(3)
+    Hq, qb, K = 4, 24, 96
+    for q_offset, buf in ((72, 0), (72, 3), (10, 3), (0, 0)):
+        probs = rng.random((Hq, qb, K)).astype(np.float32)
+        out0 = rng.random((K, Hq)).astype(np.float32)
+        want = out0.copy()
+        orc.prefill_metric_epilogue(want, probs, q_offset, buf, l2, avg, pool)
+        out = torch.from_numpy(out0).to(DEV)
+        accumulate_prefill_tile(out, torch.from_numpy(probs).to(DEV), q_offset, buf, l2, avg, pool)
+        np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+def test_reshape_and_cache_kvc(dtype):
+    rng = np.random.default_rng(4)
+    T, H, hd, bs, NB = 37, 4, 128, 16, 30
+    e = torch.empty((), dtype=dtype).element_size()
+    x = 16 // e
+    npdt = {2: np.uint16, 4: np.uint32}[e]
+    key = rng.integers(0, 2 ** 16, size=(T, H, hd)).astype(npdt)
+    val = rng.integers(0, 2 ** 16, size=(T, H, hd)).astype(npdt)
+    kc = rng.integers(0, 2 ** 16, size=(NB, hd // x, bs, x)).astype(npdt)
+    vc = rng.integers(0, 2 ** 16, size=(NB, hd, bs)).astype(npdt)
+    met = rng.random((NB, bs)).astype(np.float32)
+    slots = rng.permutation(NB * bs)[:T * H].astype(np.int64)
+    slots[5] = -1
+    bias = rng.random(H).astype(np.float32)
+    wk, wv, wm = kc.copy(), vc.copy(), met.copy()
+    orc.reshape_and_cache_kvc(key, val, wk, wv, wm, slots, bias)
+    to = lambda a: torch.from_numpy(a.view(np.uint8)).to(DEV).view(dtype).view(a.shape)
+    dk, dv = to(kc), to(vc)
+    dm = torch.from_numpy(met).to(DEV)
+    ops.reshape_and_cache_kvc(to(key), to(val), dk, dv, dm, torch.from_numpy(slots).to(DEV),
+                              torch.from_numpy(bias).to(DEV), "auto", 1.0, 1.0)
+    np.testing.assert_array_equal(dk.view(torch.uint8).cpu().numpy().reshape(-1), wk.view(np.uint8).reshape(-1))
+    np.testing.assert_array_equal(dv.view(torch.uint8).cpu().numpy().reshape(-1), wv.view(np.uint8).reshape(-1))
+    np.testing.assert_array_equal(dm.cpu().numpy(), wm)

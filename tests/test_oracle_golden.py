@@ -77,3 +77,48 @@ def test_count_block_evictions_hand_cases():
     assert idx.tolist() == [1, 2, 3, 4, 5, 6, 7, NUL, NUL, NUL, NUL, NUL,
                             NUL, 1, 1, 1,
                             3, NUL, NUL, NUL, NUL, 2, 2, 2, 9, 9, 9, 9]
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_c_oracle_matches_reference(name):
+    """oracle/kvc_oracle.c (used at large sizes and as the CPU baseline) against the same
+    golden vectors."""
+    from oracle import kvc_oracle_c as orc_c
+    g = load_golden(name)
+    bs = int(g["block_size"])
+    eli, ekc = g["ref_evicted_logical_indices"].copy(), g["ref_evicted_kv_count"].copy()
+    cmi = np.full_like(g["ref_cache_moves_idx"], 77)
+    cmc = np.zeros_like(g["ref_cache_moves_count"])
+    orc_c.schedule_cache_moves(cmi, cmc, eli, ekc, g["evicted_kv_offsets"],
+                               np.ascontiguousarray(g["block_tables"]),
+                               np.ascontiguousarray(g["context_lens"]), bs)
+    np.testing.assert_array_equal(cmi, g["ref_cache_moves_idx"])
+    np.testing.assert_array_equal(cmc, g["ref_cache_moves_count"])
+    k, v = golden_caches(g)
+    k, v = np.ascontiguousarray(k), np.ascontiguousarray(v)
+    m, p = g["metrics"].copy(), g["token_positions"].copy()
+    orc_c.execute_cache_moves(k, v, m, p, cmi, cmc, g["evicted_kv_offsets"])
+    np.testing.assert_array_equal(sha(k), g["ref_k_sha256"])
+    np.testing.assert_array_equal(sha(v), g["ref_v_sha256"])
+    np.testing.assert_array_equal(m, g["ref_metrics"])
+    np.testing.assert_array_equal(p, g["ref_positions"])
+
+
+def test_c_count_block_evictions_equals_numpy():
+    from oracle import kvc_oracle_c as orc_c
+    rng = np.random.default_rng(0)
+    for bs in (1, 2, 4, 16):
+        G = 7
+        nchunks = rng.integers(0, 6, size=G)
+        offs = np.concatenate([[0], np.cumsum(nchunks * bs)[:-1]]).astype(np.int32).reshape(1, 1, G)
+        total = int((nchunks * bs).sum())
+        idx = rng.integers(0, 50, size=total).astype(np.int32)
+        idx[rng.random(total) < 0.3] = 99
+        hang = rng.integers(1, bs + 1, size=(1, 1, G)).astype(np.int32)
+        a_idx, b_idx = idx.copy(), idx.copy()
+        a = np.zeros((1, 1, G), np.int32)
+        b = np.zeros((1, 1, G), np.int32)
+        orc.count_block_evictions(a, a_idx, offs, hang, bs, 99)
+        orc_c.count_block_evictions(b, b_idx, offs, hang, bs, 99)
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(a_idx, b_idx)

@@ -1,0 +1,205 @@
+"""KV-Compress section of the reference's ``vllm/_custom_ops.py``, on MI355X.
+
+Same function names, positional order, in-place/out-parameter conventions and error
+behaviour as the reference wrappers (``vllm/_custom_ops.py:641-658, 1065-1086,
+1158-1179, 1220-1256``); each one calls the HIP kernels of ``libkvc_mi355x.so`` through
+its C ABI on the current HIP stream.  Index tensors are int32 and are reinterpreted
+without a dtype check exactly like the reference kernels do
+(``csrc/kvcompress_eviction_kernels.cu:527-542``) -- except that here a wrong dtype
+raises instead of silently reading garbage.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import MAX_INT  # noqa: F401  (re-exported like the reference constant)
+
+_WORKSPACES = {}
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _require(t: torch.Tensor, name: str, dtype=None) -> None:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a tensor on a HIP device (no CPU fallback exists)")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+
+
+def workspace(device: torch.device, nbytes: int, tag: str) -> torch.Tensor:
+    """Persistent per-(device, tag) scratch buffer, grown geometrically; the C ABI never
+    allocates (include/kvc_mi355x.h)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    buf = _WORKSPACES.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes * 1.25), 4096), dtype=torch.uint8, device=device)
+        _WORKSPACES[key] = buf
+    return buf
+
+
+# ---------------------------------------------------------------------------------------
+def count_block_evictions(
+    evicted_block_count: torch.Tensor,
+    evicted_logical_indices: torch.Tensor,
+    evicted_kv_offsets: torch.Tensor,
+    hanging_token_count: torch.Tensor,
+    block_size: int,
+    null_value: int,
+    evicted_blocks_per_seq: Optional[torch.Tensor] = None,
+) -> None:
+    """reference vllm/_custom_ops.py:1065-1086"""
+    lib = _lib.load()
+    for n, t in (("evicted_block_count", evicted_block_count),
+                 ("evicted_logical_indices", evicted_logical_indices),
+                 ("evicted_kv_offsets", evicted_kv_offsets),
+                 ("hanging_token_count", hanging_token_count)):
+        _require(t, n, torch.int32)
+    eli = evicted_logical_indices.contiguous()
+    offs = evicted_kv_offsets.contiguous()
+    hang = hanging_token_count.contiguous()
+    with torch.cuda.device(eli.device):
+        _lib.check(lib.kvc_count_block_evictions(
+            evicted_block_count.data_ptr(), eli.data_ptr(), offs.data_ptr(), hang.data_ptr(),
+            evicted_block_count.numel(), eli.numel(), int(block_size), int(null_value),
+            _stream(eli)))
+
+
+def schedule_cache_moves(
+    out_cache_moves_indices: torch.Tensor,
+    out_cache_moves_count: torch.Tensor,
+    evicted_logical_indices: torch.Tensor,
+    evicted_kv_count: torch.Tensor,
+    evicted_kv_offsets: torch.Tensor,
+    block_tables: torch.Tensor,
+    context_lens: torch.Tensor,
+    block_size: int,
+) -> None:
+    """reference vllm/_custom_ops.py:1158-1179 (zero fill of the workspace fused in)"""
+    _schedule_t1_cache_moves(out_cache_moves_indices, out_cache_moves_count,
+                             evicted_logical_indices, evicted_kv_count, evicted_kv_offsets,
+                             block_tables, context_lens, block_size, zero_fill=True)
+
+
+def _schedule_t1_cache_moves(cache_moves_idx, cache_moves_count, evicted_logical_indices,
+                             evicted_kv_count, evicted_kv_offsets, block_tables, context_lens,
+                             block_size, zero_fill):
+    lib = _lib.load()
+    for n, t in (("cache_moves_idx", cache_moves_idx), ("cache_moves_count", cache_moves_count),
+                 ("evicted_logical_indices", evicted_logical_indices),
+                 ("evicted_kv_count", evicted_kv_count),
+                 ("evicted_kv_offsets", evicted_kv_offsets), ("block_tables", block_tables),
+                 ("context_lens", context_lens)):
+        _require(t, n, torch.int32)
+    if not cache_moves_idx.is_contiguous() or not cache_moves_count.is_contiguous():
+        raise RuntimeError("schedule_cache_moves: output tensors must be contiguous")
+    num_seqs, num_layers, num_kv_heads = evicted_kv_count.shape
+    with torch.cuda.device(cache_moves_idx.device):
+        _lib.check(lib.kvc_schedule_t1_cache_moves(
+            cache_moves_idx.data_ptr(), cache_moves_idx.shape[0], cache_moves_count.data_ptr(),
+            evicted_logical_indices.contiguous().data_ptr(),
+            evicted_kv_count.contiguous().data_ptr(),
+            evicted_kv_offsets.contiguous().data_ptr(),
+            block_tables.contiguous().data_ptr(), context_lens.contiguous().data_ptr(),
+            num_seqs, num_layers, num_kv_heads, block_tables.shape[3], int(block_size),
+            1 if zero_fill else 0, _stream(cache_moves_idx)))
+
+
+def execute_cache_moves(
+    k_cache: torch.Tensor,
+    v_cache: torch.Tensor,
+    kv_metrics: torch.Tensor,
+    kv_position: torch.Tensor,
+    cache_moves_indices: torch.Tensor,
+    cache_moves_count: torch.Tensor,
+    evicted_kv_offsets: torch.Tensor,
+    blocks_per_head: int,
+    threads_per_head: int,
+) -> None:
+    """reference vllm/_custom_ops.py:1220-1256.  ``blocks_per_head`` / ``threads_per_head``
+    are launch hints of the reference CUDA kernel; kept in the signature, unused."""
+    lib = _lib.load()
+    _require(k_cache, "k_cache")
+    _require(v_cache, "v_cache")
+    _require(kv_metrics, "kv_metrics", torch.float32)
+    for n, t in (("kv_position", kv_position), ("cache_moves_indices", cache_moves_indices),
+                 ("cache_moves_count", cache_moves_count),
+                 ("evicted_kv_offsets", evicted_kv_offsets)):
+        _require(t, n, torch.int32)
+    if k_cache.dim() != 4 or v_cache.dim() != 3:
+        raise RuntimeError("execute_cache_moves: k_cache must be [NB, hd/x, bs, x] and "
+                           "v_cache [NB, hd, bs]")
+    for n, t in (("k_cache", k_cache), ("v_cache", v_cache), ("kv_metrics", kv_metrics),
+                 ("kv_position", kv_position)):
+        if not t.is_contiguous():
+            raise RuntimeError(f"execute_cache_moves: {n} must be contiguous (mutated in place)")
+    num_blocks, head_size, block_size = v_cache.shape
+    vec = k_cache.shape[3]
+    cmi = cache_moves_indices.contiguous()
+    cmc = cache_moves_count.contiguous()
+    offs = evicted_kv_offsets.contiguous()
+    total_heads = cmc.numel()
+    ws_bytes = lib.kvc_execute_cache_moves_workspace_bytes(total_heads)
+    ws = workspace(k_cache.device, ws_bytes, "execute_cache_moves")
+    with torch.cuda.device(k_cache.device):
+        _lib.check(lib.kvc_execute_cache_moves(
+            k_cache.data_ptr(), v_cache.data_ptr(), kv_metrics.data_ptr(),
+            kv_position.data_ptr(), cmi.data_ptr(), cmc.data_ptr(), offs.data_ptr(),
+            total_heads, num_blocks, block_size, head_size, k_cache.element_size(), vec,
+            ws.data_ptr(), ws.numel(), _stream(k_cache)))
+
+
+def reshape_and_cache_kvc(
+    key: torch.Tensor,
+    value: torch.Tensor,
+    key_cache: torch.Tensor,
+    value_cache: torch.Tensor,
+    kv_metrics: torch.Tensor,
+    slot_mapping: torch.Tensor,
+    kv_metric_head_bias: torch.Tensor,
+    kv_cache_dtype: str,
+    k_scale: float,
+    v_scale: float,
+) -> None:
+    """reference vllm/_custom_ops.py:641-658 (``kv_cache_dtype == "auto"`` only so far)"""
+    lib = _lib.load()
+    if kv_cache_dtype != "auto":
+        raise RuntimeError(f"Unsupported data type of kv cache: {kv_cache_dtype}")
+    for n, t in (("key", key), ("value", value), ("key_cache", key_cache),
+                 ("value_cache", value_cache)):
+        _require(t, n)
+    _require(kv_metrics, "kv_metrics", torch.float32)
+    _require(slot_mapping, "slot_mapping", torch.int64)
+    _require(kv_metric_head_bias, "kv_metric_head_bias", torch.float32)
+    if key.dtype != key_cache.dtype or value.dtype != value_cache.dtype:
+        raise RuntimeError("reshape_and_cache_kvc: kv_cache_dtype 'auto' needs cache dtype == "
+                           "key/value dtype")
+    if key.stride(2) != 1 or key.stride(1) != key.shape[2] or \
+            value.stride(2) != 1 or value.stride(1) != value.shape[2]:
+        raise RuntimeError("reshape_and_cache_kvc: key/value must be dense in their last two dims")
+    num_tokens, num_heads, head_size = key.shape
+    block_size = key_cache.shape[2]
+    with torch.cuda.device(key.device):
+        _lib.check(lib.kvc_reshape_and_cache(
+            key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+            kv_metrics.data_ptr(), slot_mapping.contiguous().data_ptr(),
+            kv_metric_head_bias.contiguous().data_ptr(), num_tokens, num_heads, head_size,
+            block_size, key.element_size(), key.stride(0), value.stride(0), _stream(key)))
+
+
+def schedule_cache_evictions(*args, **kwargs):
+    """reference vllm/_custom_ops.py:935-1006: the V1 CUDA scheduler.  It is dead code in
+    the reference (vllm/kvcompress/scheduler.py:285 ``if False:``) and its wrapper
+    dispatches to a namespace where the op is not registered; the live
+    path is ``CompressionMetrics.schedule_evictions``."""
+    raise NotImplementedError(
+        "schedule_cache_evictions (V1) is dead code in the reference; use "
+        "vllm_kvcompress_amd.kvcompress.metrics.CompressionMetrics.schedule_evictions")

@@ -1,0 +1,96 @@
+"""ctypes binding of libkvc_mi355x.so (the C ABI declared in include/kvc_mi355x.h).
+
+There is no CPU fallback: if the shared library is missing, or a tensor is not on a
+HIP device, the ops raise.  The library is built in-tree by
+``vllm_kvcompress_amd/csrc/build.sh`` (``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkvc_mi355x.so")
+
+MAX_INT = 2147483000  # reference vllm/kvcompress/metrics.py:12
+
+
+class KvcScheduleParams(ctypes.Structure):
+    """mirror of ``kvc_schedule_params`` (include/kvc_mi355x.h)"""
+    _fields_ = [
+        ("metrics", c_void_p), ("token_positions", c_void_p),
+        ("seq_index_by_block", c_void_p), ("layer_index_by_block", c_void_p),
+        ("head_index_by_block", c_void_p), ("logical_block_num_by_block", c_void_p),
+        ("num_blocks", c_int64),
+        ("block_size", c_int32), ("num_layers", c_int32), ("num_kv_heads", c_int32),
+        ("num_seqs", c_int32),
+        ("seq_slot_of_seq", c_void_p), ("seq_slot_len", c_int32),
+        ("seq_positions", c_void_p), ("num_protected", c_void_p),
+        ("evicted_blocks_per_seq", c_void_p), ("context_lens", c_void_p),
+        ("hanging_token_count", c_void_p), ("evicted_kv_offsets", c_void_p),
+        ("total_slots", c_int64),
+        ("use_average", c_int32), ("num_sinks", c_int32),
+        ("bias", c_void_p), ("position_bins", c_void_p), ("num_bins", c_int32),
+        ("bias_weight", c_float), ("mode", c_int32), ("null_value", c_int32),
+        ("evicted_logical_indices", c_void_p), ("evicted_kv_count", c_void_p),
+        ("evicted_block_count", c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/kvc_mi355x.h
+SYMBOLS = {
+    "kvc_abi_version": (c_int32, []),
+    "kvc_last_error": (c_char_p, []),
+    "kvc_count_block_evictions": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                            c_int64, c_int32, c_int32, c_void_p]),
+    "kvc_schedule_t1_cache_moves": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                              c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "kvc_execute_cache_moves_workspace_bytes": (c_size_t, [c_int32]),
+    "kvc_execute_cache_moves": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,
+                                          c_int32, c_int32, c_void_p, c_size_t, c_void_p]),
+    "kvc_schedule_evictions_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32, c_int32]),
+    "kvc_schedule_evictions": (c_int32, [ctypes.POINTER(KvcScheduleParams), c_void_p, c_size_t,
+                                         c_void_p]),
+    "kvc_aggregate_decode": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
+                                       c_void_p]),
+    "kvc_aggregate_prefill": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
+                                        c_void_p]),
+    "kvc_prefill_metric_epilogue_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "kvc_prefill_metric_epilogue": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                              c_int32, c_int32, c_int32, c_int32, c_int32,
+                                              c_void_p, c_size_t, c_void_p]),
+    "kvc_reshape_and_cache": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
+                                        c_int32, c_int64, c_int64, c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension has not been built "
+            "(run vllm_kvcompress_amd/csrc/build.sh or __graft_entry__.build()). "
+            "There is no CPU fallback for the KV-Compress ops.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    """Error convention of the reference ops: TORCH_CHECK -> RuntimeError."""
+    if rc != 0:
+        msg = load().kvc_last_error()
+        raise RuntimeError(msg.decode() if msg else f"kvc error {rc}")

@@ -1,0 +1,10 @@
+#!/bin/bash
+# Build libkvc_mi355x.so (gfx950 only) in-tree: vllm_kvcompress_amd/libkvc_mi355x.so
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="$HERE/../libkvc_mi355x.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value \
+  "$HERE/kvc_api.hip" "$HERE/kvc_moves.hip" "$HERE/kvc_compact.hip" \
+  "$HERE/kvc_schedule.hip" "$HERE/kvc_aggregate.hip" -o "$OUT"
+echo "built $OUT"

@@ -1,0 +1,73 @@
+// Shared helpers for the gfx950 (CDNA4 / MI355X) KV-Compress kernels.
+// Wave = 64 lanes everywhere in this code base; nothing here is portable to 32-wide
+// hardware and nothing tries to be.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#define KVC_OK 0
+#define KVC_ERR_INVALID 1   // bad argument / unsupported shape  (-> RuntimeError in Python)
+#define KVC_ERR_HIP 2       // HIP runtime failure
+
+namespace kvc {
+
+void set_error(const std::string& msg);   // defined in kvc_api.hip (thread local)
+
+inline int fail_invalid(const std::string& msg) {
+  set_error(msg);
+  return KVC_ERR_INVALID;
+}
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return KVC_ERR_HIP;
+  }
+  return KVC_OK;
+}
+
+constexpr int WAVE = 64;
+
+// Order-preserving map float32 -> uint32 (ascending float order == ascending key order).
+// -0.0 is canonicalised to +0.0 (torch.sort treats them as equal) and NaNs to the positive
+// quiet NaN so they sort after +inf like torch.sort does.
+__device__ __forceinline__ uint32_t float_to_key(float v) {
+  if (v != v) return 0xFFC00000u;          // NaN -> above +inf
+  v = v + 0.0f;                            // -0 -> +0
+  uint32_t b = __float_as_uint(v);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+constexpr uint32_t KEY_INF = 0xFF800000u;  // float_to_key(+inf)
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// wave-wide inclusive scan (64 lanes) with shuffles
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t n = __shfl_up(v, d, 64);
+    if (lane_id() >= d) v += n;
+  }
+  return v;
+}
+
+__device__ __forceinline__ uint32_t wave_reduce_sum(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// last index g in [0,n) with a[g] <= x  (a ascending, a[0] <= x assumed)
+__device__ __forceinline__ int upper_bound_minus1(const int32_t* __restrict__ a, int n, int64_t x) {
+  int lo = 0, hi = n;                      // invariant: a[lo] <= x, (hi==n or a[hi] > x)
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if ((int64_t)a[mid] <= x) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+}  // namespace kvc

@@ -1,0 +1,506 @@
+// A3 CompressionMetrics.schedule_evictions for gfx950 -- without a single sort.
+//
+// The reference (vllm/kvcompress/metrics.py:441-847) masks the candidate metrics, sorts
+// them globally (twice), gathers one threshold per block-sized chunk, sorts those
+// (twice), walks the sequences on the host, counts leading evicted chunks per head and
+// sorts the surviving logical indices (twice) -- six device sorts over N slots and ~8N
+// of temporaries.  What it computes is an order-statistics problem:
+//
+//   * per head g the chunk thresholds are every bs-th order statistic of the head's
+//     masked metrics, thr[g,c] = (c*bs + hang_g)-th smallest;
+//   * per sequence the k smallest thresholds are selected; because thr[g,.] increases
+//     with c, head g frees n_g = #{c : thr[g,c] <= T*} chunks where T* is the k-th
+//     smallest threshold of the sequence, i.e. n_g = floor((R_g(T*) - hang_g)/bs) + 1
+//     with R_g(T) = #{finite keys of head g that are <= T};
+//   * the evicted slots of head g are its cnt_g = (n_g-1)*bs + hang_g smallest keys,
+//     listed by ascending logical index.
+//
+// So: one pass builds order-preserving 32-bit keys in head-contiguous *logical* order;
+// T* per sequence is found by an MSB-first radix select (4 rounds of per-head 256-bin
+// histograms, a per-head scan that turns cumulative counts into chunk counts, and a
+// per-sequence pick of the digit); a per-head radix select finds the cnt_g-th smallest
+// key, and a flag + prefix-sum pass emits the logical indices already in ascending order.
+// Everything is a streaming pass over N x 4 B; ties are resolved exactly in the canonical
+// order of DESIGN.md ((metric, physical block, offset) within a head, (threshold, head,
+// chunk) within a sequence).  The reference's batch>1 quirk (metrics.py:718-721) only
+// changes how many chunks each sequence may free, which is computed on device in
+// seq_prepare_kernel for mode 0.
+#include "kvc_common.h"
+#include "../../include/kvc_mi355x.h"
+
+namespace kvc {
+
+constexpr int RADIX = 256;
+
+struct SchedWs {
+  uint32_t* keys;        // [N]      order-preserving metric keys, index off_g + lambda
+  int32_t* chunk_phys;   // [N/bs]   physical block of logical chunk
+  uint32_t* hist;        // [G,256]  per-head digit histogram -> inclusive cumulative
+  uint32_t* chunkcnt;    // [G,256]  chunks freed if the digit were d
+  uint32_t* less;        // [G]      keys strictly below the current prefix
+  uint32_t* eq;          // [G]      keys equal to T* (after the last round)
+  uint32_t* seq_prefix;  // [B]
+  int32_t* seq_k;        // [B]      chunks this sequence frees (k'), 0 = inactive
+  int32_t* seq_tmp;      // [3B]     F (finite chunks), Cn (all chunks), offset
+};
+
+__device__ __forceinline__ uint32_t nchunks_freed(uint32_t r, uint32_t hang, uint32_t bs) {
+  return r >= hang ? (r - hang) / bs + 1u : 0u;
+}
+
+// wave-aggregated shared-memory histogram add: metric keys are often degenerate in their
+// top digits (all lanes hit one bin), which would serialise 64 LDS atomics; up to two
+// leader-elected groups are folded into one atomic each, the rest go one by one.
+__device__ __forceinline__ void hist_add(uint32_t* hist, bool valid, uint32_t digit) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const unsigned long long act = __ballot(valid);
+    if (!act) return;
+    const int leader = __ffsll((long long)act) - 1;
+    const uint32_t d0 = __shfl(digit, leader, 64);
+    const bool same = valid && digit == d0;
+    const unsigned long long grp = __ballot(same);
+    if (lane_id() == leader) atomicAdd(&hist[d0], (uint32_t)__popcll(grp));
+    valid = valid && !same;
+  }
+  if (valid) atomicAdd(&hist[digit], 1u);
+}
+
+// ------------------------------------------------------------------ 0. keys
+// one thread per (physical block, slot)                     metrics.py:465-544
+__global__ __launch_bounds__(256) void build_keys_kernel(kvc_schedule_params p, SchedWs ws) {
+  const int bs = p.block_size;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t blk = tid / bs;
+  const int off = (int)(tid % bs);
+  if (blk >= p.num_blocks) return;
+  const int s = p.seq_index_by_block[blk];
+  if (s < 0 || s >= p.seq_slot_len) return;
+  const int i = p.seq_slot_of_seq[s];
+  if (i < 0) return;
+  const int L = p.num_layers, H = p.num_kv_heads, B = p.num_seqs;
+  const int l = p.layer_index_by_block[blk], h = p.head_index_by_block[blk];
+  const int lbn = p.logical_block_num_by_block[blk];
+  const int g = (i * L + l) * H + h;
+  const int ctx = p.context_lens[(l * B + i) * H + h];
+  const int nblk = (ctx + bs - 1) / bs;
+  if (lbn < 0 || lbn >= nblk) return;          // not part of the head's slot range
+  const int pos = p.token_positions[blk * bs + off];
+  float m = p.metrics[blk * bs + off];
+  const int seq_pos = p.seq_positions[i];
+  if (p.use_average) m = __fdiv_rn(m, (float)(seq_pos - pos));          // :495-501
+  if (p.bias != nullptr) {                                               // :503-506, :54-81
+    int cnt = 0;
+    for (int k = 0; k < p.num_bins; ++k) cnt += pos >= p.position_bins[k];
+    int bi = cnt - 1;
+    if (bi < 0) bi += p.num_bins;
+    float b = p.bias[((int64_t)l * H + h) * p.num_bins + bi];
+    if (pos < 0) b = 0.0f;
+    m = __fadd_rn(m, __fmul_rn(b, p.bias_weight));
+  }
+  const bool in_range = pos <= seq_pos - p.num_protected[i] && pos >= p.num_sinks;   // :539-544
+  const uint32_t key = in_range ? float_to_key(m) : KEY_INF;
+  const int64_t base = p.evicted_kv_offsets[g];
+  ws.keys[base + (int64_t)lbn * bs + off] = key;
+  if (off == 0) ws.chunk_phys[base / bs + lbn] = (int32_t)blk;
+}
+
+// ------------------------------------------------------------------ 1. per-head histograms
+// flat tiles of TILE keys; a tile inside one head (the common case) accumulates in LDS.
+constexpr int HTILE = 2048;
+__global__ __launch_bounds__(256) void hist_round_kernel(kvc_schedule_params p, SchedWs ws, int round) {
+  __shared__ uint32_t sh[RADIX];
+  const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
+  const int LH = p.num_layers * p.num_kv_heads;
+  const int64_t N = p.total_slots;
+  const int64_t t0 = (int64_t)blockIdx.x * HTILE;
+  const int64_t t1 = min(N, t0 + HTILE);
+  const int shift = 24 - 8 * round;
+  const int g0 = upper_bound_minus1(p.evicted_kv_offsets, G, t0);
+  const int64_t g0_end = (g0 + 1 < G) ? (int64_t)p.evicted_kv_offsets[g0 + 1] : N;
+  const bool single = t1 <= g0_end;
+  if (single) {
+    const int i = g0 / LH;
+    if (ws.seq_k[i] == 0 && round > 0) return;      // inactive sequence
+    const uint32_t prefix = ws.seq_prefix[i];
+    for (int k = threadIdx.x; k < RADIX; k += blockDim.x) sh[k] = 0;
+    __syncthreads();
+    for (int64_t idx = t0 + threadIdx.x; idx < t0 + HTILE; idx += blockDim.x) {
+      bool valid = idx < t1;
+      uint32_t key = valid ? ws.keys[idx] : 0u;
+      valid = valid && key < KEY_INF && (round == 0 || (key >> (shift + 8)) == prefix);
+      hist_add(sh, valid, (key >> shift) & 0xFFu);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < RADIX; k += blockDim.x) {
+      const uint32_t v = sh[k];
+      if (v) atomicAdd(&ws.hist[(int64_t)g0 * RADIX + k], v);
+    }
+  } else {
+    for (int64_t idx = t0 + threadIdx.x; idx < t1; idx += blockDim.x) {
+      const int g = upper_bound_minus1(p.evicted_kv_offsets, G, idx);
+      const int i = g / LH;
+      const uint32_t key = ws.keys[idx];
+      if (key < KEY_INF && (round == 0 || (ws.seq_k[i] != 0 && (key >> (shift + 8)) == ws.seq_prefix[i])))
+        atomicAdd(&ws.hist[(int64_t)g * RADIX + ((key >> shift) & 0xFFu)], 1u);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ 2. per-head scan
+// one wave per head: hist -> inclusive cumulative; chunkcnt[d] = chunks freed at digit d
+__global__ __launch_bounds__(256) void scan_round_kernel(kvc_schedule_params p, SchedWs ws) {
+  const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
+  const int g = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  if (g >= G) return;
+  const int lane = lane_id();
+  uint32_t* h = ws.hist + (int64_t)g * RADIX;
+  uint4 v = reinterpret_cast<uint4*>(h)[lane];            // 4 bins per lane
+  v.y += v.x; v.z += v.y; v.w += v.z;
+  const uint32_t inc = wave_inclusive_scan(v.w);
+  const uint32_t ex = inc - v.w;
+  v.x += ex; v.y += ex; v.z += ex; v.w += ex;
+  reinterpret_cast<uint4*>(h)[lane] = v;
+  const uint32_t less = ws.less[g], hang = (uint32_t)p.hanging_token_count[g], bs = (uint32_t)p.block_size;
+  uint4 c;
+  c.x = nchunks_freed(less + v.x, hang, bs); c.y = nchunks_freed(less + v.y, hang, bs);
+  c.z = nchunks_freed(less + v.z, hang, bs); c.w = nchunks_freed(less + v.w, hang, bs);
+  reinterpret_cast<uint4*>(ws.chunkcnt + (int64_t)g * RADIX)[lane] = c;
+}
+
+// ------------------------------------------------------------------ 3. chunks per sequence
+// after round 0's scan: F_i (finite-threshold chunks), Cn_i (all chunks) and from them the
+// number of chunks k'_i each sequence really frees                 metrics.py:704-729
+__global__ __launch_bounds__(1024) void seq_prepare_kernel(kvc_schedule_params p, SchedWs ws) {
+  const int B = p.num_seqs, L = p.num_layers, H = p.num_kv_heads, LH = L * H, bs = p.block_size;
+  int32_t* F = ws.seq_tmp;
+  int32_t* Cn = ws.seq_tmp + B;
+  int32_t* Off = ws.seq_tmp + 2 * B;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    int64_t f = 0, cn = 0;
+    for (int lh = 0; lh < LH; ++lh) {
+      const int g = i * LH + lh;
+      f += ws.chunkcnt[(int64_t)g * RADIX + 255];
+      const int ctx = p.context_lens[((lh / H) * B + i) * H + (lh % H)];
+      cn += (ctx + bs - 1) / bs;
+    }
+    F[i] = (int32_t)f;
+    Cn[i] = (int32_t)cn;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t o = 0;
+    for (int i = 0; i < B; ++i) { Off[i] = (int32_t)o; o += Cn[i]; }
+  }
+  __syncthreads();
+  __shared__ int64_t un_s[1024];
+  // #inf thresholds among the first x entries of the (seq, threshold)-ordered chunk list
+  auto inf_prefix = [&](int64_t x) {
+    int64_t t = 0;
+    for (int j = 0; j < B; ++j) {
+      int64_t v = x - Off[j] - F[j];
+      const int64_t Ij = Cn[j] - F[j];
+      v = v < 0 ? 0 : (v > Ij ? Ij : v);
+      t += v;
+    }
+    return t;
+  };
+  {                                                  // B <= 1024 (checked on host)
+    const int i = threadIdx.x;
+    if (i < B) {
+      const int64_t x = (int64_t)Off[i] + p.evicted_blocks_per_seq[i];
+      int64_t ninf = inf_prefix(x);
+      if (p.mode == 1) ninf -= inf_prefix(Off[i]);
+      un_s[i] = x - ninf;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    int64_t e = un_s[i];
+    if (p.mode == 0)
+      for (int j = i + 1; j < B; ++j) e = un_s[j] < e ? un_s[j] : e;   // later seqs un-evict
+    int64_t k = e - Off[i];
+    k = k < 0 ? 0 : k;
+    k = k > F[i] ? F[i] : k;        // thresholds beyond the finite ones are never freed
+    ws.seq_k[i] = (int32_t)k;
+    ws.seq_prefix[i] = 0;
+  }
+}
+
+// ------------------------------------------------------------------ 4. pick the digit
+// one workgroup (256 threads = 256 digits) per sequence
+__global__ __launch_bounds__(256) void pick_round_kernel(kvc_schedule_params p, SchedWs ws, int round) {
+  __shared__ uint32_t sums[RADIX];
+  __shared__ int dstar_s;
+  const int i = blockIdx.x;
+  const int LH = p.num_layers * p.num_kv_heads;
+  const uint32_t k = (uint32_t)ws.seq_k[i];
+  if (k == 0) return;
+  const int d = threadIdx.x;
+  uint32_t s = 0;
+  for (int lh = 0; lh < LH; ++lh) s += ws.chunkcnt[((int64_t)i * LH + lh) * RADIX + d];
+  sums[d] = s;
+  if (d == 0) dstar_s = 255;
+  __syncthreads();
+  const bool hit = s >= k && (d == 0 || sums[d - 1] < k);      // S is non-decreasing in d
+  if (hit) dstar_s = d;
+  __syncthreads();
+  const int ds = dstar_s;
+  if (d == 0) ws.seq_prefix[i] = (ws.seq_prefix[i] << 8) | (uint32_t)ds;
+  for (int lh = d; lh < LH; lh += blockDim.x) {
+    const int g = i * LH + lh;
+    const uint32_t* cum = ws.hist + (int64_t)g * RADIX;
+    const uint32_t below = ds > 0 ? cum[ds - 1] : 0u;
+    ws.less[g] += below;
+    if (round == 3) ws.eq[g] = cum[ds] - below;
+  }
+}
+
+// ------------------------------------------------------------------ 5. per-head counts
+// chunks with threshold < T* are freed; chunks with threshold == T* are handed out in
+// (head, chunk) order until the sequence total is k'.           metrics.py:773-792
+__global__ __launch_bounds__(256) void finalize_heads_kernel(kvc_schedule_params p, SchedWs ws) {
+  __shared__ uint32_t wave_tot[4];
+  __shared__ uint32_t carry_s;
+  __shared__ uint32_t lt_total_s;
+  const int i = blockIdx.x;
+  const int LH = p.num_layers * p.num_kv_heads;
+  const uint32_t bs = (uint32_t)p.block_size;
+  const uint32_t k = (uint32_t)ws.seq_k[i];
+  const int tid = threadIdx.x, lane = lane_id(), w = tid / WAVE;
+  // pass 1: total of sure chunks
+  uint32_t part = 0;
+  for (int lh = tid; lh < LH; lh += blockDim.x) {
+    const int g = i * LH + lh;
+    if (k) part += nchunks_freed(ws.less[g], (uint32_t)p.hanging_token_count[g], bs);
+  }
+  part = wave_reduce_sum(part);
+  if (lane == 0) wave_tot[w] = part;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  if (tid == 0) lt_total_s = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+  __syncthreads();
+  const uint32_t need = k - (k ? lt_total_s : 0u);     // tie chunks still to hand out
+  for (int base = 0; base < LH; base += blockDim.x) {
+    const int lh = base + tid;
+    const int g = i * LH + lh;
+    uint32_t n_lt = 0, e = 0, hang = 1;
+    if (lh < LH) {
+      hang = (uint32_t)p.hanging_token_count[g];
+      if (k) {
+        n_lt = nchunks_freed(ws.less[g], hang, bs);
+        e = nchunks_freed(ws.less[g] + ws.eq[g], hang, bs) - n_lt;
+      }
+    }
+    const uint32_t inc = wave_inclusive_scan(e);
+    __syncthreads();
+    if (lane == 63) wave_tot[w] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int q = 0; q < w; ++q) woff += wave_tot[q];
+    const uint32_t excl = carry_s + woff + inc - e;
+    if (lh < LH) {
+      const uint32_t room = need > excl ? need - excl : 0u;
+      const uint32_t n = n_lt + (e < room ? e : room);
+      p.evicted_block_count[g] = (int32_t)n;
+      p.evicted_kv_count[g] = n > 0 ? (int32_t)((n - 1) * bs + hang) : 0;
+    }
+    __syncthreads();
+    if (tid == blockDim.x - 1) carry_s = excl + e;
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ 6. select + emit
+// one workgroup per head: cnt-th smallest (key, physical slot) by radix select, then the
+// ascending logical indices of everything at or below it.       metrics.py:822-834
+constexpr int SEL_THREADS = 512;
+
+// radix-select the rank-th (1-based) smallest value of f(idx) over idx in [0,n) where
+// pred(idx); returns the value, and the 1-based rank among equals / number of equals.
+template <typename ValF, typename PredF>
+__device__ void block_radix_select(uint32_t* hist, uint32_t* bc, int n, uint32_t rank, ValF val,
+                                   PredF pred, uint32_t& out_val, uint32_t& out_rank_in_eq,
+                                   uint32_t& out_eq) {
+  uint32_t prefix = 0;
+  for (int round = 0; round < 4; ++round) {
+    const int shift = 24 - 8 * round;
+    for (int k = threadIdx.x; k < RADIX; k += blockDim.x) hist[k] = 0;
+    __syncthreads();
+    const int nround = (n + blockDim.x - 1) / blockDim.x * blockDim.x;
+    for (int idx = threadIdx.x; idx < nround; idx += blockDim.x) {
+      bool valid = idx < n && pred(idx);
+      uint32_t v = valid ? val(idx) : 0u;
+      valid = valid && (round == 0 || (v >> (shift + 8)) == prefix);
+      hist_add(hist, valid, (v >> shift) & 0xFFu);
+    }
+    __syncthreads();
+    // 256-bin inclusive scan by the first 4 waves' worth of threads (one wave does it)
+    if (threadIdx.x < WAVE) {
+      uint4 q = reinterpret_cast<uint4*>(hist)[threadIdx.x];
+      q.y += q.x; q.z += q.y; q.w += q.z;
+      const uint32_t inc = wave_inclusive_scan(q.w);
+      const uint32_t ex = inc - q.w;
+      q.x += ex; q.y += ex; q.z += ex; q.w += ex;
+      const uint32_t c[4] = {q.x, q.y, q.z, q.w};
+      uint32_t prev = ex;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (prev < rank && rank <= c[t]) { bc[0] = threadIdx.x * 4 + t; bc[1] = prev; bc[2] = c[t] - prev; }
+        prev = c[t];
+      }
+    }
+    __syncthreads();
+    prefix = (prefix << 8) | bc[0];
+    rank -= bc[1];
+    out_eq = bc[2];
+    __syncthreads();
+  }
+  out_val = prefix;
+  out_rank_in_eq = rank;
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(kvc_schedule_params p, SchedWs ws) {
+  __shared__ __attribute__((aligned(16))) uint32_t hist[RADIX];
+  __shared__ uint32_t bc[4];
+  __shared__ uint32_t wave_tot[SEL_THREADS / WAVE];
+  __shared__ uint32_t carry_s;
+  const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
+  const int g = blockIdx.x;
+  const int bs = p.block_size;
+  const int64_t base = p.evicted_kv_offsets[g];
+  const int64_t end = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : p.total_slots;
+  const int n = (int)(end - base);
+  const uint32_t cnt = (uint32_t)p.evicted_kv_count[g];
+  const uint32_t* keys = ws.keys + base;
+  int32_t* out = p.evicted_logical_indices + base;
+  const int tid = threadIdx.x, lane = lane_id(), w = tid / WAVE;
+  if (cnt == 0) {
+    for (int idx = tid; idx < n; idx += blockDim.x) out[idx] = p.null_value;
+    return;
+  }
+  uint32_t M, take, eqn;
+  block_radix_select(hist, bc, n, cnt, [&](int idx) { return keys[idx]; },
+                     [&](int) { return true; }, M, take, eqn);
+  // ties on the metric: the `take` entries with the smallest (physical block, offset)
+  uint32_t Fstar = 0xFFFFFFFFu;
+  const int32_t* cphys = ws.chunk_phys + base / bs;
+  auto fkey = [&](int idx) { return (uint32_t)cphys[idx / bs] * (uint32_t)bs + (uint32_t)(idx % bs); };
+  if (take < eqn) {
+    uint32_t r2, e2;
+    block_radix_select(hist, bc, n, take, fkey, [&](int idx) { return keys[idx] == M; }, Fstar, r2, e2);
+  }
+  // emit: flag, block-wide exclusive scan, compact; then pad with null
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  const int nround = (n + blockDim.x - 1) / blockDim.x * blockDim.x;
+  for (int idx0 = 0; idx0 < nround; idx0 += blockDim.x) {
+    const int idx = idx0 + tid;
+    bool sel = false;
+    if (idx < n) {
+      const uint32_t key = keys[idx];
+      sel = key < M || (key == M && (Fstar == 0xFFFFFFFFu || fkey(idx) <= Fstar));
+    }
+    const unsigned long long bal = __ballot(sel);
+    const uint32_t wave_cnt = (uint32_t)__popcll(bal);
+    const uint32_t lane_ex = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[w] = wave_cnt;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+    for (int q = 0; q < SEL_THREADS / WAVE; ++q) { if (q < w) woff += wave_tot[q]; tot += wave_tot[q]; }
+    const uint32_t carry = carry_s;
+    if (sel) out[carry + woff + lane_ex] = idx;        // logical index == position in head
+    __syncthreads();
+    if (tid == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+  for (int idx = (int)cnt + tid; idx < n; idx += blockDim.x) out[idx] = p.null_value;
+}
+
+}  // namespace kvc
+
+// --------------------------------------------------------------------------- host side
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct WsLayout {
+  size_t keys, chunk_phys, hist, chunkcnt, less, eq, seq_prefix, seq_k, seq_tmp, total;
+};
+
+static WsLayout ws_layout(int64_t N, int32_t G, int32_t B, int32_t bs) {
+  WsLayout l;
+  size_t o = 0;
+  l.keys = o;        o = align_up(o + (size_t)N * 4, 256);
+  l.chunk_phys = o;  o = align_up(o + (size_t)(N / bs + 1) * 4, 256);
+  l.hist = o;        o = align_up(o + (size_t)G * kvc::RADIX * 4, 256);
+  l.chunkcnt = o;    o = align_up(o + (size_t)G * kvc::RADIX * 4, 256);
+  l.less = o;        o = align_up(o + (size_t)G * 4, 256);
+  l.eq = o;          o = align_up(o + (size_t)G * 4, 256);
+  l.seq_prefix = o;  o = align_up(o + (size_t)B * 4, 256);
+  l.seq_k = o;       o = align_up(o + (size_t)B * 4, 256);
+  l.seq_tmp = o;     o = align_up(o + (size_t)B * 12, 256);
+  l.total = o;
+  return l;
+}
+
+extern "C" size_t kvc_schedule_evictions_workspace_bytes(int64_t total_slots, int32_t total_heads,
+                                                         int32_t num_seqs, int32_t block_size) {
+  if (block_size < 1) return 0;
+  return ws_layout(total_slots, total_heads, num_seqs, block_size).total;
+}
+
+extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* workspace,
+                                      size_t workspace_bytes, kvc_stream_t stream) {
+  using namespace kvc;
+  const kvc_schedule_params p = *pp;
+  if (p.block_size < 1) return fail_invalid("Unsupported block size: " + std::to_string(p.block_size));
+  if (p.num_seqs < 1 || p.num_seqs > 1024)
+    return fail_invalid("schedule_evictions: num_seqs must be in [1,1024]");
+  if (p.mode != 0 && p.mode != 1) return fail_invalid("schedule_evictions: mode must be 0 or 1");
+  if (p.total_slots < 0 || p.total_slots >= (int64_t)2147483647)
+    return fail_invalid("schedule_evictions: total slots must stay below 2^31 (int32 offsets)");
+  if (p.total_slots % p.block_size != 0)
+    return fail_invalid("schedule_evictions: total_slots must be a multiple of block_size");
+  const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
+  const int B = p.num_seqs;
+  const WsLayout l = ws_layout(p.total_slots, G, B, p.block_size);
+  if (workspace_bytes < l.total) return fail_invalid("schedule_evictions: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  uint8_t* wb = reinterpret_cast<uint8_t*>(workspace);
+  SchedWs ws;
+  ws.keys = reinterpret_cast<uint32_t*>(wb + l.keys);
+  ws.chunk_phys = reinterpret_cast<int32_t*>(wb + l.chunk_phys);
+  ws.hist = reinterpret_cast<uint32_t*>(wb + l.hist);
+  ws.chunkcnt = reinterpret_cast<uint32_t*>(wb + l.chunkcnt);
+  ws.less = reinterpret_cast<uint32_t*>(wb + l.less);
+  ws.eq = reinterpret_cast<uint32_t*>(wb + l.eq);
+  ws.seq_prefix = reinterpret_cast<uint32_t*>(wb + l.seq_prefix);
+  ws.seq_k = reinterpret_cast<int32_t*>(wb + l.seq_k);
+  ws.seq_tmp = reinterpret_cast<int32_t*>(wb + l.seq_tmp);
+  if (p.total_slots == 0) {
+    hipMemsetAsync(p.evicted_kv_count, 0, (size_t)G * 4, s);
+    hipMemsetAsync(p.evicted_block_count, 0, (size_t)G * 4, s);
+    return check_launch("schedule_evictions(empty)");
+  }
+  // keys default to "not evictable", chunk table to 0, counters to 0
+  hipMemsetAsync(ws.keys, 0xFF, (size_t)p.total_slots * 4, s);
+  hipMemsetAsync(ws.chunk_phys, 0, (size_t)(p.total_slots / p.block_size + 1) * 4, s);
+  hipMemsetAsync(ws.less, 0, (size_t)G * 4, s);
+  hipMemsetAsync(ws.eq, 0, (size_t)G * 4, s);
+  hipMemsetAsync(ws.seq_prefix, 0, (size_t)B * 4, s);
+  hipMemsetAsync(ws.seq_k, 0, (size_t)B * 4, s);
+  {
+    const int64_t threads = p.num_blocks * p.block_size;
+    hipLaunchKernelGGL(build_keys_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p, ws);
+  }
+  const unsigned htiles = (unsigned)((p.total_slots + HTILE - 1) / HTILE);
+  for (int round = 0; round < 4; ++round) {
+    hipMemsetAsync(ws.hist, 0, (size_t)G * RADIX * 4, s);
+    hipLaunchKernelGGL(hist_round_kernel, dim3(htiles), dim3(256), 0, s, p, ws, round);
+    hipLaunchKernelGGL(scan_round_kernel, dim3((G + 3) / 4), dim3(256), 0, s, p, ws);
+    if (round == 0) hipLaunchKernelGGL(seq_prepare_kernel, dim3(1), dim3(1024), 0, s, p, ws);
+    hipLaunchKernelGGL(pick_round_kernel, dim3(B), dim3(256), 0, s, p, ws, round);
+  }
+  hipLaunchKernelGGL(finalize_heads_kernel, dim3(B), dim3(256), 0, s, p, ws);
+  hipLaunchKernelGGL(select_emit_kernel, dim3(G), dim3(SEL_THREADS), 0, s, p, ws);
+  return check_launch("schedule_evictions");
+}

@@ -1,0 +1,379 @@
+"""``CompressionMetrics`` with the reference's interface, computed by HIP kernels.
+
+Mirror of ``vllm/kvcompress/metrics.py`` (reference lines cited per method): same
+constructor, same state tensors (names, shapes, dtypes), same methods and return
+values.  What differs is *how*: ``schedule_evictions`` is one sort-free device
+pipeline (``csrc/kvc_schedule.hip``) instead of six ``torch.sort`` calls plus a host
+loop, and the aggregation methods are single fused passes.
+
+There is no CPU path: the state lives on a HIP device and every method that computes
+calls into ``libkvc_mi355x.so``.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple, Union
+
+import torch
+
+from .. import _lib
+from .._custom_ops import _stream, workspace
+from .._lib import MAX_INT, KvcScheduleParams
+
+_BIAS_KEY = "bias"                 # reference metrics.py:13-14
+_POSITION_RANGE_KEY = "pos_bins"
+
+IntsLike = Union[Sequence[int], torch.Tensor]
+
+
+@dataclass
+class KVHeadBias:
+    """reference metrics.py:44-81 (the lookup itself runs inside build_keys_kernel)"""
+    bias: torch.Tensor             # [num_layers, num_kv_heads, num_bins] f32
+    position_bins: torch.Tensor    # [num_bins] i32
+
+    def to(self, device) -> "KVHeadBias":
+        self.bias = self.bias.to(device)
+        self.position_bins = self.position_bins.to(device)
+        return self
+
+
+def _load_kv_head_bias(path: str) -> KVHeadBias:
+    """reference metrics.py:17-41"""
+    ext = path.split(".")[-1]
+    if ext == "safetensors":
+        from safetensors import safe_open
+        f = safe_open(path, framework="pt")
+        return KVHeadBias(f.get_tensor(_BIAS_KEY).type(torch.float),
+                          f.get_tensor(_POSITION_RANGE_KEY).type(torch.int))
+    if ext in ("pt", "bin"):
+        f = torch.load(path)
+        return KVHeadBias(f[_BIAS_KEY].type(torch.float), f[_POSITION_RANGE_KEY].type(torch.int))
+    if ext == "npz":
+        import numpy as np
+        f = np.load(path)
+        return KVHeadBias(torch.tensor(f[_BIAS_KEY]).type(torch.float),
+                          torch.tensor(f[_POSITION_RANGE_KEY]).type(torch.int))
+    raise ValueError(f"Unsupported file format {ext}")
+
+
+class CompressionMetrics:
+    """reference metrics.py:94-975"""
+
+    def __init__(
+        self,
+        block_size: int,
+        num_layers: int,
+        num_kv_heads: int,
+        num_queries_per_kv: int,
+        max_kv_per_sort: int,
+        kv_head_bias_file: Optional[str],
+        kv_head_bias_weight: float,
+        device: str = "cuda:0",
+        random: bool = False,
+        even_layer_evict: bool = False,
+        use_l2: bool = True,
+        use_average: bool = False,
+        record_decoding_metrics: bool = True,
+        num_attention_sinks: int = 0,
+    ) -> None:
+        _lib.load()                                   # fail loudly if the extension is absent
+        self.block_size = block_size
+        self.num_layers = num_layers
+        self.num_kv_heads = num_kv_heads
+        self.num_queries_per_kv = num_queries_per_kv
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("CompressionMetrics needs a HIP device (no CPU fallback exists)")
+        self.num_sinks = num_attention_sinks
+        self.random = random
+        self.even_layer_evict = even_layer_evict
+        self.use_l2 = use_l2
+        self.use_average = use_average
+        self.record_decoding_metrics = record_decoding_metrics
+        self._has_bias = bool(kv_head_bias_file)
+        if kv_head_bias_file:
+            expected_shape = (num_layers, num_kv_heads)
+            self.kv_metric_head_bias = _load_kv_head_bias(kv_head_bias_file).to(self.device)
+            if tuple(self.kv_metric_head_bias.bias.shape[:-1]) != expected_shape:
+                raise ValueError(f"expected shape {(*expected_shape, -1)} for KV head bias tensor "
+                                 f"but got {self.kv_metric_head_bias.bias.shape}")
+        else:
+            self.kv_metric_head_bias = KVHeadBias(
+                torch.zeros((num_layers, num_kv_heads, 1), dtype=torch.float, device=self.device),
+                torch.zeros((1,), dtype=torch.int, device=self.device))
+        self.kv_metric_bias_weight = kv_head_bias_weight
+        self.max_kv_per_sort = max_kv_per_sort
+        self.num_blocks = None
+        self.unassigned_seq_idx = -1
+        self.metrics = None
+        self._temp_metrics = None
+        self._temp_clean = False
+        self.temp_v2_metrics = None
+        self.seq_index_by_block = None
+        self.layer_index_by_block = None
+        self.head_index_by_block = None
+        self.logical_block_num_by_block = None
+        self.token_positions = None
+        self.prev_seq_lens = {}
+        # "reference": bit-exact to the reference including its batch>1 quirk
+        # (metrics.py:718-721); "per_sequence": each sequence scheduled as if alone.
+        self.schedule_mode = "reference"
+
+    # temp_metrics is handed to the attention kernels, which write into it; reading the
+    # attribute therefore marks it dirty so that the fused clear in aggregate_decode stays
+    # invisible to callers (clear_temp_metrics keeps its contract).
+    @property
+    def temp_metrics(self):
+        self._temp_clean = False
+        return self._temp_metrics
+
+    @temp_metrics.setter
+    def temp_metrics(self, value):
+        self._temp_metrics = value
+        self._temp_clean = False
+
+    # ------------------------------------------------------------------ state management
+    def reinit_kv_metadata(self) -> None:
+        num_blocks = self.num_blocks
+        self.clear_kv_metadata()
+        self.init_kv_metadata(num_blocks)
+
+    def clear_kv_metadata(self) -> None:
+        """reference metrics.py:205-214"""
+        self.num_blocks = None
+        self.metrics = None
+        self._temp_metrics = None
+        self.temp_v2_metrics = None
+        self.seq_index_by_block = None
+        self.layer_index_by_block = None
+        self.head_index_by_block = None
+        self.logical_block_num_by_block = None
+        self.token_positions = None
+
+    def init_kv_metadata(self, num_blocks: int) -> None:
+        """reference metrics.py:216-275"""
+        assert self.num_blocks is None, "already initialized"
+        self.num_blocks = num_blocks
+        dev = self.device
+        self.metrics = torch.empty((num_blocks, self.block_size), dtype=torch.float32, device=dev)
+        if self.random:
+            self.metrics.uniform_()
+        self._temp_metrics = torch.empty((num_blocks, self.block_size, self.num_queries_per_kv),
+                                         dtype=torch.float32, device=dev)
+        self._temp_clean = False
+        self.temp_v2_metrics = torch.empty_like(self._temp_metrics)
+        self.seq_index_by_block = torch.full((num_blocks,), self.unassigned_seq_idx,
+                                             dtype=torch.int, device=dev)
+        self.layer_index_by_block = torch.zeros((num_blocks,), dtype=torch.int, device=dev)
+        self.head_index_by_block = torch.zeros((num_blocks,), dtype=torch.int, device=dev)
+        self.logical_block_num_by_block = torch.zeros((num_blocks,), dtype=torch.int, device=dev)
+        self.token_positions = torch.zeros((num_blocks, self.block_size), dtype=torch.int,
+                                           device=dev)
+        self.validate_metadata()
+
+    def validate_metadata(self) -> None:
+        """reference metrics.py:372-376"""
+        allocated_mask = self.seq_index_by_block >= 0
+        assert (self.head_index_by_block[allocated_mask] < self.num_kv_heads).all()
+
+    def clear_temp_metrics(self) -> None:
+        """reference metrics.py:337-342.  A no-op when the last aggregate_decode already
+        zeroed the buffer in its own pass and nobody has touched it since."""
+        if self._temp_clean:
+            return
+        self._temp_metrics.zero_()
+        self._temp_clean = True
+
+    def insert_metadata(self, metadata) -> None:
+        """reference metrics.py:344-364 (``metadata`` is a BlockMetadata-like object)"""
+        pb = metadata.physical_blocks
+        self.seq_index_by_block[pb] = metadata.seq_indices
+        self.logical_block_num_by_block[pb] = metadata.logical_blocks.type(torch.int)
+        self.layer_index_by_block[pb] = metadata.layer_indices
+        self.head_index_by_block[pb] = metadata.head_indices
+        self.token_positions[pb] = metadata.token_positions
+
+    def remove_metadata(self, physical_blocks: torch.Tensor) -> None:
+        """reference metrics.py:366-370"""
+        self.seq_index_by_block[physical_blocks] = -1
+
+    def randomize_metric_slots(self, slot_mapping: torch.Tensor) -> None:
+        flat_indices = slot_mapping.flatten().type(torch.long)
+        self.metrics.view(-1)[flat_indices] = torch.rand(
+            flat_indices.shape, dtype=torch.float32, device=self.device)
+
+    # ------------------------------------------------------------------ aggregation
+    def aggregate_prefill(self, prefill_metrics: torch.Tensor, slot_mapping: torch.Tensor) -> None:
+        """reference metrics.py:396-427: metrics[slot[t,h]] += sum_q prefill[t, h*qpk+q]"""
+        if self.random:
+            return
+        seq_len, nq = prefill_metrics.shape
+        assert nq % self.num_kv_heads == 0
+        qpk = nq // self.num_kv_heads
+        assert tuple(slot_mapping.shape) == (seq_len, self.num_kv_heads), \
+            f"{(seq_len, self.num_kv_heads)} != {tuple(slot_mapping.shape)}"
+        lib = _lib.load()
+        pm = prefill_metrics.contiguous()
+        sm = slot_mapping.contiguous()
+        if pm.dtype != torch.float32 or sm.dtype != torch.int64 or not pm.is_cuda:
+            raise RuntimeError("aggregate_prefill: need float32 metrics and int64 slots on a HIP device")
+        with torch.cuda.device(self.device):
+            _lib.check(lib.kvc_aggregate_prefill(self.metrics.data_ptr(), pm.data_ptr(),
+                                                 sm.data_ptr(), seq_len, self.num_kv_heads, qpk,
+                                                 _stream(self.metrics)))
+
+    def aggregate_decode(self, fuse_clear: bool = True) -> None:
+        """reference metrics.py:429-439: metrics += sum_q temp^2 (L2) or sum_q temp (L1).
+        With ``fuse_clear`` the same pass also zeroes temp_metrics, which makes the next
+        ``clear_temp_metrics()`` free."""
+        if self.random or not self.record_decoding_metrics:
+            return
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.kvc_aggregate_decode(
+                self.metrics.data_ptr(), self._temp_metrics.data_ptr(), self.metrics.numel(),
+                self.num_queries_per_kv, 1 if self.use_l2 else 0, 1 if fuse_clear else 0,
+                _stream(self.metrics)))
+        self._temp_clean = bool(fuse_clear)
+
+    # ------------------------------------------------------------------ scheduling
+    def _as_i32(self, x: IntsLike) -> torch.Tensor:
+        if isinstance(x, torch.Tensor):
+            return x.to(device=self.device, dtype=torch.int32).contiguous()
+        return torch.tensor(list(x), dtype=torch.int32, device=self.device)
+
+    def schedule_evictions(
+        self,
+        seq_indices: List[int],
+        seq_positions: IntsLike,
+        evicted_blocks_per_seq: IntsLike,
+        context_lens: torch.Tensor,
+        hanging_token_count: torch.Tensor,
+        evicted_kv_offsets: torch.Tensor,
+        num_protected: IntsLike,
+        uniform_evict: bool = False,
+        debug={},
+        profile=False,
+        total_slots: Optional[int] = None,
+    ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """reference metrics.py:441-847.  Returns ``(evicted_logical_indices [N] i32,
+        evicted_kv_count [B,L,H] i32, evicted_block_count [B,L,H] i32)``.
+
+        ``total_slots`` (optional, not in the reference signature): N if the caller
+        already knows it; otherwise it is read back from ``context_lens`` (one small
+        device->host copy, the only synchronisation of this method)."""
+        assert len(seq_indices) > 0
+        assert list(sorted(seq_indices)) == list(seq_indices), (
+            "schedule_evictions input not ordered by ascending index")
+        if uniform_evict:
+            raise NotImplementedError("uniform_evict is never used by the reference scheduler "
+                                      "(vllm/kvcompress/scheduler.py:492-501)")
+        lib = _lib.load()
+        bs, L, H, B = self.block_size, self.num_layers, self.num_kv_heads, len(seq_indices)
+        dev = self.device
+        for n, t in (("context_lens", context_lens), ("hanging_token_count", hanging_token_count),
+                     ("evicted_kv_offsets", evicted_kv_offsets)):
+            if not t.is_cuda or t.dtype != torch.int32:
+                raise RuntimeError(f"schedule_evictions: {n} must be an int32 tensor on a HIP device")
+        context_lens = context_lens.contiguous()
+        hanging_token_count = hanging_token_count.contiguous()
+        evicted_kv_offsets = evicted_kv_offsets.contiguous()
+        assert tuple(context_lens.shape) == (L, B, H)
+        assert tuple(evicted_kv_offsets.shape) == (B, L, H)
+        if total_slots is None:
+            total_slots = int((((context_lens + (bs - 1)) // bs).sum(dtype=torch.int64) * bs).item())
+        N = int(total_slots)
+
+        slot_of_seq = torch.full((max(seq_indices) + 1,), -1, dtype=torch.int32)
+        slot_of_seq[torch.tensor(list(seq_indices), dtype=torch.long)] = torch.arange(
+            B, dtype=torch.int32)
+        slot_of_seq = slot_of_seq.to(dev, non_blocking=True)
+        seq_pos = self._as_i32(seq_positions)
+        prot = self._as_i32(num_protected)
+        k_per_seq = self._as_i32(evicted_blocks_per_seq)
+
+        out_idx = torch.empty((N,), dtype=torch.int32, device=dev)
+        out_kv = torch.empty((B, L, H), dtype=torch.int32, device=dev)
+        out_blk = torch.empty((B, L, H), dtype=torch.int32, device=dev)
+
+        p = KvcScheduleParams()
+        p.metrics = self.metrics.data_ptr()
+        p.token_positions = self.token_positions.data_ptr()
+        p.seq_index_by_block = self.seq_index_by_block.data_ptr()
+        p.layer_index_by_block = self.layer_index_by_block.data_ptr()
+        p.head_index_by_block = self.head_index_by_block.data_ptr()
+        p.logical_block_num_by_block = self.logical_block_num_by_block.data_ptr()
+        p.num_blocks = self.num_blocks
+        p.block_size, p.num_layers, p.num_kv_heads, p.num_seqs = bs, L, H, B
+        p.seq_slot_of_seq = slot_of_seq.data_ptr()
+        p.seq_slot_len = slot_of_seq.numel()
+        p.seq_positions = seq_pos.data_ptr()
+        p.num_protected = prot.data_ptr()
+        p.evicted_blocks_per_seq = k_per_seq.data_ptr()
+        p.context_lens = context_lens.data_ptr()
+        p.hanging_token_count = hanging_token_count.data_ptr()
+        p.evicted_kv_offsets = evicted_kv_offsets.data_ptr()
+        p.total_slots = N
+        p.use_average = 1 if self.use_average else 0
+        p.num_sinks = int(self.num_sinks)
+        if self._has_bias or float(self.kv_metric_bias_weight) != 0.0:
+            hb = self.kv_metric_head_bias
+            self._bias_keepalive = (hb.bias.contiguous(), hb.position_bins.contiguous())
+            p.bias = self._bias_keepalive[0].data_ptr()
+            p.position_bins = self._bias_keepalive[1].data_ptr()
+            p.num_bins = self._bias_keepalive[1].numel()
+        else:
+            p.bias, p.position_bins, p.num_bins = None, None, 0
+        p.bias_weight = float(self.kv_metric_bias_weight)
+        p.mode = {"reference": 0, "per_sequence": 1}[self.schedule_mode]
+        p.null_value = MAX_INT
+        p.evicted_logical_indices = out_idx.data_ptr()
+        p.evicted_kv_count = out_kv.data_ptr()
+        p.evicted_block_count = out_blk.data_ptr()
+
+        ws_bytes = lib.kvc_schedule_evictions_workspace_bytes(N, B * L * H, B, bs)
+        ws = workspace(dev, ws_bytes, "schedule_evictions")
+        with torch.cuda.device(dev):
+            _lib.check(lib.kvc_schedule_evictions(ctypes.byref(p), ws.data_ptr(), ws.numel(),
+                                                  _stream(self.metrics)))
+        return out_idx, out_kv, out_blk
+
+    def profile_schedule_evictions(self):
+        """reference metrics.py:277-335: peak extra device memory of one
+        ``schedule_evictions`` call over ``max_kv_per_sort`` slots."""
+        assert self.num_blocks is None, "cannot profile after initialization"
+        bs = self.block_size
+        sort_blocks = (self.max_kv_per_sort + bs - 1) // bs
+        total_heads = self.num_layers * self.num_kv_heads
+        blocks_per_head = (sort_blocks + total_heads - 1) // total_heads
+        total_blocks = blocks_per_head * total_heads
+        dev = self.device
+        self.init_kv_metadata(total_blocks)
+        self.metrics.zero_()
+        self.token_positions.zero_()
+        self.seq_index_by_block[:] = 0
+        self.head_index_by_block[:] = (torch.arange(self.num_kv_heads)
+                                       .repeat_interleave(blocks_per_head)
+                                       .repeat(self.num_layers).to(dev))
+        self.layer_index_by_block[:] = (torch.arange(self.num_layers)
+                                        .repeat_interleave(self.num_kv_heads * blocks_per_head)
+                                        .to(dev))
+        self.logical_block_num_by_block[:] = (torch.arange(blocks_per_head)
+                                              .repeat(total_heads).to(dev))
+        context_lens = torch.full((self.num_layers, 1, self.num_kv_heads), bs * blocks_per_head,
+                                  dtype=torch.int, device=dev)
+        hanging = torch.full((1, self.num_layers, self.num_kv_heads), bs, dtype=torch.int,
+                             device=dev)
+        offs = (torch.arange(total_heads, dtype=torch.int, device=dev) * (bs * blocks_per_head)
+                ).reshape(1, self.num_layers, self.num_kv_heads)
+        torch.cuda.synchronize(dev)
+        torch.cuda.reset_peak_memory_stats(dev)
+        init_mem = torch.cuda.max_memory_allocated(dev)
+        self.schedule_evictions([0], [1], [total_blocks], context_lens, hanging, offs, [32],
+                                profile=True)
+        torch.cuda.synchronize(dev)
+        final_mem = torch.cuda.max_memory_allocated(dev)
+        self.clear_kv_metadata()
+        return final_mem - init_mem
