@@ -147,7 +147,7 @@ def execute_cache_moves(
     cmc = cache_moves_count.contiguous()
     offs = evicted_kv_offsets.contiguous()
     total_heads = cmc.numel()
-    ws_bytes = lib.kvc_execute_cache_moves_workspace_bytes(total_heads)
+    ws_bytes = lib.kvc_execute_cache_moves_workspace_bytes(total_heads, num_blocks)
     ws = workspace(k_cache.device, ws_bytes, "execute_cache_moves")
     with torch.cuda.device(k_cache.device):
         _lib.check(lib.kvc_execute_cache_moves(

@@ -47,7 +47,7 @@ SYMBOLS = {
     "kvc_schedule_t1_cache_moves": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                               c_int32, c_int32, c_int32, c_int32, c_void_p]),
-    "kvc_execute_cache_moves_workspace_bytes": (c_size_t, [c_int32]),
+    "kvc_execute_cache_moves_workspace_bytes": (c_size_t, [c_int32, c_int64]),
     "kvc_execute_cache_moves": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,
                                           c_int32, c_int32, c_void_p, c_size_t, c_void_p]),
@@ -75,6 +75,9 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own HIP runtime; it must be the one already loaded when the kernels'
+    # library resolves libamdhip64 (a second runtime instance sees no device)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: the HIP extension has not been built "

@@ -2,54 +2,54 @@
 //
 // Reference kernel (csrc/kvcompress_eviction_kernels.cu:359-435): 128 threads per
 // (seq,layer), each thread walks whole KVs serially and copies 2-byte elements one at a
-// time at a 32 B stride.  This file restates the job around the memory system instead:
+// time at a 32 B stride.  Measured on MI355X (tools/gather_bw.hip): randomly placed
+// chunks copy at full HBM speed only from 128 B upward; 16 B chunks reach a tenth of it.
+// A KV slot is 16 B pieces in K ([hd*e/16 rows][bs slots][16 B]) and single elements in V
+// ([hd rows][bs slots * e B]), so ANY slot-granular copy is in the slow regime.  This
+// file therefore never touches HBM in less than 1 KiB per wave instruction:
 //
-//   K block  [hd*e/16 rows][bs slots][16 B]   -> a slot is hd*e/16 chunks of 16 B
-//   V block  [hd rows][bs slots * e B]        -> a slot is ONE element in each of hd rows
+//   * the unit of work is a "run": the consecutive moves of one head into ONE destination
+//     block (<= bs moves).  One 64-lane wave owns a run.  It streams the whole K and V
+//     destination block into registers (lane l holds the 16 B pieces l, l+64, ... of the
+//     block image -> perfectly contiguous 1 KiB per load), streams each source block the
+//     run reads the same way, patches the moved slots register-to-register, and streams
+//     the destination block back.
+//   * V: a slot is one element of every row; rows are RB = bs*e bytes, i.e. RB/16 lanes
+//     per row.  The element is extracted from the source piece (scalar-selected dword),
+//     handed to the lane that owns the destination piece with a DPP quad permute and
+//     inserted with one v_bfi.
+//   * K: a slot is one whole 16 B piece per K row; the piece moves between lanes of the
+//     same bs-lane group (ds_bpermute with a uniform source lane).
+//   * slot numbers are wave-uniform (v_readlane), all control flow is scalar.
 //
-// V is the hostile half: a token's 128 values sit in 128 different 32 B sectors, so any
-// move touches every sector of both its source and destination block.  The fast path
-// therefore works on whole V rows: the workgroup has one thread per V row; a thread
-// loads its row of the destination block once (wide loads), patches in the elements of
-// every move that targets that block from the matching row of the source block(s)
-// (again wide loads; consecutive moves share source blocks), and writes the row back
-// once.  The slot indices are wave-uniform, so the element extract/insert runs on
-// scalar-selected registers, no LDS, no barriers.  K is copied as independent 16 B
-// chunks with consecutive lanes on consecutive moves.
+// Rewriting whole blocks needs the wave to be the only writer of that block.  A planning
+// pass counts the runs that target each physical block (one byte per block, zeroed per
+// call); a run takes the block path only if it is the sole claimant -- always the case for
+// schedules produced by A5 (ascending dst, a block belongs to one head).  Any other run
+// (unsorted lists, blocks shared between heads) is copied slot-wise with 16 B / element
+// accesses, which is correct for every independent move list, the only case the
+// reference defines (kvcompress_eviction_kernels.cu:358).
 //
-// Work distribution: a tile is KVC_TM consecutive moves of one head.  Two tiny planning
-// kernels (per-head monotonicity check + exclusive scan of tile counts) run first so
-// that a fixed persistent grid can walk the tiles without any host synchronisation
-// (move counts live in device memory).  The row-wise V path needs all moves into one
-// destination block to be handled by one workgroup: that holds when a head's dst slots
-// are strictly ascending (always true for schedules produced by A5); a head that fails
-// the check falls back to element-wise copies, which are correct for any independent
-// move list.
+// Work distribution: a tile is KVC_TM consecutive moves of one head; a wave handles, in
+// order, the runs that START in its tile.  Move counts live in device memory, so
+// tiny planning kernels (tiles per head, exclusive scan, claims) let a fixed persistent
+// grid walk the tiles without host synchronisation.
 #include "kvc_common.h"
 #include "../../include/kvc_mi355x.h"
 
 namespace kvc {
 
-constexpr int KVC_TM = 32;            // moves per tile
+constexpr int KVC_TM = 32;            // moves per tile (one tile per wave)
+
+// native 16 B vector: HIP's uint4 is a struct whose copies lower to memcpy through a
+// private alloca, which the compiler then parks in LDS
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------- planning
-// one wave per head: flag[g] = dst strictly ascending, tiles[g] = ceil(cnt/TM)
-__global__ __launch_bounds__(256) void compact_plan_heads_kernel(
-    int32_t* __restrict__ flags, int32_t* __restrict__ tiles,
-    const int32_t* __restrict__ moves, const int32_t* __restrict__ count,
-    const int32_t* __restrict__ offs, int G) {
-  const int g = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
-  if (g >= G) return;
-  const int lane = lane_id();
-  const int cnt = count[g];
-  const int2* mv = reinterpret_cast<const int2*>(moves) + offs[g];
-  bool ok = true;
-  for (int j = lane; j + 1 < cnt; j += WAVE) ok &= mv[j].x < mv[j + 1].x;
-  const bool all_ok = __all(ok);
-  if (lane == 0) {
-    flags[g] = all_ok ? 1 : 0;
-    tiles[g] = (cnt + KVC_TM - 1) / KVC_TM;
-  }
+__global__ __launch_bounds__(256) void compact_plan_tiles_kernel(int32_t* __restrict__ tiles,
+                                                                 const int32_t* __restrict__ count, int G) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < G) tiles[g] = (count[g] + KVC_TM - 1) / KVC_TM;
 }
 
 // single workgroup: in-place exclusive scan of tiles[0..G) -> prefix[0..G]
@@ -76,136 +76,218 @@ __global__ __launch_bounds__(1024) void compact_plan_scan_kernel(int32_t* __rest
   if (tid == 0) tiles[G] = (int32_t)carry_s;
 }
 
-// ------------------------------------------------------------------------- fast path
-template <int NW>
-struct Row { uint32_t w[NW]; };
-
-template <int NW>
-__device__ __forceinline__ Row<NW> load_row(const uint8_t* p) {
-  Row<NW> r;
-  if constexpr (NW % 4 == 0) {
-#pragma unroll
-    for (int i = 0; i < NW / 4; ++i) {
-      const uint4 q = reinterpret_cast<const uint4*>(p)[i];
-      r.w[4 * i] = q.x; r.w[4 * i + 1] = q.y; r.w[4 * i + 2] = q.z; r.w[4 * i + 3] = q.w;
+// one wave per tile: every run start claims its destination block
+// (claims: 4 one-byte counters per word; a block has at most bs <= 255 claimants)
+__global__ __launch_bounds__(256) void compact_plan_claims_kernel(
+    uint32_t* __restrict__ claims, const int32_t* __restrict__ moves,
+    const int32_t* __restrict__ count, const int32_t* __restrict__ offs,
+    const int32_t* __restrict__ tile_prefix, int G, int bs) {
+  const int total_tiles = tile_prefix[G];
+  const int lane = lane_id();
+  const int nw = gridDim.x * (blockDim.x / WAVE);
+  for (int t = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE; t < total_tiles; t += nw) {
+    const int g = upper_bound_minus1(tile_prefix, G, t);
+    const int cnt = count[g];
+    const int j = (t - tile_prefix[g]) * KVC_TM + lane;
+    const int2* mv = reinterpret_cast<const int2*>(moves) + offs[g];
+    if (lane < KVC_TM && j < cnt) {
+      const int dblk = mv[j].x / bs;
+      if (j == 0 || mv[j - 1].x / bs != dblk) atomicAdd(&claims[dblk >> 2], 1u << (8 * (dblk & 3)));
     }
-  } else {
-#pragma unroll
-    for (int i = 0; i < NW; ++i) r.w[i] = reinterpret_cast<const uint32_t*>(p)[i];
   }
+}
+
+// ------------------------------------------------------------------------- block path
+// DPP quad permute with a compile-time pattern
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_quad(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+
+// broadcast, inside every group of PR lanes, the value held by the group's lane `hs`
+// (hs wave-uniform, PR in {1,2,4})
+template <int PR>
+__device__ __forceinline__ uint32_t group_bcast(uint32_t v, int hs) {
+  if constexpr (PR == 1) return v;
+  if constexpr (PR == 2) return hs == 0 ? dpp_quad<0xA0>(v) : dpp_quad<0xF5>(v);   // [0,0,2,2] / [1,1,3,3]
+  if constexpr (PR == 4) {
+    switch (hs) {
+      case 0: return dpp_quad<0x00>(v);
+      case 1: return dpp_quad<0x55>(v);
+      case 2: return dpp_quad<0xAA>(v);
+      default: return dpp_quad<0xFF>(v);
+    }
+  }
+  return v;
+}
+
+__device__ __forceinline__ uint32_t pick_dword(const u32x4& q, int w) {   // w wave-uniform
+  uint32_t r = q.x;
+  r = (w == 1) ? q.y : r;
+  r = (w == 2) ? q.z : r;
+  r = (w == 3) ? q.w : r;
   return r;
 }
 
-template <int NW>
-__device__ __forceinline__ void store_row(uint8_t* p, const Row<NW>& r) {
-  if constexpr (NW % 4 == 0) {
+// v_bfi_b32: (mask & a) | (~mask & b)
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
+  return (mask & a) | (~mask & b);
+}
+
+// NPL = 16 B pieces per lane of one block image; BS = block size; E = element bytes
+template <int NPL>
+struct BlockImg { u32x4 p[NPL]; };
+
+template <int NPL>
+__device__ __forceinline__ void img_load(BlockImg<NPL>& b, const uint8_t* base, int lane) {
 #pragma unroll
-    for (int i = 0; i < NW / 4; ++i)
-      reinterpret_cast<uint4*>(p)[i] = make_uint4(r.w[4 * i], r.w[4 * i + 1], r.w[4 * i + 2], r.w[4 * i + 3]);
-  } else {
+  for (int i = 0; i < NPL; ++i) b.p[i] = *reinterpret_cast<const u32x4*>(base + ((int64_t)i * 64 + lane) * 16);
+}
+template <int NPL>
+__device__ __forceinline__ void img_store(const BlockImg<NPL>& b, uint8_t* base, int lane) {
 #pragma unroll
-    for (int i = 0; i < NW; ++i) reinterpret_cast<uint32_t*>(p)[i] = r.w[i];
+  for (int i = 0; i < NPL; ++i) *reinterpret_cast<u32x4*>(base + ((int64_t)i * 64 + lane) * 16) = b.p[i];
+}
+
+// V: move slot `so` of the source block image to slot `dsl` of the destination image
+template <int NPL, int BS, int E>
+__device__ __forceinline__ void apply_v(BlockImg<NPL>& d, const BlockImg<NPL>& s, int so, int dsl, int lane) {
+  constexpr int RB = BS * E;          // bytes per V row
+  constexpr int PR = RB / 16;         // pieces (lanes) per row
+  constexpr int EP = 16 / E;          // elements per piece
+  constexpr int PER = 4 / E;          // elements per dword
+  constexpr uint32_t EMASK = E == 4 ? 0xFFFFFFFFu : ((1u << (8 * E)) - 1u);
+  const int hs = so / EP, es = so % EP, hd_ = dsl / EP, ed = dsl % EP;
+  const int ws = es / PER, shs = (es % PER) * 8 * E;
+  const int wd = ed / PER, shd = (ed % PER) * 8 * E;
+  const bool mine = (lane & (PR - 1)) == hd_;
+  const uint32_t lmask = mine ? (EMASK << shd) : 0u;        // per-lane insert mask
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    uint32_t val = (pick_dword(s.p[i], ws) >> shs) & EMASK;
+    val = group_bcast<PR>(val, hs) << shd;
+    if (wd == 0) d.p[i].x = bfi(lmask, val, d.p[i].x);
+    else if (wd == 1) d.p[i].y = bfi(lmask, val, d.p[i].y);
+    else if (wd == 2) d.p[i].z = bfi(lmask, val, d.p[i].z);
+    else d.p[i].w = bfi(lmask, val, d.p[i].w);
   }
 }
 
-// element `slot` (wave-uniform) of a row held in registers; E = element bytes
-template <int NW, int E>
-__device__ __forceinline__ uint32_t row_extract(const Row<NW>& r, int slot) {
-  constexpr int PER = 4 / E;                   // elements per dword
-  const int wi = slot / PER;
-  uint32_t w = r.w[0];
+// K: piece index = row*BS + slot, so a slot's pieces sit in lanes with (lane % BS) == slot
+// (BS <= 64, power of two).  Move whole 16 B pieces between lanes of the same BS-lane group.
+template <int NPL, int BS>
+__device__ __forceinline__ void apply_k(BlockImg<NPL>& d, const BlockImg<NPL>& s, int so, int dsl, int lane) {
+  const int src_lane4 = ((lane & ~(BS - 1)) | so) * 4;
+  const bool mine = (lane & (BS - 1)) == dsl;
 #pragma unroll
-  for (int i = 1; i < NW; ++i) w = (wi == i) ? r.w[i] : w;   // scalar-conditioned selects
-  if constexpr (E == 4) return w;
-  const int sh = (slot % PER) * (8 * E);
-  return (w >> sh) & ((1u << (8 * E)) - 1u);
-}
-
-template <int NW, int E>
-__device__ __forceinline__ void row_insert(Row<NW>& r, int slot, uint32_t val) {
-  constexpr int PER = 4 / E;
-  const int wi = slot / PER;
-  if constexpr (E == 4) {
-#pragma unroll
-    for (int i = 0; i < NW; ++i) r.w[i] = (wi == i) ? val : r.w[i];
-  } else {
-    const int sh = (slot % PER) * (8 * E);
-    const uint32_t mask = ((1u << (8 * E)) - 1u) << sh;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) r.w[i] = (wi == i) ? ((r.w[i] & ~mask) | (val << sh)) : r.w[i];
+  for (int i = 0; i < NPL; ++i) {
+    const uint32_t x = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)s.p[i].x);
+    const uint32_t y = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)s.p[i].y);
+    const uint32_t z = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)s.p[i].z);
+    const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)s.p[i].w);
+    d.p[i].x = mine ? x : d.p[i].x;
+    d.p[i].y = mine ? y : d.p[i].y;
+    d.p[i].z = mine ? z : d.p[i].z;
+    d.p[i].w = mine ? w : d.p[i].w;
   }
 }
 
-// HD = head size = V rows per block = threads per workgroup; BS = block size; E = elem bytes
+// HD = head size, BS = block size, E = element bytes.  256 threads = 4 independent waves,
+// every wave owns its own tile of KVC_TM consecutive moves and handles the runs that START
+// in it, in order, so a source block that feeds two consecutive runs is fetched once.
 template <int HD, int BS, int E>
-__global__ __launch_bounds__(HD) void compact_rows_kernel(
+__global__ __launch_bounds__(256) void compact_runs_kernel(
     uint8_t* __restrict__ k_cache, uint8_t* __restrict__ v_cache, float* __restrict__ metrics,
     int32_t* __restrict__ positions, const int32_t* __restrict__ moves,
     const int32_t* __restrict__ count, const int32_t* __restrict__ offs,
-    const int32_t* __restrict__ flags, const int32_t* __restrict__ tile_prefix, int G) {
-  constexpr int RB = BS * E;                   // bytes per V row
-  constexpr int NW = RB / 4;                   // dwords per V row
-  constexpr int KR = HD * E / 16;              // 16 B chunk rows per K block
+    const uint32_t* __restrict__ claims, const int32_t* __restrict__ tile_prefix, int G,
+    int phases) {
+  static_assert(BS <= 32 && (BS & (BS - 1)) == 0, "block size must be a power of two <= 32");
+  static_assert(KVC_TM + BS <= 64, "tile + look-ahead + look-behind must fit one wave");
   constexpr int64_t BLOCK_BYTES = (int64_t)HD * BS * E;
-  const int tid = threadIdx.x;
+  constexpr int NPL = (int)(BLOCK_BYTES / 16 / 64);          // 16 B pieces per lane
+  static_assert(BLOCK_BYTES % (16 * 64) == 0, "block image must be a multiple of 1 KiB");
+  constexpr int KR = HD * E / 16;                            // K rows (16 B pieces per slot)
+  constexpr int RB = BS * E;
+  const int lane = threadIdx.x & 63;
   const int total_tiles = tile_prefix[G];
-  for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+  const int nw = gridDim.x * (blockDim.x / WAVE);
+  for (int t = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x >> 6); t < total_tiles; t += nw) {
     const int g = upper_bound_minus1(tile_prefix, G, t);
     const int cnt = count[g];
     const int j0 = (t - tile_prefix[g]) * KVC_TM;
     const int j1 = min(cnt, j0 + KVC_TM);
     const int2* __restrict__ mv = reinterpret_cast<const int2*>(moves) + offs[g];
-    const bool rows_ok = flags[g] != 0;
+    // one move per lane: lane q <-> move jbase + q (one look-behind, BS-1 look-ahead)
+    const int jbase = j0 - 1;
+    int mvx = -1, mvy = -1;
+    {
+      const int q = jbase + lane;
+      if (q >= 0 && q < cnt) { const int2 m = mv[q]; mvx = m.x; mvy = m.y; }
+    }
+    auto MX = [&](int j) { return __builtin_amdgcn_readlane(mvx, j - jbase); };
+    auto MY = [&](int j) { return __builtin_amdgcn_readlane(mvy, j - jbase); };
+    // run starts inside the tile
+    const int myblk = mvx >= 0 ? mvx / BS : -2;
+    const int left = __shfl_up(myblk, 1, 64);
+    const int jl = jbase + lane;
+    unsigned long long starts = __ballot(jl >= j0 && jl < j1 && (jl == 0 || myblk != left));
 
-    // ---- metrics + positions: one lane per move ---------------------------------
-    for (int j = j0 + tid; j < j1; j += HD) {
-      const int2 m = mv[j];
-      metrics[m.x] = metrics[m.y];
-      positions[m.x] = positions[m.y];
-    }
-    // ---- K: independent 16 B chunks, consecutive lanes = consecutive moves ------
-    for (int idx = tid; idx < KVC_TM * KR; idx += HD) {
-      const int m = idx % KVC_TM, r = idx / KVC_TM;
-      if (j0 + m < j1) {
-        const int2 mm = mv[j0 + m];
-        const int64_t so = ((int64_t)(mm.y / BS) * KR + r) * (BS * 16) + (mm.y % BS) * 16;
-        const int64_t dof = ((int64_t)(mm.x / BS) * KR + r) * (BS * 16) + (mm.x % BS) * 16;
-        *reinterpret_cast<uint4*>(k_cache + dof) = *reinterpret_cast<const uint4*>(k_cache + so);
-      }
-    }
-    // ---- V ------------------------------------------------------------------------
-    if (rows_ok) {
-      // a run = the moves into one destination block; it belongs to the tile that holds
-      // its first move.  All indices below are wave-uniform.
-      for (int j = j0; j < j1; ++j) {
-        const int dslot = mv[j].x;
-        const int dblk = dslot / BS;
-        if (j > 0 && mv[j - 1].x / BS == dblk) continue;          // not a run start
-        uint8_t* drow_p = v_cache + (int64_t)dblk * BLOCK_BYTES + (int64_t)tid * RB;
-        Row<NW> drow = load_row<NW>(drow_p);
-        int cur_sblk = -1;
-        Row<NW> srow;
-        for (int jj = j; jj < cnt; ++jj) {
-          const int2 m = mv[jj];
-          if (m.x / BS != dblk) break;
-          const int sblk = m.y / BS;
+    BlockImg<NPL> kd, vd, ks, vs;
+    float md = 0.f, ms = 0.f;
+    int pd = 0, ps = 0;
+    int cur_sblk = -1;                                        // source block held in ks/vs/ms/ps
+    while (starts) {
+      const int jr = jbase + __ffsll((long long)starts) - 1;  // first move of the run
+      starts &= starts - 1;
+      const int dblk = MX(jr) / BS;
+      int je = jr + 1;                                        // run end (exclusive)
+      while (je < cnt && je - jbase < 64 && MX(je) / BS == dblk) ++je;
+      const bool sole = ((claims[dblk >> 2] >> (8 * (dblk & 3))) & 0xFFu) == 1u;
+      uint8_t* kd_p = k_cache + (int64_t)dblk * BLOCK_BYTES;
+      uint8_t* vd_p = v_cache + (int64_t)dblk * BLOCK_BYTES;
+      if (sole) {
+        if (phases & 2) img_load<NPL>(kd, kd_p, lane);
+        if (phases & 4) img_load<NPL>(vd, vd_p, lane);
+        if ((phases & 1) && lane < BS) { md = metrics[(int64_t)dblk * BS + lane]; pd = positions[(int64_t)dblk * BS + lane]; }
+        for (int j = jr; j < je; ++j) {
+          const int sy = MY(j), sblk = sy / BS;
           if (sblk != cur_sblk) {
-            srow = load_row<NW>(v_cache + (int64_t)sblk * BLOCK_BYTES + (int64_t)tid * RB);
+            if (phases & 2) img_load<NPL>(ks, k_cache + (int64_t)sblk * BLOCK_BYTES, lane);
+            if (phases & 4) img_load<NPL>(vs, v_cache + (int64_t)sblk * BLOCK_BYTES, lane);
+            if ((phases & 1) && lane < BS) { ms = metrics[(int64_t)sblk * BS + lane]; ps = positions[(int64_t)sblk * BS + lane]; }
             cur_sblk = sblk;
           }
-          row_insert<NW, E>(drow, m.x % BS, row_extract<NW, E>(srow, m.y % BS));
+          const int so = sy % BS, dsl = MX(j) % BS;
+          if (phases & 2) apply_k<NPL, BS>(kd, ks, so, dsl, lane);
+          if (phases & 4) apply_v<NPL, BS, E>(vd, vs, so, dsl, lane);
+          if (phases & 1) {
+            const int mval = __builtin_amdgcn_readlane(__builtin_bit_cast(int, ms), so);
+            const int pval = __builtin_amdgcn_readlane(ps, so);
+            md = lane == dsl ? __builtin_bit_cast(float, mval) : md;
+            pd = lane == dsl ? pval : pd;
+          }
         }
-        store_row<NW>(drow_p, drow);
-      }
-    } else {
-      // element-wise fallback: correct for any independent move list
-      for (int j = j0; j < j1; ++j) {
-        const int2 m = mv[j];
-        const int64_t so = (int64_t)(m.y / BS) * BLOCK_BYTES + (int64_t)tid * RB + (m.y % BS) * E;
-        const int64_t dof = (int64_t)(m.x / BS) * BLOCK_BYTES + (int64_t)tid * RB + (m.x % BS) * E;
-        if constexpr (E == 1) v_cache[dof] = v_cache[so];
-        else if constexpr (E == 2) *reinterpret_cast<uint16_t*>(v_cache + dof) = *reinterpret_cast<const uint16_t*>(v_cache + so);
-        else *reinterpret_cast<uint32_t*>(v_cache + dof) = *reinterpret_cast<const uint32_t*>(v_cache + so);
+        if (phases & 2) img_store<NPL>(kd, kd_p, lane);
+        if (phases & 4) img_store<NPL>(vd, vd_p, lane);
+        if ((phases & 1) && lane < BS) { metrics[(int64_t)dblk * BS + lane] = md; positions[(int64_t)dblk * BS + lane] = pd; }
+      } else {
+        // shared destination block: slot-wise, correct for any independent move list
+        for (int j = jr; j < je; ++j) {
+          const int sy = MY(j), dx = MX(j);
+          const int64_t sb = (int64_t)(sy / BS) * BLOCK_BYTES, db = (int64_t)dblk * BLOCK_BYTES;
+          if (lane == 0) { metrics[dx] = metrics[sy]; positions[dx] = positions[sy]; }
+          for (int r = lane; r < KR; r += 64)
+            *reinterpret_cast<u32x4*>(k_cache + db + ((int64_t)r * BS + dx % BS) * 16) =
+                *reinterpret_cast<const u32x4*>(k_cache + sb + ((int64_t)r * BS + sy % BS) * 16);
+          for (int dd = lane; dd < HD; dd += 64) {
+            const int64_t so = sb + (int64_t)dd * RB + (sy % BS) * E;
+            const int64_t dof = db + (int64_t)dd * RB + (dx % BS) * E;
+            if constexpr (E == 1) v_cache[dof] = v_cache[so];
+            else if constexpr (E == 2) *reinterpret_cast<uint16_t*>(v_cache + dof) = *reinterpret_cast<const uint16_t*>(v_cache + so);
+            else *reinterpret_cast<uint32_t*>(v_cache + dof) = *reinterpret_cast<const uint32_t*>(v_cache + so);
+          }
+        }
       }
     }
   }
@@ -257,8 +339,14 @@ __global__ __launch_bounds__(256) void compact_generic_kernel(
 
 }  // namespace kvc
 
-extern "C" size_t kvc_execute_cache_moves_workspace_bytes(int32_t total_heads) {
-  return (size_t)(2 * (int64_t)total_heads + 2) * sizeof(int32_t);
+// profiling hook (not part of the drop-in surface): bit0 metrics/positions, bit1 K, bit2 V
+static int g_compact_phases = 7;
+extern "C" void kvc_debug_set_compact_phases(int phases) { g_compact_phases = phases; }
+
+static size_t claims_bytes(int64_t num_blocks) { return (size_t)((num_blocks + 3) / 4 + 1) * 4; }
+
+extern "C" size_t kvc_execute_cache_moves_workspace_bytes(int32_t total_heads, int64_t num_blocks) {
+  return (size_t)((int64_t)total_heads + 2) * sizeof(int32_t) + claims_bytes(num_blocks);
 }
 
 extern "C" int kvc_execute_cache_moves(void* k_cache, void* v_cache, float* kv_metrics,
@@ -270,7 +358,6 @@ extern "C" int kvc_execute_cache_moves(void* k_cache, void* v_cache, float* kv_m
                                        void* workspace, size_t workspace_bytes,
                                        kvc_stream_t stream) {
   using namespace kvc;
-  (void)num_blocks;
   if (block_size < 1) return fail_invalid("Unsupported block size: " + std::to_string(block_size));
   if (head_size < 1) return fail_invalid("Unsupported head size: " + std::to_string(head_size));
   if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4)
@@ -279,33 +366,36 @@ extern "C" int kvc_execute_cache_moves(void* k_cache, void* v_cache, float* kv_m
   if (x < 1 || head_size % x != 0)
     return fail_invalid("Unsupported vec size: " + std::to_string(vec_size));
   if (total_heads <= 0) return KVC_OK;
-  if (workspace_bytes < kvc_execute_cache_moves_workspace_bytes(total_heads))
+  if (workspace_bytes < kvc_execute_cache_moves_workspace_bytes(total_heads, num_blocks))
     return fail_invalid("execute_cache_moves: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  int32_t* flags = reinterpret_cast<int32_t*>(workspace);
-  int32_t* prefix = flags + total_heads;
+  int32_t* prefix = reinterpret_cast<int32_t*>(workspace);
+  uint32_t* claims = reinterpret_cast<uint32_t*>(prefix + total_heads + 2);   // claim bytes
   const int G = total_heads;
-  hipLaunchKernelGGL(compact_plan_heads_kernel, dim3((G + 3) / 4), dim3(256), 0, s, flags, prefix,
-                     cache_moves_idx, cache_moves_count, evicted_kv_offsets, G);
+  const int grid = 256 * 8;     // persistent: 256 CUs x 8 workgroups of 4 independent waves
+  (void)hipMemsetAsync(claims, 0, claims_bytes(num_blocks), s);
+  hipLaunchKernelGGL(compact_plan_tiles_kernel, dim3((G + 255) / 256), dim3(256), 0, s, prefix,
+                     cache_moves_count, G);
   hipLaunchKernelGGL(compact_plan_scan_kernel, dim3(1), dim3(1024), 0, s, prefix, G);
+  hipLaunchKernelGGL(compact_plan_claims_kernel, dim3(grid), dim3(256), 0, s, claims, cache_moves_idx,
+                     cache_moves_count, evicted_kv_offsets, prefix, G, block_size);
   uint8_t* k = reinterpret_cast<uint8_t*>(k_cache);
   uint8_t* v = reinterpret_cast<uint8_t*>(v_cache);
-  const int grid = 256 * 8;     // 256 CUs x 8 resident workgroups, persistent over tiles
-#define KVC_ROWS(HD, BS, E)                                                                      \
-  hipLaunchKernelGGL((compact_rows_kernel<HD, BS, E>), dim3(grid), dim3(HD), 0, s, k, v,         \
+#define KVC_RUNS(HD, BS, E)                                                                      \
+  hipLaunchKernelGGL((compact_runs_kernel<HD, BS, E>), dim3(256 * 4), dim3(256), 0, s, k, v,     \
                      kv_metrics, kv_position, cache_moves_idx, cache_moves_count,                \
-                     evicted_kv_offsets, flags, prefix, G)
+                     evicted_kv_offsets, claims, prefix, G, g_compact_phases)
   bool fast = true;
-  if (x * elem_bytes != 16) fast = false;   // fast path copies K as 16 B chunks
-  else if (head_size == 128 && block_size == 16 && elem_bytes == 2) KVC_ROWS(128, 16, 2);
-  else if (head_size == 128 && block_size == 32 && elem_bytes == 1) KVC_ROWS(128, 32, 1);
-  else if (head_size == 128 && block_size == 32 && elem_bytes == 2) KVC_ROWS(128, 32, 2);
-  else if (head_size == 128 && block_size == 16 && elem_bytes == 1) KVC_ROWS(128, 16, 1);
-  else if (head_size == 128 && block_size == 16 && elem_bytes == 4) KVC_ROWS(128, 16, 4);
-  else if (head_size == 64 && block_size == 16 && elem_bytes == 2) KVC_ROWS(64, 16, 2);
-  else if (head_size == 256 && block_size == 16 && elem_bytes == 2) KVC_ROWS(256, 16, 2);
+  if (x * elem_bytes != 16) fast = false;   // block path assumes 16 B K vectors
+  else if (head_size == 128 && block_size == 16 && elem_bytes == 2) KVC_RUNS(128, 16, 2);
+  else if (head_size == 128 && block_size == 32 && elem_bytes == 1) KVC_RUNS(128, 32, 1);
+  else if (head_size == 128 && block_size == 32 && elem_bytes == 2) KVC_RUNS(128, 32, 2);
+  else if (head_size == 128 && block_size == 16 && elem_bytes == 1) KVC_RUNS(128, 16, 1);
+  else if (head_size == 128 && block_size == 16 && elem_bytes == 4) KVC_RUNS(128, 16, 4);
+  else if (head_size == 64 && block_size == 16 && elem_bytes == 2) KVC_RUNS(64, 16, 2);
+  else if (head_size == 256 && block_size == 16 && elem_bytes == 2) KVC_RUNS(256, 16, 2);
   else fast = false;
-#undef KVC_ROWS
+#undef KVC_RUNS
   if (!fast) {
     hipLaunchKernelGGL(compact_generic_kernel, dim3(grid), dim3(256), 0, s, k, v, kv_metrics,
                        kv_position, cache_moves_idx, cache_moves_count, evicted_kv_offsets, prefix,
