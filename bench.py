@@ -203,19 +203,16 @@ def main():
     s2 = sum(m[1].elapsed_time(m[2]) for m in marks) / args.steps
     s3 = sum(m[2].elapsed_time(m[3]) for m in marks) / args.steps
 
+    # whole-job rate = units of all ranks / slowest rank's time; the only collective of the
+    # path (RCCL all_gather of two scalars per rank)
+    from vllm_kvcompress_amd.harness import dist as hdist
     units_local = float((evicted_slots + moved_slots) * args.steps)
+    red = hdist.reduce_throughput(units_local, elapsed, device=device)
+    units, elapsed = red["units"], red["seconds"]
+    per_rank = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        u = torch.tensor([units_local, float(moved_slots), s3], dtype=torch.float64, device=device)
-        gathered = [torch.zeros_like(u) for _ in range(world)]
-        dist.all_gather(gathered, u)
-        elapsed = float(t.item())
-        units = sum(float(g[0]) for g in gathered)
-        per_rank = [{"moves": int(g[1]), "s3_ms": float(g[2])} for g in gathered]
-    else:
-        units = units_local
-        per_rank = None
+        per_rank = [{"units": u, "seconds": sec} for u, sec in
+                    zip(red["per_rank_units"], red["per_rank_seconds"])]
 
     if rank == 0:
         e = 2

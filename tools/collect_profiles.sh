@@ -1,0 +1,54 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): rocprofv3 kernel stats of the default bench command and,
+# in SEPARATE passes, the FETCH_SIZE / WRITE_SIZE PMC counters (MI355X_MICROARCH.md: TCC
+# has 4 slots, FETCH_SIZE costs 3 and WRITE_SIZE 2 -> one pass each; never mixed with
+# other trace domains).  Summaries land in gpurun_out/profiles_<tag>/ ; copy to profiles/.
+set -u
+TAG="${1:-r1}"
+REPO="${GRAFT_REPO_ROOT:-/root/repo}"
+OUT="$REPO/gpurun_out/profiles_$TAG"
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+BENCH="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" --output-format csv -- $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" --output-format csv -- $BENCH > /dev/null 2> "$OUT/fetch.log"
+timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" --output-format csv -- $BENCH > /dev/null 2> "$OUT/write.log"
+python - "$OUT" "$TAG" <<'PY'
+import csv, glob, json, sys, collections
+out, tag = sys.argv[1], sys.argv[2]
+stats = glob.glob(f"{out}/stats/*/*_kernel_stats.csv")[0]
+rows = list(csv.DictReader(open(stats)))
+with open(f"{out}/{tag}_kernel_stats.csv", "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+    for r in rows:
+        if "kvc::" in r["Name"] or "rocclr" in r["Name"]:
+            w.writerow([r["Name"][:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"],
+                        r["Percentage"], r["MinNs"], r["MaxNs"]])
+def pmc(kind, counter):
+    f = glob.glob(f"{out}/{kind}/*/*_counter_collection.csv")[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+fetch, write = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
+res = {}
+for k in sorted(set(fetch) | set(write)):
+    if "kvc::" not in k:
+        continue
+    fkb, wkb = fetch.get(k, 0.0), write.get(k, 0.0)
+    res[k[:100]] = {"FETCH_SIZE_KB_per_launch": fkb, "WRITE_SIZE_KB_per_launch": wkb,
+                    # gfx950: FETCH_SIZE counts 128 B requests as 64 B for wide coalesced
+                    # streams (MI355X_MICROARCH.md, HBM) -> doubled; WRITE_SIZE as reported
+                    "hbm_bytes_per_launch": (2.0 * fkb + wkb) * 1024.0}
+dom = [k for k in res if "compact_runs_kernel" in k]
+summary = {"tag": tag, "kernels": res}
+if dom:
+    summary["dominant_kernel"] = dom[0]
+    summary["hbm_bytes_per_launch"] = res[dom[0]]["hbm_bytes_per_launch"]
+json.dump(summary, open(f"{out}/{tag}_traffic.json", "w"), indent=1)
+print(json.dumps({k: v for k, v in summary.items() if k != "kernels"}))
+PY
+ls "$OUT"

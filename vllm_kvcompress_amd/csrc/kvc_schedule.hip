@@ -125,10 +125,18 @@ __global__ __launch_bounds__(256) void hist_round_kernel(kvc_schedule_params p, 
     const uint32_t prefix = ws.seq_prefix[i];
     for (int k = threadIdx.x; k < RADIX; k += blockDim.x) sh[k] = 0;
     __syncthreads();
-    for (int64_t idx = t0 + threadIdx.x; idx < t0 + HTILE; idx += blockDim.x) {
-      bool valid = idx < t1;
-      uint32_t key = valid ? ws.keys[idx] : 0u;
-      valid = valid && key < KEY_INF && (round == 0 || (key >> (shift + 8)) == prefix);
+    // all loads of the tile first (independent), then the ballot-heavy histogram updates
+    constexpr int U = HTILE / 256;
+    uint32_t kv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t idx = t0 + threadIdx.x + (int64_t)u * 256;
+      kv[u] = idx < t1 ? ws.keys[idx] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t key = kv[u];
+      const bool valid = key < KEY_INF && (round == 0 || (key >> (shift + 8)) == prefix);
       hist_add(sh, valid, (key >> shift) & 0xFFu);
     }
     __syncthreads();
@@ -169,25 +177,34 @@ __global__ __launch_bounds__(256) void scan_round_kernel(kvc_schedule_params p, 
 }
 
 // ------------------------------------------------------------------ 3. chunks per sequence
-// after round 0's scan: F_i (finite-threshold chunks), Cn_i (all chunks) and from them the
-// number of chunks k'_i each sequence really frees                 metrics.py:704-729
+// after round 0's scan: F_i (finite-threshold chunks) and Cn_i (all chunks) ...
+__global__ __launch_bounds__(256) void seq_totals_kernel(kvc_schedule_params p, SchedWs ws) {
+  __shared__ uint32_t red[2][4];
+  const int B = p.num_seqs, H = p.num_kv_heads, LH = p.num_layers * H, bs = p.block_size;
+  const int i = blockIdx.x;
+  uint32_t f = 0, cn = 0;
+  for (int lh = threadIdx.x; lh < LH; lh += blockDim.x) {
+    const int g = i * LH + lh;
+    f += ws.chunkcnt[(int64_t)g * RADIX + 255];
+    const int ctx = p.context_lens[((lh / H) * B + i) * H + (lh % H)];
+    cn += (uint32_t)((ctx + bs - 1) / bs);
+  }
+  f = wave_reduce_sum(f);
+  cn = wave_reduce_sum(cn);
+  if (lane_id() == 0) { red[0][threadIdx.x / WAVE] = f; red[1][threadIdx.x / WAVE] = cn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ws.seq_tmp[i] = (int32_t)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    ws.seq_tmp[B + i] = (int32_t)(red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+
+// ... and from them the number of chunks k'_i each sequence really frees   metrics.py:704-729
 __global__ __launch_bounds__(1024) void seq_prepare_kernel(kvc_schedule_params p, SchedWs ws) {
-  const int B = p.num_seqs, L = p.num_layers, H = p.num_kv_heads, LH = L * H, bs = p.block_size;
+  const int B = p.num_seqs;
   int32_t* F = ws.seq_tmp;
   int32_t* Cn = ws.seq_tmp + B;
   int32_t* Off = ws.seq_tmp + 2 * B;
-  for (int i = threadIdx.x; i < B; i += blockDim.x) {
-    int64_t f = 0, cn = 0;
-    for (int lh = 0; lh < LH; ++lh) {
-      const int g = i * LH + lh;
-      f += ws.chunkcnt[(int64_t)g * RADIX + 255];
-      const int ctx = p.context_lens[((lh / H) * B + i) * H + (lh % H)];
-      cn += (ctx + bs - 1) / bs;
-    }
-    F[i] = (int32_t)f;
-    Cn[i] = (int32_t)cn;
-  }
-  __syncthreads();
   if (threadIdx.x == 0) {
     int64_t o = 0;
     for (int i = 0; i < B; ++i) { Off[i] = (int32_t)o; o += Cn[i]; }
@@ -228,27 +245,42 @@ __global__ __launch_bounds__(1024) void seq_prepare_kernel(kvc_schedule_params p
 }
 
 // ------------------------------------------------------------------ 4. pick the digit
-// one workgroup (256 threads = 256 digits) per sequence
-__global__ __launch_bounds__(256) void pick_round_kernel(kvc_schedule_params p, SchedWs ws, int round) {
-  __shared__ uint32_t sums[RADIX];
+// one workgroup per sequence: 256 digits x 4 head partitions
+__global__ __launch_bounds__(1024) void pick_round_kernel(kvc_schedule_params p, SchedWs ws, int round) {
+  __shared__ uint32_t part[4][RADIX];
   __shared__ int dstar_s;
   const int i = blockIdx.x;
   const int LH = p.num_layers * p.num_kv_heads;
   const uint32_t k = (uint32_t)ws.seq_k[i];
   if (k == 0) return;
-  const int d = threadIdx.x;
-  uint32_t s = 0;
-  for (int lh = 0; lh < LH; ++lh) s += ws.chunkcnt[((int64_t)i * LH + lh) * RADIX + d];
-  sums[d] = s;
-  if (d == 0) dstar_s = 255;
+  const int d = threadIdx.x & 255, pt = threadIdx.x >> 8;
+  const uint32_t* cc = ws.chunkcnt + (int64_t)i * LH * RADIX + d;
+  uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  int lh = pt;
+  for (; lh + 12 < LH; lh += 16) {
+    s0 += cc[(int64_t)lh * RADIX];
+    s1 += cc[(int64_t)(lh + 4) * RADIX];
+    s2 += cc[(int64_t)(lh + 8) * RADIX];
+    s3 += cc[(int64_t)(lh + 12) * RADIX];
+  }
+  for (; lh < LH; lh += 4) s0 += cc[(int64_t)lh * RADIX];
+  part[pt][d] = s0 + s1 + s2 + s3;
+  if (threadIdx.x == 0) dstar_s = 255;
   __syncthreads();
-  const bool hit = s >= k && (d == 0 || sums[d - 1] < k);      // S is non-decreasing in d
-  if (hit) dstar_s = d;
+  if (pt == 0) {
+    const uint32_t s = part[0][d] + part[1][d] + part[2][d] + part[3][d];
+    part[0][d] = s;
+  }
+  __syncthreads();
+  if (pt == 0) {
+    const uint32_t s = part[0][d];
+    if (s >= k && (d == 0 || part[0][d - 1] < k)) dstar_s = d;     // S is non-decreasing in d
+  }
   __syncthreads();
   const int ds = dstar_s;
-  if (d == 0) ws.seq_prefix[i] = (ws.seq_prefix[i] << 8) | (uint32_t)ds;
-  for (int lh = d; lh < LH; lh += blockDim.x) {
-    const int g = i * LH + lh;
+  if (threadIdx.x == 0) ws.seq_prefix[i] = (ws.seq_prefix[i] << 8) | (uint32_t)ds;
+  for (int h2 = threadIdx.x; h2 < LH; h2 += blockDim.x) {
+    const int g = i * LH + h2;
     const uint32_t* cum = ws.hist + (int64_t)g * RADIX;
     const uint32_t below = ds > 0 ? cum[ds - 1] : 0u;
     ws.less[g] += below;
@@ -327,12 +359,22 @@ __device__ void block_radix_select(uint32_t* hist, uint32_t* bc, int n, uint32_t
     const int shift = 24 - 8 * round;
     for (int k = threadIdx.x; k < RADIX; k += blockDim.x) hist[k] = 0;
     __syncthreads();
-    const int nround = (n + blockDim.x - 1) / blockDim.x * blockDim.x;
-    for (int idx = threadIdx.x; idx < nround; idx += blockDim.x) {
-      bool valid = idx < n && pred(idx);
-      uint32_t v = valid ? val(idx) : 0u;
-      valid = valid && (round == 0 || (v >> (shift + 8)) == prefix);
-      hist_add(hist, valid, (v >> shift) & 0xFFu);
+    constexpr int U = 8;
+    const int step = blockDim.x * U;
+    for (int base = 0; base < n; base += step) {
+      uint32_t vv[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {                 // independent loads first
+        const int idx = base + u * blockDim.x + threadIdx.x;
+        ok[u] = idx < n && pred(idx);
+        vv[u] = ok[u] ? val(idx) : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool valid = ok[u] && (round == 0 || (vv[u] >> (shift + 8)) == prefix);
+        hist_add(hist, valid, (vv[u] >> shift) & 0xFFu);
+      }
     }
     __syncthreads();
     // 256-bin inclusive scan by the first 4 waves' worth of threads (one wave does it)
@@ -363,8 +405,7 @@ __device__ void block_radix_select(uint32_t* hist, uint32_t* bc, int n, uint32_t
 __global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(kvc_schedule_params p, SchedWs ws) {
   __shared__ __attribute__((aligned(16))) uint32_t hist[RADIX];
   __shared__ uint32_t bc[4];
-  __shared__ uint32_t wave_tot[SEL_THREADS / WAVE];
-  __shared__ uint32_t carry_s;
+  __shared__ uint32_t wave_tot[2][SEL_THREADS / WAVE];
   const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
   const int g = blockIdx.x;
   const int bs = p.block_size;
@@ -391,28 +432,34 @@ __global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(kvc_schedule_p
     block_radix_select(hist, bc, n, take, fkey, [&](int idx) { return keys[idx] == M; }, Fstar, r2, e2);
   }
   // emit: flag, block-wide exclusive scan, compact; then pad with null
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  const int nround = (n + blockDim.x - 1) / blockDim.x * blockDim.x;
-  for (int idx0 = 0; idx0 < nround; idx0 += blockDim.x) {
-    const int idx = idx0 + tid;
-    bool sel = false;
-    if (idx < n) {
-      const uint32_t key = keys[idx];
-      sel = key < M || (key == M && (Fstar == 0xFFFFFFFFu || fkey(idx) <= Fstar));
+  uint32_t carry = 0;
+  int buf = 0;
+  constexpr int U = 8;
+  const bool tie_cut = Fstar != 0xFFFFFFFFu;
+  for (int base0 = 0; base0 < n; base0 += SEL_THREADS * U) {
+    uint32_t kk[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {                   // independent loads first
+      const int idx = base0 + u * SEL_THREADS + tid;
+      kk[u] = idx < n ? keys[idx] : 0xFFFFFFFFu;
     }
-    const unsigned long long bal = __ballot(sel);
-    const uint32_t wave_cnt = (uint32_t)__popcll(bal);
-    const uint32_t lane_ex = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_tot[w] = wave_cnt;
-    __syncthreads();
-    uint32_t woff = 0, tot = 0;
-    for (int q = 0; q < SEL_THREADS / WAVE; ++q) { if (q < w) woff += wave_tot[q]; tot += wave_tot[q]; }
-    const uint32_t carry = carry_s;
-    if (sel) out[carry + woff + lane_ex] = idx;        // logical index == position in head
-    __syncthreads();
-    if (tid == 0) carry_s = carry + tot;
-    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base0 + u * SEL_THREADS + tid;
+      if (base0 + u * SEL_THREADS >= n) break;      // uniform
+      bool sel = false;
+      if (idx < n) sel = kk[u] < M || (kk[u] == M && (!tie_cut || fkey(idx) <= Fstar));
+      const unsigned long long bal = __ballot(sel);
+      const uint32_t lane_ex = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) wave_tot[buf][w] = (uint32_t)__popcll(bal);
+      __syncthreads();                              // one barrier per step (double buffer)
+      uint32_t woff = 0, tot = 0;
+#pragma unroll
+      for (int q = 0; q < SEL_THREADS / WAVE; ++q) { const uint32_t c = wave_tot[buf][q]; if (q < w) woff += c; tot += c; }
+      if (sel) out[carry + woff + lane_ex] = idx;   // logical index == position in head
+      carry += tot;
+      buf ^= 1;
+    }
   }
   for (int idx = (int)cnt + tid; idx < n; idx += blockDim.x) out[idx] = p.null_value;
 }
@@ -497,8 +544,11 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     hipMemsetAsync(ws.hist, 0, (size_t)G * RADIX * 4, s);
     hipLaunchKernelGGL(hist_round_kernel, dim3(htiles), dim3(256), 0, s, p, ws, round);
     hipLaunchKernelGGL(scan_round_kernel, dim3((G + 3) / 4), dim3(256), 0, s, p, ws);
-    if (round == 0) hipLaunchKernelGGL(seq_prepare_kernel, dim3(1), dim3(1024), 0, s, p, ws);
-    hipLaunchKernelGGL(pick_round_kernel, dim3(B), dim3(256), 0, s, p, ws, round);
+    if (round == 0) {
+      hipLaunchKernelGGL(seq_totals_kernel, dim3(B), dim3(256), 0, s, p, ws);
+      hipLaunchKernelGGL(seq_prepare_kernel, dim3(1), dim3(1024), 0, s, p, ws);
+    }
+    hipLaunchKernelGGL(pick_round_kernel, dim3(B), dim3(1024), 0, s, p, ws, round);
   }
   hipLaunchKernelGGL(finalize_heads_kernel, dim3(B), dim3(256), 0, s, p, ws);
   hipLaunchKernelGGL(select_emit_kernel, dim3(G), dim3(SEL_THREADS), 0, s, p, ws);
