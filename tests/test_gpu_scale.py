@@ -1,0 +1,162 @@
+"""Full-size checks on the GPU.
+
+* C1 (Llama-3-8B shape, 4k cache, 1 M slots): complete oracle comparison (NumPy schedule +
+  C move/compaction restatement), bit-exact.
+* C2 (32k cache, 8.4 M slots, 4 GiB of K/V): size-independent properties, after the
+  reference's own test (tests/kernels/test_kvcompress_eviction.py:906-924, 1107-1218,
+  1224-1226): freed blocks == requested; per-head evicted indices ascending + padded; no
+  evicted KV is a move source; EVERY surviving KV is bit-equal at its final slot (K/V are
+  filled with a hash of the KV's identity, so the expectation is recomputed from the final
+  position table); final positions are exactly the survivors; and the compaction took the
+  block path for every destination block.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kvc_oracle as orc
+from oracle import kvc_oracle_c as orc_c
+from vllm_kvcompress_amd import _custom_ops as ops
+from vllm_kvcompress_amd.harness import device as hdev
+from vllm_kvcompress_amd.harness import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+L, H, BS, HD = 32, 8, 16, 128
+MAX_INT = 2147483000
+
+
+def _evict(st, keep, T):
+    return [synth.evict_block_count(context_lens_lh=st.context_lens[:, b, :], seq_len=T + 1,
+                                    block_size=BS, protected_window_size=st.protected[b],
+                                    max_cache_tokens=int(T * keep)) for b in range(st.num_seqs)]
+
+
+def test_c1_full_oracle_parity():
+    T = 4096
+    st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=BS, seq_lens=[T + 1], seed=0,
+                          protected=32, spare_block_frac=0.02)
+    evicted = _evict(st, 0.5, T)
+    k_np, v_np = synth.make_caches_u16(0, st.num_blocks, HD, BS)
+    eli, ekc, ebc = orc.schedule_evictions(
+        metrics=st.metrics, token_positions=st.token_positions,
+        seq_index_by_block=st.seq_index_by_block, layer_index_by_block=st.layer_index_by_block,
+        head_index_by_block=st.head_index_by_block,
+        logical_block_num_by_block=st.logical_block_num_by_block, block_size=BS, num_layers=L,
+        num_kv_heads=H, seq_indices=st.seq_indices, seq_positions=st.seq_positions,
+        evicted_blocks_per_seq=evicted, context_lens=st.context_lens,
+        hanging_token_count=st.hanging_token_count, evicted_kv_offsets=st.evicted_kv_offsets,
+        num_protected=st.protected, mode="reference")
+    cmi = np.zeros((st.total_slots, 2), np.int32)
+    cmc = np.zeros(ekc.shape, np.int32)
+    orc_c.schedule_cache_moves(cmi, cmc, eli, ekc, st.evicted_kv_offsets,
+                               np.ascontiguousarray(st.block_tables),
+                               np.ascontiguousarray(st.context_lens), BS)
+    wk, wv = np.ascontiguousarray(k_np.copy()), np.ascontiguousarray(v_np.copy())
+    wm, wp = st.metrics.copy(), st.token_positions.copy()
+    orc_c.execute_cache_moves(wk, wv, wm, wp, cmi, cmc, st.evicted_kv_offsets)
+
+    ds = hdev.upload(st, DEV)
+    g_eli, g_ekc, g_ebc, g_cmi, g_cmc = hdev.schedule(ds, st, evicted)
+    k, v = torch.from_numpy(k_np.copy()).to(DEV), torch.from_numpy(v_np.copy()).to(DEV)
+    ops.execute_cache_moves(k, v, ds.cm.metrics, ds.cm.token_positions, g_cmi, g_cmc,
+                            ds.evicted_kv_offsets, 1, 16)
+    for name, got, want in (("eli", g_eli, eli), ("ekc", g_ekc, ekc), ("ebc", g_ebc, ebc),
+                            ("cmi", g_cmi, cmi), ("cmc", g_cmc, cmc), ("k", k, wk), ("v", v, wv),
+                            ("metrics", ds.cm.metrics, wm), ("positions", ds.cm.token_positions, wp)):
+        assert np.array_equal(got.cpu().numpy(), want), name
+
+
+def _hash16(ids, salt):
+    """int64 ids -> int16 pattern, different for every (id, salt)"""
+    x = (ids * 0x9E3779B97F4A7C1 + salt * 0x85EBCA6B) & 0x7FFFFFFFFFFFFFFF
+    x = x ^ (x >> 29)
+    return ((x >> 7) & 0xFFFF).to(torch.int16)
+
+
+@pytest.mark.parametrize("keep", [0.5, 0.125])
+def test_c2_properties(keep):
+    T = 32768
+    st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=BS, seq_lens=[T + 1], seed=1,
+                          protected=32, spare_block_frac=0.02)
+    evicted = _evict(st, keep, T)
+    NB, N = st.num_blocks, st.total_slots
+    ds = hdev.upload(st, DEV)
+    dev = torch.device(DEV)
+    # identity of the KV in (blk, off): id = off_g + position (position == logical index here)
+    seq_b = ds.cm.seq_index_by_block.long()
+    g_of_blk = (seq_b * L + ds.cm.layer_index_by_block.long()) * H + ds.cm.head_index_by_block.long()
+    offs_flat = ds.evicted_kv_offsets.reshape(-1).long()
+    alloc = seq_b >= 0
+    off_of_blk = torch.where(alloc, offs_flat[g_of_blk.clamp(min=0)], torch.zeros_like(g_of_blk))
+    ids0 = off_of_blk[:, None] + ds.cm.token_positions.long()                      # [NB,bs]
+    k = torch.empty((NB, HD // 8, BS, 8), dtype=torch.int16, device=dev)
+    v = torch.empty((NB, HD, BS), dtype=torch.int16, device=dev)
+    for r in range(HD // 8):
+        for e in range(8):
+            k[:, r, :, e] = _hash16(ids0, 1000 + r * 8 + e)
+    for d in range(HD):
+        v[:, d, :] = _hash16(ids0, 5000 + d)
+    pos0 = ds.cm.token_positions.clone()
+
+    eli, ekc, ebc, cmi, cmc = hdev.schedule(ds, st, evicted)
+    ops.execute_cache_moves(k, v, ds.cm.metrics, ds.cm.token_positions, cmi, cmc,
+                            ds.evicted_kv_offsets, 1, 16)
+    torch.cuda.synchronize()
+
+    # freed blocks == requested
+    assert int(ebc.sum()) == sum(evicted)
+    G = L * H
+    nblk = (ds.context_lens.transpose(0, 1).reshape(-1).long() + BS - 1) // BS
+    seg = eli.view(G, -1)                                                           # equal heads
+    cnt = ekc.reshape(-1).long()
+    ar = torch.arange(seg.shape[1], device=dev)[None, :]
+    live = ar < cnt[:, None]
+    assert bool((seg[~live] == MAX_INT).all())
+    assert bool(((seg[:, 1:] > seg[:, :-1]) | ~live[:, 1:]).all())                  # ascending
+    assert bool(((cnt - ds.hanging_token_count.reshape(-1)) % BS == 0).all())       # test :759
+
+    # moves: no evicted slot is a source, destinations are evicted slots
+    rows = torch.arange(N, device=dev)
+    j = rows - offs_flat.repeat_interleave(nblk * BS)
+    gid = torch.arange(G, device=dev).repeat_interleave(nblk * BS)
+    is_move = j < cmc.reshape(-1).long()[gid]
+    evicted_mask = torch.zeros(NB * BS, dtype=torch.bool, device=dev)
+    bt = ds.block_tables.permute(1, 0, 2, 3).reshape(G, -1).long()                 # [G,M] (B=1)
+    lam = seg[live].long()
+    g_live = torch.arange(G, device=dev)[:, None].expand_as(seg)[live]
+    phys_evicted = bt[g_live, lam // BS] * BS + lam % BS
+    evicted_mask[phys_evicted] = True
+    dst, src = cmi[is_move, 0].long(), cmi[is_move, 1].long()
+    assert not bool(evicted_mask[src].any())
+    assert bool(evicted_mask[dst].all())
+    assert dst.unique().numel() == dst.numel() and src.unique().numel() == src.numel()
+
+    # every surviving KV bit-equal at its final slot
+    new_len = ds.context_lens.transpose(0, 1).reshape(-1).long() - cnt              # [G]
+    lbn = ds.cm.logical_block_num_by_block.long()
+    lam_blk = lbn[:, None] * BS + torch.arange(BS, device=dev)[None, :]
+    live_slot = alloc[:, None] & (lam_blk < new_len[g_of_blk.clamp(min=0)][:, None])
+    ids1 = off_of_blk[:, None] + ds.cm.token_positions.long()
+    for r in range(HD // 8):
+        for e in range(8):
+            assert bool((k[:, r, :, e] == _hash16(ids1, 1000 + r * 8 + e))[live_slot].all()), (r, e)
+    for d in range(HD):
+        assert bool((v[:, d, :] == _hash16(ids1, 5000 + d))[live_slot].all()), d
+    # final live positions are exactly the survivors: distinct per head, none evicted
+    was_evicted_pos = torch.zeros(N, dtype=torch.bool, device=dev)
+    was_evicted_pos[offs_flat[g_live] + lam] = True                                # position == lambda
+    final_ids = ids1[live_slot]
+    assert final_ids.unique().numel() == final_ids.numel()
+    assert not bool(was_evicted_pos[final_ids].any())
+    assert final_ids.numel() == int((ds.context_lens.long().sum() - cnt.sum()))
+    # untouched slots keep their position
+    moved_dst = torch.zeros(NB * BS, dtype=torch.bool, device=dev)
+    moved_dst[dst] = True
+    assert bool((ds.cm.token_positions.reshape(-1)[~moved_dst] == pos0.reshape(-1)[~moved_dst]).all())
+
+    # the block (fast) path was taken for every destination block
+    ws = ops._WORKSPACES[(0, "execute_cache_moves")]
+    claims = ws[(G + 2) * 4:(G + 2) * 4 + NB]
+    assert int(claims.max()) == 1
+    assert int((claims == 1).sum()) == (dst // BS).unique().numel()

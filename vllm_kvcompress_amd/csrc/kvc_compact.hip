@@ -175,20 +175,61 @@ __device__ __forceinline__ void apply_v(BlockImg<NPL>& d, const BlockImg<NPL>& s
 
 // K: piece index = row*BS + slot, so a slot's pieces sit in lanes with (lane % BS) == slot
 // (BS <= 64, power of two).  Move whole 16 B pieces between lanes of the same BS-lane group.
-template <int NPL, int BS>
-__device__ __forceinline__ void apply_k(BlockImg<NPL>& d, const BlockImg<NPL>& s, int so, int dsl, int lane) {
-  const int src_lane4 = ((lane & ~(BS - 1)) | so) * 4;
-  const bool mine = (lane & (BS - 1)) == dsl;
+template <int N>
+__device__ __forceinline__ uint32_t dpp_row_ror(uint32_t v) {       // lane l <- lane (l - N) mod 16
+  if constexpr (N == 0) return v;
+  else return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + N, 0xf, 0xf, false);
+}
+
+template <int NPL, int N>
+__device__ __forceinline__ void apply_k_ror(BlockImg<NPL>& d, const BlockImg<NPL>& s, bool mine) {
 #pragma unroll
   for (int i = 0; i < NPL; ++i) {
-    const uint32_t x = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)s.p[i].x);
-    const uint32_t y = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)s.p[i].y);
-    const uint32_t z = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)s.p[i].z);
-    const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)s.p[i].w);
+    const uint32_t x = dpp_row_ror<N>(s.p[i].x), y = dpp_row_ror<N>(s.p[i].y);
+    const uint32_t z = dpp_row_ror<N>(s.p[i].z), w = dpp_row_ror<N>(s.p[i].w);
     d.p[i].x = mine ? x : d.p[i].x;
     d.p[i].y = mine ? y : d.p[i].y;
     d.p[i].z = mine ? z : d.p[i].z;
     d.p[i].w = mine ? w : d.p[i].w;
+  }
+}
+
+template <int NPL, int BS>
+__device__ __forceinline__ void apply_k(BlockImg<NPL>& d, const BlockImg<NPL>& s, int so, int dsl, int lane) {
+  const bool mine = (lane & (BS - 1)) == dsl;
+  if constexpr (BS == 16) {
+    // a 16-lane DPP row is exactly one K row: rotate so that lane dsl receives lane so
+    switch ((dsl - so) & 15) {               // wave-uniform
+      case 0: apply_k_ror<NPL, 0>(d, s, mine); break;
+      case 1: apply_k_ror<NPL, 1>(d, s, mine); break;
+      case 2: apply_k_ror<NPL, 2>(d, s, mine); break;
+      case 3: apply_k_ror<NPL, 3>(d, s, mine); break;
+      case 4: apply_k_ror<NPL, 4>(d, s, mine); break;
+      case 5: apply_k_ror<NPL, 5>(d, s, mine); break;
+      case 6: apply_k_ror<NPL, 6>(d, s, mine); break;
+      case 7: apply_k_ror<NPL, 7>(d, s, mine); break;
+      case 8: apply_k_ror<NPL, 8>(d, s, mine); break;
+      case 9: apply_k_ror<NPL, 9>(d, s, mine); break;
+      case 10: apply_k_ror<NPL, 10>(d, s, mine); break;
+      case 11: apply_k_ror<NPL, 11>(d, s, mine); break;
+      case 12: apply_k_ror<NPL, 12>(d, s, mine); break;
+      case 13: apply_k_ror<NPL, 13>(d, s, mine); break;
+      case 14: apply_k_ror<NPL, 14>(d, s, mine); break;
+      default: apply_k_ror<NPL, 15>(d, s, mine); break;
+    }
+  } else {
+    const int src_lane4 = ((lane & ~(BS - 1)) | so) * 4;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const uint32_t x = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)s.p[i].x);
+      const uint32_t y = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)s.p[i].y);
+      const uint32_t z = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)s.p[i].z);
+      const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)s.p[i].w);
+      d.p[i].x = mine ? x : d.p[i].x;
+      d.p[i].y = mine ? y : d.p[i].y;
+      d.p[i].z = mine ? z : d.p[i].z;
+      d.p[i].w = mine ? w : d.p[i].w;
+    }
   }
 }
 
@@ -247,9 +288,14 @@ __global__ __launch_bounds__(256) void compact_runs_kernel(
       uint8_t* kd_p = k_cache + (int64_t)dblk * BLOCK_BYTES;
       uint8_t* vd_p = v_cache + (int64_t)dblk * BLOCK_BYTES;
       if (sole) {
-        if (phases & 2) img_load<NPL>(kd, kd_p, lane);
-        if (phases & 4) img_load<NPL>(vd, vd_p, lane);
-        if ((phases & 1) && lane < BS) { md = metrics[(int64_t)dblk * BS + lane]; pd = positions[(int64_t)dblk * BS + lane]; }
+        // a run that overwrites all BS slots (distinct dst slots of one block) leaves nothing
+        // of the old block alive: no read-modify-write, the block is only written
+        const bool full = (je - jr) == BS;
+        if (!full) {
+          if (phases & 2) img_load<NPL>(kd, kd_p, lane);
+          if (phases & 4) img_load<NPL>(vd, vd_p, lane);
+          if ((phases & 1) && lane < BS) { md = metrics[(int64_t)dblk * BS + lane]; pd = positions[(int64_t)dblk * BS + lane]; }
+        }
         for (int j = jr; j < je; ++j) {
           const int sy = MY(j), sblk = sy / BS;
           if (sblk != cur_sblk) {
