@@ -66,7 +66,15 @@ __global__ __launch_bounds__(256) void epilogue_colsum_kernel(float* __restrict_
   qmin = qmin < 0 ? 0 : qmin;
   const float* col = probs + ((int64_t)h * qb) * K + k;
   float acc = 0.0f;
-  for (int q = qmin; q < qb; ++q) {
+  int q = qmin;
+  for (; q + 8 <= qb; q += 8) {                  // 8 independent loads in flight, summed in order
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = col[(int64_t)(q + u) * K];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __fadd_rn(acc, use_l2 ? __fmul_rn(t[u], t[u]) : t[u]);
+  }
+  for (; q < qb; ++q) {
     float v = col[(int64_t)q * K];
     if (use_l2) v = __fmul_rn(v, v);
     acc = __fadd_rn(acc, v);

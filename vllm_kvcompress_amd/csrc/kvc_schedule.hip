@@ -35,7 +35,8 @@ constexpr int RADIX = 256;
 struct SchedWs {
   uint32_t* keys;        // [N]      order-preserving metric keys, index off_g + lambda
   int32_t* chunk_phys;   // [N/bs]   physical block of logical chunk
-  uint32_t* hist;        // [G,256]  per-head digit histogram -> inclusive cumulative
+  uint32_t* hist;        // [G,256]  per-head digit histogram (re-zeroed by scan_round)
+  uint32_t* cum;         // [G,256]  inclusive cumulative counts of the current round
   uint32_t* chunkcnt;    // [G,256]  chunks freed if the digit were d
   uint32_t* less;        // [G]      keys strictly below the current prefix
   uint32_t* eq;          // [G]      keys equal to T* (after the last round)
@@ -164,11 +165,12 @@ __global__ __launch_bounds__(256) void scan_round_kernel(kvc_schedule_params p, 
   const int lane = lane_id();
   uint32_t* h = ws.hist + (int64_t)g * RADIX;
   uint4 v = reinterpret_cast<uint4*>(h)[lane];            // 4 bins per lane
+  reinterpret_cast<uint4*>(h)[lane] = make_uint4(0u, 0u, 0u, 0u);   // ready for the next round
   v.y += v.x; v.z += v.y; v.w += v.z;
   const uint32_t inc = wave_inclusive_scan(v.w);
   const uint32_t ex = inc - v.w;
   v.x += ex; v.y += ex; v.z += ex; v.w += ex;
-  reinterpret_cast<uint4*>(h)[lane] = v;
+  reinterpret_cast<uint4*>(ws.cum + (int64_t)g * RADIX)[lane] = v;
   const uint32_t less = ws.less[g], hang = (uint32_t)p.hanging_token_count[g], bs = (uint32_t)p.block_size;
   uint4 c;
   c.x = nchunks_freed(less + v.x, hang, bs); c.y = nchunks_freed(less + v.y, hang, bs);
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(1024) void pick_round_kernel(kvc_schedule_params p,
   if (threadIdx.x == 0) ws.seq_prefix[i] = (ws.seq_prefix[i] << 8) | (uint32_t)ds;
   for (int h2 = threadIdx.x; h2 < LH; h2 += blockDim.x) {
     const int g = i * LH + h2;
-    const uint32_t* cum = ws.hist + (int64_t)g * RADIX;
+    const uint32_t* cum = ws.cum + (int64_t)g * RADIX;
     const uint32_t below = ds > 0 ? cum[ds - 1] : 0u;
     ws.less[g] += below;
     if (round == 3) ws.eq[g] = cum[ds] - below;
@@ -470,20 +472,23 @@ __global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(kvc_schedule_p
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout {
-  size_t keys, chunk_phys, hist, chunkcnt, less, eq, seq_prefix, seq_k, seq_tmp, total;
+  size_t keys, zero_begin, chunk_phys, hist, less, eq, seq_prefix, seq_k, zero_end, cum, chunkcnt, seq_tmp, total;
 };
 
 static WsLayout ws_layout(int64_t N, int32_t G, int32_t B, int32_t bs) {
   WsLayout l;
   size_t o = 0;
   l.keys = o;        o = align_up(o + (size_t)N * 4, 256);
+  l.zero_begin = o;  // everything up to zero_end is cleared by ONE memset per call
   l.chunk_phys = o;  o = align_up(o + (size_t)(N / bs + 1) * 4, 256);
   l.hist = o;        o = align_up(o + (size_t)G * kvc::RADIX * 4, 256);
-  l.chunkcnt = o;    o = align_up(o + (size_t)G * kvc::RADIX * 4, 256);
   l.less = o;        o = align_up(o + (size_t)G * 4, 256);
   l.eq = o;          o = align_up(o + (size_t)G * 4, 256);
   l.seq_prefix = o;  o = align_up(o + (size_t)B * 4, 256);
   l.seq_k = o;       o = align_up(o + (size_t)B * 4, 256);
+  l.zero_end = o;
+  l.cum = o;         o = align_up(o + (size_t)G * kvc::RADIX * 4, 256);
+  l.chunkcnt = o;    o = align_up(o + (size_t)G * kvc::RADIX * 4, 256);
   l.seq_tmp = o;     o = align_up(o + (size_t)B * 12, 256);
   l.total = o;
   return l;
@@ -517,6 +522,7 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   ws.keys = reinterpret_cast<uint32_t*>(wb + l.keys);
   ws.chunk_phys = reinterpret_cast<int32_t*>(wb + l.chunk_phys);
   ws.hist = reinterpret_cast<uint32_t*>(wb + l.hist);
+  ws.cum = reinterpret_cast<uint32_t*>(wb + l.cum);
   ws.chunkcnt = reinterpret_cast<uint32_t*>(wb + l.chunkcnt);
   ws.less = reinterpret_cast<uint32_t*>(wb + l.less);
   ws.eq = reinterpret_cast<uint32_t*>(wb + l.eq);
@@ -528,20 +534,15 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     hipMemsetAsync(p.evicted_block_count, 0, (size_t)G * 4, s);
     return check_launch("schedule_evictions(empty)");
   }
-  // keys default to "not evictable", chunk table to 0, counters to 0
+  // keys default to "not evictable"; chunk table, histograms and counters to 0 (one memset)
   hipMemsetAsync(ws.keys, 0xFF, (size_t)p.total_slots * 4, s);
-  hipMemsetAsync(ws.chunk_phys, 0, (size_t)(p.total_slots / p.block_size + 1) * 4, s);
-  hipMemsetAsync(ws.less, 0, (size_t)G * 4, s);
-  hipMemsetAsync(ws.eq, 0, (size_t)G * 4, s);
-  hipMemsetAsync(ws.seq_prefix, 0, (size_t)B * 4, s);
-  hipMemsetAsync(ws.seq_k, 0, (size_t)B * 4, s);
+  hipMemsetAsync(wb + l.zero_begin, 0, l.zero_end - l.zero_begin, s);
   {
     const int64_t threads = p.num_blocks * p.block_size;
     hipLaunchKernelGGL(build_keys_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p, ws);
   }
   const unsigned htiles = (unsigned)((p.total_slots + HTILE - 1) / HTILE);
   for (int round = 0; round < 4; ++round) {
-    hipMemsetAsync(ws.hist, 0, (size_t)G * RADIX * 4, s);
     hipLaunchKernelGGL(hist_round_kernel, dim3(htiles), dim3(256), 0, s, p, ws, round);
     hipLaunchKernelGGL(scan_round_kernel, dim3((G + 3) / 4), dim3(256), 0, s, p, ws);
     if (round == 0) {
