@@ -1,0 +1,145 @@
+"""Parity at the shapes of the other BASELINE.json configs (scaled to oracle-friendly
+sizes): config 3 (continual compression, batch > 1, protected_window 32, several
+iterations with the block-state transitions in between), config 4 (80-layer 70B shape),
+config 5 (fp8 cache, block_size 32, full-query-range prefill metrics)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kvc_oracle as orc
+from tests.helpers import oracle_pipeline
+from vllm_kvcompress_amd import _custom_ops as ops
+from vllm_kvcompress_amd.harness import device as hdev
+from vllm_kvcompress_amd.harness import synth
+from vllm_kvcompress_amd.harness.engine_sim import EngineSim
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _gpu_step(st, evicted, k_t, v_t, mode):
+    ds = hdev.upload(st, DEV, mode=mode)
+    eli, ekc, ebc, cmi, cmc = hdev.schedule(ds, st, evicted)
+    ops.execute_cache_moves(k_t, v_t, ds.cm.metrics, ds.cm.token_positions, cmi, cmc,
+                            ds.evicted_kv_offsets, 1, 16)
+    return dict(eli=eli.cpu().numpy(), ekc=ekc.cpu().numpy(), ebc=ebc.cpu().numpy(),
+                cmi=cmi.cpu().numpy(), cmc=cmc.cpu().numpy(),
+                metrics=ds.cm.metrics.cpu().numpy(), positions=ds.cm.token_positions.cpu().numpy())
+
+
+@pytest.mark.parametrize("mode", ["per_sequence", "reference"])
+def test_config3_continual_compression(mode):
+    """4 sequences, cap of 48 tokens per head, protected_window 32, compression every step
+    for 40 decode steps; GPU and oracle carry their own state and must stay identical."""
+    L, H, bs, hd, cap = 2, 4, 16, 128, 48
+    seq_lens = [200, 130, 77, 161]
+    st_o = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs, seq_lens=seq_lens, seed=3,
+                            protected=32, spare_block_frac=0.5)
+    st_g = copy.deepcopy(st_o)
+    sim_o, sim_g = EngineSim(st_o, seq_lens), EngineSim(st_g, seq_lens)
+    k_np, v_np = synth.make_caches_u16(3, st_o.num_blocks, hd, bs)
+    k_t, v_t = torch.from_numpy(k_np.copy()).to(DEV), torch.from_numpy(v_np.copy()).to(DEV)
+    rng = np.random.default_rng(0)
+    for it in range(40):
+        evicted = [synth.evict_block_count(context_lens_lh=st_o.context_lens[:, b, :],
+                                           seq_len=int(sim_o.seq_lens[b]), block_size=bs,
+                                           protected_window_size=32, max_cache_tokens=cap)
+                   for b in range(len(seq_lens))]
+        want = oracle_pipeline(st_o, evicted, k_np, v_np, mode=mode)
+        got = _gpu_step(st_g, evicted, k_t, v_t, mode)
+        for key in ("eli", "ekc", "ebc", "cmi", "cmc", "metrics", "positions"):
+            np.testing.assert_array_equal(got[key], want[key], err_msg=f"iter {it}: {key}")
+        k_np, v_np = want["k"], want["v"]
+        np.testing.assert_array_equal(k_t.cpu().numpy(), k_np, err_msg=f"iter {it}: K")
+        np.testing.assert_array_equal(v_t.cpu().numpy(), v_np, err_msg=f"iter {it}: V")
+        # carry the compacted metric/position stores, free blocks, append one token per head
+        for st, sim, res in ((st_o, sim_o, want), (st_g, sim_g, got)):
+            st.metrics, st.token_positions = res["metrics"].copy(), res["positions"].copy()
+            sim.apply_compression(res["ekc"], res["ebc"])
+            sim.append_token()
+        # decode attention mass lands on live slots (same increments on both sides; kept
+        # tie-free by adding a distinct tiny rank term)
+        inc = rng.random(st_o.metrics.shape).astype(np.float32)
+        st_o.metrics = (st_o.metrics + inc).astype(np.float32)
+        st_g.metrics = (st_g.metrics + inc).astype(np.float32)
+        new_k, new_v = synth.make_caches_u16(100 + it, st_o.num_blocks, hd, bs)
+        # the appended KVs: overwrite the just-written slot of every head with fresh bytes
+        for b in range(len(seq_lens)):
+            for l in range(L):
+                for h in range(H):
+                    ctx = int(st_o.context_lens[l, b, h]) - 1
+                    blk = int(st_o.block_tables[l, b, h, ctx // bs])
+                    k_np[blk, :, ctx % bs, :] = new_k[blk, :, ctx % bs, :]
+                    v_np[blk, :, ctx % bs] = new_v[blk, :, ctx % bs]
+        k_t.copy_(torch.from_numpy(k_np))
+        v_t.copy_(torch.from_numpy(v_np))
+        assert np.array_equal(st_o.context_lens, st_g.context_lens)
+    if mode == "per_sequence":
+        # every sequence is held at its cap; in "reference" mode the batch>1 quirk lets later
+        # sequences under-evict -- reproduced above bit for bit
+        assert int(st_o.context_lens.max()) <= cap + bs
+
+
+def test_config4_70b_shape():
+    """80 layers x 8 KV heads, two sequences, per_sequence mode (the sharded multi-GPU case)"""
+    st = synth.make_state(num_layers=80, num_kv_heads=8, block_size=16, seq_lens=[260, 145], seed=4,
+                          protected=32)
+    bs = 16
+    nblk = ((st.context_lens.astype(np.int64) + bs - 1) // bs).sum(0).sum(-1)
+    evicted = [int(n) // 2 for n in nblk]
+    k, v = synth.make_caches_u16(4, st.num_blocks, 128, bs)
+    want = oracle_pipeline(st, evicted, k, v, mode="per_sequence")
+    kt, vt = torch.from_numpy(k.copy()).to(DEV), torch.from_numpy(v.copy()).to(DEV)
+    got = _gpu_step(st, evicted, kt, vt, "per_sequence")
+    for key in ("eli", "ekc", "ebc", "cmi", "cmc", "metrics", "positions"):
+        np.testing.assert_array_equal(got[key], want[key], err_msg=key)
+    np.testing.assert_array_equal(kt.cpu().numpy(), want["k"])
+    np.testing.assert_array_equal(vt.cpu().numpy(), want["v"])
+
+
+def test_config5_fp8_block32():
+    """1-byte cache elements (x = 16), block_size 32: the reference CUDA kernel rejects this
+    shape; parity is byte-copy semantics of the Python twin."""
+    L, H, bs, hd = 4, 8, 32, 128
+    st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs, seq_lens=[2100], seed=5,
+                          protected=32)
+    nblk = ((st.context_lens.astype(np.int64) + bs - 1) // bs).sum(0).sum(-1)
+    evicted = [int(nblk[0]) * 3 // 4]
+    rng = np.random.default_rng(5)
+    k = rng.integers(0, 256, size=(st.num_blocks, hd // 16, bs, 16), dtype=np.uint8)
+    v = rng.integers(0, 256, size=(st.num_blocks, hd, bs), dtype=np.uint8)
+    want = oracle_pipeline(st, evicted, k, v, mode="reference")
+    kt, vt = torch.from_numpy(k.copy()).to(DEV), torch.from_numpy(v.copy()).to(DEV)
+    got = _gpu_step(st, evicted, kt, vt, "reference")
+    for key in ("eli", "ekc", "ebc", "cmi", "cmc", "metrics", "positions"):
+        np.testing.assert_array_equal(got[key], want[key], err_msg=key)
+    np.testing.assert_array_equal(kt.cpu().numpy(), want["k"])
+    np.testing.assert_array_equal(vt.cpu().numpy(), want["v"])
+
+
+def test_config5_full_query_range_prefill_metrics():
+    """prefill_metric_collection_block_size smaller than the observed window: several query
+    blocks, max-pooled per block before accumulation, then aggregate_prefill."""
+    from vllm_kvcompress_amd.kvcompress.prefill import naive_kvc_attention
+    torch.manual_seed(0)
+    T, Hq, Hkv, hd, qblk = 300, 8, 2, 32, 64
+    q = torch.randn((T, Hq, hd), device=DEV, dtype=torch.float16)
+    kk = torch.randn((T, Hq, hd), device=DEV, dtype=torch.float16)
+    scale = hd ** -0.5
+    buf = torch.tensor([3], dtype=torch.int32)
+    _, got = naive_kvc_attention(q, kk, None, [T], scale, buf, n_observed=T,
+                                 max_observed_block_size=qblk, use_l2=True, use_average=False,
+                                 use_maxpool=True)
+    # float32 restatement of the reference loop (flash_attn.py:1122-1211) on the host
+    qf, kf = q.float().cpu(), kk.float().cpu()
+    want = np.zeros((T, Hq), dtype=np.float32)
+    for l in range(0, T, qblk):
+        qq = qf[l:l + qblk]
+        w = scale * torch.einsum("qhd,khd->hqk", qq, kf)
+        nq = qq.shape[0]
+        mask = torch.triu(torch.ones(nq, T), diagonal=l + 1) * torch.finfo(torch.float16).min
+        probs = torch.softmax(w + mask, dim=-1).numpy()
+        orc.prefill_metric_epilogue(want, probs, l, 3, True, False, True)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-3, atol=1e-5)
