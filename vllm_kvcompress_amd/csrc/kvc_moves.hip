@@ -67,54 +67,108 @@ __device__ __forceinline__ int move_iteration(const MoveHead& h, int j) {
   return i;
 }
 
-template <int BS>
-__global__ __launch_bounds__(256) void schedule_moves_rows_kernel(
-    int32_t* __restrict__ moves, int64_t rows, const int32_t* __restrict__ evicted,
-    const int32_t* __restrict__ ekc, const int32_t* __restrict__ offs,
-    const int32_t* __restrict__ block_tables, const int32_t* __restrict__ context_lens,
-    int B, int L, int H, int M, int bs_rt, int zero_fill) {
-  const int bs = BS > 0 ? BS : bs_rt;
-  const int G = B * L * H;
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows) return;
-  int g = upper_bound_minus1(offs, G, r);
-  const int j = (int)(r - offs[g]);
-  int2 out = make_int2(0, 0);
-  bool have = false;
-  const int cnt = ekc[g];
-  if (j < cnt) {
-    const int b = g / (L * H), lh = g % (L * H), l = lh / H, hh = lh % H;
-    const int lbh = (l * B + b) * H + hh;
-    MoveHead h{evicted + offs[g], cnt, context_lens[lbh]};
-    const int i = move_iteration(h, j);
-    if (i >= 0) {
-      const int src = h.ctx - 1 - i;
-      const int dst = h.E[j];
-      const int32_t* bt = block_tables + (int64_t)lbh * M;
-      out.x = bt[dst / bs] * bs + dst % bs;
-      out.y = bt[src / bs] * bs + src % bs;
-      have = true;
-    }
-  }
-  if (have || zero_fill) reinterpret_cast<int2*>(moves)[r] = out;
-}
+// One workgroup per head (plus a few that clear the rows behind the last head).
+//
+// Regular heads (every evicted index is a real slot, E[cnt-1] < ctx -- always true when
+// protected_window >= 1): the walk degenerates to "the j-th hole below new_len = ctx-cnt
+// receives the j-th surviving slot of the tail [new_len, ctx), counted from the top".  The
+// tail's evicted slots are marked in an LDS bitmap, the tail is scanned top-down with
+// ballot prefix sums, and M = #holes below new_len moves are written, coalesced.
+// Irregular heads and tails beyond the bitmap use the closed form above.
+constexpr int MOVE_BITMAP_WORDS = 16384;      // 512 Ki tail slots per head in LDS (64 KiB)
 
-// one thread per head: number of emitted moves (validity is monotone in j -> bisection)
-__global__ __launch_bounds__(256) void schedule_moves_count_kernel(
-    int32_t* __restrict__ count, const int32_t* __restrict__ evicted,
-    const int32_t* __restrict__ ekc, const int32_t* __restrict__ offs,
-    const int32_t* __restrict__ context_lens, int B, int L, int H) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= B * L * H) return;
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void schedule_moves_heads_kernel(
+    int32_t* __restrict__ moves, int64_t rows, int32_t* __restrict__ count,
+    const int32_t* __restrict__ evicted, const int32_t* __restrict__ ekc,
+    const int32_t* __restrict__ offs, const int32_t* __restrict__ block_tables,
+    const int32_t* __restrict__ context_lens, int B, int L, int H, int M, int bs, int zero_fill) {
+  __shared__ uint32_t bitmap[MOVE_BITMAP_WORDS];
+  __shared__ uint32_t wave_tot[2][THREADS / WAVE];
+  const int G = B * L * H;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int2* mv2 = reinterpret_cast<int2*>(moves);
+  // slots of the last head -> total number of rows that belong to heads
+  const int lastg = G - 1;
+  const int lb = lastg / (L * H), llh = lastg % (L * H);
+  const int last_ctx = context_lens[((llh / H) * B + lb) * H + (llh % H)];
+  const int64_t n_total = (int64_t)offs[lastg] + (int64_t)((last_ctx + bs - 1) / bs) * bs;
+  if ((int)blockIdx.x >= G) {                       // rows behind the last head: zeros
+    if (!zero_fill) return;
+    const int64_t stride = (int64_t)(gridDim.x - G) * THREADS;
+    for (int64_t r = n_total + (int64_t)(blockIdx.x - G) * THREADS + tid; r < rows; r += stride)
+      mv2[r] = make_int2(0, 0);
+    return;
+  }
+  const int g = blockIdx.x;
   const int b = g / (L * H), lh = g % (L * H), l = lh / H, hh = lh % H;
   const int lbh = (l * B + b) * H + hh;
-  MoveHead h{evicted + offs[g], ekc[g], context_lens[lbh]};
-  int lo = 0, hi = h.cnt;                  // first j that is NOT a move
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (move_iteration(h, mid) >= 0) lo = mid + 1; else hi = mid;
+  const int cnt = ekc[g];
+  const int ctx = context_lens[lbh];
+  const int64_t off = offs[g];
+  const int64_t seg_end = min((int64_t)rows, (g + 1 < G) ? (int64_t)offs[g + 1] : n_total);
+  const int32_t* E = evicted + off;
+  const int32_t* bt = block_tables + (int64_t)lbh * M;
+  int nmoves = 0;
+  const bool regular = cnt > 0 && E[cnt - 1] < ctx && (cnt + 31) / 32 <= MOVE_BITMAP_WORDS;
+  if (cnt > 0 && regular) {
+    const int new_len = ctx - cnt;
+    // holes below new_len = lower_bound(E, new_len)
+    int lo = 0, hi = cnt;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (E[mid] < new_len) lo = mid + 1; else hi = mid; }
+    nmoves = lo;
+    const int words = (cnt + 31) / 32;
+    for (int i = tid; i < words; i += THREADS) bitmap[i] = 0;
+    __syncthreads();
+    for (int k = nmoves + tid; k < cnt; k += THREADS) {       // evicted slots inside the tail
+      const int t = E[k] - new_len;
+      atomicOr(&bitmap[t >> 5], 1u << (t & 31));
+    }
+    __syncthreads();
+    uint32_t carry = 0;
+    int buf = 0;
+    for (int base = 0; base < cnt; base += THREADS) {         // i-th slot from the top
+      const int i = base + tid;
+      bool surv = false;
+      int slot = 0;
+      if (i < cnt) {
+        slot = ctx - 1 - i;
+        const int t = slot - new_len;
+        surv = !((bitmap[t >> 5] >> (t & 31)) & 1u);
+      }
+      const unsigned long long bal = __ballot(surv);
+      const uint32_t lane_ex = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) wave_tot[buf][w] = (uint32_t)__popcll(bal);
+      __syncthreads();
+      uint32_t woff = 0, tot = 0;
+#pragma unroll
+      for (int q = 0; q < THREADS / WAVE; ++q) { const uint32_t c = wave_tot[buf][q]; if (q < w) woff += c; tot += c; }
+      if (surv) {
+        const int j = (int)(carry + woff + lane_ex);
+        const int dst = E[j];
+        if (off + j < rows)
+          mv2[off + j] = make_int2(bt[dst / bs] * bs + dst % bs, bt[slot / bs] * bs + slot % bs);
+      }
+      carry += tot;
+      buf ^= 1;
+    }
+  } else if (cnt > 0) {
+    MoveHead h{E, cnt, ctx};
+    for (int j = tid; j < cnt; j += THREADS) {
+      const int i = move_iteration(h, j);
+      if (i >= 0) {
+        const int src = ctx - 1 - i, dst = E[j];
+        if (off + j < rows)
+          mv2[off + j] = make_int2(bt[dst / bs] * bs + dst % bs, bt[src / bs] * bs + src % bs);
+      }
+    }
+    int lo = 0, hi = cnt;                                    // first j that is not a move
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (move_iteration(h, mid) >= 0) lo = mid + 1; else hi = mid; }
+    nmoves = lo;
   }
-  count[g] = lo;
+  if (tid == 0) count[g] = nmoves;
+  if (zero_fill)
+    for (int64_t r = off + nmoves + tid; r < seg_end; r += THREADS) mv2[r] = make_int2(0, 0);
 }
 
 }  // namespace kvc
@@ -147,24 +201,16 @@ extern "C" int kvc_schedule_t1_cache_moves(
   const int G = num_seqs * num_layers * num_kv_heads;
   if (G <= 0) return KVC_OK;
   hipStream_t s = (hipStream_t)stream;
-  if (cache_moves_rows > 0) {
-    dim3 block(256), grid((unsigned)((cache_moves_rows + 255) / 256));
-#define KVC_LAUNCH_ROWS(BS)                                                                     \
-  hipLaunchKernelGGL(kvc::schedule_moves_rows_kernel<BS>, grid, block, 0, s, cache_moves_idx,   \
-                     cache_moves_rows, evicted_logical_indices, evicted_kv_count,               \
-                     evicted_kv_offsets, block_tables, context_lens, num_seqs, num_layers,      \
-                     num_kv_heads, max_num_blocks_per_seq, block_size, zero_fill)
-    switch (block_size) {
-      case 16: KVC_LAUNCH_ROWS(16); break;
-      case 32: KVC_LAUNCH_ROWS(32); break;
-      default: KVC_LAUNCH_ROWS(0); break;
-    }
-#undef KVC_LAUNCH_ROWS
-    int rc = kvc::check_launch("schedule_t1_cache_moves(rows)");
-    if (rc) return rc;
-  }
-  hipLaunchKernelGGL(kvc::schedule_moves_count_kernel, dim3((G + 255) / 256), dim3(256), 0, s,
-                     cache_moves_count, evicted_logical_indices, evicted_kv_count,
-                     evicted_kv_offsets, context_lens, num_seqs, num_layers, num_kv_heads);
-  return kvc::check_launch("schedule_t1_cache_moves(count)");
+  // extra workgroups clear the rows behind the last head's segment (wrapper zero fill)
+  const int tail_wgs = zero_fill ? 64 : 0;
+  const int64_t rows_per_head = cache_moves_rows / G;
+#define KVC_LAUNCH_HEADS(T)                                                                    \
+  hipLaunchKernelGGL(kvc::schedule_moves_heads_kernel<T>, dim3(G + tail_wgs), dim3(T), 0, s,     \
+                     cache_moves_idx, cache_moves_rows, cache_moves_count,                      \
+                     evicted_logical_indices, evicted_kv_count, evicted_kv_offsets,             \
+                     block_tables, context_lens, num_seqs, num_layers, num_kv_heads,            \
+                     max_num_blocks_per_seq, block_size, zero_fill)
+  if (rows_per_head >= 4096) KVC_LAUNCH_HEADS(1024); else KVC_LAUNCH_HEADS(256);
+#undef KVC_LAUNCH_HEADS
+  return kvc::check_launch("schedule_t1_cache_moves");
 }
