@@ -11,7 +11,8 @@ import os
 from ctypes import c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkvc_mi355x.so")
+# KVC_MI355X_LIB: alternative build of the same library (kernel experiments)
+LIB_PATH = os.environ.get("KVC_MI355X_LIB", os.path.join(_HERE, "libkvc_mi355x.so"))
 
 MAX_INT = 2147483000  # reference vllm/kvcompress/metrics.py:12
 

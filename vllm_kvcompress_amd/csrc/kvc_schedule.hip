@@ -68,12 +68,31 @@ __device__ __forceinline__ void hist_add(uint32_t* hist, bool valid, uint32_t di
 }
 
 // ------------------------------------------------------------------ 0. keys
-// one thread per (physical block, slot)                     metrics.py:465-544
+// effective metric -> order-preserving key                   metrics.py:495-544
+__device__ __forceinline__ uint32_t slot_key(const kvc_schedule_params& p, float m, int pos, int seq_pos,
+                                             int prot, int l, int h) {
+  if (p.use_average) m = __fdiv_rn(m, (float)(seq_pos - pos));          // :495-501
+  if (p.bias != nullptr) {                                               // :503-506, :54-81
+    int cnt = 0;
+    for (int k = 0; k < p.num_bins; ++k) cnt += pos >= p.position_bins[k];
+    int bi = cnt - 1;
+    if (bi < 0) bi += p.num_bins;
+    float b = p.bias[((int64_t)l * p.num_kv_heads + h) * p.num_bins + bi];
+    if (pos < 0) b = 0.0f;
+    m = __fadd_rn(m, __fmul_rn(b, p.bias_weight));
+  }
+  const bool in_range = pos <= seq_pos - prot && pos >= p.num_sinks;   // :539-544
+  return in_range ? float_to_key(m) : KEY_INF;
+}
+
+// one thread per VEC consecutive slots of a physical block (VEC = 4: 16 B loads and stores)
+template <int VEC>
 __global__ __launch_bounds__(256) void build_keys_kernel(kvc_schedule_params p, SchedWs ws) {
   const int bs = p.block_size;
+  const int per_blk = bs / VEC;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t blk = tid / bs;
-  const int off = (int)(tid % bs);
+  const int64_t blk = tid / per_blk;
+  const int off = (int)(tid % per_blk) * VEC;
   if (blk >= p.num_blocks) return;
   const int s = p.seq_index_by_block[blk];
   if (s < 0 || s >= p.seq_slot_len) return;
@@ -86,23 +105,21 @@ __global__ __launch_bounds__(256) void build_keys_kernel(kvc_schedule_params p, 
   const int ctx = p.context_lens[(l * B + i) * H + h];
   const int nblk = (ctx + bs - 1) / bs;
   if (lbn < 0 || lbn >= nblk) return;          // not part of the head's slot range
-  const int pos = p.token_positions[blk * bs + off];
-  float m = p.metrics[blk * bs + off];
-  const int seq_pos = p.seq_positions[i];
-  if (p.use_average) m = __fdiv_rn(m, (float)(seq_pos - pos));          // :495-501
-  if (p.bias != nullptr) {                                               // :503-506, :54-81
-    int cnt = 0;
-    for (int k = 0; k < p.num_bins; ++k) cnt += pos >= p.position_bins[k];
-    int bi = cnt - 1;
-    if (bi < 0) bi += p.num_bins;
-    float b = p.bias[((int64_t)l * H + h) * p.num_bins + bi];
-    if (pos < 0) b = 0.0f;
-    m = __fadd_rn(m, __fmul_rn(b, p.bias_weight));
-  }
-  const bool in_range = pos <= seq_pos - p.num_protected[i] && pos >= p.num_sinks;   // :539-544
-  const uint32_t key = in_range ? float_to_key(m) : KEY_INF;
+  const int seq_pos = p.seq_positions[i], prot = p.num_protected[i];
   const int64_t base = p.evicted_kv_offsets[g];
-  ws.keys[base + (int64_t)lbn * bs + off] = key;
+  const int64_t src = blk * bs + off, dst = base + (int64_t)lbn * bs + off;
+  if constexpr (VEC == 4) {
+    const float4 m = *reinterpret_cast<const float4*>(p.metrics + src);
+    const int4 q = *reinterpret_cast<const int4*>(p.token_positions + src);
+    uint4 k;
+    k.x = slot_key(p, m.x, q.x, seq_pos, prot, l, h);
+    k.y = slot_key(p, m.y, q.y, seq_pos, prot, l, h);
+    k.z = slot_key(p, m.z, q.z, seq_pos, prot, l, h);
+    k.w = slot_key(p, m.w, q.w, seq_pos, prot, l, h);
+    *reinterpret_cast<uint4*>(ws.keys + dst) = k;
+  } else {
+    ws.keys[dst] = slot_key(p, p.metrics[src], p.token_positions[src], seq_pos, prot, l, h);
+  }
   if (off == 0) ws.chunk_phys[base / bs + lbn] = (int32_t)blk;
 }
 
@@ -348,7 +365,7 @@ __global__ __launch_bounds__(256) void finalize_heads_kernel(kvc_schedule_params
 // ------------------------------------------------------------------ 6. select + emit
 // one workgroup per head: cnt-th smallest (key, physical slot) by radix select, then the
 // ascending logical indices of everything at or below it.       metrics.py:822-834
-constexpr int SEL_THREADS = 512;
+constexpr int SEL_THREADS = 1024;
 
 // radix-select the rank-th (1-based) smallest value of f(idx) over idx in [0,n) where
 // pred(idx); returns the value, and the 1-based rank among equals / number of equals.
@@ -404,7 +421,9 @@ __device__ void block_radix_select(uint32_t* hist, uint32_t* bc, int n, uint32_t
   out_rank_in_eq = rank;
 }
 
-__global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(kvc_schedule_params p, SchedWs ws) {
+// lds_cap = number of keys the dynamic LDS buffer can stage (0 = read keys from global/L2)
+__global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(kvc_schedule_params p, SchedWs ws, int lds_cap) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_keys[];
   __shared__ __attribute__((aligned(16))) uint32_t hist[RADIX];
   __shared__ uint32_t bc[4];
   __shared__ uint32_t wave_tot[2][SEL_THREADS / WAVE];
@@ -415,23 +434,35 @@ __global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(kvc_schedule_p
   const int64_t end = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : p.total_slots;
   const int n = (int)(end - base);
   const uint32_t cnt = (uint32_t)p.evicted_kv_count[g];
-  const uint32_t* keys = ws.keys + base;
+  const uint32_t* gkeys = ws.keys + base;
   int32_t* out = p.evicted_logical_indices + base;
   const int tid = threadIdx.x, lane = lane_id(), w = tid / WAVE;
   if (cnt == 0) {
     for (int idx = tid; idx < n; idx += blockDim.x) out[idx] = p.null_value;
     return;
   }
+  // stage the head's keys in LDS once; every later pass (4 select rounds + emit) reads LDS
+  const bool staged = n <= lds_cap;
+  if (staged) {
+    for (int idx = tid * 4; idx < n; idx += SEL_THREADS * 4) {
+      if (idx + 3 < n && ((base & 3) == 0)) {
+        *reinterpret_cast<uint4*>(lds_keys + idx) = *reinterpret_cast<const uint4*>(gkeys + idx);
+      } else {
+        for (int q = idx; q < min(n, idx + 4); ++q) lds_keys[q] = gkeys[q];
+      }
+    }
+    __syncthreads();
+  }
+  auto key_at = [&](int idx) { return staged ? lds_keys[idx] : gkeys[idx]; };
   uint32_t M, take, eqn;
-  block_radix_select(hist, bc, n, cnt, [&](int idx) { return keys[idx]; },
-                     [&](int) { return true; }, M, take, eqn);
+  block_radix_select(hist, bc, n, cnt, key_at, [&](int) { return true; }, M, take, eqn);
   // ties on the metric: the `take` entries with the smallest (physical block, offset)
   uint32_t Fstar = 0xFFFFFFFFu;
   const int32_t* cphys = ws.chunk_phys + base / bs;
   auto fkey = [&](int idx) { return (uint32_t)cphys[idx / bs] * (uint32_t)bs + (uint32_t)(idx % bs); };
   if (take < eqn) {
     uint32_t r2, e2;
-    block_radix_select(hist, bc, n, take, fkey, [&](int idx) { return keys[idx] == M; }, Fstar, r2, e2);
+    block_radix_select(hist, bc, n, take, fkey, [&](int idx) { return key_at(idx) == M; }, Fstar, r2, e2);
   }
   // emit: flag, block-wide exclusive scan, compact; then pad with null
   uint32_t carry = 0;
@@ -443,7 +474,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(kvc_schedule_p
 #pragma unroll
     for (int u = 0; u < U; ++u) {                   // independent loads first
       const int idx = base0 + u * SEL_THREADS + tid;
-      kk[u] = idx < n ? keys[idx] : 0xFFFFFFFFu;
+      kk[u] = idx < n ? key_at(idx) : 0xFFFFFFFFu;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -537,9 +568,12 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   // keys default to "not evictable"; chunk table, histograms and counters to 0 (one memset)
   hipMemsetAsync(ws.keys, 0xFF, (size_t)p.total_slots * 4, s);
   hipMemsetAsync(wb + l.zero_begin, 0, l.zero_end - l.zero_begin, s);
-  {
+  if (p.block_size % 4 == 0) {
+    const int64_t threads = p.num_blocks * (p.block_size / 4);
+    hipLaunchKernelGGL(build_keys_kernel<4>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p, ws);
+  } else {
     const int64_t threads = p.num_blocks * p.block_size;
-    hipLaunchKernelGGL(build_keys_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p, ws);
+    hipLaunchKernelGGL(build_keys_kernel<1>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p, ws);
   }
   const unsigned htiles = (unsigned)((p.total_slots + HTILE - 1) / HTILE);
   for (int round = 0; round < 4; ++round) {
@@ -552,6 +586,18 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     hipLaunchKernelGGL(pick_round_kernel, dim3(B), dim3(1024), 0, s, p, ws, round);
   }
   hipLaunchKernelGGL(finalize_heads_kernel, dim3(B), dim3(256), 0, s, p, ws);
-  hipLaunchKernelGGL(select_emit_kernel, dim3(G), dim3(SEL_THREADS), 0, s, p, ws);
+  {
+    // stage a head's keys in LDS when the average head fits (ragged heads that do not fit
+    // read from L2); small heads take a small buffer so that several workgroups share a CU
+    const int64_t avg = p.total_slots / G;
+    int lds_cap = avg <= 3072 ? 4096 : (avg <= 12288 ? 16384 : 32768);
+    static bool attr_set = false;
+    if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in (gfx950 has 160 KiB per CU)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(select_emit_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(select_emit_kernel, dim3(G), dim3(SEL_THREADS), (size_t)lds_cap * 4, s, p, ws, lds_cap);
+  }
   return check_launch("schedule_evictions");
 }
