@@ -204,6 +204,20 @@ int kvc_reshape_and_cache(const void* key, const void* value, void* key_cache,
                           int32_t elem_bytes, int64_t key_stride, int64_t value_stride,
                           kvc_stream_t stream);
 
+/* A7 with an fp8 cache: kv_cache_dtype "fp8"/"fp8_e4m3" (fp8_kind 0, OCP e4m3fn) or
+ * "fp8_e5m2" (fp8_kind 1).  cache byte = fp8(float(x) / scale), round-to-nearest-even,
+ * saturating to the largest finite value -- the reference's
+ * __nv_cvt_float_to_fp8(x / scale, __NV_SATFINITE, type)
+ *   (csrc/quantization/fp8/nvidia/quant_utils.cuh:456-489, dispatch :525-566).
+ * src_dtype: 0 = fp16, 1 = bf16, 2 = fp32.  K vectors hold x = 16 fp8 elements. */
+int kvc_reshape_and_cache_fp8(const void* key, const void* value, void* key_cache,
+                              void* value_cache, float* kv_metrics, const int64_t* slot_mapping,
+                              const float* kv_metric_head_bias, int64_t num_tokens,
+                              int32_t num_heads, int32_t head_size, int32_t block_size,
+                              int32_t src_dtype, int32_t fp8_kind, int64_t key_stride,
+                              int64_t value_stride, float k_scale, float v_scale,
+                              kvc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -352,3 +352,58 @@ def reshape_and_cache_kvc(key, value, key_cache, value_cache, kv_metrics, slot_m
             b, o = divmod(s, bs)
             key_cache[b, :, o, :] = key[t, h].reshape(hd // x, x)
             value_cache[b, :, o] = value[t, h]
+
+
+# --------------------------------------------------------------------------------------
+# fp8 KV cache (reshape_and_cache with kv_cache_dtype fp8 / fp8_e5m2)
+# csrc/quantization/fp8/nvidia/quant_utils.cuh:456-489:  fp8 = cvt(float(x) / scale,
+# __NV_SATFINITE, E4M3 | E5M2): round to nearest even, saturate to the largest finite.
+# Restated by definition: enumerate every finite code's value, pick the nearest, ties to the
+# code with an even mantissa LSB.
+# --------------------------------------------------------------------------------------
+def _fp8_table(kind):
+    mbits, bias, maxcode = (3, 7, 0x7E) if kind == "e4m3" else (2, 15, 0x7B)
+    codes = np.arange(0, maxcode + 1, dtype=np.int64)
+    exp = codes >> mbits
+    man = codes & ((1 << mbits) - 1)
+    vals = np.where(exp == 0, man * 2.0 ** (1 - bias - mbits),
+                    (1.0 + man / float(1 << mbits)) * 2.0 ** (exp.astype(np.float64) - bias))
+    return codes, vals
+
+
+def fp8_encode_satfinite(x, kind):
+    """x float32 array -> uint8 codes (OCP e4m3fn / e5m2)."""
+    codes, vals = _fp8_table(kind)
+    x = np.asarray(x, dtype=np.float32)
+    a = np.abs(x).astype(np.float64)
+    sign = (np.signbit(x)).astype(np.uint8) << 7
+    a_clip = np.minimum(a, vals[-1])                       # saturate (incl. inf)
+    hi = np.searchsorted(vals, a_clip, side="left")        # first value >= a
+    hi = np.clip(hi, 0, len(vals) - 1)
+    lo = np.clip(hi - 1, 0, len(vals) - 1)
+    dlo, dhi = np.abs(a_clip - vals[lo]), np.abs(vals[hi] - a_clip)
+    pick_hi = (dhi < dlo) | ((dhi == dlo) & ((codes[hi] & 1) == 0))
+    code = np.where(pick_hi, codes[hi], codes[lo]).astype(np.uint8)
+    code = np.where(np.isnan(x), np.uint8(0x7F), code)
+    return (code | sign).astype(np.uint8)
+
+
+def reshape_and_cache_kvc_fp8(key, value, key_cache, value_cache, kv_metrics, slot_mapping,
+                              kv_metric_head_bias, kind, k_scale, v_scale):
+    """key/value [T,H,hd] float arrays (already widened to float32 exactly), caches uint8:
+    key_cache [NB, hd/16, bs, 16], value_cache [NB, hd, bs]."""
+    T, H, hd = key.shape
+    bs = value_cache.shape[2]
+    kq = fp8_encode_satfinite((key.astype(np.float32) / np.float32(k_scale)).astype(np.float32), kind)
+    vq = fp8_encode_satfinite((value.astype(np.float32) / np.float32(v_scale)).astype(np.float32), kind)
+    sm = slot_mapping.reshape(T, H)
+    met = kv_metrics.reshape(-1)
+    for t in range(T):
+        for h in range(H):
+            s = int(sm[t, h])
+            if s < 0:
+                continue
+            met[s] = kv_metric_head_bias[h]
+            b, o = divmod(s, bs)
+            key_cache[b, :, o, :] = kq[t, h].reshape(hd // 16, 16)
+            value_cache[b, :, o] = vq[t, h]

@@ -361,3 +361,62 @@ def test_reshape_and_cache_kvc(dtype):
     np.testing.assert_array_equal(dk.view(torch.uint8).cpu().numpy().reshape(-1), wk.view(np.uint8).reshape(-1))
     np.testing.assert_array_equal(dv.view(torch.uint8).cpu().numpy().reshape(-1), wv.view(np.uint8).reshape(-1))
     np.testing.assert_array_equal(dm.cpu().numpy(), wm)
+
+
+def test_reshape_and_cache_kvc_block_path_and_ragged():
+    """prefill-shaped slot mapping (aligned whole blocks -> block path) mixed with ragged
+    tails, padding tokens and a decode-style scattered tail"""
+    rng = np.random.default_rng(7)
+    T, H, hd, bs = 75, 8, 128, 16
+    NB = H * 6 + 10
+    key = rng.integers(0, 2 ** 16, size=(T, H, hd)).astype(np.uint16)
+    val = rng.integers(0, 2 ** 16, size=(T, H, hd)).astype(np.uint16)
+    kc = rng.integers(0, 2 ** 16, size=(NB, hd // 8, bs, 8)).astype(np.uint16)
+    vc = rng.integers(0, 2 ** 16, size=(NB, hd, bs)).astype(np.uint16)
+    met = rng.random((NB, bs)).astype(np.float32)
+    blocks = rng.permutation(NB)
+    slots = np.full((T, H), -1, dtype=np.int64)
+    for h in range(H):
+        for t in range(64):                                   # 4 aligned blocks per head
+            slots[t, h] = int(blocks[h * 6 + t // bs]) * bs + t % bs
+        for t in range(64, 70):                               # ragged tail in a 5th block
+            slots[t, h] = int(blocks[h * 6 + 4]) * bs + (t - 64)
+        slots[71, h] = int(blocks[h * 6 + 5]) * bs + 3        # lone decode-style token
+    slots[10, 2] = -1                                         # padding inside a block -> slot path
+    bias = rng.random(H).astype(np.float32)
+    wk, wv, wm = kc.copy(), vc.copy(), met.copy()
+    orc.reshape_and_cache_kvc(key, val, wk, wv, wm, slots.reshape(-1), bias)
+    to = lambda a: torch.from_numpy(a.view(np.uint8)).to(DEV).view(torch.float16).view(a.shape)
+    dk, dv, dm = to(kc), to(vc), torch.from_numpy(met).to(DEV)
+    ops.reshape_and_cache_kvc(to(key), to(val), dk, dv, dm, torch.from_numpy(slots.reshape(-1)).to(DEV),
+                              torch.from_numpy(bias).to(DEV), "auto", 1.0, 1.0)
+    np.testing.assert_array_equal(dk.view(torch.uint8).cpu().numpy().reshape(-1), wk.view(np.uint8).reshape(-1))
+    np.testing.assert_array_equal(dv.view(torch.uint8).cpu().numpy().reshape(-1), wv.view(np.uint8).reshape(-1))
+    np.testing.assert_array_equal(dm.cpu().numpy(), wm)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("kv_dtype,kind", [("fp8", "e4m3"), ("fp8_e4m3", "e4m3"), ("fp8_e5m2", "e5m2")])
+def test_reshape_and_cache_kvc_fp8(dtype, kv_dtype, kind):
+    rng = np.random.default_rng(8)
+    T, H, hd, bs, NB = 21, 4, 128, 32, 12
+    scale_k, scale_v = 0.37, 2.5
+    base = torch.from_numpy(rng.normal(0, 30, size=(2, T, H, hd)).astype(np.float32))
+    base[0, 0, 0, :8] = torch.tensor([0.0, -0.0, 1e9, -1e9, float("inf"), -float("inf"), 2e-4, -3e-7])
+    key_t, val_t = base[0].to(dtype), base[1].to(dtype)
+    kc = rng.integers(0, 256, size=(NB, hd // 16, bs, 16), dtype=np.uint8)
+    vc = rng.integers(0, 256, size=(NB, hd, bs), dtype=np.uint8)
+    met = rng.random((NB, bs)).astype(np.float32)
+    slots = rng.permutation(NB * bs)[:T * H].astype(np.int64)
+    slots[3] = -1
+    bias = rng.random(H).astype(np.float32)
+    wk, wv, wm = kc.copy(), vc.copy(), met.copy()
+    orc.reshape_and_cache_kvc_fp8(key_t.float().numpy(), val_t.float().numpy(), wk, wv, wm, slots,
+                                  bias, kind, scale_k, scale_v)
+    dk, dv = torch.from_numpy(kc).to(DEV), torch.from_numpy(vc).to(DEV)
+    dm = torch.from_numpy(met).to(DEV)
+    ops.reshape_and_cache_kvc(key_t.to(DEV), val_t.to(DEV), dk, dv, dm, torch.from_numpy(slots).to(DEV),
+                              torch.from_numpy(bias).to(DEV), kv_dtype, scale_k, scale_v)
+    np.testing.assert_array_equal(dk.cpu().numpy(), wk)
+    np.testing.assert_array_equal(dv.cpu().numpy(), wv)
+    np.testing.assert_array_equal(dm.cpu().numpy(), wm)

@@ -122,3 +122,20 @@ def test_c_count_block_evictions_equals_numpy():
         orc_c.count_block_evictions(b, b_idx, offs, hang, bs, 99)
         np.testing.assert_array_equal(a, b)
         np.testing.assert_array_equal(a_idx, b_idx)
+
+
+def test_fp8_encode_against_torch_casts():
+    """the by-definition fp8 encoder of the oracle vs torch's own float8 casts (in range,
+    where torch also rounds to nearest even; torch does not saturate, the reference does)"""
+    import torch
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.normal(0, 1, 4000), rng.normal(0, 100, 4000), rng.normal(0, 1e-3, 4000),
+                        np.array([0.0, -0.0, 448.0, 447.9, 464.0, 1e9, -1e9, np.inf, -np.inf,
+                                  2.0 ** -9, 2.0 ** -10, 3 * 2.0 ** -10, 57344.0, 61440.0, 1e-8])]
+                       ).astype(np.float32)
+    for kind, dt, mx in (("e4m3", torch.float8_e4m3fn, 448.0), ("e5m2", torch.float8_e5m2, 57344.0)):
+        got = orc.fp8_encode_satfinite(x, kind)
+        clipped = torch.from_numpy(x).clamp(-mx, mx)
+        want = clipped.to(dt).view(torch.uint8).numpy()
+        np.testing.assert_array_equal(got, want)
+    assert orc.fp8_encode_satfinite(np.array([np.nan], np.float32), "e4m3")[0] & 0x7F == 0x7F

@@ -169,30 +169,47 @@ def reshape_and_cache_kvc(
     k_scale: float,
     v_scale: float,
 ) -> None:
-    """reference vllm/_custom_ops.py:641-658 (``kv_cache_dtype == "auto"`` only so far)"""
+    """reference vllm/_custom_ops.py:641-658; ``kv_cache_dtype`` in {"auto", "fp8",
+    "fp8_e4m3", "fp8_e5m2"} (csrc/quantization/fp8/nvidia/quant_utils.cuh:525-566)"""
     lib = _lib.load()
-    if kv_cache_dtype != "auto":
-        raise RuntimeError(f"Unsupported data type of kv cache: {kv_cache_dtype}")
     for n, t in (("key", key), ("value", value), ("key_cache", key_cache),
                  ("value_cache", value_cache)):
         _require(t, n)
     _require(kv_metrics, "kv_metrics", torch.float32)
     _require(slot_mapping, "slot_mapping", torch.int64)
     _require(kv_metric_head_bias, "kv_metric_head_bias", torch.float32)
-    if key.dtype != key_cache.dtype or value.dtype != value_cache.dtype:
-        raise RuntimeError("reshape_and_cache_kvc: kv_cache_dtype 'auto' needs cache dtype == "
-                           "key/value dtype")
     if key.stride(2) != 1 or key.stride(1) != key.shape[2] or \
             value.stride(2) != 1 or value.stride(1) != value.shape[2]:
         raise RuntimeError("reshape_and_cache_kvc: key/value must be dense in their last two dims")
     num_tokens, num_heads, head_size = key.shape
     block_size = key_cache.shape[2]
+    sm = slot_mapping.contiguous()
+    hb = kv_metric_head_bias.contiguous()
+    if kv_cache_dtype == "auto":
+        if key.dtype != key_cache.dtype or value.dtype != value_cache.dtype:
+            raise RuntimeError("reshape_and_cache_kvc: kv_cache_dtype 'auto' needs cache dtype == "
+                               "key/value dtype")
+        with torch.cuda.device(key.device):
+            _lib.check(lib.kvc_reshape_and_cache(
+                key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+                kv_metrics.data_ptr(), sm.data_ptr(), hb.data_ptr(), num_tokens, num_heads,
+                head_size, block_size, key.element_size(), key.stride(0), value.stride(0),
+                _stream(key)))
+        return
+    kinds = {"fp8": 0, "fp8_e4m3": 0, "fp8_e5m2": 1}
+    if kv_cache_dtype not in kinds:
+        raise RuntimeError(f"Unsupported data type of kv cache: {kv_cache_dtype}")
+    srcs = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
+    if key.dtype not in srcs or value.dtype != key.dtype:
+        raise RuntimeError(f"Unsupported input type of kv cache: {key.dtype}")
+    if key_cache.element_size() != 1 or value_cache.element_size() != 1:
+        raise RuntimeError("reshape_and_cache_kvc: an fp8 kv cache must have 1-byte elements")
     with torch.cuda.device(key.device):
-        _lib.check(lib.kvc_reshape_and_cache(
+        _lib.check(lib.kvc_reshape_and_cache_fp8(
             key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
-            kv_metrics.data_ptr(), slot_mapping.contiguous().data_ptr(),
-            kv_metric_head_bias.contiguous().data_ptr(), num_tokens, num_heads, head_size,
-            block_size, key.element_size(), key.stride(0), value.stride(0), _stream(key)))
+            kv_metrics.data_ptr(), sm.data_ptr(), hb.data_ptr(), num_tokens, num_heads, head_size,
+            block_size, srcs[key.dtype], kinds[kv_cache_dtype], key.stride(0), value.stride(0),
+            float(k_scale), float(v_scale), _stream(key)))
 
 
 def schedule_cache_evictions(*args, **kwargs):

@@ -66,6 +66,10 @@ SYMBOLS = {
     "kvc_reshape_and_cache": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
                                         c_int32, c_int64, c_int64, c_void_p]),
+    "kvc_reshape_and_cache_fp8": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
+                                            c_int32, c_int32, c_int64, c_int64, c_float, c_float,
+                                            c_void_p]),
 }
 
 _lib = None

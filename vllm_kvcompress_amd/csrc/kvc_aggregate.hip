@@ -4,6 +4,7 @@
 // the sequential float32 restatement in oracle/kvc_oracle.py.
 #include "kvc_common.h"
 #include "../../include/kvc_mi355x.h"
+#include <hip/hip_fp16.h>
 
 namespace kvc {
 
@@ -140,6 +141,176 @@ __global__ __launch_bounds__(512) void reshape_and_cache_kernel(
   }
 }
 
+// ------------------------------------------------------------------ A7 (block path)
+// Prefill writes bs consecutive tokens of a head into one fresh block.  When the slots of
+// tokens t0..t0+bs-1 are exactly one aligned block (s0 % bs == 0, s_i = s0 + i) the wave of
+// the first token assembles the whole K and V block images (lane l holds the 16 B pieces
+// l, l+64, ...) and streams them out 1 KiB per instruction instead of bs*hd scattered 2 B
+// stores; every other (token, head) falls back to element-wise stores.
+typedef uint32_t u32x4a __attribute__((ext_vector_type(4)));
+
+template <int HD, int BS, int E>
+__global__ __launch_bounds__(256) void reshape_and_cache_blocks_kernel(
+    const uint8_t* __restrict__ key, const uint8_t* __restrict__ value,
+    uint8_t* __restrict__ key_cache, uint8_t* __restrict__ value_cache,
+    float* __restrict__ kv_metrics, const int64_t* __restrict__ slot_mapping,
+    const float* __restrict__ bias, int64_t num_tokens, int num_heads, int64_t key_stride,
+    int64_t value_stride) {
+  constexpr int64_t BLOCK_BYTES = (int64_t)HD * BS * E;
+  constexpr int NPL = (int)(BLOCK_BYTES / 16 / 64);
+  constexpr int EP = 16 / E;                 // elements per 16 B piece
+  constexpr int RB = BS * E, PR = RB / 16;   // V row bytes, pieces per V row
+  constexpr int ROWB = HD * E;               // bytes of one token's head vector
+  constexpr int PPR = ROWB / 16;             // 16 B pieces per token row
+  __shared__ __attribute__((aligned(16))) uint8_t tile_s[4][BLOCK_BYTES];   // per wave: [BS tokens][HD*E]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint8_t* tile = tile_s[wave];
+  // lane <-> one (token, head) item; 64 consecutive items per wave
+  const int64_t item = ((int64_t)blockIdx.x * 4 + wave) * 64 + lane;
+  const bool live = item < num_tokens * num_heads;
+  const int64_t t = live ? item / num_heads : 0;
+  const int h = live ? (int)(item % num_heads) : 0;
+  const int64_t slot = live ? slot_mapping[t * num_heads + h] : -1;
+  // is the group of BS tokens this slot belongs to exactly one aligned block?
+  bool aligned = false;
+  if (slot >= 0) {
+    const int o = (int)(slot % BS);
+    const int64_t t0 = t - o;
+    aligned = t0 >= 0 && t0 + BS <= num_tokens;
+    for (int i = 0; aligned && i < BS; ++i) aligned = slot_mapping[(t0 + i) * num_heads + h] == slot - o + i;
+  }
+  unsigned long long starters = __ballot(aligned && slot % BS == 0);
+  unsigned long long singles = __ballot(slot >= 0 && !aligned);
+  // ---- whole blocks, one after the other, all 64 lanes on each -----------------------
+  while (starters) {
+    const int src_lane = __ffsll((long long)starters) - 1;
+    starters &= starters - 1;
+    const int64_t s0 = __shfl(slot, src_lane, 64);            // 64-bit shuffle (two halves)
+    const int64_t it0 = ((int64_t)blockIdx.x * 4 + wave) * 64 + src_lane;
+    const int64_t t0 = it0 / num_heads;
+    const int hh = (int)(it0 % num_heads);
+    const int64_t blk = s0 / BS;
+    uint8_t* kd = key_cache + blk * BLOCK_BYTES;
+    uint8_t* vd = value_cache + blk * BLOCK_BYTES;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {                            // K: piece p = r*BS + s  <- token s, chunk r
+      const int p = i * 64 + lane, r = p / BS, s = p % BS;
+      const u32x4a q = *reinterpret_cast<const u32x4a*>(key + ((t0 + s) * key_stride + (int64_t)hh * HD) * E + r * 16);
+      __builtin_nontemporal_store(q, reinterpret_cast<u32x4a*>(kd + (int64_t)p * 16));
+    }
+    // V: stage the BS value rows (coalesced 16 B pieces), then every lane gathers the EP
+    // elements of its output piece from LDS and streams the block image out
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int p = i * 64 + lane, s = p / PPR, c = p % PPR;
+      *reinterpret_cast<u32x4a*>(tile + (int64_t)p * 16) =
+          *reinterpret_cast<const u32x4a*>(value + ((t0 + s) * value_stride + (int64_t)hh * HD) * E + c * 16);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {                            // piece p = row d, slots [pr*EP, +EP)
+      const int p = i * 64 + lane, d = p / PR, pr = p % PR;
+      uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < EP; ++j) {
+        const uint8_t* src = tile + (pr * EP + j) * ROWB + d * E;
+        uint32_t e;
+        if constexpr (E == 1) e = *src;
+        else if constexpr (E == 2) e = *reinterpret_cast<const uint16_t*>(src);
+        else e = *reinterpret_cast<const uint32_t*>(src);
+        w[j * E / 4] |= e << ((j * E % 4) * 8);
+      }
+      __builtin_nontemporal_store(u32x4a{w[0], w[1], w[2], w[3]}, reinterpret_cast<u32x4a*>(vd + (int64_t)p * 16));
+    }
+    if (lane < BS) kv_metrics[s0 + lane] = bias[hh];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                           // tile is reused by the next block
+  }
+  // ---- everything else: one (token, head) at a time, element-wise -----------------------
+  while (singles) {
+    const int src_lane = __ffsll((long long)singles) - 1;
+    singles &= singles - 1;
+    const int64_t s1 = __shfl(slot, src_lane, 64);
+    const int64_t it1 = ((int64_t)blockIdx.x * 4 + wave) * 64 + src_lane;
+    const int64_t t1 = it1 / num_heads;
+    const int hh = (int)(it1 % num_heads);
+    const int64_t blk = s1 / BS;
+    const int o = (int)(s1 % BS);
+    if (lane == 0) kv_metrics[s1] = bias[hh];
+    for (int d = lane; d < HD; d += 64) {
+      const uint8_t* vs = value + (t1 * value_stride + (int64_t)hh * HD + d) * E;
+      uint8_t* vdp = value_cache + blk * BLOCK_BYTES + ((int64_t)d * BS + o) * E;
+      if constexpr (E == 1) *vdp = *vs;
+      else if constexpr (E == 2) *reinterpret_cast<uint16_t*>(vdp) = *reinterpret_cast<const uint16_t*>(vs);
+      else *reinterpret_cast<uint32_t*>(vdp) = *reinterpret_cast<const uint32_t*>(vs);
+    }
+    for (int r = lane; r < PPR; r += 64)
+      *reinterpret_cast<u32x4a*>(key_cache + blk * BLOCK_BYTES + ((int64_t)r * BS + o) * 16) =
+          *reinterpret_cast<const u32x4a*>(key + (t1 * key_stride + (int64_t)hh * HD) * E + r * 16);
+  }
+}
+
+// ------------------------------------------------------------------ A7 (fp8 cache)
+// fp8 = cvt(float(x) / scale) with round-to-nearest-even and saturation to the largest
+// finite value, OCP e4m3fn / e5m2 -- what the reference computes with
+// __nv_cvt_float_to_fp8(x / scale, __NV_SATFINITE, fp8_type)
+// (csrc/quantization/fp8/nvidia/quant_utils.cuh:456-489).  Done in integer arithmetic so
+// the result does not depend on the conversion mode bits of the hardware instruction.
+template <int MBITS, int BIAS, int MAXCODE>
+__device__ __forceinline__ uint32_t f32_to_fp8_satfinite(float f) {
+  const uint32_t u = __float_as_uint(f);
+  const uint32_t sign = (u >> 24) & 0x80u;
+  const uint32_t a = u & 0x7FFFFFFFu;
+  if (a > 0x7F800000u) return sign | 0x7Fu;                     // NaN
+  constexpr int SHIFT = 23 - MBITS;
+  constexpr uint32_t MIN_NORMAL = (uint32_t)(127 - BIAS + 1) << 23;
+  uint32_t code;
+  if (a < MIN_NORMAL) {
+    // subnormal target: integer multiple of 2^(1-BIAS-MBITS), ties to even
+    code = (uint32_t)__float2int_rn(__uint_as_float(a) * __uint_as_float((uint32_t)(127 + BIAS - 1 + MBITS) << 23));
+  } else {
+    const uint32_t r = a + ((a >> SHIFT) & 1u) + ((1u << (SHIFT - 1)) - 1u);   // RNE on the cut bits
+    code = (r - ((uint32_t)(127 - BIAS) << 23)) >> SHIFT;
+  }
+  if (code > (uint32_t)MAXCODE || a >= 0x7F800000u) code = MAXCODE;            // saturate (also +-inf)
+  return sign | code;
+}
+
+// SRC: 0 = fp16, 1 = bf16, 2 = fp32;  KIND: 0 = e4m3fn, 1 = e5m2
+template <int SRC, int KIND>
+__global__ __launch_bounds__(512) void reshape_and_cache_fp8_kernel(
+    const uint8_t* __restrict__ key, const uint8_t* __restrict__ value,
+    uint8_t* __restrict__ key_cache, uint8_t* __restrict__ value_cache,
+    float* __restrict__ kv_metrics, const int64_t* __restrict__ slot_mapping,
+    const float* __restrict__ bias, int num_heads, int head_size, int bs, int64_t key_stride,
+    int64_t value_stride, float k_scale, float v_scale) {
+  const int64_t token = blockIdx.x;
+  const int n = num_heads * head_size;
+  auto load = [&](const uint8_t* base, int64_t idx) -> float {
+    if constexpr (SRC == 0) return __half2float(reinterpret_cast<const __half*>(base)[idx]);
+    else if constexpr (SRC == 1) return __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(base)[idx] << 16);
+    else return reinterpret_cast<const float*>(base)[idx];
+  };
+  auto cvt = [&](float x, float scale) -> uint8_t {
+    const float y = __fdiv_rn(x, scale);
+    if constexpr (KIND == 0) return (uint8_t)f32_to_fp8_satfinite<3, 7, 0x7E>(y);
+    else return (uint8_t)f32_to_fp8_satfinite<2, 15, 0x7B>(y);
+  };
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int head = i / head_size, d = i % head_size;
+    const int64_t slot = slot_mapping[token * num_heads + head];
+    if (slot < 0) continue;
+    if (d == 0) kv_metrics[slot] = bias[head];
+    const int64_t blk = slot / bs;
+    const int off = (int)(slot % bs);
+    const int64_t block_bytes = (int64_t)head_size * bs;        // 1 byte per element
+    value_cache[blk * block_bytes + (int64_t)d * bs + off] = cvt(load(value, token * value_stride + i), v_scale);
+    key_cache[blk * block_bytes + ((int64_t)(d / 16) * bs + off) * 16 + d % 16] = cvt(load(key, token * key_stride + i), k_scale);
+  }
+}
+
 }  // namespace kvc
 
 extern "C" int kvc_aggregate_decode(float* metrics, float* temp_metrics, int64_t num_slots,
@@ -210,9 +381,21 @@ extern "C" int kvc_reshape_and_cache(const void* key, const void* value, void* k
   if (head_size % (16 / elem_bytes) != 0)
     return fail_invalid("Unsupported head size: " + std::to_string(head_size));
   if (num_tokens <= 0) return KVC_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t items = num_tokens * num_heads;
+#define KVC_RCB(HD, BS, E)                                                                          \
+  hipLaunchKernelGGL((reshape_and_cache_blocks_kernel<HD, BS, E>), dim3((unsigned)((items + 255) / 256)), \
+                     dim3(256), 0, s, (const uint8_t*)key, (const uint8_t*)value, (uint8_t*)key_cache, \
+                     (uint8_t*)value_cache, kv_metrics, slot_mapping, kv_metric_head_bias, num_tokens, \
+                     num_heads, key_stride, value_stride)
+  const bool key_ok = ((uintptr_t)key % 16 == 0) && ((key_stride * elem_bytes) % 16 == 0);
+  if (key_ok && head_size == 128 && block_size == 16 && elem_bytes == 2) { KVC_RCB(128, 16, 2); return check_launch("kvcompress_reshape_and_cache"); }
+  if (key_ok && head_size == 128 && block_size == 32 && elem_bytes == 2) { KVC_RCB(128, 32, 2); return check_launch("kvcompress_reshape_and_cache"); }
+  if (key_ok && head_size == 64 && block_size == 16 && elem_bytes == 2) { KVC_RCB(64, 16, 2); return check_launch("kvcompress_reshape_and_cache"); }
+  if (key_ok && head_size == 128 && block_size == 16 && elem_bytes == 4) { KVC_RCB(128, 16, 4); return check_launch("kvcompress_reshape_and_cache"); }
+#undef KVC_RCB
   const int n = num_heads * head_size;
   const int threads = n < 512 ? ((n + 63) / 64 * 64) : 512;
-  hipStream_t s = (hipStream_t)stream;
 #define KVC_RC(E)                                                                                   \
   hipLaunchKernelGGL(reshape_and_cache_kernel<E>, dim3((unsigned)num_tokens), dim3(threads), 0, s,   \
                      (const uint8_t*)key, (const uint8_t*)value, (uint8_t*)key_cache,               \
@@ -221,4 +404,37 @@ extern "C" int kvc_reshape_and_cache(const void* key, const void* value, void* k
   if (elem_bytes == 1) KVC_RC(1); else if (elem_bytes == 2) KVC_RC(2); else KVC_RC(4);
 #undef KVC_RC
   return check_launch("kvcompress_reshape_and_cache");
+}
+
+extern "C" int kvc_reshape_and_cache_fp8(const void* key, const void* value, void* key_cache,
+                                         void* value_cache, float* kv_metrics,
+                                         const int64_t* slot_mapping, const float* kv_metric_head_bias,
+                                         int64_t num_tokens, int32_t num_heads, int32_t head_size,
+                                         int32_t block_size, int32_t src_dtype, int32_t fp8_kind,
+                                         int64_t key_stride, int64_t value_stride, float k_scale,
+                                         float v_scale, kvc_stream_t stream) {
+  using namespace kvc;
+  if (src_dtype < 0 || src_dtype > 2) return fail_invalid("Unsupported input type of kv cache");
+  if (fp8_kind < 0 || fp8_kind > 1) return fail_invalid("Unsupported data type of kv cache");
+  if (head_size % 16 != 0) return fail_invalid("Unsupported head size: " + std::to_string(head_size));
+  if (num_tokens <= 0) return KVC_OK;
+  const int n = num_heads * head_size;
+  const int threads = n < 512 ? ((n + 63) / 64 * 64) : 512;
+  hipStream_t s = (hipStream_t)stream;
+#define KVC_RC8(SRC, KIND)                                                                           \
+  hipLaunchKernelGGL((reshape_and_cache_fp8_kernel<SRC, KIND>), dim3((unsigned)num_tokens),           \
+                     dim3(threads), 0, s, (const uint8_t*)key, (const uint8_t*)value,                \
+                     (uint8_t*)key_cache, (uint8_t*)value_cache, kv_metrics, slot_mapping,            \
+                     kv_metric_head_bias, num_heads, head_size, block_size, key_stride, value_stride, \
+                     k_scale, v_scale)
+  switch (src_dtype * 2 + fp8_kind) {
+    case 0: KVC_RC8(0, 0); break;
+    case 1: KVC_RC8(0, 1); break;
+    case 2: KVC_RC8(1, 0); break;
+    case 3: KVC_RC8(1, 1); break;
+    case 4: KVC_RC8(2, 0); break;
+    default: KVC_RC8(2, 1); break;
+  }
+#undef KVC_RC8
+  return check_launch("kvcompress_reshape_and_cache(fp8)");
 }
