@@ -50,7 +50,7 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=1, help="sequences per GPU")
     ap.add_argument("--keep", type=float, default=0.5, help="max_cache_tokens / seq_len")
     ap.add_argument("--protected", type=int, default=32)
-    ap.add_argument("--metric-shape", default="perm", choices=["perm", "decay"])
+    ap.add_argument("--metric-shape", default="perm", choices=["perm", "decay", "oldest"])
     ap.add_argument("--mode", default="per_sequence", choices=["per_sequence", "reference"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-json", default=os.path.join(REPO, "profiles", "traffic.json"),
@@ -89,12 +89,13 @@ def build_workload(args, seed, device):
 
 def cpu_baseline(args):
     """The oracle (a port of the reference algorithm) on the host, bounded sample:
-    BASELINE.json configs[0] (4k-token cache, one sequence), one full S1+S2+S3 pass."""
+    the same shape as the GPU workload at an 8k-token cache (BASELINE.json configs[0] x2),
+    one sequence, one full S1+S2+S3 pass."""
     from oracle import kvc_oracle as orc
     from oracle import kvc_oracle_c as orc_c
     from vllm_kvcompress_amd.harness import synth
     L, H, bs, hd = args.layers, args.kv_heads, args.block_size, args.head_size
-    T = 4096
+    T = 8192
     st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs, seq_lens=[T + 1], seed=0,
                           protected=args.protected, spare_block_frac=0.02)
     evicted = [synth.evict_block_count(context_lens_lh=st.context_lens[:, 0, :], seq_len=T + 1,

@@ -30,7 +30,7 @@
 // accesses, which is correct for every independent move list, the only case the
 // reference defines (kvcompress_eviction_kernels.cu:358).
 //
-// Work distribution: a tile is KVC_TM consecutive moves of one head; a wave handles, in
+// Work distribution: a tile is 64 - bs consecutive moves of one head; a wave handles, in
 // order, the runs that START in its tile.  Move counts live in device memory, so
 // tiny planning kernels (tiles per head, exclusive scan, claims) let a fixed persistent
 // grid walk the tiles without host synchronisation.
@@ -39,10 +39,7 @@
 
 namespace kvc {
 
-#ifndef KVC_TM_VALUE
-#define KVC_TM_VALUE 32
-#endif
-constexpr int KVC_TM = KVC_TM_VALUE;  // moves per tile (one tile per wave)
+constexpr int KVC_TM_GENERIC = 32;    // moves per tile of the generic (byte-wise) kernel
 
 // native 16 B vector: HIP's uint4 is a struct whose copies lower to memcpy through a
 // private alloca, which the compiler then parks in LDS
@@ -50,9 +47,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------- planning
 __global__ __launch_bounds__(256) void compact_plan_tiles_kernel(int32_t* __restrict__ tiles,
-                                                                 const int32_t* __restrict__ count, int G) {
+                                                                 const int32_t* __restrict__ count, int G, int tm) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g < G) tiles[g] = (count[g] + KVC_TM - 1) / KVC_TM;
+  if (g < G) tiles[g] = (count[g] + tm - 1) / tm;
 }
 
 // single workgroup: in-place exclusive scan of tiles[0..G) -> prefix[0..G]
@@ -84,16 +81,16 @@ __global__ __launch_bounds__(1024) void compact_plan_scan_kernel(int32_t* __rest
 __global__ __launch_bounds__(256) void compact_plan_claims_kernel(
     uint32_t* __restrict__ claims, const int32_t* __restrict__ moves,
     const int32_t* __restrict__ count, const int32_t* __restrict__ offs,
-    const int32_t* __restrict__ tile_prefix, int G, int bs) {
+    const int32_t* __restrict__ tile_prefix, int G, int bs, int tm) {
   const int total_tiles = tile_prefix[G];
   const int lane = lane_id();
   const int nw = gridDim.x * (blockDim.x / WAVE);
   for (int t = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE; t < total_tiles; t += nw) {
     const int g = upper_bound_minus1(tile_prefix, G, t);
     const int cnt = count[g];
-    const int j = (t - tile_prefix[g]) * KVC_TM + lane;
+    const int j = (t - tile_prefix[g]) * tm + lane;
     const int2* mv = reinterpret_cast<const int2*>(moves) + offs[g];
-    if (lane < KVC_TM && j < cnt) {
+    if (lane < tm && j < cnt) {
       const int dblk = mv[j].x / bs;
       if (j == 0 || mv[j - 1].x / bs != dblk) atomicAdd(&claims[dblk >> 2], 1u << (8 * (dblk & 3)));
     }
@@ -101,43 +98,12 @@ __global__ __launch_bounds__(256) void compact_plan_claims_kernel(
 }
 
 // ------------------------------------------------------------------------- block path
-// DPP quad permute with a compile-time pattern
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp_quad(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
-}
-
-// broadcast, inside every group of PR lanes, the value held by the group's lane `hs`
-// (hs wave-uniform, PR in {1,2,4})
-template <int PR>
-__device__ __forceinline__ uint32_t group_bcast(uint32_t v, int hs) {
-  if constexpr (PR == 1) return v;
-  if constexpr (PR == 2) return hs == 0 ? dpp_quad<0xA0>(v) : dpp_quad<0xF5>(v);   // [0,0,2,2] / [1,1,3,3]
-  if constexpr (PR == 4) {
-    switch (hs) {
-      case 0: return dpp_quad<0x00>(v);
-      case 1: return dpp_quad<0x55>(v);
-      case 2: return dpp_quad<0xAA>(v);
-      default: return dpp_quad<0xFF>(v);
-    }
-  }
-  return v;
-}
-
-__device__ __forceinline__ uint32_t pick_dword(const u32x4& q, int w) {   // w wave-uniform
-  uint32_t r = q.x;
-  r = (w == 1) ? q.y : r;
-  r = (w == 2) ? q.z : r;
-  r = (w == 3) ? q.w : r;
-  return r;
-}
-
 // v_bfi_b32: (mask & a) | (~mask & b)
 __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
   return (mask & a) | (~mask & b);
 }
 
-// NPL = 16 B pieces per lane of one block image; BS = block size; E = element bytes
+// NPL = 16 B pieces per lane of one block image
 template <int NPL>
 struct BlockImg { u32x4 p[NPL]; };
 
@@ -164,115 +130,64 @@ __device__ __forceinline__ void img_store(const BlockImg<NPL>& b, uint8_t* base,
   }
 }
 
-// V: move slot `so` of the source block image to slot `dsl` of the destination image
-template <int NPL, int BS, int E>
-__device__ __forceinline__ void apply_v(BlockImg<NPL>& d, const BlockImg<NPL>& s, int so, int dsl, int lane) {
-  constexpr int RB = BS * E;          // bytes per V row
-  constexpr int PR = RB / 16;         // pieces (lanes) per row
-  constexpr int EP = 16 / E;          // elements per piece
-  constexpr int PER = 4 / E;          // elements per dword
-  constexpr uint32_t EMASK = E == 4 ? 0xFFFFFFFFu : ((1u << (8 * E)) - 1u);
-  const int hs = so / EP, es = so % EP, hd_ = dsl / EP, ed = dsl % EP;
-  const int ws = es / PER, shs = (es % PER) * 8 * E;
-  const int wd = ed / PER, shd = (ed % PER) * 8 * E;
-  const bool mine = (lane & (PR - 1)) == hd_;
-  const uint32_t lmask = mine ? (EMASK << shd) : 0u;        // per-lane insert mask
-#pragma unroll
-  for (int i = 0; i < NPL; ++i) {
-    uint32_t val = (pick_dword(s.p[i], ws) >> shs) & EMASK;
-    val = group_bcast<PR>(val, hs) << shd;
-    if (wd == 0) d.p[i].x = bfi(lmask, val, d.p[i].x);
-    else if (wd == 1) d.p[i].y = bfi(lmask, val, d.p[i].y);
-    else if (wd == 2) d.p[i].z = bfi(lmask, val, d.p[i].z);
-    else d.p[i].w = bfi(lmask, val, d.p[i].w);
-  }
+// order LDS traffic between the lanes of one wave (no other wave shares the tile)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// K: piece index = row*BS + slot, so a slot's pieces sit in lanes with (lane % BS) == slot
-// (BS <= 64, power of two).  Move whole 16 B pieces between lanes of the same BS-lane group.
-template <int N>
-__device__ __forceinline__ uint32_t dpp_row_ror(uint32_t v) {       // lane l <- lane (l - N) mod 16
-  if constexpr (N == 0) return v;
-  else return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + N, 0xf, 0xf, false);
-}
-
-template <int NPL, int N>
-__device__ __forceinline__ void apply_k_ror(BlockImg<NPL>& d, const BlockImg<NPL>& s, bool mine) {
-#pragma unroll
-  for (int i = 0; i < NPL; ++i) {
-    const uint32_t x = dpp_row_ror<N>(s.p[i].x), y = dpp_row_ror<N>(s.p[i].y);
-    const uint32_t z = dpp_row_ror<N>(s.p[i].z), w = dpp_row_ror<N>(s.p[i].w);
-    d.p[i].x = mine ? x : d.p[i].x;
-    d.p[i].y = mine ? y : d.p[i].y;
-    d.p[i].z = mine ? z : d.p[i].z;
-    d.p[i].w = mine ? w : d.p[i].w;
-  }
-}
-
-template <int NPL, int BS>
-__device__ __forceinline__ void apply_k(BlockImg<NPL>& d, const BlockImg<NPL>& s, int so, int dsl, int lane) {
-  const bool mine = (lane & (BS - 1)) == dsl;
-  if constexpr (BS == 16) {
-    // a 16-lane DPP row is exactly one K row: rotate so that lane dsl receives lane so
-    switch ((dsl - so) & 15) {               // wave-uniform
-      case 0: apply_k_ror<NPL, 0>(d, s, mine); break;
-      case 1: apply_k_ror<NPL, 1>(d, s, mine); break;
-      case 2: apply_k_ror<NPL, 2>(d, s, mine); break;
-      case 3: apply_k_ror<NPL, 3>(d, s, mine); break;
-      case 4: apply_k_ror<NPL, 4>(d, s, mine); break;
-      case 5: apply_k_ror<NPL, 5>(d, s, mine); break;
-      case 6: apply_k_ror<NPL, 6>(d, s, mine); break;
-      case 7: apply_k_ror<NPL, 7>(d, s, mine); break;
-      case 8: apply_k_ror<NPL, 8>(d, s, mine); break;
-      case 9: apply_k_ror<NPL, 9>(d, s, mine); break;
-      case 10: apply_k_ror<NPL, 10>(d, s, mine); break;
-      case 11: apply_k_ror<NPL, 11>(d, s, mine); break;
-      case 12: apply_k_ror<NPL, 12>(d, s, mine); break;
-      case 13: apply_k_ror<NPL, 13>(d, s, mine); break;
-      case 14: apply_k_ror<NPL, 14>(d, s, mine); break;
-      default: apply_k_ror<NPL, 15>(d, s, mine); break;
-    }
-  } else {
-    const int src_lane4 = ((lane & ~(BS - 1)) | so) * 4;
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-      const uint32_t x = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)s.p[i].x);
-      const uint32_t y = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)s.p[i].y);
-      const uint32_t z = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)s.p[i].z);
-      const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)s.p[i].w);
-      d.p[i].x = mine ? x : d.p[i].x;
-      d.p[i].y = mine ? y : d.p[i].y;
-      d.p[i].z = mine ? z : d.p[i].z;
-      d.p[i].w = mine ? w : d.p[i].w;
-    }
-  }
+template <int E>
+__device__ __forceinline__ uint32_t lds_elem(const uint8_t* p) {
+  if constexpr (E == 1) return *p;
+  else if constexpr (E == 2) return *reinterpret_cast<const uint16_t*>(p);
+  else return *reinterpret_cast<const uint32_t*>(p);
 }
 
 // HD = head size, BS = block size, E = element bytes.  256 threads = 4 independent waves,
-// every wave owns its own tile of KVC_TM consecutive moves and handles the runs that START
+// every wave owns its own tile of tm = 64 - bs consecutive moves and handles the runs that START
 // in it, in order, so a source block that feeds two consecutive runs is fetched once.
+//
+// Patching (per run, per source block feeding it):
+//  * V: the source block image is parked in a per-wave LDS tile with rows padded to RB+4
+//    bytes (conflict-free column access); a move is then, per destination piece, one
+//    ds_read of the element + one shift + one v_bfi under a per-lane mask.
+//  * K: a slot is a whole 16 B piece per K row and lives in the lanes with
+//    (lane % BS) == slot.  The moves of the segment only record, per lane, which source slot
+//    it receives; ONE ds_bpermute pass over the source image then moves all pieces.
+//  * metrics / positions: 16-lane rows, v_readlane + select.
 template <int HD, int BS, int E>
 __global__ __launch_bounds__(256) void compact_runs_kernel(
     uint8_t* __restrict__ k_cache, uint8_t* __restrict__ v_cache, float* __restrict__ metrics,
     int32_t* __restrict__ positions, const int32_t* __restrict__ moves,
     const int32_t* __restrict__ count, const int32_t* __restrict__ offs,
     const uint32_t* __restrict__ claims, const int32_t* __restrict__ tile_prefix, int G,
-    int phases) {
+    int tm, int phases) {
   static_assert(BS <= 32 && (BS & (BS - 1)) == 0, "block size must be a power of two <= 32");
-  static_assert(KVC_TM + BS <= 64, "tile + look-ahead + look-behind must fit one wave");
   constexpr int64_t BLOCK_BYTES = (int64_t)HD * BS * E;
   constexpr int NPL = (int)(BLOCK_BYTES / 16 / 64);          // 16 B pieces per lane
   static_assert(BLOCK_BYTES % (16 * 64) == 0, "block image must be a multiple of 1 KiB");
   constexpr int KR = HD * E / 16;                            // K rows (16 B pieces per slot)
-  constexpr int RB = BS * E;
+  constexpr int RB = BS * E;                                 // bytes per V row
+  constexpr int PR = RB / 16;                                // pieces (lanes) per V row
+  constexpr int EP = 16 / E;                                 // elements per piece
+  constexpr int PER = 4 / E;                                 // elements per dword
+  constexpr int RBP = RB + 4;                                // padded LDS row
+  constexpr uint32_t EMASK = E == 4 ? 0xFFFFFFFFu : ((1u << (8 * E)) - 1u);
+  __shared__ __attribute__((aligned(16))) uint8_t vtile_s[4][HD * RBP];
   const int lane = threadIdx.x & 63;
+  uint8_t* vtile = vtile_s[threadIdx.x >> 6];
+  int rowoff[NPL];                                           // LDS offset of this lane's V rows
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) rowoff[i] = ((i * 64 + lane) / PR) * RBP;
+  const int my_pr = lane & (PR - 1);
   const int total_tiles = tile_prefix[G];
   const int nw = gridDim.x * (blockDim.x / WAVE);
   for (int t = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x >> 6); t < total_tiles; t += nw) {
     const int g = upper_bound_minus1(tile_prefix, G, t);
     const int cnt = count[g];
-    const int j0 = (t - tile_prefix[g]) * KVC_TM;
-    const int j1 = min(cnt, j0 + KVC_TM);
+    const int j0 = (t - tile_prefix[g]) * tm;
+    const int j1 = min(cnt, j0 + tm);
     const int2* __restrict__ mv = reinterpret_cast<const int2*>(moves) + offs[g];
     // one move per lane: lane q <-> move jbase + q (one look-behind, BS-1 look-ahead)
     const int jbase = j0 - 1;
@@ -289,10 +204,10 @@ __global__ __launch_bounds__(256) void compact_runs_kernel(
     const int jl = jbase + lane;
     unsigned long long starts = __ballot(jl >= j0 && jl < j1 && (jl == 0 || myblk != left));
 
-    BlockImg<NPL> kd, vd, ks, vs;
+    BlockImg<NPL> kd, vd, ks;
     float md = 0.f, ms = 0.f;
     int pd = 0, ps = 0;
-    int cur_sblk = -1;                                        // source block held in ks/vs/ms/ps
+    int cur_sblk = -1;                                        // source block held in ks / LDS / ms / ps
     while (starts) {
       const int jr = jbase + __ffsll((long long)starts) - 1;  // first move of the run
       starts &= starts - 1;
@@ -311,22 +226,65 @@ __global__ __launch_bounds__(256) void compact_runs_kernel(
           if (phases & 4) img_load<NPL>(vd, vd_p, lane);
           if ((phases & 1) && lane < BS) { md = metrics[(int64_t)dblk * BS + lane]; pd = positions[(int64_t)dblk * BS + lane]; }
         }
-        for (int j = jr; j < je; ++j) {
-          const int sy = MY(j), sblk = sy / BS;
+        int j = jr;
+        while (j < je) {
+          const int sblk = MY(j) / BS;
           if (sblk != cur_sblk) {
             if (phases & 2) img_load<NPL>(ks, k_cache + (int64_t)sblk * BLOCK_BYTES, lane);
-            if (phases & 4) img_load<NPL>(vs, v_cache + (int64_t)sblk * BLOCK_BYTES, lane);
             if ((phases & 1) && lane < BS) { ms = metrics[(int64_t)sblk * BS + lane]; ps = positions[(int64_t)sblk * BS + lane]; }
+            if (phases & 4) {
+              BlockImg<NPL> vs;
+              img_load<NPL>(vs, v_cache + (int64_t)sblk * BLOCK_BYTES, lane);
+              wave_lds_sync();                               // earlier reads of the tile are done
+#pragma unroll
+              for (int i = 0; i < NPL; ++i) {
+                uint32_t* dst = reinterpret_cast<uint32_t*>(vtile + rowoff[i] + my_pr * 16);
+                dst[0] = vs.p[i].x; dst[1] = vs.p[i].y; dst[2] = vs.p[i].z; dst[3] = vs.p[i].w;
+              }
+              wave_lds_sync();
+            }
             cur_sblk = sblk;
           }
-          const int so = sy % BS, dsl = MX(j) % BS;
-          if (phases & 2) apply_k<NPL, BS>(kd, ks, so, dsl, lane);
-          if (phases & 4) apply_v<NPL, BS, E>(vd, vs, so, dsl, lane);
-          if (phases & 1) {
-            const int mval = __builtin_amdgcn_readlane(__builtin_bit_cast(int, ms), so);
-            const int pval = __builtin_amdgcn_readlane(ps, so);
-            md = lane == dsl ? __builtin_bit_cast(float, mval) : md;
-            pd = lane == dsl ? pval : pd;
+          int ksrc = -1;                                      // per lane: source slot it receives
+          while (j < je) {                                    // the moves fed by this source block
+            const int sy = MY(j);
+            if (sy / BS != sblk) break;
+            const int so = sy % BS, dsl = MX(j) % BS;
+            ksrc = (lane & (BS - 1)) == dsl ? so : ksrc;
+            if (phases & 4) {
+              const int ed = dsl % EP, wd = ed / PER, shd = (ed % PER) * 8 * E;
+              const uint32_t lmask = (my_pr == dsl / EP) ? (EMASK << shd) : 0u;
+#pragma unroll
+              for (int i = 0; i < NPL; ++i) {
+                const uint32_t val = lds_elem<E>(vtile + rowoff[i] + so * E) << shd;
+                if (wd == 0) vd.p[i].x = bfi(lmask, val, vd.p[i].x);
+                else if (wd == 1) vd.p[i].y = bfi(lmask, val, vd.p[i].y);
+                else if (wd == 2) vd.p[i].z = bfi(lmask, val, vd.p[i].z);
+                else vd.p[i].w = bfi(lmask, val, vd.p[i].w);
+              }
+            }
+            if (phases & 1) {
+              const int mval = __builtin_amdgcn_readlane(__builtin_bit_cast(int, ms), so);
+              const int pval = __builtin_amdgcn_readlane(ps, so);
+              md = lane == dsl ? __builtin_bit_cast(float, mval) : md;
+              pd = lane == dsl ? pval : pd;
+            }
+            ++j;
+          }
+          if (phases & 2) {                                   // one permute pass moves all K pieces
+            const bool take = ksrc >= 0;
+            const int src_lane4 = ((lane & ~(BS - 1)) | (take ? ksrc : (lane & (BS - 1)))) * 4;
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) {
+              const uint32_t x = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)ks.p[i].x);
+              const uint32_t y = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)ks.p[i].y);
+              const uint32_t z = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)ks.p[i].z);
+              const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)ks.p[i].w);
+              kd.p[i].x = take ? x : kd.p[i].x;
+              kd.p[i].y = take ? y : kd.p[i].y;
+              kd.p[i].z = take ? z : kd.p[i].z;
+              kd.p[i].w = take ? w : kd.p[i].w;
+            }
           }
         }
         if (phases & 2) img_store<NPL>(kd, kd_p, lane);
@@ -370,8 +328,8 @@ __global__ __launch_bounds__(256) void compact_generic_kernel(
   for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
     const int g = upper_bound_minus1(tile_prefix, G, t);
     const int cnt = count[g];
-    const int j0 = (t - tile_prefix[g]) * KVC_TM;
-    const int j1 = min(cnt, j0 + KVC_TM);
+    const int j0 = (t - tile_prefix[g]) * KVC_TM_GENERIC;
+    const int j1 = min(cnt, j0 + KVC_TM_GENERIC);
     const int2* __restrict__ mv = reinterpret_cast<const int2*>(moves) + offs[g];
     for (int j = j0 + tid; j < j1; j += blockDim.x) {
       const int2 m = mv[j];
@@ -435,19 +393,25 @@ extern "C" int kvc_execute_cache_moves(void* k_cache, void* v_cache, float* kv_m
   const int G = total_heads;
   const int grid = 256 * 8;     // persistent: 256 CUs x 8 workgroups of 4 independent waves
   (void)hipMemsetAsync(claims, 0, claims_bytes(num_blocks), s);
+  // a wave holds one move per lane: tile + look-behind + (bs-1) look-ahead <= 64 lanes
+  const int combo = head_size * 10000 + block_size * 100 + elem_bytes;   // block-path instantiations
+  const bool shape_fast = x * elem_bytes == 16 &&
+      (combo == 1281602 || combo == 1283201 || combo == 1283202 || combo == 1281601 ||
+       combo == 1281604 || combo == 641602 || combo == 2561602);
+  const int tm = shape_fast ? 64 - block_size : KVC_TM_GENERIC;
   hipLaunchKernelGGL(compact_plan_tiles_kernel, dim3((G + 255) / 256), dim3(256), 0, s, prefix,
-                     cache_moves_count, G);
+                     cache_moves_count, G, tm);
   hipLaunchKernelGGL(compact_plan_scan_kernel, dim3(1), dim3(1024), 0, s, prefix, G);
   hipLaunchKernelGGL(compact_plan_claims_kernel, dim3(grid), dim3(256), 0, s, claims, cache_moves_idx,
-                     cache_moves_count, evicted_kv_offsets, prefix, G, block_size);
+                     cache_moves_count, evicted_kv_offsets, prefix, G, block_size, tm);
   uint8_t* k = reinterpret_cast<uint8_t*>(k_cache);
   uint8_t* v = reinterpret_cast<uint8_t*>(v_cache);
 #define KVC_RUNS(HD, BS, E)                                                                      \
   hipLaunchKernelGGL((compact_runs_kernel<HD, BS, E>), dim3(256 * 4), dim3(256), 0, s, k, v,     \
                      kv_metrics, kv_position, cache_moves_idx, cache_moves_count,                \
-                     evicted_kv_offsets, claims, prefix, G, g_compact_phases)
-  bool fast = true;
-  if (x * elem_bytes != 16) fast = false;   // block path assumes 16 B K vectors
+                     evicted_kv_offsets, claims, prefix, G, tm, g_compact_phases)
+  bool fast = shape_fast;
+  if (!fast) {}
   else if (head_size == 128 && block_size == 16 && elem_bytes == 2) KVC_RUNS(128, 16, 2);
   else if (head_size == 128 && block_size == 32 && elem_bytes == 1) KVC_RUNS(128, 32, 1);
   else if (head_size == 128 && block_size == 32 && elem_bytes == 2) KVC_RUNS(128, 32, 2);

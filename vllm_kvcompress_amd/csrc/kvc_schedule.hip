@@ -591,12 +591,9 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     // read from L2); small heads take a small buffer so that several workgroups share a CU
     const int64_t avg = p.total_slots / G;
     int lds_cap = avg <= 3072 ? 4096 : (avg <= 12288 ? 16384 : 32768);
-    static bool attr_set = false;
-    if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in (gfx950 has 160 KiB per CU)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(select_emit_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
-      attr_set = true;
-    }
+    // > 64 KiB of dynamic LDS needs the opt-in (gfx950 has 160 KiB per CU); per device, cheap
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(select_emit_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
     hipLaunchKernelGGL(select_emit_kernel, dim3(G), dim3(SEL_THREADS), (size_t)lds_cap * 4, s, p, ws, lds_cap);
   }
   return check_launch("schedule_evictions");

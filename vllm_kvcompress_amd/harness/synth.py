@@ -108,7 +108,9 @@ def make_state(
                   exercise the canonical tie order); default is tie-free.
     metric_shape  "perm": per-sequence random permutation cast to f32;
                   "decay": permutation re-ranked so that older positions tend to
-                  carry smaller metrics (still tie-free).
+                  carry smaller metrics (still tie-free);
+                  "oldest": metric rank == position rank (evict-oldest policy, the
+                  fully clustered extreme; tie-free).
     """
     rng = np.random.default_rng(seed)
     L, H, bs, B = num_layers, num_kv_heads, block_size, len(seq_lens)
@@ -184,6 +186,12 @@ def make_state(
         assert n_seq <= 2 ** 24, "float32 permutation is exact only up to 2^24 slots/seq"
         if tie_levels is None:
             vals = rng.permutation(n_seq).astype(np.float32)
+            if metric_shape == "oldest":
+                allpos = np.concatenate([positions[blk].reshape(-1) for blk, _ in seq_slots])
+                order = np.argsort(allpos, kind="stable")
+                ranked = np.empty(n_seq, dtype=np.float32)
+                ranked[order] = np.arange(n_seq, dtype=np.float32)
+                vals = ranked
             if metric_shape == "decay":
                 # re-rank: smaller metrics go (noisily) to older positions
                 allpos = np.concatenate([positions[blk].reshape(-1) for blk, _ in seq_slots])
