@@ -2,7 +2,8 @@
 
 * C1 (Llama-3-8B shape, 4k cache, 1 M slots): complete oracle comparison (NumPy schedule +
   C move/compaction restatement), bit-exact.
-* C2 (32k cache, 8.4 M slots, 4 GiB of K/V): size-independent properties, after the
+* C2 (fp16, bs16, 32k cache, 8.4 M slots, 4 GiB of K/V) and C5 (fp8, bs32, 64k cache,
+  16.8 M slots, 4 GiB): size-independent properties, after the
   reference's own test (tests/kernels/test_kvcompress_eviction.py:906-924, 1107-1218,
   1224-1226): freed blocks == requested; per-head evicted indices ascending + padded; no
   evicted KV is a move source; EVERY surviving KV is bit-equal at its final slot (K/V are
@@ -74,12 +75,22 @@ def _hash16(ids, salt):
     return ((x >> 7) & 0xFFFF).to(torch.int16)
 
 
-@pytest.mark.parametrize("keep", [0.5, 0.125])
-def test_c2_properties(keep):
-    T = 32768
+FULL_SIZE_CASES = [
+    # (T, block_size, cache dtype, keep)   config 2 (fp16, bs16, 32k) and config 5 (fp8, bs32, 64k)
+    (32768, 16, torch.int16, 0.5),
+    (32768, 16, torch.int16, 0.125),
+    (65536, 32, torch.uint8, 0.5),
+]
+
+
+@pytest.mark.parametrize("T,BS,cdtype,keep", FULL_SIZE_CASES)
+def test_full_size_properties(T, BS, cdtype, keep):
+    X = 16 // torch.empty((), dtype=cdtype).element_size()      # elements per 16 B K vector
     st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=BS, seq_lens=[T + 1], seed=1,
                           protected=32, spare_block_frac=0.02)
-    evicted = _evict(st, keep, T)
+    evicted = [synth.evict_block_count(context_lens_lh=st.context_lens[:, 0, :], seq_len=T + 1,
+                                       block_size=BS, protected_window_size=32,
+                                       max_cache_tokens=int(T * keep))]
     NB, N = st.num_blocks, st.total_slots
     ds = hdev.upload(st, DEV)
     dev = torch.device(DEV)
@@ -90,13 +101,13 @@ def test_c2_properties(keep):
     alloc = seq_b >= 0
     off_of_blk = torch.where(alloc, offs_flat[g_of_blk.clamp(min=0)], torch.zeros_like(g_of_blk))
     ids0 = off_of_blk[:, None] + ds.cm.token_positions.long()                      # [NB,bs]
-    k = torch.empty((NB, HD // 8, BS, 8), dtype=torch.int16, device=dev)
-    v = torch.empty((NB, HD, BS), dtype=torch.int16, device=dev)
-    for r in range(HD // 8):
-        for e in range(8):
-            k[:, r, :, e] = _hash16(ids0, 1000 + r * 8 + e)
+    k = torch.empty((NB, HD // X, BS, X), dtype=cdtype, device=dev)
+    v = torch.empty((NB, HD, BS), dtype=cdtype, device=dev)
+    for r in range(HD // X):
+        for e in range(X):
+            k[:, r, :, e] = _hash16(ids0, 1000 + r * X + e).to(cdtype)
     for d in range(HD):
-        v[:, d, :] = _hash16(ids0, 5000 + d)
+        v[:, d, :] = _hash16(ids0, 5000 + d).to(cdtype)
     pos0 = ds.cm.token_positions.clone()
 
     eli, ekc, ebc, cmi, cmc = hdev.schedule(ds, st, evicted)
@@ -138,11 +149,11 @@ def test_c2_properties(keep):
     lam_blk = lbn[:, None] * BS + torch.arange(BS, device=dev)[None, :]
     live_slot = alloc[:, None] & (lam_blk < new_len[g_of_blk.clamp(min=0)][:, None])
     ids1 = off_of_blk[:, None] + ds.cm.token_positions.long()
-    for r in range(HD // 8):
-        for e in range(8):
-            assert bool((k[:, r, :, e] == _hash16(ids1, 1000 + r * 8 + e))[live_slot].all()), (r, e)
+    for r in range(HD // X):
+        for e in range(X):
+            assert bool((k[:, r, :, e] == _hash16(ids1, 1000 + r * X + e).to(cdtype))[live_slot].all()), (r, e)
     for d in range(HD):
-        assert bool((v[:, d, :] == _hash16(ids1, 5000 + d))[live_slot].all()), d
+        assert bool((v[:, d, :] == _hash16(ids1, 5000 + d).to(cdtype))[live_slot].all()), d
     # final live positions are exactly the survivors: distinct per head, none evicted
     was_evicted_pos = torch.zeros(N, dtype=torch.bool, device=dev)
     was_evicted_pos[offs_flat[g_live] + lam] = True                                # position == lambda

@@ -361,6 +361,24 @@ __global__ __launch_bounds__(256) void compact_generic_kernel(
 // profiling hook (not part of the drop-in surface): bit0 metrics/positions, bit1 K, bit2 V
 static int g_compact_phases = 7;
 extern "C" void kvc_debug_set_compact_phases(int phases) { g_compact_phases = phases; }
+// measurement hook: HIP events recorded on the call's stream immediately before / after the
+// compaction kernel itself (not the planning kernels); pass NULLs to switch it off
+static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+extern "C" void kvc_debug_set_compact_events(void* start, void* stop) {
+  g_ev_start = (hipEvent_t)start;
+  g_ev_stop = (hipEvent_t)stop;
+}
+// event helpers so that a ctypes caller uses the SAME HIP runtime instance as the kernels
+extern "C" void* kvc_debug_event_create(void) {
+  hipEvent_t e = nullptr;
+  return hipEventCreate(&e) == hipSuccess ? (void*)e : nullptr;
+}
+extern "C" float kvc_debug_event_elapsed_ms(void* start, void* stop) {
+  float ms = -1.0f;
+  if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess) return -1.0f;
+  if (hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) return -1.0f;
+  return ms;
+}
 
 static size_t claims_bytes(int64_t num_blocks) { return (size_t)((num_blocks + 3) / 4 + 1) * 4; }
 
@@ -410,6 +428,7 @@ extern "C" int kvc_execute_cache_moves(void* k_cache, void* v_cache, float* kv_m
   hipLaunchKernelGGL((compact_runs_kernel<HD, BS, E>), dim3(256 * 4), dim3(256), 0, s, k, v,     \
                      kv_metrics, kv_position, cache_moves_idx, cache_moves_count,                \
                      evicted_kv_offsets, claims, prefix, G, tm, g_compact_phases)
+  if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
   bool fast = shape_fast;
   if (!fast) {}
   else if (head_size == 128 && block_size == 16 && elem_bytes == 2) KVC_RUNS(128, 16, 2);
@@ -426,5 +445,6 @@ extern "C" int kvc_execute_cache_moves(void* k_cache, void* v_cache, float* kv_m
                        kv_position, cache_moves_idx, cache_moves_count, evicted_kv_offsets, prefix,
                        G, block_size, head_size, elem_bytes, x);
   }
+  if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
   return check_launch("execute_cache_moves");
 }
