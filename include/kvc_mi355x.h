@@ -218,6 +218,32 @@ int kvc_reshape_and_cache_fp8(const void* key, const void* value, void* key_cach
                               int64_t value_stride, float k_scale, float v_scale,
                               kvc_stream_t stream);
 
+/* ---------------------------------------------------------------------------------
+ * F2  the block-state side of a compression step
+ * replaces BlockSpaceManagerKVC.free_compressed_blocks and what it calls
+ *   (vllm/kvcompress/block_manager.py:466-530 -> block.py:367-379 last_n_allocated_block_mask,
+ *    block.py:184-210 remove_trailing_blocks, block_manager.py:112-118 allocator.free,
+ *    vllm/kvcompress/metrics.py:366-370 remove_metadata)
+ * For batch position b (batch slot seq_slots[b]) and every (layer, head): the last
+ * freed_block_count[b,l,h] allocated blocks (logical order) are freed: listed in
+ * freed_blocks in the reference's order (layer, batch position, head, logical block
+ * ascending), free_mask[blk] = 1 (may be NULL), seq_index_by_block[blk] = -1, and
+ * context_lens[l, slot, h] -= clamp(n*bs - (bs - hanging), 0).
+ * context_lens [L, max_num_seqs, H], block_tables [L, max_num_seqs, H, M] are the FULL
+ * state tensors (BlockState, block.py:95-126); freed_block_count is [B, L, H] as produced
+ * by schedule_evictions.  *freed_total = number of freed blocks (<= freed_capacity written).
+ * --------------------------------------------------------------------------------- */
+size_t kvc_free_compressed_blocks_workspace_bytes(int32_t num_layers, int32_t batch,
+                                                  int32_t num_kv_heads);
+int kvc_free_compressed_blocks(int32_t* context_lens, int32_t* seq_index_by_block,
+                               uint8_t* free_mask, int32_t* freed_blocks, int32_t freed_capacity,
+                               int32_t* freed_total, const int32_t* block_tables,
+                               const int32_t* freed_block_count, const int32_t* seq_slots,
+                               int32_t num_layers, int32_t batch, int32_t max_num_seqs,
+                               int32_t num_kv_heads, int32_t max_num_blocks_per_seq,
+                               int32_t block_size, void* workspace, size_t workspace_bytes,
+                               kvc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

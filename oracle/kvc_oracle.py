@@ -407,3 +407,34 @@ def reshape_and_cache_kvc_fp8(key, value, key_cache, value_cache, kv_metrics, sl
             b, o = divmod(s, bs)
             key_cache[b, :, o, :] = kq[t, h].reshape(hd // 16, 16)
             value_cache[b, :, o] = vq[t, h]
+
+
+# --------------------------------------------------------------------------------------
+# block-state side of a compression step (F2)
+#   free_compressed_blocks          vllm/kvcompress/block_manager.py:466-530
+#   last_n_allocated_block_mask     vllm/kvcompress/block.py:367-379
+#   remove_trailing_blocks          vllm/kvcompress/block.py:184-210
+#   ParallelBlockAllocator.free     vllm/kvcompress/block_manager.py:112-118
+#   remove_metadata                 vllm/kvcompress/metrics.py:366-370
+# --------------------------------------------------------------------------------------
+def free_compressed_blocks(block_tables, context_lens, seq_indices, freed_block_count_blh,
+                           seq_index_by_block, block_size, free_mask=None):
+    """In place on context_lens / seq_index_by_block / free_mask; returns freed blocks in the
+    reference's order (boolean mask over [L,B,H,M] -> (l, b, h, j ascending))."""
+    bs = block_size
+    L, S, H, M = block_tables.shape
+    sel = list(seq_indices)
+    ctx = context_lens[:, sel, :].astype(np.int64)                      # [L,B,H]
+    block_counts = (ctx + bs - 1) // bs                                 # get_block_counts
+    n = freed_block_count_blh.transpose(1, 0, 2).astype(np.int64)       # stack(dim=1) -> [L,B,H]
+    j = np.arange(M)[None, None, None, :]
+    mask = (j < block_counts[..., None]) & (j >= (block_counts - n)[..., None])
+    freed = block_tables[:, sel][mask]
+    if free_mask is not None:
+        free_mask[freed] = True
+    rem = ctx % bs
+    hang = np.where(rem == 0, bs, rem)                                  # get_hanging_token_counts
+    removed = np.clip(n * bs - (bs - hang), 0, None)
+    context_lens[:, sel, :] -= removed.astype(context_lens.dtype)
+    seq_index_by_block[freed] = -1
+    return freed.astype(np.int32)

@@ -15,7 +15,8 @@ def pytest_configure(config):
 
 
 def golden_cases():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR)
+                  if f.endswith(".npz") and not f.startswith("blockstate_"))
 
 
 @pytest.fixture(scope="session")

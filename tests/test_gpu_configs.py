@@ -143,3 +143,25 @@ def test_config5_full_query_range_prefill_metrics():
         probs = torch.softmax(w + mask, dim=-1).numpy()
         orc.prefill_metric_epilogue(want, probs, l, 3, True, False, True)
     np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_free_compressed_blocks_device(case):
+    """F2 on device vs the reference-generated block-state vectors"""
+    from tests.helpers import load_golden
+    from vllm_kvcompress_amd.kvcompress.block_state import free_compressed_blocks
+    g = load_golden(f"blockstate_{case}")
+    NB = int(g["num_blocks"])
+    ctx = torch.from_numpy(g["context_lens"].copy()).to(DEV)
+    bt = torch.from_numpy(g["block_tables"].copy()).to(DEV)
+    seq_by = torch.zeros(NB, dtype=torch.int32, device=DEV)
+    free_mask = torch.zeros(NB, dtype=torch.bool, device=DEV)
+    freed = free_compressed_blocks(bt, ctx, [int(s) for s in g["seq_indices"]],
+                                   torch.from_numpy(g["freed_block_count"]).to(DEV), seq_by,
+                                   int(g["block_size"]), free_mask)
+    np.testing.assert_array_equal(freed.cpu().numpy(), g["ref_freed_blocks"])
+    np.testing.assert_array_equal(ctx.cpu().numpy(), g["ref_context_lens"])
+    want = np.zeros(NB, dtype=bool)
+    want[g["ref_freed_blocks"]] = True
+    np.testing.assert_array_equal(free_mask.cpu().numpy(), want)
+    np.testing.assert_array_equal(seq_by.cpu().numpy() == -1, want)

@@ -139,3 +139,19 @@ def test_fp8_encode_against_torch_casts():
         want = clipped.to(dt).view(torch.uint8).numpy()
         np.testing.assert_array_equal(got, want)
     assert orc.fp8_encode_satfinite(np.array([np.nan], np.float32), "e4m3")[0] & 0x7F == 0x7F
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_free_compressed_blocks_matches_reference_block_state(case):
+    """F2: oracle restatement vs vectors produced by the reference's own BlockState /
+    BlockStateView (oracle/gen_golden_blockstate.py)"""
+    g = load_golden(f"blockstate_{case}")
+    ctx = g["context_lens"].copy()
+    seq_by = np.zeros(int(g["num_blocks"]), dtype=np.int32)
+    free_mask = np.zeros(int(g["num_blocks"]), dtype=bool)
+    freed = orc.free_compressed_blocks(g["block_tables"], ctx, [int(s) for s in g["seq_indices"]],
+                                       g["freed_block_count"], seq_by, int(g["block_size"]), free_mask)
+    np.testing.assert_array_equal(freed, g["ref_freed_blocks"])
+    np.testing.assert_array_equal(ctx, g["ref_context_lens"])
+    assert np.array_equal(np.nonzero(free_mask)[0], np.sort(g["ref_freed_blocks"]))
+    assert np.array_equal(np.nonzero(seq_by == -1)[0], np.sort(g["ref_freed_blocks"]))

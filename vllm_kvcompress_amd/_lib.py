@@ -70,6 +70,11 @@ SYMBOLS = {
                                             c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
                                             c_int32, c_int32, c_int64, c_int64, c_float, c_float,
                                             c_void_p]),
+    "kvc_free_compressed_blocks_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "kvc_free_compressed_blocks": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                             c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                             c_size_t, c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,54 @@
+"""Device-side block-state update after a compression step.
+
+``free_compressed_blocks`` does, in two small kernels and without boolean-mask gathers,
+what ``BlockSpaceManagerKVC.free_compressed_blocks`` does through ``BlockStateView``,
+``ParallelBlockAllocator.free``, ``BlockState.remove_trailing_blocks`` and
+``CompressionMetrics.remove_metadata`` (vllm/kvcompress/block_manager.py:466-530,
+block.py:184-210, 367-379, metrics.py:366-370).
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from .. import _lib
+from .._custom_ops import _stream, workspace
+
+
+def free_compressed_blocks(
+    block_tables: torch.Tensor,          # [L, max_num_seqs, H, M] i32   (BlockState.block_tables)
+    context_lens: torch.Tensor,          # [L, max_num_seqs, H]    i32   (updated in place)
+    seq_indices: Sequence[int],          # batch slots of the compressed sequences (batch order)
+    freed_block_count: torch.Tensor,     # [B, L, H] i32  (evicted_block_count of schedule_evictions)
+    seq_index_by_block: torch.Tensor,    # [NB] i32  (CompressionMetrics; -1 written for freed blocks)
+    block_size: int,
+    free_mask: Optional[torch.Tensor] = None,   # [NB] bool (ParallelBlockAllocator.free_mask)
+) -> torch.Tensor:
+    """Returns the freed physical blocks (int32, the reference's order)."""
+    lib = _lib.load()
+    for n, t in (("block_tables", block_tables), ("context_lens", context_lens),
+                 ("freed_block_count", freed_block_count), ("seq_index_by_block", seq_index_by_block)):
+        if not t.is_cuda or t.dtype != torch.int32 or not t.is_contiguous():
+            raise RuntimeError(f"free_compressed_blocks: {n} must be a contiguous int32 HIP tensor")
+    L, S, H, M = block_tables.shape
+    B = len(seq_indices)
+    assert tuple(freed_block_count.shape) == (B, L, H)
+    dev = block_tables.device
+    slots = torch.tensor(list(seq_indices), dtype=torch.int32).to(dev, non_blocking=True)
+    cap = int(B * L * H * M)
+    freed = torch.empty((cap,), dtype=torch.int32, device=dev)
+    total = torch.zeros((1,), dtype=torch.int32, device=dev)
+    fm_ptr = None
+    if free_mask is not None:
+        if free_mask.dtype not in (torch.bool, torch.uint8) or not free_mask.is_cuda:
+            raise RuntimeError("free_compressed_blocks: free_mask must be a bool/uint8 HIP tensor")
+        fm_ptr = free_mask.data_ptr()
+    ws_bytes = lib.kvc_free_compressed_blocks_workspace_bytes(L, B, H)
+    ws = workspace(dev, ws_bytes, "free_compressed_blocks")
+    with torch.cuda.device(dev):
+        _lib.check(lib.kvc_free_compressed_blocks(
+            context_lens.data_ptr(), seq_index_by_block.data_ptr(), fm_ptr, freed.data_ptr(), cap,
+            total.data_ptr(), block_tables.data_ptr(), freed_block_count.data_ptr(), slots.data_ptr(),
+            L, B, S, H, M, int(block_size), ws.data_ptr(), ws.numel(), _stream(block_tables)))
+    return freed[:int(total.item())]       # exact size like the reference (one host sync)
