@@ -75,3 +75,33 @@ def oracle_pipeline(st: synth.PagedState, evicted_blocks, k_cache=None, v_cache=
         orc.execute_cache_moves(k2, v2, m2, p2, cmi, cmc, st.evicted_kv_offsets)
         out.update(k=k2, v=v2, metrics=m2, positions=p2)
     return out
+
+
+def reference_prefill_metrics_numpy(g):
+    """float32 restatement of the reference loop (flash_attn.py:1122-1211) around the
+    oracle's epilogue, on a golden case of oracle/gen_golden_aggregate.py."""
+    import torch
+    q = torch.from_numpy(g["q"].view(np.float16).copy())
+    k = torch.from_numpy(g["k"].view(np.float16).copy())
+    T, Hq, hd = q.shape
+    scale = hd ** -0.5
+    out = np.zeros((T, Hq), dtype=np.float32)
+    start = 0
+    for i, plen in enumerate(int(x) for x in g["prompt_lens"]):
+        end = start + plen
+        st = end - min(plen, int(g["n_observed"]))
+        blk = int(g["block"])
+        for l in range(st, end, blk):
+            qq = q[l:min(l + blk, end)]
+            nq = qq.shape[0]
+            q_off = l - start
+            # einsum in the query dtype, widened, THEN scaled in float32   (flash_attn.py:1186)
+            w = scale * torch.einsum("qhd,khd->hqk", qq, k[start:end]).float()
+            mask = torch.triu(torch.ones(nq, plen, dtype=torch.float16), diagonal=q_off + 1)
+            w = w + (mask * torch.finfo(torch.float16).min).float()
+            probs = torch.softmax(w, dim=-1).numpy()
+            orc.prefill_metric_epilogue(out[start:end], probs, q_off, int(g["buffer_len"][i]),
+                                        bool(int(g["use_l2"])), bool(int(g["use_average"])),
+                                        bool(int(g["use_maxpool"])))
+        start = end
+    return out

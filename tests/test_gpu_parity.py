@@ -420,3 +420,42 @@ def test_reshape_and_cache_kvc_fp8(dtype, kv_dtype, kind):
     np.testing.assert_array_equal(dk.cpu().numpy(), wk)
     np.testing.assert_array_equal(dv.cpu().numpy(), wv)
     np.testing.assert_array_equal(dm.cpu().numpy(), wm)
+
+
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
+def test_aggregation_golden_gpu(case):
+    """A2a/A2b on device vs the reference-generated vectors (1e-6 relative)"""
+    from tests.helpers import load_golden as lg
+    from vllm_kvcompress_amd.kvcompress.metrics import CompressionMetrics
+    g = lg(f"agg_decode_prefill_{case}")
+    NB, bs = g["metrics0"].shape
+    H, qpk = int(g["num_kv_heads"]), int(g["qpk"])
+    cm = CompressionMetrics(bs, 2, H, qpk, 1000, None, 0.0, device=DEV, use_l2=bool(int(g["use_l2"])))
+    cm.init_kv_metadata(NB)
+    cm.metrics.copy_(torch.from_numpy(g["metrics0"]))
+    cm.temp_metrics.copy_(torch.from_numpy(g["temp"]))
+    cm.aggregate_decode()
+    np.testing.assert_allclose(cm.metrics.cpu().numpy(), g["ref_after_decode"], rtol=1e-6, atol=0)
+    cm.metrics.copy_(torch.from_numpy(g["ref_after_decode"]))
+    cm.aggregate_prefill(torch.from_numpy(g["prefill_metrics"]).to(DEV),
+                         torch.from_numpy(g["slot_mapping"]).to(DEV))
+    np.testing.assert_allclose(cm.metrics.cpu().numpy(), g["ref_after_prefill"], rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_prefill_metrics_golden_gpu(case):
+    """A2c on device (library GEMM + softmax through torch, HIP epilogue) vs the reference's
+    _naive_kvc_attention output; fp16 QK^T on the GPU rounds differently from the CPU
+    reference, hence 5e-3 relative on values >= 1e-4"""
+    from tests.helpers import load_golden as lg
+    from vllm_kvcompress_amd.kvcompress.prefill import naive_kvc_attention
+    g = lg(f"agg_prefill_attn_{case:02d}")
+    q = torch.from_numpy(g["q"].view(np.float16).copy()).to(DEV)
+    k = torch.from_numpy(g["k"].view(np.float16).copy()).to(DEV)
+    hd = q.shape[2]
+    _, got = naive_kvc_attention(q, k, None, [int(x) for x in g["prompt_lens"]], hd ** -0.5,
+                                 torch.from_numpy(g["buffer_len"]), n_observed=int(g["n_observed"]),
+                                 max_observed_block_size=int(g["block"]),
+                                 use_l2=bool(int(g["use_l2"])), use_average=bool(int(g["use_average"])),
+                                 use_maxpool=bool(int(g["use_maxpool"])))
+    np.testing.assert_allclose(got.cpu().numpy(), g["ref_kv_metric_output"], rtol=5e-3, atol=1e-4)

@@ -155,3 +155,28 @@ def test_free_compressed_blocks_matches_reference_block_state(case):
     np.testing.assert_array_equal(ctx, g["ref_context_lens"])
     assert np.array_equal(np.nonzero(free_mask)[0], np.sort(g["ref_freed_blocks"]))
     assert np.array_equal(np.nonzero(seq_by == -1)[0], np.sort(g["ref_freed_blocks"]))
+
+
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
+def test_aggregate_decode_prefill_match_reference(case):
+    """A2a/A2b oracle vs CompressionMetrics.aggregate_decode / aggregate_prefill outputs
+    (float32; the reference sums with torch.sum, the oracle sequentially: 1e-6 relative)"""
+    g = load_golden(f"agg_decode_prefill_{case}")
+    m = g["metrics0"].copy()
+    orc.aggregate_decode(m, g["temp"], use_l2=bool(int(g["use_l2"])))
+    np.testing.assert_allclose(m, g["ref_after_decode"], rtol=1e-6, atol=0)
+    m = g["ref_after_decode"].copy()
+    orc.aggregate_prefill(m, g["prefill_metrics"], g["slot_mapping"], int(g["num_kv_heads"]))
+    np.testing.assert_allclose(m, g["ref_after_prefill"], rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_prefill_metric_epilogue_matches_reference(case):
+    """A2c: the oracle epilogue (square -> mask -> column sum -> avg scale -> maxpool per
+    q-block -> accumulate) inside a float32 restatement of the reference loop, against
+    _naive_kvc_attention's own output (all 8 flag combinations, buffer_len 0/3, n_observed
+    below / above the prompt length, several q-blocks).  Tolerance 1e-5 relative."""
+    from tests.helpers import reference_prefill_metrics_numpy
+    g = load_golden(f"agg_prefill_attn_{case:02d}")
+    got = reference_prefill_metrics_numpy(g)
+    np.testing.assert_allclose(got, g["ref_kv_metric_output"], rtol=1e-5, atol=1e-7)
