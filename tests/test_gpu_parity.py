@@ -459,3 +459,57 @@ def test_prefill_metrics_golden_gpu(case):
                                  use_l2=bool(int(g["use_l2"])), use_average=bool(int(g["use_average"])),
                                  use_maxpool=bool(int(g["use_maxpool"])))
     np.testing.assert_allclose(got.cpu().numpy(), g["ref_kv_metric_output"], rtol=5e-3, atol=1e-4)
+
+
+def test_batch_is_a_subset_of_the_resident_sequences():
+    """the cache holds 5 sequences, the compression batch is slots [1, 3, 4]: blocks of the
+    other sequences must be ignored (seq_mask of metrics.py:465-481) and batch position !=
+    slot index"""
+    full = synth.make_state(num_layers=2, num_kv_heads=3, block_size=4, seq_lens=[30, 41, 17, 58, 26],
+                            seed=21, protected=[2, 3, 1, 5, 2])
+    sel = [1, 3, 4]
+    bs = 4
+    ctx = np.ascontiguousarray(full.context_lens[:, sel, :])
+    sub = synth.PagedState(
+        block_size=bs, num_layers=2, num_kv_heads=3, num_seqs=len(sel), num_blocks=full.num_blocks,
+        metrics=full.metrics, token_positions=full.token_positions,
+        seq_index_by_block=full.seq_index_by_block, layer_index_by_block=full.layer_index_by_block,
+        head_index_by_block=full.head_index_by_block,
+        logical_block_num_by_block=full.logical_block_num_by_block, context_lens=ctx,
+        block_tables=np.ascontiguousarray(full.block_tables[:, sel]),
+        hanging_token_count=synth.hanging_tokens(ctx.transpose(1, 0, 2), bs),
+        evicted_kv_offsets=synth.kv_offsets(ctx, bs), seq_indices=sel,
+        seq_positions=np.ascontiguousarray(full.seq_positions[sel]),
+        protected=[full.protected[i] for i in sel])
+    evicted = _limit(sub, 0.6)
+    k, v = synth.make_caches_u16(21, full.num_blocks, 8, bs)
+    for mode in ("reference", "per_sequence"):
+        want = oracle_pipeline(sub, evicted, k, v, mode=mode)
+        got = _gpu_pipeline(sub, evicted, k, v, mode=mode)
+        for key in ("eli", "ekc", "ebc", "cmi", "cmc", "k", "v", "metrics", "positions"):
+            np.testing.assert_array_equal(got[key], want[key], err_msg=f"{key} {mode}")
+
+
+def test_metadata_management_and_profile():
+    """insert/remove metadata (metrics.py:344-370) and profile_schedule_evictions (:277-335)"""
+    from types import SimpleNamespace
+    from vllm_kvcompress_amd.kvcompress.metrics import CompressionMetrics
+    cm = CompressionMetrics(16, 2, 2, 1, 50_000, None, 0.0, device=DEV)
+    extra = cm.profile_schedule_evictions()
+    assert extra >= 0 and cm.num_blocks is None
+    cm.init_kv_metadata(64)
+    assert int((cm.seq_index_by_block == -1).sum()) == 64
+    md = SimpleNamespace(
+        physical_blocks=torch.tensor([5, 9, 40], device=DEV),
+        seq_indices=torch.tensor([2, 2, 7], dtype=torch.int32, device=DEV),
+        logical_blocks=torch.tensor([0, 1, 0], device=DEV),
+        layer_indices=torch.tensor([1, 1, 0], dtype=torch.int32, device=DEV),
+        head_indices=torch.tensor([0, 0, 1], dtype=torch.int32, device=DEV),
+        token_positions=torch.arange(48, dtype=torch.int32, device=DEV).view(3, 16))
+    cm.insert_metadata(md)
+    assert cm.seq_index_by_block[[5, 9, 40]].tolist() == [2, 2, 7]
+    assert cm.logical_block_num_by_block[9].item() == 1 and cm.layer_index_by_block[5].item() == 1
+    assert cm.token_positions[40, 3].item() == 35
+    cm.remove_metadata(torch.tensor([9], device=DEV))
+    assert cm.seq_index_by_block[9].item() == -1 and cm.seq_index_by_block[5].item() == 2
+    cm.validate_metadata()
