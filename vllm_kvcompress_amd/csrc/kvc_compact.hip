@@ -183,7 +183,17 @@ __global__ __launch_bounds__(256) void compact_runs_kernel(
   const int my_pr = lane & (PR - 1);
   const int total_tiles = tile_prefix[G];
   const int nw = gridDim.x * (blockDim.x / WAVE);
-  for (int t = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x >> 6); t < total_tiles; t += nw) {
+  // every wave walks a CONTIGUOUS range of tiles: consecutive tiles are consecutive moves of
+  // the same head, so the source block held at the end of one tile is usually the first one
+  // the next tile needs (saves one 8 KiB re-read per tile)
+  const int wid = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x >> 6);
+  const int t_begin = (int)((int64_t)total_tiles * wid / nw);
+  const int t_end = (int)((int64_t)total_tiles * (wid + 1) / nw);
+  BlockImg<NPL> kd, vd, ks;
+  float md = 0.f, ms = 0.f;
+  int pd = 0, ps = 0;
+  int cur_sblk = -1;                                          // source block held in ks / LDS / ms / ps
+  for (int t = t_begin; t < t_end; ++t) {
     const int g = upper_bound_minus1(tile_prefix, G, t);
     const int cnt = count[g];
     const int j0 = (t - tile_prefix[g]) * tm;
@@ -204,10 +214,6 @@ __global__ __launch_bounds__(256) void compact_runs_kernel(
     const int jl = jbase + lane;
     unsigned long long starts = __ballot(jl >= j0 && jl < j1 && (jl == 0 || myblk != left));
 
-    BlockImg<NPL> kd, vd, ks;
-    float md = 0.f, ms = 0.f;
-    int pd = 0, ps = 0;
-    int cur_sblk = -1;                                        // source block held in ks / LDS / ms / ps
     while (starts) {
       const int jr = jbase + __ffsll((long long)starts) - 1;  // first move of the run
       starts &= starts - 1;
