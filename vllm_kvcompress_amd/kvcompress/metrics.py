@@ -120,6 +120,7 @@ class CompressionMetrics:
         # "reference": bit-exact to the reference including its batch>1 quirk
         # (metrics.py:718-721); "per_sequence": each sequence scheduled as if alone.
         self.schedule_mode = "reference"
+        self._small_cache = {}
 
     # temp_metrics is handed to the attention kernels, which write into it; reading the
     # attribute therefore marks it dirty so that the fused clear in aggregate_decode stays
@@ -240,9 +241,31 @@ class CompressionMetrics:
 
     # ------------------------------------------------------------------ scheduling
     def _as_i32(self, x: IntsLike) -> torch.Tensor:
+        """int32 device tensor; small host lists are uploaded once and cached by value (the
+        scheduler passes the same protected-window / slot lists step after step)."""
         if isinstance(x, torch.Tensor):
             return x.to(device=self.device, dtype=torch.int32).contiguous()
-        return torch.tensor(list(x), dtype=torch.int32, device=self.device)
+        key = tuple(int(v) for v in x)
+        hit = self._small_cache.get(key)
+        if hit is None:
+            if len(self._small_cache) > 256:
+                self._small_cache.clear()
+            hit = torch.tensor(key, dtype=torch.int32, device=self.device)
+            self._small_cache[key] = hit
+        return hit
+
+    def _slot_map(self, seq_indices) -> torch.Tensor:
+        key = ("slots",) + tuple(int(s) for s in seq_indices)
+        hit = self._small_cache.get(key)
+        if hit is None:
+            if len(self._small_cache) > 256:
+                self._small_cache.clear()
+            m = torch.full((max(seq_indices) + 1,), -1, dtype=torch.int32)
+            m[torch.tensor(list(seq_indices), dtype=torch.long)] = torch.arange(
+                len(seq_indices), dtype=torch.int32)
+            hit = m.to(self.device)
+            self._small_cache[key] = hit
+        return hit
 
     def schedule_evictions(
         self,
@@ -286,10 +309,7 @@ class CompressionMetrics:
             total_slots = int((((context_lens + (bs - 1)) // bs).sum(dtype=torch.int64) * bs).item())
         N = int(total_slots)
 
-        slot_of_seq = torch.full((max(seq_indices) + 1,), -1, dtype=torch.int32)
-        slot_of_seq[torch.tensor(list(seq_indices), dtype=torch.long)] = torch.arange(
-            B, dtype=torch.int32)
-        slot_of_seq = slot_of_seq.to(dev, non_blocking=True)
+        slot_of_seq = self._slot_map(seq_indices)
         seq_pos = self._as_i32(seq_positions)
         prot = self._as_i32(num_protected)
         k_per_seq = self._as_i32(evicted_blocks_per_seq)
