@@ -94,6 +94,13 @@ __global__ __launch_bounds__(256) void build_keys_kernel(kvc_schedule_params p, 
   const int64_t blk = tid / per_blk;
   const int off = (int)(tid % per_blk) * VEC;
   if (blk >= p.num_blocks) return;
+  // the wide loads do not depend on the metadata chain below: issue them first
+  float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  int4 q4 = make_int4(0, 0, 0, 0);
+  if constexpr (VEC == 4) {
+    m4 = *reinterpret_cast<const float4*>(p.metrics + blk * bs + off);
+    q4 = *reinterpret_cast<const int4*>(p.token_positions + blk * bs + off);
+  }
   const int s = p.seq_index_by_block[blk];
   if (s < 0 || s >= p.seq_slot_len) return;
   const int i = p.seq_slot_of_seq[s];
@@ -109,8 +116,8 @@ __global__ __launch_bounds__(256) void build_keys_kernel(kvc_schedule_params p, 
   const int64_t base = p.evicted_kv_offsets[g];
   const int64_t src = blk * bs + off, dst = base + (int64_t)lbn * bs + off;
   if constexpr (VEC == 4) {
-    const float4 m = *reinterpret_cast<const float4*>(p.metrics + src);
-    const int4 q = *reinterpret_cast<const int4*>(p.token_positions + src);
+    const float4 m = m4;
+    const int4 q = q4;
     uint4 k;
     k.x = slot_key(p, m.x, q.x, seq_pos, prot, l, h);
     k.y = slot_key(p, m.y, q.y, seq_pos, prot, l, h);
@@ -126,51 +133,70 @@ __global__ __launch_bounds__(256) void build_keys_kernel(kvc_schedule_params p, 
 // ------------------------------------------------------------------ 1. per-head histograms
 // flat tiles of TILE keys; a tile inside one head (the common case) accumulates in LDS.
 constexpr int HTILE = 2048;
+// Persistent: every workgroup walks a contiguous range of HTILE-key tiles.  The head of the
+// first tile is found by one binary search, later tiles advance it incrementally; counts of
+// consecutive tiles of one head stay in LDS and are flushed once per head.
 __global__ __launch_bounds__(256) void hist_round_kernel(kvc_schedule_params p, SchedWs ws, int round) {
   __shared__ uint32_t sh[RADIX];
   const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
   const int LH = p.num_layers * p.num_kv_heads;
   const int64_t N = p.total_slots;
-  const int64_t t0 = (int64_t)blockIdx.x * HTILE;
-  const int64_t t1 = min(N, t0 + HTILE);
   const int shift = 24 - 8 * round;
-  const int g0 = upper_bound_minus1(p.evicted_kv_offsets, G, t0);
-  const int64_t g0_end = (g0 + 1 < G) ? (int64_t)p.evicted_kv_offsets[g0 + 1] : N;
-  const bool single = t1 <= g0_end;
-  if (single) {
-    const int i = g0 / LH;
-    if (ws.seq_k[i] == 0 && round > 0) return;      // inactive sequence
-    const uint32_t prefix = ws.seq_prefix[i];
+  const int64_t ntiles = (N + HTILE - 1) / HTILE;
+  const int64_t tb = ntiles * blockIdx.x / gridDim.x, te = ntiles * (blockIdx.x + 1) / gridDim.x;
+  if (tb >= te) return;
+  int g = upper_bound_minus1(p.evicted_kv_offsets, G, tb * HTILE);
+  int64_t g_end = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : N;
+  int cur_g = -1;                                   // head whose counts sit in sh
+  auto flush = [&]() {                              // uniform call sites only
+    __syncthreads();
+    if (cur_g >= 0)
+      for (int k = threadIdx.x; k < RADIX; k += blockDim.x) {
+        const uint32_t v = sh[k];
+        if (v) atomicAdd(&ws.hist[(int64_t)cur_g * RADIX + k], v);
+      }
+    __syncthreads();
     for (int k = threadIdx.x; k < RADIX; k += blockDim.x) sh[k] = 0;
     __syncthreads();
-    // all loads of the tile first (independent), then the ballot-heavy histogram updates
-    constexpr int U = HTILE / 256;
-    uint32_t kv[U];
+  };
+  flush();
+  constexpr int U = HTILE / 256;
+  for (int64_t t = tb; t < te; ++t) {
+    const int64_t t0 = t * HTILE, t1 = min(N, t0 + HTILE);
+    uint32_t kv[U];                                 // all loads of the tile first (independent)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t idx = t0 + threadIdx.x + (int64_t)u * 256;
       kv[u] = idx < t1 ? ws.keys[idx] : 0xFFFFFFFFu;
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t key = kv[u];
-      const bool valid = key < KEY_INF && (round == 0 || (key >> (shift + 8)) == prefix);
-      hist_add(sh, valid, (key >> shift) & 0xFFu);
-    }
-    __syncthreads();
-    for (int k = threadIdx.x; k < RADIX; k += blockDim.x) {
-      const uint32_t v = sh[k];
-      if (v) atomicAdd(&ws.hist[(int64_t)g0 * RADIX + k], v);
-    }
-  } else {
-    for (int64_t idx = t0 + threadIdx.x; idx < t1; idx += blockDim.x) {
-      const int g = upper_bound_minus1(p.evicted_kv_offsets, G, idx);
+    while (t0 >= g_end && g + 1 < G) { ++g; g_end = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : N; }
+    if (t1 <= g_end) {                              // the whole tile belongs to head g
+      if (g != cur_g) { flush(); cur_g = g; }
       const int i = g / LH;
-      const uint32_t key = ws.keys[idx];
-      if (key < KEY_INF && (round == 0 || (ws.seq_k[i] != 0 && (key >> (shift + 8)) == ws.seq_prefix[i])))
-        atomicAdd(&ws.hist[(int64_t)g * RADIX + ((key >> shift) & 0xFFu)], 1u);
+      if (round > 0 && ws.seq_k[i] == 0) continue;  // inactive sequence
+      const uint32_t prefix = ws.seq_prefix[i];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t key = kv[u];
+        const bool valid = key < KEY_INF && (round == 0 || (key >> (shift + 8)) == prefix);
+        hist_add(sh, valid, (key >> shift) & 0xFFu);
+      }
+    } else {                                        // several (small) heads in this tile
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t idx = t0 + threadIdx.x + (int64_t)u * 256;
+        if (idx >= t1) continue;
+        int gk = g;
+        int64_t ek = g_end;
+        while (idx >= ek && gk + 1 < G) { ++gk; ek = (gk + 1 < G) ? (int64_t)p.evicted_kv_offsets[gk + 1] : N; }
+        const int i = gk / LH;
+        const uint32_t key = kv[u];
+        if (key < KEY_INF && (round == 0 || (ws.seq_k[i] != 0 && (key >> (shift + 8)) == ws.seq_prefix[i])))
+          atomicAdd(&ws.hist[(int64_t)gk * RADIX + ((key >> shift) & 0xFFu)], 1u);
+      }
     }
   }
+  flush();
 }
 
 // ------------------------------------------------------------------ 2. per-head scan
@@ -426,7 +452,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(kvc_schedule_p
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_keys[];
   __shared__ __attribute__((aligned(16))) uint32_t hist[RADIX];
   __shared__ uint32_t bc[4];
-  __shared__ uint32_t wave_tot[2][SEL_THREADS / WAVE];
+  __shared__ uint32_t scan_buf[8 * (SEL_THREADS / WAVE) + 1];
   const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
   const int g = blockIdx.x;
   const int bs = p.block_size;
@@ -464,10 +490,12 @@ __global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(kvc_schedule_p
     uint32_t r2, e2;
     block_radix_select(hist, bc, n, take, fkey, [&](int idx) { return key_at(idx) == M; }, Fstar, r2, e2);
   }
-  // emit: flag, block-wide exclusive scan, compact; then pad with null
-  uint32_t carry = 0;
-  int buf = 0;
+  // emit: flags for U rows of SEL_THREADS consecutive indices at a time, one block-wide
+  // exclusive scan of the U x (waves) ballot counts (two barriers per U*SEL_THREADS keys),
+  // compact; then pad with null
   constexpr int U = 8;
+  constexpr int NWAVES = SEL_THREADS / WAVE;
+  uint32_t carry = 0;
   const bool tie_cut = Fstar != 0xFFFFFFFFu;
   for (int base0 = 0; base0 < n; base0 += SEL_THREADS * U) {
     uint32_t kk[U];
@@ -476,23 +504,36 @@ __global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(kvc_schedule_p
       const int idx = base0 + u * SEL_THREADS + tid;
       kk[u] = idx < n ? key_at(idx) : 0xFFFFFFFFu;
     }
+    uint32_t lane_ex[U];
+    bool sel[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int idx = base0 + u * SEL_THREADS + tid;
-      if (base0 + u * SEL_THREADS >= n) break;      // uniform
-      bool sel = false;
-      if (idx < n) sel = kk[u] < M || (kk[u] == M && (!tie_cut || fkey(idx) <= Fstar));
-      const unsigned long long bal = __ballot(sel);
-      const uint32_t lane_ex = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-      if (lane == 0) wave_tot[buf][w] = (uint32_t)__popcll(bal);
-      __syncthreads();                              // one barrier per step (double buffer)
-      uint32_t woff = 0, tot = 0;
-#pragma unroll
-      for (int q = 0; q < SEL_THREADS / WAVE; ++q) { const uint32_t c = wave_tot[buf][q]; if (q < w) woff += c; tot += c; }
-      if (sel) out[carry + woff + lane_ex] = idx;   // logical index == position in head
-      carry += tot;
-      buf ^= 1;
+      sel[u] = idx < n && (kk[u] < M || (kk[u] == M && (!tie_cut || fkey(idx) <= Fstar)));
+      const unsigned long long bal = __ballot(sel[u]);
+      lane_ex[u] = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) scan_buf[u * NWAVES + w] = (uint32_t)__popcll(bal);
     }
+    __syncthreads();
+    if (w == 0) {                                   // exclusive scan of U*NWAVES counts (row-major)
+      constexpr int PER = (U * NWAVES + WAVE - 1) / WAVE;
+      uint32_t v[PER], run = 0;
+#pragma unroll
+      for (int q = 0; q < PER; ++q) { const int e = lane * PER + q; v[q] = e < U * NWAVES ? scan_buf[e] : 0u; run += v[q]; }
+      const uint32_t inc = wave_inclusive_scan(run);
+      uint32_t ex = inc - run;
+#pragma unroll
+      for (int q = 0; q < PER; ++q) { const int e = lane * PER + q; if (e < U * NWAVES) scan_buf[e] = ex; ex += v[q]; }
+      if (lane == WAVE - 1) scan_buf[U * NWAVES] = inc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base0 + u * SEL_THREADS + tid;
+      if (sel[u]) out[carry + scan_buf[u * NWAVES + w] + lane_ex[u]] = idx;   // logical index == position in head
+    }
+    carry += scan_buf[U * NWAVES];
+    __syncthreads();                                // scan_buf is rewritten by the next batch
   }
   for (int idx = (int)cnt + tid; idx < n; idx += blockDim.x) out[idx] = p.null_value;
 }
@@ -575,7 +616,11 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     const int64_t threads = p.num_blocks * p.block_size;
     hipLaunchKernelGGL(build_keys_kernel<1>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p, ws);
   }
-  const unsigned htiles = (unsigned)((p.total_slots + HTILE - 1) / HTILE);
+  const int64_t htiles_all = (p.total_slots + HTILE - 1) / HTILE;
+#ifndef KVC_HIST_GRID
+#define KVC_HIST_GRID 1024
+#endif
+  const unsigned htiles = (unsigned)(htiles_all < KVC_HIST_GRID ? htiles_all : KVC_HIST_GRID);   // persistent grid
   for (int round = 0; round < 4; ++round) {
     hipLaunchKernelGGL(hist_round_kernel, dim3(htiles), dim3(256), 0, s, p, ws, round);
     hipLaunchKernelGGL(scan_round_kernel, dim3((G + 3) / 4), dim3(256), 0, s, p, ws);
