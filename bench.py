@@ -266,7 +266,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16 bytes / int32 indices / f32 metric compare",
+            "dtype": "u8",
+            "dtype_detail": "compaction copies bytes (fp16 K/V, 2-byte elements); scheduling compares "
+                            "float32 metrics and computes int32 indices",
             "data": "synthetic (seeded paged cache, tie-free permutation metrics, random K/V bits)",
             "config": {
                 "workload": f"Llama-3-8B shape L{args.layers} H{args.kv_heads} hd{args.head_size}, "

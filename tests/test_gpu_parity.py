@@ -513,3 +513,34 @@ def test_metadata_management_and_profile():
     cm.remove_metadata(torch.tensor([9], device=DEV))
     assert cm.seq_index_by_block[9].item() == -1 and cm.seq_index_by_block[5].item() == 2
     cm.validate_metadata()
+
+
+def test_empty_inputs():
+    """nothing to evict / nothing cached / no moves: every op must be a clean no-op"""
+    from vllm_kvcompress_amd.kvcompress.metrics import CompressionMetrics
+    # a batch whose heads are all empty (ctx = 0): N = 0
+    cm = CompressionMetrics(16, 2, 2, 1, 1000, None, 0.0, device=DEV)
+    cm.init_kv_metadata(8)
+    ctx = torch.zeros((2, 1, 2), dtype=torch.int32, device=DEV)
+    hang = torch.full((1, 2, 2), 16, dtype=torch.int32, device=DEV)
+    offs = torch.zeros((1, 2, 2), dtype=torch.int32, device=DEV)
+    eli, ekc, ebc = cm.schedule_evictions([0], [0], [0], ctx, hang, offs, [1])
+    assert eli.numel() == 0 and int(ekc.abs().sum()) == 0 and int(ebc.abs().sum()) == 0
+    # zero moves: caches untouched
+    k = torch.randint(0, 100, (8, 16, 16, 8), dtype=torch.int16, device=DEV)
+    v = torch.randint(0, 100, (8, 128, 16), dtype=torch.int16, device=DEV)
+    k0, v0 = k.clone(), v.clone()
+    cmi = torch.zeros((4, 2), dtype=torch.int32, device=DEV)
+    cmc = torch.zeros((1, 2, 2), dtype=torch.int32, device=DEV)
+    ops.schedule_cache_moves(cmi, cmc, torch.zeros(4, dtype=torch.int32, device=DEV), ekc, offs,
+                             torch.zeros((2, 1, 2, 1), dtype=torch.int32, device=DEV), ctx, 16)
+    assert int(cmc.abs().sum()) == 0 and int(cmi.abs().sum()) == 0
+    ops.execute_cache_moves(k, v, cm.metrics, cm.token_positions, cmi, cmc, offs, 1, 16)
+    assert torch.equal(k, k0) and torch.equal(v, v0)
+    # zero tokens
+    ops.reshape_and_cache_kvc(torch.zeros((0, 2, 128), dtype=torch.float16, device=DEV),
+                              torch.zeros((0, 2, 128), dtype=torch.float16, device=DEV),
+                              k.view(torch.float16), v.view(torch.float16), cm.metrics,
+                              torch.zeros(0, dtype=torch.int64, device=DEV),
+                              torch.zeros(2, device=DEV), "auto", 1.0, 1.0)
+    assert torch.equal(k, k0) and torch.equal(v, v0)
