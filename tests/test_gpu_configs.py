@@ -165,3 +165,71 @@ def test_free_compressed_blocks_device(case):
     want[g["ref_freed_blocks"]] = True
     np.testing.assert_array_equal(free_mask.cpu().numpy(), want)
     np.testing.assert_array_equal(seq_by.cpu().numpy() == -1, want)
+
+
+def test_compression_scheduler_mirror_end_to_end():
+    """CompressionScheduler (host glue mirror) over the FULL block state with a subset of
+    slots compressing, max_kv_per_compression cut-off, staleness order, persistent move
+    workspace and the device block-state update -- against the oracle driven by hand."""
+    from vllm_kvcompress_amd.kvcompress.scheduler import CompressionScheduler, SeqCompressionRequest
+    L, H, bs, hd = 2, 4, 16, 128
+    seq_lens = [200, 130, 77, 161, 90]
+    st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs, seq_lens=seq_lens, seed=31,
+                          protected=32, spare_block_frac=0.3)
+    ds = hdev.upload(st, DEV, mode="per_sequence")
+    k_np, v_np = synth.make_caches_u16(31, st.num_blocks, hd, bs)
+    k_t, v_t = torch.from_numpy(k_np.copy()).to(DEV), torch.from_numpy(v_np.copy()).to(DEV)
+    bt_full = torch.from_numpy(st.block_tables).to(DEV)
+    ctx_full = torch.from_numpy(st.context_lens.copy()).to(DEV)
+    free_mask = torch.from_numpy(st.seq_index_by_block < 0).to(DEV)
+    total_rows = 40000
+    sched = CompressionScheduler(bs, L, H, total_rows, ds.cm, device=DEV)
+    nblk = ((st.context_lens.astype(np.int64) + bs - 1) // bs).sum(0).sum(-1)
+    kvs = st.context_lens.astype(np.int64).sum(0).sum(-1)
+    reqs = [SeqCompressionRequest(seq_id=100 + i, slot_index=i, seq_len=seq_lens[i],
+                                  block_count=int(nblk[i]), kv_count=int(kvs[i]),
+                                  max_cache_tokens=48, protected_window_size=32)
+            for i in (4, 0, 3, 1)]                     # slot 2 does not compress
+    reqs[1].max_cache_tokens = 10 ** 6                 # slot 0: nothing to evict -> skipped
+    out = sched.schedule_compression(reqs, bt_full, ctx_full, free_mask=free_mask)
+    assert out is not None and out.slot_indices == [1, 3, 4]
+    ops.execute_cache_moves(k_t, v_t, ds.cm.metrics, ds.cm.token_positions, out.cache_moves.index,
+                            out.cache_moves.count, out.cache_moves.offsets, 1, 16)
+    # ---- the same by hand on the oracle
+    sel = [1, 3, 4]
+    ctx = np.ascontiguousarray(st.context_lens[:, sel, :])
+    sub = synth.PagedState(
+        block_size=bs, num_layers=L, num_kv_heads=H, num_seqs=3, num_blocks=st.num_blocks,
+        metrics=st.metrics, token_positions=st.token_positions,
+        seq_index_by_block=st.seq_index_by_block, layer_index_by_block=st.layer_index_by_block,
+        head_index_by_block=st.head_index_by_block,
+        logical_block_num_by_block=st.logical_block_num_by_block, context_lens=ctx,
+        block_tables=np.ascontiguousarray(st.block_tables[:, sel]),
+        hanging_token_count=synth.hanging_tokens(ctx.transpose(1, 0, 2), bs),
+        evicted_kv_offsets=synth.kv_offsets(ctx, bs), seq_indices=sel,
+        seq_positions=np.ascontiguousarray(st.seq_positions[sel]), protected=[32, 32, 32])
+    evicted = [synth.evict_block_count(context_lens_lh=st.context_lens[:, i, :], seq_len=seq_lens[i],
+                                       block_size=bs, protected_window_size=32, max_cache_tokens=48)
+               for i in sel]
+    want = oracle_pipeline(sub, evicted, k_np, v_np, mode="per_sequence")
+    N = sub.total_slots
+    np.testing.assert_array_equal(out.cache_moves.count.cpu().numpy(), want["cmc"])
+    np.testing.assert_array_equal(out.cache_moves.offsets.cpu().numpy(), sub.evicted_kv_offsets)
+    got_idx = out.cache_moves.index.cpu().numpy()
+    np.testing.assert_array_equal(got_idx[:N], want["cmi"])
+    assert not got_idx[N:].any()                       # rest of the workspace zero-filled
+    np.testing.assert_array_equal(k_t.cpu().numpy(), want["k"])
+    np.testing.assert_array_equal(v_t.cpu().numpy(), want["v"])
+    np.testing.assert_array_equal(ds.cm.metrics.cpu().numpy(), want["metrics"])
+    for i, sid in enumerate(out.seq_ids):
+        np.testing.assert_array_equal(out.freed_block_count[sid].cpu().numpy(), want["ebc"][i])
+    # block-state side
+    ctx_want = st.context_lens.copy()
+    seq_by = st.seq_index_by_block.copy()
+    fm = st.seq_index_by_block < 0
+    freed_want = orc.free_compressed_blocks(st.block_tables, ctx_want, sel, want["ebc"], seq_by, bs, fm)
+    np.testing.assert_array_equal(out.freed_blocks.cpu().numpy(), freed_want)
+    np.testing.assert_array_equal(ctx_full.cpu().numpy(), ctx_want)
+    np.testing.assert_array_equal(ds.cm.seq_index_by_block.cpu().numpy(), seq_by)
+    np.testing.assert_array_equal(free_mask.cpu().numpy(), fm)
+    assert int(ctx_full[:, sel].max()) <= 48

@@ -180,3 +180,28 @@ def test_prefill_metric_epilogue_matches_reference(case):
     g = load_golden(f"agg_prefill_attn_{case:02d}")
     got = reference_prefill_metrics_numpy(g)
     np.testing.assert_allclose(got, g["ref_kv_metric_output"], rtol=1e-5, atol=1e-7)
+
+
+def test_host_policy_matches_reference():
+    """A8: harness.synth.evict_block_count vs CompressionScheduler._schedule_seq_evictions
+    (vllm/kvcompress/scheduler.py:100-181) on 400 random parameter sets, including the cases
+    where the reference's own sanity assertion fires."""
+    from vllm_kvcompress_amd.harness import synth
+    g = load_golden("policy_cases")
+    sc, flat = g["scalars"], g["ctx_flat"]
+    o = 0
+    fired = 0
+    for row in sc:
+        L, H, bs, seq_len, prot = (int(row[i]) for i in range(5))
+        rate, mct, even, want, ok = float(row[5]), int(row[6]), bool(int(row[7])), int(row[8]), int(row[9])
+        ctx = flat[o:o + L * H].reshape(L, H)
+        o += L * H
+        kw = dict(context_lens_lh=ctx, seq_len=seq_len, block_size=bs, protected_window_size=prot,
+                  max_cache_tokens=mct, target_compression_rate=rate, even_layer_evict=even)
+        if ok:
+            assert synth.evict_block_count(**kw) == want, row[:9]
+        else:
+            fired += 1
+            with pytest.raises(AssertionError):
+                synth.evict_block_count(**kw)
+    assert o == flat.shape[0] and fired > 0
