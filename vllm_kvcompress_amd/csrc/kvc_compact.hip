@@ -192,7 +192,8 @@ __global__ __launch_bounds__(256) void compact_runs_kernel(
   BlockImg<NPL> kd, vd, ks;
   float md = 0.f, ms = 0.f;
   int pd = 0, ps = 0;
-  int cur_sblk = -1;                                          // source block held in ks / LDS / ms / ps
+  int cur_sblk = -1;                                          // source block held in LDS / ms / ps (and ks)
+  bool ks_valid = false;                                      // ks holds cur_sblk's K image
   for (int t = t_begin; t < t_end; ++t) {
     const int g = upper_bound_minus1(tile_prefix, G, t);
     const int cnt = count[g];
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256) void compact_runs_kernel(
         while (j < je) {
           const int sblk = MY(j) / BS;
           if (sblk != cur_sblk) {
-            if (phases & 2) img_load<NPL>(ks, k_cache + (int64_t)sblk * BLOCK_BYTES, lane);
+            ks_valid = false;                                // K image is fetched lazily below
             if ((phases & 1) && lane < BS) { ms = metrics[(int64_t)sblk * BS + lane]; ps = positions[(int64_t)sblk * BS + lane]; }
             if (phases & 4) {
               BlockImg<NPL> vs;
@@ -251,12 +252,30 @@ __global__ __launch_bounds__(256) void compact_runs_kernel(
             }
             cur_sblk = sblk;
           }
+          // the moves of this run fed by this source block
+          int seg_end = j + 1;
+          while (seg_end < je && MY(seg_end) / BS == sblk) ++seg_end;
+          // a source block that contributes only one or two slots (high compression: the
+          // survivors are sparse) is not worth 4 KiB of K: fetch just those 16 B pieces
+          const bool chunky = !ks_valid && (seg_end - j) <= 2;
+          if ((phases & 2) && !chunky && !ks_valid) {
+            img_load<NPL>(ks, k_cache + (int64_t)sblk * BLOCK_BYTES, lane);
+            ks_valid = true;
+          }
           int ksrc = -1;                                      // per lane: source slot it receives
-          while (j < je) {                                    // the moves fed by this source block
+          for (; j < seg_end; ++j) {
             const int sy = MY(j);
-            if (sy / BS != sblk) break;
             const int so = sy % BS, dsl = MX(j) % BS;
-            ksrc = (lane & (BS - 1)) == dsl ? so : ksrc;
+            if (chunky) {
+              if ((phases & 2) && (lane & (BS - 1)) == dsl) {
+                const uint8_t* sp = k_cache + (int64_t)sblk * BLOCK_BYTES;
+#pragma unroll
+                for (int i = 0; i < NPL; ++i)
+                  kd.p[i] = *reinterpret_cast<const u32x4*>(sp + ((int64_t)((i * 64 + lane) / BS) * BS + so) * 16);
+              }
+            } else {
+              ksrc = (lane & (BS - 1)) == dsl ? so : ksrc;
+            }
             if (phases & 4) {
               const int ed = dsl % EP, wd = ed / PER, shd = (ed % PER) * 8 * E;
               const uint32_t lmask = (my_pr == dsl / EP) ? (EMASK << shd) : 0u;
@@ -275,9 +294,8 @@ __global__ __launch_bounds__(256) void compact_runs_kernel(
               md = lane == dsl ? __builtin_bit_cast(float, mval) : md;
               pd = lane == dsl ? pval : pd;
             }
-            ++j;
           }
-          if (phases & 2) {                                   // one permute pass moves all K pieces
+          if ((phases & 2) && !chunky) {                      // one permute pass moves all K pieces
             const bool take = ksrc >= 0;
             const int src_lane4 = ((lane & ~(BS - 1)) | (take ? ksrc : (lane & (BS - 1)))) * 4;
 #pragma unroll
