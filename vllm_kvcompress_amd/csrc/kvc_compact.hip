@@ -255,9 +255,12 @@ __global__ __launch_bounds__(256) void compact_runs_kernel(
           // the moves of this run fed by this source block
           int seg_end = j + 1;
           while (seg_end < je && MY(seg_end) / BS == sblk) ++seg_end;
-          // a source block that contributes only one or two slots (high compression: the
+          // a source block that contributes only a few slots (high compression: the
           // survivors are sparse) is not worth 4 KiB of K: fetch just those 16 B pieces
-          const bool chunky = !ks_valid && (seg_end - j) <= 2;
+          #ifndef KVC_CHUNK_MAX
+#define KVC_CHUNK_MAX 3
+#endif
+          const bool chunky = !ks_valid && (seg_end - j) <= KVC_CHUNK_MAX;
           if ((phases & 2) && !chunky && !ks_valid) {
             img_load<NPL>(ks, k_cache + (int64_t)sblk * BLOCK_BYTES, lane);
             ks_valid = true;
