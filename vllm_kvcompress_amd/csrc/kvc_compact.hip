@@ -210,7 +210,8 @@ __global__ __launch_bounds__(256) void compact_runs_kernel(
     auto MX = [&](int j) { return __builtin_amdgcn_readlane(mvx, j - jbase); };
     auto MY = [&](int j) { return __builtin_amdgcn_readlane(mvy, j - jbase); };
     // run starts inside the tile
-    const int myblk = mvx >= 0 ? mvx / BS : -2;
+    const int myblk = mvx >= 0 ? mvx / BS : -2;            // destination block of this lane's move
+    const int mysb = mvy >= 0 ? mvy / BS : -2;             // source block of this lane's move
     const int left = __shfl_up(myblk, 1, 64);
     const int jl = jbase + lane;
     unsigned long long starts = __ballot(jl >= j0 && jl < j1 && (jl == 0 || myblk != left));
@@ -219,8 +220,13 @@ __global__ __launch_bounds__(256) void compact_runs_kernel(
       const int jr = jbase + __ffsll((long long)starts) - 1;  // first move of the run
       starts &= starts - 1;
       const int dblk = MX(jr) / BS;
-      int je = jr + 1;                                        // run end (exclusive)
-      while (je < cnt && je - jbase < 64 && MX(je) / BS == dblk) ++je;
+      // run end (exclusive): first later lane whose destination block differs (lanes past
+      // the head's last move hold block -2)
+      int je;
+      {
+        const unsigned long long diff = __ballot(myblk != dblk) & ~((2ull << (jr - jbase)) - 1ull);
+        je = diff ? jbase + __ffsll((long long)diff) - 1 : jbase + 64;
+      }
       const bool sole = ((claims[dblk >> 2] >> (8 * (dblk & 3))) & 0xFFu) == 1u;
       uint8_t* kd_p = k_cache + (int64_t)dblk * BLOCK_BYTES;
       uint8_t* vd_p = v_cache + (int64_t)dblk * BLOCK_BYTES;
@@ -236,8 +242,26 @@ __global__ __launch_bounds__(256) void compact_runs_kernel(
         int j = jr;
         while (j < je) {
           const int sblk = MY(j) / BS;
-          if (sblk != cur_sblk) {
-            ks_valid = false;                                // K image is fetched lazily below
+          // the moves of this run fed by this source block
+          int seg_end;
+          {
+            const unsigned long long diff = __ballot(mysb != sblk) & ~((2ull << (j - jbase)) - 1ull);
+            seg_end = diff ? jbase + __ffsll((long long)diff) - 1 : jbase + 64;
+            seg_end = seg_end < je ? seg_end : je;
+          }
+          const bool new_block = sblk != cur_sblk;
+          if (new_block) ks_valid = false;
+          // a source block that contributes only a few slots (high compression: the
+          // survivors are sparse) is not worth 4 KiB of K: fetch just those 16 B pieces
+#ifndef KVC_CHUNK_MAX
+#define KVC_CHUNK_MAX 3
+#endif
+          const bool chunky = !ks_valid && (seg_end - j) <= KVC_CHUNK_MAX;
+          if ((phases & 2) && !chunky && !ks_valid) {         // issued first: overlaps the V staging
+            img_load<NPL>(ks, k_cache + (int64_t)sblk * BLOCK_BYTES, lane);
+            ks_valid = true;
+          }
+          if (new_block) {
             if ((phases & 1) && lane < BS) { ms = metrics[(int64_t)sblk * BS + lane]; ps = positions[(int64_t)sblk * BS + lane]; }
             if (phases & 4) {
               BlockImg<NPL> vs;
@@ -251,19 +275,6 @@ __global__ __launch_bounds__(256) void compact_runs_kernel(
               wave_lds_sync();
             }
             cur_sblk = sblk;
-          }
-          // the moves of this run fed by this source block
-          int seg_end = j + 1;
-          while (seg_end < je && MY(seg_end) / BS == sblk) ++seg_end;
-          // a source block that contributes only a few slots (high compression: the
-          // survivors are sparse) is not worth 4 KiB of K: fetch just those 16 B pieces
-          #ifndef KVC_CHUNK_MAX
-#define KVC_CHUNK_MAX 3
-#endif
-          const bool chunky = !ks_valid && (seg_end - j) <= KVC_CHUNK_MAX;
-          if ((phases & 2) && !chunky && !ks_valid) {
-            img_load<NPL>(ks, k_cache + (int64_t)sblk * BLOCK_BYTES, lane);
-            ks_valid = true;
           }
           int ksrc = -1;                                      // per lane: source slot it receives
           for (; j < seg_end; ++j) {
