@@ -94,6 +94,8 @@ RANDOM_CASES = [
     (2, 3, 2, [41, 23], 3, True, 8, 0.4, None),
     (2, 2, 16, [2100], 16, False, 64, 0.5, None),       # heads longer than one histogram tile
     (1, 1, 16, [5000], 1, False, 128, 0.9, None),
+    (1, 1, 16, [5000, 100, 100, 100], 3, False, 128, 0.7, None),   # one head larger than the LDS staging buffer
+    (1, 2, 16, [6000, 64, 64], 2, False, 128, 0.5, 4),             # same, with metric ties
     # ties: canonical order (metric, physical block, offset) / (threshold, head, chunk)
     (2, 2, 4, [37, 50], 2, False, 8, 0.5, 3),
     (2, 4, 16, [300, 171], 20, True, 128, 0.6, 5),
