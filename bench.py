@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--protected", type=int, default=32)
     ap.add_argument("--metric-shape", default="perm", choices=["perm", "decay", "oldest"])
     ap.add_argument("--mode", default="per_sequence", choices=["per_sequence", "reference"])
+    ap.add_argument("--contiguous-blocks", action="store_true",
+                    help="physical blocks in allocation order (fresh prefill) instead of shuffled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--traffic-json", default=os.path.join(REPO, "profiles", "traffic.json"),
                     help="PMC-derived HBM bytes per launch of the compaction kernel, if collected")
@@ -100,7 +102,7 @@ def build_workload(args, seed, device):
     st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs,
                           seq_lens=[args.seq_len + 1] * args.batch, seed=seed,
                           protected=args.protected, metric_shape=args.metric_shape,
-                          spare_block_frac=0.02)
+                          spare_block_frac=0.02, shuffle_blocks=not args.contiguous_blocks)
     evicted = [synth.evict_block_count(context_lens_lh=st.context_lens[:, b, :],
                                        seq_len=args.seq_len + 1, block_size=bs,
                                        protected_window_size=args.protected,
@@ -274,7 +276,8 @@ def main():
                 "workload": f"Llama-3-8B shape L{args.layers} H{args.kv_heads} hd{args.head_size}, "
                             f"{args.seq_len}-token cache, block_size {bs}, batch {args.batch}/GPU, "
                             f"compress_once keep={args.keep}, protected_window={args.protected}, "
-                            f"metrics={args.metric_shape}, schedule mode={args.mode}",
+                            f"metrics={args.metric_shape}, schedule mode={args.mode}, physical blocks "
+                            f"{'in allocation order' if args.contiguous_blocks else 'shuffled'}",
                 "candidate_slots": N, "evicted_slots": evicted_slots, "moved_slots": moved_slots,
                 "freed_blocks": freed_blocks,
             },
