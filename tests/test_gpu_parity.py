@@ -546,3 +546,30 @@ def test_empty_inputs():
                               torch.zeros(0, dtype=torch.int64, device=DEV),
                               torch.zeros(2, device=DEV), "auto", 1.0, 1.0)
     assert torch.equal(k, k0) and torch.equal(v, v0)
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_fuzz_small_states(seed):
+    """deterministic fuzz: random shapes (incl. block sizes outside every fast path), ragged
+    and empty heads, random eviction requests, ties, both modes -- full pipeline vs oracle"""
+    rng = np.random.default_rng(1000 + seed)
+    L, H = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    bs = int(rng.choice([1, 2, 4, 8, 16, 32]))
+    B = int(rng.integers(1, 5))
+    seq_lens = [int(rng.integers(2, 40 * bs // 2 + 8)) for _ in range(B)]
+    prot = [int(rng.integers(1, 2 * bs + 2)) for _ in range(B)]
+    compressed = bool(rng.random() < 0.5)
+    ties = int(rng.integers(1, 6)) if rng.random() < 0.3 else None
+    hd = int(rng.choice([8, 16, 64, 128])) if bs != 32 else 128
+    st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs, seq_lens=seq_lens, seed=seed,
+                          protected=prot, compressed=compressed, tie_levels=ties)
+    nblk = ((st.context_lens.astype(np.int64) + bs - 1) // bs).sum(0).sum(-1)
+    # up to ALL blocks of a sequence: more than is evictable (protected window, SURVEY Q8);
+    # beyond the sequence's own block count the reference itself asserts (metrics.py:725)
+    evicted = [int(rng.integers(0, int(n) + 1)) for n in nblk]
+    k, v = synth.make_caches_u16(seed, st.num_blocks, hd, bs)
+    mode = "reference" if seed % 2 == 0 else "per_sequence"
+    want = oracle_pipeline(st, evicted, k, v, mode=mode)
+    got = _gpu_pipeline(st, evicted, k, v, mode=mode)
+    for key in ("eli", "ekc", "ebc", "cmi", "cmc", "k", "v", "metrics", "positions"):
+        np.testing.assert_array_equal(got[key], want[key], err_msg=f"{key} seed={seed} {mode}")
