@@ -1,0 +1,106 @@
+// A host with no Python and no torch driving libkvc_mi355x.so through its C ABI
+// (include/kvc_mi355x.h) and checking the result against the C oracle (oracle/kvc_oracle.c).
+// Built and run by tests/test_gpu_cabi.py:
+//   gcc -c oracle/kvc_oracle.c; hipcc --offload-arch=gfx950 tests/cabi/cabi_host.cpp kvc_oracle.o -Iinclude \
+//         -Lvllm_kvcompress_amd -lkvc_mi355x -o <tmp>/cabi_host
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "kvc_mi355x.h"
+
+extern "C" {
+void orc_count_block_evictions(int32_t*, int32_t*, const int32_t*, const int32_t*, int32_t, int64_t, int32_t, int32_t);
+void orc_schedule_t1_cache_moves(int32_t*, int64_t, int32_t*, const int32_t*, const int32_t*, const int32_t*,
+                                 const int32_t*, const int32_t*, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t);
+void orc_execute_cache_moves(uint8_t*, uint8_t*, float*, int32_t*, const int32_t*, const int32_t*, const int32_t*,
+                             int32_t, int32_t, int32_t, int32_t, int32_t);
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 2; } } while (0)
+#define KV(x) do { int rc_ = (x); if (rc_ != 0) { printf("kvc error %d: %s\n", rc_, kvc_last_error()); return 3; } } while (0)
+
+template <typename T> T* to_dev(const std::vector<T>& v) {
+  T* d = nullptr;
+  if (hipMalloc(&d, v.size() * sizeof(T) + 16) != hipSuccess) return nullptr;
+  hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+  return d;
+}
+template <typename T> bool same(const T* dev, const std::vector<T>& want, const char* name) {
+  std::vector<T> got(want.size());
+  hipMemcpy(got.data(), dev, want.size() * sizeof(T), hipMemcpyDeviceToHost);
+  if (memcmp(got.data(), want.data(), want.size() * sizeof(T)) != 0) { printf("MISMATCH %s\n", name); return false; }
+  return true;
+}
+
+int main() {
+  // one sequence, L=2, H=2, bs=16, hd=128, fp16; every head: ctx = 160 (10 blocks), 4 blocks freed
+  const int B = 1, L = 2, H = 2, bs = 16, hd = 128, e = 2, x = 8, G = B * L * H, M = 10;
+  const int ctx = 160, nblk = 10, NB = G * nblk + 3, seg = nblk * bs, N = G * seg;
+  const int NUL = 2147483000;
+  uint32_t rs = 12345u;
+  auto rnd = [&]() { rs = rs * 1664525u + 1013904223u; return rs >> 8; };
+  std::vector<int32_t> offs(G), hang(G, bs), ctxs(L * B * H, ctx), bt(L * B * H * M), perm(NB);
+  for (int i = 0; i < NB; ++i) perm[i] = i;
+  for (int i = NB - 1; i > 0; --i) std::swap(perm[i], perm[rnd() % (i + 1)]);
+  for (int g = 0; g < G; ++g) offs[g] = g * seg;
+  for (int i = 0; i < L * B * H * M; ++i) bt[i] = perm[i];
+  // evicted logical indices per head: 64 distinct random slots, ascending, rest null
+  std::vector<int32_t> eli(N, NUL), ekc(G, 4 * bs);
+  for (int g = 0; g < G; ++g) {
+    std::vector<char> pick(ctx, 0);
+    int c = 0;
+    while (c < 4 * bs) { int s = rnd() % ctx; if (!pick[s]) { pick[s] = 1; ++c; } }
+    int o = 0;
+    for (int s = 0; s < ctx; ++s) if (pick[s]) eli[g * seg + o++] = s;
+  }
+  std::vector<uint8_t> k((size_t)NB * hd * bs * e), v((size_t)NB * hd * bs * e);
+  for (auto& b : k) b = (uint8_t)rnd();
+  for (auto& b : v) b = (uint8_t)rnd();
+  std::vector<float> met((size_t)NB * bs);
+  std::vector<int32_t> pos((size_t)NB * bs);
+  for (size_t i = 0; i < met.size(); ++i) { met[i] = (float)(rnd() % 100000); pos[i] = (int32_t)(rnd() % 100000); }
+
+  // ---- oracle
+  std::vector<int32_t> w_eli = eli, w_ebc(G), w_moves((size_t)N * 2, 77), w_cnt(G);
+  orc_count_block_evictions(w_ebc.data(), w_eli.data(), offs.data(), hang.data(), G, N, bs, NUL);
+  orc_schedule_t1_cache_moves(w_moves.data(), N, w_cnt.data(), w_eli.data(), ekc.data(), offs.data(), bt.data(),
+                              ctxs.data(), B, L, H, M, bs, 1);
+  std::vector<uint8_t> wk = k, wv = v;
+  std::vector<float> wm = met;
+  std::vector<int32_t> wp = pos;
+  orc_execute_cache_moves(wk.data(), wv.data(), wm.data(), wp.data(), w_moves.data(), w_cnt.data(), offs.data(), G,
+                          bs, hd, e, x);
+
+  // ---- device through the C ABI
+  printf("kvc abi %d\n", kvc_abi_version());
+  hipStream_t s;
+  CK(hipStreamCreate(&s));
+  int32_t *d_eli = to_dev(eli), *d_offs = to_dev(offs), *d_hang = to_dev(hang), *d_ekc = to_dev(ekc),
+          *d_bt = to_dev(bt), *d_ctx = to_dev(ctxs), *d_pos = to_dev(pos);
+  uint8_t *d_k = to_dev(k), *d_v = to_dev(v);
+  float* d_met = to_dev(met);
+  int32_t *d_ebc, *d_moves, *d_cnt;
+  CK(hipMalloc(&d_ebc, G * 4)); CK(hipMalloc(&d_moves, (size_t)N * 8)); CK(hipMalloc(&d_cnt, G * 4));
+  CK(hipMemset(d_moves, 0x7f, (size_t)N * 8));
+  KV(kvc_count_block_evictions(d_ebc, d_eli, d_offs, d_hang, G, N, bs, NUL, s));
+  KV(kvc_schedule_t1_cache_moves(d_moves, N, d_cnt, d_eli, d_ekc, d_offs, d_bt, d_ctx, B, L, H, M, bs, 1, s));
+  const size_t wsb = kvc_execute_cache_moves_workspace_bytes(G, NB);
+  void* ws;
+  CK(hipMalloc(&ws, wsb));
+  KV(kvc_execute_cache_moves(d_k, d_v, d_met, d_pos, d_moves, d_cnt, d_offs, G, NB, bs, hd, e, x, ws, wsb, s));
+  CK(hipStreamSynchronize(s));
+  bool ok = same(d_ebc, w_ebc, "evicted_block_count") & same(d_eli, w_eli, "evicted_logical_indices") &
+            same(d_moves, w_moves, "cache_moves_idx") & same(d_cnt, w_cnt, "cache_moves_count") &
+            same(d_k, wk, "k_cache") & same(d_v, wv, "v_cache") & same(d_met, wm, "kv_metrics") &
+            same(d_pos, wp, "kv_position");
+  // error convention: unsupported block size -> rc 1 + message
+  int rc = kvc_count_block_evictions(d_ebc, d_eli, d_offs, d_hang, G, N, 0, NUL, s);
+  ok = ok && rc == 1 && strstr(kvc_last_error(), "Unsupported block size") != nullptr;
+  long moves = 0;
+  for (int g = 0; g < G; ++g) moves += w_cnt[g];
+  printf("%s (%ld moves)\n", ok ? "CABI_OK" : "CABI_FAIL", moves);
+  return ok ? 0 : 1;
+}
