@@ -52,6 +52,7 @@ __device__ __forceinline__ uint32_t nchunks_freed(uint32_t r, uint32_t hang, uin
 // wave-aggregated shared-memory histogram add: metric keys are often degenerate in their
 // top digits (all lanes hit one bin), which would serialise 64 LDS atomics; up to two
 // leader-elected groups are folded into one atomic each, the rest go one by one.
+// (also used on global memory with digit = head * 256 + digit)
 __device__ __forceinline__ void hist_add(uint32_t* hist, bool valid, uint32_t digit) {
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(256) void build_keys_kernel(kvc_schedule_params p, 
 // ------------------------------------------------------------------ 1. per-head histograms
 // flat tiles of TILE keys; a tile inside one head (the common case) accumulates in LDS.
 constexpr int HTILE = 2048;
+constexpr int HSEG_MAX = 8;      // head segments of a tile handled by LDS passes; more -> global atomics
 // Persistent: every workgroup walks a contiguous range of HTILE-key tiles.  The head of the
 // first tile is found by one binary search, later tiles advance it incrementally; counts of
 // consecutive tiles of one head stay in LDS and are flushed once per head.
@@ -181,18 +183,47 @@ __global__ __launch_bounds__(256) void hist_round_kernel(kvc_schedule_params p, 
         const bool valid = key < KEY_INF && (round == 0 || (key >> (shift + 8)) == prefix);
         hist_add(sh, valid, (key >> shift) & 0xFFu);
       }
-    } else {                                        // several (small) heads in this tile
+      continue;
+    }
+    // head boundaries inside the tile (scalar walk, capped)
+    int nseg = 1;
+    for (int gk = g + 1; gk < G && nseg <= HSEG_MAX && (int64_t)p.evicted_kv_offsets[gk] < t1; ++gk) ++nseg;
+    if (nseg <= HSEG_MAX) {
+      // one LDS pass per head segment of the tile (keys stay in registers).
+      // With heads of a few thousand slots (continual-compression steady state) every
+      // second or third tile has a boundary; per-key global atomics there cost 3x the
+      // whole pass because the top digits are degenerate.
+      int64_t seg_b = t0;
+      for (int sgi = 0; sgi < nseg; ++sgi) {
+        while (seg_b >= g_end && g + 1 < G) { ++g; g_end = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : N; }
+        const int64_t seg_e = min(t1, g_end);
+        if (g != cur_g) { flush(); cur_g = g; }
+        const int i = g / LH;
+        if (round == 0 || ws.seq_k[i] != 0) {       // else: inactive sequence
+          const uint32_t prefix = ws.seq_prefix[i];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int64_t idx = t0 + threadIdx.x + (int64_t)u * 256;
+            const uint32_t key = kv[u];
+            const bool valid = idx >= seg_b && idx < seg_e && key < KEY_INF &&
+                (round == 0 || (key >> (shift + 8)) == prefix);
+            hist_add(sh, valid, (key >> shift) & 0xFFu);
+          }
+        }
+        seg_b = seg_e;
+      }
+    } else {                                        // many tiny heads in this tile
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int64_t idx = t0 + threadIdx.x + (int64_t)u * 256;
-        if (idx >= t1) continue;
         int gk = g;
         int64_t ek = g_end;
         while (idx >= ek && gk + 1 < G) { ++gk; ek = (gk + 1 < G) ? (int64_t)p.evicted_kv_offsets[gk + 1] : N; }
         const int i = gk / LH;
         const uint32_t key = kv[u];
-        if (key < KEY_INF && (round == 0 || (ws.seq_k[i] != 0 && (key >> (shift + 8)) == ws.seq_prefix[i])))
-          atomicAdd(&ws.hist[(int64_t)gk * RADIX + ((key >> shift) & 0xFFu)], 1u);
+        const bool valid = idx < t1 && key < KEY_INF &&
+            (round == 0 || (ws.seq_k[i] != 0 && (key >> (shift + 8)) == ws.seq_prefix[i]));
+        hist_add(ws.hist, valid, (uint32_t)gk * RADIX + ((key >> shift) & 0xFFu));
       }
     }
   }
@@ -391,7 +422,6 @@ __global__ __launch_bounds__(256) void finalize_heads_kernel(kvc_schedule_params
 // ------------------------------------------------------------------ 6. select + emit
 // one workgroup per head: cnt-th smallest (key, physical slot) by radix select, then the
 // ascending logical indices of everything at or below it.       metrics.py:822-834
-constexpr int SEL_THREADS = 1024;
 
 // radix-select the rank-th (1-based) smallest value of f(idx) over idx in [0,n) where
 // pred(idx); returns the value, and the 1-based rank among equals / number of equals.
@@ -448,6 +478,7 @@ __device__ void block_radix_select(uint32_t* hist, uint32_t* bc, int n, uint32_t
 }
 
 // lds_cap = number of keys the dynamic LDS buffer can stage (0 = read keys from global/L2)
+template <int SEL_THREADS>
 __global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(kvc_schedule_params p, SchedWs ws, int lds_cap) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_keys[];
   __shared__ __attribute__((aligned(16))) uint32_t hist[RADIX];
@@ -632,14 +663,23 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   }
   hipLaunchKernelGGL(finalize_heads_kernel, dim3(B), dim3(256), 0, s, p, ws);
   {
-    // stage a head's keys in LDS when the average head fits (ragged heads that do not fit
-    // read from L2); small heads take a small buffer so that several workgroups share a CU
+    // stage a head's keys in LDS when the average head fits with 25 % slack (ragged heads
+    // that do not fit read from L2).  Small heads (the continual-compression steady state:
+    // thousands of heads of a few thousand slots) take 256-thread workgroups and a small
+    // buffer so that 6+ heads share a CU; the per-head passes are barrier-latency bound.
     const int64_t avg = p.total_slots / G;
-    int lds_cap = avg <= 3072 ? 4096 : (avg <= 12288 ? 16384 : 32768);
+    int64_t want = (avg + avg / 4 + 2047) / 2048 * 2048;
+    // (heads beyond 32k slots read their keys from L2: measured faster than one 144 KiB
+    // staging workgroup per CU)
+    const int lds_cap = (int)(want < 2048 ? 2048 : (want > 32768 ? 32768 : want));
     // > 64 KiB of dynamic LDS needs the opt-in (gfx950 has 160 KiB per CU); per device, cheap
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(select_emit_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
-    hipLaunchKernelGGL(select_emit_kernel, dim3(G), dim3(SEL_THREADS), (size_t)lds_cap * 4, s, p, ws, lds_cap);
+    if (avg <= 8192) {
+      hipLaunchKernelGGL(select_emit_kernel<256>, dim3(G), dim3(256), (size_t)lds_cap * 4, s, p, ws, lds_cap);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(select_emit_kernel<1024>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
+      hipLaunchKernelGGL(select_emit_kernel<1024>, dim3(G), dim3(1024), (size_t)lds_cap * 4, s, p, ws, lds_cap);
+    }
   }
   return check_launch("schedule_evictions");
 }

@@ -93,6 +93,7 @@ def make_state(
     tie_levels: Optional[int] = None,
     metric_shape: str = "perm",
     shuffle_blocks: bool = True,
+    steady_cap: Optional[int] = None,
 ) -> PagedState:
     """Build a synthetic state.
 
@@ -104,6 +105,9 @@ def make_state(
                   a random multiple of ``block_size`` survivors with arbitrary
                   (sorted) positions, plus a random number of appended decode
                   tokens.
+    steady_cap    continual-compression steady state: every head holds ``steady_cap`` survivors
+                  (a multiple of block_size, arbitrary sorted positions) plus ONE freshly
+                  appended token, i.e. the state right before the next compression step.
     tie_levels    if set, metrics are drawn from that many distinct values (to
                   exercise the canonical tie order); default is tie-free.
     metric_shape  "perm": per-sequence random permutation cast to f32;
@@ -123,7 +127,10 @@ def make_state(
     ctx = np.zeros((L, B, H), dtype=np.int32)
     for b in range(B):
         full = int(seq_lens[b]) - 1
-        if not compressed:
+        if steady_cap is not None:
+            assert steady_cap % bs == 0
+            ctx[:, b, :] = min(steady_cap + 1, full)
+        elif not compressed:
             ctx[:, b, :] = full
         else:
             # survivors: a multiple of bs in [0, full], then 0..bs-1 appended tokens
@@ -165,7 +172,7 @@ def make_state(
                 lbn_by[blocks] = np.arange(n, dtype=np.int32)
                 c = int(ctx[l, b, h])
                 lam = (np.arange(n, dtype=np.int32)[:, None] * bs + ar[None, :])  # [n,bs]
-                if not compressed:
+                if not compressed and steady_cap is None:
                     pos = lam.copy()                 # positions == logical index
                 else:
                     # survivors: sorted distinct positions below seq_pos; the empty
