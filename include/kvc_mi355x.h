@@ -93,7 +93,8 @@ int kvc_schedule_t1_cache_moves(int32_t* cache_moves_idx,            /* [rows,2]
  * blocks_per_head / threads_per_head of the reference signature are launch hints of the
  * CUDA kernel and have no meaning here (the Python wrapper accepts and ignores them).
  * workspace: kvc_execute_cache_moves_workspace_bytes(total_heads, num_blocks) bytes of
- * device memory (tile prefix sums + one claim byte per physical block).
+ * device memory, 16-byte aligned (tile prefix sums + one claim byte per physical block);
+ * no need to clear it, the planning kernel does.
  * --------------------------------------------------------------------------------- */
 size_t kvc_execute_cache_moves_workspace_bytes(int32_t total_heads, int64_t num_blocks);
 int kvc_execute_cache_moves(void* k_cache, void* v_cache, float* kv_metrics,

@@ -168,6 +168,7 @@ def test_full_size_properties(T, BS, cdtype, keep):
 
     # the block (fast) path was taken for every destination block
     ws = ops._WORKSPACES[(0, "execute_cache_moves")]
-    claims = ws[(G + 2) * 4:(G + 2) * 4 + NB]
+    coff = ((G + 2) * 4 + 15) // 16 * 16          # [tile prefix, padded to 16 B][claim bytes]
+    claims = ws[coff:coff + NB]
     assert int(claims.max()) == 1
     assert int((claims == 1).sum()) == (dst // BS).unique().numel()

@@ -46,14 +46,19 @@ constexpr int KVC_TM_GENERIC = 32;    // moves per tile of the generic (byte-wis
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------- planning
-__global__ __launch_bounds__(256) void compact_plan_tiles_kernel(int32_t* __restrict__ tiles,
-                                                                 const int32_t* __restrict__ count, int G, int tm) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g < G) tiles[g] = (count[g] + tm - 1) / tm;
-}
-
-// single workgroup: in-place exclusive scan of tiles[0..G) -> prefix[0..G]
-__global__ __launch_bounds__(1024) void compact_plan_scan_kernel(int32_t* __restrict__ tiles, int G) {
+// workgroup 0: exclusive scan of ceil(count/tm) -> prefix[0..G]; every other workgroup
+// zeroes a slice of the claim table (one launch instead of a memset + two kernels)
+__global__ __launch_bounds__(1024) void compact_plan_kernel(int32_t* __restrict__ prefix,
+                                                            const int32_t* __restrict__ count, int G,
+                                                            int tm, u32x4* __restrict__ claims16,
+                                                            int64_t claim_vecs) {
+  if (blockIdx.x > 0) {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (int64_t i = (int64_t)(blockIdx.x - 1) * 1024 + threadIdx.x; i < claim_vecs;
+         i += (int64_t)(gridDim.x - 1) * 1024)
+      claims16[i] = z;
+    return;
+  }
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t carry_s;
   const int tid = threadIdx.x, lane = lane_id(), w = tid / WAVE;
@@ -61,19 +66,19 @@ __global__ __launch_bounds__(1024) void compact_plan_scan_kernel(int32_t* __rest
   __syncthreads();
   for (int base = 0; base < G; base += 1024) {
     const int i = base + tid;
-    const uint32_t v = i < G ? (uint32_t)tiles[i] : 0u;
+    const uint32_t v = i < G ? (uint32_t)((count[i] + tm - 1) / tm) : 0u;
     const uint32_t inc = wave_inclusive_scan(v);
     if (lane == 63) wave_tot[w] = inc;
     __syncthreads();
     uint32_t woff = 0;
     for (int k = 0; k < w; ++k) woff += wave_tot[k];
     const uint32_t carry = carry_s;
-    if (i < G) tiles[i] = (int32_t)(carry + woff + inc - v);
+    if (i < G) prefix[i] = (int32_t)(carry + woff + inc - v);
     __syncthreads();
     if (tid == 1023) carry_s = carry + woff + inc;
     __syncthreads();
   }
-  if (tid == 0) tiles[G] = (int32_t)carry_s;
+  if (tid == 0) prefix[G] = (int32_t)carry_s;
 }
 
 // one wave per tile: every run start claims its destination block
@@ -85,15 +90,23 @@ __global__ __launch_bounds__(256) void compact_plan_claims_kernel(
   const int total_tiles = tile_prefix[G];
   const int lane = lane_id();
   const int nw = gridDim.x * (blockDim.x / WAVE);
-  for (int t = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE; t < total_tiles; t += nw) {
-    const int g = upper_bound_minus1(tile_prefix, G, t);
+  const int wv = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+  // contiguous tile range per wave: one binary search, then the head advances incrementally
+  const int tb = (int)((int64_t)total_tiles * wv / nw), te = (int)((int64_t)total_tiles * (wv + 1) / nw);
+  if (tb >= te) return;
+  int g = upper_bound_minus1(tile_prefix, G, tb);
+  int g_first = tile_prefix[g], g_next = tile_prefix[g + 1];
+  for (int t = tb; t < te; ++t) {
+    while (t >= g_next) { ++g; g_first = g_next; g_next = tile_prefix[g + 1]; }
     const int cnt = count[g];
-    const int j = (t - tile_prefix[g]) * tm + lane;
+    const int j = (t - g_first) * tm + lane;
     const int2* mv = reinterpret_cast<const int2*>(moves) + offs[g];
-    if (lane < tm && j < cnt) {
-      const int dblk = mv[j].x / bs;
-      if (j == 0 || mv[j - 1].x / bs != dblk) atomicAdd(&claims[dblk >> 2], 1u << (8 * (dblk & 3)));
-    }
+    const bool in = lane < tm && j < cnt;
+    const int dblk = in ? mv[j].x / bs : -1;
+    // destination block of the previous move: lane - 1 holds it, except for the tile's first lane
+    int prev = __shfl_up(dblk, 1, 64);
+    if (lane == 0) prev = (in && j > 0) ? mv[j - 1].x / bs : -1;
+    if (in && prev != dblk) atomicAdd(&claims[dblk >> 2], 1u << (8 * (dblk & 3)));
   }
 }
 
@@ -418,10 +431,13 @@ extern "C" float kvc_debug_event_elapsed_ms(void* start, void* stop) {
   return ms;
 }
 
-static size_t claims_bytes(int64_t num_blocks) { return (size_t)((num_blocks + 3) / 4 + 1) * 4; }
+// one byte per block, in whole 16 B vectors
+static size_t claims_bytes(int64_t num_blocks) { return (size_t)((num_blocks + 15) / 16 + 1) * 16; }
+// [prefix: (heads + 1) int32, padded to 16 B][claims]
+static size_t claims_offset(int32_t total_heads) { return ((size_t)((int64_t)total_heads + 2) * sizeof(int32_t) + 15) / 16 * 16; }
 
 extern "C" size_t kvc_execute_cache_moves_workspace_bytes(int32_t total_heads, int64_t num_blocks) {
-  return (size_t)((int64_t)total_heads + 2) * sizeof(int32_t) + claims_bytes(num_blocks);
+  return claims_offset(total_heads) + claims_bytes(num_blocks);
 }
 
 extern "C" int kvc_execute_cache_moves(void* k_cache, void* v_cache, float* kv_metrics,
@@ -445,19 +461,24 @@ extern "C" int kvc_execute_cache_moves(void* k_cache, void* v_cache, float* kv_m
     return fail_invalid("execute_cache_moves: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   int32_t* prefix = reinterpret_cast<int32_t*>(workspace);
-  uint32_t* claims = reinterpret_cast<uint32_t*>(prefix + total_heads + 2);   // claim bytes
+  if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0)
+    return fail_invalid("execute_cache_moves: workspace must be 16-byte aligned");
+  uint32_t* claims = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(workspace) + claims_offset(total_heads));
   const int G = total_heads;
   const int grid = 256 * 8;     // persistent: 256 CUs x 8 workgroups of 4 independent waves
-  (void)hipMemsetAsync(claims, 0, claims_bytes(num_blocks), s);
   // a wave holds one move per lane: tile + look-behind + (bs-1) look-ahead <= 64 lanes
   const int combo = head_size * 10000 + block_size * 100 + elem_bytes;   // block-path instantiations
   const bool shape_fast = x * elem_bytes == 16 &&
       (combo == 1281602 || combo == 1283201 || combo == 1283202 || combo == 1281601 ||
        combo == 1281604 || combo == 641602 || combo == 2561602);
   const int tm = shape_fast ? 64 - block_size : KVC_TM_GENERIC;
-  hipLaunchKernelGGL(compact_plan_tiles_kernel, dim3((G + 255) / 256), dim3(256), 0, s, prefix,
-                     cache_moves_count, G, tm);
-  hipLaunchKernelGGL(compact_plan_scan_kernel, dim3(1), dim3(1024), 0, s, prefix, G);
+  {
+    const int64_t claim_vecs = (int64_t)(claims_bytes(num_blocks) / 16);
+    const int64_t zb = (claim_vecs + 4095) / 4096;                 // 4 stores per thread
+    hipLaunchKernelGGL(compact_plan_kernel, dim3(1 + (unsigned)(zb < 1 ? 1 : (zb > 1024 ? 1024 : zb))),
+                       dim3(1024), 0, s, prefix, cache_moves_count, G, tm,
+                       reinterpret_cast<u32x4*>(claims), claim_vecs);
+  }
   hipLaunchKernelGGL(compact_plan_claims_kernel, dim3(grid), dim3(256), 0, s, claims, cache_moves_idx,
                      cache_moves_count, evicted_kv_offsets, prefix, G, block_size, tm);
   uint8_t* k = reinterpret_cast<uint8_t*>(k_cache);

@@ -88,7 +88,14 @@ __device__ __forceinline__ uint32_t slot_key(const kvc_schedule_params& p, float
 
 // one thread per VEC consecutive slots of a physical block (VEC = 4: 16 B loads and stores)
 template <int VEC>
-__global__ __launch_bounds__(256) void build_keys_kernel(kvc_schedule_params p, SchedWs ws) {
+__global__ __launch_bounds__(256) void build_keys_kernel(kvc_schedule_params p, SchedWs ws,
+                                                         unsigned data_blocks, uint4* zero16, int64_t zero_vecs) {
+  if (blockIdx.x >= data_blocks) {      // tail workgroups clear the counters of the later passes
+    for (int64_t i = (int64_t)(blockIdx.x - data_blocks) * 256 + threadIdx.x; i < zero_vecs;
+         i += (int64_t)(gridDim.x - data_blocks) * 256)
+      zero16[i] = make_uint4(0u, 0u, 0u, 0u);
+    return;
+  }
   const int bs = p.block_size;
   const int per_blk = bs / VEC;
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -581,9 +588,9 @@ struct WsLayout {
 static WsLayout ws_layout(int64_t N, int32_t G, int32_t B, int32_t bs) {
   WsLayout l;
   size_t o = 0;
-  l.keys = o;        o = align_up(o + (size_t)N * 4, 256);
-  l.zero_begin = o;  // everything up to zero_end is cleared by ONE memset per call
+  l.keys = o;        o = align_up(o + (size_t)N * 4, 256);      // keys + chunk_phys: ONE 0xFF memset
   l.chunk_phys = o;  o = align_up(o + (size_t)(N / bs + 1) * 4, 256);
+  l.zero_begin = o;  // everything up to zero_end is cleared by build_keys' tail workgroups
   l.hist = o;        o = align_up(o + (size_t)G * kvc::RADIX * 4, 256);
   l.less = o;        o = align_up(o + (size_t)G * 4, 256);
   l.eq = o;          o = align_up(o + (size_t)G * 4, 256);
@@ -619,6 +626,8 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   const int B = p.num_seqs;
   const WsLayout l = ws_layout(p.total_slots, G, B, p.block_size);
   if (workspace_bytes < l.total) return fail_invalid("schedule_evictions: workspace too small");
+  if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0)
+    return fail_invalid("schedule_evictions: workspace must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   uint8_t* wb = reinterpret_cast<uint8_t*>(workspace);
   SchedWs ws;
@@ -637,15 +646,24 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     hipMemsetAsync(p.evicted_block_count, 0, (size_t)G * 4, s);
     return check_launch("schedule_evictions(empty)");
   }
-  // keys default to "not evictable"; chunk table, histograms and counters to 0 (one memset)
-  hipMemsetAsync(ws.keys, 0xFF, (size_t)p.total_slots * 4, s);
-  hipMemsetAsync(wb + l.zero_begin, 0, l.zero_end - l.zero_begin, s);
-  if (p.block_size % 4 == 0) {
-    const int64_t threads = p.num_blocks * (p.block_size / 4);
-    hipLaunchKernelGGL(build_keys_kernel<4>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p, ws);
-  } else {
-    const int64_t threads = p.num_blocks * p.block_size;
-    hipLaunchKernelGGL(build_keys_kernel<1>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, p, ws);
+  // keys default to "not evictable" (0xFFFFFFFF > KEY_INF) and the chunk table to -1 for slots
+  // no physical block claims (inconsistent metadata); histograms and counters are zeroed by
+  // the tail workgroups of build_keys
+  hipMemsetAsync(ws.keys, 0xFF, l.zero_begin - l.keys, s);
+  {
+    uint4* z16 = reinterpret_cast<uint4*>(wb + l.zero_begin);
+    const int64_t zv = (int64_t)((l.zero_end - l.zero_begin) / 16);
+    const int64_t zb64 = (zv + 1023) / 1024;
+    const unsigned zb = (unsigned)(zb64 < 1 ? 1 : (zb64 > 2048 ? 2048 : zb64));
+    if (p.block_size % 4 == 0) {
+      const int64_t threads = p.num_blocks * (p.block_size / 4);
+      const unsigned db = (unsigned)((threads + 255) / 256);
+      hipLaunchKernelGGL(build_keys_kernel<4>, dim3(db + zb), dim3(256), 0, s, p, ws, db, z16, zv);
+    } else {
+      const int64_t threads = p.num_blocks * p.block_size;
+      const unsigned db = (unsigned)((threads + 255) / 256);
+      hipLaunchKernelGGL(build_keys_kernel<1>, dim3(db + zb), dim3(256), 0, s, p, ws, db, z16, zv);
+    }
   }
   const int64_t htiles_all = (p.total_slots + HTILE - 1) / HTILE;
 #ifndef KVC_HIST_GRID
