@@ -36,7 +36,7 @@ struct SchedWs {
   uint32_t* keys;        // [N]      order-preserving metric keys, index off_g + lambda
   int32_t* chunk_phys;   // [N/bs]   physical block of logical chunk
   uint32_t* hist;        // [G,256]  per-head digit histogram (re-zeroed by scan_round)
-  uint32_t* cum;         // [G,256]  inclusive cumulative counts of the current round
+  uint32_t* cum;         // [4,G,256] inclusive cumulative counts of every round (select_emit reuses them)
   uint32_t* chunkcnt;    // [G,256]  chunks freed if the digit were d
   uint32_t* less;        // [G]      keys strictly below the current prefix
   uint32_t* eq;          // [G]      keys equal to T* (after the last round)
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void hist_round_kernel(kvc_schedule_params p, 
 
 // ------------------------------------------------------------------ 2. per-head scan
 // one wave per head: hist -> inclusive cumulative; chunkcnt[d] = chunks freed at digit d
-__global__ __launch_bounds__(256) void scan_round_kernel(kvc_schedule_params p, SchedWs ws) {
+__global__ __launch_bounds__(256) void scan_round_kernel(kvc_schedule_params p, SchedWs ws, int round) {
   const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
   const int g = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   if (g >= G) return;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void scan_round_kernel(kvc_schedule_params p, 
   const uint32_t inc = wave_inclusive_scan(v.w);
   const uint32_t ex = inc - v.w;
   v.x += ex; v.y += ex; v.z += ex; v.w += ex;
-  reinterpret_cast<uint4*>(ws.cum + (int64_t)g * RADIX)[lane] = v;
+  reinterpret_cast<uint4*>(ws.cum + ((int64_t)round * G + g) * RADIX)[lane] = v;
   const uint32_t less = ws.less[g], hang = (uint32_t)p.hanging_token_count[g], bs = (uint32_t)p.block_size;
   uint4 c;
   c.x = nchunks_freed(less + v.x, hang, bs); c.y = nchunks_freed(less + v.y, hang, bs);
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(1024) void pick_round_kernel(kvc_schedule_params p,
   if (threadIdx.x == 0) ws.seq_prefix[i] = (ws.seq_prefix[i] << 8) | (uint32_t)ds;
   for (int h2 = threadIdx.x; h2 < LH; h2 += blockDim.x) {
     const int g = i * LH + h2;
-    const uint32_t* cum = ws.cum + (int64_t)g * RADIX;
+    const uint32_t* cum = ws.cum + ((int64_t)round * p.num_seqs * LH + g) * RADIX;
     const uint32_t below = ds > 0 ? cum[ds - 1] : 0u;
     ws.less[g] += below;
     if (round == 3) ws.eq[g] = cum[ds] - below;
@@ -432,12 +432,14 @@ __global__ __launch_bounds__(256) void finalize_heads_kernel(kvc_schedule_params
 
 // radix-select the rank-th (1-based) smallest value of f(idx) over idx in [0,n) where
 // pred(idx); returns the value, and the 1-based rank among equals / number of equals.
+// (first_round, prefix0): the top first_round digits are already known to be prefix0 and
+// `rank` counts within that bucket; first_round == 4 returns prefix0 with out_eq untouched.
 template <typename ValF, typename PredF>
 __device__ void block_radix_select(uint32_t* hist, uint32_t* bc, int n, uint32_t rank, ValF val,
                                    PredF pred, uint32_t& out_val, uint32_t& out_rank_in_eq,
-                                   uint32_t& out_eq) {
-  uint32_t prefix = 0;
-  for (int round = 0; round < 4; ++round) {
+                                   uint32_t& out_eq, int first_round = 0, uint32_t prefix0 = 0) {
+  uint32_t prefix = prefix0;
+  for (int round = first_round; round < 4; ++round) {
     const int shift = 24 - 8 * round;
     for (int k = threadIdx.x; k < RADIX; k += blockDim.x) hist[k] = 0;
     __syncthreads();
@@ -518,8 +520,57 @@ __global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(kvc_schedule_p
     __syncthreads();
   }
   auto key_at = [&](int idx) { return staged ? lds_keys[idx] : gkeys[idx]; };
-  uint32_t M, take, eqn;
-  block_radix_select(hist, bc, n, cnt, key_at, [&](int) { return true; }, M, take, eqn);
+  // Warm start from the sequence-level rounds: cum[r][g][d] counts this head's keys that share
+  // T*'s top r digits and have digit r <= d.  The cnt-th smallest key M is at most T* and at
+  // most a block's worth of keys below it, so it normally shares two or three digits with
+  // T*: find the first round r* whose below-T* count L_r reaches cnt, read M's digit r* off
+  // the stored histogram, and only run the remaining rounds r*+1..3 over the keys.
+  uint32_t M, take, eqn = 0;
+  {
+    const int i_seq = g / (p.num_layers * p.num_kv_heads);
+    const uint32_t Tstar = ws.seq_prefix[i_seq];
+    if (tid == 0) {
+      uint32_t L = 0;
+      int rstar = 4;
+      uint32_t base_rank = 0;
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t ds = (Tstar >> (24 - 8 * r)) & 0xFFu;
+        const uint32_t below = ds ? ws.cum[((int64_t)r * G + g) * RADIX + ds - 1] : 0u;
+        if (cnt <= L + below) { rstar = r; base_rank = L; break; }
+        L += below;
+      }
+      if (rstar == 4) base_rank = L;                 // M == T*: rank among the equal keys
+      bc[0] = (uint32_t)rstar;
+      bc[1] = base_rank;
+    }
+    __syncthreads();
+    const int rstar = (int)bc[0];
+    const uint32_t base_rank = bc[1];
+    __syncthreads();
+    if (rstar == 4) {
+      if (cnt - base_rank <= ws.eq[g]) {
+        M = Tstar; take = cnt - base_rank; eqn = ws.eq[g];
+      } else {                                       // not expected (finalize caps cnt): full select
+        block_radix_select(hist, bc, n, cnt, key_at, [&](int) { return true; }, M, take, eqn);
+      }
+    } else {
+      // digit r* of M: first d with cum[r*][d] >= cnt - base_rank (d < T*'s digit by construction)
+      const uint32_t* cr = ws.cum + ((int64_t)rstar * G + g) * RADIX;
+      const uint32_t tgt = cnt - base_rank;
+      for (int d = tid; d < RADIX; d += blockDim.x) {
+        const uint32_t c = cr[d], c0 = d ? cr[d - 1] : 0u;
+        if (c0 < tgt && tgt <= c) { bc[0] = (uint32_t)d; bc[1] = c0; bc[2] = c - c0; }
+      }
+      __syncthreads();
+      const uint32_t dig = bc[0], c0 = bc[1], cw = bc[2];
+      __syncthreads();
+      const uint32_t hi = rstar ? (Tstar >> (32 - 8 * rstar)) : 0u;       // shared top digits
+      const uint32_t prefix = (hi << 8) | dig;
+      eqn = cw;                                      // only final when r* == 3
+      block_radix_select(hist, bc, n, tgt - c0, key_at, [&](int) { return true; }, M, take, eqn,
+                         rstar + 1, prefix);
+    }
+  }
   // ties on the metric: the `take` entries with the smallest (physical block, offset)
   uint32_t Fstar = 0xFFFFFFFFu;
   const int32_t* cphys = ws.chunk_phys + base / bs;
@@ -597,7 +648,7 @@ static WsLayout ws_layout(int64_t N, int32_t G, int32_t B, int32_t bs) {
   l.seq_prefix = o;  o = align_up(o + (size_t)B * 4, 256);
   l.seq_k = o;       o = align_up(o + (size_t)B * 4, 256);
   l.zero_end = o;
-  l.cum = o;         o = align_up(o + (size_t)G * kvc::RADIX * 4, 256);
+  l.cum = o;         o = align_up(o + (size_t)4 * G * kvc::RADIX * 4, 256);
   l.chunkcnt = o;    o = align_up(o + (size_t)G * kvc::RADIX * 4, 256);
   l.seq_tmp = o;     o = align_up(o + (size_t)B * 12, 256);
   l.total = o;
@@ -672,7 +723,7 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   const unsigned htiles = (unsigned)(htiles_all < KVC_HIST_GRID ? htiles_all : KVC_HIST_GRID);   // persistent grid
   for (int round = 0; round < 4; ++round) {
     hipLaunchKernelGGL(hist_round_kernel, dim3(htiles), dim3(256), 0, s, p, ws, round);
-    hipLaunchKernelGGL(scan_round_kernel, dim3((G + 3) / 4), dim3(256), 0, s, p, ws);
+    hipLaunchKernelGGL(scan_round_kernel, dim3((G + 3) / 4), dim3(256), 0, s, p, ws, round);
     if (round == 0) {
       hipLaunchKernelGGL(seq_totals_kernel, dim3(B), dim3(256), 0, s, p, ws);
       hipLaunchKernelGGL(seq_prepare_kernel, dim3(1), dim3(1024), 0, s, p, ws);
