@@ -245,6 +245,50 @@ int kvc_free_compressed_blocks(int32_t* context_lens, int32_t* seq_index_by_bloc
                                int32_t block_size, void* workspace, size_t workspace_bytes,
                                kvc_stream_t stream);
 
+/* ---------------------------------------------------------------------------------
+ * F3  single-query paged attention with KV-metric output (decode step)
+ * replaces torch.ops._C.kvcompress_paged_attention_v1 / _v2
+ *   (csrc/attention/kvcompress_attention_kernels.cu:686-1056, kernels :97-455, :532-651;
+ *    vllm/_custom_ops.py:135-201; caller vllm/attention/ops/paged_attn.py:312-407)
+ * For every (sequence, query head): p = softmax(scale * q.K^T [+ ALiBi]) over the
+ * context_lens[seq, kv_head] cached keys of that KV head (per-head paged cache),
+ * out = p.V, and - if record_kv_metrics - kv_metric_out[block, offset, q % qpk] = p for
+ * every key with kv_position <= last_position[seq] - kv_metric_buffer_len[seq]; other
+ * entries of kv_metric_out are left untouched.  Softmax uses 1/(sum + 1e-6) like the
+ * reference.  Floating point: results agree with the reference within its own test
+ * tolerance (tests/kernels/test_kvcompress_attention.py:356-362), not bit for bit.
+ * Contexts longer than 512 tokens are split into 512-token partitions (the reference's
+ * v2); the four partition buffers have the v2 shapes and may be NULL when
+ * max_context_len <= 512.
+ * dtype: 0 = fp16, 1 = bf16 (query, output and cache).  kv_cache_dtype: 0 = "auto".
+ * block_size 16 or 32; head_size 64, 96, 128 or 256.
+ * --------------------------------------------------------------------------------- */
+typedef struct kvc_attention_params {
+  void* out;                            /* [num_seqs, num_heads, head_size] */
+  float* kv_metric_out;                 /* [num_blocks, block_size, qpk] */
+  float* exp_sums;                      /* [num_seqs, num_heads, max_parts] or NULL */
+  float* max_logits;                    /* [num_seqs, num_heads, max_parts] or NULL */
+  void* tmp_out;                        /* [num_seqs, num_heads, max_parts, head_size] or NULL */
+  float* tmp_kv_metric_out;             /* [num_blocks, block_size, qpk] or NULL */
+  const void* query;                    /* [num_seqs, num_heads, head_size], seq stride q_stride */
+  const void* key_cache;                /* [num_blocks, head_size/x, block_size, x] */
+  const void* value_cache;              /* [num_blocks, head_size, block_size] */
+  const int32_t* block_tables;          /* [num_seqs, num_kv_heads, max_num_blocks_per_seq] */
+  const int32_t* context_lens;          /* [num_seqs, num_kv_heads] */
+  const int32_t* kv_position;           /* [num_blocks, block_size] */
+  const int32_t* last_position;         /* [num_seqs] */
+  const int32_t* kv_metric_buffer_len;  /* [num_seqs] */
+  const float* alibi_slopes;            /* [num_heads] or NULL */
+  int64_t q_stride;                     /* elements between sequences of query */
+  int64_t kv_block_stride;              /* elements between blocks of the caches */
+  float scale, k_scale, v_scale;
+  int32_t num_seqs, num_heads, num_kv_heads, head_size, block_size;
+  int32_t max_num_blocks_per_seq, max_context_len;
+  int32_t dtype, kv_cache_dtype, record_kv_metrics;
+} kvc_attention_params;
+
+int kvc_paged_attention_decode(const kvc_attention_params* p, kvc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -438,3 +438,71 @@ def free_compressed_blocks(block_tables, context_lens, seq_indices, freed_block_
     context_lens[:, sel, :] -= removed.astype(context_lens.dtype)
     seq_index_by_block[freed] = -1
     return freed.astype(np.int32)
+
+
+# --------------------------------------------------------------------------------------
+# F3  single-query paged attention with per-key metric output
+#     csrc/attention/kvcompress_attention_kernels.cu:97-455 (main), :532-651 (v2 reduce);
+#     twin: tests/kernels/test_kvcompress_attention.py:41-145
+# --------------------------------------------------------------------------------------
+def round_to_bf16(x):
+    """float32 -> nearest-even bfloat16, returned as float32"""
+    b = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    r = ((b + np.uint32(0x7FFF) + ((b >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000))
+    return r.view(np.float32)
+
+
+def paged_attention_decode(out, kv_metric_out, query, key_cache, value_cache, num_kv_heads, scale,
+                           block_tables, context_lens, kv_position, last_position,
+                           kv_metric_buffer_len, alibi_slopes=None, record_kv_metrics=True,
+                           k_scale=1.0, v_scale=1.0, p_dtype=np.float16):
+    """query [S,Hq,hd] (f16 bits as np.float16, or f32 holding bf16 values), key_cache
+    [NB,hd/x,bs,x], value_cache [NB,hd,bs] (same element type, already dequantised for fp8),
+    block_tables [S,Hkv,M] i32, context_lens [S,Hkv] i32, kv_position [NB,bs] i32,
+    last_position / kv_metric_buffer_len [S] i32; out [S,Hq,hd] f32 (caller rounds to the
+    output type), kv_metric_out [NB,bs,qpk] f32 written in place.
+
+    Per (seq, query head): logits = scale * q.k (+ alibi_slope * (i - ctx + 1), .cu:265),
+    p = exp(l - max) / (sum + 1e-6) (.cu:291-303), out = sum_i p_i v_i with p rounded to
+    the value type first (.cu:332-420 `from_float(logits_vec, ...)`; twin :53
+    `attn_weights.to(value.dtype)`).  p is stored at [phys_block, offset, q % qpk] only
+    where kv_position <= last_position - kv_metric_buffer_len (.cu:124, :305-312); every
+    other entry of kv_metric_out is left untouched (v1 semantics; the v2 reduce kernel
+    copies whatever its tmp buffer holds for such slots, :563-568 - an artefact that is
+    not reproduced)."""
+    S, Hq, hd = query.shape
+    qpk = Hq // num_kv_heads
+    NB, _, bs = value_cache.shape
+    kc = key_cache.astype(np.float32).transpose(0, 2, 1, 3).reshape(NB, bs, hd)    # [NB,bs,hd]
+    vc = value_cache.astype(np.float32).transpose(0, 2, 1)                         # [NB,bs,hd]
+    q32 = query.astype(np.float32)
+    for s in range(S):
+        max_pos = int(last_position[s]) - int(kv_metric_buffer_len[s])
+        for h in range(num_kv_heads):
+            ctx = int(context_lens[s, h])
+            if ctx <= 0:
+                continue
+            nblk = (ctx + bs - 1) // bs
+            blocks = block_tables[s, h, :nblk].astype(np.int64)
+            keys = (kc[blocks].reshape(nblk * bs, hd)[:ctx] * np.float32(k_scale)).astype(np.float32)
+            vals = (vc[blocks].reshape(nblk * bs, hd)[:ctx] * np.float32(v_scale)).astype(np.float32)
+            phys = (blocks[:, None] * bs + np.arange(bs)[None, :]).reshape(-1)[:ctx]
+            rec = kv_position.reshape(-1)[phys] <= max_pos
+            for qo in range(qpk):
+                qh = h * qpk + qo
+                logits = (np.float32(scale) * (keys @ q32[s, qh])).astype(np.float32)
+                if alibi_slopes is not None and alibi_slopes[qh] != 0:
+                    logits = logits + np.float32(alibi_slopes[qh]) * (
+                        np.arange(ctx, dtype=np.float32) - np.float32(ctx - 1))
+                e = np.exp(logits - logits.max(), dtype=np.float32)
+                p = (e * (np.float32(1.0) / (e.sum(dtype=np.float32) + np.float32(1e-6)))).astype(np.float32)
+                if p_dtype == "bf16":
+                    pv = round_to_bf16(p)
+                elif p_dtype is not None:
+                    pv = p.astype(p_dtype).astype(np.float32)
+                else:
+                    pv = p
+                out[s, qh] = pv @ vals
+                if record_kv_metrics:
+                    flat = kv_metric_out.reshape(-1, qpk)
+                    flat[phys[rec], qo] = p[rec]

@@ -1,11 +1,13 @@
 """Pin the oracle: every function of oracle/kvc_oracle.py against the golden
 vectors produced by the reference's own Python (oracle/gen_golden.py)."""
+import os
+
 import numpy as np
 import pytest
 
 from oracle import kvc_oracle as orc
 from tests.conftest import golden_cases
-from tests.helpers import golden_caches, load_golden, sched_kwargs, sha
+from tests.helpers import GOLDEN_DIR, golden_caches, load_golden, sched_kwargs, sha
 
 
 @pytest.mark.parametrize("name", golden_cases())
@@ -205,3 +207,47 @@ def test_host_policy_matches_reference():
             with pytest.raises(AssertionError):
                 synth.evict_block_count(**kw)
     assert o == flat.shape[0] and fired > 0
+
+
+# --------------------------------------------------------------------------------------
+# F3: decode attention with metric output -- oracle vs the reference test's PyTorch twin
+ATTN_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.startswith("attn_decode_"))
+
+
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_paged_attention_decode_matches_reference_twin(case):
+    """tolerances of the reference's own test (test_kvcompress_attention.py:145 default
+    allclose on the weights, :356-357 atol 1e-3 / rtol 1e-5 on the output); the bf16 twin
+    rounds its logits to bf16, so the weights are compared at 1e-4 there."""
+    from tests.attn_helpers import decode_golden, oracle_decode
+    g = load_golden(case)
+    c = decode_golden(g)
+    NB, _, bs = c["vc"].shape
+    S = c["q"].shape[0]
+    pos = np.zeros((NB, bs), np.int32)
+    out, km = oracle_decode(c, g, pos, np.full(S, 10, np.int32), np.zeros(S, np.int32))
+    rtol = 1e-5 if c["dtype"] == "f16" else 1e-4
+    assert np.allclose(km, g["ref_probs"], rtol=rtol, atol=1e-8)
+    assert np.allclose(out, g["ref_out"], atol=1e-3, rtol=1e-5)
+    # slots outside every head stay untouched
+    assert ((g["ref_probs"] == -1.0) == (km == -1.0)).all()
+
+
+def test_paged_attention_decode_metric_window():
+    """only keys at positions <= last_position - buffer_len are recorded (.cu:124, 305-312)"""
+    from tests.attn_helpers import make_state, oracle_decode
+    rng = np.random.default_rng(5)
+    g, c, pos, last = make_state(rng, 2, 4, 2, 64, 16, 5, 60)
+    buf = np.array([7, 0], np.int32)
+    out, km = oracle_decode(c, g, pos, last, buf)
+    out2, km2 = oracle_decode(c, g, pos, last, np.zeros(2, np.int32))
+    assert np.array_equal(out, out2)
+    rec = km != -1.0
+    for s in range(2):
+        for h in range(2):
+            n = int(g["context_lens"][s, h])
+            blocks = g["block_tables"][s, h, :(n + 15) // 16]
+            p = pos[blocks].reshape(-1)[:n]
+            r = rec[blocks].reshape(-1, rec.shape[-1])[:n]
+            assert (r.all(axis=1) == (p <= last[s] - buf[s])).all()
+            assert np.allclose(km2[blocks].reshape(-1, 2)[:n].sum(0), 1.0, atol=1e-5)

@@ -220,3 +220,101 @@ def schedule_cache_evictions(*args, **kwargs):
     raise NotImplementedError(
         "schedule_cache_evictions (V1) is dead code in the reference; use "
         "vllm_kvcompress_amd.kvcompress.metrics.CompressionMetrics.schedule_evictions")
+
+
+# ---------------------------------------------------------------------------------------
+# F3: decode attention with KV-metric output      reference vllm/_custom_ops.py:135-201
+_ATTN_PARTITION = 512           # reference vllm/attention/ops/paged_attn.py:_PARTITION_SIZE
+
+
+def _paged_attention_kvc(out, kv_metric_out, exp_sum, max_logits, tmp_out, tmp_kv_metric_out,
+                         query, key_cache, value_cache, num_kv_heads, scale, block_tables,
+                         context_lens, kv_position, last_position, kv_metric_buffer_len,
+                         block_size, max_context_len, alibi_slopes, kv_cache_dtype, k_scale,
+                         v_scale, record_kv_metrics) -> None:
+    lib = _lib.load()
+    for name, t in (("out", out), ("query", query), ("key_cache", key_cache),
+                    ("value_cache", value_cache)):
+        _require(t, name)
+    _require(kv_metric_out, "kv_metric_out", torch.float32)
+    for name, t in (("block_tables", block_tables), ("context_lens", context_lens),
+                    ("kv_position", kv_position), ("last_position", last_position),
+                    ("kv_metric_buffer_len", kv_metric_buffer_len)):
+        _require(t, name, torch.int32)
+    if kv_cache_dtype != "auto":
+        raise RuntimeError(f"Unsupported data type of kv cache: {kv_cache_dtype}")
+    dtypes = {torch.float16: 0, torch.bfloat16: 1}
+    if query.dtype not in dtypes:
+        raise RuntimeError(f"Unsupported data type: {query.dtype}")
+    if key_cache.dtype != query.dtype or value_cache.dtype != query.dtype or out.dtype != query.dtype:
+        raise RuntimeError("paged_attention_kvc: query, output and \"auto\" caches must share a dtype")
+    num_seqs, num_heads, head_size = query.shape
+    if query.stride(1) != head_size or query.stride(2) != 1:
+        raise RuntimeError("paged_attention_kvc: query must be contiguous in (head, dim)")
+    if not out.is_contiguous():
+        raise RuntimeError("paged_attention_kvc: out must be contiguous")
+    bt = block_tables.contiguous()
+    p = _lib.KvcAttentionParams()
+    p.out, p.kv_metric_out = out.data_ptr(), kv_metric_out.data_ptr()
+    p.exp_sums, p.max_logits = _ptr(exp_sum), _ptr(max_logits)
+    p.tmp_out, p.tmp_kv_metric_out = _ptr(tmp_out), _ptr(tmp_kv_metric_out)
+    p.query, p.key_cache, p.value_cache = query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr()
+    p.block_tables = bt.data_ptr()
+    p.context_lens = context_lens.contiguous().data_ptr()
+    p.kv_position = kv_position.contiguous().data_ptr()
+    p.last_position = last_position.contiguous().data_ptr()
+    p.kv_metric_buffer_len = kv_metric_buffer_len.contiguous().data_ptr()
+    p.alibi_slopes = None if alibi_slopes is None else alibi_slopes.float().contiguous().data_ptr()
+    p.q_stride, p.kv_block_stride = query.stride(0), key_cache.stride(0)
+    p.scale, p.k_scale, p.v_scale = float(scale), float(k_scale), float(v_scale)
+    p.num_seqs, p.num_heads, p.num_kv_heads = num_seqs, num_heads, int(num_kv_heads)
+    p.head_size, p.block_size = head_size, int(block_size)
+    p.max_num_blocks_per_seq = bt.shape[-1]
+    p.max_context_len = int(max_context_len)
+    p.dtype, p.kv_cache_dtype, p.record_kv_metrics = dtypes[query.dtype], 0, int(bool(record_kv_metrics))
+    with torch.cuda.device(query.device):
+        _lib.check(lib.kvc_paged_attention_decode(p, _stream(query)))
+
+
+def paged_attention_kvc_v1(out, kv_metric_out, query, key_cache, value_cache, num_kv_heads: int,
+                           scale: float, block_tables, context_lens, kv_position, last_position,
+                           kv_metric_buffer_len, block_size: int, max_context_len: int,
+                           alibi_slopes, kv_cache_dtype: str, k_scale: float, v_scale: float,
+                           record_kv_metrics: bool) -> None:
+    """reference vllm/_custom_ops.py:135-163.  The reference's v1 keeps a whole context in
+    one workgroup's shared memory; here long contexts are always partitioned, so the
+    partition buffers the v1 signature does not carry come from the wrapper's scratch."""
+    num_seqs, num_heads, head_size = query.shape
+    parts = (int(max_context_len) + _ATTN_PARTITION - 1) // _ATTN_PARTITION
+    exp_sum = max_logits = tmp_out = tmp_metric = None
+    if parts > 1:
+        n = num_seqs * num_heads * parts
+        buf = workspace(query.device, n * 8 + n * head_size * query.element_size() + 256, "attn_v1")
+        exp_sum = buf[:n * 4].view(torch.float32)
+        max_logits = buf[n * 4:n * 8].view(torch.float32)
+        tmp_out = buf[n * 8:n * 8 + n * head_size * query.element_size()].view(query.dtype)
+        if record_kv_metrics:
+            tmp_metric = workspace(query.device, kv_metric_out.numel() * 4, "attn_v1_metric").view(
+                torch.float32)[:kv_metric_out.numel()]
+    _paged_attention_kvc(out, kv_metric_out, exp_sum, max_logits, tmp_out, tmp_metric, query,
+                         key_cache, value_cache, num_kv_heads, scale, block_tables, context_lens,
+                         kv_position, last_position, kv_metric_buffer_len, block_size,
+                         max_context_len, alibi_slopes, kv_cache_dtype, k_scale, v_scale,
+                         record_kv_metrics)
+
+
+def paged_attention_kvc_v2(out, kv_metric_out, exp_sum, max_logits, tmp_out, tmp_kv_metric_out,
+                           query, key_cache, value_cache, num_kv_heads: int, scale: float,
+                           block_tables, context_lens, kv_position, last_position,
+                           kv_metric_buffer_len, block_size: int, max_context_len: int,
+                           alibi_slopes, kv_cache_dtype: str, k_scale: float, v_scale: float,
+                           record_kv_metrics: bool) -> None:
+    """reference vllm/_custom_ops.py:166-201 (caller-provided partition buffers,
+    vllm/attention/ops/paged_attn.py:367-379)."""
+    _require(exp_sum, "exp_sum", torch.float32)
+    _require(max_logits, "max_logits", torch.float32)
+    _paged_attention_kvc(out, kv_metric_out, exp_sum, max_logits, tmp_out, tmp_kv_metric_out,
+                         query, key_cache, value_cache, num_kv_heads, scale, block_tables,
+                         context_lens, kv_position, last_position, kv_metric_buffer_len,
+                         block_size, max_context_len, alibi_slopes, kv_cache_dtype, k_scale,
+                         v_scale, record_kv_metrics)

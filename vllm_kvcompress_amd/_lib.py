@@ -39,6 +39,24 @@ class KvcScheduleParams(ctypes.Structure):
     ]
 
 
+class KvcAttentionParams(ctypes.Structure):
+    """mirror of ``kvc_attention_params`` (include/kvc_mi355x.h)"""
+    _fields_ = [
+        ("out", c_void_p), ("kv_metric_out", c_void_p), ("exp_sums", c_void_p),
+        ("max_logits", c_void_p), ("tmp_out", c_void_p), ("tmp_kv_metric_out", c_void_p),
+        ("query", c_void_p), ("key_cache", c_void_p), ("value_cache", c_void_p),
+        ("block_tables", c_void_p), ("context_lens", c_void_p), ("kv_position", c_void_p),
+        ("last_position", c_void_p), ("kv_metric_buffer_len", c_void_p),
+        ("alibi_slopes", c_void_p),
+        ("q_stride", c_int64), ("kv_block_stride", c_int64),
+        ("scale", c_float), ("k_scale", c_float), ("v_scale", c_float),
+        ("num_seqs", c_int32), ("num_heads", c_int32), ("num_kv_heads", c_int32),
+        ("head_size", c_int32), ("block_size", c_int32),
+        ("max_num_blocks_per_seq", c_int32), ("max_context_len", c_int32),
+        ("dtype", c_int32), ("kv_cache_dtype", c_int32), ("record_kv_metrics", c_int32),
+    ]
+
+
 # name -> (restype, argtypes); every symbol declared in include/kvc_mi355x.h
 SYMBOLS = {
     "kvc_abi_version": (c_int32, []),
@@ -75,6 +93,7 @@ SYMBOLS = {
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                              c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                              c_size_t, c_void_p]),
+    "kvc_paged_attention_decode": (c_int32, [ctypes.POINTER(KvcAttentionParams), c_void_p]),
 }
 
 _lib = None

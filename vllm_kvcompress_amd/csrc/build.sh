@@ -6,5 +6,6 @@ OUT="$HERE/../libkvc_mi355x.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value \
   "$HERE/kvc_api.hip" "$HERE/kvc_moves.hip" "$HERE/kvc_compact.hip" \
-  "$HERE/kvc_schedule.hip" "$HERE/kvc_aggregate.hip" "$HERE/kvc_blockstate.hip" -o "$OUT"
+  "$HERE/kvc_schedule.hip" "$HERE/kvc_aggregate.hip" "$HERE/kvc_blockstate.hip" \
+  "$HERE/kvc_attention.hip" -o "$OUT"
 echo "built $OUT"

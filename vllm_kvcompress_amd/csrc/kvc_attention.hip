@@ -1,0 +1,390 @@
+// F3: single-query ("decode") attention over the per-head paged cache with
+// the per-key softmax weight written out as the KV-Compress metric.
+//   replaces  torch.ops._C.kvcompress_paged_attention_v1 / _v2
+//             (csrc/attention/kvcompress_attention_kernels.cu:97-455, 532-651, 686-1056)
+//
+// MI355X design (not the reference's thread-group dot products):
+//  * one workgroup = one 512-token partition of ONE (sequence, KV head) and ALL the query heads
+//    that share that KV head (GQA): K and V are read from HBM once per group of up to 16 query
+//    heads, not once per query head;
+//  * four waves, 128 tokens each.  QK^T runs on the matrix cores as
+//    v_mfma_f32_16x16x32 with the 16 TOKENS of half a block as the M dimension, the (<= 16)
+//    query heads as N and 32 head dims per instruction as K: a lane's A operand is exactly one
+//    16-byte piece of the K cache ([hd/8][bs][8] layout: 8 dims of one token), so the wave
+//    reads 1 KiB contiguous per instruction and nothing is transposed;
+//  * softmax statistics per partition (max, sum) via two tiny LDS exchanges;
+//  * P.V on the matrix cores too: M = 16 head dims, N = query heads, K = 32 tokens; a lane's
+//    A operand is one 16-byte piece of the V cache ([hd][bs] layout: 8 tokens of one dim);
+//    P comes back from LDS in the B-operand layout;
+//  * partition results are combined by a small second kernel (same maths as the reference's
+//    v2 reduce); heads that fit one partition are finished by the first kernel.
+// The kernel is HBM-bound: 2*hd*e bytes per cached token and KV head.
+#include "kvc_common.h"
+#include "../../include/kvc_mi355x.h"
+
+#include <math.h>
+
+namespace kvc {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t au32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int ATT_PART = 512;            // tokens per workgroup (= the reference's partition)
+constexpr int ATT_WAVES = 4;
+constexpr int ATT_CHUNK = ATT_PART / ATT_WAVES;   // tokens per wave
+constexpr int ATT_NSUB = ATT_CHUNK / 16;          // 16-token MFMA row tiles per wave
+constexpr int ATT_NQ = 16;               // query heads per workgroup (MFMA N)
+
+template <typename T> struct Mma;
+template <> struct Mma<_Float16> {
+  using V8 = f16x8;
+  static __device__ __forceinline__ f32x4 mma(V8 a, V8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<__bf16> {
+  using V8 = bf16x8;
+  static __device__ __forceinline__ f32x4 mma(V8 a, V8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+struct AttnArgs {
+  void* out;                      // [S, Hq, hd] T
+  float* kv_metric_out;           // [NB, bs, qpk]
+  float* exp_sums;                // [S, Hq, max_parts]
+  float* max_logits;              // [S, Hq, max_parts]
+  void* tmp_out;                  // [S, Hq, max_parts, hd] T
+  float* tmp_kv_metric_out;       // [NB, bs, qpk]
+  const void* q;                  // [S, Hq, hd] T, seq stride q_stride
+  const void* k_cache;            // [NB, hd/8, bs, 8] T
+  const void* v_cache;            // [NB, hd, bs] T
+  const int32_t* block_tables;    // [S, Hkv, max_blocks]
+  const int32_t* context_lens;    // [S, Hkv]
+  const int32_t* kv_position;     // [NB, bs]
+  const int32_t* last_position;   // [S]
+  const int32_t* kv_metric_buffer_len;   // [S]
+  const float* alibi_slopes;      // [Hq] or null
+  int64_t q_stride, kv_block_stride;
+  float scale;
+  int32_t num_heads, num_kv_heads, max_blocks, max_parts, record;
+};
+
+__device__ __forceinline__ float group_max(float v) {     // over the 4 lanes sharing lane&15
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// dynamic LDS: [ATT_WAVES][nqr][max(ATT_CHUNK, HD)] floats (P tiles, later the per-wave outputs)
+template <typename T, int HD, int BS>
+__global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a) {
+  using M = Mma<T>;
+  using V8 = typename M::V8;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float red_max[ATT_WAVES][ATT_NQ];
+  __shared__ float red_sum[ATT_WAVES][ATT_NQ];
+  constexpr int ROW = ATT_CHUNK > HD ? ATT_CHUNK : HD;
+  constexpr int KS = HD / 32;            // QK k-steps
+  constexpr int DT = HD / 16;            // output dim tiles
+  const int qpk = a.num_heads / a.num_kv_heads;
+  const int ngroups = (qpk + ATT_NQ - 1) / ATT_NQ;
+  const int seq = blockIdx.z, hk = blockIdx.y / ngroups, qg = blockIdx.y % ngroups;
+  const int part = blockIdx.x;
+  const int ctx = a.context_lens[seq * a.num_kv_heads + hk];
+  if (part * ATT_PART >= ctx) return;
+  const int nparts = (ctx + ATT_PART - 1) / ATT_PART;
+  const int q0 = qg * ATT_NQ;
+  const int nq = min(ATT_NQ, qpk - q0);
+  const int nqr = min(ATT_NQ, qpk);                       // LDS rows allocated
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const T* kc = reinterpret_cast<const T*>(a.k_cache);
+  const T* vc = reinterpret_cast<const T*>(a.v_cache);
+  const int32_t* bt = a.block_tables + (int64_t)(seq * a.num_kv_heads + hk) * a.max_blocks;
+  const int head0 = hk * qpk + q0;                        // first query head of this group
+
+  // ---- Q fragments (B operand): lane (query c, dim group g)
+  V8 qf[KS];
+  {
+    const T* qp = reinterpret_cast<const T*>(a.q) + (int64_t)seq * a.q_stride + (int64_t)(head0 + c) * HD;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      au32x4 raw = {0u, 0u, 0u, 0u};
+      if (c < nq) raw = *reinterpret_cast<const au32x4*>(qp + 32 * s + 8 * g);
+      qf[s] = __builtin_bit_cast(V8, raw);
+    }
+  }
+  const float slope = (a.alibi_slopes != nullptr && c < nq) ? a.alibi_slopes[head0 + c] : 0.0f;
+
+  // ---- QK^T: S[sb][j] = logit(token tok_w0 + 16 sb + 4 g + j, query c)
+  const int tok_w0 = part * ATT_PART + w * ATT_CHUNK;
+  f32x4 S[ATT_NSUB];
+  float mloc = -INFINITY;
+#pragma unroll
+  for (int sb = 0; sb < ATT_NSUB; ++sb) {
+    const int t0 = tok_w0 + sb * 16;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (t0 < ctx) {                                       // wave-uniform
+      const int64_t phys = bt[t0 / BS];
+      const T* kb = kc + phys * a.kv_block_stride + ((int64_t)g * BS + (t0 % BS) + c) * 8;
+      V8 kk[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        kk[s] = __builtin_bit_cast(V8, *reinterpret_cast<const au32x4*>(kb + (int64_t)s * 4 * BS * 8));
+#pragma unroll
+      for (int s = 0; s < KS; ++s) acc = M::mma(kk[s], qf[s], acc);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int tok = t0 + 4 * g + j;
+      float v = acc[j] * a.scale;
+      if (slope != 0.0f) v += slope * (float)(tok - ctx + 1);       // .cu:265
+      v = tok < ctx ? v : -INFINITY;
+      acc[j] = v;
+      mloc = fmaxf(mloc, v);
+    }
+    S[sb] = acc;
+  }
+  mloc = group_max(mloc);
+  if (g == 0) red_max[w][c] = mloc;
+  __syncthreads();
+  const float m = fmaxf(fmaxf(red_max[0][c], red_max[1][c]), fmaxf(red_max[2][c], red_max[3][c]));
+
+  // ---- p = exp(l - m), partition sum; P tile to LDS in [query][token] order
+  float lsum = 0.0f;
+  float* pw = lds + (int64_t)w * nqr * ROW;
+#pragma unroll
+  for (int sb = 0; sb < ATT_NSUB; ++sb) {
+    f32x4 p;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float l = S[sb][j];
+      p[j] = l == -INFINITY ? 0.0f : __expf(l - m);
+      lsum += p[j];
+    }
+    S[sb] = p;
+    if (c < nq) *reinterpret_cast<f32x4*>(pw + c * ROW + sb * 16 + 4 * g) = p;
+  }
+  lsum = group_sum(lsum);
+  if (g == 0) red_sum[w][c] = lsum;
+  __syncthreads();
+  const float L = red_sum[0][c] + red_sum[1][c] + red_sum[2][c] + red_sum[3][c];
+  const float inv = __fdividef(1.0f, L + 1e-6f);                   // .cu:298
+  const bool single = nparts == 1;
+
+  // ---- metric output (normalised within the partition, like the reference's tmp buffer)
+  if (a.record && c < nq) {
+    const int max_pos = a.last_position[seq] - a.kv_metric_buffer_len[seq];     // .cu:124
+    float* mo = single ? a.kv_metric_out : a.tmp_kv_metric_out;
+#pragma unroll
+    for (int sb = 0; sb < ATT_NSUB; ++sb) {
+      const int t0 = tok_w0 + sb * 16;
+      if (t0 >= ctx) break;
+      const int64_t phys = bt[t0 / BS];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int tok = t0 + 4 * g + j;
+        if (tok < ctx) {
+          const int64_t slot = phys * BS + (tok % BS);
+          if (a.kv_position[slot] <= max_pos) mo[slot * qpk + q0 + c] = S[sb][j] * inv;   // .cu:305-312
+        }
+      }
+    }
+  }
+
+  // ---- P.V: O[i][j] = out(dim 16 i + 4 g + j, query c) over this wave's tokens
+  f32x4 O[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int pr = 0; pr < ATT_NSUB / 2; ++pr) {
+    const int t0 = tok_w0 + pr * 32;
+    if (t0 >= ctx) break;                                 // wave-uniform
+    // B operand: P[query c][tokens t0 + 8 g .. + 7], rounded to the cache type (.cu:332-420)
+    V8 pb;
+    {
+      f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+      if (c < nq) {
+        lo = *reinterpret_cast<const f32x4*>(pw + c * ROW + pr * 32 + 8 * g);
+        hi = *reinterpret_cast<const f32x4*>(pw + c * ROW + pr * 32 + 8 * g + 4);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { pb[e] = (T)lo[e]; pb[4 + e] = (T)hi[e]; }
+    }
+    // A operand: V[dim 16 i + c][tokens t0 + 8 g .. + 7]
+    const int tok = t0 + 8 * g;
+    const bool live = tok < ctx;
+    const int64_t phys = live ? bt[tok / BS] : 0;
+    const T* vb = vc + phys * a.kv_block_stride + (int64_t)c * BS + (tok % BS);
+    const bool tail = t0 + 32 > ctx;                      // wave-uniform: mask stale tokens
+    V8 vv[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) {
+      au32x4 raw = {0u, 0u, 0u, 0u};
+      if (live) raw = *reinterpret_cast<const au32x4*>(vb + (int64_t)i * 16 * BS);
+      vv[i] = __builtin_bit_cast(V8, raw);
+    }
+    if (tail) {
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (tok + e >= ctx) vv[i][e] = (T)0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < DT; ++i) O[i] = M::mma(vv[i], pb, O[i]);
+  }
+
+  // ---- combine the four waves (same max, so a plain sum), normalise, store
+  __syncthreads();                                         // all P tiles consumed
+  if (c < nq) {
+#pragma unroll
+    for (int i = 0; i < DT; ++i) *reinterpret_cast<f32x4*>(pw + c * ROW + 16 * i + 4 * g) = O[i];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < nq * HD; idx += 256) {
+    const int qq = idx / HD, d = idx % HD;
+    float o = 0.0f;
+#pragma unroll
+    for (int ww = 0; ww < ATT_WAVES; ++ww) o += lds[((int64_t)ww * nqr + qq) * ROW + d];
+    // per-query normaliser: the sums sit in red_sum (row qq)
+    const float Lq = red_sum[0][qq] + red_sum[1][qq] + red_sum[2][qq] + red_sum[3][qq];
+    o *= __fdividef(1.0f, Lq + 1e-6f);
+    const int head = head0 + qq;
+    if (single) {
+      reinterpret_cast<T*>(a.out)[((int64_t)seq * a.num_heads + head) * HD + d] = (T)o;
+    } else {
+      reinterpret_cast<T*>(a.tmp_out)[(((int64_t)seq * a.num_heads + head) * a.max_parts + part) * HD + d] = (T)o;
+    }
+  }
+  if (!single && tid < nq) {
+    const int head = head0 + tid;
+    const int64_t o = ((int64_t)seq * a.num_heads + head) * a.max_parts + part;
+    a.exp_sums[o] = red_sum[0][tid] + red_sum[1][tid] + red_sum[2][tid] + red_sum[3][tid];
+    a.max_logits[o] = fmaxf(fmaxf(red_max[0][tid], red_max[1][tid]), fmaxf(red_max[2][tid], red_max[3][tid]));
+  }
+}
+
+// second pass for heads with more than one partition            .cu:532-651
+template <typename T, int HD, int BS>
+__global__ __launch_bounds__(256) void paged_attention_reduce_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];      // [2 * max_parts]
+  __shared__ float red[8];
+  const int head = blockIdx.x, seq = blockIdx.y;
+  const int qpk = a.num_heads / a.num_kv_heads;
+  const int hk = head / qpk, qoff = head % qpk;
+  const int ctx = a.context_lens[seq * a.num_kv_heads + hk];
+  const int nparts = (ctx + ATT_PART - 1) / ATT_PART;
+  if (nparts <= 1) return;                                 // finished by the first kernel
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  float* smax = lds;
+  float* ssum = lds + a.max_parts;
+  const int64_t base = ((int64_t)seq * a.num_heads + head) * a.max_parts;
+  float mx = -INFINITY;
+  for (int i = tid; i < nparts; i += 256) { const float l = a.max_logits[base + i]; smax[i] = l; mx = fmaxf(mx, l); }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+  if (lane == 0) red[w] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float tot = 0.0f;
+  for (int i = tid; i < nparts; i += 256) {
+    const float r = a.exp_sums[base + i] * expf(smax[i] - mx);
+    ssum[i] = r;
+    tot += r;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d, 64);
+  if (lane == 0) red[4 + w] = tot;
+  __syncthreads();
+  tot = red[4] + red[5] + red[6] + red[7];
+  const float inv = __fdividef(1.0f, tot + 1e-6f);
+  const T* tp = reinterpret_cast<const T*>(a.tmp_out) + base * HD;
+  for (int d = tid; d < HD; d += 256) {
+    float acc = 0.0f;
+    for (int j = 0; j < nparts; ++j) acc += (float)tp[(int64_t)j * HD + d] * ssum[j] * inv;
+    reinterpret_cast<T*>(a.out)[((int64_t)seq * a.num_heads + head) * HD + d] = (T)acc;
+  }
+  if (a.record) {
+    const int max_pos = a.last_position[seq] - a.kv_metric_buffer_len[seq];
+    const int32_t* bt = a.block_tables + (int64_t)(seq * a.num_kv_heads + hk) * a.max_blocks;
+    for (int i = tid; i < ctx; i += 256) {
+      const int64_t slot = (int64_t)bt[i / BS] * BS + (i % BS);
+      if (a.kv_position[slot] <= max_pos) {
+        const int64_t idx = slot * qpk + qoff;
+        a.kv_metric_out[idx] = a.tmp_kv_metric_out[idx] * ssum[i / ATT_PART] * inv;
+      }
+    }
+  }
+}
+
+template <typename T, int HD, int BS>
+static int launch_attention(const AttnArgs& a, int num_seqs, hipStream_t s) {
+  const int qpk = a.num_heads / a.num_kv_heads;
+  const int ngroups = (qpk + ATT_NQ - 1) / ATT_NQ;
+  const int nqr = qpk < ATT_NQ ? qpk : ATT_NQ;
+  constexpr int ROW = ATT_CHUNK > HD ? ATT_CHUNK : HD;
+  const size_t lds_bytes = (size_t)ATT_WAVES * nqr * ROW * sizeof(float);
+  if (lds_bytes > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(paged_attention_decode_kernel<T, HD, BS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  hipLaunchKernelGGL((paged_attention_decode_kernel<T, HD, BS>),
+                     dim3(a.max_parts, a.num_kv_heads * ngroups, num_seqs), dim3(256), lds_bytes, s, a);
+  if (a.max_parts > 1)
+    hipLaunchKernelGGL((paged_attention_reduce_kernel<T, HD, BS>), dim3(a.num_heads, num_seqs), dim3(256),
+                       (size_t)2 * a.max_parts * sizeof(float), s, a);
+  return check_launch("paged_attention_decode");
+}
+
+}  // namespace kvc
+
+extern "C" int kvc_paged_attention_decode(const kvc_attention_params* p, kvc_stream_t stream) {
+  using namespace kvc;
+  if (p == nullptr) return fail_invalid("paged_attention_decode: null params");
+  if (p->num_seqs <= 0) return KVC_OK;
+  if (p->num_kv_heads < 1 || p->num_heads % p->num_kv_heads != 0)
+    return fail_invalid("paged_attention_decode: num_heads must be a multiple of num_kv_heads");
+  if (p->kv_cache_dtype != 0)
+    return fail_invalid("paged_attention_decode: only the \"auto\" cache dtype is implemented");
+  if (p->dtype != 0 && p->dtype != 1) return fail_invalid("Unsupported data type of query");
+  AttnArgs a;
+  a.out = p->out; a.kv_metric_out = p->kv_metric_out; a.exp_sums = p->exp_sums;
+  a.max_logits = p->max_logits; a.tmp_out = p->tmp_out; a.tmp_kv_metric_out = p->tmp_kv_metric_out;
+  a.q = p->query; a.k_cache = p->key_cache; a.v_cache = p->value_cache;
+  a.block_tables = p->block_tables; a.context_lens = p->context_lens; a.kv_position = p->kv_position;
+  a.last_position = p->last_position; a.kv_metric_buffer_len = p->kv_metric_buffer_len;
+  a.alibi_slopes = p->alibi_slopes; a.q_stride = p->q_stride; a.kv_block_stride = p->kv_block_stride;
+  a.scale = p->scale; a.num_heads = p->num_heads; a.num_kv_heads = p->num_kv_heads;
+  a.max_blocks = p->max_num_blocks_per_seq; a.record = p->record_kv_metrics ? 1 : 0;
+  a.max_parts = (p->max_context_len + ATT_PART - 1) / ATT_PART;
+  if (a.max_parts < 1) a.max_parts = 1;
+  if (a.max_parts > 1 && (p->exp_sums == nullptr || p->max_logits == nullptr || p->tmp_out == nullptr ||
+                          (a.record && p->tmp_kv_metric_out == nullptr)))
+    return fail_invalid("paged_attention_decode: contexts beyond 512 tokens need the partition buffers");
+  hipStream_t s = (hipStream_t)stream;
+  const int combo = p->head_size * 100 + p->block_size;
+#define KVC_ATT(HD, BS)                                                                   \
+  (p->dtype == 0 ? launch_attention<_Float16, HD, BS>(a, p->num_seqs, s)                  \
+                 : launch_attention<__bf16, HD, BS>(a, p->num_seqs, s))
+  switch (combo) {
+    case 6416: return KVC_ATT(64, 16);
+    case 6432: return KVC_ATT(64, 32);
+    case 9616: return KVC_ATT(96, 16);
+    case 9632: return KVC_ATT(96, 32);
+    case 12816: return KVC_ATT(128, 16);
+    case 12832: return KVC_ATT(128, 32);
+    case 25616: return KVC_ATT(256, 16);
+    case 25632: return KVC_ATT(256, 32);
+    default: break;
+  }
+#undef KVC_ATT
+  if (p->block_size != 16 && p->block_size != 32)
+    return fail_invalid("Unsupported block size: " + std::to_string(p->block_size));
+  return fail_invalid("Unsupported head size: " + std::to_string(p->head_size));
+}
