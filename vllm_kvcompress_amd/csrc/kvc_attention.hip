@@ -24,6 +24,12 @@
 
 #include <math.h>
 
+#ifndef KVC_ATT_DBG
+#define KVC_ATT_DBG 0
+#endif
+// K and V are streamed exactly once per call: non-temporal loads (measured +8 % at batch 256)
+#define KVC_LD(p) __builtin_nontemporal_load(p)
+
 namespace kvc {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -81,7 +87,7 @@ __device__ __forceinline__ float group_sum(float v) {
   return v + __shfl_xor(v, 32, 64);
 }
 
-// dynamic LDS: [ATT_WAVES][nqr][max(ATT_CHUNK, HD)] floats (P tiles, later the per-wave outputs)
+// dynamic LDS: 2 x [ATT_WAVES][nqr][max(ATT_CHUNK, HD)] floats (P tiles | per-wave outputs)
 template <typename T, int HD, int BS>
 __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a) {
   using M = Mma<T>;
@@ -122,8 +128,27 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
   }
   const float slope = (a.alibi_slopes != nullptr && c < nq) ? a.alibi_slopes[head0 + c] : 0.0f;
 
-  // ---- QK^T: S[sb][j] = logit(token tok_w0 + 16 sb + 4 g + j, query c)
   const int tok_w0 = part * ATT_PART + w * ATT_CHUNK;
+  // metric bookkeeping of "my" tokens (one lane per token, see below): the block-table and
+  // position loads are issued first so that their latency hides behind the K stream
+  int64_t mslot[ATT_CHUNK / 64];
+  int mpos[ATT_CHUNK / 64];
+#pragma unroll
+  for (int k = 0; k < ATT_CHUNK / 64; ++k) {
+    const int tok = tok_w0 + k * 64 + lane;
+    mslot[k] = 0;
+    mpos[k] = 0x7FFFFFFF;
+    if (a.record && tok < ctx) {
+      mslot[k] = (int64_t)bt[tok / BS] * BS + (tok % BS);
+#if KVC_ATT_DBG == 2
+      mpos[k] = 0;
+#else
+      mpos[k] = a.kv_position[mslot[k]];
+#endif
+    }
+  }
+
+  // ---- QK^T: S[sb][j] = logit(token tok_w0 + 16 sb + 4 g + j, query c)
   f32x4 S[ATT_NSUB];
   float mloc = -INFINITY;
 #pragma unroll
@@ -136,7 +161,7 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
       V8 kk[KS];
 #pragma unroll
       for (int s = 0; s < KS; ++s)
-        kk[s] = __builtin_bit_cast(V8, *reinterpret_cast<const au32x4*>(kb + (int64_t)s * 4 * BS * 8));
+        kk[s] = __builtin_bit_cast(V8, KVC_LD(reinterpret_cast<const au32x4*>(kb + (int64_t)s * 4 * BS * 8)));
 #pragma unroll
       for (int s = 0; s < KS; ++s) acc = M::mma(kk[s], qf[s], acc);
     }
@@ -178,26 +203,6 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
   const float inv = __fdividef(1.0f, L + 1e-6f);                   // .cu:298
   const bool single = nparts == 1;
 
-  // ---- metric output (normalised within the partition, like the reference's tmp buffer)
-  if (a.record && c < nq) {
-    const int max_pos = a.last_position[seq] - a.kv_metric_buffer_len[seq];     // .cu:124
-    float* mo = single ? a.kv_metric_out : a.tmp_kv_metric_out;
-#pragma unroll
-    for (int sb = 0; sb < ATT_NSUB; ++sb) {
-      const int t0 = tok_w0 + sb * 16;
-      if (t0 >= ctx) break;
-      const int64_t phys = bt[t0 / BS];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int tok = t0 + 4 * g + j;
-        if (tok < ctx) {
-          const int64_t slot = phys * BS + (tok % BS);
-          if (a.kv_position[slot] <= max_pos) mo[slot * qpk + q0 + c] = S[sb][j] * inv;   // .cu:305-312
-        }
-      }
-    }
-  }
-
   // ---- P.V: O[i][j] = out(dim 16 i + 4 g + j, query c) over this wave's tokens
   f32x4 O[DT];
 #pragma unroll
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
 #pragma unroll
     for (int i = 0; i < DT; ++i) {
       au32x4 raw = {0u, 0u, 0u, 0u};
-      if (live) raw = *reinterpret_cast<const au32x4*>(vb + (int64_t)i * 16 * BS);
+      if (live) raw = KVC_LD(reinterpret_cast<const au32x4*>(vb + (int64_t)i * 16 * BS));
       vv[i] = __builtin_bit_cast(V8, raw);
     }
     if (tail) {
@@ -242,17 +247,17 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
   }
 
   // ---- combine the four waves (same max, so a plain sum), normalise, store
-  __syncthreads();                                         // all P tiles consumed
+  float* ow = lds + (int64_t)(ATT_WAVES + w) * nqr * ROW;   // second LDS region
   if (c < nq) {
 #pragma unroll
-    for (int i = 0; i < DT; ++i) *reinterpret_cast<f32x4*>(pw + c * ROW + 16 * i + 4 * g) = O[i];
+    for (int i = 0; i < DT; ++i) *reinterpret_cast<f32x4*>(ow + c * ROW + 16 * i + 4 * g) = O[i];
   }
   __syncthreads();
   for (int idx = tid; idx < nq * HD; idx += 256) {
     const int qq = idx / HD, d = idx % HD;
     float o = 0.0f;
 #pragma unroll
-    for (int ww = 0; ww < ATT_WAVES; ++ww) o += lds[((int64_t)ww * nqr + qq) * ROW + d];
+    for (int ww = 0; ww < ATT_WAVES; ++ww) o += lds[((int64_t)(ATT_WAVES + ww) * nqr + qq) * ROW + d];
     // per-query normaliser: the sums sit in red_sum (row qq)
     const float Lq = red_sum[0][qq] + red_sum[1][qq] + red_sum[2][qq] + red_sum[3][qq];
     o *= __fdividef(1.0f, Lq + 1e-6f);
@@ -268,6 +273,42 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
     const int64_t o = ((int64_t)seq * a.num_heads + head) * a.max_parts + part;
     a.exp_sums[o] = red_sum[0][tid] + red_sum[1][tid] + red_sum[2][tid] + red_sum[3][tid];
     a.max_logits[o] = fmaxf(fmaxf(red_max[0][tid], red_max[1][tid]), fmaxf(red_max[2][tid], red_max[3][tid]));
+  }
+
+  // ---- metric output (normalised within the partition, like the reference's tmp buffer).
+  // LAST thing the wave does: vmcnt is in-order on gfx9, so a store issued before the V
+  // loads (or before a barrier) puts its full write latency on the critical path of every
+  // wave - measured 180 us of 870 at batch 256.  The P tiles live in their own LDS region.
+  // one lane per TOKEN reads the wave's P tile back from LDS and stores all query heads of
+  // the token at once (16 bytes for qpk = 4); the position test is done once per token
+  if (a.record) {
+    const int max_pos = a.last_position[seq] - a.kv_metric_buffer_len[seq];     // .cu:124
+    float* mo = single ? a.kv_metric_out : a.tmp_kv_metric_out;
+    const bool vec4 = nq == 4 && qpk == 4;
+    f32x4 inv4 = {0.f, 0.f, 0.f, 0.f};
+    if (vec4) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        inv4[q] = __fdividef(1.0f, red_sum[0][q] + red_sum[1][q] + red_sum[2][q] + red_sum[3][q] + 1e-6f);
+    }
+#pragma unroll
+    for (int k = 0; k < ATT_CHUNK / 64; ++k) {
+      const int tl = k * 64 + lane;
+      const int64_t slot = mslot[k];
+      if (mpos[k] > max_pos) continue;                     // .cu:305-312 (also: token >= ctx)
+      if (vec4) {
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = pw[q * ROW + tl] * inv4[q];
+        // streamed once: a plain store allocates in L2 and costs 15 % of the whole kernel
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(mo + slot * 4));
+      } else {
+        for (int q = 0; q < nq; ++q) {
+          const float iq = __fdividef(1.0f, red_sum[0][q] + red_sum[1][q] + red_sum[2][q] + red_sum[3][q] + 1e-6f);
+          __builtin_nontemporal_store(pw[q * ROW + tl] * iq, mo + slot * qpk + q0 + q);
+        }
+      }
+    }
   }
 }
 
@@ -311,15 +352,87 @@ __global__ __launch_bounds__(256) void paged_attention_reduce_kernel(AttnArgs a)
     for (int j = 0; j < nparts; ++j) acc += (float)tp[(int64_t)j * HD + d] * ssum[j] * inv;
     reinterpret_cast<T*>(a.out)[((int64_t)seq * a.num_heads + head) * HD + d] = (T)acc;
   }
-  if (a.record) {
-    const int max_pos = a.last_position[seq] - a.kv_metric_buffer_len[seq];
-    const int32_t* bt = a.block_tables + (int64_t)(seq * a.num_kv_heads + hk) * a.max_blocks;
-    for (int i = tid; i < ctx; i += 256) {
+}
+
+// metric side of the second pass: kv_metric_out = tmp * (partition's share of the softmax
+// denominator)  (.cu:642-650), one workgroup per 1024 tokens of a (sequence, KV head), all
+// query heads of the KV head at once (16-byte rows for qpk = 4) instead of one strided
+// 4-byte column per query head.
+constexpr int ATT_RS_TOK = 1024;
+template <int BS>
+__global__ __launch_bounds__(256) void paged_attention_metric_rescale_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float fac[];     // [qpk][2]
+  const int chunk = blockIdx.x, hk = blockIdx.y, seq = blockIdx.z;
+  const int ctx = a.context_lens[seq * a.num_kv_heads + hk];
+  const int nparts = (ctx + ATT_PART - 1) / ATT_PART;
+  if (nparts <= 1 || chunk * ATT_RS_TOK >= ctx) return;
+  const int qpk = a.num_heads / a.num_kv_heads;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int p0 = chunk * (ATT_RS_TOK / ATT_PART);
+  for (int q = w; q < qpk; q += 4) {                       // one wave per query head
+    const int64_t base = ((int64_t)seq * a.num_heads + hk * qpk + q) * a.max_parts;
+    float mx = -INFINITY;
+    for (int j = lane; j < nparts; j += 64) mx = fmaxf(mx, a.max_logits[base + j]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+    float tot = 0.0f;
+    for (int j = lane; j < nparts; j += 64) tot += a.exp_sums[base + j] * expf(a.max_logits[base + j] - mx);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) tot += __shfl_xor(tot, d, 64);
+    const float inv = __fdividef(1.0f, tot + 1e-6f);
+    if (lane < 2) {
+      const int j = p0 + lane;
+      fac[q * 2 + lane] = j < nparts ? a.exp_sums[base + j] * expf(a.max_logits[base + j] - mx) * inv : 0.0f;
+    }
+  }
+  __syncthreads();
+  const int max_pos = a.last_position[seq] - a.kv_metric_buffer_len[seq];
+  const int32_t* bt = a.block_tables + (int64_t)(seq * a.num_kv_heads + hk) * a.max_blocks;
+  constexpr int K = ATT_RS_TOK / 256;
+  if (qpk == 4) {
+    // all address loads, then all position + tmp loads, then the stores: four independent
+    // chains per lane keep enough bytes in flight for a pass that is pure streaming
+    int64_t slot[K];
+    bool ok[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int i = chunk * ATT_RS_TOK + k * 256 + tid;
+      ok[k] = i < ctx;
+      slot[k] = ok[k] ? (int64_t)bt[i / BS] * BS + (i % BS) : 0;
+    }
+    int posv[K];
+    f32x4 t[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      posv[k] = ok[k] ? a.kv_position[slot[k]] : 0x7FFFFFFF;
+      t[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if KVC_ATT_DBG == 5
+      if (ok[k]) t[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.tmp_kv_metric_out + slot[k] * 4));
+#else
+      if (ok[k]) t[k] = *reinterpret_cast<const f32x4*>(a.tmp_kv_metric_out + slot[k] * 4);
+#endif
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (!ok[k] || posv[k] > max_pos) continue;
+      const int pj = (chunk * ATT_RS_TOK + k * 256 + tid) / ATT_PART - p0;
+      f32x4 v = t[k];
+      v[0] *= fac[0 + pj]; v[1] *= fac[2 + pj]; v[2] *= fac[4 + pj]; v[3] *= fac[6 + pj];
+#if KVC_ATT_DBG == 6
+      __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.kv_metric_out + slot[k] * 4));
+#else
+      *reinterpret_cast<f32x4*>(a.kv_metric_out + slot[k] * 4) = v;
+#endif
+    }
+  } else {
+    for (int k = 0; k < K; ++k) {
+      const int i = chunk * ATT_RS_TOK + k * 256 + tid;
+      if (i >= ctx) break;
       const int64_t slot = (int64_t)bt[i / BS] * BS + (i % BS);
-      if (a.kv_position[slot] <= max_pos) {
-        const int64_t idx = slot * qpk + qoff;
-        a.kv_metric_out[idx] = a.tmp_kv_metric_out[idx] * ssum[i / ATT_PART] * inv;
-      }
+      if (a.kv_position[slot] > max_pos) continue;
+      const int pj = i / ATT_PART - p0;
+      for (int q = 0; q < qpk; ++q)
+        a.kv_metric_out[slot * qpk + q] = a.tmp_kv_metric_out[slot * qpk + q] * fac[q * 2 + pj];
     }
   }
 }
@@ -330,15 +443,20 @@ static int launch_attention(const AttnArgs& a, int num_seqs, hipStream_t s) {
   const int ngroups = (qpk + ATT_NQ - 1) / ATT_NQ;
   const int nqr = qpk < ATT_NQ ? qpk : ATT_NQ;
   constexpr int ROW = ATT_CHUNK > HD ? ATT_CHUNK : HD;
-  const size_t lds_bytes = (size_t)ATT_WAVES * nqr * ROW * sizeof(float);
+  const size_t lds_bytes = (size_t)2 * ATT_WAVES * nqr * ROW * sizeof(float);
   if (lds_bytes > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(paged_attention_decode_kernel<T, HD, BS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   hipLaunchKernelGGL((paged_attention_decode_kernel<T, HD, BS>),
                      dim3(a.max_parts, a.num_kv_heads * ngroups, num_seqs), dim3(256), lds_bytes, s, a);
-  if (a.max_parts > 1)
+  if (a.max_parts > 1) {
     hipLaunchKernelGGL((paged_attention_reduce_kernel<T, HD, BS>), dim3(a.num_heads, num_seqs), dim3(256),
                        (size_t)2 * a.max_parts * sizeof(float), s, a);
+    if (a.record)
+      hipLaunchKernelGGL((paged_attention_metric_rescale_kernel<BS>),
+                         dim3((a.max_parts * ATT_PART + ATT_RS_TOK - 1) / ATT_RS_TOK, a.num_kv_heads, num_seqs),
+                         dim3(256), (size_t)qpk * 2 * sizeof(float), s, a);
+  }
   return check_launch("paged_attention_decode");
 }
 
