@@ -19,6 +19,23 @@ pytestmark = pytest.mark.gpu
 ATTN_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.startswith("attn_decode_"))
 
 
+def _set_mode(mode):
+    """0 automatic, 1 partitioned (+ reduce / rescale kernels), 2 single pass when it fits"""
+    import ctypes
+    import vllm_kvcompress_amd
+    lib = vllm_kvcompress_amd.load()
+    lib.kvc_debug_set_attention_mode.argtypes = [ctypes.c_int32]
+    lib.kvc_debug_set_attention_mode.restype = None
+    lib.kvc_debug_set_attention_mode(mode)
+
+
+@pytest.fixture(params=[1, 2], ids=["partitioned", "single_pass"])
+def attn_mode(request):
+    _set_mode(request.param)
+    yield request.param
+    _set_mode(0)
+
+
 def _run_gpu(g, c, pos, last, buf, version="v2", record=True, fill=-1.0, max_ctx=None):
     import torch
     from vllm_kvcompress_amd import _custom_ops as ops
@@ -54,7 +71,7 @@ def _run_gpu(g, c, pos, last, buf, version="v2", record=True, fill=-1.0, max_ctx
 
 @pytest.mark.parametrize("version", ["v1", "v2"])
 @pytest.mark.parametrize("case", ATTN_CASES)
-def test_decode_attention_matches_reference_twin(case, version):
+def test_decode_attention_matches_reference_twin(case, version, attn_mode):
     g = load_golden(case)
     c = decode_golden(g)
     NB, _, bs = c["vc"].shape
@@ -78,7 +95,7 @@ def test_decode_attention_matches_reference_twin(case, version):
     (2, 8, 2, 256, 16, 20, 530, "bf16", False),
     (2, 6, 2, 96, 32, 20, 530, "f16", False),
 ])
-def test_decode_attention_matches_oracle(shape):
+def test_decode_attention_matches_oracle(shape, attn_mode):
     S, Hq, Hkv, hd, bs, lo, hi, dt, alibi = shape
     rng = np.random.default_rng(hash(shape) % (2 ** 31))
     g, c, pos, last = make_state(rng, S, Hq, Hkv, hd, bs, lo, hi, dtype=dt, magnitude=1.0, alibi=alibi)
@@ -139,7 +156,8 @@ def test_decode_attention_full_size_properties():
     last = torch.full((S,), 10, dtype=torch.int32, device=dev)
     buf = torch.zeros((S,), dtype=torch.int32, device=dev)
     outs, kms = [], []
-    for version in ("v1", "v2"):
+    for version in ("v1", "v2", "single_pass"):
+        _set_mode(2 if version == "single_pass" else 1)
         out = torch.zeros_like(q)
         km = torch.zeros((NB, bs, Hq // Hkv), dtype=torch.float32, device=dev)
         args = (q, kc, vc, Hkv, hd ** -0.5, bt, ctx, pos, last, buf, bs, ctx_len, None, "auto", 1.0,
@@ -155,7 +173,14 @@ def test_decode_attention_full_size_properties():
         outs.append(out)
         kms.append(km)
     torch.cuda.synchronize()
+    _set_mode(0)
     assert torch.equal(outs[0], outs[1]) and torch.equal(kms[0], kms[1])
+    # the single-pass kernel (wave-local running max) agrees with the partitioned one
+    assert torch.allclose(kms[2], kms[0], rtol=1e-5, atol=1e-9)
+    assert torch.allclose(outs[2].float(), outs[0].float(), atol=2e-3, rtol=2e-3)
+    for km in (kms[0], kms[2]):
+        sums = km[bt.long().view(-1)].view(S, Hkv, nblk * bs, Hq // Hkv).sum(2)
+        assert bool(((sums - 1.0).abs() < 1e-4).all()), float((sums - 1.0).abs().max())
     km = kms[0]
     # per (seq, kv head): gather its blocks, sum weights per query head
     sums = km[bt.long().view(-1)].view(S, Hkv, nblk * bs, Hq // Hkv).sum(2)

@@ -27,6 +27,12 @@
 #ifndef KVC_ATT_DBG
 #define KVC_ATT_DBG 0
 #endif
+#ifndef KVC_WHOLE_ATTR
+#define KVC_WHOLE_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
+#ifndef KVC_PF
+#define KVC_PF 3
+#endif
 // K and V are streamed exactly once per call: non-temporal loads (measured +8 % at batch 256)
 #define KVC_LD(p) __builtin_nontemporal_load(p)
 
@@ -75,7 +81,7 @@ struct AttnArgs {
   const float* alibi_slopes;      // [Hq] or null
   int64_t q_stride, kv_block_stride;
   float scale;
-  int32_t num_heads, num_kv_heads, max_blocks, max_parts, record;
+  int32_t num_heads, num_kv_heads, max_blocks, max_parts, record, max_ctx;
 };
 
 __device__ __forceinline__ float group_max(float v) {     // over the 4 lanes sharing lane&15
@@ -312,6 +318,238 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
   }
 }
 
+// ------------------------------------------------------------------ single-pass variant
+// One workgroup walks the WHOLE context of a (sequence, KV head) in 512-token steps with
+// wave-local online softmax, keeps every unnormalised weight in LDS ([query][token] fp32)
+// and writes the metric exactly once at the end: no partition buffers, no second kernels,
+// no scattered tmp traffic.  Used when the weights of the longest context fit in LDS
+// (two workgroups per CU: qpk * max_context * 4 B <= ~68 KiB - the continual-compression
+// regime, e.g. 4k-token caps at qpk 4) and there are enough (sequence, KV head) pairs to fill the chip.
+// dynamic LDS: P [nqr][prow] | O [4][nqr][HD] | mrec [niter][4][16]
+template <typename T, int HD, int BS>
+__global__ __launch_bounds__(256) KVC_WHOLE_ATTR void paged_attention_decode_whole_kernel(AttnArgs a, int prow, int niter_max) {
+  using M = Mma<T>;
+  using V8 = typename M::V8;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float red_max[ATT_WAVES][ATT_NQ];
+  __shared__ float red_sum[ATT_WAVES][ATT_NQ];
+  constexpr int KS = HD / 32;
+  constexpr int DT = HD / 16;
+  const int qpk = a.num_heads / a.num_kv_heads;
+  const int ngroups = (qpk + ATT_NQ - 1) / ATT_NQ;
+  const int seq = blockIdx.y, hk = blockIdx.x / ngroups, qg = blockIdx.x % ngroups;
+  const int ctx = a.context_lens[seq * a.num_kv_heads + hk];
+  if (ctx <= 0) return;
+  const int q0 = qg * ATT_NQ;
+  const int nq = min(ATT_NQ, qpk - q0);
+  const int nqr = min(ATT_NQ, qpk);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const T* kc = reinterpret_cast<const T*>(a.k_cache);
+  const T* vc = reinterpret_cast<const T*>(a.v_cache);
+  const int32_t* bt = a.block_tables + (int64_t)(seq * a.num_kv_heads + hk) * a.max_blocks;
+  const int head0 = hk * qpk + q0;
+  float* P = lds;                                          // [nqr][prow]
+  float* Ol = lds + (int64_t)nqr * prow;                   // [4][nqr][HD]
+  float* mrec = Ol + (int64_t)ATT_WAVES * nqr * HD;        // [niter_max][4][16]
+
+  V8 qf[KS];
+  {
+    const T* qp = reinterpret_cast<const T*>(a.q) + (int64_t)seq * a.q_stride + (int64_t)(head0 + c) * HD;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      au32x4 raw = {0u, 0u, 0u, 0u};
+      if (c < nq) raw = *reinterpret_cast<const au32x4*>(qp + 32 * s + 8 * g);
+      qf[s] = __builtin_bit_cast(V8, raw);
+    }
+  }
+  const float slope = (a.alibi_slopes != nullptr && c < nq) ? a.alibi_slopes[head0 + c] : 0.0f;
+
+  f32x4 O[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.0f;
+  const int niter = (ctx + ATT_PART - 1) / ATT_PART;
+  for (int it = 0; it < niter; ++it) {
+    const int tok_w0 = it * ATT_PART + w * ATT_CHUNK;
+    if (tok_w0 >= ctx) break;                              // wave-uniform
+    // ---- QK^T, K fragments prefetched KVC_PF sub-blocks ahead (two waves per SIMD live here,
+    // so the wave itself has to keep enough loads in flight; the scheduler is pinned with
+    // sched_barrier because it otherwise sinks the loads next to their MFMAs)
+    f32x4 S[ATT_NSUB];
+    float mloc = -INFINITY;
+    constexpr int PF = KVC_PF;
+    V8 kk[ATT_NSUB][KS];
+    auto load_k = [&](int sb) {
+      const int t0 = tok_w0 + sb * 16;
+      if (t0 < ctx) {
+        const int64_t phys = bt[t0 / BS];
+        const T* kb = kc + phys * a.kv_block_stride + ((int64_t)g * BS + (t0 % BS) + c) * 8;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+          kk[sb][s] = __builtin_bit_cast(V8, KVC_LD(reinterpret_cast<const au32x4*>(kb + (int64_t)s * 4 * BS * 8)));
+      } else {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) kk[sb][s] = __builtin_bit_cast(V8, au32x4{0u, 0u, 0u, 0u});
+      }
+    };
+#pragma unroll
+    for (int sb = 0; sb < PF && sb < ATT_NSUB; ++sb) load_k(sb);
+#pragma unroll
+    for (int sb = 0; sb < ATT_NSUB; ++sb) {
+      if (sb + PF < ATT_NSUB) load_k(sb + PF);
+      __builtin_amdgcn_sched_barrier(0);
+      const int t0 = tok_w0 + sb * 16;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) acc = M::mma(kk[sb][s], qf[s], acc);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int tok = t0 + 4 * g + j;
+        float v = acc[j] * a.scale;
+        if (slope != 0.0f) v += slope * (float)(tok - ctx + 1);
+        v = tok < ctx ? v : -INFINITY;
+        acc[j] = v;
+        mloc = fmaxf(mloc, v);
+      }
+      S[sb] = acc;
+    }
+    // ---- wave-local online softmax (the chunk holds at least one live token)
+    const float m_new = fmaxf(m_run, group_max(mloc));
+    const float alpha = __expf(m_run - m_new);             // 0 on the first chunk
+    float lsum = 0.0f;
+    float* pw = P + tok_w0;                                // + c * prow per query row
+#pragma unroll
+    for (int sb = 0; sb < ATT_NSUB; ++sb) {
+      f32x4 p;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float l = S[sb][j];
+        p[j] = l == -INFINITY ? 0.0f : __expf(l - m_new);
+        lsum += p[j];
+      }
+      if (c < nq) *reinterpret_cast<f32x4*>(pw + c * prow + sb * 16 + 4 * g) = p;
+    }
+    l_run = l_run * alpha + group_sum(lsum);
+    m_run = m_new;
+    if (g == 0) mrec[(it * ATT_WAVES + w) * ATT_NQ + c] = m_new;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) O[i] *= alpha;
+    // ---- P.V, V fragments one 32-token pair ahead
+    constexpr int NPR = ATT_NSUB / 2;
+    V8 vv[2][DT];
+    auto load_v = [&](int pr, int bufi) {
+      const int tok = tok_w0 + pr * 32 + 8 * g;
+      const bool live = tok < ctx;
+      const int64_t phys = live ? bt[tok / BS] : 0;
+      const T* vb = vc + phys * a.kv_block_stride + (int64_t)c * BS + (tok % BS);
+#pragma unroll
+      for (int i = 0; i < DT; ++i) {
+        au32x4 raw = {0u, 0u, 0u, 0u};
+        if (live) raw = KVC_LD(reinterpret_cast<const au32x4*>(vb + (int64_t)i * 16 * BS));
+        vv[bufi][i] = __builtin_bit_cast(V8, raw);
+      }
+    };
+    load_v(0, 0);
+#pragma unroll
+    for (int pr = 0; pr < NPR; ++pr) {
+      const int t0 = tok_w0 + pr * 32;
+      if (t0 >= ctx) break;
+      if (pr + 1 < NPR) load_v(pr + 1, (pr + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      V8 pb;
+      {
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+        if (c < nq) {
+          lo = *reinterpret_cast<const f32x4*>(pw + c * prow + pr * 32 + 8 * g);
+          hi = *reinterpret_cast<const f32x4*>(pw + c * prow + pr * 32 + 8 * g + 4);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pb[e] = (T)lo[e]; pb[4 + e] = (T)hi[e]; }
+      }
+      const int tok = t0 + 8 * g;
+      if (t0 + 32 > ctx) {                                 // wave-uniform: mask stale tokens
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (tok + e >= ctx) vv[pr & 1][i][e] = (T)0.0f;
+      }
+#pragma unroll
+      for (int i = 0; i < DT; ++i) O[i] = M::mma(vv[pr & 1][i], pb, O[i]);
+    }
+  }
+
+  // ---- combine the four waves: each has its own running max
+  if (g == 0) { red_max[w][c] = m_run; red_sum[w][c] = l_run; }
+  if (c < nq) {
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+      *reinterpret_cast<f32x4*>(Ol + ((int64_t)w * nqr + c) * HD + 16 * i + 4 * g) = O[i];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < nq * HD; idx += 256) {
+    const int qq = idx / HD, d = idx % HD;
+    const float Mq = fmaxf(fmaxf(red_max[0][qq], red_max[1][qq]), fmaxf(red_max[2][qq], red_max[3][qq]));
+    float o = 0.0f, Lq = 0.0f;
+#pragma unroll
+    for (int ww = 0; ww < ATT_WAVES; ++ww) {
+      const float sc = red_max[ww][qq] == -INFINITY ? 0.0f : __expf(red_max[ww][qq] - Mq);
+      o += Ol[((int64_t)ww * nqr + qq) * HD + d] * sc;
+      Lq += red_sum[ww][qq] * sc;
+    }
+    o *= __fdividef(1.0f, Lq + 1e-6f);
+    reinterpret_cast<T*>(a.out)[((int64_t)seq * a.num_heads + head0 + qq) * HD + d] = (T)o;
+  }
+
+  // ---- metrics: p = p~ * exp(m_used - M) / (L + 1e-6), one lane per token, written once
+  if (a.record) {
+    const int max_pos = a.last_position[seq] - a.kv_metric_buffer_len[seq];
+    const bool vec4 = nq == 4 && qpk == 4;
+    // per query: global max and normaliser (lanes q < nq of every wave compute their own copy)
+    float Mq[4] = {0.f, 0.f, 0.f, 0.f}, Iq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vec4) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        Mq[q] = fmaxf(fmaxf(red_max[0][q], red_max[1][q]), fmaxf(red_max[2][q], red_max[3][q]));
+        float L = 0.0f;
+#pragma unroll
+        for (int ww = 0; ww < ATT_WAVES; ++ww)
+          L += red_max[ww][q] == -INFINITY ? 0.0f : red_sum[ww][q] * __expf(red_max[ww][q] - Mq[q]);
+        Iq[q] = __fdividef(1.0f, L + 1e-6f);
+      }
+    }
+    for (int it = 0; it < niter; ++it) {
+      const int tok_w0 = it * ATT_PART + w * ATT_CHUNK;
+      if (tok_w0 >= ctx) break;
+      const float* mr = mrec + (it * ATT_WAVES + w) * ATT_NQ;
+#pragma unroll
+      for (int k = 0; k < ATT_CHUNK / 64; ++k) {
+        const int tok = tok_w0 + k * 64 + lane;
+        if (tok >= ctx) continue;
+        const int64_t slot = (int64_t)bt[tok / BS] * BS + (tok % BS);
+        if (a.kv_position[slot] > max_pos) continue;
+        if (vec4) {
+          f32x4 v;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = P[q * prow + tok] * (__expf(mr[q] - Mq[q]) * Iq[q]);
+          __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.kv_metric_out + slot * 4));
+        } else {
+          for (int q = 0; q < nq; ++q) {
+            const float Mg = fmaxf(fmaxf(red_max[0][q], red_max[1][q]), fmaxf(red_max[2][q], red_max[3][q]));
+            float L = 0.0f;
+            for (int ww = 0; ww < ATT_WAVES; ++ww)
+              L += red_max[ww][q] == -INFINITY ? 0.0f : red_sum[ww][q] * __expf(red_max[ww][q] - Mg);
+            __builtin_nontemporal_store(P[q * prow + tok] * (__expf(mr[q] - Mg) * __fdividef(1.0f, L + 1e-6f)),
+                                        a.kv_metric_out + slot * qpk + q0 + q);
+          }
+        }
+      }
+    }
+  }
+}
+
+
 // second pass for heads with more than one partition            .cu:532-651
 template <typename T, int HD, int BS>
 __global__ __launch_bounds__(256) void paged_attention_reduce_kernel(AttnArgs a) {
@@ -437,11 +675,34 @@ __global__ __launch_bounds__(256) void paged_attention_metric_rescale_kernel(Att
   }
 }
 
+static int g_attention_mode = 0;      // 0 auto, 1 partitioned, 2 single pass (kvc_debug_set_attention_mode)
+
 template <typename T, int HD, int BS>
 static int launch_attention(const AttnArgs& a, int num_seqs, hipStream_t s) {
   const int qpk = a.num_heads / a.num_kv_heads;
   const int ngroups = (qpk + ATT_NQ - 1) / ATT_NQ;
   const int nqr = qpk < ATT_NQ ? qpk : ATT_NQ;
+  // single pass: weights of the longest context in LDS (<= 72 KiB) and >= 2 workgroups per CU
+  // row = the longest context rounded to a wave chunk, + 4 to stagger the query rows over the banks
+  const int prow = (a.max_ctx + ATT_CHUNK - 1) / ATT_CHUNK * ATT_CHUNK + 4;
+  const size_t whole_lds = ((size_t)nqr * prow + (size_t)ATT_WAVES * nqr * HD +
+                            (size_t)a.max_parts * ATT_WAVES * ATT_NQ) * sizeof(float);
+  // two workgroups per CU (160 KiB of LDS); a single partition is already one pass
+  const bool whole_fits = whole_lds <= 79 * 1024 && a.max_parts > 1;
+  const bool whole = g_attention_mode == 2 ? whole_fits
+                   : (g_attention_mode == 1 ? false
+                      : (whole_fits && (int64_t)num_seqs * a.num_kv_heads * ngroups >= 512));
+  if (whole) {
+    if (whole_lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(paged_attention_decode_whole_kernel<T, HD, BS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)whole_lds);
+    hipLaunchKernelGGL((paged_attention_decode_whole_kernel<T, HD, BS>), dim3(a.num_kv_heads * ngroups, num_seqs),
+                       dim3(256), whole_lds, s, a, prow, a.max_parts);
+    return check_launch("paged_attention_decode");
+  }
+  if (a.max_parts > 1 && (a.exp_sums == nullptr || a.max_logits == nullptr || a.tmp_out == nullptr ||
+                          (a.record && a.tmp_kv_metric_out == nullptr)))
+    return fail_invalid("paged_attention_decode: this shape needs the partition buffers");
   constexpr int ROW = ATT_CHUNK > HD ? ATT_CHUNK : HD;
   const size_t lds_bytes = (size_t)2 * ATT_WAVES * nqr * ROW * sizeof(float);
   if (lds_bytes > 64 * 1024)
@@ -462,6 +723,9 @@ static int launch_attention(const AttnArgs& a, int num_seqs, hipStream_t s) {
 
 }  // namespace kvc
 
+// test hook: 0 = automatic choice, 1 = always partitioned, 2 = single pass whenever it fits
+extern "C" void kvc_debug_set_attention_mode(int32_t mode) { kvc::g_attention_mode = mode; }
+
 extern "C" int kvc_paged_attention_decode(const kvc_attention_params* p, kvc_stream_t stream) {
   using namespace kvc;
   if (p == nullptr) return fail_invalid("paged_attention_decode: null params");
@@ -480,11 +744,9 @@ extern "C" int kvc_paged_attention_decode(const kvc_attention_params* p, kvc_str
   a.alibi_slopes = p->alibi_slopes; a.q_stride = p->q_stride; a.kv_block_stride = p->kv_block_stride;
   a.scale = p->scale; a.num_heads = p->num_heads; a.num_kv_heads = p->num_kv_heads;
   a.max_blocks = p->max_num_blocks_per_seq; a.record = p->record_kv_metrics ? 1 : 0;
+  a.max_ctx = p->max_context_len > 0 ? p->max_context_len : 1;
   a.max_parts = (p->max_context_len + ATT_PART - 1) / ATT_PART;
   if (a.max_parts < 1) a.max_parts = 1;
-  if (a.max_parts > 1 && (p->exp_sums == nullptr || p->max_logits == nullptr || p->tmp_out == nullptr ||
-                          (a.record && p->tmp_kv_metric_out == nullptr)))
-    return fail_invalid("paged_attention_decode: contexts beyond 512 tokens need the partition buffers");
   hipStream_t s = (hipStream_t)stream;
   const int combo = p->head_size * 100 + p->block_size;
 #define KVC_ATT(HD, BS)                                                                   \
