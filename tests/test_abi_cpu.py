@@ -18,7 +18,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(REPO, "include", "kvc_mi355x.h")).read()
     declared = set(re.findall(r"\b(kvc_[a-z0-9_]+)\s*\(", header))
-    declared -= {"kvc_schedule_params"}
+    declared -= {"kvc_schedule_params", "kvc_attention_params"}
     assert declared, "no declarations found"
     lib = kvc.load()
     for name in sorted(declared):
@@ -44,6 +44,14 @@ def test_python_surface_matches_reference_signatures():
                                   "slot_mapping", "kv_metric_head_bias", "kv_cache_dtype",
                                   "k_scale", "v_scale"],
     }
+    # vllm/_custom_ops.py:135-155 and :167-191
+    attn_tail = ["query", "key_cache", "value_cache", "num_kv_heads", "scale", "block_tables",
+                 "context_lens", "kv_position", "last_position", "kv_metric_buffer_len",
+                 "block_size", "max_context_len", "alibi_slopes", "kv_cache_dtype", "k_scale",
+                 "v_scale", "record_kv_metrics"]
+    want["paged_attention_kvc_v1"] = ["out", "kv_metric_out"] + attn_tail
+    want["paged_attention_kvc_v2"] = ["out", "kv_metric_out", "exp_sum", "max_logits", "tmp_out",
+                                      "tmp_kv_metric_out"] + attn_tail
     for fn, params in want.items():
         assert list(inspect.signature(getattr(ops, fn)).parameters) == params
     from vllm_kvcompress_amd.kvcompress.metrics import CompressionMetrics
@@ -67,6 +75,8 @@ def test_dispatcher_names_registered():
     for name in ("count_block_evictions", "schedule_t1_cache_moves", "execute_cache_moves"):
         assert hasattr(torch.ops._C_kvc_ops, name)
     assert hasattr(torch.ops._C_cache_ops, "kvcompress_reshape_and_cache")
+    assert hasattr(torch.ops._C, "kvcompress_paged_attention_v1")
+    assert hasattr(torch.ops._C, "kvcompress_paged_attention_v2")
 
 
 def test_no_cpu_fallback():

@@ -191,3 +191,29 @@ def test_decode_attention_full_size_properties():
     assert bool((tail == 0).all())
     o = outs[0].float()
     assert bool((o >= -1e-3).all()) and bool((o <= 1.0 + 1e-3).all())
+
+
+def test_decode_attention_through_dispatcher():
+    """torch.ops._C.kvcompress_paged_attention_v1 (csrc/torch_bindings.cpp:52-64) resolves to
+    the HIP kernel after torch_ops.register()"""
+    import torch
+    from vllm_kvcompress_amd import torch_ops
+    torch_ops.register()
+    rng = np.random.default_rng(11)
+    g, c, pos, last = make_state(rng, 2, 8, 2, 128, 16, 10, 90)
+    buf = np.zeros(2, np.int32)
+    ref_out, ref_km = oracle_decode(c, g, pos, last, buf)
+    dev = "cuda:0"
+    t = lambda bits: torch.from_numpy(np.ascontiguousarray(bits)).to(dev).view(torch.float16)
+    q, kc, vc = t(g["query_bits"]), t(g["key_cache_bits"]), t(g["value_cache_bits"])
+    out = torch.zeros_like(q)
+    km = torch.full((vc.shape[0], 16, 4), -1.0, dtype=torch.float32, device=dev)
+    torch.ops._C.kvcompress_paged_attention_v1(
+        out, km, q, kc, vc, 2, float(g["scale"]), torch.from_numpy(g["block_tables"]).to(dev),
+        torch.from_numpy(g["context_lens"]).to(dev), torch.from_numpy(pos).to(dev),
+        torch.from_numpy(last).to(dev), torch.from_numpy(buf).to(dev), 16,
+        int(g["context_lens"].max()), None, "auto", 1.0, 1.0, True)
+    torch.cuda.synchronize()
+    rec = ref_km != -1.0
+    assert np.allclose(km.cpu().numpy()[rec], ref_km[rec], rtol=2e-4, atol=1e-9)
+    assert np.allclose(out.float().cpu().numpy(), ref_out, atol=2e-3, rtol=2e-3)

@@ -4,7 +4,9 @@ The fork's Python calls ``torch.ops._C_kvc_ops.count_block_evictions`` etc.
 (``vllm/_custom_ops.py:1074, 1169, 1247, 649``); its C++ registers them with
 ``TORCH_LIBRARY_EXPAND(_C_kvc_ops)`` / ``(_C_cache_ops)`` (``csrc/torch_bindings.cpp:372-418,
 353-362``).  ``register()`` defines the same schemas (or overrides the CUDA-key kernels if
-the namespace already exists) and binds them to libkvc_mi355x.so.
+the namespace already exists) and binds them to libkvc_mi355x.so.  The decode attention
+with metric output lives in the fork's main library ``_C`` (``csrc/torch_bindings.cpp:52-80``,
+called from ``vllm/_custom_ops.py:156, 192``).
 """
 from __future__ import annotations
 
@@ -34,6 +36,26 @@ _CACHE_SCHEMAS = {
         "(Tensor key, Tensor value, Tensor(a!) key_cache, Tensor(b!) value_cache, "
         "Tensor(c!) kv_metrics, Tensor slot_mapping, Tensor kv_metric_head_bias, "
         "str kv_cache_dtype, float k_scale, float v_scale) -> ()",
+}
+
+
+# library `_C` (csrc/torch_bindings.cpp:52-80): the decode attention with metric output
+_ATTN_SCHEMAS = {
+    "kvcompress_paged_attention_v1":
+        "(Tensor(a!) out, Tensor(b!) kv_metric_out, Tensor query, Tensor key_cache, "
+        "Tensor value_cache, int num_kv_heads, float scale, Tensor block_tables, "
+        "Tensor context_lens, Tensor kv_position, Tensor last_position, "
+        "Tensor kv_metric_buffer_len, int block_size, int max_context_len, "
+        "Tensor? alibi_slopes, str kv_cache_dtype, float k_scale, float v_scale, "
+        "bool record_kv_metrics) -> ()",
+    "kvcompress_paged_attention_v2":
+        "(Tensor(a!) out, Tensor(b!) kv_metric_out, Tensor exp_sums, Tensor max_logits, "
+        "Tensor tmp_out, Tensor tmp_kv_metric_out, Tensor query, Tensor key_cache, "
+        "Tensor value_cache, int num_kv_heads, float scale, Tensor block_tables, "
+        "Tensor context_lens, Tensor kv_position, Tensor last_position, "
+        "Tensor kv_metric_buffer_len, int block_size, int max_context_len, "
+        "Tensor? alibi_slopes, str kv_cache_dtype, float k_scale, float v_scale, "
+        "bool record_kv_metrics) -> ()",
 }
 
 
@@ -77,4 +99,8 @@ def register() -> None:
         "execute_cache_moves": _execute_cache_moves,
     })
     _bind("_C_cache_ops", _CACHE_SCHEMAS, {"kvcompress_reshape_and_cache": _reshape_and_cache})
+    _bind("_C", _ATTN_SCHEMAS, {
+        "kvcompress_paged_attention_v1": ops.paged_attention_kvc_v1,
+        "kvcompress_paged_attention_v2": ops.paged_attention_kvc_v2,
+    })
     _REGISTERED = True
