@@ -60,6 +60,8 @@ def parse_args():
     ap.add_argument("--contiguous-blocks", action="store_true",
                     help="physical blocks in allocation order (fresh prefill) instead of shuffled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-adjacent", action="store_true",
+                    help="skip the decode-attention (F3) side measurement")
     ap.add_argument("--traffic-json", default=os.path.join(REPO, "profiles", "traffic.json"),
                     help="PMC-derived HBM bytes per launch of the compaction kernel, if collected")
     return ap.parse_args()
@@ -319,6 +321,14 @@ def main():
         }
         if per_rank:
             res["per_rank"] = per_rank
+        if world == 1 and not args.no_adjacent:
+            # the producer of the metrics (row F3), one layer step at the continual-compression
+            # shape; not part of `value`
+            from vllm_kvcompress_amd.harness.attention_bench import run as attn_run
+            res["adjacent_decode_attention"] = [
+                attn_run(64, 4097, Hq=4 * args.kv_heads, Hkv=args.kv_heads, hd=args.head_size,
+                         bs=args.block_size if args.block_size in (16, 32) else 16, iters=10, record=r)
+                for r in (True, False)]
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(res))

@@ -260,8 +260,11 @@ int kvc_free_compressed_blocks(int32_t* context_lens, int32_t* seq_index_by_bloc
  * Contexts longer than 512 tokens are split into 512-token partitions (the reference's
  * v2); the four partition buffers have the v2 shapes and may be NULL when
  * max_context_len <= 512.
- * dtype: 0 = fp16, 1 = bf16 (query, output and cache).  kv_cache_dtype: 0 = "auto".
- * block_size 16 or 32; head_size 64, 96, 128 or 256.
+ * dtype: 0 = fp16, 1 = bf16 (query, output and an "auto" cache).  kv_cache_dtype: 0 = "auto"
+ * (cache elements of `dtype`, K vectors of x = 8), 1 = fp8 e4m3fn, 2 = fp8 e5m2 (OCP bytes,
+ * K vectors of x = 16; dequantised as dtype(float(fp8) * k_scale / v_scale) like the
+ * reference's fp8::scaled_convert, kvcompress_attention_kernels.cu:229-236, 369-377).
+ * block_size 16 or 32; head_size 64, 96, 128 or 256 ("auto"), 64 or 128 (fp8).
  * --------------------------------------------------------------------------------- */
 typedef struct kvc_attention_params {
   void* out;                            /* [num_seqs, num_heads, head_size] */

@@ -217,3 +217,49 @@ def test_decode_attention_through_dispatcher():
     rec = ref_km != -1.0
     assert np.allclose(km.cpu().numpy()[rec], ref_km[rec], rtol=2e-4, atol=1e-9)
     assert np.allclose(out.float().cpu().numpy(), ref_out, atol=2e-3, rtol=2e-3)
+
+
+@pytest.mark.parametrize("scales", [(0.5, 2.0), (1.0, 1.0)], ids=["scaled", "unit_scale"])
+@pytest.mark.parametrize("kind,bs,dt", [("fp8_e4m3", 16, "f16"), ("fp8_e5m2", 32, "f16"),
+                                        ("fp8", 32, "bf16"), ("fp8_e5m2", 16, "bf16")])
+def test_decode_attention_fp8_cache(kind, bs, dt, scales, attn_mode):
+    """fp8 K/V cache ([NB, hd/16, bs, 16] / [NB, hd, bs] bytes): the kernel dequantises
+    T(float(fp8) * scale) on load; the oracle gets the same dequantised values."""
+    import torch
+    from vllm_kvcompress_amd import _custom_ops as ops
+    rng = np.random.default_rng(21)
+    S, Hq, Hkv, hd, lo, hi = 2, 8, 2, 128, 40, 900
+    g, c, pos, last = make_state(rng, S, Hq, Hkv, hd, bs, lo, hi, dtype=dt)
+    NB = c["vc"].shape[0]
+    tf8 = torch.float8_e5m2 if kind == "fp8_e5m2" else torch.float8_e4m3fn
+    k_scale, v_scale = scales
+    # quantise random values (saturating cast of N(0,1)) -> bytes; x = 16 for the K layout
+    kq = torch.from_numpy(rng.standard_normal((NB, hd // 16, bs, 16)).astype(np.float32)).to(tf8)
+    vq = torch.from_numpy(rng.standard_normal((NB, hd, bs)).astype(np.float32)).to(tf8)
+    tdt = torch.float16 if dt == "f16" else torch.bfloat16
+    kd = (kq.float() * k_scale).to(tdt).float().numpy()            # what the kernel must see
+    vd = (vq.float() * v_scale).to(tdt).float().numpy()
+    c = dict(c, kc=kd.reshape(NB, hd // 16, bs, 16).transpose(0, 1, 3, 2).reshape(NB, hd, bs)
+             .transpose(0, 2, 1).reshape(NB, bs, hd // 8, 8).transpose(0, 2, 1, 3).copy(), vc=vd)
+    buf = np.zeros(S, np.int32)
+    ref_out, ref_km = oracle_decode(c, g, pos, last, buf)
+    dev = "cuda:0"
+    q = torch.from_numpy(np.ascontiguousarray(g["query_bits"])).to(dev).view(tdt)
+    out = torch.zeros_like(q)
+    km = torch.full((NB, bs, Hq // Hkv), -1.0, dtype=torch.float32, device=dev)
+    mx = int(g["context_lens"].max())
+    parts = (mx + 511) // 512
+    es = torch.empty((S, Hq, parts), dtype=torch.float32, device=dev)
+    ops.paged_attention_kvc_v2(
+        out, km, es, torch.empty_like(es), torch.empty((S, Hq, parts, hd), dtype=tdt, device=dev),
+        torch.empty_like(km), q, kq.view(torch.uint8).to(dev), vq.view(torch.uint8).to(dev), Hkv,
+        float(g["scale"]), torch.from_numpy(g["block_tables"]).to(dev),
+        torch.from_numpy(g["context_lens"]).to(dev), torch.from_numpy(pos).to(dev),
+        torch.from_numpy(last).to(dev), torch.from_numpy(buf).to(dev), bs, mx, None, kind, k_scale,
+        v_scale, True)
+    torch.cuda.synchronize()
+    rec = ref_km != -1.0
+    assert ((ref_km == -1.0) == (km.cpu().numpy() == -1.0)).all()
+    assert np.allclose(km.cpu().numpy()[rec], ref_km[rec], rtol=2e-4, atol=1e-9)
+    tol = 4e-3 if dt == "f16" else 3e-2
+    assert np.allclose(out.float().cpu().numpy(), ref_out, atol=tol, rtol=tol)

@@ -10,7 +10,7 @@ OUT="$REPO/gpurun_out/profiles_$TAG"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+BENCH="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-adjacent"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" --output-format csv -- $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" --output-format csv -- $BENCH > /dev/null 2> "$OUT/fetch.log"
 timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" --output-format csv -- $BENCH > /dev/null 2> "$OUT/write.log"

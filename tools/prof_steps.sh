@@ -7,7 +7,7 @@ REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 OUT="$REPO/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o "$TAG" -- python "$REPO/bench.py" --no-cpu-baseline --steps 10 "$@" > "$OUT/bench.json" 2> "$OUT/err.txt"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o "$TAG" -- python "$REPO/bench.py" --no-cpu-baseline --no-adjacent --steps 10 "$@" > "$OUT/bench.json" 2> "$OUT/err.txt"
 python - "$OUT" "$TAG" <<'PY'
 import csv, json, sys
 out, tag = sys.argv[1], sys.argv[2]

@@ -241,13 +241,19 @@ def _paged_attention_kvc(out, kv_metric_out, exp_sum, max_logits, tmp_out, tmp_k
                     ("kv_position", kv_position), ("last_position", last_position),
                     ("kv_metric_buffer_len", kv_metric_buffer_len)):
         _require(t, name, torch.int32)
-    if kv_cache_dtype != "auto":
+    kvds = {"auto": 0, "fp8": 1, "fp8_e4m3": 1, "fp8_e5m2": 2}
+    if kv_cache_dtype not in kvds:
         raise RuntimeError(f"Unsupported data type of kv cache: {kv_cache_dtype}")
     dtypes = {torch.float16: 0, torch.bfloat16: 1}
     if query.dtype not in dtypes:
         raise RuntimeError(f"Unsupported data type: {query.dtype}")
-    if key_cache.dtype != query.dtype or value_cache.dtype != query.dtype or out.dtype != query.dtype:
-        raise RuntimeError("paged_attention_kvc: query, output and \"auto\" caches must share a dtype")
+    if out.dtype != query.dtype:
+        raise RuntimeError("paged_attention_kvc: query and output must share a dtype")
+    if kv_cache_dtype == "auto":
+        if key_cache.dtype != query.dtype or value_cache.dtype != query.dtype:
+            raise RuntimeError("paged_attention_kvc: an \"auto\" cache has the query's dtype")
+    elif key_cache.element_size() != 1 or value_cache.element_size() != 1:
+        raise RuntimeError("paged_attention_kvc: an fp8 kv cache must have 1-byte elements")
     num_seqs, num_heads, head_size = query.shape
     if query.stride(1) != head_size or query.stride(2) != 1:
         raise RuntimeError("paged_attention_kvc: query must be contiguous in (head, dim)")
@@ -271,7 +277,8 @@ def _paged_attention_kvc(out, kv_metric_out, exp_sum, max_logits, tmp_out, tmp_k
     p.head_size, p.block_size = head_size, int(block_size)
     p.max_num_blocks_per_seq = bt.shape[-1]
     p.max_context_len = int(max_context_len)
-    p.dtype, p.kv_cache_dtype, p.record_kv_metrics = dtypes[query.dtype], 0, int(bool(record_kv_metrics))
+    p.dtype, p.kv_cache_dtype = dtypes[query.dtype], kvds[kv_cache_dtype]
+    p.record_kv_metrics = int(bool(record_kv_metrics))
     with torch.cuda.device(query.device):
         _lib.check(lib.kvc_paged_attention_decode(p, _stream(query)))
 

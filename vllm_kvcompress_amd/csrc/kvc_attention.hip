@@ -23,6 +23,7 @@
 #include "../../include/kvc_mi355x.h"
 
 #include <math.h>
+#include <type_traits>
 
 #ifndef KVC_ATT_DBG
 #define KVC_ATT_DBG 0
@@ -63,6 +64,72 @@ template <> struct Mma<__bf16> {
   }
 };
 
+// 8 consecutive cache elements -> MFMA operand, in two steps so that the (non-temporal) load
+// can be issued far ahead of the conversion.  KVD 0: the cache holds T (16-byte load);
+// KVD 1 / 2: OCP fp8 e4m3fn / e5m2 bytes (8-byte load), dequantised like the reference's
+// fp8::scaled_convert (csrc/attention/kvcompress_attention_kernels.cu:229-236, 369-377):
+// T(float(fp8) * scale); KVD 3 / 4: the same formats with scale == 1 (the engine default),
+// where every fp8 value is exact in fp16 and e5m2 is simply the top byte of an fp16.
+// K vectors of an fp8 cache hold x = 16 elements.
+typedef uint32_t au32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <typename T, int KVD>
+struct KvFrag {
+  using V8 = typename Mma<T>::V8;
+  static constexpr int X = KVD == 0 ? 8 : 16;            // elements per K vector
+  static constexpr bool E5M2 = KVD == 2 || KVD == 4;
+  static constexpr bool UNIT = KVD == 3 || KVD == 4;
+  struct Raw16 { au32x4 v; };
+  struct Raw8 { au32x2 v; };
+  using Raw = typename std::conditional<KVD == 0, Raw16, Raw8>::type;
+  static __device__ __forceinline__ Raw zero() { Raw r; r.v = 0; return r; }
+  static __device__ __forceinline__ Raw load(const void* base, int64_t elem) {
+    Raw r;
+    if constexpr (KVD == 0)
+      r.v = KVC_LD(reinterpret_cast<const au32x4*>(reinterpret_cast<const T*>(base) + elem));
+    else
+      r.v = KVC_LD(reinterpret_cast<const au32x2*>(reinterpret_cast<const uint8_t*>(base) + elem));
+    return r;
+  }
+  static __device__ __forceinline__ V8 convert(const Raw& r, float scale) {
+    if constexpr (KVD == 0) {
+      return __builtin_bit_cast(V8, r.v);
+    } else if constexpr (KVD == 4 && __is_same(T, _Float16)) {
+      au32x4 o;
+      o[0] = ((r.v[0] & 0xFFu) << 8) | ((r.v[0] & 0xFF00u) << 16);
+      o[1] = ((r.v[0] >> 8) & 0xFF00u) | (r.v[0] & 0xFF000000u);
+      o[2] = ((r.v[1] & 0xFFu) << 8) | ((r.v[1] & 0xFF00u) << 16);
+      o[3] = ((r.v[1] >> 8) & 0xFF00u) | (r.v[1] & 0xFF000000u);
+      return __builtin_bit_cast(V8, o);
+    } else {
+      f32x2 f[4];
+      if constexpr (!E5M2) {
+        f[0] = __builtin_amdgcn_cvt_pk_f32_fp8(r.v[0], false); f[1] = __builtin_amdgcn_cvt_pk_f32_fp8(r.v[0], true);
+        f[2] = __builtin_amdgcn_cvt_pk_f32_fp8(r.v[1], false); f[3] = __builtin_amdgcn_cvt_pk_f32_fp8(r.v[1], true);
+      } else {
+        f[0] = __builtin_amdgcn_cvt_pk_f32_bf8(r.v[0], false); f[1] = __builtin_amdgcn_cvt_pk_f32_bf8(r.v[0], true);
+        f[2] = __builtin_amdgcn_cvt_pk_f32_bf8(r.v[1], false); f[3] = __builtin_amdgcn_cvt_pk_f32_bf8(r.v[1], true);
+      }
+      V8 v;
+      if constexpr (UNIT && __is_same(T, _Float16)) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const h2 h = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(f[e][0], f[e][1]));   // exact
+          v[2 * e] = h[0]; v[2 * e + 1] = h[1];
+        }
+      } else if constexpr (UNIT) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] = (T)f[e][0]; v[2 * e + 1] = (T)f[e][1]; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] = (T)(f[e][0] * scale); v[2 * e + 1] = (T)(f[e][1] * scale); }
+      }
+      return v;
+    }
+  }
+};
+
 struct AttnArgs {
   void* out;                      // [S, Hq, hd] T
   float* kv_metric_out;           // [NB, bs, qpk]
@@ -80,7 +147,7 @@ struct AttnArgs {
   const int32_t* kv_metric_buffer_len;   // [S]
   const float* alibi_slopes;      // [Hq] or null
   int64_t q_stride, kv_block_stride;
-  float scale;
+  float scale, k_scale, v_scale;
   int32_t num_heads, num_kv_heads, max_blocks, max_parts, record, max_ctx;
 };
 
@@ -94,7 +161,7 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 // dynamic LDS: 2 x [ATT_WAVES][nqr][max(ATT_CHUNK, HD)] floats (P tiles | per-wave outputs)
-template <typename T, int HD, int BS>
+template <typename T, int HD, int BS, int KVD>
 __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a) {
   using M = Mma<T>;
   using V8 = typename M::V8;
@@ -116,8 +183,8 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
   const int nqr = min(ATT_NQ, qpk);                       // LDS rows allocated
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const T* kc = reinterpret_cast<const T*>(a.k_cache);
-  const T* vc = reinterpret_cast<const T*>(a.v_cache);
+  using KF = KvFrag<T, KVD>;
+  constexpr int X = KF::X;
   const int32_t* bt = a.block_tables + (int64_t)(seq * a.num_kv_heads + hk) * a.max_blocks;
   const int head0 = hk * qpk + q0;                        // first query head of this group
 
@@ -163,13 +230,14 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (t0 < ctx) {                                       // wave-uniform
       const int64_t phys = bt[t0 / BS];
-      const T* kb = kc + phys * a.kv_block_stride + ((int64_t)g * BS + (t0 % BS) + c) * 8;
-      V8 kk[KS];
+      // dims 32 s + 8 g .. + 7 of token t0 + c: vector (dim / X), element (dim % X)
+      const int64_t kb = phys * a.kv_block_stride + (int64_t)((t0 % BS) + c) * X;
+      typename KF::Raw kk[KS];
 #pragma unroll
       for (int s = 0; s < KS; ++s)
-        kk[s] = __builtin_bit_cast(V8, KVC_LD(reinterpret_cast<const au32x4*>(kb + (int64_t)s * 4 * BS * 8)));
+        kk[s] = KF::load(a.k_cache, kb + (int64_t)((32 * s + 8 * g) / X) * BS * X + (32 * s + 8 * g) % X);
 #pragma unroll
-      for (int s = 0; s < KS; ++s) acc = M::mma(kk[s], qf[s], acc);
+      for (int s = 0; s < KS; ++s) acc = M::mma(KF::convert(kk[s], a.k_scale), qf[s], acc);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -232,24 +300,21 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
     const int tok = t0 + 8 * g;
     const bool live = tok < ctx;
     const int64_t phys = live ? bt[tok / BS] : 0;
-    const T* vb = vc + phys * a.kv_block_stride + (int64_t)c * BS + (tok % BS);
+    const int64_t vb = phys * a.kv_block_stride + (int64_t)c * BS + (tok % BS);
     const bool tail = t0 + 32 > ctx;                      // wave-uniform: mask stale tokens
-    V8 vv[DT];
+    typename KF::Raw vr[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) vr[i] = live ? KF::load(a.v_cache, vb + (int64_t)i * 16 * BS) : KF::zero();
 #pragma unroll
     for (int i = 0; i < DT; ++i) {
-      au32x4 raw = {0u, 0u, 0u, 0u};
-      if (live) raw = KVC_LD(reinterpret_cast<const au32x4*>(vb + (int64_t)i * 16 * BS));
-      vv[i] = __builtin_bit_cast(V8, raw);
-    }
-    if (tail) {
-#pragma unroll
-      for (int i = 0; i < DT; ++i)
+      V8 vv = KF::convert(vr[i], a.v_scale);
+      if (tail) {
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          if (tok + e >= ctx) vv[i][e] = (T)0.0f;
+          if (tok + e >= ctx) vv[e] = (T)0.0f;
+      }
+      O[i] = M::mma(vv, pb, O[i]);
     }
-#pragma unroll
-    for (int i = 0; i < DT; ++i) O[i] = M::mma(vv[i], pb, O[i]);
   }
 
   // ---- combine the four waves (same max, so a plain sum), normalise, store
@@ -326,7 +391,7 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
 // (two workgroups per CU: qpk * max_context * 4 B <= ~68 KiB - the continual-compression
 // regime, e.g. 4k-token caps at qpk 4) and there are enough (sequence, KV head) pairs to fill the chip.
 // dynamic LDS: P [nqr][prow] | O [4][nqr][HD] | mrec [niter][4][16]
-template <typename T, int HD, int BS>
+template <typename T, int HD, int BS, int KVD>
 __global__ __launch_bounds__(256) KVC_WHOLE_ATTR void paged_attention_decode_whole_kernel(AttnArgs a, int prow, int niter_max) {
   using M = Mma<T>;
   using V8 = typename M::V8;
@@ -345,8 +410,8 @@ __global__ __launch_bounds__(256) KVC_WHOLE_ATTR void paged_attention_decode_who
   const int nqr = min(ATT_NQ, qpk);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const T* kc = reinterpret_cast<const T*>(a.k_cache);
-  const T* vc = reinterpret_cast<const T*>(a.v_cache);
+  using KF = KvFrag<T, KVD>;
+  constexpr int X = KF::X;
   const int32_t* bt = a.block_tables + (int64_t)(seq * a.num_kv_heads + hk) * a.max_blocks;
   const int head0 = hk * qpk + q0;
   float* P = lds;                                          // [nqr][prow]
@@ -379,18 +444,18 @@ __global__ __launch_bounds__(256) KVC_WHOLE_ATTR void paged_attention_decode_who
     f32x4 S[ATT_NSUB];
     float mloc = -INFINITY;
     constexpr int PF = KVC_PF;
-    V8 kk[ATT_NSUB][KS];
+    typename KF::Raw kk[ATT_NSUB][KS];
     auto load_k = [&](int sb) {
       const int t0 = tok_w0 + sb * 16;
       if (t0 < ctx) {
         const int64_t phys = bt[t0 / BS];
-        const T* kb = kc + phys * a.kv_block_stride + ((int64_t)g * BS + (t0 % BS) + c) * 8;
+        const int64_t kb = phys * a.kv_block_stride + (int64_t)((t0 % BS) + c) * X;
 #pragma unroll
         for (int s = 0; s < KS; ++s)
-          kk[sb][s] = __builtin_bit_cast(V8, KVC_LD(reinterpret_cast<const au32x4*>(kb + (int64_t)s * 4 * BS * 8)));
+          kk[sb][s] = KF::load(a.k_cache, kb + (int64_t)((32 * s + 8 * g) / X) * BS * X + (32 * s + 8 * g) % X);
       } else {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) kk[sb][s] = __builtin_bit_cast(V8, au32x4{0u, 0u, 0u, 0u});
+        for (int s = 0; s < KS; ++s) kk[sb][s] = KF::zero();
       }
     };
 #pragma unroll
@@ -402,7 +467,7 @@ __global__ __launch_bounds__(256) KVC_WHOLE_ATTR void paged_attention_decode_who
       const int t0 = tok_w0 + sb * 16;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < KS; ++s) acc = M::mma(kk[sb][s], qf[s], acc);
+      for (int s = 0; s < KS; ++s) acc = M::mma(KF::convert(kk[sb][s], a.k_scale), qf[s], acc);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int tok = t0 + 4 * g + j;
@@ -437,18 +502,15 @@ __global__ __launch_bounds__(256) KVC_WHOLE_ATTR void paged_attention_decode_who
     for (int i = 0; i < DT; ++i) O[i] *= alpha;
     // ---- P.V, V fragments one 32-token pair ahead
     constexpr int NPR = ATT_NSUB / 2;
-    V8 vv[2][DT];
+    typename KF::Raw vv[2][DT];
     auto load_v = [&](int pr, int bufi) {
       const int tok = tok_w0 + pr * 32 + 8 * g;
       const bool live = tok < ctx;
       const int64_t phys = live ? bt[tok / BS] : 0;
-      const T* vb = vc + phys * a.kv_block_stride + (int64_t)c * BS + (tok % BS);
+      const int64_t vb = phys * a.kv_block_stride + (int64_t)c * BS + (tok % BS);
 #pragma unroll
-      for (int i = 0; i < DT; ++i) {
-        au32x4 raw = {0u, 0u, 0u, 0u};
-        if (live) raw = KVC_LD(reinterpret_cast<const au32x4*>(vb + (int64_t)i * 16 * BS));
-        vv[bufi][i] = __builtin_bit_cast(V8, raw);
-      }
+      for (int i = 0; i < DT; ++i)
+        vv[bufi][i] = live ? KF::load(a.v_cache, vb + (int64_t)i * 16 * BS) : KF::zero();
     };
     load_v(0, 0);
 #pragma unroll
@@ -468,15 +530,17 @@ __global__ __launch_bounds__(256) KVC_WHOLE_ATTR void paged_attention_decode_who
         for (int e = 0; e < 4; ++e) { pb[e] = (T)lo[e]; pb[4 + e] = (T)hi[e]; }
       }
       const int tok = t0 + 8 * g;
-      if (t0 + 32 > ctx) {                                 // wave-uniform: mask stale tokens
+      const bool tail = t0 + 32 > ctx;                     // wave-uniform: mask stale tokens
 #pragma unroll
-        for (int i = 0; i < DT; ++i)
+      for (int i = 0; i < DT; ++i) {
+        V8 vf = KF::convert(vv[pr & 1][i], a.v_scale);
+        if (tail) {
 #pragma unroll
           for (int e = 0; e < 8; ++e)
-            if (tok + e >= ctx) vv[pr & 1][i][e] = (T)0.0f;
+            if (tok + e >= ctx) vf[e] = (T)0.0f;
+        }
+        O[i] = M::mma(vf, pb, O[i]);
       }
-#pragma unroll
-      for (int i = 0; i < DT; ++i) O[i] = M::mma(vv[pr & 1][i], pb, O[i]);
     }
   }
 
@@ -677,7 +741,7 @@ __global__ __launch_bounds__(256) void paged_attention_metric_rescale_kernel(Att
 
 static int g_attention_mode = 0;      // 0 auto, 1 partitioned, 2 single pass (kvc_debug_set_attention_mode)
 
-template <typename T, int HD, int BS>
+template <typename T, int HD, int BS, int KVD>
 static int launch_attention(const AttnArgs& a, int num_seqs, hipStream_t s) {
   const int qpk = a.num_heads / a.num_kv_heads;
   const int ngroups = (qpk + ATT_NQ - 1) / ATT_NQ;
@@ -694,9 +758,9 @@ static int launch_attention(const AttnArgs& a, int num_seqs, hipStream_t s) {
                       : (whole_fits && (int64_t)num_seqs * a.num_kv_heads * ngroups >= 512));
   if (whole) {
     if (whole_lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(paged_attention_decode_whole_kernel<T, HD, BS>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(paged_attention_decode_whole_kernel<T, HD, BS, KVD>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)whole_lds);
-    hipLaunchKernelGGL((paged_attention_decode_whole_kernel<T, HD, BS>), dim3(a.num_kv_heads * ngroups, num_seqs),
+    hipLaunchKernelGGL((paged_attention_decode_whole_kernel<T, HD, BS, KVD>), dim3(a.num_kv_heads * ngroups, num_seqs),
                        dim3(256), whole_lds, s, a, prow, a.max_parts);
     return check_launch("paged_attention_decode");
   }
@@ -706,9 +770,9 @@ static int launch_attention(const AttnArgs& a, int num_seqs, hipStream_t s) {
   constexpr int ROW = ATT_CHUNK > HD ? ATT_CHUNK : HD;
   const size_t lds_bytes = (size_t)2 * ATT_WAVES * nqr * ROW * sizeof(float);
   if (lds_bytes > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(paged_attention_decode_kernel<T, HD, BS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(paged_attention_decode_kernel<T, HD, BS, KVD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  hipLaunchKernelGGL((paged_attention_decode_kernel<T, HD, BS>),
+  hipLaunchKernelGGL((paged_attention_decode_kernel<T, HD, BS, KVD>),
                      dim3(a.max_parts, a.num_kv_heads * ngroups, num_seqs), dim3(256), lds_bytes, s, a);
   if (a.max_parts > 1) {
     hipLaunchKernelGGL((paged_attention_reduce_kernel<T, HD, BS>), dim3(a.num_heads, num_seqs), dim3(256),
@@ -732,8 +796,8 @@ extern "C" int kvc_paged_attention_decode(const kvc_attention_params* p, kvc_str
   if (p->num_seqs <= 0) return KVC_OK;
   if (p->num_kv_heads < 1 || p->num_heads % p->num_kv_heads != 0)
     return fail_invalid("paged_attention_decode: num_heads must be a multiple of num_kv_heads");
-  if (p->kv_cache_dtype != 0)
-    return fail_invalid("paged_attention_decode: only the \"auto\" cache dtype is implemented");
+  if (p->kv_cache_dtype < 0 || p->kv_cache_dtype > 2)
+    return fail_invalid("Unsupported data type of kv cache: " + std::to_string(p->kv_cache_dtype));
   if (p->dtype != 0 && p->dtype != 1) return fail_invalid("Unsupported data type of query");
   AttnArgs a;
   a.out = p->out; a.kv_metric_out = p->kv_metric_out; a.exp_sums = p->exp_sums;
@@ -742,16 +806,33 @@ extern "C" int kvc_paged_attention_decode(const kvc_attention_params* p, kvc_str
   a.block_tables = p->block_tables; a.context_lens = p->context_lens; a.kv_position = p->kv_position;
   a.last_position = p->last_position; a.kv_metric_buffer_len = p->kv_metric_buffer_len;
   a.alibi_slopes = p->alibi_slopes; a.q_stride = p->q_stride; a.kv_block_stride = p->kv_block_stride;
-  a.scale = p->scale; a.num_heads = p->num_heads; a.num_kv_heads = p->num_kv_heads;
+  a.scale = p->scale; a.k_scale = p->k_scale; a.v_scale = p->v_scale; a.num_heads = p->num_heads; a.num_kv_heads = p->num_kv_heads;
   a.max_blocks = p->max_num_blocks_per_seq; a.record = p->record_kv_metrics ? 1 : 0;
   a.max_ctx = p->max_context_len > 0 ? p->max_context_len : 1;
   a.max_parts = (p->max_context_len + ATT_PART - 1) / ATT_PART;
   if (a.max_parts < 1) a.max_parts = 1;
   hipStream_t s = (hipStream_t)stream;
   const int combo = p->head_size * 100 + p->block_size;
-#define KVC_ATT(HD, BS)                                                                   \
-  (p->dtype == 0 ? launch_attention<_Float16, HD, BS>(a, p->num_seqs, s)                  \
-                 : launch_attention<__bf16, HD, BS>(a, p->num_seqs, s))
+#define KVC_ATT_T(HD, BS, KVD)                                                             \
+  (p->dtype == 0 ? launch_attention<_Float16, HD, BS, KVD>(a, p->num_seqs, s)             \
+                 : launch_attention<__bf16, HD, BS, KVD>(a, p->num_seqs, s))
+#define KVC_ATT(HD, BS) KVC_ATT_T(HD, BS, 0)
+  if (p->kv_cache_dtype != 0) {                  // fp8 caches: head sizes 64 and 128
+    // 1 / 2: e4m3 / e5m2 with scales; 3 / 4: both scales 1 (cheaper dequantisation)
+    const int kvd = p->kv_cache_dtype + ((p->k_scale == 1.0f && p->v_scale == 1.0f) ? 2 : 0);
+#define KVC_ATT_F8(HD, BS)                                                                 \
+  (kvd == 1 ? KVC_ATT_T(HD, BS, 1) : kvd == 2 ? KVC_ATT_T(HD, BS, 2)                       \
+            : kvd == 3 ? KVC_ATT_T(HD, BS, 3) : KVC_ATT_T(HD, BS, 4))
+    switch (combo) {
+      case 6416: return KVC_ATT_F8(64, 16);
+      case 6432: return KVC_ATT_F8(64, 32);
+      case 12816: return KVC_ATT_F8(128, 16);
+      case 12832: return KVC_ATT_F8(128, 32);
+      default:
+        return fail_invalid("paged_attention_decode: fp8 caches support head sizes 64 and 128 with "
+                            "block sizes 16 and 32");
+    }
+  }
   switch (combo) {
     case 6416: return KVC_ATT(64, 16);
     case 6432: return KVC_ATT(64, 32);
@@ -763,6 +844,8 @@ extern "C" int kvc_paged_attention_decode(const kvc_attention_params* p, kvc_str
     case 25632: return KVC_ATT(256, 32);
     default: break;
   }
+#undef KVC_ATT_F8
+#undef KVC_ATT_T
 #undef KVC_ATT
   if (p->block_size != 16 && p->block_size != 32)
     return fail_invalid("Unsupported block size: " + std::to_string(p->block_size));
