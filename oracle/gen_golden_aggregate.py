@@ -88,7 +88,32 @@ def main():
                 block=np.int32(blk), use_l2=np.int32(l2), use_average=np.int32(avg),
                 use_maxpool=np.int32(pool), ref_kv_metric_output=res.numpy().astype(np.float32))
             case += 1
-    print(f"wrote 4 decode/prefill cases and {case} prefill-attention cases")
+    # ---- F4: the same reference function on MFMA-sized shapes (hd 64 / 128) for the fused
+    # collector; keys are given per query head, as the engine passes them (flash_attn.py:988-991)
+    torch.manual_seed(1)
+    fcase = 0
+    for (l2, avg, pool, lens, n_obs, blk, buf, Hq, hd, dt) in [
+            (True, False, True, [150], 100, 64, [0], 4, 64, torch.float16),
+            (True, True, True, [70, 200], 1000, 64, [3, 0], 4, 64, torch.float16),
+            (False, False, False, [333], 333, 128, [5], 2, 128, torch.float16),
+            (True, False, True, [260], 260, 100, [0], 4, 128, torch.bfloat16),
+            (False, True, True, [97, 40], 50, 50, [0, 7], 8, 64, torch.float16)]:
+        T = sum(lens)
+        q = (torch.randn(T, Hq, hd) * 1.2).to(dt)
+        k = (torch.randn(T, Hq, hd) * 1.2).to(dt)
+        with contextlib.redirect_stdout(io.StringIO()):
+            _, res = naive(q, k, k, lens, hd ** -0.5, torch.tensor(buf, dtype=torch.int32),
+                           n_observed=n_obs, max_observed_block_size=blk, use_l2=l2,
+                           use_average=avg, use_maxpool=pool)
+        np.savez_compressed(
+            os.path.join(out, f"agg_prefill_fused_{fcase}.npz"), q=q.view(torch.int16).numpy(),
+            k=k.view(torch.int16).numpy(), dtype=("f16" if dt == torch.float16 else "bf16"),
+            prompt_lens=np.asarray(lens, np.int32), buffer_len=np.asarray(buf, np.int32),
+            n_observed=np.int32(n_obs), block=np.int32(blk), use_l2=np.int32(l2),
+            use_average=np.int32(avg), use_maxpool=np.int32(pool),
+            ref_kv_metric_output=res.numpy().astype(np.float32))
+        fcase += 1
+    print(f"wrote 4 decode/prefill cases, {case} prefill-attention cases and {fcase} fused-collector cases")
 
 
 if __name__ == "__main__":

@@ -81,8 +81,9 @@ def reference_prefill_metrics_numpy(g):
     """float32 restatement of the reference loop (flash_attn.py:1122-1211) around the
     oracle's epilogue, on a golden case of oracle/gen_golden_aggregate.py."""
     import torch
-    q = torch.from_numpy(g["q"].view(np.float16).copy())
-    k = torch.from_numpy(g["k"].view(np.float16).copy())
+    tdt = torch.bfloat16 if ("dtype" in g and str(g["dtype"]) == "bf16") else torch.float16
+    q = torch.from_numpy(g["q"].view(np.int16).copy()).view(tdt)
+    k = torch.from_numpy(g["k"].view(np.int16).copy()).view(tdt)
     T, Hq, hd = q.shape
     scale = hd ** -0.5
     out = np.zeros((T, Hq), dtype=np.float32)
@@ -97,8 +98,8 @@ def reference_prefill_metrics_numpy(g):
             q_off = l - start
             # einsum in the query dtype, widened, THEN scaled in float32   (flash_attn.py:1186)
             w = scale * torch.einsum("qhd,khd->hqk", qq, k[start:end]).float()
-            mask = torch.triu(torch.ones(nq, plen, dtype=torch.float16), diagonal=q_off + 1)
-            w = w + (mask * torch.finfo(torch.float16).min).float()
+            mask = torch.triu(torch.ones(nq, plen, dtype=tdt), diagonal=q_off + 1)
+            w = w + (mask * torch.finfo(tdt).min).float()
             probs = torch.softmax(w, dim=-1).numpy()
             orc.prefill_metric_epilogue(out[start:end], probs, q_off, int(g["buffer_len"][i]),
                                         bool(int(g["use_l2"])), bool(int(g["use_average"])),

@@ -184,6 +184,16 @@ def test_prefill_metric_epilogue_matches_reference(case):
     np.testing.assert_allclose(got, g["ref_kv_metric_output"], rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("case", range(5))
+def test_prefill_metric_oracle_on_fused_collector_cases(case):
+    """the same restatement on the MFMA-sized cases (hd 64 / 128, fp16 / bf16) that pin the
+    fused collector (F4)"""
+    from tests.helpers import reference_prefill_metrics_numpy
+    g = load_golden(f"agg_prefill_fused_{case}")
+    got = reference_prefill_metrics_numpy(g)
+    np.testing.assert_allclose(got, g["ref_kv_metric_output"], rtol=1e-5, atol=1e-7)
+
+
 def test_host_policy_matches_reference():
     """A8: harness.synth.evict_block_count vs CompressionScheduler._schedule_seq_evictions
     (vllm/kvcompress/scheduler.py:100-181) on 400 random parameter sets, including the cases

@@ -7,5 +7,5 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value \
   "$HERE/kvc_api.hip" "$HERE/kvc_moves.hip" "$HERE/kvc_compact.hip" \
   "$HERE/kvc_schedule.hip" "$HERE/kvc_aggregate.hip" "$HERE/kvc_blockstate.hip" \
-  "$HERE/kvc_attention.hip" -o "$OUT"
+  "$HERE/kvc_attention.hip" "$HERE/kvc_prefill_attn.hip" -o "$OUT"
 echo "built $OUT"

@@ -344,6 +344,17 @@ extern "C" int kvc_aggregate_prefill(float* metrics, const float* prefill_metric
   return check_launch("aggregate_prefill");
 }
 
+namespace kvc {
+// shared with the fused collector (kvc_prefill_attn.hip): step 2 of the epilogue
+int launch_epilogue_pool(float* out_kh, const float* colsum, int num_q_heads, int num_keys,
+                         int use_maxpool, hipStream_t s) {
+  const int64_t n = (int64_t)num_keys * num_q_heads;
+  hipLaunchKernelGGL(epilogue_pool_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out_kh,
+                     colsum, num_q_heads, num_keys, use_maxpool);
+  return check_launch("prefill_metric_epilogue(pool)");
+}
+}  // namespace kvc
+
 extern "C" size_t kvc_prefill_metric_epilogue_workspace_bytes(int32_t num_q_heads, int32_t num_keys) {
   return (size_t)num_q_heads * (size_t)num_keys * sizeof(float);
 }

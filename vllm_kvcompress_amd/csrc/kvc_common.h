@@ -29,6 +29,10 @@ inline int check_launch(const char* what) {
   return KVC_OK;
 }
 
+// kvc_aggregate.hip: max_pool1d(7) over keys + accumulate, out_kh[K,Hq] += pool(colsum[Hq,K])
+int launch_epilogue_pool(float* out_kh, const float* colsum, int num_q_heads, int num_keys,
+                         int use_maxpool, hipStream_t s);
+
 constexpr int WAVE = 64;
 
 // Order-preserving map float32 -> uint32 (ascending float order == ascending key order).

@@ -1,0 +1,267 @@
+// F4: fused prefill metric collector.
+//   replaces  _naive_kvc_attention / _naive_kvc_masked_attention
+//             (vllm/attention/backends/flash_attn.py:1120-1211)
+// For one sequence and one block of observed queries the reference materialises
+// P = softmax(scale * Q K^T + causal) as fp32 [Hq, qb, K] (8 GiB at Hq 32, qb 1024, K 65536)
+// plus four temporaries of the same size, then reduces it to [Hq, K] column sums.  Here P
+// never exists in memory: two matrix-core passes over S = Q K^T,
+//   1. per query row: log-sum-exp over the causal keys (online max / sum),
+//   2. per key column: sum over the block's queries of P (or P^2) under the metric-window
+//      mask, P recomputed as exp(S - lse),
+// followed by the existing pool + accumulate step.  Both passes hold one operand tile of
+// 64 rows in registers per wave (queries in pass 1, keys in pass 2) and stream the other.
+// v_mfma_f32_32x32x16 with M = keys, N = queries, K = head dims; the contraction order is
+// free, so a lane's operand is one 16-byte piece of a token's head vector.
+// Numerics follow the reference: logits are rounded to the input type before the softmax
+// (its einsum returns fp16 / bf16, flash_attn.py:1189), everything after is fp32.
+#include "kvc_common.h"
+#include "../../include/kvc_mi355x.h"
+
+#include <math.h>
+
+namespace kvc {
+
+typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t pu32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Mma32;
+template <> struct Mma32<_Float16> {
+  using V8 = pf16x8;
+  static __device__ __forceinline__ f32x16 mma(V8 a, V8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma32<__bf16> {
+  using V8 = pbf16x8;
+  static __device__ __forceinline__ f32x16 mma(V8 a, V8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+struct PfArgs {
+  const void* q;        // first query row of the block, [nq, Hq, hd], token stride q_stride
+  const void* k;        // first key of the sequence, [K, Hk, hd], token stride k_stride
+  float* lse;           // [Hq, nq]  (log2 domain)
+  float* colsum;        // [Hq, K]
+  int64_t q_stride, k_stride;
+  float scale;
+  int32_t Hq, Hk, nq, K, q_offset, buffer_len, use_l2, use_average;
+};
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+// 64 rows x HD of one head as MFMA operand fragments: frag[blk][s] holds, for row
+// (32 blk + lane % 32), head dims 16 s + 8 (lane / 32) .. + 7
+template <typename T, int HD>
+__device__ __forceinline__ void load_rows(typename Mma32<T>::V8 (&frag)[2][HD / 16], const T* base,
+                                          int64_t stride, int row0, int nrows, int lane) {
+  using V8 = typename Mma32<T>::V8;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int r = row0 + 32 * b + (lane & 31);
+    const bool ok = r < nrows;
+    const T* p = base + (int64_t)(ok ? r : 0) * stride + 8 * (lane >> 5);
+#pragma unroll
+    for (int s = 0; s < HD / 16; ++s) {
+      pu32x4 raw = {0u, 0u, 0u, 0u};
+      if (ok) raw = *reinterpret_cast<const pu32x4*>(p + 16 * s);
+      frag[b][s] = __builtin_bit_cast(V8, raw);
+    }
+  }
+}
+
+// pass 1: lse[h, r] = log2 sum_k 2^(t[r,k]) over keys k <= q_offset + r, t = logit * log2(e)
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void prefill_lse_kernel(PfArgs a) {
+  using M = Mma32<T>;
+  using V8 = typename M::V8;
+  constexpr int KS = HD / 16;
+  const int h = blockIdx.y, hk = h / (a.Hq / a.Hk);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r0 = (blockIdx.x * 4 + w) * 64;                 // this wave's first query row
+  if (r0 >= a.nq) return;
+  const T* qb = reinterpret_cast<const T*>(a.q) + (int64_t)h * HD;
+  const T* kb = reinterpret_cast<const T*>(a.k) + (int64_t)hk * HD;
+  V8 bq[2][KS];
+  load_rows<T, HD>(bq, qb, a.q_stride, r0, a.nq, lane);
+  const float sc = a.scale * LOG2E;
+  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.0f, 0.0f};
+  const int col = lane & 31, half = lane >> 5;
+  const int pq_last = a.q_offset + min(a.nq, r0 + 64) - 1;  // last causal key of the wave
+  const int kend = min(a.K, pq_last + 1);
+  for (int k0 = 0; k0 < kend; k0 += 64) {
+    V8 ak[2][KS];
+    load_rows<T, HD>(ak, kb, a.k_stride, k0, a.K, lane);
+    const bool diag = k0 + 63 > a.q_offset + r0 || k0 + 64 > a.K;   // wave-uniform: needs masking
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      f32x16 c[2];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        c[mb] = f32x16{0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) c[mb] = M::mma(ak[mb][s], bq[nb][s], c[mb]);
+      }
+      const int pq = a.q_offset + r0 + 32 * nb + col;      // this lane's query position
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float t = (float)(T)c[mb][i] * sc;                // logits are rounded to T (:1189)
+          if (diag) {
+            const int key = k0 + 32 * mb + (i & 3) + 8 * (i >> 2) + 4 * half;
+            if (key > pq || key >= a.K) t = -INFINITY;
+          }
+          c[mb][i] = t;
+          tmax = fmaxf(tmax, t);
+        }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float mn = fmaxf(m[nb], tmax);
+      float sum = 0.0f;
+      if (mn != -INFINITY) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) sum += __builtin_amdgcn_exp2f(c[mb][i] - mn);
+        sum += __shfl_xor(sum, 32, 64);
+        l[nb] = l[nb] * __builtin_amdgcn_exp2f(m[nb] - mn) + sum;
+        m[nb] = mn;
+      }
+    }
+  }
+  if (half == 0) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int r = r0 + 32 * nb + col;
+      if (r < a.nq) a.lse[(int64_t)h * a.nq + r] = m[nb] + __builtin_amdgcn_logf(l[nb]);
+    }
+  }
+}
+
+// pass 2: colsum[h, k] = sum over the block's query rows r with k + buffer_len <= q_offset + r
+// of P[r, k] (or its square), P = 2^(t - lse)
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void prefill_colsum_kernel(PfArgs a) {
+  using M = Mma32<T>;
+  using V8 = typename M::V8;
+  constexpr int KS = HD / 16;
+  const int h = blockIdx.y, hk = h / (a.Hq / a.Hk);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int k0 = (blockIdx.x * 4 + w) * 64;                 // this wave's first key
+  if (k0 >= a.K) return;
+  const T* qb = reinterpret_cast<const T*>(a.q) + (int64_t)h * HD;
+  const T* kb = reinterpret_cast<const T*>(a.k) + (int64_t)hk * HD;
+  V8 ak[2][KS];
+  load_rows<T, HD>(ak, kb, a.k_stride, k0, a.K, lane);
+  const float sc = a.scale * LOG2E;
+  const int col = lane & 31, half = lane >> 5;
+  f32x16 acc[2];
+  acc[0] = f32x16{0.f};
+  acc[1] = f32x16{0.f};
+  // first query row that can see key k0 through the metric window
+  int rs = k0 + a.buffer_len - a.q_offset;
+  rs = rs < 0 ? 0 : rs;
+  for (int r0 = rs / 64 * 64; r0 < a.nq; r0 += 64) {
+    V8 bq[2][KS];
+    load_rows<T, HD>(bq, qb, a.q_stride, r0, a.nq, lane);
+    // every (key, query) pair of the tile inside the window and inside the block?
+    const bool edge = k0 + 63 + a.buffer_len > a.q_offset + r0 || r0 + 64 > a.nq || k0 + 64 > a.K;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int r = r0 + 32 * nb + col;
+      const float ls = r < a.nq ? a.lse[(int64_t)h * a.nq + r] : 0.0f;
+      const int pq = a.q_offset + r;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        f32x16 c = f32x16{0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) c = M::mma(ak[mb][s], bq[nb][s], c);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float p = __builtin_amdgcn_exp2f((float)(T)c[i] * sc - ls);
+          if (a.use_l2) p *= p;
+          if (edge) {
+            const int key = k0 + 32 * mb + (i & 3) + 8 * (i >> 2) + 4 * half;
+            if (key + a.buffer_len > pq || r >= a.nq || key >= a.K) p = 0.0f;
+          }
+          acc[mb][i] += p;
+        }
+      }
+    }
+  }
+  // sum over the 32 query columns held by the lanes of each half
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float v = acc[mb][i];
+#pragma unroll
+      for (int d = 1; d < 32; d <<= 1) v += __shfl_xor(v, d, 64);
+      acc[mb][i] = v;
+    }
+  // lane `col` of each half writes the keys (i = col % 16, mb = col / 16) of its half
+  {
+    const int mb = col >> 4, i = col & 15;
+    float v = 0.0f;
+#pragma unroll
+    for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+      for (int ii = 0; ii < 16; ++ii)
+        if (mm == mb && ii == i) v = acc[mm][ii];
+    const int key = k0 + 32 * mb + (i & 3) + 8 * (i >> 2) + 4 * half;
+    if (key < a.K) {
+      if (a.use_average) v = __fmul_rn(v, __fdiv_rn((float)(key + 1), (float)a.nq));   // :1196-1203
+      a.colsum[(int64_t)h * a.K + key] = v;
+    }
+  }
+}
+
+template <typename T, int HD>
+static int launch_prefill(const PfArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL((prefill_lse_kernel<T, HD>), dim3((a.nq + 255) / 256, a.Hq), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((prefill_colsum_kernel<T, HD>), dim3((a.K + 255) / 256, a.Hq), dim3(256), 0, s, a);
+  return check_launch("prefill_metric_fused");
+}
+
+}  // namespace kvc
+
+extern "C" size_t kvc_prefill_metric_fused_workspace_bytes(int32_t num_q_heads, int32_t q_block,
+                                                           int32_t num_keys) {
+  return ((size_t)num_q_heads * (size_t)num_keys + (size_t)num_q_heads * (size_t)q_block) * sizeof(float);
+}
+
+extern "C" int kvc_prefill_metric_fused(float* out_kh, const void* query, const void* key,
+                                        int32_t num_q_heads, int32_t num_k_heads, int32_t head_size,
+                                        int32_t q_block, int32_t num_keys, int32_t q_offset,
+                                        int32_t buffer_len, int64_t q_stride, int64_t k_stride,
+                                        float scale, int32_t dtype, int32_t use_l2,
+                                        int32_t use_average, int32_t use_maxpool, void* workspace,
+                                        size_t workspace_bytes, kvc_stream_t stream) {
+  using namespace kvc;
+  if (num_q_heads <= 0 || num_keys <= 0 || q_block <= 0) return KVC_OK;
+  if (num_k_heads < 1 || num_q_heads % num_k_heads != 0)
+    return fail_invalid("prefill_metric_fused: query heads must be a multiple of key heads");
+  if (dtype != 0 && dtype != 1) return fail_invalid("Unsupported data type of query");
+  if (workspace_bytes < kvc_prefill_metric_fused_workspace_bytes(num_q_heads, q_block, num_keys))
+    return fail_invalid("prefill_metric_fused: workspace too small");
+  if ((reinterpret_cast<uintptr_t>(query) & 15) || (reinterpret_cast<uintptr_t>(key) & 15) ||
+      (q_stride % 8) || (k_stride % 8))
+    return fail_invalid("prefill_metric_fused: query / key rows must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  PfArgs a;
+  a.q = query; a.k = key;
+  a.colsum = reinterpret_cast<float*>(workspace);
+  a.lse = a.colsum + (size_t)num_q_heads * num_keys;
+  a.q_stride = q_stride; a.k_stride = k_stride; a.scale = scale;
+  a.Hq = num_q_heads; a.Hk = num_k_heads; a.nq = q_block; a.K = num_keys;
+  a.q_offset = q_offset; a.buffer_len = buffer_len; a.use_l2 = use_l2; a.use_average = use_average;
+  int rc;
+  if (head_size == 128) rc = dtype == 0 ? launch_prefill<_Float16, 128>(a, s) : launch_prefill<__bf16, 128>(a, s);
+  else if (head_size == 64) rc = dtype == 0 ? launch_prefill<_Float16, 64>(a, s) : launch_prefill<__bf16, 64>(a, s);
+  else return fail_invalid("Unsupported head size: " + std::to_string(head_size));
+  if (rc != KVC_OK) return rc;
+  return launch_epilogue_pool(out_kh, a.colsum, num_q_heads, num_keys, use_maxpool, s);
+}

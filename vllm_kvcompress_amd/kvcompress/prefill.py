@@ -71,3 +71,46 @@ def naive_kvc_attention(query: torch.Tensor, key: torch.Tensor, value, prompt_le
                                     use_average, use_maxpool)
         start += prompt_len
     return None, out
+
+
+def fused_kvc_attention(query: torch.Tensor, key: torch.Tensor, value, prompt_lens: List[int],
+                        scale: float, kv_metric_buffer_len: torch.Tensor, n_observed: int = 32,
+                        max_observed_block_size: int = 4096, use_l2: bool = True,
+                        use_average: bool = False, use_maxpool: bool = True):
+    """Same contract and loop structure as the reference ``_naive_kvc_attention``
+    (flash_attn.py:1120-1164) -- returns ``(None, kv_metric_output [T, Hq] f32)`` -- but the
+    probabilities are never materialised: per (sequence, query block) two matrix-core passes
+    (row log-sum-exp, then masked column sums of P or P^2 recomputed from it) and the pool +
+    accumulate step run inside ``kvc_prefill_metric_fused``.
+    ``key`` may carry one head per query head (what the engine passes after repeating the KV
+    heads, flash_attn.py:988-991) or the un-repeated KV heads."""
+    lib = _lib.load()
+    if not (query.is_cuda and key.is_cuda):
+        raise RuntimeError("fused_kvc_attention: tensors must be on a HIP device")
+    dtypes = {torch.float16: 0, torch.bfloat16: 1}
+    if query.dtype not in dtypes or key.dtype != query.dtype:
+        raise RuntimeError(f"Unsupported data type: {query.dtype}")
+    T, Hq, hd = query.shape
+    Hk = key.shape[1]
+    if query.stride(2) != 1 or query.stride(1) != hd or key.stride(2) != 1 or key.stride(1) != hd:
+        raise RuntimeError("fused_kvc_attention: query / key must be contiguous in (head, dim)")
+    out = torch.zeros((key.shape[0], Hq), dtype=torch.float32, device=key.device)
+    buf = kv_metric_buffer_len.tolist()
+    esz = query.element_size()
+    start = 0
+    with torch.cuda.device(query.device):
+        for i, prompt_len in enumerate(prompt_lens):
+            end = start + prompt_len
+            start_trunc = end - min(prompt_len, n_observed)
+            for l in range(start_trunc, end, max_observed_block_size):
+                nq = min(l + max_observed_block_size, end) - l
+                ws_bytes = lib.kvc_prefill_metric_fused_workspace_bytes(Hq, nq, prompt_len)
+                ws = workspace(query.device, ws_bytes, "prefill_fused")
+                _lib.check(lib.kvc_prefill_metric_fused(
+                    out[start:end].data_ptr(), query.data_ptr() + l * query.stride(0) * esz,
+                    key.data_ptr() + start * key.stride(0) * esz, Hq, Hk, hd, nq, prompt_len,
+                    l - start, int(buf[i]), query.stride(0), key.stride(0), float(scale),
+                    dtypes[query.dtype], int(bool(use_l2)), int(bool(use_average)),
+                    int(bool(use_maxpool)), ws.data_ptr(), ws.numel(), _stream(query)))
+            start += prompt_len
+    return None, out
