@@ -190,25 +190,27 @@ int kvc_prefill_metric_epilogue(float* out_kh, const float* probs_hqk, int32_t n
                                 kvc_stream_t stream);
 size_t kvc_prefill_metric_epilogue_workspace_bytes(int32_t num_q_heads, int32_t num_keys);
 
-/* F4  fused prefill metric collector: the whole of _naive_kvc_masked_attention for one
- * sequence and one block of observed queries, without materialising the probabilities
- *   (vllm/attention/backends/flash_attn.py:1166-1211; loop over blocks :1143-1161)
- * out_kh [K, Hq] += maxpool7( sum over the block's query rows r with
- *                   k + buffer_len <= q_offset + r of P[r,k]^(2 if use_l2) [* (k+1)/q_block] )
- * P = softmax over keys k <= q_offset + r of scale * (q_r . k_k), logits rounded to the input
- * type first like the reference's einsum.  query: first row of the block, [q_block, Hq, hd];
- * key: first key of the sequence, [K, Hk, hd] (Hk = Hq or the un-repeated KV heads); strides
- * in elements between tokens; dtype 0 = fp16, 1 = bf16; head_size 64 or 128.
+/* F4  fused prefill metric collector: the whole of _naive_kvc_attention's inner loop for one
+ * sequence, without materialising the probabilities
+ *   (vllm/attention/backends/flash_attn.py:1143-1161 block loop, :1166-1211 per block)
+ * The last num_observed query rows of the sequence (first one at position q_offset) are
+ * processed in blocks of q_block rows; for every block
+ *   out_kh [K, Hq] += maxpool7( sum over the block's rows r with k + buffer_len <= pos(r)
+ *                               of P[r,k]^(2 if use_l2) [* (k+1)/rows_in_block] ),
+ * P = softmax over keys k <= pos(r) of scale * (q_r . k_k), logits rounded to the input type
+ * first like the reference's einsum.  query: first observed row, [num_observed, Hq, hd]; key:
+ * first key of the sequence, [K, Hk, hd] (Hk = Hq or the un-repeated KV heads); strides in
+ * elements between tokens; dtype 0 = fp16, 1 = bf16; head_size 64 or 128.
  * Floating point: agrees with the reference within the rounding of its fp16 logits. */
-size_t kvc_prefill_metric_fused_workspace_bytes(int32_t num_q_heads, int32_t q_block,
+size_t kvc_prefill_metric_fused_workspace_bytes(int32_t num_q_heads, int32_t num_observed,
                                                 int32_t num_keys);
 int kvc_prefill_metric_fused(float* out_kh, const void* query, const void* key,
                              int32_t num_q_heads, int32_t num_k_heads, int32_t head_size,
-                             int32_t q_block, int32_t num_keys, int32_t q_offset,
-                             int32_t buffer_len, int64_t q_stride, int64_t k_stride, float scale,
-                             int32_t dtype, int32_t use_l2, int32_t use_average,
-                             int32_t use_maxpool, void* workspace, size_t workspace_bytes,
-                             kvc_stream_t stream);
+                             int32_t num_observed, int32_t q_block, int32_t num_keys,
+                             int32_t q_offset, int32_t buffer_len, int64_t q_stride,
+                             int64_t k_stride, float scale, int32_t dtype, int32_t use_l2,
+                             int32_t use_average, int32_t use_maxpool, void* workspace,
+                             size_t workspace_bytes, kvc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * A7  kvcompress_reshape_and_cache  ("auto" cache dtype: byte-identical store)

@@ -95,7 +95,7 @@ SYMBOLS = {
                                              c_size_t, c_void_p]),
     "kvc_prefill_metric_fused_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "kvc_prefill_metric_fused": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
-                                           c_int32, c_int32, c_int32, c_int32, c_int64, c_int64,
+                                           c_int32, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64,
                                            c_float, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                            c_size_t, c_void_p]),
     "kvc_paged_attention_decode": (c_int32, [ctypes.POINTER(KvcAttentionParams), c_void_p]),

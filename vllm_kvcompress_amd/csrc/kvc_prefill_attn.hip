@@ -43,7 +43,8 @@ template <> struct Mma32<__bf16> {
 struct PfArgs {
   const void* q;        // first query row of the block, [nq, Hq, hd], token stride q_stride
   const void* k;        // first key of the sequence, [K, Hk, hd], token stride k_stride
-  float* lse;           // [Hq, nq]  (log2 domain)
+  float* lse;           // [Hq, lse_stride]  (log2 domain), entry [h, r] for query row r of `q`
+  int64_t lse_stride;
   float* colsum;        // [Hq, K]
   int64_t q_stride, k_stride;
   float scale;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void prefill_lse_kernel(PfArgs a) {
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
       const int r = r0 + 32 * nb + col;
-      if (r < a.nq) a.lse[(int64_t)h * a.nq + r] = m[nb] + __builtin_amdgcn_logf(l[nb]);
+      if (r < a.nq) a.lse[(int64_t)h * a.lse_stride + r] = m[nb] + __builtin_amdgcn_logf(l[nb]);
     }
   }
 }
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void prefill_colsum_kernel(PfArgs a) {
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
       const int r = r0 + 32 * nb + col;
-      const float ls = r < a.nq ? a.lse[(int64_t)h * a.nq + r] : 0.0f;
+      const float ls = r < a.nq ? a.lse[(int64_t)h * a.lse_stride + r] : 0.0f;
       const int pq = a.q_offset + r;
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
@@ -219,33 +220,49 @@ __global__ __launch_bounds__(256) void prefill_colsum_kernel(PfArgs a) {
   }
 }
 
+// pass 1 once for ALL observed rows (it does not depend on the block structure and one query
+// block alone cannot fill the chip), then per query block: pass 2 + pool/accumulate
 template <typename T, int HD>
-static int launch_prefill(const PfArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL((prefill_lse_kernel<T, HD>), dim3((a.nq + 255) / 256, a.Hq), dim3(256), 0, s, a);
-  hipLaunchKernelGGL((prefill_colsum_kernel<T, HD>), dim3((a.K + 255) / 256, a.Hq), dim3(256), 0, s, a);
+static int launch_prefill(PfArgs a, float* out_kh, int n_obs, int q_block, int use_maxpool, hipStream_t s) {
+  const T* q0 = reinterpret_cast<const T*>(a.q);
+  float* lse0 = a.lse;
+  const int off0 = a.q_offset;
+  a.nq = n_obs;
+  a.lse_stride = n_obs;
+  hipLaunchKernelGGL((prefill_lse_kernel<T, HD>), dim3((n_obs + 255) / 256, a.Hq), dim3(256), 0, s, a);
+  for (int l = 0; l < n_obs; l += q_block) {
+    a.q = q0 + (int64_t)l * a.q_stride;
+    a.lse = lse0 + l;
+    a.nq = n_obs - l < q_block ? n_obs - l : q_block;
+    a.q_offset = off0 + l;
+    hipLaunchKernelGGL((prefill_colsum_kernel<T, HD>), dim3((a.K + 255) / 256, a.Hq), dim3(256), 0, s, a);
+    const int rc = launch_epilogue_pool(out_kh, a.colsum, a.Hq, a.K, use_maxpool, s);
+    if (rc != KVC_OK) return rc;
+  }
   return check_launch("prefill_metric_fused");
 }
 
 }  // namespace kvc
 
-extern "C" size_t kvc_prefill_metric_fused_workspace_bytes(int32_t num_q_heads, int32_t q_block,
+extern "C" size_t kvc_prefill_metric_fused_workspace_bytes(int32_t num_q_heads, int32_t num_observed,
                                                            int32_t num_keys) {
-  return ((size_t)num_q_heads * (size_t)num_keys + (size_t)num_q_heads * (size_t)q_block) * sizeof(float);
+  return ((size_t)num_q_heads * (size_t)num_keys + (size_t)num_q_heads * (size_t)num_observed) * sizeof(float);
 }
 
 extern "C" int kvc_prefill_metric_fused(float* out_kh, const void* query, const void* key,
                                         int32_t num_q_heads, int32_t num_k_heads, int32_t head_size,
-                                        int32_t q_block, int32_t num_keys, int32_t q_offset,
-                                        int32_t buffer_len, int64_t q_stride, int64_t k_stride,
-                                        float scale, int32_t dtype, int32_t use_l2,
+                                        int32_t num_observed, int32_t q_block, int32_t num_keys,
+                                        int32_t q_offset, int32_t buffer_len, int64_t q_stride,
+                                        int64_t k_stride, float scale, int32_t dtype, int32_t use_l2,
                                         int32_t use_average, int32_t use_maxpool, void* workspace,
                                         size_t workspace_bytes, kvc_stream_t stream) {
   using namespace kvc;
-  if (num_q_heads <= 0 || num_keys <= 0 || q_block <= 0) return KVC_OK;
+  if (num_q_heads <= 0 || num_keys <= 0 || num_observed <= 0) return KVC_OK;
+  if (q_block <= 0) return fail_invalid("prefill_metric_fused: q_block must be positive");
   if (num_k_heads < 1 || num_q_heads % num_k_heads != 0)
     return fail_invalid("prefill_metric_fused: query heads must be a multiple of key heads");
   if (dtype != 0 && dtype != 1) return fail_invalid("Unsupported data type of query");
-  if (workspace_bytes < kvc_prefill_metric_fused_workspace_bytes(num_q_heads, q_block, num_keys))
+  if (workspace_bytes < kvc_prefill_metric_fused_workspace_bytes(num_q_heads, num_observed, num_keys))
     return fail_invalid("prefill_metric_fused: workspace too small");
   if ((reinterpret_cast<uintptr_t>(query) & 15) || (reinterpret_cast<uintptr_t>(key) & 15) ||
       (q_stride % 8) || (k_stride % 8))
@@ -255,13 +272,15 @@ extern "C" int kvc_prefill_metric_fused(float* out_kh, const void* query, const 
   a.q = query; a.k = key;
   a.colsum = reinterpret_cast<float*>(workspace);
   a.lse = a.colsum + (size_t)num_q_heads * num_keys;
+  a.lse_stride = num_observed;
   a.q_stride = q_stride; a.k_stride = k_stride; a.scale = scale;
-  a.Hq = num_q_heads; a.Hk = num_k_heads; a.nq = q_block; a.K = num_keys;
+  a.Hq = num_q_heads; a.Hk = num_k_heads; a.nq = num_observed; a.K = num_keys;
   a.q_offset = q_offset; a.buffer_len = buffer_len; a.use_l2 = use_l2; a.use_average = use_average;
-  int rc;
-  if (head_size == 128) rc = dtype == 0 ? launch_prefill<_Float16, 128>(a, s) : launch_prefill<__bf16, 128>(a, s);
-  else if (head_size == 64) rc = dtype == 0 ? launch_prefill<_Float16, 64>(a, s) : launch_prefill<__bf16, 64>(a, s);
-  else return fail_invalid("Unsupported head size: " + std::to_string(head_size));
-  if (rc != KVC_OK) return rc;
-  return launch_epilogue_pool(out_kh, a.colsum, num_q_heads, num_keys, use_maxpool, s);
+  if (head_size == 128)
+    return dtype == 0 ? launch_prefill<_Float16, 128>(a, out_kh, num_observed, q_block, use_maxpool, s)
+                      : launch_prefill<__bf16, 128>(a, out_kh, num_observed, q_block, use_maxpool, s);
+  if (head_size == 64)
+    return dtype == 0 ? launch_prefill<_Float16, 64>(a, out_kh, num_observed, q_block, use_maxpool, s)
+                      : launch_prefill<__bf16, 64>(a, out_kh, num_observed, q_block, use_maxpool, s);
+  return fail_invalid("Unsupported head size: " + std::to_string(head_size));
 }

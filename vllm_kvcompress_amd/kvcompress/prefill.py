@@ -101,16 +101,16 @@ def fused_kvc_attention(query: torch.Tensor, key: torch.Tensor, value, prompt_le
     with torch.cuda.device(query.device):
         for i, prompt_len in enumerate(prompt_lens):
             end = start + prompt_len
-            start_trunc = end - min(prompt_len, n_observed)
-            for l in range(start_trunc, end, max_observed_block_size):
-                nq = min(l + max_observed_block_size, end) - l
-                ws_bytes = lib.kvc_prefill_metric_fused_workspace_bytes(Hq, nq, prompt_len)
-                ws = workspace(query.device, ws_bytes, "prefill_fused")
-                _lib.check(lib.kvc_prefill_metric_fused(
-                    out[start:end].data_ptr(), query.data_ptr() + l * query.stride(0) * esz,
-                    key.data_ptr() + start * key.stride(0) * esz, Hq, Hk, hd, nq, prompt_len,
-                    l - start, int(buf[i]), query.stride(0), key.stride(0), float(scale),
-                    dtypes[query.dtype], int(bool(use_l2)), int(bool(use_average)),
-                    int(bool(use_maxpool)), ws.data_ptr(), ws.numel(), _stream(query)))
+            n_obs = min(prompt_len, n_observed)
+            first = end - n_obs
+            ws_bytes = lib.kvc_prefill_metric_fused_workspace_bytes(Hq, n_obs, prompt_len)
+            ws = workspace(query.device, ws_bytes, "prefill_fused")
+            _lib.check(lib.kvc_prefill_metric_fused(
+                out[start:end].data_ptr(), query.data_ptr() + first * query.stride(0) * esz,
+                key.data_ptr() + start * key.stride(0) * esz, Hq, Hk, hd, n_obs,
+                int(max_observed_block_size), prompt_len, first - start, int(buf[i]),
+                query.stride(0), key.stride(0), float(scale), dtypes[query.dtype],
+                int(bool(use_l2)), int(bool(use_average)), int(bool(use_maxpool)), ws.data_ptr(),
+                ws.numel(), _stream(query)))
             start += prompt_len
     return None, out
