@@ -18,6 +18,7 @@
 #include "../../include/kvc_mi355x.h"
 
 #include <math.h>
+#include <type_traits>
 
 namespace kvc {
 
@@ -73,9 +74,27 @@ __device__ __forceinline__ void load_rows(typename Mma32<T>::V8 (&frag)[2][HD / 
   }
 }
 
-// pass 1: lse[h, r] = log2 sum_k 2^(t[r,k]) over keys k <= q_offset + r, t = logit * log2(e)
+// 32 streamed rows x HD: frag[s] holds, for row (row0 + lane % 32), dims 16 s + 8 (lane / 32) .. + 7
 template <typename T, int HD>
-__global__ __launch_bounds__(256) void prefill_lse_kernel(PfArgs a) {
+__device__ __forceinline__ void load_rows32(typename Mma32<T>::V8 (&frag)[HD / 16], const T* base,
+                                            int64_t stride, int row0, int nrows, int lane) {
+  using V8 = typename Mma32<T>::V8;
+  const int r = row0 + (lane & 31);
+  const bool ok = r < nrows;
+  const T* p = base + (int64_t)(ok ? r : 0) * stride + 8 * (lane >> 5);
+#pragma unroll
+  for (int s = 0; s < HD / 16; ++s) {
+    pu32x4 raw = {0u, 0u, 0u, 0u};
+    if (ok) raw = *reinterpret_cast<const pu32x4*>(p + 16 * s);
+    frag[s] = __builtin_bit_cast(V8, raw);
+  }
+}
+
+// pass 1: lse[h, r] = log2 sum_k 2^(t[r,k]) over keys k <= q_offset + r, t = logit * log2(e).
+// The wave keeps its 64 queries in registers and streams 32 keys per step, the next step's
+// keys already in flight (double buffer, order pinned with sched_barrier).
+template <typename T, int HD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void prefill_lse_kernel(PfArgs a) {
   using M = Mma32<T>;
   using V8 = typename M::V8;
   constexpr int KS = HD / 16;
@@ -92,46 +111,49 @@ __global__ __launch_bounds__(256) void prefill_lse_kernel(PfArgs a) {
   const int col = lane & 31, half = lane >> 5;
   const int pq_last = a.q_offset + min(a.nq, r0 + 64) - 1;  // last causal key of the wave
   const int kend = min(a.K, pq_last + 1);
-  for (int k0 = 0; k0 < kend; k0 += 64) {
-    V8 ak[2][KS];
-    load_rows<T, HD>(ak, kb, a.k_stride, k0, a.K, lane);
-    const bool diag = k0 + 63 > a.q_offset + r0 || k0 + 64 > a.K;   // wave-uniform: needs masking
+  V8 ak0[KS], ak1[KS];                                      // two named buffers: no dynamic indexing
+  load_rows32<T, HD>(ak0, kb, a.k_stride, 0, a.K, lane);
+  auto step = [&](int k0, V8 (&cur)[KS], V8 (&nxt)[KS]) {
+    if (k0 + 32 < kend) load_rows32<T, HD>(nxt, kb, a.k_stride, k0 + 32, a.K, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    const bool diag = k0 + 31 > a.q_offset + r0 || k0 + 32 > a.K;   // wave-uniform: needs masking
+    // two copies of the body so that the mask arithmetic exists only on the diagonal tiles
+    auto body = [&](auto diag_tag) {
+      constexpr bool DIAG = decltype(diag_tag)::value;
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      f32x16 c[2];
+      for (int nb = 0; nb < 2; ++nb) {
+        f32x16 c = f32x16{0.f};
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-        c[mb] = f32x16{0.f};
-#pragma unroll
-        for (int s = 0; s < KS; ++s) c[mb] = M::mma(ak[mb][s], bq[nb][s], c[mb]);
-      }
-      const int pq = a.q_offset + r0 + 32 * nb + col;      // this lane's query position
-      float tmax = -INFINITY;
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
+        for (int s = 0; s < KS; ++s) c = M::mma(cur[s], bq[nb][s], c);
+        const int pq = a.q_offset + r0 + 32 * nb + col;    // this lane's query position
+        float tmax = -INFINITY;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          float t = (float)(T)c[mb][i] * sc;                // logits are rounded to T (:1189)
-          if (diag) {
-            const int key = k0 + 32 * mb + (i & 3) + 8 * (i >> 2) + 4 * half;
+          float t = (float)(T)c[i] * sc;                    // logits are rounded to T (:1189)
+          if constexpr (DIAG) {
+            const int key = k0 + (i & 3) + 8 * (i >> 2) + 4 * half;
             if (key > pq || key >= a.K) t = -INFINITY;
           }
-          c[mb][i] = t;
+          c[i] = t;
           tmax = fmaxf(tmax, t);
         }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float mn = fmaxf(m[nb], tmax);
-      float sum = 0.0f;
-      if (mn != -INFINITY) {
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mn = fmaxf(m[nb], tmax);
+        if (mn != -INFINITY) {
+          float sum = 0.0f;
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) sum += __builtin_amdgcn_exp2f(c[mb][i] - mn);
-        sum += __shfl_xor(sum, 32, 64);
-        l[nb] = l[nb] * __builtin_amdgcn_exp2f(m[nb] - mn) + sum;
-        m[nb] = mn;
+          for (int i = 0; i < 16; ++i) sum += __builtin_amdgcn_exp2f(c[i] - mn);
+          sum += __shfl_xor(sum, 32, 64);
+          l[nb] = l[nb] * __builtin_amdgcn_exp2f(m[nb] - mn) + sum;
+          m[nb] = mn;
+        }
       }
-    }
+    };
+    if (diag) body(std::true_type{}); else body(std::false_type{});
+  };
+  for (int k0 = 0; k0 < kend; k0 += 64) {
+    step(k0, ak0, ak1);
+    if (k0 + 32 < kend) step(k0 + 32, ak1, ak0);
   }
   if (half == 0) {
 #pragma unroll
@@ -143,9 +165,10 @@ __global__ __launch_bounds__(256) void prefill_lse_kernel(PfArgs a) {
 }
 
 // pass 2: colsum[h, k] = sum over the block's query rows r with k + buffer_len <= q_offset + r
-// of P[r, k] (or its square), P = 2^(t - lse)
-template <typename T, int HD>
-__global__ __launch_bounds__(256) void prefill_colsum_kernel(PfArgs a) {
+// of P[r, k] (or its square), P = 2^(t - lse).  The wave keeps its 64 keys in registers and
+// streams 32 queries per step (double buffered).
+template <typename T, int HD, bool L2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void prefill_colsum_kernel(PfArgs a) {
   using M = Mma32<T>;
   using V8 = typename M::V8;
   constexpr int KS = HD / 16;
@@ -164,34 +187,42 @@ __global__ __launch_bounds__(256) void prefill_colsum_kernel(PfArgs a) {
   acc[1] = f32x16{0.f};
   // first query row that can see key k0 through the metric window
   int rs = k0 + a.buffer_len - a.q_offset;
-  rs = rs < 0 ? 0 : rs;
-  for (int r0 = rs / 64 * 64; r0 < a.nq; r0 += 64) {
-    V8 bq[2][KS];
-    load_rows<T, HD>(bq, qb, a.q_stride, r0, a.nq, lane);
+  rs = rs < 0 ? 0 : rs / 32 * 32;
+  const float* lse_h = a.lse + (int64_t)h * a.lse_stride;
+  V8 bq0[KS], bq1[KS];                                      // two named buffers: no dynamic indexing
+  if (rs < a.nq) load_rows32<T, HD>(bq0, qb, a.q_stride, rs, a.nq, lane);
+  auto step = [&](int r0, V8 (&cur)[KS], V8 (&nxt)[KS]) {
+    if (r0 + 32 < a.nq) load_rows32<T, HD>(nxt, qb, a.q_stride, r0 + 32, a.nq, lane);
+    const int r = r0 + col;
+    const float ls = r < a.nq ? lse_h[r] : 0.0f;
+    __builtin_amdgcn_sched_barrier(0);
     // every (key, query) pair of the tile inside the window and inside the block?
-    const bool edge = k0 + 63 + a.buffer_len > a.q_offset + r0 || r0 + 64 > a.nq || k0 + 64 > a.K;
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      const int r = r0 + 32 * nb + col;
-      const float ls = r < a.nq ? a.lse[(int64_t)h * a.lse_stride + r] : 0.0f;
-      const int pq = a.q_offset + r;
+    const bool edge = k0 + 63 + a.buffer_len > a.q_offset + r0 || r0 + 32 > a.nq || k0 + 64 > a.K;
+    const int pq = a.q_offset + r;
+    auto body = [&](auto edge_tag) {
+      constexpr bool EDGE = decltype(edge_tag)::value;
 #pragma unroll
       for (int mb = 0; mb < 2; ++mb) {
         f32x16 c = f32x16{0.f};
 #pragma unroll
-        for (int s = 0; s < KS; ++s) c = M::mma(ak[mb][s], bq[nb][s], c);
+        for (int s = 0; s < KS; ++s) c = M::mma(ak[mb][s], cur[s], c);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          float p = __builtin_amdgcn_exp2f((float)(T)c[i] * sc - ls);
-          if (a.use_l2) p *= p;
-          if (edge) {
+          float p = __builtin_amdgcn_exp2f(__builtin_fmaf((float)(T)c[i], sc, -ls));
+          if constexpr (EDGE) {
             const int key = k0 + 32 * mb + (i & 3) + 8 * (i >> 2) + 4 * half;
             if (key + a.buffer_len > pq || r >= a.nq || key >= a.K) p = 0.0f;
           }
-          acc[mb][i] += p;
+          if constexpr (L2) acc[mb][i] = __builtin_fmaf(p, p, acc[mb][i]);
+          else acc[mb][i] += p;
         }
       }
-    }
+    };
+    if (edge) body(std::true_type{}); else body(std::false_type{});
+  };
+  for (int r0 = rs; r0 < a.nq; r0 += 64) {
+    step(r0, bq0, bq1);
+    if (r0 + 32 < a.nq) step(r0 + 32, bq1, bq0);
   }
   // sum over the 32 query columns held by the lanes of each half
 #pragma unroll
@@ -235,7 +266,10 @@ static int launch_prefill(PfArgs a, float* out_kh, int n_obs, int q_block, int u
     a.lse = lse0 + l;
     a.nq = n_obs - l < q_block ? n_obs - l : q_block;
     a.q_offset = off0 + l;
-    hipLaunchKernelGGL((prefill_colsum_kernel<T, HD>), dim3((a.K + 255) / 256, a.Hq), dim3(256), 0, s, a);
+    if (a.use_l2)
+      hipLaunchKernelGGL((prefill_colsum_kernel<T, HD, true>), dim3((a.K + 255) / 256, a.Hq), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((prefill_colsum_kernel<T, HD, false>), dim3((a.K + 255) / 256, a.Hq), dim3(256), 0, s, a);
     const int rc = launch_epilogue_pool(out_kh, a.colsum, a.Hq, a.K, use_maxpool, s);
     if (rc != KVC_OK) return rc;
   }
