@@ -25,9 +25,6 @@
 #include <math.h>
 #include <type_traits>
 
-#ifndef KVC_ATT_DBG
-#define KVC_ATT_DBG 0
-#endif
 #ifndef KVC_WHOLE_ATTR
 #define KVC_WHOLE_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
@@ -175,7 +172,9 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
   const int ngroups = (qpk + ATT_NQ - 1) / ATT_NQ;
   const int seq = blockIdx.z, hk = blockIdx.y / ngroups, qg = blockIdx.y % ngroups;
   const int part = blockIdx.x;
-  const int ctx = a.context_lens[seq * a.num_kv_heads + hk];
+  // a context longer than max_context_len (a caller bug) is truncated instead of overrunning
+  // the buffers that were sized from it
+  const int ctx = min(a.context_lens[seq * a.num_kv_heads + hk], a.max_ctx);
   if (part * ATT_PART >= ctx) return;
   const int nparts = (ctx + ATT_PART - 1) / ATT_PART;
   const int q0 = qg * ATT_NQ;
@@ -213,11 +212,7 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
     mpos[k] = 0x7FFFFFFF;
     if (a.record && tok < ctx) {
       mslot[k] = (int64_t)bt[tok / BS] * BS + (tok % BS);
-#if KVC_ATT_DBG == 2
-      mpos[k] = 0;
-#else
       mpos[k] = a.kv_position[mslot[k]];
-#endif
     }
   }
 
@@ -403,7 +398,9 @@ __global__ __launch_bounds__(256) KVC_WHOLE_ATTR void paged_attention_decode_who
   const int qpk = a.num_heads / a.num_kv_heads;
   const int ngroups = (qpk + ATT_NQ - 1) / ATT_NQ;
   const int seq = blockIdx.y, hk = blockIdx.x / ngroups, qg = blockIdx.x % ngroups;
-  const int ctx = a.context_lens[seq * a.num_kv_heads + hk];
+  // a context longer than max_context_len (a caller bug) is truncated instead of overrunning
+  // the buffers that were sized from it
+  const int ctx = min(a.context_lens[seq * a.num_kv_heads + hk], a.max_ctx);
   if (ctx <= 0) return;
   const int q0 = qg * ATT_NQ;
   const int nq = min(ATT_NQ, qpk - q0);
@@ -622,7 +619,9 @@ __global__ __launch_bounds__(256) void paged_attention_reduce_kernel(AttnArgs a)
   const int head = blockIdx.x, seq = blockIdx.y;
   const int qpk = a.num_heads / a.num_kv_heads;
   const int hk = head / qpk, qoff = head % qpk;
-  const int ctx = a.context_lens[seq * a.num_kv_heads + hk];
+  // a context longer than max_context_len (a caller bug) is truncated instead of overrunning
+  // the buffers that were sized from it
+  const int ctx = min(a.context_lens[seq * a.num_kv_heads + hk], a.max_ctx);
   const int nparts = (ctx + ATT_PART - 1) / ATT_PART;
   if (nparts <= 1) return;                                 // finished by the first kernel
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -665,7 +664,9 @@ template <int BS>
 __global__ __launch_bounds__(256) void paged_attention_metric_rescale_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float fac[];     // [qpk][2]
   const int chunk = blockIdx.x, hk = blockIdx.y, seq = blockIdx.z;
-  const int ctx = a.context_lens[seq * a.num_kv_heads + hk];
+  // a context longer than max_context_len (a caller bug) is truncated instead of overrunning
+  // the buffers that were sized from it
+  const int ctx = min(a.context_lens[seq * a.num_kv_heads + hk], a.max_ctx);
   const int nparts = (ctx + ATT_PART - 1) / ATT_PART;
   if (nparts <= 1 || chunk * ATT_RS_TOK >= ctx) return;
   const int qpk = a.num_heads / a.num_kv_heads;
@@ -708,11 +709,7 @@ __global__ __launch_bounds__(256) void paged_attention_metric_rescale_kernel(Att
     for (int k = 0; k < K; ++k) {
       posv[k] = ok[k] ? a.kv_position[slot[k]] : 0x7FFFFFFF;
       t[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-#if KVC_ATT_DBG == 5
-      if (ok[k]) t[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.tmp_kv_metric_out + slot[k] * 4));
-#else
       if (ok[k]) t[k] = *reinterpret_cast<const f32x4*>(a.tmp_kv_metric_out + slot[k] * 4);
-#endif
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -720,11 +717,7 @@ __global__ __launch_bounds__(256) void paged_attention_metric_rescale_kernel(Att
       const int pj = (chunk * ATT_RS_TOK + k * 256 + tid) / ATT_PART - p0;
       f32x4 v = t[k];
       v[0] *= fac[0 + pj]; v[1] *= fac[2 + pj]; v[2] *= fac[4 + pj]; v[3] *= fac[6 + pj];
-#if KVC_ATT_DBG == 6
-      __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.kv_metric_out + slot[k] * 4));
-#else
       *reinterpret_cast<f32x4*>(a.kv_metric_out + slot[k] * 4) = v;
-#endif
     }
   } else {
     for (int k = 0; k < K; ++k) {
