@@ -506,3 +506,42 @@ def paged_attention_decode(out, kv_metric_out, query, key_cache, value_cache, nu
                 if record_kv_metrics:
                     flat = kv_metric_out.reshape(-1, qpk)
                     flat[phys[rec], qo] = p[rec]
+
+
+def naive_kvc_attention(query, key, prompt_lens, scale, kv_metric_buffer_len, n_observed=32,
+                        max_observed_block_size=4096, use_l2=True, use_average=False,
+                        use_maxpool=True, logit_round="f16"):
+    """The whole of ``_naive_kvc_attention`` + ``_naive_kvc_masked_attention``
+    (vllm/attention/backends/flash_attn.py:1120-1211) in NumPy: ``query`` / ``key``
+    [T, Hq, hd] as float32 arrays holding the fp16 / bf16 input values.  The reference's
+    einsum returns the input type, so the logits are rounded to it (``logit_round``: "f16",
+    "bf16" or None) before ``scale *`` and the fp32 softmax (:1189); masked logits get the
+    type's most negative finite value added, which the softmax turns into exact zeros.
+    Returns kv_metric_output [T, Hq] float32."""
+    T, Hq, hd = query.shape
+    out = np.zeros((T, Hq), np.float32)
+    fmin = np.float32(-65504.0) if logit_round != "bf16" else np.float32(-3.3895313892515355e38)
+    start = 0
+    for i, plen in enumerate(int(x) for x in prompt_lens):
+        end = start + plen
+        first = end - min(plen, int(n_observed))
+        kk = key[start:end].astype(np.float32)
+        for l in range(first, end, int(max_observed_block_size)):
+            qq = query[l:min(l + int(max_observed_block_size), end)].astype(np.float32)
+            nq = qq.shape[0]
+            q_off = l - start
+            w = np.einsum("qhd,khd->hqk", qq, kk, dtype=np.float32)
+            if logit_round == "f16":
+                w = w.astype(np.float16).astype(np.float32)
+            elif logit_round == "bf16":
+                w = round_to_bf16(w)
+            w = (np.float32(scale) * w).astype(np.float32)
+            masked = (np.arange(plen)[None, :] - np.arange(nq)[:, None]) > q_off   # triu(q_off + 1)
+            w = w + np.where(masked, fmin, np.float32(0.0))[None].astype(np.float32)
+            w = w - w.max(axis=-1, keepdims=True)
+            e = np.exp(w, dtype=np.float32)
+            probs = (e / e.sum(axis=-1, keepdims=True, dtype=np.float32)).astype(np.float32)
+            prefill_metric_epilogue(out[start:end], probs, q_off, int(kv_metric_buffer_len[i]),
+                                    use_l2, use_average, use_maxpool)
+        start = end
+    return out

@@ -78,31 +78,17 @@ def oracle_pipeline(st: synth.PagedState, evicted_blocks, k_cache=None, v_cache=
 
 
 def reference_prefill_metrics_numpy(g):
-    """float32 restatement of the reference loop (flash_attn.py:1122-1211) around the
-    oracle's epilogue, on a golden case of oracle/gen_golden_aggregate.py."""
-    import torch
-    tdt = torch.bfloat16 if ("dtype" in g and str(g["dtype"]) == "bf16") else torch.float16
-    q = torch.from_numpy(g["q"].view(np.int16).copy()).view(tdt)
-    k = torch.from_numpy(g["k"].view(np.int16).copy()).view(tdt)
-    T, Hq, hd = q.shape
-    scale = hd ** -0.5
-    out = np.zeros((T, Hq), dtype=np.float32)
-    start = 0
-    for i, plen in enumerate(int(x) for x in g["prompt_lens"]):
-        end = start + plen
-        st = end - min(plen, int(g["n_observed"]))
-        blk = int(g["block"])
-        for l in range(st, end, blk):
-            qq = q[l:min(l + blk, end)]
-            nq = qq.shape[0]
-            q_off = l - start
-            # einsum in the query dtype, widened, THEN scaled in float32   (flash_attn.py:1186)
-            w = scale * torch.einsum("qhd,khd->hqk", qq, k[start:end]).float()
-            mask = torch.triu(torch.ones(nq, plen, dtype=tdt), diagonal=q_off + 1)
-            w = w + (mask * torch.finfo(tdt).min).float()
-            probs = torch.softmax(w, dim=-1).numpy()
-            orc.prefill_metric_epilogue(out[start:end], probs, q_off, int(g["buffer_len"][i]),
-                                        bool(int(g["use_l2"])), bool(int(g["use_average"])),
-                                        bool(int(g["use_maxpool"])))
-        start = end
-    return out
+    """the oracle's NumPy restatement of the reference loop (flash_attn.py:1120-1211) on a
+    golden case of oracle/gen_golden_aggregate.py"""
+    bf16 = "dtype" in g and str(g["dtype"]) == "bf16"
+    if bf16:
+        conv = lambda b: (b.view(np.uint16).astype(np.uint32) << np.uint32(16)).view(np.float32)
+    else:
+        conv = lambda b: b.view(np.float16).astype(np.float32)
+    q, k = conv(g["q"]), conv(g["k"])
+    hd = q.shape[2]
+    return orc.naive_kvc_attention(
+        q, k, g["prompt_lens"], hd ** -0.5, g["buffer_len"], n_observed=int(g["n_observed"]),
+        max_observed_block_size=int(g["block"]), use_l2=bool(int(g["use_l2"])),
+        use_average=bool(int(g["use_average"])), use_maxpool=bool(int(g["use_maxpool"])),
+        logit_round="bf16" if bf16 else "f16")

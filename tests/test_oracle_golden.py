@@ -187,11 +187,16 @@ def test_prefill_metric_epilogue_matches_reference(case):
 @pytest.mark.parametrize("case", range(5))
 def test_prefill_metric_oracle_on_fused_collector_cases(case):
     """the same restatement on the MFMA-sized cases (hd 64 / 128, fp16 / bf16) that pin the
-    fused collector (F4)"""
+    fused collector (F4).  The reference rounds its logits to fp16 (einsum output type); with
+    64..128-term dot products a handful of logits sit on a rounding boundary and land on
+    either side depending on the GEMM's summation order (NumPy here, torch-CPU there), which
+    moves a few of the ~1000 outputs by up to 1e-4 relative: tolerance 5e-4."""
     from tests.helpers import reference_prefill_metrics_numpy
     g = load_golden(f"agg_prefill_fused_{case}")
     got = reference_prefill_metrics_numpy(g)
-    np.testing.assert_allclose(got, g["ref_kv_metric_output"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(got, g["ref_kv_metric_output"], rtol=5e-4, atol=1e-7)
+    err = np.abs(got - g["ref_kv_metric_output"]) / (np.abs(g["ref_kv_metric_output"]) + 1e-7)
+    assert (err > 1e-5).mean() < 0.02
 
 
 def test_host_policy_matches_reference():
