@@ -74,34 +74,55 @@ __device__ __forceinline__ void load_rows(typename Mma32<T>::V8 (&frag)[2][HD / 
   }
 }
 
-// 32 streamed rows x HD: frag[s] holds, for row (row0 + lane % 32), dims 16 s + 8 (lane / 32) .. + 7
+// The streamed operand: 32 rows x HD per step, shared by the four waves of a workgroup.
+// Reading it straight from global memory costs 64 different cache lines per wave load
+// instruction (every lane another token row) and makes the kernel L1-line-rate bound
+// (measured: 2.3x off the VALU bound).  So the workgroup fetches the tile once, coalesced
+// (16 consecutive lanes = one 256-byte row), and parks it in LDS in operand order:
+// 16-byte unit (p, row) at index p * 33 + row, p = dim / 8 -- the pad makes the transposing
+// write 2-way instead of 16-way conflicted, the fragment reads are conflict free.
 template <typename T, int HD>
-__device__ __forceinline__ void load_rows32(typename Mma32<T>::V8 (&frag)[HD / 16], const T* base,
-                                            int64_t stride, int row0, int nrows, int lane) {
-  using V8 = typename Mma32<T>::V8;
-  const int r = row0 + (lane & 31);
-  const bool ok = r < nrows;
-  const T* p = base + (int64_t)(ok ? r : 0) * stride + 8 * (lane >> 5);
+struct StreamTile {
+  static constexpr int PP = HD / 8;                 // 16-byte pieces per row
+  static constexpr int CH = 32 * PP / 256;          // chunks per thread
+  static constexpr int UNITS = PP * 33;
+  pu32x4 regs[CH];
+  __device__ __forceinline__ void fetch(const T* base, int64_t stride, int row0, int nrows, int tid) {
 #pragma unroll
-  for (int s = 0; s < HD / 16; ++s) {
-    pu32x4 raw = {0u, 0u, 0u, 0u};
-    if (ok) raw = *reinterpret_cast<const pu32x4*>(p + 16 * s);
-    frag[s] = __builtin_bit_cast(V8, raw);
+    for (int j = 0; j < CH; ++j) {
+      const int c = tid + 256 * j, row = c / PP, p = c % PP;
+      regs[j] = pu32x4{0u, 0u, 0u, 0u};
+      if (row0 + row < nrows)
+        regs[j] = *reinterpret_cast<const pu32x4*>(base + (int64_t)(row0 + row) * stride + 8 * p);
+    }
   }
-}
+  __device__ __forceinline__ void park(pu32x4* lds, int tid) const {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int c = tid + 256 * j, row = c / PP, p = c % PP;
+      lds[p * 33 + row] = regs[j];
+    }
+  }
+  // fragment of k-step s for lane (row = lane % 32, half = lane / 32): dims 16 s + 8 half ..
+  static __device__ __forceinline__ typename Mma32<T>::V8 frag(const pu32x4* lds, int s, int lane) {
+    return __builtin_bit_cast(typename Mma32<T>::V8, lds[(2 * s + (lane >> 5)) * 33 + (lane & 31)]);
+  }
+};
 
 // pass 1: lse[h, r] = log2 sum_k 2^(t[r,k]) over keys k <= q_offset + r, t = logit * log2(e).
-// The wave keeps its 64 queries in registers and streams 32 keys per step, the next step's
-// keys already in flight (double buffer, order pinned with sched_barrier).
+// A wave keeps its 64 queries in registers; the workgroup streams the keys through LDS.
 template <typename T, int HD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void prefill_lse_kernel(PfArgs a) {
   using M = Mma32<T>;
   using V8 = typename M::V8;
+  using ST = StreamTile<T, HD>;
   constexpr int KS = HD / 16;
+  __shared__ __attribute__((aligned(16))) pu32x4 tile[2][ST::UNITS];
   const int h = blockIdx.y, hk = h / (a.Hq / a.Hk);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int r0 = (blockIdx.x * 4 + w) * 64;                 // this wave's first query row
-  if (r0 >= a.nq) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int rwg = blockIdx.x * 256;                         // the workgroup's first query row
+  const int r0 = rwg + w * 64;                              // this wave's first query row
+  const bool active = r0 < a.nq;
   const T* qb = reinterpret_cast<const T*>(a.q) + (int64_t)h * HD;
   const T* kb = reinterpret_cast<const T*>(a.k) + (int64_t)hk * HD;
   V8 bq[2][KS];
@@ -109,53 +130,60 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const float sc = a.scale * LOG2E;
   float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.0f, 0.0f};
   const int col = lane & 31, half = lane >> 5;
-  const int pq_last = a.q_offset + min(a.nq, r0 + 64) - 1;  // last causal key of the wave
-  const int kend = min(a.K, pq_last + 1);
-  V8 ak0[KS], ak1[KS];                                      // two named buffers: no dynamic indexing
-  load_rows32<T, HD>(ak0, kb, a.k_stride, 0, a.K, lane);
-  auto step = [&](int k0, V8 (&cur)[KS], V8 (&nxt)[KS]) {
-    if (k0 + 32 < kend) load_rows32<T, HD>(nxt, kb, a.k_stride, k0 + 32, a.K, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    const bool diag = k0 + 31 > a.q_offset + r0 || k0 + 32 > a.K;   // wave-uniform: needs masking
-    // two copies of the body so that the mask arithmetic exists only on the diagonal tiles
-    auto body = [&](auto diag_tag) {
-      constexpr bool DIAG = decltype(diag_tag)::value;
+  const int kend = min(a.K, a.q_offset + min(a.nq, r0 + 64));          // this wave's causal limit
+  const int kend_wg = min(a.K, a.q_offset + min(a.nq, rwg + 256));      // the workgroup's
+  ST st;
+  st.fetch(kb, a.k_stride, 0, a.K, tid);
+  st.park(tile[0], tid);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < kend_wg; k0 += 32, buf ^= 1) {
+    const bool more = k0 + 32 < kend_wg;
+    if (more) st.fetch(kb, a.k_stride, k0 + 32, a.K, tid);
+    if (active && k0 < kend) {
+      const pu32x4* tl = tile[buf];
+      const bool diag = k0 + 31 > a.q_offset + r0 || k0 + 32 > a.K;   // wave-uniform: needs masking
+      // two copies of the body so that the mask arithmetic exists only on the diagonal tiles
+      auto body = [&](auto diag_tag) {
+        constexpr bool DIAG = decltype(diag_tag)::value;
+        V8 ak[KS];
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
-        f32x16 c = f32x16{0.f};
+        for (int s = 0; s < KS; ++s) ak[s] = ST::frag(tl, s, lane);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) c = M::mma(cur[s], bq[nb][s], c);
-        const int pq = a.q_offset + r0 + 32 * nb + col;    // this lane's query position
-        float tmax = -INFINITY;
+        for (int nb = 0; nb < 2; ++nb) {
+          f32x16 c = f32x16{0.f};
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          float t = (float)(T)c[i] * sc;                    // logits are rounded to T (:1189)
-          if constexpr (DIAG) {
-            const int key = k0 + (i & 3) + 8 * (i >> 2) + 4 * half;
-            if (key > pq || key >= a.K) t = -INFINITY;
+          for (int s = 0; s < KS; ++s) c = M::mma(ak[s], bq[nb][s], c);
+          const int pq = a.q_offset + r0 + 32 * nb + col;  // this lane's query position
+          float tmax = -INFINITY;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            float t = (float)(T)c[i] * sc;                  // logits are rounded to T (:1189)
+            if constexpr (DIAG) {
+              const int key = k0 + (i & 3) + 8 * (i >> 2) + 4 * half;
+              if (key > pq || key >= a.K) t = -INFINITY;
+            }
+            c[i] = t;
+            tmax = fmaxf(tmax, t);
           }
-          c[i] = t;
-          tmax = fmaxf(tmax, t);
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float mn = fmaxf(m[nb], tmax);
-        if (mn != -INFINITY) {
-          float sum = 0.0f;
+          tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+          const float mn = fmaxf(m[nb], tmax);
+          if (mn != -INFINITY) {
+            float sum = 0.0f;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) sum += __builtin_amdgcn_exp2f(c[i] - mn);
-          sum += __shfl_xor(sum, 32, 64);
-          l[nb] = l[nb] * __builtin_amdgcn_exp2f(m[nb] - mn) + sum;
-          m[nb] = mn;
+            for (int i = 0; i < 16; ++i) sum += __builtin_amdgcn_exp2f(c[i] - mn);
+            sum += __shfl_xor(sum, 32, 64);
+            l[nb] = l[nb] * __builtin_amdgcn_exp2f(m[nb] - mn) + sum;
+            m[nb] = mn;
+          }
         }
-      }
-    };
-    if (diag) body(std::true_type{}); else body(std::false_type{});
-  };
-  for (int k0 = 0; k0 < kend; k0 += 64) {
-    step(k0, ak0, ak1);
-    if (k0 + 32 < kend) step(k0 + 32, ak1, ak0);
+      };
+      if (diag) body(std::true_type{}); else body(std::false_type{});
+    }
+    if (more) st.park(tile[buf ^ 1], tid);
+    __syncthreads();
   }
-  if (half == 0) {
+  if (active && half == 0) {
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
       const int r = r0 + 32 * nb + col;
@@ -165,17 +193,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // pass 2: colsum[h, k] = sum over the block's query rows r with k + buffer_len <= q_offset + r
-// of P[r, k] (or its square), P = 2^(t - lse).  The wave keeps its 64 keys in registers and
-// streams 32 queries per step (double buffered).
+// of P[r, k] (or its square), P = 2^(t - lse).  A wave keeps its 64 keys in registers; the
+// workgroup streams the queries through LDS.
 template <typename T, int HD, bool L2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void prefill_colsum_kernel(PfArgs a) {
   using M = Mma32<T>;
   using V8 = typename M::V8;
+  using ST = StreamTile<T, HD>;
   constexpr int KS = HD / 16;
+  __shared__ __attribute__((aligned(16))) pu32x4 tile[2][ST::UNITS];
   const int h = blockIdx.y, hk = h / (a.Hq / a.Hk);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int k0 = (blockIdx.x * 4 + w) * 64;                 // this wave's first key
-  if (k0 >= a.K) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kwg = blockIdx.x * 256;                         // the workgroup's first key
+  const int k0 = kwg + w * 64;                              // this wave's first key
+  const bool active = k0 < a.K;
   const T* qb = reinterpret_cast<const T*>(a.q) + (int64_t)h * HD;
   const T* kb = reinterpret_cast<const T*>(a.k) + (int64_t)hk * HD;
   V8 ak[2][KS];
@@ -185,45 +216,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   f32x16 acc[2];
   acc[0] = f32x16{0.f};
   acc[1] = f32x16{0.f};
-  // first query row that can see key k0 through the metric window
-  int rs = k0 + a.buffer_len - a.q_offset;
-  rs = rs < 0 ? 0 : rs / 32 * 32;
+  // first query row that can see the first key of the wave / workgroup through the window
+  auto first_row = [&](int key) { const int r = key + a.buffer_len - a.q_offset; return r < 0 ? 0 : r / 32 * 32; };
+  const int rs = first_row(k0), rs_wg = first_row(kwg);
   const float* lse_h = a.lse + (int64_t)h * a.lse_stride;
-  V8 bq0[KS], bq1[KS];                                      // two named buffers: no dynamic indexing
-  if (rs < a.nq) load_rows32<T, HD>(bq0, qb, a.q_stride, rs, a.nq, lane);
-  auto step = [&](int r0, V8 (&cur)[KS], V8 (&nxt)[KS]) {
-    if (r0 + 32 < a.nq) load_rows32<T, HD>(nxt, qb, a.q_stride, r0 + 32, a.nq, lane);
-    const int r = r0 + col;
-    const float ls = r < a.nq ? lse_h[r] : 0.0f;
-    __builtin_amdgcn_sched_barrier(0);
-    // every (key, query) pair of the tile inside the window and inside the block?
-    const bool edge = k0 + 63 + a.buffer_len > a.q_offset + r0 || r0 + 32 > a.nq || k0 + 64 > a.K;
-    const int pq = a.q_offset + r;
-    auto body = [&](auto edge_tag) {
-      constexpr bool EDGE = decltype(edge_tag)::value;
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-        f32x16 c = f32x16{0.f};
-#pragma unroll
-        for (int s = 0; s < KS; ++s) c = M::mma(ak[mb][s], cur[s], c);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          float p = __builtin_amdgcn_exp2f(__builtin_fmaf((float)(T)c[i], sc, -ls));
-          if constexpr (EDGE) {
-            const int key = k0 + 32 * mb + (i & 3) + 8 * (i >> 2) + 4 * half;
-            if (key + a.buffer_len > pq || r >= a.nq || key >= a.K) p = 0.0f;
-          }
-          if constexpr (L2) acc[mb][i] = __builtin_fmaf(p, p, acc[mb][i]);
-          else acc[mb][i] += p;
-        }
-      }
-    };
-    if (edge) body(std::true_type{}); else body(std::false_type{});
-  };
-  for (int r0 = rs; r0 < a.nq; r0 += 64) {
-    step(r0, bq0, bq1);
-    if (r0 + 32 < a.nq) step(r0 + 32, bq1, bq0);
+  ST st;
+  if (rs_wg < a.nq) {
+    st.fetch(qb, a.q_stride, rs_wg, a.nq, tid);
+    st.park(tile[0], tid);
   }
+  __syncthreads();
+  int buf = 0;
+  for (int r0 = rs_wg; r0 < a.nq; r0 += 32, buf ^= 1) {
+    const bool more = r0 + 32 < a.nq;
+    if (more) st.fetch(qb, a.q_stride, r0 + 32, a.nq, tid);
+    if (active && r0 >= rs) {
+      const pu32x4* tl = tile[buf];
+      const int r = r0 + col;
+      const float ls = r < a.nq ? lse_h[r] : 0.0f;
+      // every (key, query) pair of the tile inside the window and inside the block?
+      const bool edge = k0 + 63 + a.buffer_len > a.q_offset + r0 || r0 + 32 > a.nq || k0 + 64 > a.K;
+      const int pq = a.q_offset + r;
+      auto body = [&](auto edge_tag) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        V8 bq[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) bq[s] = ST::frag(tl, s, lane);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          f32x16 c = f32x16{0.f};
+#pragma unroll
+          for (int s = 0; s < KS; ++s) c = M::mma(ak[mb][s], bq[s], c);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            float p = __builtin_amdgcn_exp2f(__builtin_fmaf((float)(T)c[i], sc, -ls));
+            if constexpr (EDGE) {
+              const int key = k0 + 32 * mb + (i & 3) + 8 * (i >> 2) + 4 * half;
+              if (key + a.buffer_len > pq || r >= a.nq || key >= a.K) p = 0.0f;
+            }
+            if constexpr (L2) acc[mb][i] = __builtin_fmaf(p, p, acc[mb][i]);
+            else acc[mb][i] += p;
+          }
+        }
+      };
+      if (edge) body(std::true_type{}); else body(std::false_type{});
+    }
+    if (more) st.park(tile[buf ^ 1], tid);
+    __syncthreads();
+  }
+  if (!active) return;
   // sum over the 32 query columns held by the lanes of each half
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb)
