@@ -282,6 +282,11 @@ int kvc_free_compressed_blocks(int32_t* context_lens, int32_t* seq_index_by_bloc
  * Contexts longer than 512 tokens are split into 512-token partitions (the reference's
  * v2); the four partition buffers have the v2 shapes and may be NULL when
  * max_context_len <= 512.
+ * Extension (not in the reference, kvcompress/README.md:32,49 lists it as a to-do): with
+ * fused_metrics != NULL nothing is written to kv_metric_out; instead, for every key inside the
+ * metric window, fused_metrics[slot] += sum over the KV head's query heads of p^2 (or p) --
+ * exactly what CompressionMetrics.aggregate_decode (metrics.py:429-439) would add from the
+ * stored weights, bit for bit, without the [NB, bs, qpk] round trip.  Needs qpk <= 16.
  * dtype: 0 = fp16, 1 = bf16 (query, output and an "auto" cache).  kv_cache_dtype: 0 = "auto"
  * (cache elements of `dtype`, K vectors of x = 8), 1 = fp8 e4m3fn, 2 = fp8 e5m2 (OCP bytes,
  * K vectors of x = 16; dequantised as dtype(float(fp8) * k_scale / v_scale) like the
@@ -295,6 +300,7 @@ typedef struct kvc_attention_params {
   float* max_logits;                    /* [num_seqs, num_heads, max_parts] or NULL */
   void* tmp_out;                        /* [num_seqs, num_heads, max_parts, head_size] or NULL */
   float* tmp_kv_metric_out;             /* [num_blocks, block_size, qpk] or NULL */
+  float* fused_metrics;                 /* optional (may be NULL): [num_blocks, block_size]; see below */
   const void* query;                    /* [num_seqs, num_heads, head_size], seq stride q_stride */
   const void* key_cache;                /* [num_blocks, head_size/x, block_size, x] */
   const void* value_cache;              /* [num_blocks, head_size, block_size] */
@@ -310,6 +316,7 @@ typedef struct kvc_attention_params {
   int32_t num_seqs, num_heads, num_kv_heads, head_size, block_size;
   int32_t max_num_blocks_per_seq, max_context_len;
   int32_t dtype, kv_cache_dtype, record_kv_metrics;
+  int32_t fused_use_l2;                 /* with fused_metrics: accumulate p^2 (1) or p (0) */
 } kvc_attention_params;
 
 int kvc_paged_attention_decode(const kvc_attention_params* p, kvc_stream_t stream);

@@ -263,3 +263,43 @@ def test_decode_attention_fp8_cache(kind, bs, dt, scales, attn_mode):
     assert np.allclose(km.cpu().numpy()[rec], ref_km[rec], rtol=2e-4, atol=1e-9)
     tol = 4e-3 if dt == "f16" else 3e-2
     assert np.allclose(out.float().cpu().numpy(), ref_out, atol=tol, rtol=tol)
+
+
+@pytest.mark.parametrize("shape", [(3, 8, 2, 128, 16, 1, 700, "f16"), (2, 16, 2, 128, 32, 100, 1300, "bf16"),
+                                   (2, 6, 2, 64, 16, 10, 400, "f16")])
+@pytest.mark.parametrize("use_l2", [True, False])
+def test_decode_attention_fused_metric_aggregation(shape, use_l2, attn_mode):
+    """metrics += sum_q p^2 inside the attention == kv_metric_out + aggregate_decode, bit for
+    bit (same products, same summation order)"""
+    import torch
+    from vllm_kvcompress_amd import _custom_ops as ops
+    from vllm_kvcompress_amd import _lib
+    S, Hq, Hkv, hd, bs, lo, hi, dt = shape
+    rng = np.random.default_rng(hash(shape) % (2 ** 31))
+    g, c, pos, last = make_state(rng, S, Hq, Hkv, hd, bs, lo, hi, dtype=dt)
+    buf = rng.integers(0, 30, size=S).astype(np.int32)
+    out_ref, km = _run_gpu(g, c, pos, last, buf, "v1", fill=0.0)
+    dev = "cuda:0"
+    NB = km.shape[0]
+    qpk = Hq // Hkv
+    m0 = torch.from_numpy(rng.random((NB, bs)).astype(np.float32)).to(dev)
+    # unfused: aggregate the stored weights with the A2a kernel
+    want = m0.clone()
+    temp = torch.from_numpy(km).to(dev).contiguous()
+    lib = _lib.load()
+    _lib.check(lib.kvc_aggregate_decode(want.data_ptr(), temp.data_ptr(), NB * bs, qpk, int(use_l2), 0,
+                                        torch.cuda.current_stream().cuda_stream))
+    # fused
+    tdt = torch.float16 if dt == "f16" else torch.bfloat16
+    t = lambda bits: torch.from_numpy(np.ascontiguousarray(bits)).to(dev).view(tdt)
+    q, kc, vc = t(g["query_bits"]), t(g["key_cache_bits"]), t(g["value_cache_bits"])
+    out = torch.zeros_like(q)
+    got = m0.clone()
+    ops.paged_attention_kvc_fused_metrics(
+        out, got, q, kc, vc, Hkv, float(g["scale"]), torch.from_numpy(g["block_tables"]).to(dev),
+        torch.from_numpy(g["context_lens"]).to(dev), torch.from_numpy(pos).to(dev),
+        torch.from_numpy(last).to(dev), torch.from_numpy(buf).to(dev), bs,
+        int(g["context_lens"].max()), None, "auto", 1.0, 1.0, use_l2=use_l2)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert np.array_equal(out.float().cpu().numpy(), out_ref)

@@ -30,6 +30,10 @@ def main():
             res.append(r)
             print(json.dumps(r))
     if not args.only:
+        for S, ctx in ((256, 4097), (16, 32769)):
+            r = run(S, ctx, fused=True)
+            res.append(r)
+            print(json.dumps(r))
         for kvd, bs, ks in (("fp8_e4m3", 16, 1.0), ("fp8_e5m2", 32, 1.0), ("fp8_e4m3", 16, 0.01)):
             r = run(256, 4097, bs=bs, kv_dtype=kvd, k_scale=ks)
             res.append(r)

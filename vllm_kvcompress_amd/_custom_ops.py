@@ -231,12 +231,17 @@ def _paged_attention_kvc(out, kv_metric_out, exp_sum, max_logits, tmp_out, tmp_k
                          query, key_cache, value_cache, num_kv_heads, scale, block_tables,
                          context_lens, kv_position, last_position, kv_metric_buffer_len,
                          block_size, max_context_len, alibi_slopes, kv_cache_dtype, k_scale,
-                         v_scale, record_kv_metrics) -> None:
+                         v_scale, record_kv_metrics, fused_metrics=None, use_l2=True) -> None:
     lib = _lib.load()
     for name, t in (("out", out), ("query", query), ("key_cache", key_cache),
                     ("value_cache", value_cache)):
         _require(t, name)
-    _require(kv_metric_out, "kv_metric_out", torch.float32)
+    if fused_metrics is None:
+        _require(kv_metric_out, "kv_metric_out", torch.float32)
+    else:
+        _require(fused_metrics, "metrics", torch.float32)
+        if not fused_metrics.is_contiguous():
+            raise RuntimeError("paged_attention_kvc: metrics must be contiguous (updated in place)")
     for name, t in (("block_tables", block_tables), ("context_lens", context_lens),
                     ("kv_position", kv_position), ("last_position", last_position),
                     ("kv_metric_buffer_len", kv_metric_buffer_len)):
@@ -261,7 +266,8 @@ def _paged_attention_kvc(out, kv_metric_out, exp_sum, max_logits, tmp_out, tmp_k
         raise RuntimeError("paged_attention_kvc: out must be contiguous")
     bt = block_tables.contiguous()
     p = _lib.KvcAttentionParams()
-    p.out, p.kv_metric_out = out.data_ptr(), kv_metric_out.data_ptr()
+    p.out, p.kv_metric_out = out.data_ptr(), _ptr(kv_metric_out)
+    p.fused_metrics, p.fused_use_l2 = _ptr(fused_metrics), int(bool(use_l2))
     p.exp_sums, p.max_logits = _ptr(exp_sum), _ptr(max_logits)
     p.tmp_out, p.tmp_kv_metric_out = _ptr(tmp_out), _ptr(tmp_kv_metric_out)
     p.query, p.key_cache, p.value_cache = query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr()
@@ -291,23 +297,50 @@ def paged_attention_kvc_v1(out, kv_metric_out, query, key_cache, value_cache, nu
     """reference vllm/_custom_ops.py:135-163.  The reference's v1 keeps a whole context in
     one workgroup's shared memory; here long contexts are always partitioned, so the
     partition buffers the v1 signature does not carry come from the wrapper's scratch."""
-    num_seqs, num_heads, head_size = query.shape
-    parts = (int(max_context_len) + _ATTN_PARTITION - 1) // _ATTN_PARTITION
-    exp_sum = max_logits = tmp_out = tmp_metric = None
-    if parts > 1:
-        n = num_seqs * num_heads * parts
-        buf = workspace(query.device, n * 8 + n * head_size * query.element_size() + 256, "attn_v1")
-        exp_sum = buf[:n * 4].view(torch.float32)
-        max_logits = buf[n * 4:n * 8].view(torch.float32)
-        tmp_out = buf[n * 8:n * 8 + n * head_size * query.element_size()].view(query.dtype)
-        if record_kv_metrics:
-            tmp_metric = workspace(query.device, kv_metric_out.numel() * 4, "attn_v1_metric").view(
-                torch.float32)[:kv_metric_out.numel()]
+    exp_sum, max_logits, tmp_out, tmp_metric = _partition_scratch(
+        query, max_context_len, kv_metric_out.numel() if record_kv_metrics else 0, "attn_v1")
     _paged_attention_kvc(out, kv_metric_out, exp_sum, max_logits, tmp_out, tmp_metric, query,
                          key_cache, value_cache, num_kv_heads, scale, block_tables, context_lens,
                          kv_position, last_position, kv_metric_buffer_len, block_size,
                          max_context_len, alibi_slopes, kv_cache_dtype, k_scale, v_scale,
                          record_kv_metrics)
+
+
+def _partition_scratch(query, max_context_len, metric_numel, tag):
+    num_seqs, num_heads, head_size = query.shape
+    parts = (int(max_context_len) + _ATTN_PARTITION - 1) // _ATTN_PARTITION
+    if parts <= 1:
+        return None, None, None, None
+    n = num_seqs * num_heads * parts
+    buf = workspace(query.device, n * 8 + n * head_size * query.element_size() + 256, tag)
+    exp_sum = buf[:n * 4].view(torch.float32)
+    max_logits = buf[n * 4:n * 8].view(torch.float32)
+    tmp_out = buf[n * 8:n * 8 + n * head_size * query.element_size()].view(query.dtype)
+    tmp_metric = None
+    if metric_numel:
+        tmp_metric = workspace(query.device, metric_numel * 4, tag + "_metric").view(
+            torch.float32)[:metric_numel]
+    return exp_sum, max_logits, tmp_out, tmp_metric
+
+
+def paged_attention_kvc_fused_metrics(out, metrics, query, key_cache, value_cache,
+                                      num_kv_heads: int, scale: float, block_tables, context_lens,
+                                      kv_position, last_position, kv_metric_buffer_len,
+                                      block_size: int, max_context_len: int, alibi_slopes,
+                                      kv_cache_dtype: str, k_scale: float, v_scale: float,
+                                      use_l2: bool = True) -> None:
+    """Extension (the reference lists it as a to-do, vllm/kvcompress/README.md:32,49): the
+    attention of ``paged_attention_kvc_v1`` that adds ``sum_q p^2`` (or ``sum_q p``) of every
+    key inside the metric window straight into ``metrics [num_blocks, block_size]`` -- what
+    ``kv_metric_out`` + ``CompressionMetrics.aggregate_decode`` + ``clear_temp_metrics`` do
+    together (metrics.py:429-439, 337-342), bit for bit, without the [NB, bs, qpk] buffer."""
+    qpk = query.shape[1] // int(num_kv_heads)
+    es, ml, to, tm = _partition_scratch(query, max_context_len, metrics.numel() * qpk, "attn_fused")
+    _paged_attention_kvc(out, None, es, ml, to, tm, query, key_cache, value_cache, num_kv_heads,
+                         scale, block_tables, context_lens, kv_position, last_position,
+                         kv_metric_buffer_len, block_size, max_context_len, alibi_slopes,
+                         kv_cache_dtype, k_scale, v_scale, True, fused_metrics=metrics,
+                         use_l2=use_l2)
 
 
 def paged_attention_kvc_v2(out, kv_metric_out, exp_sum, max_logits, tmp_out, tmp_kv_metric_out,

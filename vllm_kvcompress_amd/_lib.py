@@ -44,6 +44,7 @@ class KvcAttentionParams(ctypes.Structure):
     _fields_ = [
         ("out", c_void_p), ("kv_metric_out", c_void_p), ("exp_sums", c_void_p),
         ("max_logits", c_void_p), ("tmp_out", c_void_p), ("tmp_kv_metric_out", c_void_p),
+        ("fused_metrics", c_void_p),
         ("query", c_void_p), ("key_cache", c_void_p), ("value_cache", c_void_p),
         ("block_tables", c_void_p), ("context_lens", c_void_p), ("kv_position", c_void_p),
         ("last_position", c_void_p), ("kv_metric_buffer_len", c_void_p),
@@ -54,6 +55,7 @@ class KvcAttentionParams(ctypes.Structure):
         ("head_size", c_int32), ("block_size", c_int32),
         ("max_num_blocks_per_seq", c_int32), ("max_context_len", c_int32),
         ("dtype", c_int32), ("kv_cache_dtype", c_int32), ("record_kv_metrics", c_int32),
+        ("fused_use_l2", c_int32),
     ]
 
 

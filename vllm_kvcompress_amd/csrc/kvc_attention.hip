@@ -134,6 +134,7 @@ struct AttnArgs {
   float* max_logits;              // [S, Hq, max_parts]
   void* tmp_out;                  // [S, Hq, max_parts, hd] T
   float* tmp_kv_metric_out;       // [NB, bs, qpk]
+  float* fused_metrics;           // [NB, bs] or null: metrics[slot] += sum_q p^2 (or p) instead of kv_metric_out
   const void* q;                  // [S, Hq, hd] T, seq stride q_stride
   const void* k_cache;            // [NB, hd/8, bs, 8] T
   const void* v_cache;            // [NB, hd, bs] T
@@ -145,8 +146,16 @@ struct AttnArgs {
   const float* alibi_slopes;      // [Hq] or null
   int64_t q_stride, kv_block_stride;
   float scale, k_scale, v_scale;
-  int32_t num_heads, num_kv_heads, max_blocks, max_parts, record, max_ctx;
+  int32_t num_heads, num_kv_heads, max_blocks, max_parts, record, max_ctx, use_l2;
 };
+
+// fused aggregation (what CompressionMetrics.aggregate_decode does with the stored weights,
+// vllm/kvcompress/metrics.py:429-439): metrics[slot] += sum_q p_q^2 (L2) or sum_q p_q, summed in
+// query order with individually rounded operations, so the result is bit-identical to writing
+// kv_metric_out and aggregating afterwards
+__device__ __forceinline__ float metric_term(float acc, float p, int use_l2) {
+  return __fadd_rn(acc, use_l2 ? __fmul_rn(p, p) : p);
+}
 
 __device__ __forceinline__ float group_max(float v) {     // over the 4 lanes sharing lane&15
   v = fmaxf(v, __shfl_xor(v, 16, 64));
@@ -350,6 +359,7 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
   if (a.record) {
     const int max_pos = a.last_position[seq] - a.kv_metric_buffer_len[seq];     // .cu:124
     float* mo = single ? a.kv_metric_out : a.tmp_kv_metric_out;
+    const bool fuse = single && a.fused_metrics != nullptr;    // else: the rescale pass accumulates
     const bool vec4 = nq == 4 && qpk == 4;
     f32x4 inv4 = {0.f, 0.f, 0.f, 0.f};
     if (vec4) {
@@ -365,14 +375,25 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
       if (vec4) {
         f32x4 v;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = pw[q * ROW + tl] * inv4[q];
-        // streamed once: a plain store allocates in L2 and costs 15 % of the whole kernel
-        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(mo + slot * 4));
+        for (int q = 0; q < 4; ++q) v[q] = __fmul_rn(pw[q * ROW + tl], inv4[q]);
+        if (fuse) {
+          float acc = 0.0f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc = metric_term(acc, v[q], a.use_l2);
+          a.fused_metrics[slot] = __fadd_rn(a.fused_metrics[slot], acc);
+        } else {
+          // streamed once: a plain store allocates in L2 and costs 15 % of the whole kernel
+          __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(mo + slot * 4));
+        }
       } else {
+        float acc = 0.0f;
         for (int q = 0; q < nq; ++q) {
           const float iq = __fdividef(1.0f, red_sum[0][q] + red_sum[1][q] + red_sum[2][q] + red_sum[3][q] + 1e-6f);
-          __builtin_nontemporal_store(pw[q * ROW + tl] * iq, mo + slot * qpk + q0 + q);
+          const float v = __fmul_rn(pw[q * ROW + tl], iq);
+          if (fuse) acc = metric_term(acc, v, a.use_l2);
+          else __builtin_nontemporal_store(v, mo + slot * qpk + q0 + q);
         }
+        if (fuse) a.fused_metrics[slot] = __fadd_rn(a.fused_metrics[slot], acc);
       }
     }
   }
@@ -593,17 +614,27 @@ __global__ __launch_bounds__(256) KVC_WHOLE_ATTR void paged_attention_decode_who
         if (vec4) {
           f32x4 v;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = P[q * prow + tok] * (__expf(mr[q] - Mq[q]) * Iq[q]);
-          __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.kv_metric_out + slot * 4));
+          for (int q = 0; q < 4; ++q) v[q] = __fmul_rn(P[q * prow + tok], __expf(mr[q] - Mq[q]) * Iq[q]);
+          if (a.fused_metrics != nullptr) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = metric_term(acc, v[q], a.use_l2);
+            a.fused_metrics[slot] = __fadd_rn(a.fused_metrics[slot], acc);
+          } else {
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.kv_metric_out + slot * 4));
+          }
         } else {
+          float acc = 0.0f;
           for (int q = 0; q < nq; ++q) {
             const float Mg = fmaxf(fmaxf(red_max[0][q], red_max[1][q]), fmaxf(red_max[2][q], red_max[3][q]));
             float L = 0.0f;
             for (int ww = 0; ww < ATT_WAVES; ++ww)
               L += red_max[ww][q] == -INFINITY ? 0.0f : red_sum[ww][q] * __expf(red_max[ww][q] - Mg);
-            __builtin_nontemporal_store(P[q * prow + tok] * (__expf(mr[q] - Mg) * __fdividef(1.0f, L + 1e-6f)),
-                                        a.kv_metric_out + slot * qpk + q0 + q);
+            const float v = __fmul_rn(P[q * prow + tok], __expf(mr[q] - Mg) * __fdividef(1.0f, L + 1e-6f));
+            if (a.fused_metrics != nullptr) acc = metric_term(acc, v, a.use_l2);
+            else __builtin_nontemporal_store(v, a.kv_metric_out + slot * qpk + q0 + q);
           }
+          if (a.fused_metrics != nullptr) a.fused_metrics[slot] = __fadd_rn(a.fused_metrics[slot], acc);
         }
       }
     }
@@ -716,8 +747,16 @@ __global__ __launch_bounds__(256) void paged_attention_metric_rescale_kernel(Att
       if (!ok[k] || posv[k] > max_pos) continue;
       const int pj = (chunk * ATT_RS_TOK + k * 256 + tid) / ATT_PART - p0;
       f32x4 v = t[k];
-      v[0] *= fac[0 + pj]; v[1] *= fac[2 + pj]; v[2] *= fac[4 + pj]; v[3] *= fac[6 + pj];
-      *reinterpret_cast<f32x4*>(a.kv_metric_out + slot[k] * 4) = v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = __fmul_rn(v[q], fac[2 * q + pj]);
+      if (a.fused_metrics != nullptr) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = metric_term(acc, v[q], a.use_l2);
+        a.fused_metrics[slot[k]] = __fadd_rn(a.fused_metrics[slot[k]], acc);
+      } else {
+        *reinterpret_cast<f32x4*>(a.kv_metric_out + slot[k] * 4) = v;
+      }
     }
   } else {
     for (int k = 0; k < K; ++k) {
@@ -726,8 +765,13 @@ __global__ __launch_bounds__(256) void paged_attention_metric_rescale_kernel(Att
       const int64_t slot = (int64_t)bt[i / BS] * BS + (i % BS);
       if (a.kv_position[slot] > max_pos) continue;
       const int pj = i / ATT_PART - p0;
-      for (int q = 0; q < qpk; ++q)
-        a.kv_metric_out[slot * qpk + q] = a.tmp_kv_metric_out[slot * qpk + q] * fac[q * 2 + pj];
+      float acc = 0.0f;
+      for (int q = 0; q < qpk; ++q) {
+        const float v = __fmul_rn(a.tmp_kv_metric_out[slot * qpk + q], fac[q * 2 + pj]);
+        if (a.fused_metrics != nullptr) acc = metric_term(acc, v, a.use_l2);
+        else a.kv_metric_out[slot * qpk + q] = v;
+      }
+      if (a.fused_metrics != nullptr) a.fused_metrics[slot] = __fadd_rn(a.fused_metrics[slot], acc);
     }
   }
 }
@@ -795,6 +839,9 @@ extern "C" int kvc_paged_attention_decode(const kvc_attention_params* p, kvc_str
   AttnArgs a;
   a.out = p->out; a.kv_metric_out = p->kv_metric_out; a.exp_sums = p->exp_sums;
   a.max_logits = p->max_logits; a.tmp_out = p->tmp_out; a.tmp_kv_metric_out = p->tmp_kv_metric_out;
+  a.fused_metrics = p->fused_metrics; a.use_l2 = p->fused_use_l2 ? 1 : 0;
+  if (a.fused_metrics != nullptr && p->num_heads / p->num_kv_heads > ATT_NQ)
+    return fail_invalid("paged_attention_decode: fused metric aggregation needs <= 16 query heads per KV head");
   a.q = p->query; a.k_cache = p->key_cache; a.v_cache = p->value_cache;
   a.block_tables = p->block_tables; a.context_lens = p->context_lens; a.kv_position = p->kv_position;
   a.last_position = p->last_position; a.kv_metric_buffer_len = p->kv_metric_buffer_len;

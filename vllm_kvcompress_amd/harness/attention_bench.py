@@ -7,7 +7,7 @@ from __future__ import annotations
 
 
 def run(S, ctx_len, Hq=32, Hkv=8, hd=128, bs=16, iters=20, record=True, dtype="f16", kv_dtype="auto",
-        k_scale=1.0):
+        k_scale=1.0, fused=False):
     import torch
     from vllm_kvcompress_amd import _custom_ops as ops
     dev = "cuda:0"
@@ -40,7 +40,15 @@ def run(S, ctx_len, Hq=32, Hkv=8, hd=128, bs=16, iters=20, record=True, dtype="f
     to = torch.empty((S, Hq, parts, hd), dtype=tdt, device=dev)
     tkm = torch.empty_like(km)
 
+    metrics = torch.zeros((NB, bs), dtype=torch.float32, device=dev)
+
+    def step_fused():
+        ops.paged_attention_kvc_fused_metrics(out, metrics, q, kc, vc, Hkv, hd ** -0.5, bt, ctx, pos, last,
+                                              buf, bs, ctx_len, None, kv_dtype, k_scale, 1.0, True)
+
     def step():
+        if fused:
+            return step_fused()
         ops.paged_attention_kvc_v2(out, km, es, ml, to, tkm, q, kc, vc, Hkv, hd ** -0.5, bt, ctx, pos,
                                    last, buf, bs, ctx_len, None, kv_dtype, k_scale, 1.0, record)
     for _ in range(3):
@@ -54,8 +62,9 @@ def run(S, ctx_len, Hq=32, Hkv=8, hd=128, bs=16, iters=20, record=True, dtype="f
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     tokens = S * Hkv * ctx_len
-    alg = tokens * (2 * hd * kc.element_size() + 4 * record + 4 * qpk * record)
+    # fused: position read + metrics read-modify-write instead of the qpk-wide store
+    alg = tokens * (2 * hd * kc.element_size() + ((4 + 8) if fused else (4 * record + 4 * qpk * record)))
     return {"num_seqs": S, "context_len": ctx_len, "num_heads": Hq, "num_kv_heads": Hkv,
-            "head_size": hd, "block_size": bs, "dtype": dtype, "kv_cache_dtype": kv_dtype, "k_scale": k_scale, "record_kv_metrics": record,
+            "head_size": hd, "block_size": bs, "dtype": dtype, "kv_cache_dtype": kv_dtype, "k_scale": k_scale, "record_kv_metrics": record, "fused_metric_aggregation": fused,
             "ms_per_layer_step": ms, "algorithmic_bytes": alg, "GBps": alg / ms / 1e6,
             "frac_of_8TBps": alg / ms / 1e6 / 8000.0, "cached_tokens_per_s": tokens / ms * 1e3}
