@@ -19,6 +19,12 @@
 
 #include <math.h>
 #include <type_traits>
+#ifndef KVC_PF_RB
+#define KVC_PF_RB 1
+#endif
+#ifndef KVC_PF_RBQ
+#define KVC_PF_RBQ 2
+#endif
 
 namespace kvc {
 
@@ -74,6 +80,22 @@ __device__ __forceinline__ void load_rows(typename Mma32<T>::V8 (&frag)[2][HD / 
   }
 }
 
+// 32 resident rows x HD: frag[s] holds, for row (row0 + lane % 32), dims 16 s + 8 (lane / 32) .. + 7
+template <typename T, int HD>
+__device__ __forceinline__ void load_rows32(typename Mma32<T>::V8 (&frag)[HD / 16], const T* base,
+                                            int64_t stride, int row0, int nrows, int lane) {
+  using V8 = typename Mma32<T>::V8;
+  const int r = row0 + (lane & 31);
+  const bool ok = r < nrows;
+  const T* p = base + (int64_t)(ok ? r : 0) * stride + 8 * (lane >> 5);
+#pragma unroll
+  for (int s = 0; s < HD / 16; ++s) {
+    pu32x4 raw = {0u, 0u, 0u, 0u};
+    if (ok) raw = *reinterpret_cast<const pu32x4*>(p + 16 * s);
+    frag[s] = __builtin_bit_cast(V8, raw);
+  }
+}
+
 // The streamed operand: 32 rows x HD per step, shared by the four waves of a workgroup.
 // Reading it straight from global memory costs 64 different cache lines per wave load
 // instruction (every lane another token row) and makes the kernel L1-line-rate bound
@@ -81,16 +103,16 @@ __device__ __forceinline__ void load_rows(typename Mma32<T>::V8 (&frag)[2][HD / 
 // (16 consecutive lanes = one 256-byte row), and parks it in LDS in operand order:
 // 16-byte unit (p, row) at index p * 33 + row, p = dim / 8 -- the pad makes the transposing
 // write 2-way instead of 16-way conflicted, the fragment reads are conflict free.
-template <typename T, int HD>
+template <typename T, int HD, int THREADS = 256>
 struct StreamTile {
   static constexpr int PP = HD / 8;                 // 16-byte pieces per row
-  static constexpr int CH = 32 * PP / 256;          // chunks per thread
+  static constexpr int CH = 32 * PP / THREADS;      // chunks per thread
   static constexpr int UNITS = PP * 33;
   pu32x4 regs[CH];
   __device__ __forceinline__ void fetch(const T* base, int64_t stride, int row0, int nrows, int tid) {
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-      const int c = tid + 256 * j, row = c / PP, p = c % PP;
+      const int c = tid + THREADS * j, row = c / PP, p = c % PP;
       regs[j] = pu32x4{0u, 0u, 0u, 0u};
       if (row0 + row < nrows)
         regs[j] = *reinterpret_cast<const pu32x4*>(base + (int64_t)(row0 + row) * stride + 8 * p);
@@ -99,7 +121,7 @@ struct StreamTile {
   __device__ __forceinline__ void park(pu32x4* lds, int tid) const {
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-      const int c = tid + 256 * j, row = c / PP, p = c % PP;
+      const int c = tid + THREADS * j, row = c / PP, p = c % PP;
       lds[p * 33 + row] = regs[j];
     }
   }
@@ -111,8 +133,8 @@ struct StreamTile {
 
 // pass 1: lse[h, r] = log2 sum_k 2^(t[r,k]) over keys k <= q_offset + r, t = logit * log2(e).
 // A wave keeps its 64 queries in registers; the workgroup streams the keys through LDS.
-template <typename T, int HD>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void prefill_lse_kernel(PfArgs a) {
+template <typename T, int HD, int RB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void prefill_lse_kernel(PfArgs a) {
   using M = Mma32<T>;
   using V8 = typename M::V8;
   using ST = StreamTile<T, HD>;
@@ -120,18 +142,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   __shared__ __attribute__((aligned(16))) pu32x4 tile[2][ST::UNITS];
   const int h = blockIdx.y, hk = h / (a.Hq / a.Hk);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int rwg = blockIdx.x * 256;                         // the workgroup's first query row
-  const int r0 = rwg + w * 64;                              // this wave's first query row
+  constexpr int WQ = 32 * RB;                               // queries per wave (RB resident 32-row blocks)
+  const int rwg = blockIdx.x * (4 * WQ);                    // the workgroup's first query row
+  const int r0 = rwg + w * WQ;                              // this wave's first query row
   const bool active = r0 < a.nq;
   const T* qb = reinterpret_cast<const T*>(a.q) + (int64_t)h * HD;
   const T* kb = reinterpret_cast<const T*>(a.k) + (int64_t)hk * HD;
-  V8 bq[2][KS];
-  load_rows<T, HD>(bq, qb, a.q_stride, r0, a.nq, lane);
+  V8 bq[RB][KS];
+#pragma unroll
+  for (int nb = 0; nb < RB; ++nb) load_rows32<T, HD>(bq[nb], qb, a.q_stride, r0 + 32 * nb, a.nq, lane);
   const float sc = a.scale * LOG2E;
-  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.0f, 0.0f};
+  float m[RB], l[RB];
+#pragma unroll
+  for (int nb = 0; nb < RB; ++nb) { m[nb] = -INFINITY; l[nb] = 0.0f; }
   const int col = lane & 31, half = lane >> 5;
-  const int kend = min(a.K, a.q_offset + min(a.nq, r0 + 64));          // this wave's causal limit
-  const int kend_wg = min(a.K, a.q_offset + min(a.nq, rwg + 256));      // the workgroup's
+  const int kend = min(a.K, a.q_offset + min(a.nq, r0 + WQ));          // this wave's causal limit
+  const int kend_wg = min(a.K, a.q_offset + min(a.nq, rwg + 4 * WQ));   // the workgroup's
   ST st;
   st.fetch(kb, a.k_stride, 0, a.K, tid);
   st.park(tile[0], tid);
@@ -150,7 +176,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int s = 0; s < KS; ++s) ak[s] = ST::frag(tl, s, lane);
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
+        for (int nb = 0; nb < RB; ++nb) {
           f32x16 c = f32x16{0.f};
 #pragma unroll
           for (int s = 0; s < KS; ++s) c = M::mma(ak[s], bq[nb][s], c);
@@ -185,7 +211,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   if (active && half == 0) {
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
+    for (int nb = 0; nb < RB; ++nb) {
       const int r = r0 + 32 * nb + col;
       if (r < a.nq) a.lse[(int64_t)h * a.lse_stride + r] = m[nb] + __builtin_amdgcn_logf(l[nb]);
     }
@@ -195,8 +221,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // pass 2: colsum[h, k] = sum over the block's query rows r with k + buffer_len <= q_offset + r
 // of P[r, k] (or its square), P = 2^(t - lse).  A wave keeps its 64 keys in registers; the
 // workgroup streams the queries through LDS.
-template <typename T, int HD, bool L2>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void prefill_colsum_kernel(PfArgs a) {
+template <typename T, int HD, bool L2, int RB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void prefill_colsum_kernel(PfArgs a) {
   using M = Mma32<T>;
   using V8 = typename M::V8;
   using ST = StreamTile<T, HD>;
@@ -204,18 +230,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   __shared__ __attribute__((aligned(16))) pu32x4 tile[2][ST::UNITS];
   const int h = blockIdx.y, hk = h / (a.Hq / a.Hk);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int kwg = blockIdx.x * 256;                         // the workgroup's first key
-  const int k0 = kwg + w * 64;                              // this wave's first key
+  constexpr int WK = 32 * RB;                               // keys per wave (RB resident 32-row blocks)
+  const int kwg = blockIdx.x * (4 * WK);                    // the workgroup's first key
+  const int k0 = kwg + w * WK;                              // this wave's first key
   const bool active = k0 < a.K;
   const T* qb = reinterpret_cast<const T*>(a.q) + (int64_t)h * HD;
   const T* kb = reinterpret_cast<const T*>(a.k) + (int64_t)hk * HD;
-  V8 ak[2][KS];
-  load_rows<T, HD>(ak, kb, a.k_stride, k0, a.K, lane);
+  V8 ak[RB][KS];
+#pragma unroll
+  for (int mb = 0; mb < RB; ++mb) load_rows32<T, HD>(ak[mb], kb, a.k_stride, k0 + 32 * mb, a.K, lane);
   const float sc = a.scale * LOG2E;
   const int col = lane & 31, half = lane >> 5;
-  f32x16 acc[2];
-  acc[0] = f32x16{0.f};
-  acc[1] = f32x16{0.f};
+  f32x16 acc[RB];
+#pragma unroll
+  for (int mb = 0; mb < RB; ++mb) acc[mb] = f32x16{0.f};
   // first query row that can see the first key of the wave / workgroup through the window
   auto first_row = [&](int key) { const int r = key + a.buffer_len - a.q_offset; return r < 0 ? 0 : r / 32 * 32; };
   const int rs = first_row(k0), rs_wg = first_row(kwg);
@@ -235,7 +263,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int r = r0 + col;
       const float ls = r < a.nq ? lse_h[r] : 0.0f;
       // every (key, query) pair of the tile inside the window and inside the block?
-      const bool edge = k0 + 63 + a.buffer_len > a.q_offset + r0 || r0 + 32 > a.nq || k0 + 64 > a.K;
+      const bool edge = k0 + WK - 1 + a.buffer_len > a.q_offset + r0 || r0 + 32 > a.nq || k0 + WK > a.K;
       const int pq = a.q_offset + r;
       auto body = [&](auto edge_tag) {
         constexpr bool EDGE = decltype(edge_tag)::value;
@@ -243,7 +271,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int s = 0; s < KS; ++s) bq[s] = ST::frag(tl, s, lane);
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
+        for (int mb = 0; mb < RB; ++mb) {
           f32x16 c = f32x16{0.f};
 #pragma unroll
           for (int s = 0; s < KS; ++s) c = M::mma(ak[mb][s], bq[s], c);
@@ -267,7 +295,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (!active) return;
   // sum over the 32 query columns held by the lanes of each half
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb)
+  for (int mb = 0; mb < RB; ++mb)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       float v = acc[mb][i];
@@ -276,11 +304,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       acc[mb][i] = v;
     }
   // lane `col` of each half writes the keys (i = col % 16, mb = col / 16) of its half
-  {
+  if (col < 16 * RB) {
     const int mb = col >> 4, i = col & 15;
     float v = 0.0f;
 #pragma unroll
-    for (int mm = 0; mm < 2; ++mm)
+    for (int mm = 0; mm < RB; ++mm)
 #pragma unroll
       for (int ii = 0; ii < 16; ++ii)
         if (mm == mb && ii == i) v = acc[mm][ii];
@@ -301,16 +329,20 @@ static int launch_prefill(PfArgs a, float* out_kh, int n_obs, int q_block, int u
   const int off0 = a.q_offset;
   a.nq = n_obs;
   a.lse_stride = n_obs;
-  hipLaunchKernelGGL((prefill_lse_kernel<T, HD>), dim3((n_obs + 255) / 256, a.Hq), dim3(256), 0, s, a);
+  constexpr int RBQ = KVC_PF_RBQ;
+  hipLaunchKernelGGL((prefill_lse_kernel<T, HD, RBQ>), dim3((n_obs + 128 * RBQ - 1) / (128 * RBQ), a.Hq),
+                     dim3(256), 0, s, a);
   for (int l = 0; l < n_obs; l += q_block) {
     a.q = q0 + (int64_t)l * a.q_stride;
     a.lse = lse0 + l;
     a.nq = n_obs - l < q_block ? n_obs - l : q_block;
     a.q_offset = off0 + l;
+    constexpr int RB = KVC_PF_RB;
+    const dim3 grid((a.K + 128 * RB - 1) / (128 * RB), a.Hq);
     if (a.use_l2)
-      hipLaunchKernelGGL((prefill_colsum_kernel<T, HD, true>), dim3((a.K + 255) / 256, a.Hq), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((prefill_colsum_kernel<T, HD, true, RB>), grid, dim3(256), 0, s, a);
     else
-      hipLaunchKernelGGL((prefill_colsum_kernel<T, HD, false>), dim3((a.K + 255) / 256, a.Hq), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((prefill_colsum_kernel<T, HD, false, RB>), grid, dim3(256), 0, s, a);
     const int rc = launch_epilogue_pool(out_kh, a.colsum, a.Hq, a.K, use_maxpool, s);
     if (rc != KVC_OK) return rc;
   }
