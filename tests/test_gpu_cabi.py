@@ -1,6 +1,7 @@
 """The drop-in boundary without Python in the loop: a C++ host (tests/cabi/cabi_host.cpp)
 links libkvc_mi355x.so by its header only, runs count -> moves -> compaction and compares
-with the C oracle."""
+with the C oracle, then the decode attention through its parameter struct against a plain
+float loop."""
 import os
 import shutil
 import subprocess
