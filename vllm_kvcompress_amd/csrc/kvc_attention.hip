@@ -678,12 +678,34 @@ __global__ __launch_bounds__(256) void paged_attention_reduce_kernel(AttnArgs a)
   __syncthreads();
   tot = red[4] + red[5] + red[6] + red[7];
   const float inv = __fdividef(1.0f, tot + 1e-6f);
+  // out[d] = sum_j tmp_out[j][d] * share_j: the partitions are split over 256 / HD thread
+  // groups and each thread keeps 8 loads in flight (this kernel is pure latency: at one
+  // sequence of 32k tokens it used to cost a third of the whole attention call)
   const T* tp = reinterpret_cast<const T*>(a.tmp_out) + base * HD;
-  for (int d = tid; d < HD; d += 256) {
-    float acc = 0.0f;
-    for (int j = 0; j < nparts; ++j) acc += (float)tp[(int64_t)j * HD + d] * ssum[j] * inv;
-    reinterpret_cast<T*>(a.out)[((int64_t)seq * a.num_heads + head) * HD + d] = (T)acc;
+  constexpr int NG = HD <= 256 ? 256 / HD : 1;              // thread groups over partitions
+  __shared__ float part_acc[256];
+  const int d = tid % HD, grp = tid / HD;
+  float acc = 0.0f;
+  if (grp < NG) {
+    int j = grp;
+    for (; j + 7 * NG < nparts; j += 8 * NG) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = (float)tp[(int64_t)(j + u * NG) * HD + d];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u] * (ssum[j + u * NG] * inv);
+    }
+    for (; j < nparts; j += NG) acc += (float)tp[(int64_t)j * HD + d] * (ssum[j] * inv);
   }
+  if (NG > 1) {
+    part_acc[tid] = acc;
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+      for (int g2 = 1; g2 < NG; ++g2) acc += part_acc[g2 * HD + d];
+    }
+  }
+  if (grp == 0 && d < HD) reinterpret_cast<T*>(a.out)[((int64_t)seq * a.num_heads + head) * HD + d] = (T)acc;
 }
 
 // metric side of the second pass: kv_metric_out = tmp * (partition's share of the softmax
