@@ -189,10 +189,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = f"cuda:{local_rank}"
+    # one rank per GPU; KVC_BENCH_BACKEND=gloo (test hook) lets several ranks share the one
+    # GPU of a single-GPU box to exercise the N > 1 code path
+    backend = os.environ.get("KVC_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = f"cuda:{dev_index}"
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device(device))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend=backend)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     st, ds, evicted, k_cache, v_cache = build_workload(args, seed=rank, device=device)

@@ -1,0 +1,58 @@
+"""bench.py's output contract on the GPU box: the single-rank line carries `roofline` and
+`cpu_baseline`; the N > 1 path (barrier, per-rank shards, all_gather of the two scalars,
+whole-job value) is exercised with two ranks sharing the box's one GPU through the gloo test
+hook (on a multi-GPU node the same code runs over RCCL, one rank per GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+        "scaling", "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _last_json(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_rank_line():
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "4", "--warmup", "1",
+                          "--seq-len", "4096", "--no-adjacent"], capture_output=True, text=True,
+                         timeout=600, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1
+    assert d["unit"] == "KV slots/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+    assert "workload" in d["config"] and d["config"]["freed_blocks"] > 0
+    # value == units / time
+    units = d["config"]["evicted_slots"] + d["config"]["moved_slots"]
+    assert abs(d["value"] - units / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+
+
+def test_two_ranks_share_the_gpu():
+    env = dict(os.environ, KVC_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29517",
+                          os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--seq-len", "4096"], capture_output=True, text=True, timeout=900, cwd=REPO,
+                         env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
+    assert len(d["per_rank"]) == 2
+    units = sum(r["units"] for r in d["per_rank"])
+    worst = max(r["seconds"] for r in d["per_rank"])
+    assert abs(d["value"] - units / worst) / d["value"] < 1e-9
+    # both ranks processed a full shard of their own
+    assert all(r["units"] > 0 for r in d["per_rank"])
