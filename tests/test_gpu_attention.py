@@ -47,7 +47,7 @@ def _run_gpu(g, c, pos, last, buf, version="v2", record=True, fill=-1.0, max_ctx
     Hkv = int(g["num_kv_heads"])
     NB, _, bs = vc.shape
     qpk = Hq // Hkv
-    out = torch.zeros_like(q)
+    out = torch.full_like(q, 7.0)                    # every output element must be written
     km = torch.full((NB, bs, qpk), fill, dtype=torch.float32, device=dev)
     bt = torch.from_numpy(g["block_tables"]).to(dev)
     ctx = torch.from_numpy(g["context_lens"]).to(dev)
@@ -303,3 +303,20 @@ def test_decode_attention_fused_metric_aggregation(shape, use_l2, attn_mode):
     torch.cuda.synchronize()
     assert torch.equal(got, want)
     assert np.array_equal(out.float().cpu().numpy(), out_ref)
+
+
+def test_decode_attention_empty_head(attn_mode):
+    """a head with nothing cached (context_len 0) gets a zero output and writes no metric;
+    the other heads of the same call are unaffected"""
+    rng = np.random.default_rng(8)
+    g, c, pos, last = make_state(rng, 2, 8, 2, 128, 16, 30, 650)
+    g["context_lens"] = g["context_lens"].copy()
+    g["context_lens"][0, 1] = 0
+    buf = np.zeros(2, np.int32)
+    ref_out, ref_km = oracle_decode(c, g, pos, last, buf)           # the oracle skips empty heads (zeros)
+    out, km = _run_gpu(g, c, pos, last, buf, "v2", max_ctx=650)
+    assert ((ref_km == -1.0) == (km == -1.0)).all()
+    rec = ref_km != -1.0
+    assert np.allclose(km[rec], ref_km[rec], rtol=2e-4, atol=1e-9)
+    assert np.allclose(out, ref_out, atol=2e-3, rtol=2e-3)
+    assert (out[0, 4:8] == 0).all()

@@ -184,7 +184,16 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
   // a context longer than max_context_len (a caller bug) is truncated instead of overrunning
   // the buffers that were sized from it
   const int ctx = min(a.context_lens[seq * a.num_kv_heads + hk], a.max_ctx);
-  if (part * ATT_PART >= ctx) return;
+  if (part * ATT_PART >= ctx) {
+    // an empty head (nothing cached) attends to nothing: its output is zero, like the
+    // reference's empty accumulation (.cu:332-420 with num_tokens = 0)
+    if (ctx <= 0 && part == 0) {
+      const int q0e = qg * ATT_NQ, nqe = min(ATT_NQ, qpk - q0e);
+      for (int idx = threadIdx.x; idx < nqe * HD; idx += 256)
+        reinterpret_cast<T*>(a.out)[((int64_t)seq * a.num_heads + hk * qpk + q0e + idx / HD) * HD + idx % HD] = (T)0.0f;
+    }
+    return;
+  }
   const int nparts = (ctx + ATT_PART - 1) / ATT_PART;
   const int q0 = qg * ATT_NQ;
   const int nq = min(ATT_NQ, qpk - q0);
@@ -422,7 +431,12 @@ __global__ __launch_bounds__(256) KVC_WHOLE_ATTR void paged_attention_decode_who
   // a context longer than max_context_len (a caller bug) is truncated instead of overrunning
   // the buffers that were sized from it
   const int ctx = min(a.context_lens[seq * a.num_kv_heads + hk], a.max_ctx);
-  if (ctx <= 0) return;
+  if (ctx <= 0) {                                         // empty head: zero output (see above)
+    const int q0e = qg * ATT_NQ, nqe = min(ATT_NQ, qpk - q0e);
+    for (int idx = threadIdx.x; idx < nqe * HD; idx += 256)
+      reinterpret_cast<T*>(a.out)[((int64_t)seq * a.num_heads + hk * qpk + q0e + idx / HD) * HD + idx % HD] = (T)0.0f;
+    return;
+  }
   const int q0 = qg * ATT_NQ;
   const int nq = min(ATT_NQ, qpk - q0);
   const int nqr = min(ATT_NQ, qpk);
