@@ -284,33 +284,35 @@ __global__ __launch_bounds__(256) void seq_totals_kernel(kvc_schedule_params p, 
 
 // ... and from them the number of chunks k'_i each sequence really frees   metrics.py:704-729
 __global__ __launch_bounds__(1024) void seq_prepare_kernel(kvc_schedule_params p, SchedWs ws) {
-  const int B = p.num_seqs;
-  int32_t* F = ws.seq_tmp;
-  int32_t* Cn = ws.seq_tmp + B;
-  int32_t* Off = ws.seq_tmp + 2 * B;
-  if (threadIdx.x == 0) {
+  const int B = p.num_seqs;                          // <= 1024 (checked on host)
+  // everything lives in LDS: the loops below are O(B^2) over three small tables, and walking
+  // them in global memory cost 117 us at 256 sequences
+  __shared__ int64_t un_s[1024];
+  __shared__ int32_t f_s[1024], cn_s[1024], off_s[1024];
+  for (int i = threadIdx.x; i < B; i += blockDim.x) { f_s[i] = ws.seq_tmp[i]; cn_s[i] = ws.seq_tmp[B + i]; }
+  __syncthreads();
+  if (threadIdx.x == 0) {                            // exclusive prefix of the chunk counts
     int64_t o = 0;
-    for (int i = 0; i < B; ++i) { Off[i] = (int32_t)o; o += Cn[i]; }
+    for (int i = 0; i < B; ++i) { off_s[i] = (int32_t)o; o += cn_s[i]; }
   }
   __syncthreads();
-  __shared__ int64_t un_s[1024];
   // #inf thresholds among the first x entries of the (seq, threshold)-ordered chunk list
   auto inf_prefix = [&](int64_t x) {
     int64_t t = 0;
     for (int j = 0; j < B; ++j) {
-      int64_t v = x - Off[j] - F[j];
-      const int64_t Ij = Cn[j] - F[j];
+      int64_t v = x - off_s[j] - f_s[j];
+      const int64_t Ij = cn_s[j] - f_s[j];
       v = v < 0 ? 0 : (v > Ij ? Ij : v);
       t += v;
     }
     return t;
   };
-  {                                                  // B <= 1024 (checked on host)
+  {
     const int i = threadIdx.x;
     if (i < B) {
-      const int64_t x = (int64_t)Off[i] + p.evicted_blocks_per_seq[i];
+      const int64_t x = (int64_t)off_s[i] + p.evicted_blocks_per_seq[i];
       int64_t ninf = inf_prefix(x);
-      if (p.mode == 1) ninf -= inf_prefix(Off[i]);
+      if (p.mode == 1) ninf -= inf_prefix(off_s[i]);
       un_s[i] = x - ninf;
     }
   }
@@ -319,11 +321,12 @@ __global__ __launch_bounds__(1024) void seq_prepare_kernel(kvc_schedule_params p
     int64_t e = un_s[i];
     if (p.mode == 0)
       for (int j = i + 1; j < B; ++j) e = un_s[j] < e ? un_s[j] : e;   // later seqs un-evict
-    int64_t k = e - Off[i];
+    int64_t k = e - off_s[i];
     k = k < 0 ? 0 : k;
-    k = k > F[i] ? F[i] : k;        // thresholds beyond the finite ones are never freed
+    k = k > f_s[i] ? f_s[i] : k;    // thresholds beyond the finite ones are never freed
     ws.seq_k[i] = (int32_t)k;
     ws.seq_prefix[i] = 0;
+    ws.seq_tmp[2 * B + i] = off_s[i];
   }
 }
 
