@@ -210,7 +210,7 @@ extern "C" int kvc_schedule_t1_cache_moves(
                      evicted_logical_indices, evicted_kv_count, evicted_kv_offsets,             \
                      block_tables, context_lens, num_seqs, num_layers, num_kv_heads,            \
                      max_num_blocks_per_seq, block_size, zero_fill)
-  if (rows_per_head >= 4096) KVC_LAUNCH_HEADS(1024); else KVC_LAUNCH_HEADS(256);
+  if (rows_per_head >= 8192) KVC_LAUNCH_HEADS(1024); else KVC_LAUNCH_HEADS(256);
 #undef KVC_LAUNCH_HEADS
   return kvc::check_launch("schedule_t1_cache_moves");
 }
