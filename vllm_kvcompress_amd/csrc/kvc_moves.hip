@@ -77,13 +77,13 @@ __device__ __forceinline__ int move_iteration(const MoveHead& h, int j) {
 // Irregular heads and tails beyond the bitmap use the closed form above.
 constexpr int MOVE_BITMAP_WORDS = 16384;      // 512 Ki tail slots per head in LDS (64 KiB)
 
-template <int THREADS>
+template <int THREADS, int BITMAP_WORDS>
 __global__ __launch_bounds__(THREADS) void schedule_moves_heads_kernel(
     int32_t* __restrict__ moves, int64_t rows, int32_t* __restrict__ count,
     const int32_t* __restrict__ evicted, const int32_t* __restrict__ ekc,
     const int32_t* __restrict__ offs, const int32_t* __restrict__ block_tables,
     const int32_t* __restrict__ context_lens, int B, int L, int H, int M, int bs, int zero_fill) {
-  __shared__ uint32_t bitmap[MOVE_BITMAP_WORDS];
+  __shared__ uint32_t bitmap[BITMAP_WORDS];       // 64 KiB for long heads, 4 KiB for short ones (occupancy)
   __shared__ uint32_t wave_tot[2][THREADS / WAVE];
   const int G = B * L * H;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(THREADS) void schedule_moves_heads_kernel(
   const int32_t* E = evicted + off;
   const int32_t* bt = block_tables + (int64_t)lbh * M;
   int nmoves = 0;
-  const bool regular = cnt > 0 && E[cnt - 1] < ctx && (cnt + 31) / 32 <= MOVE_BITMAP_WORDS;
+  const bool regular = cnt > 0 && E[cnt - 1] < ctx && (cnt + 31) / 32 <= BITMAP_WORDS;
   if (cnt > 0 && regular) {
     const int new_len = ctx - cnt;
     // holes below new_len = lower_bound(E, new_len)
@@ -204,13 +204,13 @@ extern "C" int kvc_schedule_t1_cache_moves(
   // extra workgroups clear the rows behind the last head's segment (wrapper zero fill)
   const int tail_wgs = zero_fill ? 64 : 0;
   const int64_t rows_per_head = cache_moves_rows / G;
-#define KVC_LAUNCH_HEADS(T)                                                                    \
-  hipLaunchKernelGGL(kvc::schedule_moves_heads_kernel<T>, dim3(G + tail_wgs), dim3(T), 0, s,     \
+#define KVC_LAUNCH_HEADS(T, W)                                                                 \
+  hipLaunchKernelGGL((kvc::schedule_moves_heads_kernel<T, W>), dim3(G + tail_wgs), dim3(T), 0, s,     \
                      cache_moves_idx, cache_moves_rows, cache_moves_count,                      \
                      evicted_logical_indices, evicted_kv_count, evicted_kv_offsets,             \
                      block_tables, context_lens, num_seqs, num_layers, num_kv_heads,            \
                      max_num_blocks_per_seq, block_size, zero_fill)
-  if (rows_per_head >= 8192) KVC_LAUNCH_HEADS(1024); else KVC_LAUNCH_HEADS(256);
+  if (rows_per_head >= 8192) KVC_LAUNCH_HEADS(1024, kvc::MOVE_BITMAP_WORDS); else KVC_LAUNCH_HEADS(256, 1024);
 #undef KVC_LAUNCH_HEADS
   return kvc::check_launch("schedule_t1_cache_moves");
 }
