@@ -532,13 +532,17 @@ __global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(kvc_schedule_p
   {
     const int i_seq = g / (p.num_layers * p.num_kv_heads);
     const uint32_t Tstar = ws.seq_prefix[i_seq];
+    if (tid < 4) {                                   // the four lookups in parallel (latency)
+      const uint32_t ds = (Tstar >> (24 - 8 * tid)) & 0xFFu;
+      bc[tid] = ds ? ws.cum[((int64_t)tid * G + g) * RADIX + ds - 1] : 0u;
+    }
+    __syncthreads();
     if (tid == 0) {
       uint32_t L = 0;
       int rstar = 4;
       uint32_t base_rank = 0;
       for (int r = 0; r < 4; ++r) {
-        const uint32_t ds = (Tstar >> (24 - 8 * r)) & 0xFFu;
-        const uint32_t below = ds ? ws.cum[((int64_t)r * G + g) * RADIX + ds - 1] : 0u;
+        const uint32_t below = bc[r];
         if (cnt <= L + below) { rstar = r; base_rank = L; break; }
         L += below;
       }
