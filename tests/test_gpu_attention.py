@@ -94,6 +94,8 @@ def test_decode_attention_matches_reference_twin(case, version, attn_mode):
     (1, 40, 2, 128, 16, 50, 600, "f16", False),          # qpk 20 -> two query groups
     (2, 8, 2, 256, 16, 20, 530, "bf16", False),
     (2, 6, 2, 96, 32, 20, 530, "f16", False),
+    (1, 16, 2, 128, 16, 3000, 4100, "f16", False),       # qpk 8 at a 4k cap: 8-wave single pass
+    (1, 4, 1, 128, 16, 6000, 8300, "bf16", False),       # qpk 4 at 8k: 8-wave single pass
 ])
 def test_decode_attention_matches_oracle(shape, attn_mode):
     S, Hq, Hkv, hd, bs, lo, hi, dt, alibi = shape
@@ -266,7 +268,7 @@ def test_decode_attention_fp8_cache(kind, bs, dt, scales, attn_mode):
 
 
 @pytest.mark.parametrize("shape", [(3, 8, 2, 128, 16, 1, 700, "f16"), (2, 16, 2, 128, 32, 100, 1300, "bf16"),
-                                   (2, 6, 2, 64, 16, 10, 400, "f16")])
+                                   (2, 6, 2, 64, 16, 10, 400, "f16"), (1, 16, 2, 128, 16, 2500, 4100, "f16")])
 @pytest.mark.parametrize("use_l2", [True, False])
 def test_decode_attention_fused_metric_aggregation(shape, use_l2, attn_mode):
     """metrics += sum_q p^2 inside the attention == kv_metric_out + aggregate_decode, bit for

@@ -34,6 +34,13 @@ def main():
             r = run(S, ctx, fused=True)
             res.append(r)
             print(json.dumps(r))
+        # Llama-3-70B heads (64 query / 8 KV, qpk 8) at a 4k cap, and qpk 4 at an 8k cap: the
+        # 8-wave single-pass schedule
+        for (S, ctx, hq) in ((128, 4097, 64), (128, 8193, 32)):
+            for rec in (True, False):
+                r = run(S, ctx, Hq=hq, record=rec)
+                res.append(r)
+                print(json.dumps(r))
         for kvd, bs, ks in (("fp8_e4m3", 16, 1.0), ("fp8_e5m2", 32, 1.0), ("fp8_e4m3", 16, 0.01)):
             r = run(256, 4097, bs=bs, kv_dtype=kvd, k_scale=ks)
             res.append(r)

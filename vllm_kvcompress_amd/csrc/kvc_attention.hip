@@ -157,6 +157,27 @@ __device__ __forceinline__ float metric_term(float acc, float p, int use_l2) {
   return __fadd_rn(acc, use_l2 ? __fmul_rn(p, p) : p);
 }
 
+// one token's metric row: the nq weights val(q) of query heads q0 .. q0 + nq - 1 either go to
+// mo[slot, q0 + q] (16-byte non-temporal stores when rows of 4 heads are aligned: a plain store
+// allocates in L2 and costs 15 % of the whole kernel) or are folded into metrics[slot]
+template <typename F>
+__device__ __forceinline__ void put_metric_row(const AttnArgs& a, float* mo, bool fuse, int64_t slot,
+                                               int qpk, int q0, int nq, F val) {
+  if (fuse) {
+    float acc = 0.0f;
+    for (int q = 0; q < nq; ++q) acc = metric_term(acc, val(q), a.use_l2);
+    a.fused_metrics[slot] = __fadd_rn(a.fused_metrics[slot], acc);
+  } else if (((qpk | nq) & 3) == 0) {
+    for (int q = 0; q < nq; q += 4) {
+      f32x4 v;
+      v[0] = val(q); v[1] = val(q + 1); v[2] = val(q + 2); v[3] = val(q + 3);
+      __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(mo + slot * qpk + q0 + q));
+    }
+  } else {
+    for (int q = 0; q < nq; ++q) __builtin_nontemporal_store(val(q), mo + slot * qpk + q0 + q);
+  }
+}
+
 __device__ __forceinline__ float group_max(float v) {     // over the 4 lanes sharing lane&15
   v = fmaxf(v, __shfl_xor(v, 16, 64));
   return fmaxf(v, __shfl_xor(v, 32, 64));
@@ -369,41 +390,17 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
     const int max_pos = a.last_position[seq] - a.kv_metric_buffer_len[seq];     // .cu:124
     float* mo = single ? a.kv_metric_out : a.tmp_kv_metric_out;
     const bool fuse = single && a.fused_metrics != nullptr;    // else: the rescale pass accumulates
-    const bool vec4 = nq == 4 && qpk == 4;
-    f32x4 inv4 = {0.f, 0.f, 0.f, 0.f};
-    if (vec4) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        inv4[q] = __fdividef(1.0f, red_sum[0][q] + red_sum[1][q] + red_sum[2][q] + red_sum[3][q] + 1e-6f);
-    }
+    // per-query normaliser, once per workgroup (row q of red_max is free again: reuse it)
+    __syncthreads();
+    if (tid < nq) red_max[0][tid] = __fdividef(1.0f, red_sum[0][tid] + red_sum[1][tid] + red_sum[2][tid] + red_sum[3][tid] + 1e-6f);
+    __syncthreads();
+    const float* inv_q = red_max[0];
 #pragma unroll
     for (int k = 0; k < ATT_CHUNK / 64; ++k) {
       const int tl = k * 64 + lane;
-      const int64_t slot = mslot[k];
       if (mpos[k] > max_pos) continue;                     // .cu:305-312 (also: token >= ctx)
-      if (vec4) {
-        f32x4 v;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = __fmul_rn(pw[q * ROW + tl], inv4[q]);
-        if (fuse) {
-          float acc = 0.0f;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc = metric_term(acc, v[q], a.use_l2);
-          a.fused_metrics[slot] = __fadd_rn(a.fused_metrics[slot], acc);
-        } else {
-          // streamed once: a plain store allocates in L2 and costs 15 % of the whole kernel
-          __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(mo + slot * 4));
-        }
-      } else {
-        float acc = 0.0f;
-        for (int q = 0; q < nq; ++q) {
-          const float iq = __fdividef(1.0f, red_sum[0][q] + red_sum[1][q] + red_sum[2][q] + red_sum[3][q] + 1e-6f);
-          const float v = __fmul_rn(pw[q * ROW + tl], iq);
-          if (fuse) acc = metric_term(acc, v, a.use_l2);
-          else __builtin_nontemporal_store(v, mo + slot * qpk + q0 + q);
-        }
-        if (fuse) a.fused_metrics[slot] = __fadd_rn(a.fused_metrics[slot], acc);
-      }
+      put_metric_row(a, mo, fuse, mslot[k], qpk, q0, nq,
+                     [&](int q) { return __fmul_rn(pw[q * ROW + tl], inv_q[q]); });
     }
   }
 }
@@ -416,13 +413,18 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
 // (two workgroups per CU: qpk * max_context * 4 B <= ~68 KiB - the continual-compression
 // regime, e.g. 4k-token caps at qpk 4) and there are enough (sequence, KV head) pairs to fill the chip.
 // dynamic LDS: P [nqr][prow] | O [4][nqr][HD] | mrec [niter][4][16]
-template <typename T, int HD, int BS, int KVD>
-__global__ __launch_bounds__(256) KVC_WHOLE_ATTR void paged_attention_decode_whole_kernel(AttnArgs a, int prow, int niter_max) {
+template <typename T, int HD, int BS, int KVD, int NW>
+__global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode_whole_kernel(AttnArgs a, int prow, int niter_max) {
   using M = Mma<T>;
   using V8 = typename M::V8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ float red_max[ATT_WAVES][ATT_NQ];
-  __shared__ float red_sum[ATT_WAVES][ATT_NQ];
+  __shared__ float red_max[NW][ATT_NQ];
+  __shared__ float red_sum[NW][ATT_NQ];
+  constexpr int STEP = NW * ATT_CHUNK;                    // tokens per workgroup iteration
+  auto wg_max = [&](int q) { float v = red_max[0][q];
+#pragma unroll
+    for (int ww = 1; ww < NW; ++ww) v = fmaxf(v, red_max[ww][q]);
+    return v; };
   constexpr int KS = HD / 32;
   constexpr int DT = HD / 16;
   const int qpk = a.num_heads / a.num_kv_heads;
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(256) KVC_WHOLE_ATTR void paged_attention_decode_who
   const int ctx = min(a.context_lens[seq * a.num_kv_heads + hk], a.max_ctx);
   if (ctx <= 0) {                                         // empty head: zero output (see above)
     const int q0e = qg * ATT_NQ, nqe = min(ATT_NQ, qpk - q0e);
-    for (int idx = threadIdx.x; idx < nqe * HD; idx += 256)
+    for (int idx = threadIdx.x; idx < nqe * HD; idx += 64 * NW)
       reinterpret_cast<T*>(a.out)[((int64_t)seq * a.num_heads + hk * qpk + q0e + idx / HD) * HD + idx % HD] = (T)0.0f;
     return;
   }
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(256) KVC_WHOLE_ATTR void paged_attention_decode_who
   const int head0 = hk * qpk + q0;
   float* P = lds;                                          // [nqr][prow]
   float* Ol = lds + (int64_t)nqr * prow;                   // [4][nqr][HD]
-  float* mrec = Ol + (int64_t)ATT_WAVES * nqr * HD;        // [niter_max][4][16]
+  float* mrec = Ol + (int64_t)NW * nqr * HD;               // [niter_max][NW][16]
 
   V8 qf[KS];
   {
@@ -466,9 +468,9 @@ __global__ __launch_bounds__(256) KVC_WHOLE_ATTR void paged_attention_decode_who
 #pragma unroll
   for (int i = 0; i < DT; ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.0f;
-  const int niter = (ctx + ATT_PART - 1) / ATT_PART;
+  const int niter = (ctx + STEP - 1) / STEP;
   for (int it = 0; it < niter; ++it) {
-    const int tok_w0 = it * ATT_PART + w * ATT_CHUNK;
+    const int tok_w0 = it * STEP + w * ATT_CHUNK;
     if (tok_w0 >= ctx) break;                              // wave-uniform
     // ---- QK^T, K fragments prefetched KVC_PF sub-blocks ahead (two waves per SIMD live here,
     // so the wave itself has to keep enough loads in flight; the scheduler is pinned with
@@ -529,7 +531,7 @@ __global__ __launch_bounds__(256) KVC_WHOLE_ATTR void paged_attention_decode_who
     }
     l_run = l_run * alpha + group_sum(lsum);
     m_run = m_new;
-    if (g == 0) mrec[(it * ATT_WAVES + w) * ATT_NQ + c] = m_new;
+    if (g == 0) mrec[(it * NW + w) * ATT_NQ + c] = m_new;
 #pragma unroll
     for (int i = 0; i < DT; ++i) O[i] *= alpha;
     // ---- P.V, V fragments one 32-token pair ahead
@@ -584,12 +586,12 @@ __global__ __launch_bounds__(256) KVC_WHOLE_ATTR void paged_attention_decode_who
       *reinterpret_cast<f32x4*>(Ol + ((int64_t)w * nqr + c) * HD + 16 * i + 4 * g) = O[i];
   }
   __syncthreads();
-  for (int idx = tid; idx < nq * HD; idx += 256) {
+  for (int idx = tid; idx < nq * HD; idx += 64 * NW) {
     const int qq = idx / HD, d = idx % HD;
-    const float Mq = fmaxf(fmaxf(red_max[0][qq], red_max[1][qq]), fmaxf(red_max[2][qq], red_max[3][qq]));
+    const float Mq = wg_max(qq);
     float o = 0.0f, Lq = 0.0f;
 #pragma unroll
-    for (int ww = 0; ww < ATT_WAVES; ++ww) {
+    for (int ww = 0; ww < NW; ++ww) {
       const float sc = red_max[ww][qq] == -INFINITY ? 0.0f : __expf(red_max[ww][qq] - Mq);
       o += Ol[((int64_t)ww * nqr + qq) * HD + d] * sc;
       Lq += red_sum[ww][qq] * sc;
@@ -601,60 +603,41 @@ __global__ __launch_bounds__(256) KVC_WHOLE_ATTR void paged_attention_decode_who
   // ---- metrics: p = p~ * exp(m_used - M) / (L + 1e-6), one lane per token, written once
   if (a.record) {
     const int max_pos = a.last_position[seq] - a.kv_metric_buffer_len[seq];
-    const bool vec4 = nq == 4 && qpk == 4;
-    // per query: global max and normaliser (lanes q < nq of every wave compute their own copy)
-    float Mq[4] = {0.f, 0.f, 0.f, 0.f}, Iq[4] = {0.f, 0.f, 0.f, 0.f};
-    if (vec4) {
+    // per query: global max M and normaliser 1 / (L + 1e-6), once per workgroup, then per wave
+    // and iteration the factor exp(m_used - M) / (L + 1e-6) of each query head
+    __shared__ float fin_m[ATT_NQ], fin_i[ATT_NQ], wfac[NW][ATT_NQ];
+    if (tid < nq) {
+      const float Mg = wg_max(tid);
+      float L = 0.0f;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        Mq[q] = fmaxf(fmaxf(red_max[0][q], red_max[1][q]), fmaxf(red_max[2][q], red_max[3][q]));
-        float L = 0.0f;
-#pragma unroll
-        for (int ww = 0; ww < ATT_WAVES; ++ww)
-          L += red_max[ww][q] == -INFINITY ? 0.0f : red_sum[ww][q] * __expf(red_max[ww][q] - Mq[q]);
-        Iq[q] = __fdividef(1.0f, L + 1e-6f);
-      }
+      for (int ww = 0; ww < NW; ++ww)
+        L += red_max[ww][tid] == -INFINITY ? 0.0f : red_sum[ww][tid] * __expf(red_max[ww][tid] - Mg);
+      fin_m[tid] = Mg;
+      fin_i[tid] = __fdividef(1.0f, L + 1e-6f);
     }
+    __syncthreads();
+    const bool fuse = a.fused_metrics != nullptr;
     for (int it = 0; it < niter; ++it) {
-      const int tok_w0 = it * ATT_PART + w * ATT_CHUNK;
+      const int tok_w0 = it * STEP + w * ATT_CHUNK;
       if (tok_w0 >= ctx) break;
-      const float* mr = mrec + (it * ATT_WAVES + w) * ATT_NQ;
+      const float* mr = mrec + (it * NW + w) * ATT_NQ;
+      if (lane < nq) wfac[w][lane] = __expf(mr[lane] - fin_m[lane]) * fin_i[lane];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const float* fq = wfac[w];
 #pragma unroll
       for (int k = 0; k < ATT_CHUNK / 64; ++k) {
         const int tok = tok_w0 + k * 64 + lane;
         if (tok >= ctx) continue;
         const int64_t slot = (int64_t)bt[tok / BS] * BS + (tok % BS);
         if (a.kv_position[slot] > max_pos) continue;
-        if (vec4) {
-          f32x4 v;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = __fmul_rn(P[q * prow + tok], __expf(mr[q] - Mq[q]) * Iq[q]);
-          if (a.fused_metrics != nullptr) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc = metric_term(acc, v[q], a.use_l2);
-            a.fused_metrics[slot] = __fadd_rn(a.fused_metrics[slot], acc);
-          } else {
-            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.kv_metric_out + slot * 4));
-          }
-        } else {
-          float acc = 0.0f;
-          for (int q = 0; q < nq; ++q) {
-            const float Mg = fmaxf(fmaxf(red_max[0][q], red_max[1][q]), fmaxf(red_max[2][q], red_max[3][q]));
-            float L = 0.0f;
-            for (int ww = 0; ww < ATT_WAVES; ++ww)
-              L += red_max[ww][q] == -INFINITY ? 0.0f : red_sum[ww][q] * __expf(red_max[ww][q] - Mg);
-            const float v = __fmul_rn(P[q * prow + tok], __expf(mr[q] - Mg) * __fdividef(1.0f, L + 1e-6f));
-            if (a.fused_metrics != nullptr) acc = metric_term(acc, v, a.use_l2);
-            else __builtin_nontemporal_store(v, a.kv_metric_out + slot * qpk + q0 + q);
-          }
-          if (a.fused_metrics != nullptr) a.fused_metrics[slot] = __fadd_rn(a.fused_metrics[slot], acc);
-        }
+        put_metric_row(a, a.kv_metric_out, fuse, slot, qpk, q0, nq,
+                       [&](int q) { return __fmul_rn(P[q * prow + tok], fq[q]); });
       }
+      __builtin_amdgcn_wave_barrier();               // wfac[w] is rewritten by the next iteration
     }
   }
 }
-
 
 // second pass for heads with more than one partition            .cu:532-651
 template <typename T, int HD, int BS>
@@ -759,39 +742,44 @@ __global__ __launch_bounds__(256) void paged_attention_metric_rescale_kernel(Att
   const int max_pos = a.last_position[seq] - a.kv_metric_buffer_len[seq];
   const int32_t* bt = a.block_tables + (int64_t)(seq * a.num_kv_heads + hk) * a.max_blocks;
   constexpr int K = ATT_RS_TOK / 256;
-  if (qpk == 4) {
+  const bool fuse = a.fused_metrics != nullptr;
+  if ((qpk & 3) == 0 && !(fuse && qpk != 4)) {
     // all address loads, then all position + tmp loads, then the stores: four independent
-    // chains per lane keep enough bytes in flight for a pass that is pure streaming
+    // chains per lane keep enough bytes in flight for a pass that is pure streaming; query
+    // heads go in aligned groups of four (16-byte rows)
     int64_t slot[K];
     bool ok[K];
+    int posv[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int i = chunk * ATT_RS_TOK + k * 256 + tid;
       ok[k] = i < ctx;
       slot[k] = ok[k] ? (int64_t)bt[i / BS] * BS + (i % BS) : 0;
     }
-    int posv[K];
-    f32x4 t[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      posv[k] = ok[k] ? a.kv_position[slot[k]] : 0x7FFFFFFF;
-      t[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (ok[k]) t[k] = *reinterpret_cast<const f32x4*>(a.tmp_kv_metric_out + slot[k] * 4);
-    }
+    for (int k = 0; k < K; ++k) posv[k] = ok[k] ? a.kv_position[slot[k]] : 0x7FFFFFFF;
+    for (int qb = 0; qb < qpk; qb += 4) {
+      f32x4 t[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      if (!ok[k] || posv[k] > max_pos) continue;
-      const int pj = (chunk * ATT_RS_TOK + k * 256 + tid) / ATT_PART - p0;
-      f32x4 v = t[k];
+      for (int k = 0; k < K; ++k) {
+        t[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok[k]) t[k] = *reinterpret_cast<const f32x4*>(a.tmp_kv_metric_out + slot[k] * qpk + qb);
+      }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = __fmul_rn(v[q], fac[2 * q + pj]);
-      if (a.fused_metrics != nullptr) {
-        float acc = 0.0f;
+      for (int k = 0; k < K; ++k) {
+        if (!ok[k] || posv[k] > max_pos) continue;
+        const int pj = (chunk * ATT_RS_TOK + k * 256 + tid) / ATT_PART - p0;
+        f32x4 v = t[k];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc = metric_term(acc, v[q], a.use_l2);
-        a.fused_metrics[slot[k]] = __fadd_rn(a.fused_metrics[slot[k]], acc);
-      } else {
-        *reinterpret_cast<f32x4*>(a.kv_metric_out + slot[k] * 4) = v;
+        for (int q = 0; q < 4; ++q) v[q] = __fmul_rn(v[q], fac[2 * (qb + q) + pj]);
+        if (fuse) {                                  // qpk == 4 here
+          float acc = 0.0f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc = metric_term(acc, v[q], a.use_l2);
+          a.fused_metrics[slot[k]] = __fadd_rn(a.fused_metrics[slot[k]], acc);
+        } else {
+          *reinterpret_cast<f32x4*>(a.kv_metric_out + slot[k] * qpk + qb) = v;
+        }
       }
     }
   } else {
@@ -804,10 +792,10 @@ __global__ __launch_bounds__(256) void paged_attention_metric_rescale_kernel(Att
       float acc = 0.0f;
       for (int q = 0; q < qpk; ++q) {
         const float v = __fmul_rn(a.tmp_kv_metric_out[slot * qpk + q], fac[q * 2 + pj]);
-        if (a.fused_metrics != nullptr) acc = metric_term(acc, v, a.use_l2);
+        if (fuse) acc = metric_term(acc, v, a.use_l2);
         else a.kv_metric_out[slot * qpk + q] = v;
       }
-      if (a.fused_metrics != nullptr) a.fused_metrics[slot] = __fadd_rn(a.fused_metrics[slot], acc);
+      if (fuse) a.fused_metrics[slot] = __fadd_rn(a.fused_metrics[slot], acc);
     }
   }
 }
@@ -819,22 +807,34 @@ static int launch_attention(const AttnArgs& a, int num_seqs, hipStream_t s) {
   const int qpk = a.num_heads / a.num_kv_heads;
   const int ngroups = (qpk + ATT_NQ - 1) / ATT_NQ;
   const int nqr = qpk < ATT_NQ ? qpk : ATT_NQ;
-  // single pass: weights of the longest context in LDS (<= 72 KiB) and >= 2 workgroups per CU
+  // single pass: the fp32 weights of the longest context in LDS; 4 waves with two workgroups
+  // per CU when that fits (<= 79 KiB each), else 8 waves with one workgroup per CU
   // row = the longest context rounded to a wave chunk, + 4 to stagger the query rows over the banks
   const int prow = (a.max_ctx + ATT_CHUNK - 1) / ATT_CHUNK * ATT_CHUNK + 4;
-  const size_t whole_lds = ((size_t)nqr * prow + (size_t)ATT_WAVES * nqr * HD +
-                            (size_t)a.max_parts * ATT_WAVES * ATT_NQ) * sizeof(float);
-  // two workgroups per CU (160 KiB of LDS); a single partition is already one pass
-  const bool whole_fits = whole_lds <= 79 * 1024 && a.max_parts > 1;
+  auto whole_bytes = [&](int nw) {
+    const int niter = (a.max_ctx + nw * ATT_CHUNK - 1) / (nw * ATT_CHUNK);
+    return ((size_t)nqr * prow + (size_t)nw * nqr * HD + (size_t)niter * nw * ATT_NQ) * sizeof(float);
+  };
+  const int nw = whole_bytes(4) <= 79 * 1024 ? 4 : 8;
+  const size_t whole_lds = whole_bytes(nw);
+  const bool whole_fits = a.max_parts > 1 && whole_lds <= (nw == 4 ? 79 : 155) * 1024;   // 1 partition is one pass anyway
+  const int64_t wgs = (int64_t)num_seqs * a.num_kv_heads * ngroups;
   const bool whole = g_attention_mode == 2 ? whole_fits
-                   : (g_attention_mode == 1 ? false
-                      : (whole_fits && (int64_t)num_seqs * a.num_kv_heads * ngroups >= 512));
+                   : (g_attention_mode == 1 ? false : (whole_fits && wgs >= (nw == 4 ? 512 : 256)));
   if (whole) {
-    if (whole_lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(paged_attention_decode_whole_kernel<T, HD, BS, KVD>),
+    const int niter = (a.max_ctx + nw * ATT_CHUNK - 1) / (nw * ATT_CHUNK);
+    if (nw == 4) {
+      if (whole_lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(paged_attention_decode_whole_kernel<T, HD, BS, KVD, 4>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)whole_lds);
+      hipLaunchKernelGGL((paged_attention_decode_whole_kernel<T, HD, BS, KVD, 4>), dim3(a.num_kv_heads * ngroups, num_seqs),
+                         dim3(256), whole_lds, s, a, prow, niter);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(paged_attention_decode_whole_kernel<T, HD, BS, KVD, 8>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)whole_lds);
-    hipLaunchKernelGGL((paged_attention_decode_whole_kernel<T, HD, BS, KVD>), dim3(a.num_kv_heads * ngroups, num_seqs),
-                       dim3(256), whole_lds, s, a, prow, a.max_parts);
+      hipLaunchKernelGGL((paged_attention_decode_whole_kernel<T, HD, BS, KVD, 8>), dim3(a.num_kv_heads * ngroups, num_seqs),
+                         dim3(512), whole_lds, s, a, prow, niter);
+    }
     return check_launch("paged_attention_decode");
   }
   if (a.max_parts > 1 && (a.exp_sums == nullptr || a.max_logits == nullptr || a.tmp_out == nullptr ||
