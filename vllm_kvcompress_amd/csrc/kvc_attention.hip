@@ -450,7 +450,7 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
   const int head0 = hk * qpk + q0;
   float* P = lds;                                          // [nqr][prow]
   float* Ol = lds + (int64_t)nqr * prow;                   // [4][nqr][HD]
-  float* mrec = Ol + (int64_t)NW * nqr * HD;               // [niter_max][NW][16]
+  float* mrec = Ol + (int64_t)4 * nqr * HD;                // [niter_max][NW][16]
 
   V8 qf[KS];
   {
@@ -578,26 +578,50 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
     }
   }
 
-  // ---- combine the four waves: each has its own running max
+  // ---- combine the waves (each has its own running max), four at a time through the
+  // [4][nqr][HD] output region so that the 8-wave variant needs no more LDS than the 4-wave one
   if (g == 0) { red_max[w][c] = m_run; red_sum[w][c] = l_run; }
-  if (c < nq) {
+  constexpr int OUTS = (ATT_NQ * HD + 64 * NW - 1) / (64 * NW);    // outputs per thread (upper bound)
+  float oacc[OUTS];
 #pragma unroll
-    for (int i = 0; i < DT; ++i)
-      *reinterpret_cast<f32x4*>(Ol + ((int64_t)w * nqr + c) * HD + 16 * i + 4 * g) = O[i];
-  }
-  __syncthreads();
-  for (int idx = tid; idx < nq * HD; idx += 64 * NW) {
-    const int qq = idx / HD, d = idx % HD;
-    const float Mq = wg_max(qq);
-    float o = 0.0f, Lq = 0.0f;
+  for (int k = 0; k < OUTS; ++k) oacc[k] = 0.0f;
 #pragma unroll
-    for (int ww = 0; ww < NW; ++ww) {
-      const float sc = red_max[ww][qq] == -INFINITY ? 0.0f : __expf(red_max[ww][qq] - Mq);
-      o += Ol[((int64_t)ww * nqr + qq) * HD + d] * sc;
-      Lq += red_sum[ww][qq] * sc;
+  for (int hlf = 0; hlf < NW / 4; ++hlf) {
+    if (w / 4 == hlf && c < nq) {
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+        *reinterpret_cast<f32x4*>(Ol + ((int64_t)(w % 4) * nqr + c) * HD + 16 * i + 4 * g) = O[i];
     }
-    o *= __fdividef(1.0f, Lq + 1e-6f);
-    reinterpret_cast<T*>(a.out)[((int64_t)seq * a.num_heads + head0 + qq) * HD + d] = (T)o;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < OUTS; ++k) {
+      const int idx = tid + k * 64 * NW;
+      if (idx < nq * HD) {
+        const int qq = idx / HD, d = idx % HD;
+        const float Mq = wg_max(qq);
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+          const float mw = red_max[4 * hlf + ww][qq];
+          const float sc = mw == -INFINITY ? 0.0f : __expf(mw - Mq);
+          oacc[k] += Ol[((int64_t)ww * nqr + qq) * HD + d] * sc;
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < OUTS; ++k) {
+    const int idx = tid + k * 64 * NW;
+    if (idx < nq * HD) {
+      const int qq = idx / HD, d = idx % HD;
+      const float Mq = wg_max(qq);
+      float Lq = 0.0f;
+#pragma unroll
+      for (int ww = 0; ww < NW; ++ww)
+        Lq += red_max[ww][qq] == -INFINITY ? 0.0f : red_sum[ww][qq] * __expf(red_max[ww][qq] - Mq);
+      reinterpret_cast<T*>(a.out)[((int64_t)seq * a.num_heads + head0 + qq) * HD + d] =
+          (T)(oacc[k] * __fdividef(1.0f, Lq + 1e-6f));
+    }
   }
 
   // ---- metrics: p = p~ * exp(m_used - M) / (L + 1e-6), one lane per token, written once
@@ -813,7 +837,7 @@ static int launch_attention(const AttnArgs& a, int num_seqs, hipStream_t s) {
   const int prow = (a.max_ctx + ATT_CHUNK - 1) / ATT_CHUNK * ATT_CHUNK + 4;
   auto whole_bytes = [&](int nw) {
     const int niter = (a.max_ctx + nw * ATT_CHUNK - 1) / (nw * ATT_CHUNK);
-    return ((size_t)nqr * prow + (size_t)nw * nqr * HD + (size_t)niter * nw * ATT_NQ) * sizeof(float);
+    return ((size_t)nqr * prow + (size_t)4 * nqr * HD + (size_t)niter * nw * ATT_NQ) * sizeof(float);
   };
   const int nw = whole_bytes(4) <= 79 * 1024 ? 4 : 8;
   const size_t whole_lds = whole_bytes(nw);
