@@ -320,6 +320,11 @@ typedef struct kvc_attention_params {
 } kvc_attention_params;
 
 int kvc_paged_attention_decode(const kvc_attention_params* p, kvc_stream_t stream);
+/* 1 if a call with these sizes goes through the partition buffers (exp_sums, max_logits, tmp_out,
+ * tmp_kv_metric_out), 0 if it finishes in one kernel and they may be NULL. */
+int32_t kvc_paged_attention_decode_uses_partitions(int32_t num_seqs, int32_t num_heads,
+                                                   int32_t num_kv_heads, int32_t head_size,
+                                                   int32_t max_context_len);
 
 #ifdef __cplusplus
 }

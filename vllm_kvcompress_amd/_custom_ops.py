@@ -298,7 +298,7 @@ def paged_attention_kvc_v1(out, kv_metric_out, query, key_cache, value_cache, nu
     one workgroup's shared memory; here long contexts are always partitioned, so the
     partition buffers the v1 signature does not carry come from the wrapper's scratch."""
     exp_sum, max_logits, tmp_out, tmp_metric = _partition_scratch(
-        query, max_context_len, kv_metric_out.numel() if record_kv_metrics else 0, "attn_v1")
+        query, num_kv_heads, max_context_len, kv_metric_out.numel() if record_kv_metrics else 0, "attn_v1")
     _paged_attention_kvc(out, kv_metric_out, exp_sum, max_logits, tmp_out, tmp_metric, query,
                          key_cache, value_cache, num_kv_heads, scale, block_tables, context_lens,
                          kv_position, last_position, kv_metric_buffer_len, block_size,
@@ -306,11 +306,12 @@ def paged_attention_kvc_v1(out, kv_metric_out, query, key_cache, value_cache, nu
                          record_kv_metrics)
 
 
-def _partition_scratch(query, max_context_len, metric_numel, tag):
+def _partition_scratch(query, num_kv_heads, max_context_len, metric_numel, tag):
     num_seqs, num_heads, head_size = query.shape
     parts = (int(max_context_len) + _ATTN_PARTITION - 1) // _ATTN_PARTITION
-    if parts <= 1:
-        return None, None, None, None
+    if parts <= 1 or not _lib.load().kvc_paged_attention_decode_uses_partitions(
+            num_seqs, num_heads, int(num_kv_heads), head_size, int(max_context_len)):
+        return None, None, None, None      # one kernel finishes the call: no scratch at all
     n = num_seqs * num_heads * parts
     buf = workspace(query.device, n * 8 + n * head_size * query.element_size() + 256, tag)
     exp_sum = buf[:n * 4].view(torch.float32)
@@ -335,7 +336,8 @@ def paged_attention_kvc_fused_metrics(out, metrics, query, key_cache, value_cach
     ``kv_metric_out`` + ``CompressionMetrics.aggregate_decode`` + ``clear_temp_metrics`` do
     together (metrics.py:429-439, 337-342), bit for bit, without the [NB, bs, qpk] buffer."""
     qpk = query.shape[1] // int(num_kv_heads)
-    es, ml, to, tm = _partition_scratch(query, max_context_len, metrics.numel() * qpk, "attn_fused")
+    es, ml, to, tm = _partition_scratch(query, num_kv_heads, max_context_len, metrics.numel() * qpk,
+                                        "attn_fused")
     _paged_attention_kvc(out, None, es, ml, to, tm, query, key_cache, value_cache, num_kv_heads,
                          scale, block_tables, context_lens, kv_position, last_position,
                          kv_metric_buffer_len, block_size, max_context_len, alibi_slopes,

@@ -826,25 +826,40 @@ __global__ __launch_bounds__(256) void paged_attention_metric_rescale_kernel(Att
 
 static int g_attention_mode = 0;      // 0 auto, 1 partitioned, 2 single pass (kvc_debug_set_attention_mode)
 
+// which schedule a call takes (shared by the launcher and kvc_paged_attention_decode_uses_partitions)
+struct AttnPlan { bool whole; int nw, prow; size_t whole_lds; };
+static AttnPlan attention_plan(int num_seqs, int num_heads, int num_kv_heads, int head_size, int max_ctx) {
+  const int qpk = num_heads / num_kv_heads;
+  const int ngroups = (qpk + ATT_NQ - 1) / ATT_NQ;
+  const int nqr = qpk < ATT_NQ ? qpk : ATT_NQ;
+  const int max_parts = (max_ctx + ATT_PART - 1) / ATT_PART;
+  // single pass: the fp32 weights of the longest context in LDS; 4 waves with two workgroups
+  // per CU when that fits (<= 79 KiB each), else 8 waves with one workgroup per CU.
+  // row = the longest context rounded to a wave chunk, + 4 to stagger the query rows over the banks
+  AttnPlan p;
+  p.prow = (max_ctx + ATT_CHUNK - 1) / ATT_CHUNK * ATT_CHUNK + 4;
+  auto whole_bytes = [&](int nw) {
+    const int niter = (max_ctx + nw * ATT_CHUNK - 1) / (nw * ATT_CHUNK);
+    return ((size_t)nqr * p.prow + (size_t)4 * nqr * head_size + (size_t)niter * nw * ATT_NQ) * sizeof(float);
+  };
+  p.nw = whole_bytes(4) <= 79 * 1024 ? 4 : 8;
+  p.whole_lds = whole_bytes(p.nw);
+  const bool fits = max_parts > 1 && p.whole_lds <= (size_t)(p.nw == 4 ? 79 : 155) * 1024;   // 1 partition is one pass anyway
+  const int64_t wgs = (int64_t)num_seqs * num_kv_heads * ngroups;
+  p.whole = g_attention_mode == 2 ? fits
+          : (g_attention_mode == 1 ? false : (fits && wgs >= (p.nw == 4 ? 512 : 256)));
+  return p;
+}
+
 template <typename T, int HD, int BS, int KVD>
 static int launch_attention(const AttnArgs& a, int num_seqs, hipStream_t s) {
   const int qpk = a.num_heads / a.num_kv_heads;
   const int ngroups = (qpk + ATT_NQ - 1) / ATT_NQ;
   const int nqr = qpk < ATT_NQ ? qpk : ATT_NQ;
-  // single pass: the fp32 weights of the longest context in LDS; 4 waves with two workgroups
-  // per CU when that fits (<= 79 KiB each), else 8 waves with one workgroup per CU
-  // row = the longest context rounded to a wave chunk, + 4 to stagger the query rows over the banks
-  const int prow = (a.max_ctx + ATT_CHUNK - 1) / ATT_CHUNK * ATT_CHUNK + 4;
-  auto whole_bytes = [&](int nw) {
-    const int niter = (a.max_ctx + nw * ATT_CHUNK - 1) / (nw * ATT_CHUNK);
-    return ((size_t)nqr * prow + (size_t)4 * nqr * HD + (size_t)niter * nw * ATT_NQ) * sizeof(float);
-  };
-  const int nw = whole_bytes(4) <= 79 * 1024 ? 4 : 8;
-  const size_t whole_lds = whole_bytes(nw);
-  const bool whole_fits = a.max_parts > 1 && whole_lds <= (nw == 4 ? 79 : 155) * 1024;   // 1 partition is one pass anyway
-  const int64_t wgs = (int64_t)num_seqs * a.num_kv_heads * ngroups;
-  const bool whole = g_attention_mode == 2 ? whole_fits
-                   : (g_attention_mode == 1 ? false : (whole_fits && wgs >= (nw == 4 ? 512 : 256)));
+  const AttnPlan plan = attention_plan(num_seqs, a.num_heads, a.num_kv_heads, HD, a.max_ctx);
+  const int prow = plan.prow, nw = plan.nw;
+  const size_t whole_lds = plan.whole_lds;
+  const bool whole = plan.whole;
   if (whole) {
     const int niter = (a.max_ctx + nw * ATT_CHUNK - 1) / (nw * ATT_CHUNK);
     if (nw == 4) {
@@ -883,6 +898,13 @@ static int launch_attention(const AttnArgs& a, int num_seqs, hipStream_t s) {
 }
 
 }  // namespace kvc
+
+extern "C" int32_t kvc_paged_attention_decode_uses_partitions(int32_t num_seqs, int32_t num_heads,
+                                                              int32_t num_kv_heads, int32_t head_size,
+                                                              int32_t max_context_len) {
+  if (num_kv_heads < 1 || num_heads < num_kv_heads || max_context_len <= kvc::ATT_PART) return 0;
+  return kvc::attention_plan(num_seqs, num_heads, num_kv_heads, head_size, max_context_len).whole ? 0 : 1;
+}
 
 // test hook: 0 = automatic choice, 1 = always partitioned, 2 = single pass whenever it fits
 extern "C" void kvc_debug_set_attention_mode(int32_t mode) { kvc::g_attention_mode = mode; }
