@@ -167,10 +167,13 @@ def test_free_compressed_blocks_device(case):
     np.testing.assert_array_equal(seq_by.cpu().numpy() == -1, want)
 
 
-def test_compression_scheduler_mirror_end_to_end():
+@pytest.mark.parametrize("zero_fill", [True, False])
+def test_compression_scheduler_mirror_end_to_end(zero_fill):
     """CompressionScheduler (host glue mirror) over the FULL block state with a subset of
     slots compressing, max_kv_per_compression cut-off, staleness order, persistent move
-    workspace and the device block-state update -- against the oracle driven by hand."""
+    workspace and the device block-state update -- against the oracle driven by hand.
+    ``zero_fill=False`` is the opt-out of the reference's whole-workspace clear: the rows a
+    consumer reads (offset_g .. offset_g + count_g) and everything downstream are unchanged."""
     from vllm_kvcompress_amd.kvcompress.scheduler import CompressionScheduler, SeqCompressionRequest
     L, H, bs, hd = 2, 4, 16, 128
     seq_lens = [200, 130, 77, 161, 90]
@@ -183,7 +186,8 @@ def test_compression_scheduler_mirror_end_to_end():
     ctx_full = torch.from_numpy(st.context_lens.copy()).to(DEV)
     free_mask = torch.from_numpy(st.seq_index_by_block < 0).to(DEV)
     total_rows = 40000
-    sched = CompressionScheduler(bs, L, H, total_rows, ds.cm, device=DEV)
+    sched = CompressionScheduler(bs, L, H, total_rows, ds.cm, device=DEV, zero_fill_moves=zero_fill)
+    sched.cache_move_indices.fill_(-7)                 # stale junk from earlier iterations
     nblk = ((st.context_lens.astype(np.int64) + bs - 1) // bs).sum(0).sum(-1)
     kvs = st.context_lens.astype(np.int64).sum(0).sum(-1)
     reqs = [SeqCompressionRequest(seq_id=100 + i, slot_index=i, seq_len=seq_lens[i],
@@ -216,8 +220,13 @@ def test_compression_scheduler_mirror_end_to_end():
     np.testing.assert_array_equal(out.cache_moves.count.cpu().numpy(), want["cmc"])
     np.testing.assert_array_equal(out.cache_moves.offsets.cpu().numpy(), sub.evicted_kv_offsets)
     got_idx = out.cache_moves.index.cpu().numpy()
-    np.testing.assert_array_equal(got_idx[:N], want["cmi"])
-    assert not got_idx[N:].any()                       # rest of the workspace zero-filled
+    if zero_fill:
+        np.testing.assert_array_equal(got_idx[:N], want["cmi"])
+        assert not got_idx[N:].any()                   # rest of the workspace zero-filled
+    else:
+        offs, cnt = sub.evicted_kv_offsets.reshape(-1), want["cmc"].reshape(-1)
+        for o, c in zip(offs, cnt):
+            np.testing.assert_array_equal(got_idx[o:o + c], want["cmi"][o:o + c])
     np.testing.assert_array_equal(k_t.cpu().numpy(), want["k"])
     np.testing.assert_array_equal(v_t.cpu().numpy(), want["v"])
     np.testing.assert_array_equal(ds.cm.metrics.cpu().numpy(), want["metrics"])

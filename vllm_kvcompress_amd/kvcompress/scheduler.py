@@ -68,7 +68,8 @@ class CompressionScheduler:
     def __init__(self, block_size: int, num_layers: int, num_kv_heads: int,
                  max_kv_per_compression: int, compression_metrics: CompressionMetrics,
                  device: str = "cuda:0", even_layer_evict: bool = False,
-                 compression_interval: int = 1, new_token_limit: int = -1) -> None:
+                 compression_interval: int = 1, new_token_limit: int = -1,
+                 zero_fill_moves: bool = True) -> None:
         self.block_size = block_size
         self.num_layers = num_layers
         self.num_kv_heads = num_kv_heads
@@ -78,6 +79,9 @@ class CompressionScheduler:
         self.even_layer_evict = even_layer_evict
         self.compression_interval = compression_interval
         self.new_token_limit = new_token_limit
+        # the reference clears the WHOLE move workspace every call (_custom_ops.py:1168); nothing
+        # reads rows outside [offset_g, offset_g + count_g), so an engine may opt out (extension)
+        self.zero_fill_moves = zero_fill_moves
         self.iteration_count = 0
         self.new_tokens = 0
         self._iters_since_compression: Dict[int, int] = {}
@@ -177,8 +181,12 @@ class CompressionScheduler:
             slots, last_token_positions, evicted_blocks, ctx, hanging, offsets,
             [r.protected_window_size for r in chosen], total_slots=total_slots)
         cache_moves_count = torch.empty((B, L, H), dtype=torch.int32, device=self.device)
-        ops.schedule_cache_moves(self.cache_move_indices, cache_moves_count, eli, ekc, offsets, bt,
-                                 ctx, bs)                                        # :505-523
+        if self.zero_fill_moves:
+            ops.schedule_cache_moves(self.cache_move_indices, cache_moves_count, eli, ekc, offsets,
+                                     bt, ctx, bs)                                # :505-523
+        else:
+            ops._schedule_t1_cache_moves(self.cache_move_indices, cache_moves_count, eli, ekc,
+                                         offsets, bt, ctx, bs, zero_fill=False)
         cache_moves = CacheMoves(self.cache_move_indices, cache_moves_count, offsets)
         freed_block_count = {r.seq_id: ebc[i] for i, r in enumerate(chosen)}     # :531-534
         for sid in self._iters_since_compression:                                # :92-96
