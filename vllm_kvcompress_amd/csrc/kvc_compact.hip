@@ -37,6 +37,10 @@
 #include "kvc_common.h"
 #include "../../include/kvc_mi355x.h"
 
+#ifndef KVC_RUNS_WGS
+#define KVC_RUNS_WGS 4     // persistent workgroups per CU of the compaction kernel
+#endif
+
 namespace kvc {
 
 constexpr int KVC_TM_GENERIC = 32;    // moves per tile of the generic (byte-wise) kernel
@@ -484,7 +488,7 @@ extern "C" int kvc_execute_cache_moves(void* k_cache, void* v_cache, float* kv_m
   uint8_t* k = reinterpret_cast<uint8_t*>(k_cache);
   uint8_t* v = reinterpret_cast<uint8_t*>(v_cache);
 #define KVC_RUNS(HD, BS, E)                                                                      \
-  hipLaunchKernelGGL((compact_runs_kernel<HD, BS, E>), dim3(256 * 4), dim3(256), 0, s, k, v,     \
+  hipLaunchKernelGGL((compact_runs_kernel<HD, BS, E>), dim3(256 * KVC_RUNS_WGS), dim3(256), 0, s, k, v, \
                      kv_metrics, kv_position, cache_moves_idx, cache_moves_count,                \
                      evicted_kv_offsets, claims, prefix, G, tm, g_compact_phases)
   if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
