@@ -59,6 +59,9 @@ def parse_args():
                          "appended token and is compressed back to the cap (max_cache_tokens)")
     ap.add_argument("--contiguous-blocks", action="store_true",
                     help="physical blocks in allocation order (fresh prefill) instead of shuffled")
+    ap.add_argument("--lean", action="store_true",
+                    help="extension: no MAX_INT padding / key-scratch clear in schedule_evictions and no "
+                         "zero fill of the move workspace (outputs a consumer reads are unchanged)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-adjacent", action="store_true",
                     help="skip the decode-attention (F3) side measurement")
@@ -117,6 +120,7 @@ def build_workload(args, seed, device):
                                        protected_window_size=args.protected, max_cache_tokens=cap)
                for b in range(args.batch)]
     ds = hdev.upload(st, device, num_queries_per_kv=1, mode=args.mode)
+    ds.cm.lean_outputs = bool(args.lean)
     g = torch.Generator(device=device)
     g.manual_seed(1234 + seed)
     if args.kv_dtype == "fp8":
@@ -234,8 +238,12 @@ def main():
                                                  ds.context_lens, ds.hanging_token_count,
                                                  ds.evicted_kv_offsets, prot, total_slots=N)
         if i is not None: marks[i][1].record()
-        ops.schedule_cache_moves(cmi, cmc, eli, ekc, ds.evicted_kv_offsets, ds.block_tables,
-                                 ds.context_lens, bs)
+        if args.lean:
+            ops._schedule_t1_cache_moves(cmi, cmc, eli, ekc, ds.evicted_kv_offsets, ds.block_tables,
+                                         ds.context_lens, bs, zero_fill=False)
+        else:
+            ops.schedule_cache_moves(cmi, cmc, eli, ekc, ds.evicted_kv_offsets, ds.block_tables,
+                                     ds.context_lens, bs)
         if i is not None:
             marks[i][2].record()
             kev.arm(i)
@@ -314,7 +322,8 @@ def main():
                             + (f"continual steady state cap={args.steady_cap}+1 token, " if args.steady_cap
                                else f"compress_once keep={args.keep}, ")
                             + f"protected_window={args.protected}, "
-                            f"metrics={args.metric_shape}, schedule mode={args.mode}, physical blocks "
+                            f"metrics={args.metric_shape}, schedule mode={args.mode}"
+                            + (", lean outputs (extension)" if args.lean else "") + ", physical blocks "
                             f"{'in allocation order' if args.contiguous_blocks else 'shuffled'}",
                 "candidate_slots": N, "evicted_slots": evicted_slots, "moved_slots": moved_slots,
                 "freed_blocks": freed_blocks,

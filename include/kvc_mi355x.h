@@ -149,6 +149,14 @@ typedef struct kvc_schedule_params {
   float bias_weight;
   int32_t mode;                               /* 0 reference, 1 per_sequence */
   int32_t null_value;                         /* MAX_INT = 2147483000 (metrics.py:12) */
+  int32_t lean;                               /* extension, 0 = reference-observable outputs.
+                                               * bit 0: do not pad evicted_logical_indices with
+                                               *   null_value behind the evicted_kv_count[g] entries
+                                               *   of a head (consumers read only those);
+                                               * bit 1: skip the defensive 0xFF clear of the key
+                                               *   scratch (valid when every logical block below
+                                               *   ceil(ctx/bs) of the selected sequences has
+                                               *   block metadata, as the engine maintains) */
   /* outputs */
   int32_t* evicted_logical_indices;           /* [N] */
   int32_t* evicted_kv_count;                  /* [B,L,H] */

@@ -298,3 +298,46 @@ def test_compression_step_is_graph_capturable():
         if a.dtype == torch.float16:
             a, b = a.view(torch.int16), b.view(torch.int16)
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("mode", ["per_sequence", "reference"])
+def test_lean_outputs_leave_everything_downstream_unchanged(mode):
+    """CompressionMetrics.lean_outputs (extension): no MAX_INT padding behind a head's evicted
+    indices and no defensive clear of the key scratch.  Counts, the evicted indices a consumer
+    reads, the move schedule and the compacted caches are identical to the default."""
+    st = synth.make_state(num_layers=3, num_kv_heads=2, block_size=16, seq_lens=[900, 333, 1500], seed=9,
+                          protected=[5, 40, 12], compressed=True)
+    evicted = [25, 7, 60]
+    k, v = synth.make_caches_u16(9, st.num_blocks, 128, 16)
+    res = {}
+    for lean in (False, True):
+        ds = hdev.upload(st, DEV, num_queries_per_kv=1, mode=mode)
+        ds.cm.lean_outputs = lean
+        ev = torch.tensor(evicted, dtype=torch.int32, device=DEV)
+        # poison the scratch so that a missing clear would show
+        from vllm_kvcompress_amd import _custom_ops as _ops
+        for buf in _ops._WORKSPACES.values():
+            buf.fill_(0x5A)
+        eli, ekc, ebc = ds.cm.schedule_evictions(list(st.seq_indices), ds.seq_positions, ev, ds.context_lens,
+                                                 ds.hanging_token_count, ds.evicted_kv_offsets,
+                                                 list(st.protected), total_slots=st.total_slots)
+        cmi = torch.zeros((st.total_slots, 2), dtype=torch.int32, device=DEV)
+        cmc = torch.zeros((3, 3, 2), dtype=torch.int32, device=DEV)
+        ops.schedule_cache_moves(cmi, cmc, eli, ekc, ds.evicted_kv_offsets, ds.block_tables,
+                                 ds.context_lens, 16)
+        kc = torch.from_numpy(k.copy()).to(DEV)
+        vc = torch.from_numpy(v.copy()).to(DEV)
+        ops.execute_cache_moves(kc.view(torch.float16), vc.view(torch.float16), ds.cm.metrics,
+                                ds.cm.token_positions, cmi, cmc, ds.evicted_kv_offsets, 1, 16)
+        torch.cuda.synchronize()
+        res[lean] = dict(eli=eli.cpu().numpy(), ekc=ekc.cpu().numpy(), ebc=ebc.cpu().numpy(),
+                         cmi=cmi.cpu().numpy(), cmc=cmc.cpu().numpy(), k=kc.cpu().numpy(),
+                         v=vc.cpu().numpy(), m=ds.cm.metrics.cpu().numpy(),
+                         p=ds.cm.token_positions.cpu().numpy())
+    a, b = res[False], res[True]
+    for key in ("ekc", "ebc", "cmi", "cmc", "k", "v", "m", "p"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    offs, cnt = st.evicted_kv_offsets.reshape(-1), a["ekc"].reshape(-1)
+    for o, c in zip(offs, cnt):
+        np.testing.assert_array_equal(a["eli"][o:o + c], b["eli"][o:o + c])
+    assert (a["eli"] == 2147483000).any()              # the default pads with MAX_INT

@@ -33,7 +33,7 @@ class KvcScheduleParams(ctypes.Structure):
         ("total_slots", c_int64),
         ("use_average", c_int32), ("num_sinks", c_int32),
         ("bias", c_void_p), ("position_bins", c_void_p), ("num_bins", c_int32),
-        ("bias_weight", c_float), ("mode", c_int32), ("null_value", c_int32),
+        ("bias_weight", c_float), ("mode", c_int32), ("null_value", c_int32), ("lean", c_int32),
         ("evicted_logical_indices", c_void_p), ("evicted_kv_count", c_void_p),
         ("evicted_block_count", c_void_p),
     ]

@@ -507,7 +507,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(kvc_schedule_p
   int32_t* out = p.evicted_logical_indices + base;
   const int tid = threadIdx.x, lane = lane_id(), w = tid / WAVE;
   if (cnt == 0) {
-    for (int idx = tid; idx < n; idx += blockDim.x) out[idx] = p.null_value;
+    if (!(p.lean & 1))
+      for (int idx = tid; idx < n; idx += blockDim.x) out[idx] = p.null_value;
     return;
   }
   // stage the head's keys in LDS once; every later pass (4 select rounds + emit) reads LDS
@@ -631,7 +632,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(kvc_schedule_p
     carry += scan_buf[U * NWAVES];
     __syncthreads();                                // scan_buf is rewritten by the next batch
   }
-  for (int idx = (int)cnt + tid; idx < n; idx += blockDim.x) out[idx] = p.null_value;
+  if (!(p.lean & 1))
+    for (int idx = (int)cnt + tid; idx < n; idx += blockDim.x) out[idx] = p.null_value;
 }
 
 }  // namespace kvc
@@ -707,7 +709,7 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   // keys default to "not evictable" (0xFFFFFFFF > KEY_INF) and the chunk table to -1 for slots
   // no physical block claims (inconsistent metadata); histograms and counters are zeroed by
   // the tail workgroups of build_keys
-  hipMemsetAsync(ws.keys, 0xFF, l.zero_begin - l.keys, s);
+  if (!(p.lean & 2)) hipMemsetAsync(ws.keys, 0xFF, l.zero_begin - l.keys, s);
   {
     uint4* z16 = reinterpret_cast<uint4*>(wb + l.zero_begin);
     const int64_t zv = (int64_t)((l.zero_end - l.zero_begin) / 16);
