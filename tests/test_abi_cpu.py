@@ -97,3 +97,19 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(root, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
                 assert "kvc_oracle" not in src.replace("oracle/kvc_oracle.py", ""), f
+
+
+def test_sources_are_gfx950_only():
+    """no compatibility layers in the product: no dual CUDA/HIP paths, no hipify residue, no
+    Triton, no 32-lane idioms; build script targets gfx950 and nothing else"""
+    pkg = os.path.join(REPO, "vllm_kvcompress_amd")
+    banned = ("__HIP_PLATFORM", "__CUDA_ARCH__", "cuda_runtime", "__shfl_sync", "__ballot_sync",
+              "import triton", "warpSize", "hipify")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".hip", ".h", ".py", ".sh")):
+                src = open(os.path.join(root, f)).read()
+                for b in banned:
+                    assert b not in src, (f, b)
+    build = open(os.path.join(pkg, "csrc", "build.sh")).read()
+    assert "--offload-arch=gfx950" in build and build.count("--offload-arch") == 1
