@@ -91,6 +91,18 @@ struct KvFrag {
   static __device__ __forceinline__ V8 convert(const Raw& r, float scale) {
     if constexpr (KVD == 0) {
       return __builtin_bit_cast(V8, r.v);
+    } else if constexpr (KVD == 3 && __is_same(T, _Float16)) {
+      // gfx950 converts two e4m3 bytes straight to packed fp16 (exact; the scale operand only
+      // contributes its exponent, so this is the unit-scale path)
+      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+      const h2 a0 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(r.v[0], 1.0f, false);
+      const h2 a1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(r.v[0], 1.0f, true);
+      const h2 a2 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(r.v[1], 1.0f, false);
+      const h2 a3 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(r.v[1], 1.0f, true);
+      V8 v;
+      v[0] = a0[0]; v[1] = a0[1]; v[2] = a1[0]; v[3] = a1[1];
+      v[4] = a2[0]; v[5] = a2[1]; v[6] = a3[0]; v[7] = a3[1];
+      return v;
     } else if constexpr (KVD == 4 && __is_same(T, _Float16)) {
       au32x4 o;
       o[0] = ((r.v[0] & 0xFFu) << 8) | ((r.v[0] & 0xFF00u) << 16);
