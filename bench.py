@@ -70,34 +70,6 @@ def parse_args():
     return ap.parse_args()
 
 
-class KernelEvents:
-    """HIP events owned by the kernel library (same HIP runtime instance as the launches).
-    The library records a pair on its launch stream right around the compaction kernel
-    (kvc_debug_set_compact_events), which excludes the tiny planning kernels."""
-
-    def __init__(self, lib, n):
-        import ctypes
-        lib.kvc_debug_event_create.restype = ctypes.c_void_p
-        lib.kvc_debug_event_elapsed_ms.restype = ctypes.c_float
-        lib.kvc_debug_event_elapsed_ms.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-        lib.kvc_debug_set_compact_events.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-        lib.kvc_debug_set_compact_events.restype = None
-        self.lib = lib
-        self.pairs = [(lib.kvc_debug_event_create(), lib.kvc_debug_event_create()) for _ in range(n)]
-        assert all(a and b for a, b in self.pairs)
-
-    def arm(self, i):
-        if i is None:
-            self.lib.kvc_debug_set_compact_events(None, None)
-        else:
-            self.lib.kvc_debug_set_compact_events(self.pairs[i][0], self.pairs[i][1])
-
-    def elapsed_ms(self, i):
-        ms = float(self.lib.kvc_debug_event_elapsed_ms(self.pairs[i][0], self.pairs[i][1]))
-        assert ms >= 0.0
-        return ms
-
-
 def alg_bytes_per_move(head_size: int, elem_bytes: int) -> int:
     """K and V, read+write, + metric r/w + position r/w + move pair read."""
     return 4 * head_size * elem_bytes + 24
@@ -228,9 +200,10 @@ def main():
     prot = list(st.protected)
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
-    marks = [[ev() for _ in range(4)] for _ in range(args.steps)]
+    # marks: S1 start, S2 start, S3 start (plan half), data kernel start, end.  All events are
+    # recorded on the stream the kernels are launched on (torch's current stream).
+    marks = [[ev() for _ in range(5)] for _ in range(args.steps)]
     out = {}
-    kev = KernelEvents(vllm_kvcompress_amd.load(), args.steps)
 
     def step(i=None):
         if i is not None: marks[i][0].record()
@@ -244,12 +217,15 @@ def main():
         else:
             ops.schedule_cache_moves(cmi, cmc, eli, ekc, ds.evicted_kv_offsets, ds.block_tables,
                                      ds.context_lens, bs)
-        if i is not None:
-            marks[i][2].record()
-            kev.arm(i)
-        ops.execute_cache_moves(k_cache, v_cache, work_metrics, work_pos, cmi, cmc,
-                                ds.evicted_kv_offsets, 1, 16)
+        if i is not None: marks[i][2].record()
+        # execute_cache_moves = its two halves (kvc_execute_cache_moves_plan / _apply), called
+        # separately so that the data kernel is bracketed by events of its own
+        ops._execute_cache_moves(k_cache, v_cache, work_metrics, work_pos, cmi, cmc,
+                                 ds.evicted_kv_offsets, "plan")
         if i is not None: marks[i][3].record()
+        ops._execute_cache_moves(k_cache, v_cache, work_metrics, work_pos, cmi, cmc,
+                                 ds.evicted_kv_offsets, "apply")
+        if i is not None: marks[i][4].record()
         out["ekc"], out["ebc"] = ekc, ebc
 
     for _ in range(args.warmup):
@@ -265,8 +241,7 @@ def main():
         dist.barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    kev.arm(None)
-    kernel_ms = sum(kev.elapsed_ms(i) for i in range(args.steps)) / args.steps
+    kernel_ms = sum(m[3].elapsed_time(m[4]) for m in marks) / args.steps
 
     evicted_slots = int(out["ekc"].sum().item())
     moved_slots = int(cmc.sum().item())
@@ -275,7 +250,7 @@ def main():
         assert freed_blocks == sum(evicted), (freed_blocks, sum(evicted))
     s1 = sum(m[0].elapsed_time(m[1]) for m in marks) / args.steps
     s2 = sum(m[1].elapsed_time(m[2]) for m in marks) / args.steps
-    s3 = sum(m[2].elapsed_time(m[3]) for m in marks) / args.steps
+    s3 = sum(m[2].elapsed_time(m[4]) for m in marks) / args.steps
 
     # whole-job rate = units of all ranks / slowest rank's time; the only collective of the
     # path (RCCL all_gather of two scalars per rank)
@@ -340,8 +315,8 @@ def main():
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_move": bpm,
                 "avg_launch_ms": kernel_ms,
-                "timing": "HIP events recorded by the library on its launch stream around the "
-                          "compaction kernel, every timed step",
+                "timing": "HIP events on the launch stream around the compaction kernel "
+                          "(kvc_execute_cache_moves_apply), every timed step",
                 "traffic_frac_of_peak": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
             },
         }

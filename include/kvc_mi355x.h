@@ -95,6 +95,10 @@ int kvc_schedule_t1_cache_moves(int32_t* cache_moves_idx,            /* [rows,2]
  * workspace: kvc_execute_cache_moves_workspace_bytes(total_heads, num_blocks) bytes of
  * device memory, 16-byte aligned (tile prefix sums + one claim byte per physical block);
  * no need to clear it, the planning kernel does.
+ * The op is two halves that may also be called separately on the same stream with the same
+ * move list and workspace (what bench.py does to time the data kernel alone with events on
+ * the caller's stream): _plan = the two small planning launches (reads only the move list),
+ * _apply = the compaction kernel.  kvc_execute_cache_moves == _plan followed by _apply.
  * --------------------------------------------------------------------------------- */
 size_t kvc_execute_cache_moves_workspace_bytes(int32_t total_heads, int64_t num_blocks);
 int kvc_execute_cache_moves(void* k_cache, void* v_cache, float* kv_metrics,
@@ -105,6 +109,18 @@ int kvc_execute_cache_moves(void* k_cache, void* v_cache, float* kv_metrics,
                             int32_t total_heads, int64_t num_blocks, int32_t block_size,
                             int32_t head_size, int32_t elem_bytes, int32_t vec_size,
                             void* workspace, size_t workspace_bytes, kvc_stream_t stream);
+int kvc_execute_cache_moves_plan(const int32_t* cache_moves_idx, const int32_t* cache_moves_count,
+                                 const int32_t* evicted_kv_offsets, int32_t total_heads,
+                                 int64_t num_blocks, int32_t block_size, int32_t head_size,
+                                 int32_t elem_bytes, int32_t vec_size, void* workspace,
+                                 size_t workspace_bytes, kvc_stream_t stream);
+int kvc_execute_cache_moves_apply(void* k_cache, void* v_cache, float* kv_metrics,
+                                  int32_t* kv_position, const int32_t* cache_moves_idx,
+                                  const int32_t* cache_moves_count,
+                                  const int32_t* evicted_kv_offsets, int32_t total_heads,
+                                  int64_t num_blocks, int32_t block_size, int32_t head_size,
+                                  int32_t elem_bytes, int32_t vec_size, void* workspace,
+                                  size_t workspace_bytes, kvc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * A3  CompressionMetrics.schedule_evictions  (mask -> select -> count -> emit)
@@ -325,6 +341,8 @@ typedef struct kvc_attention_params {
   int32_t max_num_blocks_per_seq, max_context_len;
   int32_t dtype, kv_cache_dtype, record_kv_metrics;
   int32_t fused_use_l2;                 /* with fused_metrics: accumulate p^2 (1) or p (0) */
+  int32_t schedule;                     /* 0 = automatic, 1 = always partitioned (the reference's v2
+                                           shape), 2 = single pass whenever the context fits in LDS */
 } kvc_attention_params;
 
 int kvc_paged_attention_decode(const kvc_attention_params* p, kvc_stream_t stream);
@@ -332,7 +350,7 @@ int kvc_paged_attention_decode(const kvc_attention_params* p, kvc_stream_t strea
  * tmp_kv_metric_out), 0 if it finishes in one kernel and they may be NULL. */
 int32_t kvc_paged_attention_decode_uses_partitions(int32_t num_seqs, int32_t num_heads,
                                                    int32_t num_kv_heads, int32_t head_size,
-                                                   int32_t max_context_len);
+                                                   int32_t max_context_len, int32_t schedule);
 
 #ifdef __cplusplus
 }

@@ -20,13 +20,10 @@ ATTN_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.startswith("attn
 
 
 def _set_mode(mode):
-    """0 automatic, 1 partitioned (+ reduce / rescale kernels), 2 single pass when it fits"""
-    import ctypes
-    import vllm_kvcompress_amd
-    lib = vllm_kvcompress_amd.load()
-    lib.kvc_debug_set_attention_mode.argtypes = [ctypes.c_int32]
-    lib.kvc_debug_set_attention_mode.restype = None
-    lib.kvc_debug_set_attention_mode(mode)
+    """0 automatic, 1 partitioned (+ reduce / rescale kernels), 2 single pass when it fits;
+    travels per call in kvc_attention_params.schedule"""
+    from vllm_kvcompress_amd import _custom_ops as ops
+    ops.set_attention_schedule(mode)
 
 
 @pytest.fixture(params=[1, 2], ids=["partitioned", "single_pass"])
@@ -301,7 +298,8 @@ def test_decode_attention_fused_metric_aggregation(shape, use_l2, attn_mode):
         out, got, q, kc, vc, Hkv, float(g["scale"]), torch.from_numpy(g["block_tables"]).to(dev),
         torch.from_numpy(g["context_lens"]).to(dev), torch.from_numpy(pos).to(dev),
         torch.from_numpy(last).to(dev), torch.from_numpy(buf).to(dev), bs,
-        int(g["context_lens"].max()), None, "auto", 1.0, 1.0, use_l2=use_l2)
+        int(g["context_lens"].max()), None, "auto", 1.0, 1.0, use_l2=use_l2,
+        temp_metrics=torch.empty((NB, bs, qpk), dtype=torch.float32, device=dev))
     torch.cuda.synchronize()
     assert torch.equal(got, want)
     assert np.array_equal(out.float().cpu().numpy(), out_ref)

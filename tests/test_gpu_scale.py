@@ -167,7 +167,7 @@ def test_full_size_properties(T, BS, cdtype, keep):
     assert bool((ds.cm.token_positions.reshape(-1)[~moved_dst] == pos0.reshape(-1)[~moved_dst]).all())
 
     # the block (fast) path was taken for every destination block
-    ws = ops._WORKSPACES[(0, "execute_cache_moves")]
+    ws = ops.workspace(torch.device(dev), 0, "execute_cache_moves")   # the buffer the op just used
     coff = ((G + 2) * 4 + 15) // 16 * 16          # [tile prefix, padded to 16 B][claim bytes]
     claims = ws[coff:coff + NB]
     assert int(claims.max()) == 1

@@ -36,14 +36,36 @@ def _require(t: torch.Tensor, name: str, dtype=None) -> None:
 
 
 def workspace(device: torch.device, nbytes: int, tag: str) -> torch.Tensor:
-    """Persistent per-(device, tag) scratch buffer, grown geometrically; the C ABI never
-    allocates (include/kvc_mi355x.h)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    """Persistent per-(device, stream, tag) scratch buffer, grown geometrically; the C ABI never
+    allocates (include/kvc_mi355x.h).  Keyed by the current stream so that calls enqueued on
+    different streams never share scratch; a buffer that is outgrown stays referenced by the
+    caching allocator's stream ordering until the kernels already enqueued on it have run
+    (``record_stream``)."""
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    stream = torch.cuda.current_stream(index)
+    key = (index, stream.cuda_stream, tag)
     buf = _WORKSPACES.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes * 1.25), 4096), dtype=torch.uint8, device=device)
+        if buf is not None:
+            buf.record_stream(stream)
+        buf = torch.empty(max(int(nbytes * 1.25), 4096), dtype=torch.uint8,
+                          device=torch.device("cuda", index))
         _WORKSPACES[key] = buf
     return buf
+
+
+def reserve_workspace(device: torch.device, nbytes: int, tag: str) -> None:
+    """Size a scratch buffer ahead of time (engine start-up / before HIP-graph capture) so that no
+    op ever allocates while serving."""
+    workspace(device, nbytes, tag)
+
+
+def _contig(t: torch.Tensor, keep: list) -> torch.Tensor:
+    """contiguous view of a read-only input; a temporary made here is kept alive in ``keep``
+    until the launch that reads it through a raw pointer has been enqueued"""
+    c = t.contiguous()
+    keep.append(c)
+    return c
 
 
 # ---------------------------------------------------------------------------------------
@@ -63,7 +85,10 @@ def count_block_evictions(
                  ("evicted_kv_offsets", evicted_kv_offsets),
                  ("hanging_token_count", hanging_token_count)):
         _require(t, n, torch.int32)
-    eli = evicted_logical_indices.contiguous()
+    if not evicted_logical_indices.is_contiguous() or not evicted_block_count.is_contiguous():
+        raise RuntimeError("count_block_evictions: evicted_logical_indices / evicted_block_count "
+                           "must be contiguous (written in place)")
+    eli = evicted_logical_indices
     offs = evicted_kv_offsets.contiguous()
     hang = hanging_token_count.contiguous()
     with torch.cuda.device(eli.device):
@@ -102,13 +127,14 @@ def _schedule_t1_cache_moves(cache_moves_idx, cache_moves_count, evicted_logical
     if not cache_moves_idx.is_contiguous() or not cache_moves_count.is_contiguous():
         raise RuntimeError("schedule_cache_moves: output tensors must be contiguous")
     num_seqs, num_layers, num_kv_heads = evicted_kv_count.shape
+    keep = []
     with torch.cuda.device(cache_moves_idx.device):
         _lib.check(lib.kvc_schedule_t1_cache_moves(
             cache_moves_idx.data_ptr(), cache_moves_idx.shape[0], cache_moves_count.data_ptr(),
-            evicted_logical_indices.contiguous().data_ptr(),
-            evicted_kv_count.contiguous().data_ptr(),
-            evicted_kv_offsets.contiguous().data_ptr(),
-            block_tables.contiguous().data_ptr(), context_lens.contiguous().data_ptr(),
+            _contig(evicted_logical_indices, keep).data_ptr(),
+            _contig(evicted_kv_count, keep).data_ptr(),
+            _contig(evicted_kv_offsets, keep).data_ptr(),
+            _contig(block_tables, keep).data_ptr(), _contig(context_lens, keep).data_ptr(),
             num_seqs, num_layers, num_kv_heads, block_tables.shape[3], int(block_size),
             1 if zero_fill else 0, _stream(cache_moves_idx)))
 
@@ -141,6 +167,16 @@ def execute_cache_moves(
                  ("kv_position", kv_position)):
         if not t.is_contiguous():
             raise RuntimeError(f"execute_cache_moves: {n} must be contiguous (mutated in place)")
+    _execute_cache_moves(k_cache, v_cache, kv_metrics, kv_position, cache_moves_indices,
+                         cache_moves_count, evicted_kv_offsets, "both")
+
+
+def _execute_cache_moves(k_cache, v_cache, kv_metrics, kv_position, cache_moves_indices,
+                         cache_moves_count, evicted_kv_offsets, half: str) -> None:
+    """``half``: "both" (the op), or "plan" / "apply" -- the op's two halves
+    (kvc_execute_cache_moves_plan / _apply), which bench.py separates to put events around the
+    data kernel on the caller's own stream."""
+    lib = _lib.load()
     num_blocks, head_size, block_size = v_cache.shape
     vec = k_cache.shape[3]
     cmi = cache_moves_indices.contiguous()
@@ -149,12 +185,17 @@ def execute_cache_moves(
     total_heads = cmc.numel()
     ws_bytes = lib.kvc_execute_cache_moves_workspace_bytes(total_heads, num_blocks)
     ws = workspace(k_cache.device, ws_bytes, "execute_cache_moves")
+    shape = (total_heads, num_blocks, block_size, head_size, k_cache.element_size(), vec,
+             ws.data_ptr(), ws.numel(), _stream(k_cache))
     with torch.cuda.device(k_cache.device):
-        _lib.check(lib.kvc_execute_cache_moves(
-            k_cache.data_ptr(), v_cache.data_ptr(), kv_metrics.data_ptr(),
-            kv_position.data_ptr(), cmi.data_ptr(), cmc.data_ptr(), offs.data_ptr(),
-            total_heads, num_blocks, block_size, head_size, k_cache.element_size(), vec,
-            ws.data_ptr(), ws.numel(), _stream(k_cache)))
+        if half == "plan":
+            _lib.check(lib.kvc_execute_cache_moves_plan(cmi.data_ptr(), cmc.data_ptr(),
+                                                        offs.data_ptr(), *shape))
+        else:
+            fn = lib.kvc_execute_cache_moves if half == "both" else lib.kvc_execute_cache_moves_apply
+            _lib.check(fn(k_cache.data_ptr(), v_cache.data_ptr(), kv_metrics.data_ptr(),
+                          kv_position.data_ptr(), cmi.data_ptr(), cmc.data_ptr(), offs.data_ptr(),
+                          *shape))
 
 
 def reshape_and_cache_kvc(
@@ -225,6 +266,17 @@ def schedule_cache_evictions(*args, **kwargs):
 # ---------------------------------------------------------------------------------------
 # F3: decode attention with KV-metric output      reference vllm/_custom_ops.py:135-201
 _ATTN_PARTITION = 512           # reference vllm/attention/ops/paged_attn.py:_PARTITION_SIZE
+_ATTENTION_SCHEDULE = 0         # kvc_attention_params.schedule of every call (0 = automatic)
+
+
+def set_attention_schedule(schedule: int) -> None:
+    """0 automatic (default), 1 always partitioned (the reference's v2 shape: per-partition kernel
+    + reduce + metric rescale), 2 single pass whenever the context fits in LDS.  Passed per call
+    in ``kvc_attention_params.schedule``; the library holds no state."""
+    global _ATTENTION_SCHEDULE
+    if schedule not in (0, 1, 2):
+        raise ValueError("attention schedule must be 0, 1 or 2")
+    _ATTENTION_SCHEDULE = int(schedule)
 
 
 def _paged_attention_kvc(out, kv_metric_out, exp_sum, max_logits, tmp_out, tmp_kv_metric_out,
@@ -264,7 +316,8 @@ def _paged_attention_kvc(out, kv_metric_out, exp_sum, max_logits, tmp_out, tmp_k
         raise RuntimeError("paged_attention_kvc: query must be contiguous in (head, dim)")
     if not out.is_contiguous():
         raise RuntimeError("paged_attention_kvc: out must be contiguous")
-    bt = block_tables.contiguous()
+    keep = []
+    bt = _contig(block_tables, keep)
     p = _lib.KvcAttentionParams()
     p.out, p.kv_metric_out = out.data_ptr(), _ptr(kv_metric_out)
     p.fused_metrics, p.fused_use_l2 = _ptr(fused_metrics), int(bool(use_l2))
@@ -272,11 +325,11 @@ def _paged_attention_kvc(out, kv_metric_out, exp_sum, max_logits, tmp_out, tmp_k
     p.tmp_out, p.tmp_kv_metric_out = _ptr(tmp_out), _ptr(tmp_kv_metric_out)
     p.query, p.key_cache, p.value_cache = query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr()
     p.block_tables = bt.data_ptr()
-    p.context_lens = context_lens.contiguous().data_ptr()
-    p.kv_position = kv_position.contiguous().data_ptr()
-    p.last_position = last_position.contiguous().data_ptr()
-    p.kv_metric_buffer_len = kv_metric_buffer_len.contiguous().data_ptr()
-    p.alibi_slopes = None if alibi_slopes is None else alibi_slopes.float().contiguous().data_ptr()
+    p.context_lens = _contig(context_lens, keep).data_ptr()
+    p.kv_position = _contig(kv_position, keep).data_ptr()
+    p.last_position = _contig(last_position, keep).data_ptr()
+    p.kv_metric_buffer_len = _contig(kv_metric_buffer_len, keep).data_ptr()
+    p.alibi_slopes = None if alibi_slopes is None else _contig(alibi_slopes.float(), keep).data_ptr()
     p.q_stride, p.kv_block_stride = query.stride(0), key_cache.stride(0)
     p.scale, p.k_scale, p.v_scale = float(scale), float(k_scale), float(v_scale)
     p.num_seqs, p.num_heads, p.num_kv_heads = num_seqs, num_heads, int(num_kv_heads)
@@ -285,6 +338,7 @@ def _paged_attention_kvc(out, kv_metric_out, exp_sum, max_logits, tmp_out, tmp_k
     p.max_context_len = int(max_context_len)
     p.dtype, p.kv_cache_dtype = dtypes[query.dtype], kvds[kv_cache_dtype]
     p.record_kv_metrics = int(bool(record_kv_metrics))
+    p.schedule = _ATTENTION_SCHEDULE
     with torch.cuda.device(query.device):
         _lib.check(lib.kvc_paged_attention_decode(p, _stream(query)))
 
@@ -295,10 +349,14 @@ def paged_attention_kvc_v1(out, kv_metric_out, query, key_cache, value_cache, nu
                            alibi_slopes, kv_cache_dtype: str, k_scale: float, v_scale: float,
                            record_kv_metrics: bool) -> None:
     """reference vllm/_custom_ops.py:135-163.  The reference's v1 keeps a whole context in
-    one workgroup's shared memory; here long contexts are always partitioned, so the
-    partition buffers the v1 signature does not carry come from the wrapper's scratch."""
-    exp_sum, max_logits, tmp_out, tmp_metric = _partition_scratch(
-        query, num_kv_heads, max_context_len, kv_metric_out.numel() if record_kv_metrics else 0, "attn_v1")
+    one workgroup's shared memory; here long contexts at small batch are partitioned, so the
+    small per-partition buffers the v1 signature does not carry (exp sums, max logits, partial
+    outputs) come from the wrapper's scratch (``reserve_attention_scratch`` sizes it ahead of
+    time).  The unnormalised per-partition weights need no buffer of their own: they are written
+    to ``kv_metric_out`` and rescaled in place (the rescale kernel reads and writes the same
+    ``slot * qpk + q`` element)."""
+    exp_sum, max_logits, tmp_out = _partition_scratch(query, num_kv_heads, max_context_len, "attn_v1")
+    tmp_metric = kv_metric_out if (record_kv_metrics and exp_sum is not None) else None
     _paged_attention_kvc(out, kv_metric_out, exp_sum, max_logits, tmp_out, tmp_metric, query,
                          key_cache, value_cache, num_kv_heads, scale, block_tables, context_lens,
                          kv_position, last_position, kv_metric_buffer_len, block_size,
@@ -306,22 +364,36 @@ def paged_attention_kvc_v1(out, kv_metric_out, query, key_cache, value_cache, nu
                          record_kv_metrics)
 
 
-def _partition_scratch(query, num_kv_heads, max_context_len, metric_numel, tag):
+def _partition_scratch_bytes(num_seqs, num_heads, head_size, elem_bytes, max_context_len):
+    parts = (int(max_context_len) + _ATTN_PARTITION - 1) // _ATTN_PARTITION
+    n = num_seqs * num_heads * parts
+    return n, n * 8 + n * head_size * elem_bytes + 256
+
+
+def reserve_attention_scratch(device, num_seqs: int, num_heads: int, head_size: int,
+                              elem_bytes: int, max_context_len: int) -> None:
+    """Pre-size the partition scratch of ``paged_attention_kvc_v1`` / ``_fused_metrics`` for the
+    largest batch the engine will run (call at start-up, next to the cache allocation), so the
+    ops never allocate while serving or inside a HIP-graph capture."""
+    _, nbytes = _partition_scratch_bytes(num_seqs, num_heads, head_size, elem_bytes, max_context_len)
+    for tag in ("attn_v1", "attn_fused"):
+        reserve_workspace(torch.device(device), nbytes, tag)
+
+
+def _partition_scratch(query, num_kv_heads, max_context_len, tag):
     num_seqs, num_heads, head_size = query.shape
     parts = (int(max_context_len) + _ATTN_PARTITION - 1) // _ATTN_PARTITION
     if parts <= 1 or not _lib.load().kvc_paged_attention_decode_uses_partitions(
-            num_seqs, num_heads, int(num_kv_heads), head_size, int(max_context_len)):
-        return None, None, None, None      # one kernel finishes the call: no scratch at all
-    n = num_seqs * num_heads * parts
-    buf = workspace(query.device, n * 8 + n * head_size * query.element_size() + 256, tag)
+            num_seqs, num_heads, int(num_kv_heads), head_size, int(max_context_len),
+            _ATTENTION_SCHEDULE):
+        return None, None, None            # one kernel finishes the call: no scratch at all
+    n, nbytes = _partition_scratch_bytes(num_seqs, num_heads, head_size, query.element_size(),
+                                         max_context_len)
+    buf = workspace(query.device, nbytes, tag)
     exp_sum = buf[:n * 4].view(torch.float32)
     max_logits = buf[n * 4:n * 8].view(torch.float32)
     tmp_out = buf[n * 8:n * 8 + n * head_size * query.element_size()].view(query.dtype)
-    tmp_metric = None
-    if metric_numel:
-        tmp_metric = workspace(query.device, metric_numel * 4, tag + "_metric").view(
-            torch.float32)[:metric_numel]
-    return exp_sum, max_logits, tmp_out, tmp_metric
+    return exp_sum, max_logits, tmp_out
 
 
 def paged_attention_kvc_fused_metrics(out, metrics, query, key_cache, value_cache,
@@ -329,15 +401,30 @@ def paged_attention_kvc_fused_metrics(out, metrics, query, key_cache, value_cach
                                       kv_position, last_position, kv_metric_buffer_len,
                                       block_size: int, max_context_len: int, alibi_slopes,
                                       kv_cache_dtype: str, k_scale: float, v_scale: float,
-                                      use_l2: bool = True) -> None:
+                                      use_l2: bool = True,
+                                      temp_metrics: Optional[torch.Tensor] = None) -> None:
     """Extension (the reference lists it as a to-do, vllm/kvcompress/README.md:32,49): the
     attention of ``paged_attention_kvc_v1`` that adds ``sum_q p^2`` (or ``sum_q p``) of every
     key inside the metric window straight into ``metrics [num_blocks, block_size]`` -- what
     ``kv_metric_out`` + ``CompressionMetrics.aggregate_decode`` + ``clear_temp_metrics`` do
-    together (metrics.py:429-439, 337-342), bit for bit, without the [NB, bs, qpk] buffer."""
-    qpk = query.shape[1] // int(num_kv_heads)
-    es, ml, to, tm = _partition_scratch(query, num_kv_heads, max_context_len, metrics.numel() * qpk,
-                                        "attn_fused")
+    together (metrics.py:429-439, 337-342), bit for bit, without the [NB, bs, qpk] round trip.
+    When the call takes the partitioned schedule (long contexts at small batch) the
+    unnormalised weights need a ``[num_blocks, block_size, qpk]`` float32 scratch: pass
+    ``CompressionMetrics.temp_metrics`` (which this path otherwise leaves unused) as
+    ``temp_metrics``; the op never allocates a buffer of that size itself."""
+    es, ml, to = _partition_scratch(query, num_kv_heads, max_context_len, "attn_fused")
+    tm = None
+    if es is not None:
+        qpk = query.shape[1] // int(num_kv_heads)
+        if temp_metrics is None:
+            raise RuntimeError("paged_attention_kvc_fused_metrics: this shape takes the partitioned "
+                               "schedule, which needs temp_metrics [num_blocks, block_size, qpk] "
+                               "(CompressionMetrics.temp_metrics)")
+        _require(temp_metrics, "temp_metrics", torch.float32)
+        if not temp_metrics.is_contiguous() or temp_metrics.numel() < metrics.numel() * qpk:
+            raise RuntimeError("paged_attention_kvc_fused_metrics: temp_metrics must be contiguous "
+                               "with at least num_blocks * block_size * qpk elements")
+        tm = temp_metrics
     _paged_attention_kvc(out, None, es, ml, to, tm, query, key_cache, value_cache, num_kv_heads,
                          scale, block_tables, context_lens, kv_position, last_position,
                          kv_metric_buffer_len, block_size, max_context_len, alibi_slopes,

@@ -55,7 +55,7 @@ class KvcAttentionParams(ctypes.Structure):
         ("head_size", c_int32), ("block_size", c_int32),
         ("max_num_blocks_per_seq", c_int32), ("max_context_len", c_int32),
         ("dtype", c_int32), ("kv_cache_dtype", c_int32), ("record_kv_metrics", c_int32),
-        ("fused_use_l2", c_int32),
+        ("fused_use_l2", c_int32), ("schedule", c_int32),
     ]
 
 
@@ -72,6 +72,13 @@ SYMBOLS = {
     "kvc_execute_cache_moves": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,
                                           c_int32, c_int32, c_void_p, c_size_t, c_void_p]),
+    "kvc_execute_cache_moves_plan": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64,
+                                               c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                               c_size_t, c_void_p]),
+    "kvc_execute_cache_moves_apply": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                c_void_p, c_void_p, c_int32, c_int64, c_int32,
+                                                c_int32, c_int32, c_int32, c_void_p, c_size_t,
+                                                c_void_p]),
     "kvc_schedule_evictions_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32, c_int32]),
     "kvc_schedule_evictions": (c_int32, [ctypes.POINTER(KvcScheduleParams), c_void_p, c_size_t,
                                          c_void_p]),
@@ -100,7 +107,8 @@ SYMBOLS = {
                                            c_int32, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64,
                                            c_float, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                            c_size_t, c_void_p]),
-    "kvc_paged_attention_decode_uses_partitions": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "kvc_paged_attention_decode_uses_partitions": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32,
+                                                             c_int32]),
     "kvc_paged_attention_decode": (c_int32, [ctypes.POINTER(KvcAttentionParams), c_void_p]),
 }
 

@@ -2,9 +2,10 @@
 # Build libkvc_mi355x.so (gfx950 only) in-tree: vllm_kvcompress_amd/libkvc_mi355x.so
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
-OUT="$HERE/../libkvc_mi355x.so"
+# KVC_OUT / KVC_EXTRA_FLAGS: experiment builds of the same library (tools/, loaded through KVC_MI355X_LIB)
+OUT="${KVC_OUT:-$HERE/../libkvc_mi355x.so}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value \
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value ${KVC_EXTRA_FLAGS:-} \
   "$HERE/kvc_api.hip" "$HERE/kvc_moves.hip" "$HERE/kvc_compact.hip" \
   "$HERE/kvc_schedule.hip" "$HERE/kvc_aggregate.hip" "$HERE/kvc_blockstate.hip" \
   "$HERE/kvc_attention.hip" "$HERE/kvc_prefill_attn.hip" -o "$OUT"

@@ -158,7 +158,7 @@ struct AttnArgs {
   const float* alibi_slopes;      // [Hq] or null
   int64_t q_stride, kv_block_stride;
   float scale, k_scale, v_scale;
-  int32_t num_heads, num_kv_heads, max_blocks, max_parts, record, max_ctx, use_l2;
+  int32_t num_heads, num_kv_heads, max_blocks, max_parts, record, max_ctx, use_l2, schedule;
 };
 
 // fused aggregation (what CompressionMetrics.aggregate_decode does with the stored weights,
@@ -836,11 +836,10 @@ __global__ __launch_bounds__(256) void paged_attention_metric_rescale_kernel(Att
   }
 }
 
-static int g_attention_mode = 0;      // 0 auto, 1 partitioned, 2 single pass (kvc_debug_set_attention_mode)
-
 // which schedule a call takes (shared by the launcher and kvc_paged_attention_decode_uses_partitions)
 struct AttnPlan { bool whole; int nw, prow; size_t whole_lds; };
-static AttnPlan attention_plan(int num_seqs, int num_heads, int num_kv_heads, int head_size, int max_ctx) {
+// schedule: 0 automatic, 1 always partitioned, 2 single pass whenever it fits (kvc_attention_params.schedule)
+static AttnPlan attention_plan(int num_seqs, int num_heads, int num_kv_heads, int head_size, int max_ctx, int schedule) {
   const int qpk = num_heads / num_kv_heads;
   const int ngroups = (qpk + ATT_NQ - 1) / ATT_NQ;
   const int nqr = qpk < ATT_NQ ? qpk : ATT_NQ;
@@ -858,8 +857,8 @@ static AttnPlan attention_plan(int num_seqs, int num_heads, int num_kv_heads, in
   p.whole_lds = whole_bytes(p.nw);
   const bool fits = max_parts > 1 && p.whole_lds <= (size_t)(p.nw == 4 ? 79 : 155) * 1024;   // 1 partition is one pass anyway
   const int64_t wgs = (int64_t)num_seqs * num_kv_heads * ngroups;
-  p.whole = g_attention_mode == 2 ? fits
-          : (g_attention_mode == 1 ? false : (fits && wgs >= (p.nw == 4 ? 512 : 256)));
+  p.whole = schedule == 2 ? fits
+          : (schedule == 1 ? false : (fits && wgs >= (p.nw == 4 ? 512 : 256)));
   return p;
 }
 
@@ -868,7 +867,7 @@ static int launch_attention(const AttnArgs& a, int num_seqs, hipStream_t s) {
   const int qpk = a.num_heads / a.num_kv_heads;
   const int ngroups = (qpk + ATT_NQ - 1) / ATT_NQ;
   const int nqr = qpk < ATT_NQ ? qpk : ATT_NQ;
-  const AttnPlan plan = attention_plan(num_seqs, a.num_heads, a.num_kv_heads, HD, a.max_ctx);
+  const AttnPlan plan = attention_plan(num_seqs, a.num_heads, a.num_kv_heads, HD, a.max_ctx, a.schedule);
   const int prow = plan.prow, nw = plan.nw;
   const size_t whole_lds = plan.whole_lds;
   const bool whole = plan.whole;
@@ -913,13 +912,10 @@ static int launch_attention(const AttnArgs& a, int num_seqs, hipStream_t s) {
 
 extern "C" int32_t kvc_paged_attention_decode_uses_partitions(int32_t num_seqs, int32_t num_heads,
                                                               int32_t num_kv_heads, int32_t head_size,
-                                                              int32_t max_context_len) {
+                                                              int32_t max_context_len, int32_t schedule) {
   if (num_kv_heads < 1 || num_heads < num_kv_heads || max_context_len <= kvc::ATT_PART) return 0;
-  return kvc::attention_plan(num_seqs, num_heads, num_kv_heads, head_size, max_context_len).whole ? 0 : 1;
+  return kvc::attention_plan(num_seqs, num_heads, num_kv_heads, head_size, max_context_len, schedule).whole ? 0 : 1;
 }
-
-// test hook: 0 = automatic choice, 1 = always partitioned, 2 = single pass whenever it fits
-extern "C" void kvc_debug_set_attention_mode(int32_t mode) { kvc::g_attention_mode = mode; }
 
 extern "C" int kvc_paged_attention_decode(const kvc_attention_params* p, kvc_stream_t stream) {
   using namespace kvc;
@@ -943,6 +939,7 @@ extern "C" int kvc_paged_attention_decode(const kvc_attention_params* p, kvc_str
   a.scale = p->scale; a.k_scale = p->k_scale; a.v_scale = p->v_scale; a.num_heads = p->num_heads; a.num_kv_heads = p->num_kv_heads;
   a.max_blocks = p->max_num_blocks_per_seq; a.record = p->record_kv_metrics ? 1 : 0;
   a.max_ctx = p->max_context_len > 0 ? p->max_context_len : 1;
+  a.schedule = p->schedule;
   a.max_parts = (p->max_context_len + ATT_PART - 1) / ATT_PART;
   if (a.max_parts < 1) a.max_parts = 1;
   hipStream_t s = (hipStream_t)stream;

@@ -127,31 +127,25 @@ struct BlockImg { u32x4 p[NPL]; };
 template <int NPL>
 __device__ __forceinline__ void img_load(BlockImg<NPL>& b, const uint8_t* base, int lane) {
 #pragma unroll
-  for (int i = 0; i < NPL; ++i) {
-#ifndef KVC_NO_NT   // block images are touched once: non-temporal (measured -15 % kernel time)
+  for (int i = 0; i < NPL; ++i)   // block images are touched once: non-temporal (measured -15 % kernel time)
     b.p[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + ((int64_t)i * 64 + lane) * 16));
-#else
-    b.p[i] = *reinterpret_cast<const u32x4*>(base + ((int64_t)i * 64 + lane) * 16);
-#endif
-  }
 }
 template <int NPL>
 __device__ __forceinline__ void img_store(const BlockImg<NPL>& b, uint8_t* base, int lane) {
 #pragma unroll
-  for (int i = 0; i < NPL; ++i) {
-#ifndef KVC_NO_NT
+  for (int i = 0; i < NPL; ++i)
     __builtin_nontemporal_store(b.p[i], reinterpret_cast<u32x4*>(base + ((int64_t)i * 64 + lane) * 16));
-#else
-    *reinterpret_cast<u32x4*>(base + ((int64_t)i * 64 + lane) * 16) = b.p[i];
-#endif
-  }
 }
 
-// order LDS traffic between the lanes of one wave (no other wave shares the tile)
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+// asynchronous copy of one block image HBM -> this wave's LDS buffer (global_load_lds_dwordx4:
+// 64 lanes x 16 B = 1 KiB per instruction, no VGPRs, LDS destination = uniform base + lane*16)
+template <int NPL>
+__device__ __forceinline__ void img_load_lds(uint8_t* lds_base, const uint8_t* base, int lane) {
+#pragma unroll
+  for (int i = 0; i < NPL; ++i)
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(base + ((int64_t)i * 64 + lane) * 16),
+        (__attribute__((address_space(3))) void*)(lds_base + i * 1024), 16, 0, 0);
 }
 
 template <int E>
@@ -161,194 +155,299 @@ __device__ __forceinline__ uint32_t lds_elem(const uint8_t* p) {
   else return *reinterpret_cast<const uint32_t*>(p);
 }
 
-// HD = head size, BS = block size, E = element bytes.  256 threads = 4 independent waves,
-// every wave owns its own tile of tm = 64 - bs consecutive moves and handles the runs that START
-// in it, in order, so a source block that feeds two consecutive runs is fetched once.
+// HD = head size, BS = block size, E = element bytes, WPB = waves per workgroup.  Waves are
+// independent (no workgroup barrier); every wave owns a contiguous range of tiles of
+// tm = 64 - bs consecutive moves and handles the runs that START in its tiles, in order.
 //
-// Patching (per run, per source block feeding it):
-//  * V: the source block image is parked in a per-wave LDS tile with rows padded to RB+4
-//    bytes (conflict-free column access); a move is then, per destination piece, one
-//    ds_read of the element + one shift + one v_bfi under a per-lane mask.
-//  * K: a slot is a whole 16 B piece per K row and lives in the lanes with
-//    (lane % BS) == slot.  The moves of the segment only record, per lane, which source slot
-//    it receives; ONE ds_bpermute pass over the source image then moves all pieces.
-//  * metrics / positions: 16-lane rows, v_readlane + select.
-template <int HD, int BS, int E>
-__global__ __launch_bounds__(256) void compact_runs_kernel(
+// What bounds this kernel is the number of DEPENDENT memory round trips per run, not its
+// instruction count: with the chip's queues full a round trip costs 5-15 us whatever its size
+// (tools/blockmix_bw.hip: the bare access pattern -- read destination + source images, write the
+// destination back, one round trip per run -- sustains 6.0-6.2 TB/s from 8 waves per CU).  So a
+// run is ONE round trip: the destination K / V images are streamed into REGISTERS (lane l holds
+// pieces l, l+64, ...) and, in the same breath, the source images of up to two source blocks
+// straight into this wave's two LDS slots (global_load_lds, asynchronous, no registers); a
+// source block that is already resident (it fed the previous run) is not fetched again; the next
+// tile's moves and the claim bytes of their destination blocks are fetched one tile ahead, and
+// the head walk is incremental.  Then the patch is a handful of lane-masked LDS reads -- there is
+// no per-move loop:
+//  * slot table: the moves of a (run, source block) segment live one per lane; ONE ds_permute
+//    scatters "source slot" to the lane numbered "destination slot", two shuffles pack 4
+//    consecutive entries per lane, and every lane fetches the entries of the slots it owns
+//    (crossbar only, no LDS memory, built while the loads are in flight);
+//  * K: a slot is a whole 16 B piece per K row, owned by the lanes with lane % BS == slot: one
+//    masked ds_read_b128 per image piece from [row][table slot];
+//  * V: a slot is one element of every row; a lane owns EP = 16/E consecutive slots of one row
+//    per piece: per destination dword, 4/E ds_reads of the elements + one v_bfi under the
+//    lane's mask;
+//  * metrics / positions: 16-lane rows, ds_bpermute + select.
+// A source block that contributes <= KVC_CHUNK_MAX slots (high compression: survivors are
+// sparse) has only those 16 B K pieces fetched, straight from HBM.
+// Tried and dropped (profiles/r2_compact_variants.md): not reading the destination K image and
+// storing only the moved 16 B pieces under the lane mask -- FETCH_SIZE falls by 24 %, the kernel
+// gets 11 % SLOWER (partial-line writes are read-modify-writes further down).
+#ifndef KVC_CHUNK_MAX
+#define KVC_CHUNK_MAX 3
+#endif
+template <int HD, int BS, int E, int WPB>
+__global__ __launch_bounds__(64 * WPB) void compact_runs_kernel(
     uint8_t* __restrict__ k_cache, uint8_t* __restrict__ v_cache, float* __restrict__ metrics,
     int32_t* __restrict__ positions, const int32_t* __restrict__ moves,
     const int32_t* __restrict__ count, const int32_t* __restrict__ offs,
     const uint32_t* __restrict__ claims, const int32_t* __restrict__ tile_prefix, int G,
-    int tm, int phases) {
+    int tm) {
   static_assert(BS <= 32 && (BS & (BS - 1)) == 0, "block size must be a power of two <= 32");
-  constexpr int64_t BLOCK_BYTES = (int64_t)HD * BS * E;
-  constexpr int NPL = (int)(BLOCK_BYTES / 16 / 64);          // 16 B pieces per lane
+  constexpr int BLOCK_BYTES = HD * BS * E;
+  constexpr int NPL = BLOCK_BYTES / 16 / 64;                 // 16 B pieces per lane
   static_assert(BLOCK_BYTES % (16 * 64) == 0, "block image must be a multiple of 1 KiB");
   constexpr int KR = HD * E / 16;                            // K rows (16 B pieces per slot)
   constexpr int RB = BS * E;                                 // bytes per V row
   constexpr int PR = RB / 16;                                // pieces (lanes) per V row
-  constexpr int EP = 16 / E;                                 // elements per piece
+  constexpr int EP = 16 / E;                                 // slots per V piece
   constexpr int PER = 4 / E;                                 // elements per dword
-  constexpr int RBP = RB + 4;                                // padded LDS row
+  constexpr int TW = EP / 4;                                 // packed table dwords per lane
+  static_assert(PR >= 1 && PR * EP == BS, "V rows must be whole pieces");
   constexpr uint32_t EMASK = E == 4 ? 0xFFFFFFFFu : ((1u << (8 * E)) - 1u);
-  __shared__ __attribute__((aligned(16))) uint8_t vtile_s[4][HD * RBP];
+  constexpr int SLOT_BYTES = 2 * BLOCK_BYTES;                // one source block: [K image | V image]
+  __shared__ __attribute__((aligned(16))) uint8_t lds_s[WPB][2 * SLOT_BYTES];
   const int lane = threadIdx.x & 63;
-  uint8_t* vtile = vtile_s[threadIdx.x >> 6];
-  int rowoff[NPL];                                           // LDS offset of this lane's V rows
-#pragma unroll
-  for (int i = 0; i < NPL; ++i) rowoff[i] = ((i * 64 + lane) / PR) * RBP;
-  const int my_pr = lane & (PR - 1);
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint8_t* const lds_w = lds_s[wib];
+  const int slot_k = lane & (BS - 1);                        // K / metric slot this lane owns
+  const int kgrp16 = (lane & ~(BS - 1)) * 16;                // byte offset of this lane's K row group
+  const int vrow = (lane / PR) * RB;                         // byte offset of this lane's V row
+  const int vfirst = (lane & (PR - 1)) * EP;                 // first slot of this lane's V pieces
   const int total_tiles = tile_prefix[G];
-  const int nw = gridDim.x * (blockDim.x / WAVE);
-  // every wave walks a CONTIGUOUS range of tiles: consecutive tiles are consecutive moves of
-  // the same head, so the source block held at the end of one tile is usually the first one
-  // the next tile needs (saves one 8 KiB re-read per tile)
-  const int wid = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x >> 6);
+  const int nw = gridDim.x * WPB;
+  const int wid = blockIdx.x * WPB + wib;
   const int t_begin = (int)((int64_t)total_tiles * wid / nw);
   const int t_end = (int)((int64_t)total_tiles * (wid + 1) / nw);
-  BlockImg<NPL> kd, vd, ks;
-  float md = 0.f, ms = 0.f;
-  int pd = 0, ps = 0;
-  int cur_sblk = -1;                                          // source block held in LDS / ms / ps (and ks)
-  bool ks_valid = false;                                      // ks holds cur_sblk's K image
-  for (int t = t_begin; t < t_end; ++t) {
-    const int g = upper_bound_minus1(tile_prefix, G, t);
+  if (t_begin >= t_end) return;
+
+  // ---- tile fetch: incremental head walk + this lane's move (lane q <-> move jbase + q: one
+  // look-behind, tm moves of the tile, BS-1 look-ahead)
+  int g = upper_bound_minus1(tile_prefix, G, t_begin);
+  int g_first = tile_prefix[g], g_next = tile_prefix[g + 1];
+  auto fetch_moves = [&](int t, int& jbase_o, int& j1_o, int& mvx_o, int& mvy_o) {
+    while (t >= g_next) { ++g; g_first = g_next; g_next = tile_prefix[g + 1]; }
     const int cnt = count[g];
-    const int j0 = (t - tile_prefix[g]) * tm;
-    const int j1 = min(cnt, j0 + tm);
+    const int j0 = (t - g_first) * tm;
     const int2* __restrict__ mv = reinterpret_cast<const int2*>(moves) + offs[g];
-    // one move per lane: lane q <-> move jbase + q (one look-behind, BS-1 look-ahead)
-    const int jbase = j0 - 1;
-    int mvx = -1, mvy = -1;
-    {
-      const int q = jbase + lane;
-      if (q >= 0 && q < cnt) { const int2 m = mv[q]; mvx = m.x; mvy = m.y; }
-    }
-    auto MX = [&](int j) { return __builtin_amdgcn_readlane(mvx, j - jbase); };
-    auto MY = [&](int j) { return __builtin_amdgcn_readlane(mvy, j - jbase); };
-    // run starts inside the tile
+    jbase_o = j0 - 1;
+    j1_o = min(cnt, j0 + tm);
+    const int jl = j0 - 1 + lane;
+    mvx_o = -1; mvy_o = -1;
+    if (jl >= 0 && jl < cnt) { const int2 m = mv[jl]; mvx_o = m.x; mvy_o = m.y; }
+  };
+  // claim word of a move's destination block (4 one-byte run counters; 1 = the run is the block's
+  // only writer).  The byte is extracted at the point of use so that issuing the load never waits.
+  auto claim_word = [&](int mx) -> uint32_t {
+    uint32_t w = 0u;
+    if (mx >= 0) w = claims[(mx / BS) >> 2];
+    return w;
+  };
+  auto claim_of = [&](uint32_t w, int mx) -> int { return (int)((w >> (8 * ((mx / BS) & 3))) & 0xFFu); };
+
+  BlockImg<NPL> kd, vd;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) { kd.p[i] = u32x4{0u, 0u, 0u, 0u}; vd.p[i] = u32x4{0u, 0u, 0u, 0u}; }
+  float md = 0.f;
+  int pd = 0;
+  // the two LDS source slots: block held, whether its K image is there too (a "chunky" block has
+  // only its V image fetched), its metric / position row (lanes < BS)
+  int held0 = -1, held1 = -1;
+  bool kval0 = false, kval1 = false;
+  float ms0 = 0.f, ms1 = 0.f;
+  int ps0 = 0, ps1 = 0;
+  int last_slot = 1;
+
+  int jbase, j1, mvx, mvy;
+  fetch_moves(t_begin, jbase, j1, mvx, mvy);
+  uint32_t clw = claim_word(mvx);
+  for (int t = t_begin; t < t_end; ++t) {
+    // the next tile's moves are requested now and land during this tile's first round trip
+    int n_jbase = 0, n_j1 = 0, n_mvx = -1, n_mvy = -1;
+    uint32_t n_clw = 0u;
+    const int clm = claim_of(clw, mvx);
+    const bool has_next = t + 1 < t_end;
+    if (has_next) fetch_moves(t + 1, n_jbase, n_j1, n_mvx, n_mvy);
+    bool clm_pending = has_next;
+
+    const int jl = jbase + lane;
     const int myblk = mvx >= 0 ? mvx / BS : -2;            // destination block of this lane's move
     const int mysb = mvy >= 0 ? mvy / BS : -2;             // source block of this lane's move
     const int left = __shfl_up(myblk, 1, 64);
-    const int jl = jbase + lane;
-    unsigned long long starts = __ballot(jl >= j0 && jl < j1 && (jl == 0 || myblk != left));
+    const int sleft = __shfl_up(mysb, 1, 64);
+    // run starts inside the tile
+    unsigned long long starts = __ballot(jl > jbase && jl < j1 && (jl == 0 || myblk != left));
 
     while (starts) {
-      const int jr = jbase + __ffsll((long long)starts) - 1;  // first move of the run
+      const int qr = __ffsll((long long)starts) - 1;        // lane of the run's first move
       starts &= starts - 1;
-      const int dblk = MX(jr) / BS;
+      const int dblk = __builtin_amdgcn_readlane(myblk, qr);
       // run end (exclusive): first later lane whose destination block differs (lanes past
       // the head's last move hold block -2)
-      int je;
+      int qe;
       {
-        const unsigned long long diff = __ballot(myblk != dblk) & ~((2ull << (jr - jbase)) - 1ull);
-        je = diff ? jbase + __ffsll((long long)diff) - 1 : jbase + 64;
+        const unsigned long long diff = __ballot(myblk != dblk) & ~((2ull << qr) - 1ull);
+        qe = diff ? __ffsll((long long)diff) - 1 : 64;
       }
-      const bool sole = ((claims[dblk >> 2] >> (8 * (dblk & 3))) & 0xFFu) == 1u;
+      const bool sole = __builtin_amdgcn_readlane(clm, qr) == 1;
       uint8_t* kd_p = k_cache + (int64_t)dblk * BLOCK_BYTES;
       uint8_t* vd_p = v_cache + (int64_t)dblk * BLOCK_BYTES;
       if (sole) {
         // a run that overwrites all BS slots (distinct dst slots of one block) leaves nothing
         // of the old block alive: no read-modify-write, the block is only written
-        const bool full = (je - jr) == BS;
-        if (!full) {
-          if (phases & 2) img_load<NPL>(kd, kd_p, lane);
-          if (phases & 4) img_load<NPL>(vd, vd_p, lane);
-          if ((phases & 1) && lane < BS) { md = metrics[(int64_t)dblk * BS + lane]; pd = positions[(int64_t)dblk * BS + lane]; }
-        }
-        int j = jr;
-        while (j < je) {
-          const int sblk = MY(j) / BS;
-          // the moves of this run fed by this source block
-          int seg_end;
-          {
-            const unsigned long long diff = __ballot(mysb != sblk) & ~((2ull << (j - jbase)) - 1ull);
-            seg_end = diff ? jbase + __ffsll((long long)diff) - 1 : jbase + 64;
-            seg_end = seg_end < je ? seg_end : je;
+        bool want_dst = (qe - qr) != BS;
+        // segments = maximal stretches of the run fed by one source block
+        unsigned long long segs = __ballot(lane >= qr && lane < qe && (lane == qr || mysb != sleft));
+        while (segs) {
+          // ---- up to two segments per round trip
+          const int qa = __ffsll((long long)segs) - 1;
+          segs &= segs - 1;
+          const int qa_end = segs ? __ffsll((long long)segs) - 1 : qe;
+          const int sa = __builtin_amdgcn_readlane(mysb, qa);
+          const bool hasb = segs != 0ull;
+          int qb = qe, qb_end = qe, sb = -3;
+          if (hasb) {
+            qb = qa_end;
+            segs &= segs - 1;
+            qb_end = segs ? __ffsll((long long)segs) - 1 : qe;
+            sb = __builtin_amdgcn_readlane(mysb, qb);
           }
-          const bool new_block = sblk != cur_sblk;
-          if (new_block) ks_valid = false;
-          // a source block that contributes only a few slots (high compression: the
-          // survivors are sparse) is not worth 4 KiB of K: fetch just those 16 B pieces
-#ifndef KVC_CHUNK_MAX
-#define KVC_CHUNK_MAX 3
-#endif
-          const bool chunky = !ks_valid && (seg_end - j) <= KVC_CHUNK_MAX;
-          if ((phases & 2) && !chunky && !ks_valid) {         // issued first: overlaps the V staging
-            img_load<NPL>(ks, k_cache + (int64_t)sblk * BLOCK_BYTES, lane);
-            ks_valid = true;
+          // LDS slot of each: the one that already holds the block, else the one not used last
+          const int slot_a = sa == held0 ? 0 : (sa == held1 ? 1 : 1 - last_slot);
+          const int slot_b = 1 - slot_a;
+          const bool new_a = (slot_a == 0 ? held0 : held1) != sa;
+          const bool kv_a = !new_a && (slot_a == 0 ? kval0 : kval1);
+          const bool chunky_a = !kv_a && (qa_end - qa) <= KVC_CHUNK_MAX;
+          const bool new_b = hasb && (slot_b == 0 ? held0 : held1) != sb;
+          const bool kv_b = hasb && !new_b && (slot_b == 0 ? kval0 : kval1);
+          const bool chunky_b = hasb && !kv_b && (qb_end - qb) <= KVC_CHUNK_MAX;
+          uint8_t* const la = lds_w + slot_a * SLOT_BYTES;
+          uint8_t* const lb = lds_w + slot_b * SLOT_BYTES;
+          const uint8_t* ka_p = k_cache + (int64_t)sa * BLOCK_BYTES;
+          const uint8_t* kb_p = k_cache + (int64_t)sb * BLOCK_BYTES;
+          // ---- issue every load of the round trip
+          if (want_dst) {
+            img_load<NPL>(kd, kd_p, lane);
+            img_load<NPL>(vd, vd_p, lane);
+            if (lane < BS) { md = metrics[(int64_t)dblk * BS + lane]; pd = positions[(int64_t)dblk * BS + lane]; }
+            want_dst = false;
           }
-          if (new_block) {
-            if ((phases & 1) && lane < BS) { ms = metrics[(int64_t)sblk * BS + lane]; ps = positions[(int64_t)sblk * BS + lane]; }
-            if (phases & 4) {
-              BlockImg<NPL> vs;
-              img_load<NPL>(vs, v_cache + (int64_t)sblk * BLOCK_BYTES, lane);
-              wave_lds_sync();                               // earlier reads of the tile are done
+          // the LDS reads of earlier patches have returned before a slot is refilled
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          // per physical slot (no value loaded here is consumed before the common wait below; the
+          // metric / position rows go straight into the slot's own registers)
+          const bool a0 = slot_a == 0;
+          const int blk0 = a0 ? sa : sb, blk1 = a0 ? sb : sa;
+          const bool new0 = a0 ? new_a : new_b, new1 = a0 ? new_b : new_a;
+          const bool ldk_a = !chunky_a && !kv_a, ldk_b = hasb && !chunky_b && !kv_b;
+          const bool ldk0 = a0 ? ldk_a : ldk_b, ldk1 = a0 ? ldk_b : ldk_a;
+          if (new0) {
+            img_load_lds<NPL>(lds_w + BLOCK_BYTES, v_cache + (int64_t)blk0 * BLOCK_BYTES, lane);
+            if (lane < BS) { ms0 = metrics[(int64_t)blk0 * BS + lane]; ps0 = positions[(int64_t)blk0 * BS + lane]; }
+            held0 = blk0; kval0 = false;
+          }
+          if (ldk0) { img_load_lds<NPL>(lds_w, k_cache + (int64_t)blk0 * BLOCK_BYTES, lane); kval0 = true; }
+          if (new1) {
+            img_load_lds<NPL>(lds_w + SLOT_BYTES + BLOCK_BYTES, v_cache + (int64_t)blk1 * BLOCK_BYTES, lane);
+            if (lane < BS) { ms1 = metrics[(int64_t)blk1 * BS + lane]; ps1 = positions[(int64_t)blk1 * BS + lane]; }
+            held1 = blk1; kval1 = false;
+          }
+          if (ldk1) { img_load_lds<NPL>(lds_w + SLOT_BYTES, k_cache + (int64_t)blk1 * BLOCK_BYTES, lane); kval1 = true; }
+          // ---- slot tables (crossbar only; overlap the loads).  Lane s < BS receives the entry
+          // of destination slot s: 0x80 | source slot, or 0; then every lane fetches the entry of
+          // its K slot and the packed entries of its V slots.
+          uint32_t tk_a, tk_b = 0u, tw_a[TW], tw_b[TW];
+          auto slot_table = [&](int q0, int q1, uint32_t& tk, uint32_t (&tw)[TW]) {
+            const bool in_seg = lane >= q0 && lane < q1;
+            const int tblv = __builtin_amdgcn_ds_permute((in_seg ? (mvx & (BS - 1)) : 63) * 4,
+                                                         in_seg ? (0x80 | (mvy & (BS - 1))) : 0);
+            tk = (uint32_t)__builtin_amdgcn_ds_bpermute(slot_k * 4, tblv);
+            const uint32_t t1 = (uint32_t)tblv | ((uint32_t)__shfl_down(tblv, 1, 64) << 8);
+            const uint32_t t2 = t1 | ((uint32_t)__shfl_down((int)t1, 2, 64) << 16);   // entries s .. s+3
 #pragma unroll
-              for (int i = 0; i < NPL; ++i) {
-                uint32_t* dst = reinterpret_cast<uint32_t*>(vtile + rowoff[i] + my_pr * 16);
-                dst[0] = vs.p[i].x; dst[1] = vs.p[i].y; dst[2] = vs.p[i].z; dst[3] = vs.p[i].w;
-              }
-              wave_lds_sync();
-            }
-            cur_sblk = sblk;
+            for (int w = 0; w < TW; ++w)
+              tw[w] = (uint32_t)__builtin_amdgcn_ds_bpermute((vfirst + 4 * w) * 4, (int)t2);
+          };
+          slot_table(qa, qa_end, tk_a, tw_a);
+#pragma unroll
+          for (int w = 0; w < TW; ++w) tw_b[w] = 0u;
+          if (hasb) slot_table(qb, qb_end, tk_b, tw_b);
+          // sparse source blocks: just the needed 16 B K pieces, from HBM into registers of their own
+          // (merged after the wait: a load on top of the in-flight destination image would be
+          // serialised behind it)
+          BlockImg<NPL> kc_a, kc_b;
+#pragma unroll
+          for (int i = 0; i < NPL; ++i) { kc_a.p[i] = u32x4{0u, 0u, 0u, 0u}; kc_b.p[i] = u32x4{0u, 0u, 0u, 0u}; }
+          if (chunky_a && (tk_a & 0x80u)) {
+#pragma unroll
+            for (int i = 0; i < NPL; ++i)
+              kc_a.p[i] = *reinterpret_cast<const u32x4*>(ka_p + i * 1024 + kgrp16 + (int)(tk_a & 0x7Fu) * 16);
           }
-          int ksrc = -1;                                      // per lane: source slot it receives
-          for (; j < seg_end; ++j) {
-            const int sy = MY(j);
-            const int so = sy % BS, dsl = MX(j) % BS;
+          if (chunky_b && (tk_b & 0x80u)) {
+#pragma unroll
+            for (int i = 0; i < NPL; ++i)
+              kc_b.p[i] = *reinterpret_cast<const u32x4*>(kb_p + i * 1024 + kgrp16 + (int)(tk_b & 0x7Fu) * 16);
+          }
+          // ---- everything has landed
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          // ---- patch
+          auto patch = [&](const uint8_t* ls, uint32_t tk, const uint32_t (&tw)[TW], bool chunky,
+                           const BlockImg<NPL>& kc, float ms, int ps) {
+            const bool take = (tk & 0x80u) != 0u;
+            const int ksl = kgrp16 + (int)(tk & 0x7Fu) * 16;
             if (chunky) {
-              if ((phases & 2) && (lane & (BS - 1)) == dsl) {
-                const uint8_t* sp = k_cache + (int64_t)sblk * BLOCK_BYTES;
+              if (take) {
 #pragma unroll
-                for (int i = 0; i < NPL; ++i)
-                  kd.p[i] = *reinterpret_cast<const u32x4*>(sp + ((int64_t)((i * 64 + lane) / BS) * BS + so) * 16);
+                for (int i = 0; i < NPL; ++i) kd.p[i] = kc.p[i];
               }
-            } else {
-              ksrc = (lane & (BS - 1)) == dsl ? so : ksrc;
+            } else if (take) {
+#pragma unroll
+              for (int i = 0; i < NPL; ++i)
+                kd.p[i] = *reinterpret_cast<const u32x4*>(ls + i * 1024 + ksl);
             }
-            if (phases & 4) {
-              const int ed = dsl % EP, wd = ed / PER, shd = (ed % PER) * 8 * E;
-              const uint32_t lmask = (my_pr == dsl / EP) ? (EMASK << shd) : 0u;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {                     // destination dword w of every V piece
+              uint32_t mask = 0u;
+              int addr[PER];
+#pragma unroll
+              for (int q = 0; q < PER; ++q) {
+                const int e = w * PER + q;                    // slot vfirst + e
+                const uint32_t tb = (tw[e >> 2] >> (8 * (e & 3))) & 0xFFu;
+                addr[q] = vrow + (int)(tb & 0x7Fu) * E;
+                mask |= (tb & 0x80u) ? (EMASK << (8 * E * q)) : 0u;
+              }
+              if (__ballot(mask != 0u) == 0ull) continue;     // nobody patches this dword
 #pragma unroll
               for (int i = 0; i < NPL; ++i) {
-                const uint32_t val = lds_elem<E>(vtile + rowoff[i] + so * E) << shd;
-                if (wd == 0) vd.p[i].x = bfi(lmask, val, vd.p[i].x);
-                else if (wd == 1) vd.p[i].y = bfi(lmask, val, vd.p[i].y);
-                else if (wd == 2) vd.p[i].z = bfi(lmask, val, vd.p[i].z);
-                else vd.p[i].w = bfi(lmask, val, vd.p[i].w);
+                uint32_t val = 0u;
+#pragma unroll
+                for (int q = 0; q < PER; ++q)
+                  val |= lds_elem<E>(ls + BLOCK_BYTES + i * 1024 + addr[q]) << (8 * E * q);
+                vd.p[i][w] = bfi(mask, val, vd.p[i][w]);
               }
             }
-            if (phases & 1) {
-              const int mval = __builtin_amdgcn_readlane(__builtin_bit_cast(int, ms), so);
-              const int pval = __builtin_amdgcn_readlane(ps, so);
-              md = lane == dsl ? __builtin_bit_cast(float, mval) : md;
-              pd = lane == dsl ? pval : pd;
-            }
-          }
-          if ((phases & 2) && !chunky) {                      // one permute pass moves all K pieces
-            const bool take = ksrc >= 0;
-            const int src_lane4 = ((lane & ~(BS - 1)) | (take ? ksrc : (lane & (BS - 1)))) * 4;
-#pragma unroll
-            for (int i = 0; i < NPL; ++i) {
-              const uint32_t x = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)ks.p[i].x);
-              const uint32_t y = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)ks.p[i].y);
-              const uint32_t z = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)ks.p[i].z);
-              const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)ks.p[i].w);
-              kd.p[i].x = take ? x : kd.p[i].x;
-              kd.p[i].y = take ? y : kd.p[i].y;
-              kd.p[i].z = take ? z : kd.p[i].z;
-              kd.p[i].w = take ? w : kd.p[i].w;
-            }
-          }
+            const int mval = __builtin_amdgcn_ds_bpermute((int)(tk & 0x7Fu) * 4, __builtin_bit_cast(int, ms));
+            const int pval = __builtin_amdgcn_ds_bpermute((int)(tk & 0x7Fu) * 4, ps);
+            md = take ? __builtin_bit_cast(float, mval) : md;
+            pd = take ? pval : pd;
+          };
+          patch(la, tk_a, tw_a, chunky_a, kc_a, slot_a == 0 ? ms0 : ms1, slot_a == 0 ? ps0 : ps1);
+          if (hasb) patch(lb, tk_b, tw_b, chunky_b, kc_b, slot_b == 0 ? ms0 : ms1, slot_b == 0 ? ps0 : ps1);
+          last_slot = hasb ? slot_b : slot_a;
         }
-        if (phases & 2) img_store<NPL>(kd, kd_p, lane);
-        if (phases & 4) img_store<NPL>(vd, vd_p, lane);
-        if ((phases & 1) && lane < BS) { metrics[(int64_t)dblk * BS + lane] = md; positions[(int64_t)dblk * BS + lane] = pd; }
+        // the next tile's moves have landed with the round trip above: request the claim words of
+        // their destination blocks (behind the last LDS read of the patch: the compiler drains
+        // every outstanding load in front of the first LDS read that follows an LDS-DMA)
+        if (clm_pending) { n_clw = claim_word(n_mvx); clm_pending = false; }
+        img_store<NPL>(kd, kd_p, lane);
+        img_store<NPL>(vd, vd_p, lane);
+        if (lane < BS) { metrics[(int64_t)dblk * BS + lane] = md; positions[(int64_t)dblk * BS + lane] = pd; }
       } else {
         // shared destination block: slot-wise, correct for any independent move list
-        for (int j = jr; j < je; ++j) {
-          const int sy = MY(j), dx = MX(j);
+        for (int q = qr; q < qe; ++q) {
+          const int sy = __builtin_amdgcn_readlane(mvy, q), dx = __builtin_amdgcn_readlane(mvx, q);
           const int64_t sb = (int64_t)(sy / BS) * BLOCK_BYTES, db = (int64_t)dblk * BLOCK_BYTES;
           if (lane == 0) { metrics[dx] = metrics[sy]; positions[dx] = positions[sy]; }
           for (int r = lane; r < KR; r += 64)
@@ -364,6 +463,8 @@ __global__ __launch_bounds__(256) void compact_runs_kernel(
         }
       }
     }
+    if (clm_pending) n_clw = claim_word(n_mvx);
+    jbase = n_jbase; j1 = n_j1; mvx = n_mvx; mvy = n_mvy; clw = n_clw;
   }
 }
 
@@ -413,28 +514,6 @@ __global__ __launch_bounds__(256) void compact_generic_kernel(
 
 }  // namespace kvc
 
-// profiling hook (not part of the drop-in surface): bit0 metrics/positions, bit1 K, bit2 V
-static int g_compact_phases = 7;
-extern "C" void kvc_debug_set_compact_phases(int phases) { g_compact_phases = phases; }
-// measurement hook: HIP events recorded on the call's stream immediately before / after the
-// compaction kernel itself (not the planning kernels); pass NULLs to switch it off
-static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
-extern "C" void kvc_debug_set_compact_events(void* start, void* stop) {
-  g_ev_start = (hipEvent_t)start;
-  g_ev_stop = (hipEvent_t)stop;
-}
-// event helpers so that a ctypes caller uses the SAME HIP runtime instance as the kernels
-extern "C" void* kvc_debug_event_create(void) {
-  hipEvent_t e = nullptr;
-  return hipEventCreate(&e) == hipSuccess ? (void*)e : nullptr;
-}
-extern "C" float kvc_debug_event_elapsed_ms(void* start, void* stop) {
-  float ms = -1.0f;
-  if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess) return -1.0f;
-  if (hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) return -1.0f;
-  return ms;
-}
-
 // one byte per block, in whole 16 B vectors
 static size_t claims_bytes(int64_t num_blocks) { return (size_t)((num_blocks + 15) / 16 + 1) * 16; }
 // [prefix: (heads + 1) int32, padded to 16 B][claims]
@@ -444,55 +523,116 @@ extern "C" size_t kvc_execute_cache_moves_workspace_bytes(int32_t total_heads, i
   return claims_offset(total_heads) + claims_bytes(num_blocks);
 }
 
-extern "C" int kvc_execute_cache_moves(void* k_cache, void* v_cache, float* kv_metrics,
-                                       int32_t* kv_position, const int32_t* cache_moves_idx,
-                                       const int32_t* cache_moves_count,
-                                       const int32_t* evicted_kv_offsets, int32_t total_heads,
-                                       int64_t num_blocks, int32_t block_size,
-                                       int32_t head_size, int32_t elem_bytes, int32_t vec_size,
-                                       void* workspace, size_t workspace_bytes,
-                                       kvc_stream_t stream) {
-  using namespace kvc;
+namespace kvc {
+
+// block-path instantiations (head size, block size, element bytes)
+static bool compact_shape_fast(int head_size, int block_size, int elem_bytes, int vec_size) {
+  const int combo = head_size * 10000 + block_size * 100 + elem_bytes;
+  return vec_size * elem_bytes == 16 &&
+      (combo == 1281602 || combo == 1283201 || combo == 1283202 || combo == 1281601 ||
+       combo == 1281604 || combo == 641602 || combo == 2561602);
+}
+
+static int compact_check_args(int32_t total_heads, int64_t num_blocks, int32_t block_size,
+                              int32_t head_size, int32_t elem_bytes, int32_t vec_size,
+                              const void* workspace, size_t workspace_bytes) {
   if (block_size < 1) return fail_invalid("Unsupported block size: " + std::to_string(block_size));
   if (head_size < 1) return fail_invalid("Unsupported head size: " + std::to_string(head_size));
   if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4)
     return fail_invalid("Unsupported cache element size: " + std::to_string(elem_bytes));
-  const int x = vec_size;
-  if (x < 1 || head_size % x != 0)
+  if (vec_size < 1 || head_size % vec_size != 0)
     return fail_invalid("Unsupported vec size: " + std::to_string(vec_size));
   if (total_heads <= 0) return KVC_OK;
   if (workspace_bytes < kvc_execute_cache_moves_workspace_bytes(total_heads, num_blocks))
     return fail_invalid("execute_cache_moves: workspace too small");
-  hipStream_t s = (hipStream_t)stream;
-  int32_t* prefix = reinterpret_cast<int32_t*>(workspace);
   if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0)
     return fail_invalid("execute_cache_moves: workspace must be 16-byte aligned");
+  return KVC_OK;
+}
+
+// persistent grid of the compaction kernel = what is resident at once (asked once per
+// instantiation and device: LDS-bound, 2 block images per wave)
+template <int HD, int BS, int E, int WPB>
+static int compact_runs_grid() {
+  static int grid[64] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (grid[dev] == 0) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, compact_runs_kernel<HD, BS, E, WPB>,
+                                                     64 * WPB, 0) != hipSuccess || per_cu < 1)
+      per_cu = 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+      cus = 256;
+    grid[dev] = per_cu * cus;
+  }
+  return grid[dev];
+}
+
+}  // namespace kvc
+
+#ifndef KVC_COMPACT_WPB
+#define KVC_COMPACT_WPB 4   // waves per workgroup of the compaction kernel (waves are independent; measured:
+                            // 4-wave workgroups, one wave per SIMD, beat single-wave workgroups by 5-7 %)
+#endif
+
+// planning half: tile prefix sums + destination-block claim counts (2 small launches)
+extern "C" int kvc_execute_cache_moves_plan(const int32_t* cache_moves_idx,
+                                            const int32_t* cache_moves_count,
+                                            const int32_t* evicted_kv_offsets, int32_t total_heads,
+                                            int64_t num_blocks, int32_t block_size,
+                                            int32_t head_size, int32_t elem_bytes, int32_t vec_size,
+                                            void* workspace, size_t workspace_bytes,
+                                            kvc_stream_t stream) {
+  using namespace kvc;
+  if (int rc = compact_check_args(total_heads, num_blocks, block_size, head_size, elem_bytes, vec_size,
+                                  workspace, workspace_bytes)) return rc;
+  if (total_heads <= 0) return KVC_OK;
+  hipStream_t s = (hipStream_t)stream;
+  int32_t* prefix = reinterpret_cast<int32_t*>(workspace);
   uint32_t* claims = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(workspace) + claims_offset(total_heads));
   const int G = total_heads;
-  const int grid = 256 * 8;     // persistent: 256 CUs x 8 workgroups of 4 independent waves
   // a wave holds one move per lane: tile + look-behind + (bs-1) look-ahead <= 64 lanes
-  const int combo = head_size * 10000 + block_size * 100 + elem_bytes;   // block-path instantiations
-  const bool shape_fast = x * elem_bytes == 16 &&
-      (combo == 1281602 || combo == 1283201 || combo == 1283202 || combo == 1281601 ||
-       combo == 1281604 || combo == 641602 || combo == 2561602);
-  const int tm = shape_fast ? 64 - block_size : KVC_TM_GENERIC;
-  {
-    const int64_t claim_vecs = (int64_t)(claims_bytes(num_blocks) / 16);
-    const int64_t zb = (claim_vecs + 4095) / 4096;                 // 4 stores per thread
-    hipLaunchKernelGGL(compact_plan_kernel, dim3(1 + (unsigned)(zb < 1 ? 1 : (zb > 1024 ? 1024 : zb))),
-                       dim3(1024), 0, s, prefix, cache_moves_count, G, tm,
-                       reinterpret_cast<u32x4*>(claims), claim_vecs);
-  }
-  hipLaunchKernelGGL(compact_plan_claims_kernel, dim3(grid), dim3(256), 0, s, claims, cache_moves_idx,
+  const int tm = compact_shape_fast(head_size, block_size, elem_bytes, vec_size) ? 64 - block_size : KVC_TM_GENERIC;
+  const int64_t claim_vecs = (int64_t)(claims_bytes(num_blocks) / 16);
+  const int64_t zb = (claim_vecs + 4095) / 4096;                 // 4 stores per thread
+  hipLaunchKernelGGL(compact_plan_kernel, dim3(1 + (unsigned)(zb < 1 ? 1 : (zb > 1024 ? 1024 : zb))),
+                     dim3(1024), 0, s, prefix, cache_moves_count, G, tm,
+                     reinterpret_cast<u32x4*>(claims), claim_vecs);
+  hipLaunchKernelGGL(compact_plan_claims_kernel, dim3(256 * 8), dim3(256), 0, s, claims, cache_moves_idx,
                      cache_moves_count, evicted_kv_offsets, prefix, G, block_size, tm);
+  return check_launch("execute_cache_moves (plan)");
+}
+
+// data half: the compaction kernel itself, on a workspace filled by _plan for the same move list
+extern "C" int kvc_execute_cache_moves_apply(void* k_cache, void* v_cache, float* kv_metrics,
+                                             int32_t* kv_position, const int32_t* cache_moves_idx,
+                                             const int32_t* cache_moves_count,
+                                             const int32_t* evicted_kv_offsets, int32_t total_heads,
+                                             int64_t num_blocks, int32_t block_size,
+                                             int32_t head_size, int32_t elem_bytes, int32_t vec_size,
+                                             void* workspace, size_t workspace_bytes,
+                                             kvc_stream_t stream) {
+  using namespace kvc;
+  if (int rc = compact_check_args(total_heads, num_blocks, block_size, head_size, elem_bytes, vec_size,
+                                  workspace, workspace_bytes)) return rc;
+  if (total_heads <= 0) return KVC_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int32_t* prefix = reinterpret_cast<const int32_t*>(workspace);
+  const uint32_t* claims = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(workspace) + claims_offset(total_heads));
+  const int G = total_heads;
   uint8_t* k = reinterpret_cast<uint8_t*>(k_cache);
   uint8_t* v = reinterpret_cast<uint8_t*>(v_cache);
-#define KVC_RUNS(HD, BS, E)                                                                      \
-  hipLaunchKernelGGL((compact_runs_kernel<HD, BS, E>), dim3(256 * KVC_RUNS_WGS), dim3(256), 0, s, k, v, \
-                     kv_metrics, kv_position, cache_moves_idx, cache_moves_count,                \
-                     evicted_kv_offsets, claims, prefix, G, tm, g_compact_phases)
-  if (g_ev_start) (void)hipEventRecord(g_ev_start, s);
-  bool fast = shape_fast;
+  // a wave's two LDS source slots take 4 block images: 4 waves per workgroup for 4 KiB images
+  // (two workgroups per CU), half as many for 8 KiB images
+#define KVC_WPB(HD, BS, E) ((HD) * (BS) * (E) <= 4096 ? KVC_COMPACT_WPB : (KVC_COMPACT_WPB + 1) / 2)
+#define KVC_RUNS(HD, BS, E)                                                                        \
+  hipLaunchKernelGGL((compact_runs_kernel<HD, BS, E, KVC_WPB(HD, BS, E)>),                          \
+                     dim3(compact_runs_grid<HD, BS, E, KVC_WPB(HD, BS, E)>()),                      \
+                     dim3(64 * KVC_WPB(HD, BS, E)), 0, s, k, v, kv_metrics, kv_position,            \
+                     cache_moves_idx, cache_moves_count, evicted_kv_offsets, claims, prefix, G, 64 - BS)
+  bool fast = compact_shape_fast(head_size, block_size, elem_bytes, vec_size);
   if (!fast) {}
   else if (head_size == 128 && block_size == 16 && elem_bytes == 2) KVC_RUNS(128, 16, 2);
   else if (head_size == 128 && block_size == 32 && elem_bytes == 1) KVC_RUNS(128, 32, 1);
@@ -503,11 +643,28 @@ extern "C" int kvc_execute_cache_moves(void* k_cache, void* v_cache, float* kv_m
   else if (head_size == 256 && block_size == 16 && elem_bytes == 2) KVC_RUNS(256, 16, 2);
   else fast = false;
 #undef KVC_RUNS
+#undef KVC_WPB
   if (!fast) {
-    hipLaunchKernelGGL(compact_generic_kernel, dim3(grid), dim3(256), 0, s, k, v, kv_metrics,
+    hipLaunchKernelGGL(compact_generic_kernel, dim3(256 * 8), dim3(256), 0, s, k, v, kv_metrics,
                        kv_position, cache_moves_idx, cache_moves_count, evicted_kv_offsets, prefix,
-                       G, block_size, head_size, elem_bytes, x);
+                       G, block_size, head_size, elem_bytes, vec_size);
   }
-  if (g_ev_stop) (void)hipEventRecord(g_ev_stop, s);
   return check_launch("execute_cache_moves");
+}
+
+extern "C" int kvc_execute_cache_moves(void* k_cache, void* v_cache, float* kv_metrics,
+                                       int32_t* kv_position, const int32_t* cache_moves_idx,
+                                       const int32_t* cache_moves_count,
+                                       const int32_t* evicted_kv_offsets, int32_t total_heads,
+                                       int64_t num_blocks, int32_t block_size,
+                                       int32_t head_size, int32_t elem_bytes, int32_t vec_size,
+                                       void* workspace, size_t workspace_bytes,
+                                       kvc_stream_t stream) {
+  if (int rc = kvc_execute_cache_moves_plan(cache_moves_idx, cache_moves_count, evicted_kv_offsets,
+                                            total_heads, num_blocks, block_size, head_size, elem_bytes,
+                                            vec_size, workspace, workspace_bytes, stream)) return rc;
+  return kvc_execute_cache_moves_apply(k_cache, v_cache, kv_metrics, kv_position, cache_moves_idx,
+                                       cache_moves_count, evicted_kv_offsets, total_heads, num_blocks,
+                                       block_size, head_size, elem_bytes, vec_size, workspace,
+                                       workspace_bytes, stream);
 }

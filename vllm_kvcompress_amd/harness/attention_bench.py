@@ -44,7 +44,8 @@ def run(S, ctx_len, Hq=32, Hkv=8, hd=128, bs=16, iters=20, record=True, dtype="f
 
     def step_fused():
         ops.paged_attention_kvc_fused_metrics(out, metrics, q, kc, vc, Hkv, hd ** -0.5, bt, ctx, pos, last,
-                                              buf, bs, ctx_len, None, kv_dtype, k_scale, 1.0, True)
+                                              buf, bs, ctx_len, None, kv_dtype, k_scale, 1.0, True,
+                                              temp_metrics=tkm)
 
     def step():
         if fused:
