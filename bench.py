@@ -10,13 +10,16 @@ batch of synthetic paged-cache state resident in HBM:
 
 Default workload = BASELINE.json configs[1]: Llama-3-8B shape (32 layers, 8 KV heads,
 hd 128), 32k-token cache, block_size 16, batch 1, compress_once to half the cache
-(max_cache_tokens = T/2), fp16 K/V, tie-free permutation metrics.  Scheduling always
-reads the pristine metric store; compaction writes working copies, so every step does
-identical work (the moves never touch their own sources).
+(max_cache_tokens = T/2), fp16 K/V, tie-free permutation metrics.  ``--config c3|c4|c5``
+select the other BASELINE configurations (c3: 256 resident sequences in the continual
+steady state; c4: Llama-3-70B shape, 16k tokens, 32 sequences per GPU; c5: fp8, bs 32, 64k).
+Scheduling always reads the pristine metric store; compaction writes working copies, so
+every step does identical work (the moves never touch their own sources).
 
-Multi GPU (launched by torch.distributed.run): sequences are sharded, every rank owns a
-private cache and runs the same per-rank workload (weak scaling); the only collective is
-the reduction of the throughput scalars.
+Multi GPU: ``python bench.py --gpus N`` launches N ranks itself (one per GPU, RCCL) when it
+is not already running under torch.distributed.run; sequences are sharded, every rank owns
+a private cache (weak scaling: the same per-rank workload; ``--scaling strong`` splits a
+fixed batch); the only collective is the reduction of the throughput scalars.
 
 Prints ONE JSON line (rank 0).
 """
@@ -25,6 +28,9 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -36,25 +42,36 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
+CONFIGS = {     # BASELINE.json configs[1..4]; c2 is the configuration the metric is quoted on
+    "c2": {},
+    "c3": {"batch": 256, "steady_cap": 4096},
+    "c4": {"layers": 80, "seq_len": 16384, "batch": 32},
+    "c5": {"kv_dtype": "fp8", "block_size": 32, "seq_len": 65536},
+}
 
-def parse_args():
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS),
+                    help="BASELINE.json configuration (explicit shape flags override it)")
+    ap.add_argument("--layers", type=int, default=None)
     ap.add_argument("--kv-heads", type=int, default=8)
     ap.add_argument("--head-size", type=int, default=128)
-    ap.add_argument("--block-size", type=int, default=16)
-    ap.add_argument("--seq-len", type=int, default=32768, help="cached tokens per sequence")
-    ap.add_argument("--batch", type=int, default=1, help="sequences per GPU")
+    ap.add_argument("--block-size", type=int, default=None)
+    ap.add_argument("--seq-len", type=int, default=None, help="cached tokens per sequence")
+    ap.add_argument("--batch", type=int, default=None, help="sequences per GPU (weak scaling)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="strong: --batch is the whole job's sequence count, split over the GPUs")
     ap.add_argument("--keep", type=float, default=0.5, help="max_cache_tokens / seq_len")
     ap.add_argument("--protected", type=int, default=32)
     ap.add_argument("--metric-shape", default="perm", choices=["perm", "decay", "oldest"])
     ap.add_argument("--mode", default="per_sequence", choices=["per_sequence", "reference"])
-    ap.add_argument("--kv-dtype", default="fp16", choices=["fp16", "fp8"],
+    ap.add_argument("--kv-dtype", default=None, choices=["fp16", "fp8"],
                     help="cache element type (fp8 = 1-byte elements, K vectors of 16)")
-    ap.add_argument("--steady-cap", type=int, default=0,
+    ap.add_argument("--steady-cap", type=int, default=None,
                     help="continual-compression steady state: every head holds this many survivors + 1 "
                          "appended token and is compressed back to the cap (max_cache_tokens)")
     ap.add_argument("--contiguous-blocks", action="store_true",
@@ -65,9 +82,37 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-adjacent", action="store_true",
                     help="skip the decode-attention (F3) side measurement")
+    ap.add_argument("--no-s0", action="store_true", help="skip the S0 (metric aggregation) stage timings")
+    ap.add_argument("--no-probe", action="store_true",
+                    help="skip the access-pattern ceiling probe (tools/libkvc_probe.so)")
     ap.add_argument("--traffic-json", default=os.path.join(REPO, "profiles", "traffic.json"),
                     help="PMC-derived HBM bytes per launch of the compaction kernel, if collected")
-    return ap.parse_args()
+    args = ap.parse_args(argv)
+    preset = CONFIGS[args.config]
+    for key, default in (("layers", 32), ("block_size", 16), ("seq_len", 32768), ("batch", 1),
+                         ("kv_dtype", "fp16"), ("steady_cap", 0)):
+        if getattr(args, key) is None:
+            setattr(args, key, preset.get(key, default))
+    return args
+
+
+# --------------------------------------------------------------------------- launch
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args) -> int:
+    """``python bench.py --gpus N`` outside torch.distributed.run: start N ranks on this node
+    (one per GPU, rendezvous on 127.0.0.1) running this same command line, relay rank 0's line."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env, cwd=REPO).returncode
 
 
 def alg_bytes_per_move(head_size: int, elem_bytes: int) -> int:
@@ -75,14 +120,15 @@ def alg_bytes_per_move(head_size: int, elem_bytes: int) -> int:
     return 4 * head_size * elem_bytes + 24
 
 
-def build_workload(args, seed, device):
+def build_workload(args, seed, device, batch=None):
     import torch
     from vllm_kvcompress_amd.harness import device as hdev
     from vllm_kvcompress_amd.harness import synth
     L, H, bs, hd = args.layers, args.kv_heads, args.block_size, args.head_size
+    batch = args.batch if batch is None else batch
     # seq_len counts the freshly sampled token whose KV is not cached yet
     st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs,
-                          seq_lens=[args.seq_len + 1] * args.batch, seed=seed,
+                          seq_lens=[args.seq_len + 1] * batch, seed=seed,
                           protected=args.protected, metric_shape=args.metric_shape,
                           spare_block_frac=0.02, shuffle_blocks=not args.contiguous_blocks,
                           steady_cap=args.steady_cap or None)
@@ -90,7 +136,7 @@ def build_workload(args, seed, device):
     evicted = [synth.evict_block_count(context_lens_lh=st.context_lens[:, b, :],
                                        seq_len=args.seq_len + 1, block_size=bs,
                                        protected_window_size=args.protected, max_cache_tokens=cap)
-               for b in range(args.batch)]
+               for b in range(batch)]
     ds = hdev.upload(st, device, num_queries_per_kv=1, mode=args.mode)
     ds.cm.lean_outputs = bool(args.lean)
     g = torch.Generator(device=device)
@@ -105,12 +151,169 @@ def build_workload(args, seed, device):
     return st, ds, evicted, k_cache, v_cache
 
 
+def build_workload_that_fits(args, seed, device, batch):
+    """the requested per-GPU batch, or the largest power-of-two fraction of it that fits in HBM
+    next to the workspaces (said in config.workload)"""
+    import torch
+    while True:
+        try:
+            return (batch,) + build_workload(args, seed, device, batch)
+        except torch.OutOfMemoryError:
+            torch.cuda.empty_cache()
+            if batch <= 1:
+                raise
+            batch //= 2
+
+
+# --------------------------------------------------------------------------- roofline helpers
+def traffic_floor(cmi, cmc, offs, bs, block_bytes):
+    """HBM bytes the cache LAYOUT forces for this move list: a destination block is
+    rewritten whole (K + V images) and, unless every slot of it is overwritten, read whole first;
+    every source block is read whole once; + the 8 B metric / position pair of the same slots and
+    the move list itself."""
+    import torch
+    cnt = cmc.reshape(-1).long()
+    total = int(cnt.sum())
+    if total == 0:
+        return {"bytes": 0, "dst_blocks": 0, "dst_blocks_fully_overwritten": 0, "src_blocks": 0}
+    o = offs.reshape(-1).long()
+    start = torch.cumsum(cnt, 0) - cnt
+    rows = torch.repeat_interleave(o - start, cnt) + torch.arange(total, device=cmi.device)
+    dst = cmi[rows, 0].long() // bs
+    src = cmi[rows, 1].long() // bs
+    _, per_dst = torch.unique(dst, return_counts=True)
+    d = int(per_dst.numel())
+    full = int((per_dst == bs).sum())
+    s = int(torch.unique(src).numel())
+    img = 2 * block_bytes + 8 * bs                       # K + V images + metric / position rows
+    return {"bytes": (d - full) * img + d * img + s * img + total * 8,
+            "dst_blocks": d, "dst_blocks_fully_overwritten": full, "src_blocks": s}
+
+
+def pattern_ceiling(k_cache, v_cache, block_bytes, iters=6):
+    """What THIS box sustains for the compaction kernel's bare access pattern (tools/kvc_probe.hip:
+    random block images, one round trip per run, no logic), on the bench's own cache buffers.
+    The same binary differs by 20 % between MI355X boxes (profiles/r2_compact_variants.md)."""
+    import ctypes
+    import torch
+    path = os.path.join(REPO, "tools", "libkvc_probe.so")
+    if block_bytes not in (4096, 8192) or not os.path.exists(path):
+        return None
+    lib = ctypes.CDLL(path)
+    fn = lib.kvc_probe_block_stream
+    fn.restype = ctypes.c_int32
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                   ctypes.c_int32, ctypes.c_void_p]
+    nb = min(int(k_cache.shape[0]), 1 << 20)
+    nruns = nb // 2
+    runs = torch.randperm(nb, device=k_cache.device)[:2 * nruns].to(torch.int32).reshape(nruns, 2).contiguous()
+    stream = torch.cuda.current_stream(k_cache.device).cuda_stream
+    out = {}
+    for name, rd, per_run in (("rmw_2R1W", 1, 6 * block_bytes), ("copy_1R1W", 0, 4 * block_bytes)):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for i in range(2 + iters):
+            if i == 2:
+                a.record()
+            if fn(k_cache.data_ptr(), v_cache.data_ptr(), runs.data_ptr(), nruns, block_bytes, rd, stream):
+                return None
+        b.record()
+        torch.cuda.synchronize()
+        out[name] = per_run * nruns / (a.elapsed_time(b) / iters * 1e-3) / 1e9
+    out["what"] = (f"tools/kvc_probe.hip on this GPU, {nruns} runs over {nb} random {block_bytes}-byte "
+                   "K + V block images: rmw = read destination + source images, write destination "
+                   "(random evictions); copy = read source, write destination (clustered evictions)")
+    return out
+
+
+def s0_stages(args, device):
+    """Stage S0 (metric aggregation, rows A2a / A2b / A2c) at the bench shape, COLD: each call works
+    on the next of several buffer sets whose total exceeds twice the 256 MiB Infinity Cache, so
+    the rates are HBM rates (round 1's single-buffer numbers were cache numbers)."""
+    import torch
+    import vllm_kvcompress_amd
+    from vllm_kvcompress_amd.kvcompress.prefill import accumulate_prefill_tile
+    lib = vllm_kvcompress_amd.load()
+    L, H, bs, qpk = args.layers, args.kv_heads, args.block_size, 4
+    T = min(args.seq_len, 32768)
+    slots = L * H * (T // bs) * bs
+    stream = torch.cuda.current_stream(device).cuda_stream
+    set_bytes = slots * (4 * qpk + 4)
+    nsets = max(2, -(-(640 << 20) // set_bytes))
+    temps = [torch.rand((slots, qpk), device=device) for _ in range(nsets)]
+    mets = [torch.zeros(slots, device=device) for _ in range(nsets)]
+
+    def timed(fn, iters):
+        for i in range(nsets):
+            fn(i)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for i in range(iters):
+            fn(i)
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / iters
+
+    out, iters = {}, 3 * nsets
+    for name, clear, bps in (("S0_aggregate_decode", 0, 4 * qpk + 8), ("S0_aggregate_decode_fused_clear", 1, 8 * qpk + 8)):
+        ms = timed(lambda i: lib.kvc_aggregate_decode(mets[i % nsets].data_ptr(), temps[i % nsets].data_ptr(),
+                                                      slots, qpk, 1, clear, stream), iters)
+        out[name] = {"ms": ms, "slots": slots, "bytes_per_slot": bps, "GBps": slots * bps / ms / 1e6,
+                     "frac_of_hbm_peak": slots * bps / ms / 1e6 / HBM_PEAK_GBPS,
+                     "buffer_sets": nsets, "working_set_MiB": nsets * set_bytes >> 20}
+    # aggregate_prefill: the T tokens of one layer scattered into a cold metric store
+    pm = [torch.rand((T, H * qpk), device=device) for _ in range(nsets)]
+    sm = torch.randperm(slots, device=device)[:T * H].reshape(T, H).contiguous()
+    ms = timed(lambda i: lib.kvc_aggregate_prefill(mets[i % nsets].data_ptr(), pm[i % nsets].data_ptr(),
+                                                   sm.data_ptr(), T, H, qpk, stream), iters)
+    # 64 B sectors: a scattered 4 B read-modify-write moves a whole sector each way
+    out["S0_aggregate_prefill"] = {"ms": ms, "tokens": T, "algorithmic_GBps": T * H * (4 * qpk + 16) / ms / 1e6,
+                                   "note": "T tokens x H heads of one layer; 8 B slot index + 16 B of "
+                                           "weights read, one scattered 4 B metric updated per (token, head)"}
+    del temps, mets, pm, sm
+    torch.cuda.empty_cache()
+    # prefill epilogue: one query block of softmax probabilities (Hq x qb x K floats, 4 GiB at the
+    # bench shape: far beyond any cache)
+    Hq, qb, K = H * qpk, 1024, T
+    probs = torch.rand((Hq, qb, K), device=device)
+    outm = torch.zeros((K, Hq), device=device)
+    for _ in range(2):
+        accumulate_prefill_tile(outm, probs, K - qb, 0, True, False, True)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(4):
+        accumulate_prefill_tile(outm, probs, K - qb, 0, True, False, True)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 4
+    nbytes = Hq * qb * K * 4 + Hq * K * 12
+    out["S0_prefill_epilogue"] = {"ms": ms, "tile": f"Hq{Hq} x qb{qb} x K{K} float32", "GBps": nbytes / ms / 1e6,
+                                  "frac_of_hbm_peak": nbytes / ms / 1e6 / HBM_PEAK_GBPS}
+    del probs, outm
+    torch.cuda.empty_cache()
+    return out
+
+
+# --------------------------------------------------------------------------- CPU baseline
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args):
-    """The oracle (a port of the reference algorithm) on the host, one core: one full S1+S2+S3
-    pass over ONE sequence of the bench's own shape and cache length (the default workload
-    itself: ~5-10 s of CPU work), capped at 32k tokens for bigger configurations."""
+    """The reference's scheduler path on the host cores of this box: S1 in
+    the reference's own formulation -- six global torch.sort calls + the per-sequence host loop,
+    oracle/kvc_oracle_torch.py -- with torch.set_num_threads(all cores); S2 / S3 = the C
+    restatement of the serial kernels, head loop under OpenMP on all cores.  ONE sequence of the
+    bench's shape (the default workload itself), 1 warm-up + 5 timed passes per stage, medians."""
+    import torch
     from oracle import kvc_oracle as orc
     from oracle import kvc_oracle_c as orc_c
+    from oracle import kvc_oracle_torch as orc_t
     from vllm_kvcompress_amd.harness import synth
     L, H, bs, hd = args.layers, args.kv_heads, args.block_size, args.head_size
     T = min(args.seq_len, 32768)
@@ -130,47 +333,76 @@ def cpu_baseline(args):
     k = np.ascontiguousarray(kflat.view(dt).reshape(st.num_blocks, hd // x, bs, x))
     v = np.ascontiguousarray(vflat.view(dt).reshape(st.num_blocks, hd, bs))
     m, p = st.metrics.copy(), st.token_positions.copy()
-    t0 = time.perf_counter()
-    eli, ekc, ebc = orc.schedule_evictions(
-        metrics=st.metrics, token_positions=st.token_positions,
-        seq_index_by_block=st.seq_index_by_block, layer_index_by_block=st.layer_index_by_block,
-        head_index_by_block=st.head_index_by_block,
-        logical_block_num_by_block=st.logical_block_num_by_block, block_size=bs, num_layers=L,
-        num_kv_heads=H, seq_indices=st.seq_indices, seq_positions=st.seq_positions,
-        evicted_blocks_per_seq=evicted, context_lens=st.context_lens,
-        hanging_token_count=st.hanging_token_count, evicted_kv_offsets=st.evicted_kv_offsets,
-        num_protected=st.protected, mode="reference")
-    t1 = time.perf_counter()
+    kw = dict(metrics=st.metrics, token_positions=st.token_positions,
+              seq_index_by_block=st.seq_index_by_block, layer_index_by_block=st.layer_index_by_block,
+              head_index_by_block=st.head_index_by_block,
+              logical_block_num_by_block=st.logical_block_num_by_block, block_size=bs, num_layers=L,
+              num_kv_heads=H, seq_indices=st.seq_indices, seq_positions=st.seq_positions,
+              evicted_blocks_per_seq=evicted, context_lens=st.context_lens,
+              hanging_token_count=st.hanging_token_count, evicted_kv_offsets=st.evicted_kv_offsets,
+              num_protected=st.protected, mode="reference")
+    cores = os.cpu_count() or 1
+    prev_threads = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    orc_c.set_threads(min(cores, orc_c.max_threads()))
+    bt = np.ascontiguousarray(st.block_tables)
+    cl = np.ascontiguousarray(st.context_lens)
+
+    def med(fn, iters=5):
+        fn()                                        # warm-up
+        ts = []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts), r
+
+    s1, (eli, ekc, ebc) = med(lambda: orc_t.schedule_evictions(**kw))
     cmi = np.zeros((st.total_slots, 2), np.int32)
     cmc = np.zeros(ekc.shape, np.int32)
-    orc_c.schedule_cache_moves(cmi, cmc, eli, ekc, st.evicted_kv_offsets,
-                               np.ascontiguousarray(st.block_tables),
-                               np.ascontiguousarray(st.context_lens), bs)
-    t2 = time.perf_counter()
-    orc_c.execute_cache_moves(k, v, m, p, cmi, cmc, st.evicted_kv_offsets)
-    t3 = time.perf_counter()
+    s2, _ = med(lambda: orc_c.schedule_cache_moves(cmi, cmc, eli, ekc, st.evicted_kv_offsets, bt, cl, bs))
+    s3, _ = med(lambda: orc_c.execute_cache_moves(k, v, m, p, cmi, cmc, st.evicted_kv_offsets))
     units = int(ekc.sum()) + int(cmc.sum())
+    torch_threads = torch.get_num_threads()
+    # the round-1 figure for continuity: the same pass on ONE core (NumPy lexsort port + serial C)
+    orc_c.set_threads(1)
+    torch.set_num_threads(prev_threads)
+    t0 = time.perf_counter()
+    eli1, ekc1, _ = orc.schedule_evictions(**kw)
+    t1 = time.perf_counter()
+    orc_c.schedule_cache_moves(cmi, cmc, eli1, ekc1, st.evicted_kv_offsets, bt, cl, bs)
+    orc_c.execute_cache_moves(k, v, m, p, cmi, cmc, st.evicted_kv_offsets)
+    t2 = time.perf_counter()
     same = T == args.seq_len and args.batch == 1 and not args.steady_cap
+    total = s1 + s2 + s3
     return {
-        "value": units / (t3 - t0), "unit": "KV slots/s", "cores": 1, "kind": "port",
+        "value": units / total, "unit": "KV slots/s", "cores": cores, "kind": "port",
+        "torch_threads": torch_threads, "openmp_threads": min(cores, orc_c.max_threads()),
+        "cpu_model": _cpu_model(),
         "sample": ("the bench workload itself" if same else "one sequence of the bench's shape")
                   + f": L{L} H{H} hd{hd}, {T}-token cache, bs{bs}, B=1, keep={args.keep}, "
-                  f"{args.metric_shape} metrics - one S1+S2+S3 pass of the oracle (NumPy "
-                  f"schedule_evictions + C move / compaction loops), {units} slots in {t3 - t0:.2f} s",
-        "stage_seconds": {"S1_schedule": t1 - t0, "S2_moves": t2 - t1, "S3_compact": t3 - t2},
-        "host_cpus": os.cpu_count(),
+                  f"{args.metric_shape} metrics; S1 = the reference's six-sort torch formulation "
+                  "(oracle/kvc_oracle_torch.py), S2/S3 = the C restatement of the serial kernels with the "
+                  f"head loop on all cores; 1 warm-up + 5 passes per stage, medians; {units} slots per pass",
+        "stage_seconds": {"S1_schedule": s1, "S2_moves": s2, "S3_compact": s3},
+        "single_core_port": {"value": units / (t2 - t0), "cores": 1,
+                             "stage_seconds": {"S1_schedule_numpy_lexsort": t1 - t0, "S2_S3_serial_C": t2 - t1},
+                             "note": "one pass, no warm-up (the round-1 baseline)"},
     }
 
 
+# --------------------------------------------------------------------------- main
 def main():
     args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import torch
     import torch.distributed as dist
     from vllm_kvcompress_amd import _custom_ops as ops
     import vllm_kvcompress_amd
     vllm_kvcompress_amd.load()      # fail loudly if the HIP extension is missing
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -178,6 +410,9 @@ def main():
     # one rank per GPU; KVC_BENCH_BACKEND=gloo (test hook) lets several ranks share the one
     # GPU of a single-GPU box to exercise the N > 1 code path
     backend = os.environ.get("KVC_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py --gpus {world}: this node has {torch.cuda.device_count()} GPU(s) "
+                         "(one rank per GPU over RCCL; KVC_BENCH_BACKEND=gloo shares a GPU for tests)")
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     device = f"cuda:{dev_index}"
@@ -188,7 +423,15 @@ def main():
             dist.init_process_group(backend=backend)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    st, ds, evicted, k_cache, v_cache = build_workload(args, seed=rank, device=device)
+    # sequences of this rank: weak = --batch each; strong = --batch split by harness.dist
+    from vllm_kvcompress_amd.harness import dist as hdist
+    if args.scaling == "strong":
+        want_batch = len(hdist.shard_sequences([1.0] * args.batch, world)[rank])
+        if want_batch == 0:
+            raise SystemExit(f"--scaling strong: {args.batch} sequence(s) cannot feed {world} ranks")
+    else:
+        want_batch = args.batch
+    batch, st, ds, evicted, k_cache, v_cache = build_workload_that_fits(args, rank, device, want_batch)
     bs = args.block_size
     N = st.total_slots
     work_metrics = ds.cm.metrics.clone()
@@ -246,7 +489,7 @@ def main():
     evicted_slots = int(out["ekc"].sum().item())
     moved_slots = int(cmc.sum().item())
     freed_blocks = int(out["ebc"].sum().item())
-    if args.mode == "per_sequence" or args.batch == 1:   # the reference's batch>1 quirk frees fewer
+    if args.mode == "per_sequence" or batch == 1:   # the reference's batch>1 quirk frees fewer
         assert freed_blocks == sum(evicted), (freed_blocks, sum(evicted))
     s1 = sum(m[0].elapsed_time(m[1]) for m in marks) / args.steps
     s2 = sum(m[1].elapsed_time(m[2]) for m in marks) / args.steps
@@ -254,7 +497,6 @@ def main():
 
     # whole-job rate = units of all ranks / slowest rank's time; the only collective of the
     # path (RCCL all_gather of two scalars per rank)
-    from vllm_kvcompress_amd.harness import dist as hdist
     units_local = float((evicted_slots + moved_slots) * args.steps)
     red = hdist.reduce_throughput(units_local, elapsed, device=device)
     units, elapsed = red["units"], red["seconds"]
@@ -265,35 +507,47 @@ def main():
 
     if rank == 0:
         e = 1 if args.kv_dtype == "fp8" else 2
+        block_bytes = args.head_size * bs * e
         bpm = alg_bytes_per_move(args.head_size, e)
         alg_bytes = moved_slots * bpm + 8 * st.total_heads
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        default_workload = (args.layers, args.kv_heads, args.head_size, bs, args.seq_len, args.batch,
+        floor = traffic_floor(cmi, cmc, ds.evicted_kv_offsets, bs, block_bytes)
+        floor_gbps = floor["bytes"] / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_source = None, None
+        default_workload = (args.layers, args.kv_heads, args.head_size, bs, args.seq_len, batch,
                             args.keep, args.protected, args.metric_shape, args.kv_dtype,
                             args.steady_cap, args.contiguous_blocks) == (
                                 32, 8, 128, 16, 32768, 1, 0.5, 32, "perm", "fp16", 0, False)
-        # the committed PMC figure belongs to the default workload only
+        # the committed PMC figure belongs to the default workload only; it is a separately
+        # profiled run of the same kernel and workload, not a measurement of this run
         if default_workload and os.path.exists(args.traffic_json):
             try:
-                traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch")
+                tj = json.load(open(args.traffic_json))
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = (f"{os.path.relpath(args.traffic_json, REPO)} "
+                                  f"({tj.get('tag', '?')}; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
+                                  "separate passes over this same command, 2 x FETCH + WRITE)")
             except Exception:
                 traffic = None
+        ceiling = None if (world > 1 or args.no_probe) else pattern_ceiling(k_cache, v_cache, block_bytes)
+        model = "Llama-3-8B" if args.layers == 32 else "Llama-3-70B" if args.layers == 80 else "custom"
         res = {
             "metric": "KV slots evicted+compacted/sec and HBM GB/s, Llama-3-8B 32k cache blk16",
             "value": units / elapsed,
             "unit": "KV slots/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u8",
             "dtype_detail": f"compaction copies bytes ({args.kv_dtype} K/V, {e}-byte elements); scheduling "
                             "compares float32 metrics and computes int32 indices",
             "data": "synthetic (seeded paged cache, tie-free permutation metrics, random K/V bits)",
             "config": {
-                "workload": f"{'Llama-3-8B' if args.layers == 32 else 'Llama-3-70B' if args.layers == 80 else 'custom'} shape L{args.layers} H{args.kv_heads} hd{args.head_size}, "
-                            f"{args.seq_len}-token cache, block_size {bs}, batch {args.batch}/GPU, "
-                            f"{args.kv_dtype} K/V, "
+                "workload": f"{args.config}: {model} shape L{args.layers} H{args.kv_heads} hd{args.head_size}, "
+                            f"{args.seq_len}-token cache, block_size {bs}, batch {batch}/GPU"
+                            + (f" (asked for {want_batch}: the largest that fits in HBM)" if batch != want_batch else "")
+                            + (f" ({args.batch} sequences split over {world} GPUs)" if args.scaling == "strong" else "")
+                            + f", {args.kv_dtype} K/V, "
                             + (f"continual steady state cap={args.steady_cap}+1 token, " if args.steady_cap
                                else f"compress_once keep={args.keep}, ")
                             + f"protected_window={args.protected}, "
@@ -312,16 +566,26 @@ def main():
             "roofline": {
                 "kernel": f"kvc::compact_runs_kernel<{args.head_size},{bs},{e}> (execute_cache_moves)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_move": bpm,
                 "avg_launch_ms": kernel_ms,
                 "timing": "HIP events on the launch stream around the compaction kernel "
                           "(kvc_execute_cache_moves_apply), every timed step",
                 "traffic_frac_of_peak": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                # what the K [NB,hd/x,bs,x] / V [NB,hd,bs] layout forces through HBM for this move list
+                "traffic_floor_bytes": floor["bytes"], "traffic_floor": floor,
+                "floor_GBps": floor_gbps, "frac_of_floor": floor_gbps / HBM_PEAK_GBPS,
+                "pattern_ceiling_GBps": ceiling,
+                "floor_frac_of_pattern_ceiling": (
+                    floor_gbps / (ceiling["rmw_2R1W"] if floor["dst_blocks_fully_overwritten"] * 2 < floor["dst_blocks"]
+                                  else ceiling["copy_1R1W"]) if ceiling else None),
             },
         }
         if per_rank:
             res["per_rank"] = per_rank
+        if world == 1 and not args.no_s0:
+            del cmi, work_metrics, work_pos
+            res["stages_ms_S0"] = s0_stages(args, device)
         if world == 1 and not args.no_adjacent:
             # the producer of the metrics (row F3), one layer step at the continual-compression
             # shape; not part of `value`

@@ -8,15 +8,25 @@
  * loop iteration of the outer head loop); it is pinned to the golden vectors through
  * tests/test_oracle_golden.py (C oracle == NumPy oracle == reference fixtures).
  *
- * build: gcc -O2 -shared -fPIC -o oracle/_build/libkvc_oracle.so oracle/kvc_oracle.c
+ * The outer head loops are independent (one "thread" each in the reference), so they run under
+ * OpenMP: orc_set_threads(n) picks how many host cores the cpu_baseline leg uses (1 = the scalar
+ * port); results do not depend on it.
+ *
+ * build: gcc -O2 -fopenmp -shared -fPIC -o oracle/_build/libkvc_oracle.so oracle/kvc_oracle.c
  */
+#include <omp.h>
 #include <stdint.h>
 #include <string.h>
+
+static int g_threads = 1;
+void orc_set_threads(int32_t n) { g_threads = n < 1 ? 1 : n; }
+int32_t orc_max_threads(void) { return omp_get_num_procs(); }
 
 /* count_block_evictions_kernel   csrc/kvcompress_eviction_kernels.cu:190-221 */
 void orc_count_block_evictions(int32_t* evicted_block_count, int32_t* idx, const int32_t* offs,
                                const int32_t* hang, int32_t total_heads, int64_t total_kvs,
                                int32_t bs, int32_t null_value) {
+#pragma omp parallel for schedule(static) num_threads(g_threads)
   for (int32_t g = 0; g < total_heads; ++g) {
     const int64_t start = offs[g];
     const int64_t end = (g + 1 >= total_heads) ? total_kvs : offs[g + 1];
@@ -40,8 +50,9 @@ void orc_schedule_t1_cache_moves(int32_t* moves, int64_t rows, int32_t* moves_co
                                  int32_t B, int32_t L, int32_t H, int32_t M, int32_t bs,
                                  int32_t zero_fill) {
   if (zero_fill) memset(moves, 0, (size_t)rows * 2 * sizeof(int32_t));
-  for (int32_t b = 0; b < B; ++b)
-    for (int32_t l = 0; l < L; ++l)
+#pragma omp parallel for schedule(dynamic, 4) num_threads(g_threads)
+  for (int32_t bl = 0; bl < B * L; ++bl) {
+      const int32_t b = bl / L, l = bl % L;
       for (int32_t h = 0; h < H; ++h) {
         const int32_t slh = (b * L + l) * H + h;
         const int32_t lsh = (l * B + b) * H + h;
@@ -61,6 +72,7 @@ void orc_schedule_t1_cache_moves(int32_t* moves, int64_t rows, int32_t* moves_co
         }
         moves_count[slh] = mc;
       }
+  }
 }
 
 /* execute_cache_moves_kernel   csrc/kvcompress_eviction_kernels.cu:359-435
@@ -70,6 +82,8 @@ void orc_execute_cache_moves(uint8_t* k, uint8_t* v, float* metrics, int32_t* po
                              int32_t total_heads, int32_t bs, int32_t hd, int32_t e, int32_t x) {
   const int64_t block_stride = (int64_t)bs * hd;      /* elements */
   const int64_t k_stride = (int64_t)bs * x;
+  /* moves are independent (kvcompress_eviction_kernels.cu:358), heads touch disjoint slots */
+#pragma omp parallel for schedule(dynamic, 4) num_threads(g_threads)
   for (int32_t g = 0; g < total_heads; ++g) {
     for (int64_t i = offs[g]; i < (int64_t)offs[g] + count[g]; ++i) {
       const int32_t dst = moves[i * 2], src = moves[i * 2 + 1];

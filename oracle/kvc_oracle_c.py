@@ -26,6 +26,15 @@ def _load():
     return _lib
 
 
+def set_threads(n: int) -> None:
+    """host threads of the head loops (1 = scalar port; results do not depend on it)"""
+    _load().orc_set_threads(ctypes.c_int32(int(n)))
+
+
+def max_threads() -> int:
+    return int(_load().orc_max_threads())
+
+
 def _p(a: np.ndarray):
     assert a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(ctypes.c_void_p)

@@ -1,0 +1,68 @@
+"""bench.py's host-side pieces that need no GPU: argument presets, the layout traffic floor of a
+move list, the cpu_baseline leg (oracle on the host cores) and the self-launch command."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import bench  # noqa: E402
+
+
+def test_config_presets_and_overrides():
+    a = bench.parse_args([])
+    assert (a.layers, a.block_size, a.seq_len, a.batch, a.kv_dtype, a.steady_cap) == (32, 16, 32768, 1, "fp16", 0)
+    a = bench.parse_args(["--config", "c4"])
+    assert (a.layers, a.seq_len, a.batch) == (80, 16384, 32)
+    a = bench.parse_args(["--config", "c3"])
+    assert (a.batch, a.steady_cap) == (256, 4096)
+    a = bench.parse_args(["--config", "c5"])
+    assert (a.kv_dtype, a.block_size, a.seq_len) == ("fp8", 32, 65536)
+    a = bench.parse_args(["--config", "c4", "--batch", "4"])       # explicit flags win
+    assert (a.layers, a.batch) == (80, 4)
+
+
+def test_traffic_floor_of_a_small_move_list():
+    bs, bb = 4, 256
+    # head 0: two moves into block 5 (kept partly) from blocks 9 and 10; head 1: a full overwrite
+    # of block 2 (4 moves) from block 7
+    cmi = torch.tensor([[20, 36], [22, 40], [0, 0], [8, 28], [9, 29], [10, 30], [11, 31]], dtype=torch.int32)
+    cmc = torch.tensor([[[2, 4]]], dtype=torch.int32)
+    offs = torch.tensor([[[0, 3]]], dtype=torch.int32)
+    f = bench.traffic_floor(cmi, cmc, offs, bs, bb)
+    assert (f["dst_blocks"], f["dst_blocks_fully_overwritten"], f["src_blocks"]) == (2, 1, 3)
+    img = 2 * bb + 8 * bs
+    assert f["bytes"] == 1 * img + 2 * img + 3 * img + 6 * 8
+    z = bench.traffic_floor(cmi, torch.zeros_like(cmc), offs, bs, bb)
+    assert z["bytes"] == 0
+
+
+def test_cpu_baseline_leg_runs_on_all_cores():
+    a = bench.parse_args(["--layers", "2", "--kv-heads", "2", "--seq-len", "512"])
+    c = bench.cpu_baseline(a)
+    assert c["kind"] == "port" and c["cores"] == os.cpu_count() and c["value"] > 0
+    assert c["torch_threads"] == os.cpu_count()
+    assert set(c["stage_seconds"]) == {"S1_schedule", "S2_moves", "S3_compact"}
+    assert c["single_core_port"]["cores"] == 1 and c["single_core_port"]["value"] > 0
+
+
+def test_self_launch_command(monkeypatch):
+    seen = {}
+
+    class R:
+        returncode = 0
+
+    def fake_run(cmd, env=None, cwd=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return R()
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    assert bench.self_launch(bench.parse_args(["--gpus", "4", "--steps", "3"])) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

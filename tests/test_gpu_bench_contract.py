@@ -32,21 +32,33 @@ def test_single_rank_line():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
+    assert r["traffic_floor_bytes"] >= r["algorithmic_bytes_per_launch"] > 0
+    assert abs(r["frac_of_floor"] - r["floor_GBps"] / r["peak"]) < 1e-12
+    assert r["pattern_ceiling_GBps"] is None or r["pattern_ceiling_GBps"]["rmw_2R1W"] > 1000
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+    assert c["kind"] == "port" and c["cores"] == os.cpu_count() and c["value"] > 0
+    assert c["single_core_port"]["cores"] == 1
+    s0 = d["stages_ms_S0"]
+    assert {"S0_aggregate_decode", "S0_aggregate_decode_fused_clear", "S0_aggregate_prefill",
+            "S0_prefill_epilogue"} <= set(s0) and all(v["ms"] > 0 for v in s0.values())
     assert "workload" in d["config"] and d["config"]["freed_blocks"] > 0
     # value == units / time
     units = d["config"]["evicted_slots"] + d["config"]["moved_slots"]
     assert abs(d["value"] - units / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
 
 
-def test_two_ranks_share_the_gpu():
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_two_ranks_share_the_gpu(launcher):
+    """`python bench.py --gpus 2` starts its own ranks (the command shape the driver uses); the
+    torch.distributed.run form is what it re-executes itself under"""
     env = dict(os.environ, KVC_BENCH_BACKEND="gloo")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29517",
-                          os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                          "--seq-len", "4096"], capture_output=True, text=True, timeout=900, cwd=REPO,
-                         env=env)
+    tail = [os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--seq-len", "4096"]
+    if launcher == "self":
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", "29517"] + tail
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     d = _last_json(out.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
@@ -56,3 +68,24 @@ def test_two_ranks_share_the_gpu():
     assert abs(d["value"] - units / worst) / d["value"] < 1e-9
     # both ranks processed a full shard of their own
     assert all(r["units"] > 0 for r in d["per_rank"])
+
+
+def test_strong_scaling_splits_a_fixed_batch():
+    env = dict(os.environ, KVC_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2",
+                          "--warmup", "1", "--seq-len", "2048", "--batch", "3", "--scaling", "strong"],
+                         capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and len(d["per_rank"]) == 2
+    u = sorted(r["units"] for r in d["per_rank"])
+    assert abs(u[1] / u[0] - 2.0) < 0.05          # 3 equal sequences -> shards of 1 and 2
+
+
+def test_nccl_with_more_ranks_than_gpus_is_refused():
+    import torch
+    n = torch.cuda.device_count() + 1
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n), "--steps", "1",
+                          "--warmup", "0", "--seq-len", "1024"], capture_output=True, text=True,
+                         timeout=600, cwd=REPO)
+    assert out.returncode != 0 and "GPU(s)" in (out.stderr + out.stdout)

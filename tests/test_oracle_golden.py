@@ -20,6 +20,45 @@ def test_schedule_evictions_matches_reference(name):
 
 
 @pytest.mark.parametrize("name", golden_cases())
+def test_torch_sort_formulation_matches_reference(name):
+    """oracle/kvc_oracle_torch.py (the reference's six-sort formulation on torch CPU tensors, what
+    bench.py's cpu_baseline times) against the same fixtures; bias cases are not restated there"""
+    from oracle import kvc_oracle_torch as orc_t
+    g = load_golden(name)
+    kw = sched_kwargs(g)
+    if "bias" in kw:
+        pytest.skip("bias is restated in kvc_oracle.py only")
+    eli, ekc, ebc = orc_t.schedule_evictions(**kw, mode="reference")
+    np.testing.assert_array_equal(eli, g["ref_evicted_logical_indices"])
+    np.testing.assert_array_equal(ekc, g["ref_evicted_kv_count"])
+    np.testing.assert_array_equal(ebc, g["ref_evicted_block_count"])
+
+
+def test_c_oracle_threads_do_not_change_results():
+    """the OpenMP head loops of oracle/kvc_oracle.c (cpu_baseline runs them on all cores)"""
+    from oracle import kvc_oracle_c as orc_c
+    g = load_golden("b2_bs16_L4H8_med")
+    bs = int(g["block_size"])
+    outs = []
+    for threads in (1, 4):
+        orc_c.set_threads(threads)
+        cmi = np.zeros_like(g["ref_cache_moves_idx"])
+        cmc = np.zeros_like(g["ref_cache_moves_count"])
+        orc_c.schedule_cache_moves(cmi, cmc, g["ref_evicted_logical_indices"], g["ref_evicted_kv_count"],
+                                   g["evicted_kv_offsets"], np.ascontiguousarray(g["block_tables"]),
+                                   np.ascontiguousarray(g["context_lens"]), bs)
+        k, v = golden_caches(g)
+        m, p = g["metrics"].copy(), g["token_positions"].copy()
+        orc_c.execute_cache_moves(k, v, m, p, cmi, cmc, g["evicted_kv_offsets"])
+        outs.append((cmi, cmc, sha(k), sha(v), m, p))
+    orc_c.set_threads(1)
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(outs[0][0], g["ref_cache_moves_idx"])
+    np.testing.assert_array_equal(outs[0][2], g["ref_k_sha256"])
+
+
+@pytest.mark.parametrize("name", golden_cases())
 def test_schedule_and_execute_moves_match_reference(name):
     g = load_golden(name)
     bs = int(g["block_size"])

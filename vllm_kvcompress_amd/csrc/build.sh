@@ -10,3 +10,9 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
   "$HERE/kvc_schedule.hip" "$HERE/kvc_aggregate.hip" "$HERE/kvc_blockstate.hip" \
   "$HERE/kvc_attention.hip" "$HERE/kvc_prefill_attn.hip" -o "$OUT"
 echo "built $OUT"
+# measurement aid for bench.py / tools (never loaded by the package): the bare access pattern of
+# the compaction kernel
+if [ -z "${KVC_OUT:-}" ]; then
+  "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared "$HERE/../../tools/kvc_probe.hip" -o "$HERE/../../tools/libkvc_probe.so"
+  echo "built tools/libkvc_probe.so"
+fi
