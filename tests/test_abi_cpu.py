@@ -112,4 +112,4 @@ def test_sources_are_gfx950_only():
                 for b in banned:
                     assert b not in src, (f, b)
     build = open(os.path.join(pkg, "csrc", "build.sh")).read()
-    assert "--offload-arch=gfx950" in build and build.count("--offload-arch") == 1
+    assert build.count("--offload-arch=gfx950") == build.count("--offload-arch") >= 1
