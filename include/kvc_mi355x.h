@@ -173,6 +173,16 @@ typedef struct kvc_schedule_params {
                                                *   scratch (valid when every logical block below
                                                *   ceil(ctx/bs) of the selected sequences has
                                                *   block metadata, as the engine maintains) */
+  int32_t max_evicted_blocks_hint;            /* host-known upper bound of evicted_blocks_per_seq (the
+                                               * reference passes a Python list, scheduler.py:184-560),
+                                               * or -1 if unknown.  Picks the schedule: when a step frees
+                                               * on average <= 2 blocks per head (bs 16) of short heads --
+                                               * the continual-compression steady state -- every key is
+                                               * read once instead of five times.  Results
+                                               * are identical either way; a wrong hint only costs time. */
+  int32_t schedule_path;                      /* 0 = choose by the hint, 1 = general pipeline only,
+                                               * 2 = small-eviction schedule whenever the shapes allow
+                                               * (falls back on device when it cannot finish exactly) */
   /* outputs */
   int32_t* evicted_logical_indices;           /* [N] */
   int32_t* evicted_kv_count;                  /* [B,L,H] */
@@ -183,6 +193,12 @@ size_t kvc_schedule_evictions_workspace_bytes(int64_t total_slots, int32_t total
                                               int32_t num_seqs, int32_t block_size);
 int kvc_schedule_evictions(const kvc_schedule_params* p, void* workspace,
                            size_t workspace_bytes, kvc_stream_t stream);
+/* introspection (tests, bench.py): 1 if a call with these parameters enqueues the small-eviction
+ * schedule; and the byte offset inside the workspace of that schedule's `fallback` word -- non-zero
+ * after the call if it could not finish exactly and the general pipeline recomputed the result. */
+int32_t kvc_schedule_evictions_uses_small_eviction_schedule(const kvc_schedule_params* p);
+size_t kvc_schedule_evictions_fallback_offset(int64_t total_slots, int32_t total_heads,
+                                              int32_t num_seqs, int32_t block_size);
 
 /* ---------------------------------------------------------------------------------
  * A2a  aggregate_decode (+ clear_temp_metrics fused)

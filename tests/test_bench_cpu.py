@@ -42,8 +42,8 @@ def test_traffic_floor_of_a_small_move_list():
 def test_cpu_baseline_leg_runs_on_all_cores():
     a = bench.parse_args(["--layers", "2", "--kv-heads", "2", "--seq-len", "512"])
     c = bench.cpu_baseline(a)
-    assert c["kind"] == "port" and c["cores"] == os.cpu_count() and c["value"] > 0
-    assert c["torch_threads"] == os.cpu_count()
+    assert c["kind"] == "port" and c["host_cpus"] == os.cpu_count() and c["value"] > 0
+    assert c["cores"] == c["torch_threads"] and str(os.cpu_count()) in c["S1_seconds_by_torch_threads"]
     assert set(c["stage_seconds"]) == {"S1_schedule", "S2_moves", "S3_compact"}
     assert c["single_core_port"]["cores"] == 1 and c["single_core_port"]["value"] > 0
 

@@ -18,11 +18,12 @@ def test_c_host_through_the_c_abi(tmp_path):
     libdir = os.path.join(REPO, "vllm_kvcompress_amd")
     host_o = str(tmp_path / "cabi_host.o")
     orc_o = str(tmp_path / "kvc_oracle.o")
-    subprocess.check_call(["gcc", "-O2", "-c", os.path.join(REPO, "oracle", "kvc_oracle.c"), "-o", orc_o])
+    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-c", os.path.join(REPO, "oracle", "kvc_oracle.c"), "-o", orc_o])
+    gomp = subprocess.check_output(["gcc", "-print-file-name=libgomp.so"], text=True).strip()
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-c",
                            os.path.join(REPO, "tests", "cabi", "cabi_host.cpp"), "-I",
                            os.path.join(REPO, "include"), "-o", host_o])
-    subprocess.check_call([hipcc, host_o, orc_o, "-L", libdir, "-lkvc_mi355x",
+    subprocess.check_call([hipcc, host_o, orc_o, gomp, "-L", libdir, "-lkvc_mi355x",
                            f"-Wl,-rpath,{libdir}", "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "CABI_OK" in out.stdout, out.stdout + out.stderr

@@ -34,6 +34,7 @@ class KvcScheduleParams(ctypes.Structure):
         ("use_average", c_int32), ("num_sinks", c_int32),
         ("bias", c_void_p), ("position_bins", c_void_p), ("num_bins", c_int32),
         ("bias_weight", c_float), ("mode", c_int32), ("null_value", c_int32), ("lean", c_int32),
+        ("max_evicted_blocks_hint", c_int32), ("schedule_path", c_int32),
         ("evicted_logical_indices", c_void_p), ("evicted_kv_count", c_void_p),
         ("evicted_block_count", c_void_p),
     ]
@@ -82,6 +83,8 @@ SYMBOLS = {
     "kvc_schedule_evictions_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32, c_int32]),
     "kvc_schedule_evictions": (c_int32, [ctypes.POINTER(KvcScheduleParams), c_void_p, c_size_t,
                                          c_void_p]),
+    "kvc_schedule_evictions_uses_small_eviction_schedule": (c_int32, [ctypes.POINTER(KvcScheduleParams)]),
+    "kvc_schedule_evictions_fallback_offset": (c_size_t, [c_int64, c_int32, c_int32, c_int32]),
     "kvc_aggregate_decode": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
                                        c_void_p]),
     "kvc_aggregate_prefill": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,

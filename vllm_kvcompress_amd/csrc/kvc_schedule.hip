@@ -43,7 +43,25 @@ struct SchedWs {
   uint32_t* seq_prefix;  // [B]
   int32_t* seq_k;        // [B]      chunks this sequence frees (k'), 0 = inactive
   int32_t* seq_tmp;      // [3B]     F (finite chunks), Cn (all chunks), offset
+  // small-eviction schedule (section 7 below)
+  uint32_t* rec_key;     // [G,KREC] the KREC smallest keys of every head, ascending (canonical tie order)
+  uint32_t* rec_idx;     // [G,KREC] their logical slot indices
+  uint32_t* head_f;      // [G]      finite (evictable) keys of the head
+  uint32_t* seq_fcn;     // [2B]     per sequence: finite-threshold chunks, all chunks (accumulated by head_topk)
+  uint32_t* fallback;    // [1]      != 0: the small-eviction schedule could not finish exactly
+  const uint32_t* gate;  // general-path kernels run only if gate == nullptr or *gate != 0
 };
+
+constexpr int KREC = 256;   // record length of the small-eviction schedule (keys per head)
+
+__device__ __forceinline__ bool gated_off(const SchedWs& ws) { return ws.gate != nullptr && *ws.gate == 0u; }
+
+// order LDS traffic between the lanes of one wave (no other wave shares the buffer)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 __device__ __forceinline__ uint32_t nchunks_freed(uint32_t r, uint32_t hang, uint32_t bs) {
   return r >= hang ? (r - hang) / bs + 1u : 0u;
@@ -90,6 +108,7 @@ __device__ __forceinline__ uint32_t slot_key(const kvc_schedule_params& p, float
 template <int VEC>
 __global__ __launch_bounds__(256) void build_keys_kernel(kvc_schedule_params p, SchedWs ws,
                                                          unsigned data_blocks, uint4* zero16, int64_t zero_vecs) {
+  if (gated_off(ws)) return;
   if (blockIdx.x >= data_blocks) {      // tail workgroups clear the counters of the later passes
     for (int64_t i = (int64_t)(blockIdx.x - data_blocks) * 256 + threadIdx.x; i < zero_vecs;
          i += (int64_t)(gridDim.x - data_blocks) * 256)
@@ -98,10 +117,11 @@ __global__ __launch_bounds__(256) void build_keys_kernel(kvc_schedule_params p, 
   }
   const int bs = p.block_size;
   const int per_blk = bs / VEC;
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // (grid-stride: behind the small-eviction schedule this kernel is launched gated, with a small grid)
+  for (int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; tid < p.num_blocks * per_blk;
+       tid += (int64_t)data_blocks * blockDim.x) {
   const int64_t blk = tid / per_blk;
   const int off = (int)(tid % per_blk) * VEC;
-  if (blk >= p.num_blocks) return;
   // the wide loads do not depend on the metadata chain below: issue them first
   float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f);
   int4 q4 = make_int4(0, 0, 0, 0);
@@ -110,16 +130,16 @@ __global__ __launch_bounds__(256) void build_keys_kernel(kvc_schedule_params p, 
     q4 = *reinterpret_cast<const int4*>(p.token_positions + blk * bs + off);
   }
   const int s = p.seq_index_by_block[blk];
-  if (s < 0 || s >= p.seq_slot_len) return;
+  if (s < 0 || s >= p.seq_slot_len) continue;
   const int i = p.seq_slot_of_seq[s];
-  if (i < 0) return;
+  if (i < 0) continue;
   const int L = p.num_layers, H = p.num_kv_heads, B = p.num_seqs;
   const int l = p.layer_index_by_block[blk], h = p.head_index_by_block[blk];
   const int lbn = p.logical_block_num_by_block[blk];
   const int g = (i * L + l) * H + h;
   const int ctx = p.context_lens[(l * B + i) * H + h];
   const int nblk = (ctx + bs - 1) / bs;
-  if (lbn < 0 || lbn >= nblk) return;          // not part of the head's slot range
+  if (lbn < 0 || lbn >= nblk) continue;        // not part of the head's slot range
   const int seq_pos = p.seq_positions[i], prot = p.num_protected[i];
   const int64_t base = p.evicted_kv_offsets[g];
   const int64_t src = blk * bs + off, dst = base + (int64_t)lbn * bs + off;
@@ -136,6 +156,7 @@ __global__ __launch_bounds__(256) void build_keys_kernel(kvc_schedule_params p, 
     ws.keys[dst] = slot_key(p, p.metrics[src], p.token_positions[src], seq_pos, prot, l, h);
   }
   if (off == 0) ws.chunk_phys[base / bs + lbn] = (int32_t)blk;
+  }
 }
 
 // ------------------------------------------------------------------ 1. per-head histograms
@@ -146,6 +167,7 @@ constexpr int HSEG_MAX = 8;      // head segments of a tile handled by LDS passe
 // first tile is found by one binary search, later tiles advance it incrementally; counts of
 // consecutive tiles of one head stay in LDS and are flushed once per head.
 __global__ __launch_bounds__(256) void hist_round_kernel(kvc_schedule_params p, SchedWs ws, int round) {
+  if (gated_off(ws)) return;
   __shared__ uint32_t sh[RADIX];
   const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
   const int LH = p.num_layers * p.num_kv_heads;
@@ -240,6 +262,7 @@ __global__ __launch_bounds__(256) void hist_round_kernel(kvc_schedule_params p, 
 // ------------------------------------------------------------------ 2. per-head scan
 // one wave per head: hist -> inclusive cumulative; chunkcnt[d] = chunks freed at digit d
 __global__ __launch_bounds__(256) void scan_round_kernel(kvc_schedule_params p, SchedWs ws, int round) {
+  if (gated_off(ws)) return;
   const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
   const int g = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
   if (g >= G) return;
@@ -262,6 +285,7 @@ __global__ __launch_bounds__(256) void scan_round_kernel(kvc_schedule_params p, 
 // ------------------------------------------------------------------ 3. chunks per sequence
 // after round 0's scan: F_i (finite-threshold chunks) and Cn_i (all chunks) ...
 __global__ __launch_bounds__(256) void seq_totals_kernel(kvc_schedule_params p, SchedWs ws) {
+  if (gated_off(ws)) return;
   __shared__ uint32_t red[2][4];
   const int B = p.num_seqs, H = p.num_kv_heads, LH = p.num_layers * H, bs = p.block_size;
   const int i = blockIdx.x;
@@ -283,13 +307,10 @@ __global__ __launch_bounds__(256) void seq_totals_kernel(kvc_schedule_params p, 
 }
 
 // ... and from them the number of chunks k'_i each sequence really frees   metrics.py:704-729
-__global__ __launch_bounds__(1024) void seq_prepare_kernel(kvc_schedule_params p, SchedWs ws) {
-  const int B = p.num_seqs;                          // <= 1024 (checked on host)
-  // everything lives in LDS: the loops below are O(B^2) over three small tables, and walking
-  // them in global memory cost 117 us at 256 sequences
-  __shared__ int64_t un_s[1024];
-  __shared__ int32_t f_s[1024], cn_s[1024], off_s[1024];
-  for (int i = threadIdx.x; i < B; i += blockDim.x) { f_s[i] = ws.seq_tmp[i]; cn_s[i] = ws.seq_tmp[B + i]; }
+// (f_s = finite-threshold chunks, cn_s = all chunks of every sequence, already in LDS)
+__device__ void seq_prepare_body(const kvc_schedule_params& p, SchedWs& ws, int64_t* un_s,
+                                 int32_t* f_s, int32_t* cn_s, int32_t* off_s) {
+  const int B = p.num_seqs;
   __syncthreads();
   if (threadIdx.x == 0) {                            // exclusive prefix of the chunk counts
     int64_t o = 0;
@@ -307,14 +328,11 @@ __global__ __launch_bounds__(1024) void seq_prepare_kernel(kvc_schedule_params p
     }
     return t;
   };
-  {
-    const int i = threadIdx.x;
-    if (i < B) {
-      const int64_t x = (int64_t)off_s[i] + p.evicted_blocks_per_seq[i];
-      int64_t ninf = inf_prefix(x);
-      if (p.mode == 1) ninf -= inf_prefix(off_s[i]);
-      un_s[i] = x - ninf;
-    }
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    const int64_t x = (int64_t)off_s[i] + p.evicted_blocks_per_seq[i];
+    int64_t ninf = inf_prefix(x);
+    if (p.mode == 1) ninf -= inf_prefix(off_s[i]);
+    un_s[i] = x - ninf;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < B; i += blockDim.x) {
@@ -330,9 +348,25 @@ __global__ __launch_bounds__(1024) void seq_prepare_kernel(kvc_schedule_params p
   }
 }
 
+// everything lives in LDS: the loops are O(B^2) over three small tables, and walking them in
+// global memory cost 117 us at 256 sequences.  Any number of sequences: tables of B entries in
+// dynamic LDS (the reference has no limit either).
+__global__ __launch_bounds__(1024) void seq_prepare_kernel(kvc_schedule_params p, SchedWs ws) {
+  if (gated_off(ws)) return;
+  extern __shared__ __attribute__((aligned(16))) uint8_t prep_lds[];
+  const int B = p.num_seqs;
+  int64_t* un_s = reinterpret_cast<int64_t*>(prep_lds);
+  int32_t* f_s = reinterpret_cast<int32_t*>(un_s + B);
+  int32_t* cn_s = f_s + B;
+  int32_t* off_s = cn_s + B;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) { f_s[i] = ws.seq_tmp[i]; cn_s[i] = ws.seq_tmp[B + i]; }
+  seq_prepare_body(p, ws, un_s, f_s, cn_s, off_s);
+}
+
 // ------------------------------------------------------------------ 4. pick the digit
 // one workgroup per sequence: 256 digits x 4 head partitions
 __global__ __launch_bounds__(1024) void pick_round_kernel(kvc_schedule_params p, SchedWs ws, int round) {
+  if (gated_off(ws)) return;
   __shared__ uint32_t part[4][RADIX];
   __shared__ int dstar_s;
   const int i = blockIdx.x;
@@ -378,6 +412,7 @@ __global__ __launch_bounds__(1024) void pick_round_kernel(kvc_schedule_params p,
 // chunks with threshold < T* are freed; chunks with threshold == T* are handed out in
 // (head, chunk) order until the sequence total is k'.           metrics.py:773-792
 __global__ __launch_bounds__(256) void finalize_heads_kernel(kvc_schedule_params p, SchedWs ws) {
+  if (gated_off(ws)) return;
   __shared__ uint32_t wave_tot[4];
   __shared__ uint32_t carry_s;
   __shared__ uint32_t lt_total_s;
@@ -492,6 +527,7 @@ __device__ void block_radix_select(uint32_t* hist, uint32_t* bc, int n, uint32_t
 // lds_cap = number of keys the dynamic LDS buffer can stage (0 = read keys from global/L2)
 template <int SEL_THREADS>
 __global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(kvc_schedule_params p, SchedWs ws, int lds_cap) {
+  if (gated_off(ws)) return;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_keys[];
   __shared__ __attribute__((aligned(16))) uint32_t hist[RADIX];
   __shared__ uint32_t bc[4];
@@ -636,13 +672,349 @@ __global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(kvc_schedule_p
     for (int idx = (int)cnt + tid; idx < n; idx += blockDim.x) out[idx] = p.null_value;
 }
 
+// ------------------------------------------------------------------ 7. small-eviction schedule
+// Continual compression frees about one block per head and step, from thousands of short heads
+// (config 3: 65 536 heads of ~4 k slots).  The general pipeline above writes a key per slot and
+// then reads every key five times (four sequence-level digit rounds + the per-head select) to
+// evict 0.4 % of them.  Here the metrics are read ONCE and no key array exists:
+//   * chunk_table_kernel: block metadata -> physical block of every logical chunk (4 B / block);
+//   * head_topk_kernel: one wave per head gathers the head's metric / position rows through that
+//     table (64 B rows), turns them into keys on the fly, keeps the candidates below a pivot
+//     taken from a 128-key sample, sorts them in LDS and stores the KREC = 256 smallest
+//     (canonical tie order) as the head's record;
+//   * chunk thresholds are every bs-th entry of a record, so the sequence-level selection (one
+//     workgroup per sequence: a sort of the <= 256 / bs thresholds of each of its heads by
+//     (threshold, head, chunk)) and the emission (the first cnt record entries, re-sorted by
+//     logical index) never touch the metrics again.
+// HBM: 1.25 B (metadata) + 8 B (metrics, positions) + 4 B (null padding of the output) per
+// candidate slot = the 12.75 B lower bound of SURVEY 8(d) + 0.5 B of records.
+// A record covers 256 / bs chunks of a head; if a sequence needs more from some head (its k-th
+// threshold reaches the end of a truncated record), a head's candidates overflow the LDS buffer
+// (e.g. all metrics tied) or a head is too long for the sample, `fallback` is raised and the
+// general pipeline -- enqueued behind, gated on that flag -- recomputes everything.  Chosen by the
+// host from kvc_schedule_params.max_evicted_blocks_hint (average <= 256 / bs / 8 blocks per head).
+
+constexpr int CAND_CAP = 1024;      // candidate (key, physical slot) pairs a wave keeps in LDS
+
+// ascending bitonic sort of SZ (power of two >= 128) LDS elements by one wave
+template <typename T, int SZ>
+__device__ void wave_bitonic_sort(T* a) {
+  const int lane = lane_id();
+  for (int k = 2; k <= SZ; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = lane; t < SZ / 2; t += WAVE) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int l = i + j;
+        const bool up = (i & k) == 0;
+        const T x = a[i], y = a[l];
+        if ((x > y) == up) { a[i] = y; a[l] = x; }
+      }
+      wave_lds_sync();
+    }
+}
+
+// physical block of every logical chunk of the selected sequences (the table build_keys also
+// fills); the tail workgroups clear the counters of the later passes
+__global__ __launch_bounds__(256) void chunk_table_kernel(kvc_schedule_params p, SchedWs ws, unsigned data_blocks,
+                                                          uint4* zero16, int64_t zero_vecs) {
+  if (blockIdx.x >= data_blocks) {
+    for (int64_t i = (int64_t)(blockIdx.x - data_blocks) * 256 + threadIdx.x; i < zero_vecs;
+         i += (int64_t)(gridDim.x - data_blocks) * 256)
+      zero16[i] = make_uint4(0u, 0u, 0u, 0u);
+    return;
+  }
+  const int64_t blk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (blk >= p.num_blocks) return;
+  const int s = p.seq_index_by_block[blk];
+  if (s < 0 || s >= p.seq_slot_len) return;
+  const int i = p.seq_slot_of_seq[s];
+  if (i < 0) return;
+  const int bs = p.block_size, L = p.num_layers, H = p.num_kv_heads, B = p.num_seqs;
+  const int l = p.layer_index_by_block[blk], h = p.head_index_by_block[blk];
+  const int lbn = p.logical_block_num_by_block[blk];
+  const int g = (i * L + l) * H + h;
+  const int ctx = p.context_lens[(l * B + i) * H + h];
+  if (lbn < 0 || lbn >= (ctx + bs - 1) / bs) return;       // not part of the head's slot range
+  ws.chunk_phys[p.evicted_kv_offsets[g] / bs + lbn] = (int32_t)blk;
+}
+
+// one wave per head: record = the KREC smallest (key, physical slot) pairs, ascending.
+// LDS per wave: CAND_CAP x 8 B candidates + 128 sorted sample keys
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void head_topk_kernel(kvc_schedule_params p, SchedWs ws) {
+  __shared__ __attribute__((aligned(16))) uint64_t cand_s[WAVES][CAND_CAP];
+  __shared__ uint32_t samp_s[WAVES][4 * WAVE];
+  const int lane = lane_id();
+  const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int L = p.num_layers, H = p.num_kv_heads, B = p.num_seqs;
+  const int G = B * L * H;
+  const int g = blockIdx.x * WAVES + w;
+  if (g >= G) return;
+  uint64_t* cand = cand_s[w];
+  uint32_t* samp = samp_s[w];
+  const int bs = p.block_size;                       // 8, 16 or 32 (host)
+  const int bs_shift = 31 - __builtin_clz(bs);
+  const int i_seq = g / (L * H), l = (g / H) % L, h = g % H;
+  const int64_t base = p.evicted_kv_offsets[g];
+  const int64_t end = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : p.total_slots;
+  const int n = (int)(end - base);
+  const int nchunks = n / bs;
+  const int ctx = p.context_lens[(l * B + i_seq) * H + h];
+  const int seq_pos = p.seq_positions[i_seq], prot = p.num_protected[i_seq];
+  const uint32_t hang = (uint32_t)p.hanging_token_count[g];
+  const int32_t* cphys = ws.chunk_phys + base / bs;
+  // null padding of the head's output segment (emit_topk overwrites its first cnt entries)
+  if (!(p.lean & 1)) {
+    typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+    i32x4* o4 = reinterpret_cast<i32x4*>(p.evicted_logical_indices + base);
+    const i32x4 nv = {p.null_value, p.null_value, p.null_value, p.null_value};
+    for (int i = lane; i < n / 4; i += WAVE) __builtin_nontemporal_store(nv, o4 + i);
+  }
+  // ---- pivot: heads that fit the candidate buffer take every evictable key; longer ones the
+  // rank of a 256-key sample (four slots of each of 64 evenly spaced chunks) that leaves about
+  // 1.6 x KREC candidates
+  constexpr int NSAMP = 4 * WAVE;
+  uint32_t pivot = KEY_INF - 1u;
+  int rank = NSAMP - 1;
+  if (n > CAND_CAP) {
+    const int phys = cphys[(int)((int64_t)lane * nchunks / WAVE)];
+    float sm[4];
+    int sq[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      sm[k] = 0.f; sq[k] = 0;
+      if (phys >= 0) {                               // (phys < 0: nobody claimed the chunk)
+        const int64_t sl = (int64_t)phys * bs + (lane * 5 + k * (bs / 4)) % bs;
+        sm[k] = p.metrics[sl];
+        sq[k] = p.token_positions[sl];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      samp[k * WAVE + lane] = phys >= 0 ? slot_key(p, sm[k], sq[k], seq_pos, prot, l, h) : 0xFFFFFFFFu;
+    wave_lds_sync();
+    wave_bitonic_sort<uint32_t, NSAMP>(samp);
+    rank = (int)((int64_t)NSAMP * (KREC + KREC * 5 / 8) / n);
+    rank = rank < 4 ? 4 : (rank > NSAMP - 1 ? NSAMP - 1 : rank);
+    pivot = samp[rank];
+    if (pivot >= KEY_INF) pivot = KEY_INF - 1u;
+  }
+  // ---- gather pass(es): metric / position rows through the chunk table, keys on the fly,
+  // candidates (key <= pivot) compacted into LDS.  16 row pairs are requested before the first
+  // one is used (a wave has one head: the round trips, not the bytes, are what it waits for).
+  constexpr int UB = 16;
+  uint32_t F = 0, C = 0;
+  for (int attempt = 0;; ++attempt) {
+    F = 0; C = 0;
+    int my_phys = lane < nchunks ? cphys[lane] : -1;
+    for (int c0 = 0; c0 < nchunks; c0 += WAVE) {     // groups of 64 chunks
+      const int gch = min(WAVE, nchunks - c0);
+      const int iters = (gch * bs + WAVE - 1) / WAVE;
+      const int cnext = c0 + WAVE + lane;
+      const int next_phys = cnext < nchunks ? cphys[cnext] : -1;
+      for (int ib = 0; ib < iters; ib += UB) {
+        // branch-free on purpose: with control flow between the loads the compiler drains the
+        // whole queue (vmcnt(0)) in front of every shuffle, one round trip per iteration
+        float m[UB];
+        int q[UB], ph[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int sidx = (ib + u) * WAVE + lane;   // slot inside this group of chunks
+          const int cl = sidx >> bs_shift;
+          const int pv = __shfl(my_phys, cl & (WAVE - 1), 64);
+          ph[u] = (ib + u < iters && cl < gch) ? pv : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int sidx = (ib + u) * WAVE + lane;
+          const int64_t sl = (int64_t)(ph[u] < 0 ? 0 : ph[u]) * bs + (sidx & (bs - 1));
+          m[u] = p.metrics[sl];
+          q[u] = p.token_positions[sl];
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int sidx = (ib + u) * WAVE + lane;
+          const uint32_t k0 = slot_key(p, m[u], q[u], seq_pos, prot, l, h);
+          const uint32_t key = ph[u] >= 0 ? k0 : 0xFFFFFFFFu;          // (phys < 0: nobody claimed the chunk)
+          F += (uint32_t)__popcll(__ballot(key < KEY_INF));
+          const bool sel = key <= pivot && key < KEY_INF;
+          const unsigned long long bal = __ballot(sel);
+          const uint32_t pos = C + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+          if (sel && pos < (uint32_t)CAND_CAP)
+            cand[pos] = ((uint64_t)key << 32) | ((uint32_t)ph[u] * (uint32_t)bs + (uint32_t)(sidx & (bs - 1)));
+          C += (uint32_t)__popcll(bal);
+        }
+      }
+      my_phys = next_phys;
+    }
+    const uint32_t need = F < (uint32_t)KREC ? F : (uint32_t)KREC;
+    if (C >= need && C <= (uint32_t)CAND_CAP) break;
+    // the sample misjudged this head: too few candidates -> twice the rank, overflow -> half of it
+    // (rows now come from L2).  All metrics tied, or four misses: the general pipeline takes over.
+    const bool over = C > (uint32_t)CAND_CAP;
+    if (attempt >= 3 || (over && rank <= 1) || (!over && rank >= NSAMP - 1)) {
+      if (lane == 0) atomicOr(ws.fallback, 1u);
+      return;
+    }
+    rank = over ? rank / 2 : (rank * 2 < NSAMP - 1 ? rank * 2 : NSAMP - 1);
+    pivot = (rank >= NSAMP - 1 || n <= CAND_CAP) ? KEY_INF - 1u : samp[rank];
+    if (pivot >= KEY_INF) pivot = KEY_INF - 1u;
+  }
+  // ---- exact part: sort the candidates by (key, physical slot), keep the first KREC
+  wave_lds_sync();
+  const int SZ = C <= 256 ? 256 : (C <= 512 ? 512 : 1024);
+  for (int j = (int)C + lane; j < SZ; j += WAVE) cand[j] = ~0ull;
+  wave_lds_sync();
+  if (SZ == 256) wave_bitonic_sort<uint64_t, 256>(cand);
+  else if (SZ == 512) wave_bitonic_sort<uint64_t, 512>(cand);
+  else wave_bitonic_sort<uint64_t, 1024>(cand);
+  for (int j = lane; j < KREC; j += WAVE) {
+    const uint64_t e = cand[j];
+    uint32_t key = 0xFFFFFFFFu, idx = 0xFFFFFFFFu;
+    if (e != ~0ull) {
+      const uint32_t fk = (uint32_t)e;
+      key = (uint32_t)(e >> 32);
+      idx = (uint32_t)p.logical_block_num_by_block[fk / (uint32_t)bs] * (uint32_t)bs + fk % (uint32_t)bs;
+    }
+    ws.rec_key[(int64_t)g * KREC + j] = key;
+    ws.rec_idx[(int64_t)g * KREC + j] = idx;
+  }
+  if (lane == 0) {
+    ws.head_f[g] = F;
+    atomicAdd(&ws.seq_fcn[i_seq], nchunks_freed(F, hang, (uint32_t)bs));          // finite-threshold chunks
+    atomicAdd(&ws.seq_fcn[B + i_seq], (uint32_t)((ctx + bs - 1) / bs));          // all chunks
+  }
+}
+
+// the k'_i of seq_prepare_body from the per-sequence chunk counts head_topk_kernel accumulated
+__global__ __launch_bounds__(1024) void seq_prepare_topk_kernel(kvc_schedule_params p, SchedWs ws) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t prep_lds[];
+  const int B = p.num_seqs;
+  int64_t* un_s = reinterpret_cast<int64_t*>(prep_lds);
+  int32_t* f_s = reinterpret_cast<int32_t*>(un_s + B);
+  int32_t* cn_s = f_s + B;
+  int32_t* off_s = cn_s + B;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) { f_s[i] = (int32_t)ws.seq_fcn[i]; cn_s[i] = (int32_t)ws.seq_fcn[B + i]; }
+  seq_prepare_body(p, ws, un_s, f_s, cn_s, off_s);
+}
+
+// one workgroup per sequence: sort the recorded thresholds of its heads by (threshold, head,
+// chunk); the first k' are the freed chunks (metrics.py:704-729 + 773-792)
+__global__ __launch_bounds__(1024) void seq_select_topk_kernel(kvc_schedule_params p, SchedWs ws, int P2) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t sel_lds[];
+  uint64_t* arr = reinterpret_cast<uint64_t*>(sel_lds);
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(arr + P2);
+  const int i = blockIdx.x;
+  const int LH = p.num_layers * p.num_kv_heads;
+  const uint32_t bs = (uint32_t)p.block_size;
+  const int MCH = KREC / p.block_size;               // thresholds a record holds
+  const uint32_t k = (uint32_t)ws.seq_k[i];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < P2; e += blockDim.x) {
+    const int lh = e / MCH, c = e % MCH;
+    uint64_t v = ~0ull;
+    if (lh < LH && k > 0) {
+      const int64_t g = (int64_t)i * LH + lh;
+      const uint32_t hang = (uint32_t)p.hanging_token_count[g];
+      const uint32_t have = min(ws.head_f[g], (uint32_t)KREC);
+      const uint32_t r = hang - 1u + (uint32_t)c * bs;          // rank - 1 of threshold c
+      if (hang >= 1u && r < have) v = ((uint64_t)ws.rec_key[g * KREC + r] << 32) | (uint32_t)e;
+    }
+    arr[e] = v;
+  }
+  for (int lh = tid; lh < LH; lh += blockDim.x) cnt[lh] = 0;
+  __syncthreads();
+  if (k > 0) {
+    for (int kk = 2; kk <= P2; kk <<= 1)
+      for (int j = kk >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < P2 / 2; t += blockDim.x) {
+          const int a = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          const int b = a + j;
+          const bool up = (a & kk) == 0;
+          const uint64_t x = arr[a], y = arr[b];
+          if ((x > y) == up) { arr[a] = y; arr[b] = x; }
+        }
+        __syncthreads();
+      }
+    for (uint32_t e = tid; e < k; e += blockDim.x) {
+      const uint64_t v = e < (uint32_t)P2 ? arr[e] : ~0ull;
+      if (v == ~0ull) atomicOr(ws.fallback, 1u);     // the records do not hold k' thresholds
+      else atomicAdd(&cnt[(uint32_t)v / (uint32_t)MCH], 1u);
+    }
+  }
+  __syncthreads();
+  const uint32_t Tstar = (k > 0 && k <= (uint32_t)P2) ? (uint32_t)(arr[k - 1] >> 32) : 0u;
+  if (tid == 0) ws.seq_prefix[i] = Tstar;
+  for (int lh = tid; lh < LH; lh += blockDim.x) {
+    const int64_t g = (int64_t)i * LH + lh;
+    const uint32_t hang = (uint32_t)p.hanging_token_count[g];
+    const uint32_t n = k > 0 ? cnt[lh] : 0u;
+    if (k > 0) {
+      // a head whose record is truncated must not reach the cut: every threshold it does not
+      // list is >= the record's last key, which therefore has to lie strictly above T*
+      const uint32_t F = ws.head_f[g];
+      if (F > (uint32_t)KREC && nchunks_freed(F, hang, bs) > nchunks_freed((uint32_t)KREC, hang, bs) &&
+          !(ws.rec_key[g * KREC + KREC - 1] > Tstar))
+        atomicOr(ws.fallback, 1u);
+    }
+    p.evicted_block_count[g] = (int32_t)n;
+    p.evicted_kv_count[g] = n > 0 ? (int32_t)((n - 1) * bs + hang) : 0;
+  }
+}
+
+// one wave per head: the first cnt record entries, ascending by logical index  (metrics.py:822-834)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void emit_topk_kernel(kvc_schedule_params p, SchedWs ws) {
+  __shared__ uint32_t sort_s[WAVES][KREC];
+  if (*ws.fallback != 0u) return;                    // the general pipeline (gated behind) writes everything
+  const int lane = lane_id();
+  const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
+  const int g = blockIdx.x * WAVES + w;
+  if (g >= G) return;
+  const uint32_t cnt = (uint32_t)p.evicted_kv_count[g];
+  if (cnt == 0) return;
+  int32_t* out = p.evicted_logical_indices + p.evicted_kv_offsets[g];
+  if (cnt <= (uint32_t)WAVE) {
+    // the usual case (a block or two per head): one index per lane, bitonic sort across the lanes
+    uint32_t v = (uint32_t)lane < cnt ? ws.rec_idx[(int64_t)g * KREC + lane] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 2; k <= WAVE; k <<= 1)
+#pragma unroll
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, j, 64);
+        const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+        v = (lower == up) ? (v < o ? v : o) : (v > o ? v : o);
+      }
+    if ((uint32_t)lane < cnt) out[lane] = (int32_t)v;
+    return;
+  }
+  uint32_t* a = sort_s[w];
+  for (int j = lane; j < KREC; j += WAVE)
+    a[j] = (uint32_t)j < cnt ? ws.rec_idx[(int64_t)g * KREC + j] : 0xFFFFFFFFu;
+  wave_lds_sync();
+  wave_bitonic_sort<uint32_t, KREC>(a);
+  for (int j = lane; j < (int)cnt; j += WAVE) out[j] = (int32_t)a[j];
+}
+
+// general pipeline behind the small-eviction schedule (gated): keys of chunks nobody claimed were
+// not cleared on that path
+__global__ __launch_bounds__(256) void fix_unclaimed_kernel(kvc_schedule_params p, SchedWs ws) {
+  if (gated_off(ws)) return;
+  const int64_t nchunks = p.total_slots / p.block_size;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += (int64_t)gridDim.x * blockDim.x)
+    if (ws.chunk_phys[c] < 0)
+      for (int o = 0; o < p.block_size; ++o) ws.keys[c * p.block_size + o] = 0xFFFFFFFFu;
+}
+
 }  // namespace kvc
 
 // --------------------------------------------------------------------------- host side
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout {
-  size_t keys, zero_begin, chunk_phys, hist, less, eq, seq_prefix, seq_k, zero_end, cum, chunkcnt, seq_tmp, total;
+  size_t keys, zero_begin, chunk_phys, hist, less, eq, seq_prefix, seq_k, zero_end, cum, chunkcnt,
+      seq_tmp, tz_begin, fallback, seq_fcn, tz_end, rec_key, rec_idx, head_f, total;
 };
 
 static WsLayout ws_layout(int64_t N, int32_t G, int32_t B, int32_t bs) {
@@ -660,8 +1032,54 @@ static WsLayout ws_layout(int64_t N, int32_t G, int32_t B, int32_t bs) {
   l.cum = o;         o = align_up(o + (size_t)4 * G * kvc::RADIX * 4, 256);
   l.chunkcnt = o;    o = align_up(o + (size_t)G * kvc::RADIX * 4, 256);
   l.seq_tmp = o;     o = align_up(o + (size_t)B * 12, 256);
+  l.tz_begin = o;    // cleared by chunk_table_kernel's tail workgroups (small-eviction schedule)
+  l.fallback = o;    o = align_up(o + 16, 256);
+  l.seq_fcn = o;     o = align_up(o + (size_t)B * 8, 256);
+  l.tz_end = o;
+  l.rec_key = o;     o = align_up(o + (size_t)G * kvc::KREC * 4, 256);
+  l.rec_idx = o;     o = align_up(o + (size_t)G * kvc::KREC * 4, 256);
+  l.head_f = o;      o = align_up(o + (size_t)G * 4, 256);
   l.total = o;
   return l;
+}
+
+// small-eviction schedule (section 7) or not: the host knows how many blocks a sequence frees at
+// most (the reference passes a Python list); eligible when that is on average <= 1/8 of what a
+// head's record covers, the heads fit a wave's LDS staging buffer and a sequence's thresholds fit
+// one workgroup's LDS.  cap = keys staged per wave, p2 = padded threshold count per sequence.
+static void topk_plan(const kvc_schedule_params& p, int& cap, int& p2_out) {
+  cap = 0; p2_out = 0;
+  const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
+  if (G < 1 || p.total_slots <= 0) return;
+  const int LH = p.num_layers * p.num_kv_heads;
+  const int64_t avg_head = p.total_slots / G;
+  const int bsz = p.block_size;
+  if (!(bsz == 8 || bsz == 16 || bsz == 32) || avg_head > 8192 || p.schedule_path == 1) return;
+  const int mch = kvc::KREC / bsz;
+  int p2 = 128;
+  while (p2 < LH * mch && p2 <= 16384) p2 <<= 1;
+  if (p2 > 16384) return;
+  const bool hint_ok = p.schedule_path == 2 ||
+      (p.max_evicted_blocks_hint >= 0 && (int64_t)p.max_evicted_blocks_hint * 8 <= (int64_t)mch * LH);
+  if (!hint_ok) return;
+  const int64_t want = (avg_head + avg_head / 8 + 63) / 64 * 64 + 64;   // 12 % slack for ragged heads
+  cap = (int)(want < 1024 ? 1024 : want);
+  p2_out = p2;
+}
+
+// introspection for tests and bench.py: 1 if a call with these parameters enqueues the
+// small-eviction schedule; byte offset of its `fallback` word inside the workspace (non-zero
+// after the call = the general pipeline behind it recomputed the result)
+extern "C" int32_t kvc_schedule_evictions_uses_small_eviction_schedule(const kvc_schedule_params* p) {
+  int cap = 0, p2 = 0;
+  if (p != nullptr) topk_plan(*p, cap, p2);
+  return cap > 0 ? 1 : 0;
+}
+static WsLayout ws_layout(int64_t N, int32_t G, int32_t B, int32_t bs);
+extern "C" size_t kvc_schedule_evictions_fallback_offset(int64_t total_slots, int32_t total_heads,
+                                                         int32_t num_seqs, int32_t block_size) {
+  if (block_size < 1) return 0;
+  return ws_layout(total_slots, total_heads, num_seqs, block_size).fallback;
 }
 
 extern "C" size_t kvc_schedule_evictions_workspace_bytes(int64_t total_slots, int32_t total_heads,
@@ -675,8 +1093,9 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   using namespace kvc;
   const kvc_schedule_params p = *pp;
   if (p.block_size < 1) return fail_invalid("Unsupported block size: " + std::to_string(p.block_size));
-  if (p.num_seqs < 1 || p.num_seqs > 1024)
-    return fail_invalid("schedule_evictions: num_seqs must be in [1,1024]");
+  // (the per-sequence tables of seq_prepare live in LDS: 20 B per sequence of the 160 KiB)
+  if (p.num_seqs < 1 || p.num_seqs > 8000)
+    return fail_invalid("schedule_evictions: num_seqs must be in [1,8000]");
   if (p.mode != 0 && p.mode != 1) return fail_invalid("schedule_evictions: mode must be 0 or 1");
   if (p.total_slots < 0 || p.total_slots >= (int64_t)2147483647)
     return fail_invalid("schedule_evictions: total slots must stay below 2^31 (int32 offsets)");
@@ -701,6 +1120,12 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   ws.seq_prefix = reinterpret_cast<uint32_t*>(wb + l.seq_prefix);
   ws.seq_k = reinterpret_cast<int32_t*>(wb + l.seq_k);
   ws.seq_tmp = reinterpret_cast<int32_t*>(wb + l.seq_tmp);
+  ws.rec_key = reinterpret_cast<uint32_t*>(wb + l.rec_key);
+  ws.rec_idx = reinterpret_cast<uint32_t*>(wb + l.rec_idx);
+  ws.head_f = reinterpret_cast<uint32_t*>(wb + l.head_f);
+  ws.fallback = reinterpret_cast<uint32_t*>(wb + l.fallback);
+  ws.seq_fcn = reinterpret_cast<uint32_t*>(wb + l.seq_fcn);
+  ws.gate = nullptr;
   if (p.total_slots == 0) {
     hipMemsetAsync(p.evicted_kv_count, 0, (size_t)G * 4, s);
     hipMemsetAsync(p.evicted_block_count, 0, (size_t)G * 4, s);
@@ -709,22 +1134,61 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   // keys default to "not evictable" (0xFFFFFFFF > KEY_INF) and the chunk table to -1 for slots
   // no physical block claims (inconsistent metadata); histograms and counters are zeroed by
   // the tail workgroups of build_keys
-  if (!(p.lean & 2)) hipMemsetAsync(ws.keys, 0xFF, l.zero_begin - l.keys, s);
+  const int LH = p.num_layers * p.num_kv_heads;
+  int topk_cap = 0, topk_p2 = 0;
+  topk_plan(p, topk_cap, topk_p2);
+  const bool topk = topk_cap > 0;
+  const size_t prep_lds = (size_t)B * 20;
+  if (prep_lds > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_prepare_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_prepare_topk_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
+  }
+  if (topk) {
+    // ---- small-eviction schedule (section 7): 6 launches; the general pipeline is enqueued
+    // behind it and runs only if the flag was raised
+    if (!(p.lean & 2)) hipMemsetAsync(ws.chunk_phys, 0xFF, l.zero_begin - l.chunk_phys, s);
+    {
+      uint4* z16 = reinterpret_cast<uint4*>(wb + l.tz_begin);
+      const int64_t zv = (int64_t)((l.tz_end - l.tz_begin) / 16);
+      const unsigned db = (unsigned)((p.num_blocks + 255) / 256);
+      hipLaunchKernelGGL(chunk_table_kernel, dim3(db + 1), dim3(256), 0, s, p, ws, db, z16, zv);
+    }
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_select_topk_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_done = true;
+    }
+    constexpr int TW = 4;
+    hipLaunchKernelGGL(head_topk_kernel<TW>, dim3((G + TW - 1) / TW), dim3(64 * TW), 0, s, p, ws);
+    hipLaunchKernelGGL(seq_prepare_topk_kernel, dim3(1), dim3(1024), prep_lds, s, p, ws);
+    hipLaunchKernelGGL(seq_select_topk_kernel, dim3(B), dim3(1024), (size_t)topk_p2 * 8 + (size_t)LH * 4, s, p, ws, topk_p2);
+    hipLaunchKernelGGL(emit_topk_kernel<4>, dim3((G + 3) / 4), dim3(256), 0, s, p, ws);
+    ws.gate = ws.fallback;
+  }
+  // ---- general pipeline
+  // keys default to "not evictable" (0xFFFFFFFF > KEY_INF) and the chunk table to -1 for slots
+  // no physical block claims (inconsistent metadata); histograms and counters are zeroed by
+  // the tail workgroups of build_keys.  Behind the small-eviction schedule (gated) the clear is a
+  // gated kernel instead of a memset.
+  if (!topk && !(p.lean & 2)) hipMemsetAsync(ws.keys, 0xFF, l.zero_begin - l.keys, s);
   {
     uint4* z16 = reinterpret_cast<uint4*>(wb + l.zero_begin);
     const int64_t zv = (int64_t)((l.zero_end - l.zero_begin) / 16);
     const int64_t zb64 = (zv + 1023) / 1024;
     const unsigned zb = (unsigned)(zb64 < 1 ? 1 : (zb64 > 2048 ? 2048 : zb64));
-    if (p.block_size % 4 == 0) {
-      const int64_t threads = p.num_blocks * (p.block_size / 4);
-      const unsigned db = (unsigned)((threads + 255) / 256);
+    const int64_t threads = p.block_size % 4 == 0 ? p.num_blocks * (p.block_size / 4) : p.num_blocks * p.block_size;
+    int64_t db64 = (threads + 255) / 256;
+    if (topk && db64 > 8192) db64 = 8192;            // gated: a no-op unless the flag was raised
+    const unsigned db = (unsigned)db64;
+    if (p.block_size % 4 == 0)
       hipLaunchKernelGGL(build_keys_kernel<4>, dim3(db + zb), dim3(256), 0, s, p, ws, db, z16, zv);
-    } else {
-      const int64_t threads = p.num_blocks * p.block_size;
-      const unsigned db = (unsigned)((threads + 255) / 256);
+    else
       hipLaunchKernelGGL(build_keys_kernel<1>, dim3(db + zb), dim3(256), 0, s, p, ws, db, z16, zv);
-    }
   }
+  if (topk && !(p.lean & 2)) hipLaunchKernelGGL(fix_unclaimed_kernel, dim3(1024), dim3(256), 0, s, p, ws);
   const int64_t htiles_all = (p.total_slots + HTILE - 1) / HTILE;
   // persistent grid: 4 workgroups per CU up to 4M keys per round-pass, growing to 16 per CU for
   // very large batches (measured: 1024 is best at 8M keys, 4096 is 18 % faster at 270M)
@@ -736,7 +1200,7 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     hipLaunchKernelGGL(scan_round_kernel, dim3((G + 3) / 4), dim3(256), 0, s, p, ws, round);
     if (round == 0) {
       hipLaunchKernelGGL(seq_totals_kernel, dim3(B), dim3(256), 0, s, p, ws);
-      hipLaunchKernelGGL(seq_prepare_kernel, dim3(1), dim3(1024), 0, s, p, ws);
+      hipLaunchKernelGGL(seq_prepare_kernel, dim3(1), dim3(1024), prep_lds, s, p, ws);
     }
     hipLaunchKernelGGL(pick_round_kernel, dim3(B), dim3(1024), 0, s, p, ws, round);
   }
@@ -755,8 +1219,12 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     if (avg <= 8192) {
       hipLaunchKernelGGL(select_emit_kernel<256>, dim3(G), dim3(256), (size_t)lds_cap * 4, s, p, ws, lds_cap);
     } else {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(select_emit_kernel<1024>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
+      static bool attr_long = false;                 // once per process (per-function attribute)
+      if (!attr_long) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(select_emit_kernel<1024>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
+        attr_long = true;
+      }
       hipLaunchKernelGGL(select_emit_kernel<1024>, dim3(G), dim3(1024), (size_t)lds_cap * 4, s, p, ws, lds_cap);
     }
   }

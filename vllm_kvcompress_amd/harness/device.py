@@ -59,7 +59,7 @@ def schedule(ds: DeviceState, st: PagedState, evicted_blocks, move_rows: Optiona
     """A3 -> A5.  Returns (eli, ekc, ebc, cache_moves_idx, cache_moves_count)."""
     eli, ekc, ebc = ds.cm.schedule_evictions(
         list(st.seq_indices), ds.seq_positions,
-        torch.as_tensor(np.asarray(evicted_blocks, dtype=np.int32), device=ds.cm.device),
+        [int(x) for x in np.asarray(evicted_blocks).reshape(-1)],     # a host list, like the reference scheduler's
         ds.context_lens, ds.hanging_token_count, ds.evicted_kv_offsets, list(st.protected),
         total_slots=ds.total_slots)
     rows = ds.total_slots if move_rows is None else move_rows

@@ -12,6 +12,7 @@ calls into ``libkvc_mi355x.so``.
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple, Union
 
@@ -125,6 +126,10 @@ class CompressionMetrics:
         # clear of the key scratch (the engine keeps block metadata consistent); saves two
         # N x 4 B passes per call, which is 12 % of the schedule at 256 resident sequences
         self.lean_outputs = False
+        # 0 = pick the schedule from the eviction counts, 1 = general pipeline only, 2 = small-eviction
+        # schedule whenever the shapes allow (kvc_schedule_params.schedule_path; tests force both)
+        self.schedule_path = int(os.environ.get("KVC_SCHEDULE_PATH", "0"))
+        self.last_schedule = None      # (workspace, fallback offset, small-eviction schedule enqueued)
         self._small_cache = {}
 
     # temp_metrics is handed to the attention kernels, which write into it; reading the
@@ -355,6 +360,13 @@ class CompressionMetrics:
         p.mode = {"reference": 0, "per_sequence": 1}[self.schedule_mode]
         p.null_value = MAX_INT
         p.lean = 3 if self.lean_outputs else 0
+        # the reference scheduler passes a Python list (scheduler.py:184-560): its maximum picks the
+        # schedule (include/kvc_mi355x.h); a device tensor would cost a sync to inspect -> unknown
+        if isinstance(evicted_blocks_per_seq, torch.Tensor) and evicted_blocks_per_seq.is_cuda:
+            p.max_evicted_blocks_hint = -1
+        else:
+            p.max_evicted_blocks_hint = int(max(int(v) for v in evicted_blocks_per_seq))
+        p.schedule_path = int(self.schedule_path)
         p.evicted_logical_indices = out_idx.data_ptr()
         p.evicted_kv_count = out_kv.data_ptr()
         p.evicted_block_count = out_blk.data_ptr()
@@ -364,7 +376,19 @@ class CompressionMetrics:
         with torch.cuda.device(dev):
             _lib.check(lib.kvc_schedule_evictions(ctypes.byref(p), ws.data_ptr(), ws.numel(),
                                                   _stream(self.metrics)))
+        self.last_schedule = (ws, int(lib.kvc_schedule_evictions_fallback_offset(N, B * L * H, B, bs)),
+                              bool(lib.kvc_schedule_evictions_uses_small_eviction_schedule(ctypes.byref(p))))
         return out_idx, out_kv, out_blk
+
+    def last_schedule_path(self) -> str:
+        """Which schedule produced the last ``schedule_evictions`` result (synchronises; tests and
+        bench.py): "general", "small_eviction", or "small_eviction+fallback" when the
+        small-eviction schedule could not finish exactly and the general pipeline redid the work."""
+        ws, off, small = self.last_schedule
+        if not small:
+            return "general"
+        flag = int(ws[off:off + 4].view(torch.int32).item())
+        return "small_eviction" if flag == 0 else "small_eviction+fallback"
 
     def profile_schedule_evictions(self):
         """reference metrics.py:277-335: peak extra device memory of one
