@@ -1,0 +1,128 @@
+"""Child process of tests/test_gpu_dispatch_bindings.py and tools/bench_dispatch_overhead.py: drive
+the six dispatcher ops under ONE binding ("compiled" = libkvc_torch.so, "python" = Python impls)
+and compare with the oracle; with --time also the host cost per call."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from oracle import kvc_oracle as orc                                   # noqa: E402
+from tests.attn_helpers import make_state as make_attn_state, oracle_decode   # noqa: E402
+from tests.helpers import oracle_pipeline                              # noqa: E402
+from vllm_kvcompress_amd import torch_ops                              # noqa: E402
+from vllm_kvcompress_amd.harness import device as hdev, synth         # noqa: E402
+
+DEV = "cuda:0"
+
+
+def main():
+    binding = sys.argv[1]
+    timing = "--time" in sys.argv
+    assert torch_ops.register(binding) == binding
+    res = {"binding": binding}
+    dump = torch._C._dispatch_dump("_C_kvc_ops::execute_cache_moves")
+    res["registered_from"] = "kvc_torch_binding.cpp" if "kvc_torch_binding.cpp" in dump else "python"
+    # ---- count -> moves -> compaction
+    st = synth.make_state(num_layers=2, num_kv_heads=2, block_size=16, seq_lens=[200, 90], seed=2, protected=16)
+    bs = st.block_size
+    nblk = ((st.context_lens.astype(np.int64) + bs - 1) // bs).sum(0).sum(-1)
+    evicted = [int(n) // 2 for n in nblk]
+    k, v = synth.make_caches_u16(2, st.num_blocks, 128, 16)
+    want = oracle_pipeline(st, evicted, k, v)
+    ds = hdev.upload(st, DEV)
+    eli, ekc, ebc = ds.cm.schedule_evictions(list(st.seq_indices), ds.seq_positions, evicted, ds.context_lens,
+                                             ds.hanging_token_count, ds.evicted_kv_offsets, list(st.protected))
+    # count_block_evictions on the oracle's pre-count list
+    flat = torch.from_numpy(want["eli"].copy()).to(DEV)
+    cnt = torch.empty_like(ebc)
+    torch.ops._C_kvc_ops.count_block_evictions(cnt, flat, ds.evicted_kv_offsets, ds.hanging_token_count, 16, 2147483000)
+    assert np.array_equal(cnt.cpu().numpy(), want["ebc"])
+    cmi = torch.zeros((st.total_slots, 2), dtype=torch.int32, device=DEV)
+    cmc = torch.empty_like(ekc)
+    torch.ops._C_kvc_ops.schedule_t1_cache_moves(cmi, cmc, eli, ekc, ds.evicted_kv_offsets, ds.block_tables,
+                                                 ds.context_lens, 16)
+    kd, vd = torch.from_numpy(k.copy()).to(DEV), torch.from_numpy(v.copy()).to(DEV)
+    torch.ops._C_kvc_ops.execute_cache_moves(kd, vd, ds.cm.metrics, ds.cm.token_positions, cmi, cmc,
+                                             ds.evicted_kv_offsets, 1, 16)
+    assert np.array_equal(cmi.cpu().numpy(), want["cmi"]) and np.array_equal(cmc.cpu().numpy(), want["cmc"])
+    assert np.array_equal(kd.cpu().numpy(), want["k"]) and np.array_equal(vd.cpu().numpy(), want["v"])
+    assert np.array_equal(ds.cm.metrics.cpu().numpy(), want["metrics"])
+    # ---- reshape_and_cache ("auto" and fp8)
+    rng = np.random.default_rng(0)
+    T, H, hd, nb = 37, 2, 128, 12
+    key = torch.from_numpy(rng.standard_normal((T, H, hd)).astype(np.float16)).to(DEV)
+    val = torch.from_numpy(rng.standard_normal((T, H, hd)).astype(np.float16)).to(DEV)
+    slots = torch.from_numpy(rng.permutation(nb * 16)[:T * H].astype(np.int64)).to(DEV)
+    bias = torch.tensor([0.25, -1.5], device=DEV)
+    for kvd, cdt in (("auto", torch.float16), ("fp8_e5m2", torch.uint8)):
+        x = 16 // torch.empty((), dtype=cdt).element_size()
+        kc = torch.zeros((nb, hd // x, 16, x), dtype=cdt, device=DEV)
+        vc = torch.zeros((nb, hd, 16), dtype=cdt, device=DEV)
+        met = torch.zeros((nb, 16), device=DEV)
+        torch.ops._C_cache_ops.kvcompress_reshape_and_cache(key, val, kc, vc, met, slots, bias, kvd, 1.0, 1.0)
+        from vllm_kvcompress_amd import _custom_ops as ops
+        kc2, vc2, met2 = torch.zeros_like(kc), torch.zeros_like(vc), torch.zeros_like(met)
+        ops.reshape_and_cache_kvc(key, val, kc2, vc2, met2, slots, bias, kvd, 1.0, 1.0)    # ctypes path (oracle-tested)
+        assert torch.equal(kc, kc2) and torch.equal(vc, vc2) and torch.equal(met, met2), kvd
+    # ---- decode attention v1 (scratch from the binding) and v2
+    g, c, pos, last = make_attn_state(np.random.default_rng(3), 3, 8, 2, 128, 16, 40, 1300)
+    buf = np.zeros(3, np.int32)
+    ref_out, ref_km = oracle_decode(c, g, pos, last, buf)
+    tdt = torch.float16 if c["dtype"] == "f16" else torch.bfloat16
+    t = lambda bits: torch.from_numpy(np.ascontiguousarray(bits)).to(DEV).view(tdt)
+    q, kc, vc = t(g["query_bits"]), t(g["key_cache_bits"]), t(g["value_cache_bits"])
+    NB = kc.shape[0]
+    qpk = 8 // 2
+    maxc = int(g["context_lens"].max())
+    args = (2, float(g["scale"]), torch.from_numpy(g["block_tables"]).to(DEV),
+            torch.from_numpy(g["context_lens"]).to(DEV), torch.from_numpy(pos).to(DEV),
+            torch.from_numpy(last).to(DEV), torch.from_numpy(buf).to(DEV), 16, maxc, None, "auto", 1.0, 1.0, True)
+    out1 = torch.zeros_like(q)
+    km1 = torch.full((NB, 16, qpk), -1.0, device=DEV)
+    torch.ops._C.kvcompress_paged_attention_v1(out1, km1, q, kc.view(NB, 128 // 8, 16, 8), vc.view(NB, 128, 16), *args)
+    parts = (maxc + 511) // 512
+    es = torch.empty((3, 8, parts), device=DEV)
+    ml = torch.empty_like(es)
+    to = torch.empty((3, 8, parts, 128), dtype=tdt, device=DEV)
+    tkm = torch.empty((NB, 16, qpk), device=DEV)
+    out2 = torch.zeros_like(q)
+    km2 = torch.full((NB, 16, qpk), -1.0, device=DEV)
+    torch.ops._C.kvcompress_paged_attention_v2(out2, km2, es, ml, to, tkm, q, kc.view(NB, 128 // 8, 16, 8),
+                                               vc.view(NB, 128, 16), *args)
+    for out, km in ((out1, km1), (out2, km2)):
+        kmn = km.cpu().numpy()
+        rec = ref_km != -1.0
+        assert ((ref_km == -1.0) == (kmn == -1.0)).all()
+        assert np.allclose(kmn[rec], ref_km[rec], rtol=2e-4, atol=1e-9)
+        assert np.allclose(out.float().cpu().numpy(), ref_out, atol=2e-3, rtol=2e-3)
+    res["ops_ok"] = 7
+    if timing:
+        # host cost per call: tiny inputs, so the device finishes long before the host returns
+        n = 3000
+        for name, fn in (
+            ("execute_cache_moves", lambda: torch.ops._C_kvc_ops.execute_cache_moves(
+                kd, vd, ds.cm.metrics, ds.cm.token_positions, cmi, cmc, ds.evicted_kv_offsets, 1, 16)),
+            ("schedule_t1_cache_moves", lambda: torch.ops._C_kvc_ops.schedule_t1_cache_moves(
+                cmi, cmc, eli, ekc, ds.evicted_kv_offsets, ds.block_tables, ds.context_lens, 16)),
+            ("count_block_evictions", lambda: torch.ops._C_kvc_ops.count_block_evictions(
+                cnt, flat, ds.evicted_kv_offsets, ds.hanging_token_count, 16, 2147483000)),
+        ):
+            for _ in range(200):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            host = (time.perf_counter() - t0) / n
+            torch.cuda.synchronize()
+            res[f"host_us_{name}"] = host * 1e6
+    print("DISPATCH_RESULT " + json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

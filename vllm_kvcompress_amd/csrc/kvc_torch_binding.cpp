@@ -1,0 +1,362 @@
+// libkvc_torch.so -- the dispatcher binding of the drop-in boundary, compiled.
+//
+// The fork calls torch.ops._C_kvc_ops.{count_block_evictions, schedule_t1_cache_moves,
+// execute_cache_moves}, torch.ops._C_cache_ops.kvcompress_reshape_and_cache and
+// torch.ops._C.kvcompress_paged_attention_v1/_v2 (vllm/_custom_ops.py:1074, 1169, 1247, 649, 156,
+// 192); its own extension registers them from C++ (csrc/torch_bindings.cpp:52-80, 353-362,
+// 395-418).  This file does the same for MI355X: the schemas of those lines, and HIP-key kernels
+// that unpack the tensors and call the C ABI of libkvc_mi355x.so (include/kvc_mi355x.h) on
+// torch's current stream -- no Python frame between the dispatcher and the launch.
+//
+// Host code only (no device code here); built by csrc/build.sh, loaded with
+// torch.ops.load_library by vllm_kvcompress_amd.torch_ops.register().
+#include <ATen/ATen.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include <map>
+#include <mutex>
+#include <optional>
+#include <string>
+#include <tuple>
+
+#include "../../include/kvc_mi355x.h"
+
+namespace {
+
+using at::Tensor;
+
+void* current_stream(const Tensor& t) {
+  return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.get_device()).stream();
+}
+
+void check(int rc) {
+  if (rc != 0) {
+    const char* msg = kvc_last_error();
+    TORCH_CHECK(false, (msg && *msg) ? msg : "kvc error");
+  }
+}
+
+void require(const Tensor& t, const char* name) {
+  TORCH_CHECK(t.defined() && t.is_cuda(), name, ": expected a tensor on a HIP device (no CPU fallback exists)");
+}
+void require(const Tensor& t, const char* name, at::ScalarType dt) {
+  require(t, name);
+  TORCH_CHECK(t.scalar_type() == dt, name, ": expected dtype ", dt, ", got ", t.scalar_type());
+}
+
+// persistent per-(device, stream, tag) scratch, grown geometrically; the C ABI never allocates
+Tensor workspace(const Tensor& like, size_t nbytes, const char* tag) {
+  static std::mutex mu;
+  static std::map<std::tuple<int, void*, std::string>, Tensor> cache;
+  std::lock_guard<std::mutex> g(mu);
+  auto key = std::make_tuple((int)like.get_device(), current_stream(like), std::string(tag));
+  auto it = cache.find(key);
+  if (it == cache.end() || (size_t)it->second.numel() < nbytes) {
+    const int64_t n = std::max<int64_t>((int64_t)(nbytes + nbytes / 4), 4096);
+    Tensor buf = at::empty({n}, like.options().dtype(at::kByte));
+    cache[key] = buf;
+    return buf;
+  }
+  return it->second;
+}
+
+// ------------------------------------------------------------------ _C_kvc_ops
+void count_block_evictions(Tensor& evicted_block_count, Tensor& evicted_logical_indices,
+                           const Tensor& evicted_kv_offsets, const Tensor& hanging_token_count,
+                           int64_t block_size, int64_t null_value) {
+  require(evicted_block_count, "evicted_block_count", at::kInt);
+  require(evicted_logical_indices, "evicted_logical_indices", at::kInt);
+  require(evicted_kv_offsets, "evicted_kv_offsets", at::kInt);
+  require(hanging_token_count, "hanging_token_count", at::kInt);
+  TORCH_CHECK(evicted_logical_indices.is_contiguous() && evicted_block_count.is_contiguous(),
+              "count_block_evictions: evicted_logical_indices / evicted_block_count must be contiguous "
+              "(written in place)");
+  const Tensor offs = evicted_kv_offsets.contiguous(), hang = hanging_token_count.contiguous();
+  c10::DeviceGuard guard(evicted_logical_indices.device());
+  check(kvc_count_block_evictions(evicted_block_count.data_ptr<int32_t>(),
+                                  evicted_logical_indices.data_ptr<int32_t>(), offs.data_ptr<int32_t>(),
+                                  hang.data_ptr<int32_t>(), (int32_t)evicted_block_count.numel(),
+                                  evicted_logical_indices.numel(), (int32_t)block_size, (int32_t)null_value,
+                                  current_stream(evicted_logical_indices)));
+}
+
+// the bare op: rows that hold no move are left untouched (the Python wrapper of the reference
+// zero-fills the workspace in front of it, vllm/_custom_ops.py:1168)
+void schedule_t1_cache_moves(Tensor& cache_moves_idx, Tensor& cache_moves_count,
+                             const Tensor& evicted_logical_indices, const Tensor& evicted_kv_count,
+                             const Tensor& evicted_kv_offsets, const Tensor& block_tables,
+                             const Tensor& context_lens, int64_t block_size) {
+  for (auto p : {std::make_pair(&cache_moves_idx, "cache_moves_idx"), std::make_pair(&cache_moves_count, "cache_moves_count")})
+    require(*p.first, p.second, at::kInt);
+  for (auto p : {std::make_pair(&evicted_logical_indices, "evicted_logical_indices"),
+                 std::make_pair(&evicted_kv_count, "evicted_kv_count"),
+                 std::make_pair(&evicted_kv_offsets, "evicted_kv_offsets"),
+                 std::make_pair(&block_tables, "block_tables"), std::make_pair(&context_lens, "context_lens")})
+    require(*p.first, p.second, at::kInt);
+  TORCH_CHECK(cache_moves_idx.is_contiguous() && cache_moves_count.is_contiguous(),
+              "schedule_cache_moves: output tensors must be contiguous");
+  TORCH_CHECK(evicted_kv_count.dim() == 3 && block_tables.dim() == 4, "schedule_cache_moves: bad shapes");
+  const Tensor eli = evicted_logical_indices.contiguous(), ekc = evicted_kv_count.contiguous(),
+               offs = evicted_kv_offsets.contiguous(), bt = block_tables.contiguous(),
+               ctx = context_lens.contiguous();
+  c10::DeviceGuard guard(cache_moves_idx.device());
+  check(kvc_schedule_t1_cache_moves(cache_moves_idx.data_ptr<int32_t>(), cache_moves_idx.size(0),
+                                    cache_moves_count.data_ptr<int32_t>(), eli.data_ptr<int32_t>(),
+                                    ekc.data_ptr<int32_t>(), offs.data_ptr<int32_t>(), bt.data_ptr<int32_t>(),
+                                    ctx.data_ptr<int32_t>(), (int32_t)ekc.size(0), (int32_t)ekc.size(1),
+                                    (int32_t)ekc.size(2), (int32_t)bt.size(3), (int32_t)block_size, 0,
+                                    current_stream(cache_moves_idx)));
+}
+
+void execute_cache_moves(Tensor& k_cache, Tensor& v_cache, Tensor& kv_metrics, Tensor& kv_position,
+                         const Tensor& cache_moves_idx, const Tensor& cache_moves_count,
+                         const Tensor& evicted_kv_offsets, int64_t /*blocks_per_head*/,
+                         int64_t /*threads_per_head*/) {
+  require(k_cache, "k_cache");
+  require(v_cache, "v_cache");
+  require(kv_metrics, "kv_metrics", at::kFloat);
+  require(kv_position, "kv_position", at::kInt);
+  require(cache_moves_idx, "cache_moves_indices", at::kInt);
+  require(cache_moves_count, "cache_moves_count", at::kInt);
+  require(evicted_kv_offsets, "evicted_kv_offsets", at::kInt);
+  TORCH_CHECK(k_cache.dim() == 4 && v_cache.dim() == 3,
+              "execute_cache_moves: k_cache must be [NB, hd/x, bs, x] and v_cache [NB, hd, bs]");
+  TORCH_CHECK(k_cache.is_contiguous() && v_cache.is_contiguous() && kv_metrics.is_contiguous() &&
+                  kv_position.is_contiguous(),
+              "execute_cache_moves: caches, kv_metrics and kv_position must be contiguous (mutated in place)");
+  const Tensor cmi = cache_moves_idx.contiguous(), cmc = cache_moves_count.contiguous(),
+               offs = evicted_kv_offsets.contiguous();
+  const int64_t num_blocks = v_cache.size(0), head_size = v_cache.size(1), block_size = v_cache.size(2);
+  const int32_t total_heads = (int32_t)cmc.numel();
+  const size_t ws_bytes = kvc_execute_cache_moves_workspace_bytes(total_heads, num_blocks);
+  c10::DeviceGuard guard(k_cache.device());
+  Tensor ws = workspace(k_cache, ws_bytes, "execute_cache_moves");
+  check(kvc_execute_cache_moves(k_cache.data_ptr(), v_cache.data_ptr(), kv_metrics.data_ptr<float>(),
+                                kv_position.data_ptr<int32_t>(), cmi.data_ptr<int32_t>(),
+                                cmc.data_ptr<int32_t>(), offs.data_ptr<int32_t>(), total_heads, num_blocks,
+                                (int32_t)block_size, (int32_t)head_size, (int32_t)k_cache.element_size(),
+                                (int32_t)k_cache.size(3), ws.data_ptr(), (size_t)ws.numel(),
+                                current_stream(k_cache)));
+}
+
+// ------------------------------------------------------------------ _C_cache_ops
+void kvcompress_reshape_and_cache(const Tensor& key, const Tensor& value, Tensor& key_cache,
+                                  Tensor& value_cache, const Tensor& kv_metrics, const Tensor& slot_mapping,
+                                  const Tensor& kv_metric_head_bias, std::string kv_cache_dtype,
+                                  double k_scale, double v_scale) {
+  require(key, "key");
+  require(value, "value");
+  require(key_cache, "key_cache");
+  require(value_cache, "value_cache");
+  require(kv_metrics, "kv_metrics", at::kFloat);
+  require(slot_mapping, "slot_mapping", at::kLong);
+  require(kv_metric_head_bias, "kv_metric_head_bias", at::kFloat);
+  TORCH_CHECK(key.dim() == 3 && key.stride(2) == 1 && key.stride(1) == key.size(2) && value.stride(2) == 1 &&
+                  value.stride(1) == value.size(2),
+              "reshape_and_cache_kvc: key/value must be dense in their last two dims");
+  const int64_t num_tokens = key.size(0), num_heads = key.size(1), head_size = key.size(2);
+  const int64_t block_size = key_cache.size(2);
+  const Tensor sm = slot_mapping.contiguous(), hb = kv_metric_head_bias.contiguous();
+  c10::DeviceGuard guard(key.device());
+  float* met = const_cast<float*>(kv_metrics.data_ptr<float>());
+  if (kv_cache_dtype == "auto") {
+    TORCH_CHECK(key.scalar_type() == key_cache.scalar_type() && value.scalar_type() == value_cache.scalar_type(),
+                "reshape_and_cache_kvc: kv_cache_dtype 'auto' needs cache dtype == key/value dtype");
+    check(kvc_reshape_and_cache(key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+                                met, sm.data_ptr<int64_t>(), hb.data_ptr<float>(), num_tokens,
+                                (int32_t)num_heads, (int32_t)head_size, (int32_t)block_size,
+                                (int32_t)key.element_size(), key.stride(0), value.stride(0), current_stream(key)));
+    return;
+  }
+  int kind = 0;
+  if (kv_cache_dtype == "fp8" || kv_cache_dtype == "fp8_e4m3") kind = 0;
+  else if (kv_cache_dtype == "fp8_e5m2") kind = 1;
+  else { TORCH_CHECK(false, "Unsupported data type of kv cache: ", kv_cache_dtype); }
+  int src = 0;
+  if (key.scalar_type() == at::kHalf) src = 0;
+  else if (key.scalar_type() == at::kBFloat16) src = 1;
+  else if (key.scalar_type() == at::kFloat) src = 2;
+  else { TORCH_CHECK(false, "Unsupported input type of kv cache: ", key.scalar_type()); }
+  TORCH_CHECK(value.scalar_type() == key.scalar_type(), "Unsupported input type of kv cache: ", value.scalar_type());
+  TORCH_CHECK(key_cache.element_size() == 1 && value_cache.element_size() == 1,
+              "reshape_and_cache_kvc: an fp8 kv cache must have 1-byte elements");
+  check(kvc_reshape_and_cache_fp8(key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+                                  met, sm.data_ptr<int64_t>(), hb.data_ptr<float>(), num_tokens,
+                                  (int32_t)num_heads, (int32_t)head_size, (int32_t)block_size, src, kind,
+                                  key.stride(0), value.stride(0), (float)k_scale, (float)v_scale,
+                                  current_stream(key)));
+}
+
+// ------------------------------------------------------------------ _C (decode attention)
+void paged_attention_kvc(Tensor& out, Tensor& kv_metric_out, const Tensor* exp_sums, const Tensor* max_logits,
+                         const Tensor* tmp_out, const Tensor* tmp_kv_metric_out, const Tensor& query,
+                         const Tensor& key_cache, const Tensor& value_cache, int64_t num_kv_heads, double scale,
+                         const Tensor& block_tables, const Tensor& context_lens, const Tensor& kv_position,
+                         const Tensor& last_position, const Tensor& kv_metric_buffer_len, int64_t block_size,
+                         int64_t max_context_len, const std::optional<Tensor>& alibi_slopes,
+                         const std::string& kv_cache_dtype, double k_scale, double v_scale,
+                         bool record_kv_metrics) {
+  require(out, "out");
+  require(query, "query");
+  require(key_cache, "key_cache");
+  require(value_cache, "value_cache");
+  require(kv_metric_out, "kv_metric_out", at::kFloat);
+  for (auto p : {std::make_pair(&block_tables, "block_tables"), std::make_pair(&context_lens, "context_lens"),
+                 std::make_pair(&kv_position, "kv_position"), std::make_pair(&last_position, "last_position"),
+                 std::make_pair(&kv_metric_buffer_len, "kv_metric_buffer_len")})
+    require(*p.first, p.second, at::kInt);
+  int kvd = 0;
+  if (kv_cache_dtype == "auto") kvd = 0;
+  else if (kv_cache_dtype == "fp8" || kv_cache_dtype == "fp8_e4m3") kvd = 1;
+  else if (kv_cache_dtype == "fp8_e5m2") kvd = 2;
+  else { TORCH_CHECK(false, "Unsupported data type of kv cache: ", kv_cache_dtype); }
+  int dt = 0;
+  if (query.scalar_type() == at::kHalf) dt = 0;
+  else if (query.scalar_type() == at::kBFloat16) dt = 1;
+  else { TORCH_CHECK(false, "Unsupported data type: ", query.scalar_type()); }
+  TORCH_CHECK(out.scalar_type() == query.scalar_type(), "paged_attention_kvc: query and output must share a dtype");
+  if (kvd == 0) {
+    TORCH_CHECK(key_cache.scalar_type() == query.scalar_type() && value_cache.scalar_type() == query.scalar_type(),
+                "paged_attention_kvc: an \"auto\" cache has the query's dtype");
+  } else {
+    TORCH_CHECK(key_cache.element_size() == 1 && value_cache.element_size() == 1,
+                "paged_attention_kvc: an fp8 kv cache must have 1-byte elements");
+  }
+  TORCH_CHECK(query.dim() == 3 && query.stride(1) == query.size(2) && query.stride(2) == 1,
+              "paged_attention_kvc: query must be contiguous in (head, dim)");
+  TORCH_CHECK(out.is_contiguous(), "paged_attention_kvc: out must be contiguous");
+  const Tensor bt = block_tables.contiguous(), ctx = context_lens.contiguous(), pos = kv_position.contiguous(),
+               last = last_position.contiguous(), buf = kv_metric_buffer_len.contiguous();
+  Tensor alibi;
+  if (alibi_slopes.has_value() && alibi_slopes->defined()) alibi = alibi_slopes->to(at::kFloat).contiguous();
+  kvc_attention_params p;
+  memset(&p, 0, sizeof(p));
+  p.out = out.data_ptr();
+  p.kv_metric_out = kv_metric_out.data_ptr<float>();
+  p.query = query.data_ptr();
+  p.key_cache = key_cache.data_ptr();
+  p.value_cache = value_cache.data_ptr();
+  p.block_tables = bt.data_ptr<int32_t>();
+  p.context_lens = ctx.data_ptr<int32_t>();
+  p.kv_position = pos.data_ptr<int32_t>();
+  p.last_position = last.data_ptr<int32_t>();
+  p.kv_metric_buffer_len = buf.data_ptr<int32_t>();
+  p.alibi_slopes = alibi.defined() ? alibi.data_ptr<float>() : nullptr;
+  p.q_stride = query.stride(0);
+  p.kv_block_stride = key_cache.stride(0);
+  p.scale = (float)scale; p.k_scale = (float)k_scale; p.v_scale = (float)v_scale;
+  p.num_seqs = (int32_t)query.size(0); p.num_heads = (int32_t)query.size(1); p.num_kv_heads = (int32_t)num_kv_heads;
+  p.head_size = (int32_t)query.size(2); p.block_size = (int32_t)block_size;
+  p.max_num_blocks_per_seq = (int32_t)bt.size(-1);
+  p.max_context_len = (int32_t)max_context_len;
+  p.dtype = dt; p.kv_cache_dtype = kvd; p.record_kv_metrics = record_kv_metrics ? 1 : 0;
+  c10::DeviceGuard guard(query.device());
+  Tensor scratch;                                   // v1: the small partition buffers the signature does not carry
+  if (exp_sums != nullptr) {
+    require(*exp_sums, "exp_sum", at::kFloat);
+    require(*max_logits, "max_logits", at::kFloat);
+    p.exp_sums = exp_sums->data_ptr<float>();
+    p.max_logits = max_logits->data_ptr<float>();
+    p.tmp_out = tmp_out->data_ptr();
+    p.tmp_kv_metric_out = tmp_kv_metric_out->data_ptr<float>();
+  } else if (kvc_paged_attention_decode_uses_partitions(p.num_seqs, p.num_heads, p.num_kv_heads, p.head_size,
+                                                        p.max_context_len, 0)) {
+    const int64_t parts = (max_context_len + 511) / 512;
+    const int64_t n = (int64_t)p.num_seqs * p.num_heads * parts;
+    const size_t nbytes = (size_t)n * 8 + (size_t)n * p.head_size * query.element_size() + 256;
+    scratch = workspace(query, nbytes, "attn_v1");
+    uint8_t* b = scratch.data_ptr<uint8_t>();
+    p.exp_sums = reinterpret_cast<float*>(b);
+    p.max_logits = reinterpret_cast<float*>(b + n * 4);
+    p.tmp_out = b + n * 8;
+    // the unnormalised per-partition weights are rescaled in place (same slot * qpk + q element)
+    p.tmp_kv_metric_out = record_kv_metrics ? kv_metric_out.data_ptr<float>() : nullptr;
+  }
+  check(kvc_paged_attention_decode(&p, current_stream(query)));
+}
+
+void kvcompress_paged_attention_v1(Tensor& out, Tensor& kv_metric_out, const Tensor& query, const Tensor& key_cache,
+                                   const Tensor& value_cache, int64_t num_kv_heads, double scale,
+                                   const Tensor& block_tables, const Tensor& context_lens, const Tensor& kv_position,
+                                   const Tensor& last_position, const Tensor& kv_metric_buffer_len,
+                                   int64_t block_size, int64_t max_context_len,
+                                   const std::optional<Tensor>& alibi_slopes, std::string kv_cache_dtype,
+                                   double k_scale, double v_scale, bool record_kv_metrics) {
+  paged_attention_kvc(out, kv_metric_out, nullptr, nullptr, nullptr, nullptr, query, key_cache, value_cache,
+                      num_kv_heads, scale, block_tables, context_lens, kv_position, last_position,
+                      kv_metric_buffer_len, block_size, max_context_len, alibi_slopes, kv_cache_dtype, k_scale,
+                      v_scale, record_kv_metrics);
+}
+
+void kvcompress_paged_attention_v2(Tensor& out, Tensor& kv_metric_out, const Tensor& exp_sums,
+                                   const Tensor& max_logits, const Tensor& tmp_out, const Tensor& tmp_kv_metric_out,
+                                   const Tensor& query, const Tensor& key_cache, const Tensor& value_cache,
+                                   int64_t num_kv_heads, double scale, const Tensor& block_tables,
+                                   const Tensor& context_lens, const Tensor& kv_position, const Tensor& last_position,
+                                   const Tensor& kv_metric_buffer_len, int64_t block_size, int64_t max_context_len,
+                                   const std::optional<Tensor>& alibi_slopes, std::string kv_cache_dtype,
+                                   double k_scale, double v_scale, bool record_kv_metrics) {
+  paged_attention_kvc(out, kv_metric_out, &exp_sums, &max_logits, &tmp_out, &tmp_kv_metric_out, query, key_cache,
+                      value_cache, num_kv_heads, scale, block_tables, context_lens, kv_position, last_position,
+                      kv_metric_buffer_len, block_size, max_context_len, alibi_slopes, kv_cache_dtype, k_scale,
+                      v_scale, record_kv_metrics);
+}
+
+bool has_schema(const char* name) {
+  return c10::Dispatcher::singleton().findSchema({name, ""}).has_value();
+}
+
+}  // namespace
+
+// Schemas: the fork's own (csrc/torch_bindings.cpp:52-80, 353-362, 395-418).  FRAGMENTs, and only
+// for names nobody defined yet, so the library can be loaded next to an extension that already
+// carries the schemas; the kernels below are registered for the HIP (CUDA-key) backend either way.
+TORCH_LIBRARY_FRAGMENT(_C_kvc_ops, m) {
+  if (!has_schema("_C_kvc_ops::count_block_evictions"))
+    m.def("count_block_evictions(Tensor! evicted_block_count, Tensor! evicted_logical_indices, "
+          "Tensor evicted_kv_offsets, Tensor hanging_token_count, int block_size, int null_value) -> ()");
+  if (!has_schema("_C_kvc_ops::schedule_t1_cache_moves"))
+    m.def("schedule_t1_cache_moves(Tensor! cache_moves_idx, Tensor! cache_moves_count, "
+          "Tensor evicted_logical_indices, Tensor evicted_kv_count, Tensor evicted_kv_offsets, "
+          "Tensor block_tables, Tensor context_lens, int block_size) -> ()");
+  if (!has_schema("_C_kvc_ops::execute_cache_moves"))
+    m.def("execute_cache_moves(Tensor! k_cache, Tensor! v_cache, Tensor! kv_metrics, Tensor! kv_position, "
+          "Tensor cache_moves_idx, Tensor cache_moves_count, Tensor evicted_kv_offsets, "
+          "int blocks_per_head, int threads_per_head) -> ()");
+}
+TORCH_LIBRARY_FRAGMENT(_C_cache_ops, m) {
+  if (!has_schema("_C_cache_ops::kvcompress_reshape_and_cache"))
+    m.def("kvcompress_reshape_and_cache(Tensor key, Tensor value, Tensor! key_cache, Tensor! value_cache, "
+          "Tensor kv_metrics, Tensor slot_mapping, Tensor kv_metric_head_bias, str kv_cache_dtype, "
+          "float k_scale, float v_scale) -> ()");
+}
+TORCH_LIBRARY_FRAGMENT(_C, m) {
+  if (!has_schema("_C::kvcompress_paged_attention_v1"))
+    m.def("kvcompress_paged_attention_v1(Tensor! out, Tensor! kv_metric_out, Tensor query, Tensor key_cache, "
+          "Tensor value_cache, int num_kv_heads, float scale, Tensor block_tables, Tensor context_lens, "
+          "Tensor kv_position, Tensor last_position, Tensor kv_metric_buffer_len, int block_size, "
+          "int max_context_len, Tensor? alibi_slopes, str kv_cache_dtype, float k_scale, float v_scale, "
+          "bool record_kv_metrics) -> ()");
+  if (!has_schema("_C::kvcompress_paged_attention_v2"))
+    m.def("kvcompress_paged_attention_v2(Tensor! out, Tensor! kv_metric_out, Tensor exp_sums, Tensor max_logits, "
+          "Tensor tmp_out, Tensor tmp_kv_metric_out, Tensor query, Tensor key_cache, Tensor value_cache, "
+          "int num_kv_heads, float scale, Tensor block_tables, Tensor context_lens, Tensor kv_position, "
+          "Tensor last_position, Tensor kv_metric_buffer_len, int block_size, int max_context_len, "
+          "Tensor? alibi_slopes, str kv_cache_dtype, float k_scale, float v_scale, bool record_kv_metrics) -> ()");
+}
+
+TORCH_LIBRARY_IMPL(_C_kvc_ops, CUDA, m) {
+  m.impl("count_block_evictions", &count_block_evictions);
+  m.impl("schedule_t1_cache_moves", &schedule_t1_cache_moves);
+  m.impl("execute_cache_moves", &execute_cache_moves);
+}
+TORCH_LIBRARY_IMPL(_C_cache_ops, CUDA, m) {
+  m.impl("kvcompress_reshape_and_cache", &kvcompress_reshape_and_cache);
+}
+TORCH_LIBRARY_IMPL(_C, CUDA, m) {
+  m.impl("kvcompress_paged_attention_v1", &kvcompress_paged_attention_v1);
+  m.impl("kvcompress_paged_attention_v2", &kvcompress_paged_attention_v2);
+}

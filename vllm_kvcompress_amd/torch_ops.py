@@ -3,19 +3,24 @@
 The fork's Python calls ``torch.ops._C_kvc_ops.count_block_evictions`` etc.
 (``vllm/_custom_ops.py:1074, 1169, 1247, 649``); its C++ registers them with
 ``TORCH_LIBRARY_EXPAND(_C_kvc_ops)`` / ``(_C_cache_ops)`` (``csrc/torch_bindings.cpp:372-418,
-353-362``).  ``register()`` defines the same schemas (or overrides the CUDA-key kernels if
-the namespace already exists) and binds them to libkvc_mi355x.so.  The decode attention
+353-362``).  ``register()`` makes the same names resolve here: by loading the compiled binding
+``libkvc_torch.so`` (``csrc/kvc_torch_binding.cpp``, C++ kernels registered with
+TORCH_LIBRARY_IMPL that call the C ABI of libkvc_mi355x.so directly), or -- when that library
+has not been built, or on request -- by defining the same schemas from Python with Python
+callables that go through ``_custom_ops`` and ctypes.  The decode attention
 with metric output lives in the fork's main library ``_C`` (``csrc/torch_bindings.cpp:52-80``,
 called from ``vllm/_custom_ops.py:156, 192``).
 """
 from __future__ import annotations
+
+import os
 
 import torch
 
 from . import _custom_ops as ops
 
 _KEEP = []          # Library objects must stay alive
-_REGISTERED = False
+_REGISTERED = ""          # "" | "compiled" | "python"
 
 _KVC_SCHEMAS = {
     "count_block_evictions":
@@ -77,22 +82,50 @@ def _reshape_and_cache(key, value, kc, vc, met, slots, bias, dtype, k_scale, v_s
 
 
 def _bind(ns, schemas, impls):
-    try:
-        lib = torch.library.Library(ns, "DEF")
-        for name, schema in schemas.items():
+    # FRAGMENT coexists with a TORCH_LIBRARY of the same namespace loaded before or after (the
+    # fork's own extension); a schema is defined only if nobody has defined the op yet
+    lib = torch.library.Library(ns, "FRAGMENT")
+    for name, schema in schemas.items():
+        if not _has_op(ns, name):
             lib.define(name + schema)
-    except RuntimeError:
-        # namespace already defined (e.g. the fork's own extension is loaded): override
-        lib = torch.library.Library(ns, "IMPL")
     for name, fn in impls.items():
         lib.impl(name, fn, "CUDA")
     _KEEP.append(lib)
 
 
-def register() -> None:
+def _has_op(ns: str, name: str) -> bool:
+    try:
+        torch._C._dispatch_find_schema_or_throw(f"{ns}::{name}", "")
+        return True
+    except RuntimeError:
+        return False
+
+
+COMPILED_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libkvc_torch.so")
+
+
+def register(binding: str = "auto") -> str:
+    """Make ``torch.ops._C_kvc_ops.*``, ``torch.ops._C_cache_ops.kvcompress_reshape_and_cache`` and
+    ``torch.ops._C.kvcompress_paged_attention_v1/_v2`` resolve to the MI355X kernels.
+
+    ``binding``: "compiled" = load ``libkvc_torch.so`` (csrc/kvc_torch_binding.cpp: C++ kernels
+    registered with TORCH_LIBRARY_IMPL, no Python frame between the dispatcher and the C ABI);
+    "python" = Python callables going through ``_custom_ops`` / ctypes; "auto" = compiled when
+    the library has been built, else python.  Returns the binding in effect.  Import order
+    next to the fork's own extension does not matter (FRAGMENT definitions on both sides); a
+    process uses ONE binding -- registering a second kernel for the same op and key is an error
+    in the dispatcher."""
     global _REGISTERED
     if _REGISTERED:
-        return
+        return _REGISTERED
+    if binding not in ("auto", "compiled", "python"):
+        raise ValueError(binding)
+    if binding == "compiled" or (binding == "auto" and os.path.exists(COMPILED_LIB)):
+        from . import _lib
+        _lib.load()                     # libkvc_mi355x.so first (and torch's HIP runtime before it)
+        torch.ops.load_library(COMPILED_LIB)
+        _REGISTERED = "compiled"
+        return _REGISTERED
     _bind("_C_kvc_ops", _KVC_SCHEMAS, {
         "count_block_evictions": _count_block_evictions,
         "schedule_t1_cache_moves": _schedule_t1_cache_moves,
@@ -103,4 +136,5 @@ def register() -> None:
         "kvcompress_paged_attention_v1": ops.paged_attention_kvc_v1,
         "kvcompress_paged_attention_v2": ops.paged_attention_kvc_v2,
     })
-    _REGISTERED = True
+    _REGISTERED = "python"
+    return _REGISTERED
