@@ -308,6 +308,37 @@ int kvc_free_compressed_blocks(int32_t* context_lens, int32_t* seq_index_by_bloc
                                kvc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
+ * F2  the append side of the block state: one decode step, token_count = 1
+ * replaces BlockSpaceManagerKVC._append_to_sequence_batch and what it calls
+ *   (vllm/kvcompress/block_manager.py:269-294 -> block.py:359-365 allocated_block_mask,
+ *    block_manager.py:103-110 ParallelBlockAllocator.allocate, block.py:513-620
+ *    get_batch_new_block_metadata, vllm/kvcompress/metrics.py:344-361 insert_metadata)
+ * For batch position b (batch slot seq_slots[b]) and every (layer, head): a head whose context
+ * length is a multiple of block_size gets logical block ctx / block_size; the new blocks are the
+ * lowest-numbered free ones (free_mask != 0), handed out in (layer, batch position, head)
+ * order; free_mask[blk] = 0, block_tables[l, slot, h, m] = blk, the four metadata rows of blk
+ * are written and token_positions[blk, :] = last_token_position[b] + arange(block_size); then
+ * context_lens[l, slot, h] += 1 for every head of the batch.  write_token_position != 0 (an
+ * extension; the reference relies on the row written when the block was allocated) also stores
+ * last_token_position[b] in the appended token's own slot.
+ * status[0] = new blocks needed, status[1] = free blocks before the call, or -1 if some head's
+ * block table has no room for its next block.  If there are fewer free blocks than needed (the
+ * reference raises "Out of memory!") or a table is full, NOTHING is modified -- the caller
+ * compares the two numbers.
+ * --------------------------------------------------------------------------------- */
+size_t kvc_append_slots_workspace_bytes(int32_t num_layers, int32_t batch, int32_t num_kv_heads,
+                                        int64_t num_blocks);
+int kvc_append_slots(int32_t* context_lens, int32_t* block_tables, uint8_t* free_mask,
+                     int32_t* seq_index_by_block, int32_t* layer_index_by_block,
+                     int32_t* head_index_by_block, int32_t* logical_block_num_by_block,
+                     int32_t* token_positions, const int32_t* seq_slots,
+                     const int32_t* last_token_position, int32_t* status, int32_t num_layers,
+                     int32_t batch, int32_t max_num_seqs, int32_t num_kv_heads,
+                     int32_t max_num_blocks_per_seq, int64_t num_blocks, int32_t block_size,
+                     int32_t write_token_position, void* workspace, size_t workspace_bytes,
+                     kvc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
  * F3  single-query paged attention with KV-metric output (decode step)
  * replaces torch.ops._C.kvcompress_paged_attention_v1 / _v2
  *   (csrc/attention/kvcompress_attention_kernels.cu:686-1056, kernels :97-455, :532-651;

@@ -440,6 +440,54 @@ def free_compressed_blocks(block_tables, context_lens, seq_indices, freed_block_
     return freed.astype(np.int32)
 
 
+def append_slots(block_tables, context_lens, seq_indices, last_token_position, free_mask,
+                 seq_index_by_block, layer_index_by_block, head_index_by_block,
+                 logical_block_num_by_block, token_positions, block_size,
+                 write_token_position=False):
+    """One decode step's append (token_count = 1) for the batch slots ``seq_indices``: in place on
+    every argument; returns the number of newly allocated blocks.
+
+    BlockSpaceManagerKVC._append_to_sequence_batch  vllm/kvcompress/block_manager.py:269-294
+    ParallelBlockAllocator.allocate                 vllm/kvcompress/block_manager.py:103-110
+    BlockStateView.get_batch_new_block_metadata     vllm/kvcompress/block.py:513-620
+    CompressionMetrics.insert_metadata              vllm/kvcompress/metrics.py:344-361
+    A head whose context length sits on a block boundary gets the next logical block; the new
+    blocks are the lowest-numbered free ones, handed out in (layer, batch position, head) order
+    (boolean mask over [L,B,H,M]); their metadata rows are written and their position row is
+    ``last_token_position + arange(bs)``.  ``write_token_position`` (not in the reference, which
+    relies on the row written when the block was allocated) also stores the appended token's
+    position in its slot -- what vllm_kvcompress_amd/harness/engine_sim.py models."""
+    bs = block_size
+    L, S, H, M = block_tables.shape
+    sel = [int(s) for s in seq_indices]
+    ctx_old = context_lens[:, sel, :].astype(np.int64)                   # [L,B,H]
+    need = ctx_old % bs == 0
+    idx = np.argwhere(need)                                              # row-major (l, b, h)
+    n = idx.shape[0]
+    free = np.nonzero(free_mask)[0][:n]
+    if free.shape[0] < n:
+        raise ValueError(f"Out of memory! Requested {n} out of {int(free_mask.sum())} available blocks.")
+    assert (ctx_old[need] // bs < M).all(), "block table too short for the appended token"
+    ar = np.arange(bs, dtype=token_positions.dtype)
+    for r, (l, b, h) in enumerate(idx):
+        blk, m = int(free[r]), int(ctx_old[l, b, h] // bs)
+        block_tables[l, sel[b], h, m] = blk
+        seq_index_by_block[blk] = sel[b]
+        layer_index_by_block[blk] = l
+        head_index_by_block[blk] = h
+        logical_block_num_by_block[blk] = m
+        token_positions[blk] = int(last_token_position[b]) + ar
+    free_mask[free] = False
+    if write_token_position:
+        for l in range(L):
+            for b, s_ in enumerate(sel):
+                for h in range(H):
+                    c = int(ctx_old[l, b, h])
+                    token_positions[block_tables[l, s_, h, c // bs], c % bs] = int(last_token_position[b])
+    context_lens[:, sel, :] += 1
+    return n
+
+
 # --------------------------------------------------------------------------------------
 # F3  single-query paged attention with per-key metric output
 #     csrc/attention/kvcompress_attention_kernels.cu:97-455 (main), :532-651 (v2 reduce);

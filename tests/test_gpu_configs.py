@@ -341,3 +341,140 @@ def test_lean_outputs_leave_everything_downstream_unchanged(mode):
     for o, c in zip(offs, cnt):
         np.testing.assert_array_equal(a["eli"][o:o + c], b["eli"][o:o + c])
     assert (a["eli"] == 2147483000).any()              # the default pads with MAX_INT
+
+
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
+def test_append_slots_device(case):
+    """the append side of F2 on device vs vectors produced by the reference's own
+    _append_to_sequence_batch / ParallelBlockAllocator / BlockState / insert_metadata"""
+    from types import SimpleNamespace
+    from tests.helpers import load_golden
+    from vllm_kvcompress_amd.kvcompress.block_state import append_slots
+    g = load_golden(f"append_{case}")
+    t = lambda k: torch.from_numpy(g[k].copy()).to(DEV)
+    bt, ctx, fm = t("block_tables"), t("context_lens"), t("free_mask")
+    cm = SimpleNamespace(seq_index_by_block=t("seq_index_by_block"), layer_index_by_block=t("layer_index_by_block"),
+                         head_index_by_block=t("head_index_by_block"),
+                         logical_block_num_by_block=t("logical_block_num_by_block"),
+                         token_positions=t("token_positions"))
+    n = append_slots(bt, ctx, [int(s) for s in g["seq_indices"]], [int(p) for p in g["last_token_position"]],
+                     fm, cm, int(g["block_size"]))
+    assert n == int(g["free_mask"].sum()) - int(g["ref_free_count"])
+    for got, ref in ((bt, "ref_block_tables"), (ctx, "ref_context_lens"), (fm, "ref_free_mask"),
+                     (cm.seq_index_by_block, "ref_seq_index_by_block"),
+                     (cm.layer_index_by_block, "ref_layer_index_by_block"),
+                     (cm.head_index_by_block, "ref_head_index_by_block"),
+                     (cm.logical_block_num_by_block, "ref_logical_block_num_by_block"),
+                     (cm.token_positions, "ref_token_positions")):
+        np.testing.assert_array_equal(got.cpu().numpy(), g[ref], err_msg=ref)
+    # out of blocks: ValueError like ParallelBlockAllocator.allocate, and nothing is modified
+    bt2, ctx2 = t("block_tables"), t("context_lens")
+    fm2 = torch.zeros_like(fm)
+    fm2[:max(n - 1, 0)] = True
+    before = (bt2.clone(), ctx2.clone(), fm2.clone(), cm.token_positions.clone())
+    if n > 0:
+        with pytest.raises(ValueError, match="Out of memory"):
+            append_slots(bt2, ctx2, [int(s) for s in g["seq_indices"]], [int(p) for p in g["last_token_position"]],
+                         fm2, cm, int(g["block_size"]))
+        for a, b in zip((bt2, ctx2, fm2, cm.token_positions), before):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("mode", ["per_sequence", "reference"])
+def test_config3_continual_compression_all_state_on_device(mode):
+    """The continual loop with NO host state on the device side: metric store, block tables,
+    context lengths, free list and K/V stay in HBM for 30 decode steps; every transition is a
+    device op (schedule -> moves -> compaction -> free_compressed_blocks -> append_slots ->
+    reshape_and_cache of the new token).  The oracle side runs the reference-pinned NumPy
+    restatements of the same transitions; all state is compared every step."""
+    from vllm_kvcompress_amd.kvcompress.block_state import append_slots, free_compressed_blocks
+    L, H, bs, hd, cap = 2, 4, 16, 128, 48
+    seq_lens = [200, 130, 77, 161]
+    B = len(seq_lens)
+    st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs, seq_lens=seq_lens, seed=5,
+                          protected=32, spare_block_frac=0.6)
+    NB = st.num_blocks
+    M = st.block_tables.shape[3] + 2
+    bt_np = np.zeros((L, B, H, M), np.int32)
+    bt_np[..., :st.block_tables.shape[3]] = st.block_tables
+    ctx_np = st.context_lens.copy()
+    free_np = st.seq_index_by_block < 0
+    k_np, v_np = synth.make_caches_u16(5, NB, hd, bs)
+    o = dict(metrics=st.metrics.copy(), pos=st.token_positions.copy(), seq=st.seq_index_by_block.copy(),
+             lay=st.layer_index_by_block.copy(), head=st.head_index_by_block.copy(),
+             lbn=st.logical_block_num_by_block.copy())
+    # ---- device side
+    ds = hdev.upload(st, DEV, mode=mode)
+    cm = ds.cm
+    bt = torch.from_numpy(bt_np.copy()).to(DEV)
+    ctx = torch.from_numpy(ctx_np.copy()).to(DEV)
+    fm = torch.from_numpy(free_np.copy()).to(DEV)
+    k_t, v_t = torch.from_numpy(k_np.copy()).to(DEV), torch.from_numpy(v_np.copy()).to(DEV)
+    slots = list(range(B))
+    lens = np.asarray(seq_lens, np.int64).copy()
+    rng = np.random.default_rng(1)
+    bias = torch.zeros(H, device=DEV)
+    for it in range(30):
+        seq_pos = (lens - 1).astype(np.int32)
+        # host policy on the (small) context-length table, like the reference's scheduler
+        ctx_h = ctx.cpu().numpy()
+        assert np.array_equal(ctx_h, ctx_np), f"iter {it}: context_lens"
+        evicted = [synth.evict_block_count(context_lens_lh=ctx_h[:, b, :], seq_len=int(lens[b]), block_size=bs,
+                                           protected_window_size=32, max_cache_tokens=cap) for b in range(B)]
+        hang_np = synth.hanging_tokens(ctx_np.transpose(1, 0, 2), bs)
+        offs_np = synth.kv_offsets(ctx_np, bs)
+        N = int(((ctx_np.astype(np.int64) + bs - 1) // bs).sum()) * bs
+        # ---- oracle
+        eli, ekc, ebc = orc.schedule_evictions(
+            metrics=o["metrics"], token_positions=o["pos"], seq_index_by_block=o["seq"],
+            layer_index_by_block=o["lay"], head_index_by_block=o["head"], logical_block_num_by_block=o["lbn"],
+            block_size=bs, num_layers=L, num_kv_heads=H, seq_indices=slots, seq_positions=seq_pos,
+            evicted_blocks_per_seq=evicted, context_lens=ctx_np, hanging_token_count=hang_np,
+            evicted_kv_offsets=offs_np, num_protected=[32] * B, mode=mode)
+        cmi_o = np.zeros((N, 2), np.int32)
+        cmc_o = np.zeros(ekc.shape, np.int32)
+        orc.schedule_cache_moves(cmi_o, cmc_o, eli, ekc, offs_np, bt_np, ctx_np, bs)
+        orc.execute_cache_moves(k_np, v_np, o["metrics"], o["pos"], cmi_o, cmc_o, offs_np)
+        orc.free_compressed_blocks(bt_np, ctx_np, slots, ebc, o["seq"], bs, free_np)
+        orc.append_slots(bt_np, ctx_np, slots, seq_pos, free_np, o["seq"], o["lay"], o["head"], o["lbn"],
+                         o["pos"], bs, write_token_position=True)
+        # ---- device (the derived per-step tensors are torch ops on device, as in the reference)
+        hang = torch.from_numpy(hang_np).to(DEV)
+        offs = torch.from_numpy(offs_np).to(DEV)
+        g_eli, g_ekc, g_ebc = cm.schedule_evictions(slots, torch.from_numpy(seq_pos).to(DEV), evicted, ctx, hang,
+                                                    offs, [32] * B, total_slots=N)
+        cmi = torch.full((N, 2), 77, dtype=torch.int32, device=DEV)
+        cmc = torch.empty_like(g_ekc)
+        ops.schedule_cache_moves(cmi, cmc, g_eli, g_ekc, offs, bt, ctx, bs)
+        ops.execute_cache_moves(k_t, v_t, cm.metrics, cm.token_positions, cmi, cmc, offs, 1, 16)
+        free_compressed_blocks(bt, ctx, slots, g_ebc, cm.seq_index_by_block, bs, fm)
+        append_slots(bt, ctx, slots, [int(p) for p in seq_pos], fm, cm, bs, write_token_position=True)
+        for name, got, want in (("eli", g_eli, eli), ("ekc", g_ekc, ekc), ("ebc", g_ebc, ebc), ("cmi", cmi, cmi_o),
+                                ("cmc", cmc, cmc_o), ("context_lens", ctx, ctx_np), ("free_mask", fm, free_np),
+                                ("positions", cm.token_positions, o["pos"]), ("seq_index", cm.seq_index_by_block, o["seq"]),
+                                ("lbn", cm.logical_block_num_by_block, o["lbn"])):
+            np.testing.assert_array_equal(got.cpu().numpy(), want, err_msg=f"iter {it}: {name}")
+        # allocated part of the block tables (entries past a head's blocks are don't-care)
+        nblk = (ctx_np + bs - 1) // bs
+        live = np.arange(M)[None, None, None, :] < nblk[..., None]
+        assert np.array_equal(bt.cpu().numpy()[live], bt_np[live]), f"iter {it}: block_tables"
+        # ---- the new token's KV: reshape_and_cache per layer on device, NumPy writes on the oracle side
+        key = rng.standard_normal((L, B, H, hd)).astype(np.float16)
+        val = rng.standard_normal((L, B, H, hd)).astype(np.float16)
+        c1 = ctx_np - 1
+        slot_map = (np.take_along_axis(bt_np, (c1 // bs)[..., None], axis=3)[..., 0].astype(np.int64) * bs + c1 % bs)
+        for l in range(L):
+            ops.reshape_and_cache_kvc(torch.from_numpy(key[l]).to(DEV), torch.from_numpy(val[l]).to(DEV),
+                                      k_t.view(torch.float16), v_t.view(torch.float16), cm.metrics,
+                                      torch.from_numpy(slot_map[l].reshape(-1)).to(DEV), bias, "auto", 1.0, 1.0)
+            orc.reshape_and_cache_kvc(key[l], val[l], k_np.view(np.float16), v_np.view(np.float16), o["metrics"],
+                                      slot_map[l].reshape(-1), np.zeros(H, np.float32))
+        inc = rng.random(o["metrics"].shape).astype(np.float32)
+        o["metrics"] = (o["metrics"] + inc).astype(np.float32)
+        cm.metrics.add_(torch.from_numpy(inc).to(DEV))
+        np.testing.assert_array_equal(cm.metrics.cpu().numpy(), o["metrics"], err_msg=f"iter {it}: metrics")
+        np.testing.assert_array_equal(k_t.cpu().numpy(), k_np, err_msg=f"iter {it}: K")
+        np.testing.assert_array_equal(v_t.cpu().numpy(), v_np, err_msg=f"iter {it}: V")
+        lens += 1
+    if mode == "per_sequence":
+        assert int(ctx_np.max()) <= cap + bs

@@ -305,3 +305,37 @@ def test_paged_attention_decode_metric_window():
             r = rec[blocks].reshape(-1, rec.shape[-1])[:n]
             assert (r.all(axis=1) == (p <= last[s] - buf[s])).all()
             assert np.allclose(km2[blocks].reshape(-1, 2)[:n].sum(0), 1.0, atol=1e-5)
+
+
+APPEND_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.startswith("append_"))
+APPEND_KEYS = (("block_tables", "ref_block_tables"), ("context_lens", "ref_context_lens"),
+               ("free_mask", "ref_free_mask"), ("seq_index_by_block", "ref_seq_index_by_block"),
+               ("layer_index_by_block", "ref_layer_index_by_block"),
+               ("head_index_by_block", "ref_head_index_by_block"),
+               ("logical_block_num_by_block", "ref_logical_block_num_by_block"),
+               ("token_positions", "ref_token_positions"))
+
+
+@pytest.mark.parametrize("name", APPEND_CASES)
+def test_append_slots_matches_reference(name):
+    """fixtures produced by the reference's own _append_to_sequence_batch + ParallelBlockAllocator +
+    BlockState + CompressionMetrics.insert_metadata (oracle/gen_golden_append.py)"""
+    g = load_golden(name)
+    w = {k: g[k].copy() for k, _ in APPEND_KEYS}
+    n = orc.append_slots(w["block_tables"], w["context_lens"], g["seq_indices"], g["last_token_position"],
+                         w["free_mask"], w["seq_index_by_block"], w["layer_index_by_block"],
+                         w["head_index_by_block"], w["logical_block_num_by_block"], w["token_positions"],
+                         int(g["block_size"]))
+    for k, r in APPEND_KEYS:
+        np.testing.assert_array_equal(w[k], g[r], err_msg=k)
+    assert n == int(g["free_mask"].sum()) - int(g["ref_free_count"])
+
+
+def test_append_slots_out_of_memory_like_the_reference():
+    g = load_golden(APPEND_CASES[0])
+    fm = np.zeros_like(g["free_mask"])
+    with pytest.raises(ValueError, match="Out of memory"):
+        orc.append_slots(g["block_tables"].copy(), g["context_lens"].copy(), g["seq_indices"],
+                         g["last_token_position"], fm, g["seq_index_by_block"].copy(),
+                         g["layer_index_by_block"].copy(), g["head_index_by_block"].copy(),
+                         g["logical_block_num_by_block"].copy(), g["token_positions"].copy(), int(g["block_size"]))

@@ -88,6 +88,163 @@ __global__ __launch_bounds__(256) void blockstate_free_kernel(
   }
 }
 
+// ------------------------------------------------------------------------- append side
+// One decode step appends one KV per head (token_count = 1):
+//   BlockSpaceManagerKVC._append_to_sequence_batch  vllm/kvcompress/block_manager.py:269-294
+//   ParallelBlockAllocator.allocate                 vllm/kvcompress/block_manager.py:103-110
+//   BlockStateView.get_batch_new_block_metadata     vllm/kvcompress/block.py:513-620
+//   CompressionMetrics.insert_metadata              vllm/kvcompress/metrics.py:344-361
+// In torch: two boolean masks over [L,B,H,M], a masked gather of the free list, a masked scatter
+// into the block tables, a metadata gather and five indexed stores, with a host sync for the
+// count.  Here: a scan over the (layer, batch position, head) heads that sit on a block boundary,
+// a tiled rank of the free list (the n lowest-numbered free blocks, like block_numbers[free_mask][:n]),
+// and one pass that wires block r to the r-th such head, writes its metadata and position row
+// and bumps every context length.
+struct AppendWs {
+  int32_t* prefix;      // [n + 1]   exclusive scan of "needs a new block" in (l, b, h) order
+  int32_t* tile_off;    // [tiles + 1] exclusive scan of free blocks per tile
+  int32_t* alloc;       // [n]       the blocks handed out, ascending
+  int32_t* ok;          // [1]       1 = enough free blocks and every new logical block fits the table
+};
+constexpr int FREE_TILE = 4096;
+
+__global__ __launch_bounds__(1024) void append_scan_kernel(AppendWs ws, const int32_t* __restrict__ context_lens,
+                                                           const int32_t* __restrict__ seq_slots, int L, int B,
+                                                           int S, int H, int M, int bs) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t carry_s;
+  __shared__ int fits_s;
+  const int n = L * B * H;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) { carry_s = 0; fits_s = 1; }
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + tid;
+    uint32_t v = 0;
+    if (i < n) {
+      const int l = i / (B * H), b = (i / H) % B, h = i % H;
+      const int ctx = context_lens[((int64_t)l * S + seq_slots[b]) * H + h];
+      v = ctx % bs == 0 ? 1u : 0u;
+      if (v && ctx / bs >= M) fits_s = 0;            // the block table has no room for it
+    }
+    const uint32_t inc = wave_inclusive_scan(v);
+    if (lane == 63) wave_tot[w] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int k = 0; k < w; ++k) woff += wave_tot[k];
+    const uint32_t carry = carry_s;
+    if (i < n) ws.prefix[i] = (int32_t)(carry + woff + inc - v);
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + woff + inc;
+    __syncthreads();
+  }
+  if (tid == 0) { ws.prefix[n] = (int32_t)carry_s; *ws.ok = fits_s; }
+}
+
+__global__ __launch_bounds__(256) void free_tile_count_kernel(AppendWs ws, const uint8_t* __restrict__ free_mask,
+                                                              int64_t num_blocks) {
+  __shared__ uint32_t red[4];
+  const int64_t t0 = (int64_t)blockIdx.x * FREE_TILE;
+  uint32_t c = 0;
+  for (int k = threadIdx.x; k < FREE_TILE; k += 256) {
+    const int64_t blk = t0 + k;
+    c += (blk < num_blocks && free_mask[blk]) ? 1u : 0u;
+  }
+  c = wave_reduce_sum(c);
+  if (lane_id() == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) ws.tile_off[blockIdx.x] = (int32_t)(red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(1024) void free_tile_scan_kernel(AppendWs ws, int tiles, int n_heads,
+                                                              int32_t* __restrict__ status) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < tiles; base += 1024) {
+    const int i = base + tid;
+    const uint32_t v = i < tiles ? (uint32_t)ws.tile_off[i] : 0u;
+    const uint32_t inc = wave_inclusive_scan(v);
+    if (lane == 63) wave_tot[w] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int k = 0; k < w; ++k) woff += wave_tot[k];
+    const uint32_t carry = carry_s;
+    if (i < tiles) ws.tile_off[i] = (int32_t)(carry + woff + inc - v);
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + woff + inc;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const int need = ws.prefix[n_heads];
+    ws.tile_off[tiles] = (int32_t)carry_s;
+    status[0] = need;
+    status[1] = *ws.ok ? (int32_t)carry_s : -1;      // -1: a head's block table is full
+    if ((int)carry_s < need) *ws.ok = 0;             // "Out of memory!" (block_manager.py:104-106)
+  }
+}
+
+// the `need` lowest-numbered free blocks, ascending; they leave the free list
+__global__ __launch_bounds__(256) void free_pick_kernel(AppendWs ws, uint8_t* __restrict__ free_mask,
+                                                        int64_t num_blocks, int n_heads) {
+  __shared__ uint32_t wave_cnt[4];
+  if (*ws.ok == 0) return;
+  const int need = ws.prefix[n_heads];
+  uint32_t rank0 = (uint32_t)ws.tile_off[blockIdx.x];
+  if ((int)rank0 >= need) return;
+  const int64_t t0 = (int64_t)blockIdx.x * FREE_TILE;
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  for (int k0 = 0; k0 < FREE_TILE; k0 += 256) {
+    const int64_t blk = t0 + k0 + threadIdx.x;
+    const bool f = blk < num_blocks && free_mask[blk];
+    const unsigned long long bal = __ballot(f);
+    if (lane == 0) wave_cnt[w] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t off = rank0;
+    for (int q = 0; q < w; ++q) off += wave_cnt[q];
+    const uint32_t r = off + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    if (f && (int)r < need) { ws.alloc[r] = (int32_t)blk; free_mask[blk] = 0; }
+    rank0 += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+}
+
+// one thread per (l, b, h)
+__global__ __launch_bounds__(256) void append_apply_kernel(
+    AppendWs ws, int32_t* __restrict__ context_lens, int32_t* __restrict__ block_tables,
+    int32_t* __restrict__ seq_index_by_block, int32_t* __restrict__ layer_index_by_block,
+    int32_t* __restrict__ head_index_by_block, int32_t* __restrict__ logical_block_num_by_block,
+    int32_t* __restrict__ token_positions, const int32_t* __restrict__ seq_slots,
+    const int32_t* __restrict__ last_token_position, int L, int B, int S, int H, int M, int bs,
+    int write_token_position) {
+  if (*ws.ok == 0) return;                           // nothing is modified when the step cannot be done
+  const int n = L * B * H;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int l = i / (B * H), b = (i / H) % B, h = i % H;
+  const int slot = seq_slots[b];
+  const int64_t lsh = ((int64_t)l * S + slot) * H + h;
+  const int ctx = context_lens[lsh];
+  const int m = ctx / bs;
+  const int last = last_token_position[b];
+  int blk;
+  if (ctx % bs == 0) {                               // first token of a new block
+    blk = ws.alloc[ws.prefix[i]];
+    block_tables[lsh * M + m] = blk;
+    seq_index_by_block[blk] = slot;                  // insert_metadata
+    layer_index_by_block[blk] = l;
+    head_index_by_block[blk] = h;
+    logical_block_num_by_block[blk] = m;
+    for (int o = 0; o < bs; ++o) token_positions[(int64_t)blk * bs + o] = last + o;
+  } else {
+    blk = block_tables[lsh * M + m];
+  }
+  if (write_token_position) token_positions[(int64_t)blk * bs + ctx % bs] = last;
+  context_lens[lsh] = ctx + 1;
+}
+
 }  // namespace kvc
 
 extern "C" size_t kvc_free_compressed_blocks_workspace_bytes(int32_t num_layers, int32_t batch,
@@ -120,4 +277,47 @@ extern "C" int kvc_free_compressed_blocks(int32_t* context_lens, int32_t* seq_in
                      block_tables, freed_block_count, seq_slots, num_layers, batch, max_num_seqs,
                      num_kv_heads, max_num_blocks_per_seq, block_size);
   return check_launch("free_compressed_blocks");
+}
+
+static size_t append_tiles(int64_t num_blocks) { return (size_t)((num_blocks + kvc::FREE_TILE - 1) / kvc::FREE_TILE); }
+
+extern "C" size_t kvc_append_slots_workspace_bytes(int32_t num_layers, int32_t batch, int32_t num_kv_heads,
+                                                   int64_t num_blocks) {
+  const size_t n = (size_t)num_layers * batch * num_kv_heads;
+  return ((n + 1) + (append_tiles(num_blocks) + 1) + n + 4) * sizeof(int32_t);
+}
+
+extern "C" int kvc_append_slots(int32_t* context_lens, int32_t* block_tables, uint8_t* free_mask,
+                                int32_t* seq_index_by_block, int32_t* layer_index_by_block,
+                                int32_t* head_index_by_block, int32_t* logical_block_num_by_block,
+                                int32_t* token_positions, const int32_t* seq_slots,
+                                const int32_t* last_token_position, int32_t* status, int32_t num_layers,
+                                int32_t batch, int32_t max_num_seqs, int32_t num_kv_heads,
+                                int32_t max_num_blocks_per_seq, int64_t num_blocks, int32_t block_size,
+                                int32_t write_token_position, void* workspace, size_t workspace_bytes,
+                                kvc_stream_t stream) {
+  using namespace kvc;
+  if (block_size < 1) return fail_invalid("Unsupported block size: " + std::to_string(block_size));
+  const int n = num_layers * batch * num_kv_heads;
+  if (n <= 0) return KVC_OK;
+  if (num_blocks < 1) return fail_invalid("append_slots: no blocks");
+  if (workspace_bytes < kvc_append_slots_workspace_bytes(num_layers, batch, num_kv_heads, num_blocks))
+    return fail_invalid("append_slots: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int tiles = (int)append_tiles(num_blocks);
+  AppendWs ws;
+  ws.prefix = reinterpret_cast<int32_t*>(workspace);
+  ws.tile_off = ws.prefix + n + 1;
+  ws.alloc = ws.tile_off + tiles + 1;
+  ws.ok = ws.alloc + n;
+  hipLaunchKernelGGL(append_scan_kernel, dim3(1), dim3(1024), 0, s, ws, context_lens, seq_slots, num_layers,
+                     batch, max_num_seqs, num_kv_heads, max_num_blocks_per_seq, block_size);
+  hipLaunchKernelGGL(free_tile_count_kernel, dim3(tiles), dim3(256), 0, s, ws, free_mask, num_blocks);
+  hipLaunchKernelGGL(free_tile_scan_kernel, dim3(1), dim3(1024), 0, s, ws, tiles, n, status);
+  hipLaunchKernelGGL(free_pick_kernel, dim3(tiles), dim3(256), 0, s, ws, free_mask, num_blocks, n);
+  hipLaunchKernelGGL(append_apply_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ws, context_lens, block_tables,
+                     seq_index_by_block, layer_index_by_block, head_index_by_block, logical_block_num_by_block,
+                     token_positions, seq_slots, last_token_position, num_layers, batch, max_num_seqs,
+                     num_kv_heads, max_num_blocks_per_seq, block_size, write_token_position);
+  return check_launch("append_slots");
 }

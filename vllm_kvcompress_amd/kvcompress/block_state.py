@@ -52,3 +52,53 @@ def free_compressed_blocks(
             total.data_ptr(), block_tables.data_ptr(), freed_block_count.data_ptr(), slots.data_ptr(),
             L, B, S, H, M, int(block_size), ws.data_ptr(), ws.numel(), _stream(block_tables)))
     return freed[:int(total.item())]       # exact size like the reference (one host sync)
+
+
+def append_slots(
+    block_tables: torch.Tensor,          # [L, max_num_seqs, H, M] i32   (BlockState.block_tables, updated)
+    context_lens: torch.Tensor,          # [L, max_num_seqs, H]    i32   (updated)
+    seq_indices: Sequence[int],          # batch slots of the decoding sequences (batch order)
+    last_token_position: Sequence[int],  # per sequence: seq.data.get_len() - 1
+    free_mask: torch.Tensor,             # [NB] bool (ParallelBlockAllocator.free_mask, updated)
+    kv_metrics,                          # CompressionMetrics: metadata rows + token_positions (updated)
+    block_size: int,
+    write_token_position: bool = False,
+) -> int:
+    """``BlockSpaceManagerKVC._append_to_sequence_batch`` (vllm/kvcompress/block_manager.py:269-294)
+    with ``token_count = 1`` on device: five small launches instead of two boolean masks over
+    [L,B,H,M], a masked gather / scatter and five indexed stores.  Returns the number of newly
+    allocated blocks (one host sync, which the reference has too: ``new_mask.sum()``); raises
+    ``ValueError("Out of memory! ...")`` like ``ParallelBlockAllocator.allocate`` -- in that case
+    nothing has been modified."""
+    lib = _lib.load()
+    for n, t in (("block_tables", block_tables), ("context_lens", context_lens),
+                 ("seq_index_by_block", kv_metrics.seq_index_by_block),
+                 ("token_positions", kv_metrics.token_positions)):
+        if not t.is_cuda or t.dtype != torch.int32 or not t.is_contiguous():
+            raise RuntimeError(f"append_slots: {n} must be a contiguous int32 HIP tensor")
+    if free_mask.dtype not in (torch.bool, torch.uint8) or not free_mask.is_cuda or not free_mask.is_contiguous():
+        raise RuntimeError("append_slots: free_mask must be a contiguous bool/uint8 HIP tensor")
+    L, S, H, M = block_tables.shape
+    B = len(seq_indices)
+    assert len(last_token_position) == B
+    dev = block_tables.device
+    host = torch.tensor(list(seq_indices) + list(last_token_position), dtype=torch.int32).to(dev, non_blocking=True)
+    status = torch.zeros((2,), dtype=torch.int32, device=dev)
+    NB = int(free_mask.numel())
+    ws_bytes = lib.kvc_append_slots_workspace_bytes(L, B, H, NB)
+    ws = workspace(dev, ws_bytes, "append_slots")
+    cm = kv_metrics
+    with torch.cuda.device(dev):
+        _lib.check(lib.kvc_append_slots(
+            context_lens.data_ptr(), block_tables.data_ptr(), free_mask.data_ptr(),
+            cm.seq_index_by_block.data_ptr(), cm.layer_index_by_block.data_ptr(),
+            cm.head_index_by_block.data_ptr(), cm.logical_block_num_by_block.data_ptr(),
+            cm.token_positions.data_ptr(), host.data_ptr(), host[B:].data_ptr(), status.data_ptr(),
+            L, B, S, H, M, NB, int(block_size), 1 if write_token_position else 0, ws.data_ptr(),
+            ws.numel(), _stream(block_tables)))
+    need, free = (int(x) for x in status.tolist())
+    if free < 0:
+        raise RuntimeError("append_slots: a head's block table is full (max_num_blocks_per_head reached)")
+    if need > free:
+        raise ValueError(f"Out of memory! Requested {need} out of {free} available blocks.")
+    return need
