@@ -79,6 +79,9 @@ def parse_args(argv=None):
     ap.add_argument("--lean", action="store_true",
                     help="extension: no MAX_INT padding / key-scratch clear in schedule_evictions and no "
                          "zero fill of the move workspace (outputs a consumer reads are unchanged)")
+    ap.add_argument("--pass-block-tables", action="store_true",
+                    help="extension: hand BlockState.block_tables to schedule_evictions (not in the reference "
+                         "signature; saves the small-eviction schedule its chunk-table pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-adjacent", action="store_true",
                     help="skip the decode-attention (F3) side measurement")
@@ -465,7 +468,8 @@ def main():
         if i is not None: marks[i][0].record()
         eli, ekc, ebc = ds.cm.schedule_evictions(seq_idx, ds.seq_positions, evicted,
                                                  ds.context_lens, ds.hanging_token_count,
-                                                 ds.evicted_kv_offsets, prot, total_slots=N)
+                                                 ds.evicted_kv_offsets, prot, total_slots=N,
+                                                 block_tables=ds.block_tables if args.pass_block_tables else None)
         if i is not None: marks[i][1].record()
         if args.lean:
             ops._schedule_t1_cache_moves(cmi, cmc, eli, ekc, ds.evicted_kv_offsets, ds.block_tables,
@@ -565,7 +569,9 @@ def main():
                                else f"compress_once keep={args.keep}, ")
                             + f"protected_window={args.protected}, "
                             f"metrics={args.metric_shape}, schedule mode={args.mode}"
-                            + (", lean outputs (extension)" if args.lean else "") + ", physical blocks "
+                            + (", lean outputs (extension)" if args.lean else "")
+                            + (", block_tables passed to schedule_evictions (extension)" if args.pass_block_tables else "")
+                            + ", physical blocks "
                             f"{'in allocation order' if args.contiguous_blocks else 'shuffled'}",
                 "candidate_slots": N, "evicted_slots": evicted_slots, "moved_slots": moved_slots,
                 "freed_blocks": freed_blocks,

@@ -199,3 +199,34 @@ def test_config3_full_size_steady_state_properties():
     evictable = (pos <= seqpos - prot) & (j < ctx)
     below = (evictable & (m_all <= worst_evicted[:, None])).sum(dim=1)
     assert torch.equal(below, cnt)
+
+
+@pytest.mark.parametrize("mode", ["reference", "per_sequence"])
+def test_block_tables_input_replaces_the_chunk_table_pass(mode):
+    """optional extension: with BlockState.block_tables at hand the small-eviction schedule reads
+    the physical blocks from it (no chunk-table pass); identical results, also for a batch that is
+    a subset of the resident sequences (rows indexed by sequence index)"""
+    st, evicted = _steady(3, 4, 16, 4, 512, 9)
+    want = oracle_pipeline(st, evicted, mode=mode)
+    ds = hdev.upload(st, DEV, mode=mode)
+    args = (list(st.seq_indices), ds.seq_positions, evicted, ds.context_lens, ds.hanging_token_count,
+            ds.evicted_kv_offsets, list(st.protected))
+    a = ds.cm.schedule_evictions(*args, total_slots=st.total_slots, block_tables=ds.block_tables)
+    assert ds.cm.last_schedule_path() == "small_eviction"
+    for got, key in zip(a, ("eli", "ekc", "ebc")):
+        np.testing.assert_array_equal(got.cpu().numpy(), want[key], err_msg=key)
+    # two of the four sequences, table rows of all four resident ones
+    sub = [1, 3]
+    lh = st.num_layers * st.num_kv_heads
+    ctx = ds.context_lens[:, sub].contiguous()
+    hang = ds.hanging_token_count[sub].contiguous()
+    offs_np = synth.kv_offsets(st.context_lens[:, sub], st.block_size)
+    offs = torch.from_numpy(offs_np).to(DEV)
+    n_sub = int(((st.context_lens[:, sub].astype(np.int64) + 15) // 16).sum()) * 16
+    b = ds.cm.schedule_evictions(sub, ds.seq_positions[sub].contiguous(), [evicted[i] for i in sub], ctx, hang, offs,
+                                 [st.protected[i] for i in sub], total_slots=n_sub, block_tables=ds.block_tables)
+    assert ds.cm.last_schedule_path() == "small_eviction"
+    c = ds.cm.schedule_evictions(sub, ds.seq_positions[sub].contiguous(), [evicted[i] for i in sub], ctx, hang, offs,
+                                 [st.protected[i] for i in sub], total_slots=n_sub)
+    for x, y in zip(b, c):
+        assert torch.equal(x, y)

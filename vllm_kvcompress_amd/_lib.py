@@ -34,7 +34,10 @@ class KvcScheduleParams(ctypes.Structure):
         ("use_average", c_int32), ("num_sinks", c_int32),
         ("bias", c_void_p), ("position_bins", c_void_p), ("num_bins", c_int32),
         ("bias_weight", c_float), ("mode", c_int32), ("null_value", c_int32), ("lean", c_int32),
-        ("max_evicted_blocks_hint", c_int32), ("schedule_path", c_int32),
+        ("max_evicted_blocks_hint", c_int32),
+        ("block_tables", c_void_p), ("seq_index_of_slot", c_void_p),
+        ("max_num_seqs", c_int32), ("block_tables_width", c_int32),
+        ("schedule_path", c_int32),
         ("evicted_logical_indices", c_void_p), ("evicted_kv_count", c_void_p),
         ("evicted_block_count", c_void_p),
     ]

@@ -762,7 +762,15 @@ __global__ __launch_bounds__(64 * WAVES) void head_topk_kernel(kvc_schedule_para
   const int ctx = p.context_lens[(l * B + i_seq) * H + h];
   const int seq_pos = p.seq_positions[i_seq], prot = p.num_protected[i_seq];
   const uint32_t hang = (uint32_t)p.hanging_token_count[g];
-  const int32_t* cphys = ws.chunk_phys + base / bs;
+  if (p.block_tables != nullptr && nchunks > p.block_tables_width) {   // inconsistent caller state
+    if (lane == 0) atomicOr(ws.fallback, 1u);
+    return;
+  }
+  // physical block of every logical chunk: the caller's block table if it passed one, else the
+  // table chunk_table_kernel built from the per-block metadata
+  const int32_t* cphys = p.block_tables != nullptr
+      ? p.block_tables + (((int64_t)l * p.max_num_seqs + p.seq_index_of_slot[i_seq]) * H + h) * p.block_tables_width
+      : ws.chunk_phys + base / bs;
   // null padding of the head's output segment (emit_topk overwrites its first cnt entries)
   if (!(p.lean & 1)) {
     typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
@@ -1148,8 +1156,11 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   if (topk) {
     // ---- small-eviction schedule (section 7): 6 launches; the general pipeline is enqueued
     // behind it and runs only if the flag was raised
-    if (!(p.lean & 2)) hipMemsetAsync(ws.chunk_phys, 0xFF, l.zero_begin - l.chunk_phys, s);
-    {
+    if (p.block_tables != nullptr) {
+      // the caller's block table replaces the chunk-table pass; only the flag / totals are cleared
+      hipMemsetAsync(wb + l.tz_begin, 0, l.tz_end - l.tz_begin, s);
+    } else {
+      if (!(p.lean & 2)) hipMemsetAsync(ws.chunk_phys, 0xFF, l.zero_begin - l.chunk_phys, s);
       uint4* z16 = reinterpret_cast<uint4*>(wb + l.tz_begin);
       const int64_t zv = (int64_t)((l.tz_end - l.tz_begin) / 16);
       const unsigned db = (unsigned)((p.num_blocks + 255) / 256);

@@ -290,13 +290,19 @@ class CompressionMetrics:
         debug={},
         profile=False,
         total_slots: Optional[int] = None,
+        block_tables: Optional[torch.Tensor] = None,
     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """reference metrics.py:441-847.  Returns ``(evicted_logical_indices [N] i32,
         evicted_kv_count [B,L,H] i32, evicted_block_count [B,L,H] i32)``.
 
         ``total_slots`` (optional, not in the reference signature): N if the caller
         already knows it; otherwise it is read back from ``context_lens`` (one small
-        device->host copy, the only synchronisation of this method)."""
+        device->host copy, the only synchronisation of this method).
+
+        ``block_tables`` (optional, not in the reference signature): ``BlockState.block_tables``
+        ``[L, max_num_seqs, H, M]`` (rows indexed by sequence index).  The fork's scheduler has it
+        next to the ``context_lens`` it already passes; with it the small-eviction schedule skips
+        its chunk-table pass (kvc_schedule_params.block_tables).  Results are identical."""
         assert len(seq_indices) > 0
         assert list(sorted(seq_indices)) == list(seq_indices), (
             "schedule_evictions input not ordered by ascending index")
@@ -367,6 +373,19 @@ class CompressionMetrics:
         else:
             p.max_evicted_blocks_hint = int(max(int(v) for v in evicted_blocks_per_seq))
         p.schedule_path = int(self.schedule_path)
+        if block_tables is not None:
+            if (not block_tables.is_cuda or block_tables.dtype != torch.int32 or block_tables.dim() != 4
+                    or not block_tables.is_contiguous() or block_tables.shape[0] != L or block_tables.shape[2] != H):
+                raise RuntimeError("schedule_evictions: block_tables must be a contiguous int32 HIP tensor "
+                                   "[L, max_num_seqs, H, M]")
+            if max(seq_indices) >= block_tables.shape[1]:
+                raise RuntimeError("schedule_evictions: a sequence index lies outside block_tables")
+            p.block_tables = block_tables.data_ptr()
+            p.seq_index_of_slot = self._as_i32([int(s) for s in seq_indices]).data_ptr()
+            p.max_num_seqs, p.block_tables_width = int(block_tables.shape[1]), int(block_tables.shape[3])
+        else:
+            p.block_tables, p.seq_index_of_slot = None, None
+            p.max_num_seqs, p.block_tables_width = 0, 0
         p.evicted_logical_indices = out_idx.data_ptr()
         p.evicted_kv_count = out_kv.data_ptr()
         p.evicted_block_count = out_blk.data_ptr()
