@@ -172,3 +172,84 @@ def test_full_size_properties(T, BS, cdtype, keep):
     claims = ws[coff:coff + NB]
     assert int(claims.max()) == 1
     assert int((claims == 1).sum()) == (dst // BS).unique().numel()
+
+
+def test_config4_full_size_properties():
+    """BASELINE configs[3] as one GPU of the 8 sees it: Llama-3-70B shape (80 layers, 8 KV heads,
+    hd 128), 16 384-token cache, 32 sequences (336 M candidate slots, 172 GB of K/V), compress_once
+    to half the cache, per_sequence scheduling.  Size-independent properties: every sequence frees
+    exactly what was asked; per head the evicted indices are ascending, distinct and padded; no
+    evicted slot is a move source and every destination is an evicted slot; EVERY surviving KV
+    sits bit-equal at its final slot (K/V rows carry a hash of the KV's identity); the block path
+    was taken for every destination block."""
+    Lc, Hc, T, Bc = 80, 8, 16384, 32
+    need = 2 * Lc * Hc * Bc * (T // BS + 2) * BS * HD * 2 + (24 << 30)
+    free, _ = torch.cuda.mem_get_info()
+    if free < need:
+        pytest.skip(f"needs {need >> 30} GiB of free HBM")
+    st = synth.make_state(num_layers=Lc, num_kv_heads=Hc, block_size=BS, seq_lens=[T + 1] * Bc, seed=4,
+                          protected=32, spare_block_frac=0.01)
+    evicted = _evict(st, 0.5, T)
+    NB, N = st.num_blocks, st.total_slots
+    ds = hdev.upload(st, DEV, mode="per_sequence")
+    dev = torch.device(DEV)
+    seq_b = ds.cm.seq_index_by_block.long()
+    g_of_blk = (seq_b * Lc + ds.cm.layer_index_by_block.long()) * Hc + ds.cm.head_index_by_block.long()
+    offs_flat = ds.evicted_kv_offsets.reshape(-1).long()
+    alloc = seq_b >= 0
+    off_of_blk = torch.where(alloc, offs_flat[g_of_blk.clamp(min=0)], torch.zeros_like(g_of_blk))
+    ids0 = off_of_blk[:, None] + ds.cm.token_positions.long()                      # [NB,bs]
+    # K[blk, r, s, e] = h(id, r); V[blk, d, s] = h(id, d / 8): one broadcast copy per cache
+    k = torch.empty((NB, HD // 8, BS, 8), dtype=torch.int16, device=dev)
+    v = torch.empty((NB, HD, BS), dtype=torch.int16, device=dev)
+    for r in range(HD // 8):
+        hr = _hash16(ids0, 1000 + r)
+        k[:, r] = hr[:, :, None]
+        v[:, r * 8:(r + 1) * 8] = hr[:, None, :]
+    del hr
+    eli, ekc, ebc = ds.cm.schedule_evictions(list(st.seq_indices), ds.seq_positions, evicted, ds.context_lens,
+                                             ds.hanging_token_count, ds.evicted_kv_offsets, list(st.protected),
+                                             total_slots=N)
+    cmi = torch.empty((N, 2), dtype=torch.int32, device=dev)
+    cmc = torch.empty_like(ekc)
+    ops.schedule_cache_moves(cmi, cmc, eli, ekc, ds.evicted_kv_offsets, ds.block_tables, ds.context_lens, BS)
+    ops.execute_cache_moves(k, v, ds.cm.metrics, ds.cm.token_positions, cmi, cmc, ds.evicted_kv_offsets, 1, 16)
+    torch.cuda.synchronize()
+    assert ebc.sum(dim=(1, 2)).cpu().tolist() == evicted
+    G = Bc * Lc * Hc
+    n = N // G
+    seg = eli.view(G, n)
+    cnt = ekc.reshape(-1).long()
+    ar = torch.arange(n, device=dev)[None, :]
+    live = ar < cnt[:, None]
+    assert bool((seg[~live] == MAX_INT).all())
+    assert bool(((seg[:, 1:] > seg[:, :-1]) | ~live[:, 1:]).all())
+    assert bool(((cnt - ds.hanging_token_count.reshape(-1)) % BS == 0).all())
+    # moves
+    nmov = cmc.reshape(-1).long()
+    rows = offs_flat.repeat_interleave(nmov) + (torch.arange(int(nmov.sum()), device=dev)
+                                                - (torch.cumsum(nmov, 0) - nmov).repeat_interleave(nmov))
+    dst, src = cmi[rows, 0].long(), cmi[rows, 1].long()
+    evicted_mask = torch.zeros(NB * BS, dtype=torch.bool, device=dev)
+    bt = ds.block_tables.permute(1, 0, 2, 3).reshape(G, -1).long()                 # [G,M] in (b,l,h) order
+    lam = seg.clamp(max=n - 1).long()
+    phys = bt.gather(1, lam // BS) * BS + lam % BS
+    evicted_mask[phys[live]] = True
+    assert not bool(evicted_mask[src].any()) and bool(evicted_mask[dst].all())
+    del phys, lam
+    # every surviving KV bit-equal at its final slot
+    new_len = ds.context_lens.permute(1, 0, 2).reshape(-1).long() - cnt            # [G] in (b,l,h) order
+    lam_blk = ds.cm.logical_block_num_by_block.long()[:, None] * BS + torch.arange(BS, device=dev)[None, :]
+    live_slot = alloc[:, None] & (lam_blk < new_len[g_of_blk.clamp(min=0)][:, None])
+    ids1 = off_of_blk[:, None] + ds.cm.token_positions.long()
+    for r in range(HD // 8):
+        hr = _hash16(ids1, 1000 + r)
+        assert bool(((k[:, r] == hr[:, :, None]).all(dim=2))[live_slot].all()), ("K", r)
+        assert bool(((v[:, r * 8:(r + 1) * 8] == hr[:, None, :]).all(dim=1))[live_slot].all()), ("V", r)
+    final_ids = ids1[live_slot]
+    assert final_ids.numel() == int(ds.context_lens.long().sum() - cnt.sum())
+    assert final_ids.unique().numel() == final_ids.numel()
+    ws = ops.workspace(dev, 0, "execute_cache_moves")
+    coff = ((G + 2) * 4 + 15) // 16 * 16
+    claims = ws[coff:coff + NB]
+    assert int(claims.max()) == 1 and int((claims == 1).sum()) == (dst // BS).unique().numel()

@@ -1,17 +1,25 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun): rocprofv3 kernel stats of the default bench command and,
-# in SEPARATE passes, the FETCH_SIZE / WRITE_SIZE PMC counters (MI355X_MICROARCH.md: TCC
-# has 4 slots, FETCH_SIZE costs 3 and WRITE_SIZE 2 -> one pass each; never mixed with
-# other trace domains).  Summaries land in gpurun_out/profiles_<tag>/ ; copy to profiles/.
+# Run on the GPU box (via gpurun): the judged measurements of one round.
+#   1. the default bench line (everything on)                          -> <tag>_bench.json
+#   2. rocprofv3 --kernel-trace --stats of the default bench command   -> <tag>_kernel_stats.csv
+#   3. in SEPARATE passes the FETCH_SIZE / WRITE_SIZE PMC counters (MI355X_MICROARCH.md: TCC has 4
+#      slots, FETCH_SIZE costs 3 and WRITE_SIZE 2 -> one pass each; never mixed with trace domains)
+#                                                                       -> <tag>_traffic.json
+#   4. the compaction sweep (metric shape x keep) and the other BASELINE configurations
+#                                                                       -> <tag>_sweep.jsonl, <tag>_configs.jsonl
+# Summaries land in gpurun_out/profiles_<tag>/ ; copy the ones to be judged to profiles/.
 set -u
-TAG="${1:-r1}"
+TAG="${1:-r2}"
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 OUT="$REPO/gpurun_out/profiles_$TAG"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+(rocm-smi --showuniqueid --showclocks 2>&1 | grep -E "Unique|mclk|fclk") > "$OUT/${TAG}_box.txt"
+cd "$REPO"
+timeout 900 python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
 cd /tmp
-BENCH="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-adjacent"
-timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" --output-format csv -- $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
+BENCH="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-adjacent --no-s0 --no-probe"
+timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" --output-format csv -- $BENCH > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/stats.log"
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" --output-format csv -- $BENCH > /dev/null 2> "$OUT/fetch.log"
 timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" --output-format csv -- $BENCH > /dev/null 2> "$OUT/write.log"
 python - "$OUT" "$TAG" <<'PY'
@@ -44,11 +52,23 @@ for k in sorted(set(fetch) | set(write)):
                     # streams (MI355X_MICROARCH.md, HBM) -> doubled; WRITE_SIZE as reported
                     "hbm_bytes_per_launch": (2.0 * fkb + wkb) * 1024.0}
 dom = [k for k in res if "compact_runs_kernel" in k]
-summary = {"tag": tag, "kernels": res}
+summary = {"tag": tag, "command": "bench.py --steps 10 --warmup 2 (default workload)", "kernels": res}
 if dom:
     summary["dominant_kernel"] = dom[0]
     summary["hbm_bytes_per_launch"] = res[dom[0]]["hbm_bytes_per_launch"]
 json.dump(summary, open(f"{out}/{tag}_traffic.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if k != "kernels"}))
 PY
+cd "$REPO"
+B="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-adjacent --no-s0"
+for shape in perm decay oldest; do
+  for keep in 0.5 0.125 0.015625; do
+    [ "$shape" = oldest ] && [ "$keep" = 0.015625 ] && continue
+    timeout 300 $B --metric-shape $shape --keep $keep >> "$OUT/${TAG}_sweep.jsonl" 2>> "$OUT/sweep.err"
+  done
+done
+for cfg in "--batch 4" "--batch 16 --steady-cap 4096" "--batch 64 --steady-cap 4096" "--config c3" "--config c3 --pass-block-tables" "--config c3 --lean" "--config c4" "--config c5" "--layers 80 --seq-len 16384 --batch 4"; do
+  timeout 900 $B $cfg >> "$OUT/${TAG}_configs.jsonl" 2>> "$OUT/configs.err"
+done
+timeout 600 python tools/bench_attention.py > "$OUT/${TAG}_attention_bench.json" 2> "$OUT/attention.err"
 ls "$OUT"

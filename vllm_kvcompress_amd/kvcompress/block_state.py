@@ -24,8 +24,10 @@ def free_compressed_blocks(
     seq_index_by_block: torch.Tensor,    # [NB] i32  (CompressionMetrics; -1 written for freed blocks)
     block_size: int,
     free_mask: Optional[torch.Tensor] = None,   # [NB] bool (ParallelBlockAllocator.free_mask)
+    max_freed: Optional[int] = None,            # host-known upper bound: sum(evicted_blocks_per_seq)
 ) -> torch.Tensor:
-    """Returns the freed physical blocks (int32, the reference's order)."""
+    """Returns the freed physical blocks (int32, the reference's order).  ``max_freed`` sizes the
+    output list (default: every block of the batch, B*L*H*M entries)."""
     lib = _lib.load()
     for n, t in (("block_tables", block_tables), ("context_lens", context_lens),
                  ("freed_block_count", freed_block_count), ("seq_index_by_block", seq_index_by_block)):
@@ -36,7 +38,7 @@ def free_compressed_blocks(
     assert tuple(freed_block_count.shape) == (B, L, H)
     dev = block_tables.device
     slots = torch.tensor(list(seq_indices), dtype=torch.int32).to(dev, non_blocking=True)
-    cap = int(B * L * H * M)
+    cap = int(B * L * H * M) if max_freed is None else max(int(max_freed), 1)
     freed = torch.empty((cap,), dtype=torch.int32, device=dev)
     total = torch.zeros((1,), dtype=torch.int32, device=dev)
     fm_ptr = None
