@@ -74,6 +74,9 @@ def parse_args(argv=None):
     ap.add_argument("--steady-cap", type=int, default=None,
                     help="continual-compression steady state: every head holds this many survivors + 1 "
                          "appended token and is compressed back to the cap (max_cache_tokens)")
+    ap.add_argument("--spare-blocks", type=float, default=0.02,
+                    help="free blocks in the cache as a fraction of the allocated ones (an engine sizes its "
+                         "cache to fill HBM: e.g. 30 puts the sequence's blocks into a 31x larger cache)")
     ap.add_argument("--contiguous-blocks", action="store_true",
                     help="physical blocks in allocation order (fresh prefill) instead of shuffled")
     ap.add_argument("--lean", action="store_true",
@@ -133,7 +136,7 @@ def build_workload(args, seed, device, batch=None):
     st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs,
                           seq_lens=[args.seq_len + 1] * batch, seed=seed,
                           protected=args.protected, metric_shape=args.metric_shape,
-                          spare_block_frac=0.02, shuffle_blocks=not args.contiguous_blocks,
+                          spare_block_frac=args.spare_blocks, shuffle_blocks=not args.contiguous_blocks,
                           steady_cap=args.steady_cap or None)
     cap = args.steady_cap if args.steady_cap else int(args.seq_len * args.keep)
     evicted = [synth.evict_block_count(context_lens_lh=st.context_lens[:, b, :],
@@ -533,8 +536,8 @@ def main():
         traffic, traffic_source = None, None
         default_workload = (args.layers, args.kv_heads, args.head_size, bs, args.seq_len, batch,
                             args.keep, args.protected, args.metric_shape, args.kv_dtype,
-                            args.steady_cap, args.contiguous_blocks) == (
-                                32, 8, 128, 16, 32768, 1, 0.5, 32, "perm", "fp16", 0, False)
+                            args.steady_cap, args.contiguous_blocks, args.spare_blocks) == (
+                                32, 8, 128, 16, 32768, 1, 0.5, 32, "perm", "fp16", 0, False, 0.02)
         # the committed PMC figure belongs to the default workload only; it is a separately
         # profiled run of the same kernel and workload, not a measurement of this run
         if default_workload and os.path.exists(args.traffic_json):
@@ -572,7 +575,8 @@ def main():
                             + (", lean outputs (extension)" if args.lean else "")
                             + (", block_tables passed to schedule_evictions (extension)" if args.pass_block_tables else "")
                             + ", physical blocks "
-                            f"{'in allocation order' if args.contiguous_blocks else 'shuffled'}",
+                            f"{'in allocation order' if args.contiguous_blocks else 'shuffled'}"
+                            + (f" inside a cache of {st.num_blocks} blocks" if args.spare_blocks != 0.02 else ""),
                 "candidate_slots": N, "evicted_slots": evicted_slots, "moved_slots": moved_slots,
                 "freed_blocks": freed_blocks,
             },
