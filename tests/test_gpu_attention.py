@@ -93,6 +93,8 @@ def test_decode_attention_matches_reference_twin(case, version, attn_mode):
     (2, 6, 2, 96, 32, 20, 530, "f16", False),
     (1, 16, 2, 128, 16, 3000, 4100, "f16", False),       # qpk 8 at a 4k cap: 8-wave single pass
     (1, 4, 1, 128, 16, 6000, 8300, "bf16", False),       # qpk 4 at 8k: 8-wave single pass
+    (3, 8, 2, 128, 8, 1, 700, "f16", False),             # block size 8 (a 16-token sub-block spans two blocks)
+    (2, 4, 4, 64, 8, 5, 1100, "bf16", True),
 ])
 def test_decode_attention_matches_oracle(shape, attn_mode):
     S, Hq, Hkv, hd, bs, lo, hi, dt, alibi = shape

@@ -275,9 +275,12 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
     const int t0 = tok_w0 + sb * 16;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (t0 < ctx) {                                       // wave-uniform
-      const int64_t phys = bt[t0 / BS];
-      // dims 32 s + 8 g .. + 7 of token t0 + c: vector (dim / X), element (dim % X)
-      const int64_t kb = phys * a.kv_block_stride + (int64_t)((t0 % BS) + c) * X;
+      // dims 32 s + 8 g .. + 7 of token t0 + c: vector (dim / X), element (dim % X).  A 16-token
+      // sub-block lies inside one cache block for BS >= 16; for BS = 8 it spans two, so every lane
+      // looks its own block up (tokens past the context are clamped onto the last one and masked below)
+      const int tk = BS >= 16 ? t0 + c : min(t0 + c, ctx - 1);
+      const int64_t phys = BS >= 16 ? bt[t0 / BS] : bt[tk / BS];
+      const int64_t kb = phys * a.kv_block_stride + (int64_t)(tk % BS) * X;
       typename KF::Raw kk[KS];
 #pragma unroll
       for (int s = 0; s < KS; ++s)
@@ -494,8 +497,9 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
     auto load_k = [&](int sb) {
       const int t0 = tok_w0 + sb * 16;
       if (t0 < ctx) {
-        const int64_t phys = bt[t0 / BS];
-        const int64_t kb = phys * a.kv_block_stride + (int64_t)((t0 % BS) + c) * X;
+        const int tk = BS >= 16 ? t0 + c : min(t0 + c, ctx - 1);
+        const int64_t phys = BS >= 16 ? bt[t0 / BS] : bt[tk / BS];
+        const int64_t kb = phys * a.kv_block_stride + (int64_t)(tk % BS) * X;
 #pragma unroll
         for (int s = 0; s < KS; ++s)
           kk[sb][s] = KF::load(a.k_cache, kb + (int64_t)((32 * s + 8 * g) / X) * BS * X + (32 * s + 8 * g) % X);
@@ -965,6 +969,8 @@ extern "C" int kvc_paged_attention_decode(const kvc_attention_params* p, kvc_str
     }
   }
   switch (combo) {
+    case 6408: return KVC_ATT(64, 8);
+    case 12808: return KVC_ATT(128, 8);
     case 6416: return KVC_ATT(64, 16);
     case 6432: return KVC_ATT(64, 32);
     case 9616: return KVC_ATT(96, 16);
@@ -978,7 +984,7 @@ extern "C" int kvc_paged_attention_decode(const kvc_attention_params* p, kvc_str
 #undef KVC_ATT_F8
 #undef KVC_ATT_T
 #undef KVC_ATT
-  if (p->block_size != 16 && p->block_size != 32)
+  if (p->block_size != 8 && p->block_size != 16 && p->block_size != 32)
     return fail_invalid("Unsupported block size: " + std::to_string(p->block_size));
   return fail_invalid("Unsupported head size: " + std::to_string(p->head_size));
 }

@@ -122,15 +122,17 @@ __global__ __launch_bounds__(256) void build_keys_kernel(kvc_schedule_params p, 
        tid += (int64_t)data_blocks * blockDim.x) {
   const int64_t blk = tid / per_blk;
   const int off = (int)(tid % per_blk) * VEC;
-  // the wide loads do not depend on the metadata chain below: issue them first
+  // free blocks (an engine's cache is sized to HBM: most blocks do not belong to the batch) cost
+  // their 4 B of sequence index and nothing else; for the others the wide loads do not depend on
+  // the rest of the metadata chain below and are issued first
+  const int s = p.seq_index_by_block[blk];
+  if (s < 0 || s >= p.seq_slot_len) continue;
   float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f);
   int4 q4 = make_int4(0, 0, 0, 0);
   if constexpr (VEC == 4) {
     m4 = *reinterpret_cast<const float4*>(p.metrics + blk * bs + off);
     q4 = *reinterpret_cast<const int4*>(p.token_positions + blk * bs + off);
   }
-  const int s = p.seq_index_by_block[blk];
-  if (s < 0 || s >= p.seq_slot_len) continue;
   const int i = p.seq_slot_of_seq[s];
   if (i < 0) continue;
   const int L = p.num_layers, H = p.num_kv_heads, B = p.num_seqs;
