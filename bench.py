@@ -53,8 +53,8 @@ CONFIGS = {     # BASELINE.json configs[1..4]; c2 is the configuration the metri
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS),
                     help="BASELINE.json configuration (explicit shape flags override it)")
     ap.add_argument("--layers", type=int, default=None)
@@ -210,8 +210,8 @@ def pattern_ceiling(k_cache, v_cache, block_bytes, iters=6):
     fn.restype = ctypes.c_int32
     fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
                    ctypes.c_int32, ctypes.c_void_p]
-    nb = min(int(k_cache.shape[0]), 1 << 20)
-    nruns = nb // 2
+    nb = int(k_cache.shape[0])                      # block ids from the whole cache, like the sequence's own
+    nruns = min(nb // 2, 1 << 19)
     runs = torch.randperm(nb, device=k_cache.device)[:2 * nruns].to(torch.int32).reshape(nruns, 2).contiguous()
     stream = torch.cuda.current_stream(k_cache.device).cuda_stream
     out = {}
@@ -225,8 +225,8 @@ def pattern_ceiling(k_cache, v_cache, block_bytes, iters=6):
         b.record()
         torch.cuda.synchronize()
         out[name] = per_run * nruns / (a.elapsed_time(b) / iters * 1e-3) / 1e9
-    out["what"] = (f"tools/kvc_probe.hip on this GPU, {nruns} runs over {nb} random {block_bytes}-byte "
-                   "K + V block images: rmw = read destination + source images, write destination "
+    out["what"] = (f"tools/kvc_probe.hip on this GPU, {nruns} runs over random {block_bytes}-byte images of the cache's {nb} blocks: "
+                   "rmw = read destination + source K + V images, write destination "
                    "(random evictions); copy = read source, write destination (clustered evictions)")
     return out
 

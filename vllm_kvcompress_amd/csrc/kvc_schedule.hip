@@ -1193,8 +1193,12 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     const int64_t zb64 = (zv + 1023) / 1024;
     const unsigned zb = (unsigned)(zb64 < 1 ? 1 : (zb64 > 2048 ? 2048 : zb64));
     const int64_t threads = p.block_size % 4 == 0 ? p.num_blocks * (p.block_size / 4) : p.num_blocks * p.block_size;
+    // grid-stride: at most 16 Ki workgroups (an engine-sized cache has tens of millions of blocks,
+    // most of them outside the batch: one workgroup per 64 of them cost 0.5 ms in dispatch alone);
+    // half of that behind the small-eviction schedule, where the launch is a no-op unless the flag was raised
     int64_t db64 = (threads + 255) / 256;
-    if (topk && db64 > 8192) db64 = 8192;            // gated: a no-op unless the flag was raised
+    const int64_t cap = topk ? 8192 : 16384;
+    if (db64 > cap) db64 = cap;
     const unsigned db = (unsigned)db64;
     if (p.block_size % 4 == 0)
       hipLaunchKernelGGL(build_keys_kernel<4>, dim3(db + zb), dim3(256), 0, s, p, ws, db, z16, zv);
