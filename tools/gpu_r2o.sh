@@ -1,0 +1,25 @@
+#!/bin/bash
+set -u
+REPO="${GRAFT_REPO_ROOT:-/root/repo}"
+OUT="$REPO/gpurun_out/r2o"
+mkdir -p "$OUT"
+cd "$REPO"
+timeout 600 python tools/soak_schedule_paths.py 400 > "$OUT/soak_paths.log" 2>&1; tail -2 "$OUT/soak_paths.log"
+timeout 600 python tools/soak_medium.py 300 > "$OUT/soak_medium.log" 2>&1; tail -2 "$OUT/soak_medium.log"
+KVC_FUZZ_SEEDS=5000 timeout 600 python -m pytest tests/test_gpu_parity.py -k fuzz -x -q > "$OUT/fuzz.log" 2>&1; tail -2 "$OUT/fuzz.log"
+timeout 600 python tools/soak_attention.py 600 > "$OUT/soak_attention.log" 2>&1; tail -2 "$OUT/soak_attention.log"
+B="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-adjacent --no-s0"
+for sp in 0.02 30 60; do
+  echo "== spare $sp" >> "$OUT/spare.log"
+  timeout 600 $B --spare-blocks $sp >> "$OUT/spare.log" 2>> "$OUT/spare.err"
+done
+python - "$OUT/spare.log" <<'PY'
+import json, sys
+tag = None
+for line in open(sys.argv[1]):
+    if line.startswith("=="):
+        tag = line.strip()
+    elif line.startswith("{"):
+        q = json.loads(line); f = q["roofline"]; c = f["pattern_ceiling_GBps"]
+        print(tag, "value %.3g step %.3f" % (q["value"], q["ms_per_step"]), {k: round(v, 3) for k, v in q["stages_ms"].items()}, "kernel %.3f ms frac %.3f" % (f["avg_launch_ms"], f["frac"]), "ceil", c and (round(c["rmw_2R1W"]), round(c["copy_1R1W"])))
+PY

@@ -161,6 +161,69 @@ __global__ __launch_bounds__(256) void build_keys_kernel(kvc_schedule_params p, 
   }
 }
 
+// The same pass for bs in {4, 8, 16, 32, 64} (16 B per thread), organised so that blocks OUTSIDE the
+// batch cost one coalesced 4 B read and nothing else: a wave looks at 64 consecutive blocks (one
+// sequence index per lane), ballots the ones that belong to the batch, compacts their lane
+// numbers with one ds_permute, and then groups of bs/4 lanes build the keys of one such block
+// each.  An engine sizes its cache to HBM: most blocks do not belong to the sequences being
+// compressed, and with one thread per 4 slots of EVERY block the pass was bound by the latency of
+// the per-thread index load (0.42 ms for a 32 M-block cache holding one 32k sequence).
+__global__ __launch_bounds__(256) void build_keys_wave_kernel(kvc_schedule_params p, SchedWs ws,
+                                                              unsigned data_blocks, uint4* zero16, int64_t zero_vecs) {
+  if (gated_off(ws)) return;
+  if (blockIdx.x >= data_blocks) {      // tail workgroups clear the counters of the later passes
+    for (int64_t i = (int64_t)(blockIdx.x - data_blocks) * 256 + threadIdx.x; i < zero_vecs;
+         i += (int64_t)(gridDim.x - data_blocks) * 256)
+      zero16[i] = make_uint4(0u, 0u, 0u, 0u);
+    return;
+  }
+  const int bs = p.block_size;
+  const int per_blk = bs / 4;                        // lanes per block: 1, 2, 4, 8 or 16
+  const int groups = WAVE / per_blk;                 // blocks a wave builds at a time
+  const int lane = lane_id();
+  const int L = p.num_layers, H = p.num_kv_heads, B = p.num_seqs;
+  const int64_t nwaves = (int64_t)data_blocks * 4;
+  for (int64_t blk0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * WAVE; blk0 < p.num_blocks; blk0 += nwaves * WAVE) {
+    const int64_t myb = blk0 + lane;
+    int i_mine = -1;
+    if (myb < p.num_blocks) {
+      const int s = p.seq_index_by_block[myb];
+      if (s >= 0 && s < p.seq_slot_len) i_mine = p.seq_slot_of_seq[s];
+    }
+    const unsigned long long mask = __ballot(i_mine >= 0);
+    if (mask == 0ull) continue;
+    const int nvalid = __popcll(mask);
+    // lane r receives the lane number of the r-th block of the batch (ascending)
+    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+    const int list = __builtin_amdgcn_ds_permute((i_mine >= 0 ? rank : WAVE - 1) * 4, lane);
+    for (int base = 0; base < nvalid; base += groups) {
+      const int k = base + lane / per_blk;
+      const bool on = k < nvalid;
+      const int src = __builtin_amdgcn_ds_bpermute((on ? k : 0) * 4, list);
+      const int i = __builtin_amdgcn_ds_bpermute(src * 4, i_mine);
+      if (!on) continue;
+      const int64_t blk = blk0 + src;
+      const int off = (lane % per_blk) * 4;
+      const float4 m = *reinterpret_cast<const float4*>(p.metrics + blk * bs + off);
+      const int4 q = *reinterpret_cast<const int4*>(p.token_positions + blk * bs + off);
+      const int l = p.layer_index_by_block[blk], h = p.head_index_by_block[blk];
+      const int lbn = p.logical_block_num_by_block[blk];
+      const int g = (i * L + l) * H + h;
+      const int ctx = p.context_lens[(l * B + i) * H + h];
+      if (lbn < 0 || lbn >= (ctx + bs - 1) / bs) continue;       // not part of the head's slot range
+      const int seq_pos = p.seq_positions[i], prot = p.num_protected[i];
+      const int64_t base_g = p.evicted_kv_offsets[g];
+      uint4 kq;
+      kq.x = slot_key(p, m.x, q.x, seq_pos, prot, l, h);
+      kq.y = slot_key(p, m.y, q.y, seq_pos, prot, l, h);
+      kq.z = slot_key(p, m.z, q.z, seq_pos, prot, l, h);
+      kq.w = slot_key(p, m.w, q.w, seq_pos, prot, l, h);
+      *reinterpret_cast<uint4*>(ws.keys + base_g + (int64_t)lbn * bs + off) = kq;
+      if (off == 0) ws.chunk_phys[base_g / bs + lbn] = (int32_t)blk;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ 1. per-head histograms
 // flat tiles of TILE keys; a tile inside one head (the common case) accumulates in LDS.
 constexpr int HTILE = 2048;
@@ -1200,7 +1263,17 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     const int64_t cap = topk ? 8192 : 16384;
     if (db64 > cap) db64 = cap;
     const unsigned db = (unsigned)db64;
-    if (p.block_size % 4 == 0)
+    const int bsz = p.block_size;
+    // blocks of the batch / blocks of the cache: a dense cache is faster with one independent thread
+    // per 4 slots (build_keys_kernel), a sparse one with the wave-organised sweep
+    const bool sparse = p.total_slots < (int64_t)p.num_blocks * bsz / 2;
+    if (sparse && (bsz == 4 || bsz == 8 || bsz == 16 || bsz == 32 || bsz == 64)) {
+      // one wave per 64 blocks and sweep; at most ~8 sweeps of the resident waves
+      int64_t wb64 = (p.num_blocks + 255) / 256;
+      if (wb64 > cap) wb64 = cap;
+      const unsigned wbk = (unsigned)(wb64 < 1 ? 1 : wb64);
+      hipLaunchKernelGGL(build_keys_wave_kernel, dim3(wbk + zb), dim3(256), 0, s, p, ws, wbk, z16, zv);
+    } else if (p.block_size % 4 == 0)
       hipLaunchKernelGGL(build_keys_kernel<4>, dim3(db + zb), dim3(256), 0, s, p, ws, db, z16, zv);
     else
       hipLaunchKernelGGL(build_keys_kernel<1>, dim3(db + zb), dim3(256), 0, s, p, ws, db, z16, zv);
