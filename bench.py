@@ -89,6 +89,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-adjacent", action="store_true",
                     help="skip the decode-attention (F3) side measurement")
     ap.add_argument("--no-s0", action="store_true", help="skip the S0 (metric aggregation) stage timings")
+    ap.add_argument("--no-engine-cache", action="store_true",
+                    help="skip the second measurement of the same step in an HBM-filling cache")
+    ap.add_argument("--engine-cache-frac", type=float, default=0.80,
+                    help="fraction of the free HBM that second cache takes")
     ap.add_argument("--no-probe", action="store_true",
                     help="skip the access-pattern ceiling probe (tools/libkvc_probe.so)")
     ap.add_argument("--traffic-json", default=os.path.join(REPO, "profiles", "traffic.json"),
@@ -297,6 +301,76 @@ def s0_stages(args, device):
     del probs, outm
     torch.cuda.empty_cache()
     return out
+
+
+def engine_sized_cache_run(args, rank, device, steps=20, warmup=3):
+    """The SAME step with the sequence's blocks inside a cache sized the way an engine sizes it: to
+    the GPU's memory (vLLM's gpu_memory_utilization) instead of to the sequence.  Candidate, evicted
+    and moved slots are identical to the main run; only the number of (free) blocks in the cache
+    tensor differs.  Reported next to the main line because random 4 KiB block traffic runs at
+    5.1 or 6.1 TB/s depending on where the blocks lie in HBM."""
+    import copy
+    import torch
+    from vllm_kvcompress_amd import _custom_ops as ops
+    e = 1 if args.kv_dtype == "fp8" else 2
+    bs, hd = args.block_size, args.head_size
+    block_bytes = hd * bs * e
+    free, _ = torch.cuda.mem_get_info()
+    own = args.layers * args.kv_heads * args.batch * (args.seq_len // bs + 1)
+    nb_target = int(args.engine_cache_frac * free / (2 * block_bytes + 8 * bs + 16))
+    if nb_target < 8 * own:
+        return None
+    a2 = copy.copy(args)
+    a2.spare_blocks = nb_target / own - 1.0
+    try:
+        st, ds, evicted, k_cache, v_cache = build_workload(a2, rank + 1000, device)
+    except torch.OutOfMemoryError:
+        torch.cuda.empty_cache()
+        return None
+    N = st.total_slots
+    wm, wp = ds.cm.metrics.clone(), ds.cm.token_positions.clone()
+    cmi = torch.empty((N, 2), dtype=torch.int32, device=device)
+    cmc = torch.empty((st.num_seqs, st.num_layers, st.num_kv_heads), dtype=torch.int32, device=device)
+    seq_idx, prot = list(st.seq_indices), list(st.protected)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    marks = [[ev() for _ in range(5)] for _ in range(steps)]
+    out = {}
+    for i in range(-warmup, steps):
+        rec = i >= 0
+        if rec: marks[i][0].record()
+        eli, ekc, ebc = ds.cm.schedule_evictions(seq_idx, ds.seq_positions, evicted, ds.context_lens,
+                                                 ds.hanging_token_count, ds.evicted_kv_offsets, prot, total_slots=N)
+        if rec: marks[i][1].record()
+        ops.schedule_cache_moves(cmi, cmc, eli, ekc, ds.evicted_kv_offsets, ds.block_tables, ds.context_lens, bs)
+        if rec: marks[i][2].record()
+        ops._execute_cache_moves(k_cache, v_cache, wm, wp, cmi, cmc, ds.evicted_kv_offsets, "plan")
+        if rec: marks[i][3].record()
+        ops._execute_cache_moves(k_cache, v_cache, wm, wp, cmi, cmc, ds.evicted_kv_offsets, "apply")
+        if rec: marks[i][4].record()
+        out["ekc"] = ekc
+    torch.cuda.synchronize()
+    ms = lambda a, b: sum(m[a].elapsed_time(m[b]) for m in marks) / steps
+    kernel_ms, step_ms = ms(3, 4), ms(0, 4)
+    moved, evs = int(cmc.sum().item()), int(out["ekc"].sum().item())
+    alg = moved * alg_bytes_per_move(hd, e) + 8 * st.total_heads
+    floor = traffic_floor(cmi, cmc, ds.evicted_kv_offsets, bs, block_bytes)
+    res = {
+        "what": f"the same step, the sequence's blocks scattered over a cache that fills {args.engine_cache_frac:.0%} of the free HBM "
+                "(as an engine sizes it) instead of one sized to the sequence",
+        "cache_blocks": st.num_blocks, "cache_GiB": 2 * st.num_blocks * block_bytes / 2 ** 30,
+        "evicted_slots": evs, "moved_slots": moved,
+        "ms_per_step": step_ms, "value": (evs + moved) / (step_ms * 1e-3),
+        "stages_ms": {"S1_schedule_evictions": ms(0, 1), "S2_schedule_moves": ms(1, 2), "S3_execute_moves": ms(2, 4)},
+        "roofline": {"avg_launch_ms": kernel_ms, "achieved": alg / (kernel_ms * 1e-3) / 1e9,
+                     "frac": alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "floor_GBps": floor["bytes"] / (kernel_ms * 1e-3) / 1e9,
+                     "frac_of_floor": floor["bytes"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "pattern_ceiling_GBps": None if args.no_probe else pattern_ceiling(k_cache, v_cache, block_bytes)},
+        "timing": f"{steps} steps after {warmup} warm-up steps, HIP events on the launch stream",
+    }
+    del k_cache, v_cache, ds, cmi, wm, wp
+    torch.cuda.empty_cache()
+    return res
 
 
 # --------------------------------------------------------------------------- CPU baseline
@@ -607,6 +681,8 @@ def main():
         }
         if per_rank:
             res["per_rank"] = per_rank
+        if world == 1 and not args.no_engine_cache and not args.steady_cap and args.spare_blocks == 0.02:
+            res["engine_sized_cache"] = engine_sized_cache_run(args, rank, device)
         if world == 1 and not args.no_s0:
             del cmi, work_metrics, work_pos
             res["stages_ms_S0"] = s0_stages(args, device)

@@ -23,7 +23,8 @@ def _last_json(stdout):
 
 def test_single_rank_line():
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "4", "--warmup", "1",
-                          "--seq-len", "4096", "--no-adjacent"], capture_output=True, text=True,
+                          "--seq-len", "4096", "--no-adjacent", "--engine-cache-frac", "0.02"],
+                         capture_output=True, text=True,
                          timeout=600, cwd=REPO)
     assert out.returncode == 0, out.stderr[-2000:]
     d = _last_json(out.stdout)
@@ -38,6 +39,9 @@ def test_single_rank_line():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["host_cpus"] == os.cpu_count() and c["cores"] >= 1 and c["value"] > 0
     assert c["single_core_port"]["cores"] == 1
+    ec = d["engine_sized_cache"]      # the same step in a (here: 2 % of HBM) larger cache: identical work
+    assert ec["evicted_slots"] == d["config"]["evicted_slots"] and ec["moved_slots"] == d["config"]["moved_slots"]
+    assert ec["cache_blocks"] > 8 * 32 * 8 * 257 and 0 < ec["roofline"]["frac"] < 1
     s0 = d["stages_ms_S0"]
     assert {"S0_aggregate_decode", "S0_aggregate_decode_fused_clear", "S0_aggregate_prefill",
             "S0_prefill_epilogue"} <= set(s0) and all(v["ms"] > 0 for v in s0.values())

@@ -230,3 +230,31 @@ def test_block_tables_input_replaces_the_chunk_table_pass(mode):
                                  [st.protected[i] for i in sub], total_slots=n_sub)
     for x, y in zip(b, c):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("bs,hd", [(4, 8), (8, 64), (16, 128), (32, 128)])
+def test_sparse_batch_in_a_large_cache(bs, hd):
+    """an engine sizes its cache to HBM: most blocks do not belong to the batch.  The key pass then
+    takes its wave-organised form (one coalesced index read per 64 blocks, keys only for the
+    batch's blocks); bulk and small evictions, both modes, against the oracle, end to end"""
+    from tests.helpers import oracle_pipeline as pipe
+    from vllm_kvcompress_amd import _custom_ops as ops
+    for seed, (compressed, frac) in enumerate([(False, 0.5), (True, 0.6), (False, 0.03)]):
+        st = synth.make_state(num_layers=2, num_kv_heads=3, block_size=bs, seq_lens=[40 * bs, 13 * bs + 5, 70 * bs],
+                              seed=20 + seed, protected=[bs + 1, 3, 2 * bs], compressed=compressed,
+                              spare_block_frac=4.0)
+        assert st.total_slots < st.num_blocks * bs // 2
+        nblk = ((st.context_lens.astype(np.int64) + bs - 1) // bs).sum(0).sum(-1)
+        evicted = [int(n * frac) for n in nblk]
+        k, v = synth.make_caches_u16(seed, st.num_blocks, hd, bs)
+        for mode in ("reference", "per_sequence"):
+            want = pipe(st, evicted, k, v, mode=mode)
+            ds = hdev.upload(st, DEV, mode=mode)
+            ds.cm.schedule_path = 1
+            eli, ekc, ebc, cmi, cmc = hdev.schedule(ds, st, evicted)
+            kd, vd = torch.from_numpy(k.copy()).to(DEV), torch.from_numpy(v.copy()).to(DEV)
+            ops.execute_cache_moves(kd, vd, ds.cm.metrics, ds.cm.token_positions, cmi, cmc, ds.evicted_kv_offsets, 1, 16)
+            for name, got, w in (("eli", eli, want["eli"]), ("ekc", ekc, want["ekc"]), ("ebc", ebc, want["ebc"]),
+                                 ("cmi", cmi, want["cmi"]), ("cmc", cmc, want["cmc"]), ("k", kd, want["k"]),
+                                 ("v", vd, want["v"]), ("metrics", ds.cm.metrics, want["metrics"])):
+                np.testing.assert_array_equal(got.cpu().numpy(), w, err_msg=f"{name} bs={bs} seed={seed} {mode}")

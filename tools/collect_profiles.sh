@@ -18,7 +18,7 @@ export TMPDIR=/tmp
 cd "$REPO"
 timeout 900 python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
 cd /tmp
-BENCH="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-adjacent --no-s0 --no-probe"
+BENCH="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-adjacent --no-s0 --no-probe --no-engine-cache"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" --output-format csv -- $BENCH > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/stats.log"
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" --output-format csv -- $BENCH > /dev/null 2> "$OUT/fetch.log"
 timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" --output-format csv -- $BENCH > /dev/null 2> "$OUT/write.log"
@@ -60,14 +60,14 @@ json.dump(summary, open(f"{out}/{tag}_traffic.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if k != "kernels"}))
 PY
 cd "$REPO"
-B="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-adjacent --no-s0"
+B="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-adjacent --no-s0 --no-engine-cache"
 for shape in perm decay oldest; do
   for keep in 0.5 0.125 0.015625; do
     [ "$shape" = oldest ] && [ "$keep" = 0.015625 ] && continue
     timeout 300 $B --metric-shape $shape --keep $keep >> "$OUT/${TAG}_sweep.jsonl" 2>> "$OUT/sweep.err"
   done
 done
-for cfg in "--batch 4" "--batch 16 --steady-cap 4096" "--batch 64 --steady-cap 4096" "--config c3" "--config c3 --pass-block-tables" "--config c3 --lean" "--config c4" "--config c5" "--layers 80 --seq-len 16384 --batch 4"; do
+for cfg in "--spare-blocks 30" "--spare-blocks 60" "--batch 4" "--batch 16 --steady-cap 4096" "--batch 64 --steady-cap 4096" "--config c3" "--config c3 --pass-block-tables" "--config c3 --lean" "--config c4" "--config c5" "--layers 80 --seq-len 16384 --batch 4"; do
   timeout 900 $B $cfg >> "$OUT/${TAG}_configs.jsonl" 2>> "$OUT/configs.err"
 done
 timeout 600 python tools/bench_attention.py > "$OUT/${TAG}_attention_bench.json" 2> "$OUT/attention.err"
