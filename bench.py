@@ -306,8 +306,8 @@ def s0_stages(args, device):
 def engine_sized_cache_run(args, rank, device, steps=20, warmup=3):
     """The SAME step with the sequence's blocks inside a cache sized the way an engine sizes it: to
     the GPU's memory (vLLM's gpu_memory_utilization) instead of to the sequence.  Candidate, evicted
-    and moved slots are identical to the main run; only the number of (free) blocks in the cache
-    tensor differs.  Reported next to the main line because random 4 KiB block traffic runs at
+    slots are identical to the main run and the moved ones differ by a fraction of a percent (another
+    seed's metrics); what changes is the number of (free) blocks in the cache tensor.  Reported next to the main line because random 4 KiB block traffic runs at
     5.1 or 6.1 TB/s depending on where the blocks lie in HBM."""
     import copy
     import torch
