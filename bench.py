@@ -10,9 +10,9 @@ batch of synthetic paged-cache state resident in HBM:
 
 Default workload = BASELINE.json configs[1]: Llama-3-8B shape (32 layers, 8 KV heads,
 hd 128), 32k-token cache, block_size 16, batch 1, compress_once to half the cache
-(max_cache_tokens = T/2), fp16 K/V, tie-free permutation metrics.  ``--config c3|c4|c5``
+(max_cache_tokens = T/2), fp16 K/V, tie-free permutation metrics.  ``--config c3|c3i|c4|c5``
 select the other BASELINE configurations (c3: 256 resident sequences in the continual
-steady state; c4: Llama-3-70B shape, 16k tokens, 32 sequences per GPU; c5: fp8, bs 32, 64k).
+steady state; c3i: its initial phase, a wave of 16 sequences compressed 32k -> 4k tokens; c4: Llama-3-70B shape, 16k tokens, 32 sequences per GPU; c5: fp8, bs 32, 64k).
 Scheduling always reads the pristine metric store; compaction writes working copies, so
 every step does identical work (the moves never touch their own sources).
 
@@ -44,7 +44,8 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 CONFIGS = {     # BASELINE.json configs[1..4]; c2 is the configuration the metric is quoted on
     "c2": {},
-    "c3": {"batch": 256, "steady_cap": 4096},
+    "c3": {"batch": 256, "steady_cap": 4096},           # phase ii: all 256 sequences resident at the cap
+    "c3i": {"batch": 16, "keep": 0.125},               # phase i: a wave of 16 sequences, 32k -> 4k tokens
     "c4": {"layers": 80, "seq_len": 16384, "batch": 32},
     "c5": {"kv_dtype": "fp8", "block_size": 32, "seq_len": 65536},
 }
@@ -65,7 +66,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=None, help="sequences per GPU (weak scaling)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="strong: --batch is the whole job's sequence count, split over the GPUs")
-    ap.add_argument("--keep", type=float, default=0.5, help="max_cache_tokens / seq_len")
+    ap.add_argument("--keep", type=float, default=None, help="max_cache_tokens / seq_len (default 0.5)")
     ap.add_argument("--protected", type=int, default=32)
     ap.add_argument("--metric-shape", default="perm", choices=["perm", "decay", "oldest"])
     ap.add_argument("--mode", default="per_sequence", choices=["per_sequence", "reference"])
@@ -100,7 +101,7 @@ def parse_args(argv=None):
     args = ap.parse_args(argv)
     preset = CONFIGS[args.config]
     for key, default in (("layers", 32), ("block_size", 16), ("seq_len", 32768), ("batch", 1),
-                         ("kv_dtype", "fp16"), ("steady_cap", 0)):
+                         ("kv_dtype", "fp16"), ("steady_cap", 0), ("keep", 0.5)):
         if getattr(args, key) is None:
             setattr(args, key, preset.get(key, default))
     return args

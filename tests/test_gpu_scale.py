@@ -177,19 +177,30 @@ def test_full_size_properties(T, BS, cdtype, keep):
 def test_config4_full_size_properties():
     """BASELINE configs[3] as one GPU of the 8 sees it: Llama-3-70B shape (80 layers, 8 KV heads,
     hd 128), 16 384-token cache, 32 sequences (336 M candidate slots, 172 GB of K/V), compress_once
-    to half the cache, per_sequence scheduling.  Size-independent properties: every sequence frees
+    to half the cache, per_sequence scheduling."""
+    _multi_sequence_full_size(80, 8, 16384, 32, 0.5)
+
+
+def test_config3_initial_compression_full_size_properties():
+    """BASELINE configs[2], phase i: a wave of 16 sequences with 32k-token
+    histories compressed to the 4k-token cap in one call (134 M candidate slots, 69 GB of K/V,
+    7/8 of every head evicted), per_sequence scheduling."""
+    _multi_sequence_full_size(32, 8, 32768, 16, 0.125)
+
+
+def _multi_sequence_full_size(Lc, Hc, T, Bc, keep):
+    """Size-independent properties: every sequence frees
     exactly what was asked; per head the evicted indices are ascending, distinct and padded; no
     evicted slot is a move source and every destination is an evicted slot; EVERY surviving KV
     sits bit-equal at its final slot (K/V rows carry a hash of the KV's identity); the block path
     was taken for every destination block."""
-    Lc, Hc, T, Bc = 80, 8, 16384, 32
     need = 2 * Lc * Hc * Bc * (T // BS + 2) * BS * HD * 2 + (24 << 30)
     free, _ = torch.cuda.mem_get_info()
     if free < need:
         pytest.skip(f"needs {need >> 30} GiB of free HBM")
     st = synth.make_state(num_layers=Lc, num_kv_heads=Hc, block_size=BS, seq_lens=[T + 1] * Bc, seed=4,
                           protected=32, spare_block_frac=0.01)
-    evicted = _evict(st, 0.5, T)
+    evicted = _evict(st, keep, T)
     NB, N = st.num_blocks, st.total_slots
     ds = hdev.upload(st, DEV, mode="per_sequence")
     dev = torch.device(DEV)

@@ -67,7 +67,7 @@ for shape in perm decay oldest; do
     timeout 300 $B --metric-shape $shape --keep $keep >> "$OUT/${TAG}_sweep.jsonl" 2>> "$OUT/sweep.err"
   done
 done
-for cfg in "--spare-blocks 30" "--spare-blocks 60" "--batch 4" "--batch 16 --steady-cap 4096" "--batch 64 --steady-cap 4096" "--config c3" "--config c3 --pass-block-tables" "--config c3 --lean" "--config c4" "--config c5" "--layers 80 --seq-len 16384 --batch 4"; do
+for cfg in "--spare-blocks 30" "--spare-blocks 60" "--batch 4" "--batch 16 --steady-cap 4096" "--batch 64 --steady-cap 4096" "--config c3" "--config c3 --pass-block-tables" "--config c3 --lean" "--config c3i" "--config c4" "--config c5" "--layers 80 --seq-len 16384 --batch 4"; do
   timeout 900 $B $cfg >> "$OUT/${TAG}_configs.jsonl" 2>> "$OUT/configs.err"
 done
 timeout 600 python tools/bench_attention.py > "$OUT/${TAG}_attention_bench.json" 2> "$OUT/attention.err"
