@@ -340,6 +340,34 @@ def test_prefill_metric_epilogue(l2, avg, pool):
         np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("Hq,qb,K", [(4, 24, 96), (3, 70, 100), (2, 17, 97), (2, 50, 40), (1, 5, 8), (2, 33, 1024),
+                                     # workgroups of 256, 512 and 1024 threads (host heuristic)
+                                     (64, 7, 4096), (64, 9, 8192), (128, 5, 8192)])
+def test_prefill_metric_epilogue_shapes_and_both_column_kernels(Hq, qb, K):
+    """the four-columns-per-thread kernel (K % 4 == 0, 16 B aligned tile) and the scalar one sum
+    every column in the same order: bit-identical results, and both within float rounding of the
+    oracle; diagonals inside, left and right of the tile"""
+    from vllm_kvcompress_amd.kvcompress.prefill import accumulate_prefill_tile
+    rng = np.random.default_rng(Hq * 1000 + K)
+    for q_offset, buf in ((max(K - qb, 0), 0), (max(K - qb, 0), 5), (K // 2, 1), (3, 7), (0, 0), (K + 9, 2)):
+        for l2, avg, pool in ((True, False, True), (False, True, False)):
+            probs = rng.random((Hq, qb, K)).astype(np.float32)
+            out0 = rng.random((K, Hq)).astype(np.float32)
+            want = out0.copy()
+            orc.prefill_metric_epilogue(want, probs, q_offset, buf, l2, avg, pool)
+            out = torch.from_numpy(out0).to(DEV)
+            accumulate_prefill_tile(out, torch.from_numpy(probs).to(DEV), q_offset, buf, l2, avg, pool)
+            np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-6, atol=1e-7)
+            # the same tile at an address that is not 16 B aligned takes the scalar kernel
+            flat = torch.empty(probs.size + 1, dtype=torch.float32, device=DEV)
+            shifted = flat[1:].view(Hq, qb, K)
+            shifted.copy_(torch.from_numpy(probs))
+            assert shifted.data_ptr() % 16 != 0 and shifted.is_contiguous()
+            out2 = torch.from_numpy(out0).to(DEV)
+            accumulate_prefill_tile(out2, shifted, q_offset, buf, l2, avg, pool)
+            assert torch.equal(out, out2)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
 def test_reshape_and_cache_kvc(dtype):
     rng = np.random.default_rng(4)

@@ -232,6 +232,24 @@ def test_block_tables_input_replaces_the_chunk_table_pass(mode):
         assert torch.equal(x, y)
 
 
+def test_block_tables_with_entries_outside_the_cache_fall_back():
+    """a caller's table naming blocks the cache does not have is never dereferenced: the
+    small-eviction schedule hands over to the general pipeline, which only reads the per-block
+    metadata, and the result is still the oracle's"""
+    st, evicted = _steady(3, 4, 16, 4, 512, 11)
+    want = oracle_pipeline(st, evicted, mode="per_sequence")
+    ds = hdev.upload(st, DEV, mode="per_sequence")
+    args = (list(st.seq_indices), ds.seq_positions, evicted, ds.context_lens, ds.hanging_token_count,
+            ds.evicted_kv_offsets, list(st.protected))
+    bad = ds.block_tables.clone()
+    bad[1, 2, 3, 5] = st.num_blocks + 7            # inside the head's chunk range
+    bad[0, 0, 0, 0] = 2 ** 31 - 1
+    a = ds.cm.schedule_evictions(*args, total_slots=st.total_slots, block_tables=bad)
+    assert ds.cm.last_schedule_path() == "small_eviction+fallback"
+    for got, key in zip(a, ("eli", "ekc", "ebc")):
+        np.testing.assert_array_equal(got.cpu().numpy(), want[key], err_msg=key)
+
+
 @pytest.mark.parametrize("bs,hd", [(4, 8), (8, 64), (16, 128), (32, 128)])
 def test_sparse_batch_in_a_large_cache(bs, hd):
     """an engine sizes its cache to HBM: most blocks do not belong to the batch.  The key pass then

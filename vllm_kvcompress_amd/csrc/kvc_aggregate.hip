@@ -84,6 +84,82 @@ __global__ __launch_bounds__(256) void epilogue_colsum_kernel(float* __restrict_
   colsum[(int64_t)h * K + k] = acc;
 }
 
+// The same sums, four adjacent key columns per thread (16 B loads) with the next batch of rows
+// requested before the current one is added up.  Every column is still summed in ascending
+// query order, so the result is bit-identical to the kernel above.  What decides the rate is how
+// much of a query row one workgroup reads contiguously (rows are K x 4 B apart): on a 4 GiB tile
+// (Hq 32, qb 1024, K 32768) 1 KiB per row and workgroup (the scalar kernel) 1.55 ms = 2.8 TB/s,
+// 2 KiB 1.69 ms, 4 KiB 1.43 ms, 8 KiB 1.00 ms, 16 KiB 0.86 ms = 5.0 TB/s; streaming loads cost
+// 10 %.  The host picks the largest workgroup that still gives one workgroup per CU.
+// Needs K % 4 == 0 and 16 B aligned tile / workspace.
+constexpr int EPI_ROWS = 4;
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void epilogue_colsum4_kernel(float* __restrict__ colsum,
+                                                                   const float* __restrict__ probs,
+                                                                   int Hq, int qb, int K, int q_offset,
+                                                                   int buffer_len, int use_l2,
+                                                                   int use_average) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int k = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int h = blockIdx.y;
+  if (k >= K) return;
+  const int diag = q_offset - buffer_len;
+  int qmin[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { qmin[c] = k + c - diag; qmin[c] = qmin[c] < 0 ? 0 : qmin[c]; }
+  const f32x4* col = reinterpret_cast<const f32x4*>(probs + ((int64_t)h * qb) * K + k);
+  const int64_t rs = K / 4;                       // row stride in vectors
+  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  auto add_row = [&](const f32x4& t, int q) {
+    const float v[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      // rows above a column's first counted query add nothing (+0 leaves the sum's bits alone)
+      const float x = q >= qmin[c] ? (use_l2 ? __fmul_rn(v[c], v[c]) : v[c]) : 0.0f;
+      acc[c] = __fadd_rn(acc[c], x);
+    }
+  };
+  int q = qmin[0];
+  f32x4 cur[EPI_ROWS], nxt[EPI_ROWS];
+  auto load_rows = [&](f32x4 (&dst)[EPI_ROWS], int q0) {
+#pragma unroll
+    for (int u = 0; u < EPI_ROWS; ++u) dst[u] = col[(int64_t)(q0 + u) * rs];
+  };
+  auto add_rows = [&](const f32x4 (&src)[EPI_ROWS], int q0) {
+#pragma unroll
+    for (int u = 0; u < EPI_ROWS; ++u) add_row(src[u], q0 + u);
+  };
+  if (q + EPI_ROWS <= qb) {
+    load_rows(cur, q);                            // cur = rows [q, q + R)
+    // ping-pong between the two register sets (a copy from one to the other would wait for the
+    // rows still in flight)
+    while (q + 3 * EPI_ROWS <= qb) {
+      load_rows(nxt, q + EPI_ROWS);
+      add_rows(cur, q);
+      load_rows(cur, q + 2 * EPI_ROWS);
+      add_rows(nxt, q + EPI_ROWS);
+      q += 2 * EPI_ROWS;
+    }
+    if (q + 2 * EPI_ROWS <= qb) {
+      load_rows(nxt, q + EPI_ROWS);
+      add_rows(cur, q);
+      add_rows(nxt, q + EPI_ROWS);
+      q += 2 * EPI_ROWS;
+    } else {
+      add_rows(cur, q);
+      q += EPI_ROWS;
+    }
+  }
+  for (; q < qb; ++q) add_row(col[(int64_t)q * rs], q);
+  f32x4 o;
+  float r[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    r[c] = use_average ? __fmul_rn(acc[c], __fdiv_rn((float)(k + c + 1), (float)qb)) : acc[c];
+  o.x = r[0]; o.y = r[1]; o.z = r[2]; o.w = r[3];
+  *reinterpret_cast<f32x4*>(colsum + (int64_t)h * K + k) = o;
+}
+
 // step 2: max_pool1d(kernel 7, pad 3, stride 1) over keys, accumulate into out[K,Hq]
 // reference: flash_attn.py:1204-1210 and the accumulation at :1161
 __global__ __launch_bounds__(256) void epilogue_pool_kernel(float* __restrict__ out_kh,
@@ -371,9 +447,24 @@ extern "C" int kvc_prefill_metric_epilogue(float* out_kh, const float* probs_hqk
     return fail_invalid("prefill_metric_epilogue: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   float* colsum = reinterpret_cast<float*>(workspace);
-  hipLaunchKernelGGL(epilogue_colsum_kernel, dim3((num_keys + 255) / 256, num_q_heads), dim3(256), 0,
-                     s, colsum, probs_hqk, num_q_heads, q_block, num_keys, q_offset, buffer_len,
-                     use_l2, use_average);
+  if (num_keys % 4 == 0 && ((reinterpret_cast<uintptr_t>(probs_hqk) | reinterpret_cast<uintptr_t>(workspace)) & 15u) == 0) {
+    const int cg = num_keys / 4;                        // column groups
+    int threads = 1024;
+    while (threads > 128 && (int64_t)((cg + threads - 1) / threads) * num_q_heads < 256) threads >>= 1;
+    const dim3 grid((cg + threads - 1) / threads, num_q_heads);
+#define KVC_EPI_LAUNCH(T)                                                                          \
+    hipLaunchKernelGGL(epilogue_colsum4_kernel<T>, grid, dim3(T), 0, s, colsum, probs_hqk, num_q_heads, \
+                       q_block, num_keys, q_offset, buffer_len, use_l2, use_average)
+    if (threads == 1024) KVC_EPI_LAUNCH(1024);
+    else if (threads == 512) KVC_EPI_LAUNCH(512);
+    else if (threads == 256) KVC_EPI_LAUNCH(256);
+    else KVC_EPI_LAUNCH(128);
+#undef KVC_EPI_LAUNCH
+  }
+  else
+    hipLaunchKernelGGL(epilogue_colsum_kernel, dim3((num_keys + 255) / 256, num_q_heads), dim3(256), 0,
+                       s, colsum, probs_hqk, num_q_heads, q_block, num_keys, q_offset, buffer_len,
+                       use_l2, use_average);
   const int64_t n = (int64_t)num_keys * num_q_heads;
   hipLaunchKernelGGL(epilogue_pool_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out_kh,
                      colsum, num_q_heads, num_keys, use_maxpool);

@@ -827,15 +827,23 @@ __global__ __launch_bounds__(64 * WAVES) void head_topk_kernel(kvc_schedule_para
   const int ctx = p.context_lens[(l * B + i_seq) * H + h];
   const int seq_pos = p.seq_positions[i_seq], prot = p.num_protected[i_seq];
   const uint32_t hang = (uint32_t)p.hanging_token_count[g];
-  if (p.block_tables != nullptr && nchunks > p.block_tables_width) {   // inconsistent caller state
-    if (lane == 0) atomicOr(ws.fallback, 1u);
-    return;
+  const int bt_row = p.block_tables != nullptr ? p.seq_index_of_slot[i_seq] : 0;
+  if (p.block_tables != nullptr && (nchunks > p.block_tables_width || bt_row < 0 || bt_row >= p.max_num_seqs)) {
+    if (lane == 0) atomicOr(ws.fallback, 1u);        // inconsistent caller state: the general pipeline
+    return;                                          // (which reads the per-block metadata only) decides
   }
   // physical block of every logical chunk: the caller's block table if it passed one, else the
   // table chunk_table_kernel built from the per-block metadata
   const int32_t* cphys = p.block_tables != nullptr
-      ? p.block_tables + (((int64_t)l * p.max_num_seqs + p.seq_index_of_slot[i_seq]) * H + h) * p.block_tables_width
+      ? p.block_tables + (((int64_t)l * p.max_num_seqs + bt_row) * H + h) * p.block_tables_width
       : ws.chunk_phys + base / bs;
+  // a caller's table may name blocks the cache does not have: never dereferenced, and the general
+  // pipeline (per-block metadata only) takes over
+  bool bad_entry = false;
+  auto table_entry = [&](int v) {
+    if (v >= (int)p.num_blocks || (v < 0 && p.block_tables != nullptr)) { bad_entry = true; return -1; }
+    return v;
+  };
   // null padding of the head's output segment (emit_topk overwrites its first cnt entries)
   if (!(p.lean & 1)) {
     typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
@@ -850,7 +858,7 @@ __global__ __launch_bounds__(64 * WAVES) void head_topk_kernel(kvc_schedule_para
   uint32_t pivot = KEY_INF - 1u;
   int rank = NSAMP - 1;
   if (n > CAND_CAP) {
-    const int phys = cphys[(int)((int64_t)lane * nchunks / WAVE)];
+    const int phys = table_entry(cphys[(int)((int64_t)lane * nchunks / WAVE)]);
     float sm[4];
     int sq[4];
 #pragma unroll
@@ -879,12 +887,12 @@ __global__ __launch_bounds__(64 * WAVES) void head_topk_kernel(kvc_schedule_para
   uint32_t F = 0, C = 0;
   for (int attempt = 0;; ++attempt) {
     F = 0; C = 0;
-    int my_phys = lane < nchunks ? cphys[lane] : -1;
+    int my_phys = lane < nchunks ? table_entry(cphys[lane]) : -1;
     for (int c0 = 0; c0 < nchunks; c0 += WAVE) {     // groups of 64 chunks
       const int gch = min(WAVE, nchunks - c0);
       const int iters = (gch * bs + WAVE - 1) / WAVE;
       const int cnext = c0 + WAVE + lane;
-      const int next_phys = cnext < nchunks ? cphys[cnext] : -1;
+      const int next_phys = cnext < nchunks ? table_entry(cphys[cnext]) : -1;
       for (int ib = 0; ib < iters; ib += UB) {
         // branch-free on purpose: with control flow between the loads the compiler drains the
         // whole queue (vmcnt(0)) in front of every shuffle, one round trip per iteration
@@ -932,6 +940,10 @@ __global__ __launch_bounds__(64 * WAVES) void head_topk_kernel(kvc_schedule_para
     rank = over ? rank / 2 : (rank * 2 < NSAMP - 1 ? rank * 2 : NSAMP - 1);
     pivot = (rank >= NSAMP - 1 || n <= CAND_CAP) ? KEY_INF - 1u : samp[rank];
     if (pivot >= KEY_INF) pivot = KEY_INF - 1u;
+  }
+  if (__ballot(bad_entry) != 0ull) {
+    if (lane == 0) atomicOr(ws.fallback, 1u);
+    return;
   }
   // ---- exact part: sort the candidates by (key, physical slot), keep the first KREC
   wave_lds_sync();
