@@ -167,11 +167,24 @@ def case_grid():
                   seq_lens=[150, 91], seed=12, protected=32), "mid", dict(hd=128)))
     cases.append(("b2_bs16_L4H8_med", dict(num_layers=4, num_kv_heads=8, block_size=16,
                   seq_lens=[300, 171], seed=14, protected=32), "mid", {}))
+    # continual-compression steady state (every head at the cap + 1 appended token, about one
+    # block per head freed): what the small-eviction schedule of the HIP path is chosen for
+    cases.append(("b2_bs16_steady256", dict(num_layers=2, num_kv_heads=2, block_size=16,
+                  seq_lens=[768, 768], seed=21, protected=17, steady_cap=256), "cap256", {}))
+    cases.append(("b3_bs32_steady512", dict(num_layers=2, num_kv_heads=2, block_size=32,
+                  seq_lens=[1536] * 3, seed=22, protected=33, steady_cap=512), "cap512", {}))
+    cases.append(("b1_bs8_steady128", dict(num_layers=3, num_kv_heads=2, block_size=8,
+                  seq_lens=[384], seed=23, protected=9, steady_cap=128), "cap128", {}))
     return cases
 
 
 def eviction_spec(st, spec, rng):
     bs = st.block_size
+    if spec.startswith("cap"):       # the scheduler's own count (Appendix B of SURVEY.md, harness/synth.py)
+        cap = int(spec[3:])
+        return [synth.evict_block_count(context_lens_lh=st.context_lens[:, b, :], seq_len=3 * cap,
+                                        block_size=bs, protected_window_size=st.protected[b],
+                                        max_cache_tokens=cap) for b in range(st.num_seqs)]
     nblk = ((st.context_lens.astype(np.int64) + bs - 1) // bs).sum(0).sum(-1)    # [B]
     TH = st.num_layers * st.num_kv_heads
     out = []

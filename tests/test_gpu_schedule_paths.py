@@ -36,6 +36,26 @@ def _steady(L, H, bs, B, cap, seed, **kw):
     return st, evicted
 
 
+@pytest.mark.parametrize("name", ["b2_bs16_steady256", "b3_bs32_steady512", "b1_bs8_steady128"])
+def test_reference_generated_steady_states(name):
+    """steady-state fixtures produced by the reference's own CompressionMetrics.schedule_evictions
+    and move twins (oracle/gen_golden.py): the small-eviction schedule is the one that runs, and
+    both schedules reproduce the reference bit for bit (reference mode, batch>1 quirk included)"""
+    from tests.helpers import load_golden
+    from tests.test_gpu_parity import _state_from_golden
+    g = load_golden(name)
+    st = _state_from_golden(g)
+    evicted = [int(x) for x in g["evicted_blocks_per_seq"]]
+    for path, how_want in ((0, "small_eviction"), (1, "general")):
+        out, how = _run(st, evicted, path, "reference")
+        assert how == how_want
+        np.testing.assert_array_equal(out["eli"], g["ref_evicted_logical_indices"])
+        np.testing.assert_array_equal(out["ekc"], g["ref_evicted_kv_count"])
+        np.testing.assert_array_equal(out["ebc"], g["ref_evicted_block_count"])
+        np.testing.assert_array_equal(out["cmi"], g["ref_cache_moves_idx"])
+        np.testing.assert_array_equal(out["cmc"], g["ref_cache_moves_count"])
+
+
 @pytest.mark.parametrize("mode", ["reference", "per_sequence"])
 @pytest.mark.parametrize("L,H,bs,B,cap", [(4, 4, 16, 3, 512), (2, 8, 32, 2, 1024), (3, 2, 8, 2, 256),
                                           (2, 2, 16, 1, 4096)])
