@@ -195,6 +195,9 @@ def _multi_sequence_full_size(Lc, Hc, T, Bc, keep):
     sits bit-equal at its final slot (K/V rows carry a hash of the KV's identity); the block path
     was taken for every destination block."""
     need = 2 * Lc * Hc * Bc * (T // BS + 2) * BS * HD * 2 + (24 << 30)
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()            # blocks cached by earlier tests do not count as used
     free, _ = torch.cuda.mem_get_info()
     if free < need:
         pytest.skip(f"needs {need >> 30} GiB of free HBM")
