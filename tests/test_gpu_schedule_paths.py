@@ -182,6 +182,9 @@ def test_config3_full_size_steady_state_properties():
     frees exactly what was asked, per head the evicted indices are ascending and distinct and are
     exactly the head's cnt lowest-metric evictable slots, the two schedules agree bit for bit."""
     L, H, bs, B, cap = 32, 8, 16, 256, 4096
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
     if free < 40 << 30:
         pytest.skip("needs ~40 GB of free HBM")
