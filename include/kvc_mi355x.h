@@ -372,8 +372,9 @@ int kvc_append_slots(int32_t* context_lens, int32_t* block_tables, uint8_t* free
  * (cache elements of `dtype`, K vectors of x = 8), 1 = fp8 e4m3fn, 2 = fp8 e5m2 (OCP bytes,
  * K vectors of x = 16; dequantised as dtype(float(fp8) * k_scale / v_scale) like the
  * reference's fp8::scaled_convert, kvcompress_attention_kernels.cu:229-236, 369-377).
- * block_size 16 or 32 (and 8 for "auto" caches with head_size 64 / 128); head_size 64, 96, 128
- * or 256 ("auto"), 64 or 128 (fp8).  (The reference also instantiates block size 1.)
+ * block_size 16 or 32 (for "auto" caches also 8 with head_size 64 / 128 and 1 with head_size
+ * 128 -- the reference's launcher enables head size 128 with block sizes 1 / 8 / 16 / 32,
+ * kvcompress_attention_kernels.cu:749-806); head_size 64, 96, 128 or 256 ("auto"), 64 or 128 (fp8).
  * --------------------------------------------------------------------------------- */
 typedef struct kvc_attention_params {
   void* out;                            /* [num_seqs, num_heads, head_size] */

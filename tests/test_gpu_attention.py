@@ -95,6 +95,8 @@ def test_decode_attention_matches_reference_twin(case, version, attn_mode):
     (1, 4, 1, 128, 16, 6000, 8300, "bf16", False),       # qpk 4 at 8k: 8-wave single pass
     (3, 8, 2, 128, 8, 1, 700, "f16", False),             # block size 8 (a 16-token sub-block spans two blocks)
     (2, 4, 4, 64, 8, 5, 1100, "bf16", True),
+    (2, 8, 2, 128, 1, 1, 600, "f16", False),             # block size 1: every token in a block of its own
+    (2, 4, 1, 128, 1, 300, 900, "bf16", True),
 ])
 def test_decode_attention_matches_oracle(shape, attn_mode):
     S, Hq, Hkv, hd, bs, lo, hi, dt, alibi = shape

@@ -88,6 +88,19 @@ struct KvFrag {
       r.v = KVC_LD(reinterpret_cast<const au32x2*>(reinterpret_cast<const uint8_t*>(base) + elem));
     return r;
   }
+  // blocks of fewer than 8 tokens (the reference instantiates block size 1,
+  // kvcompress_attention_kernels.cu:797): the 8 tokens of a V fragment sit in different blocks,
+  // one 2-byte element each.  pe[e] = element offset of token e's block (+ its slot), < 0: masked
+  static __device__ __forceinline__ Raw gather(const void* base, const int64_t (&pe)[8], int64_t off) {
+    static_assert(KVD == 0, "small blocks: unquantised caches only");
+    const uint16_t* b = reinterpret_cast<const uint16_t*>(base);
+    uint32_t h[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = pe[e] >= 0 ? (uint32_t)b[pe[e] + off] : 0u;
+    Raw r;
+    r.v = au32x4{h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+    return r;
+  }
   static __device__ __forceinline__ V8 convert(const Raw& r, float scale) {
     if constexpr (KVD == 0) {
       return __builtin_bit_cast(V8, r.v);
@@ -276,7 +289,7 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (t0 < ctx) {                                       // wave-uniform
       // dims 32 s + 8 g .. + 7 of token t0 + c: vector (dim / X), element (dim % X).  A 16-token
-      // sub-block lies inside one cache block for BS >= 16; for BS = 8 it spans two, so every lane
+      // sub-block lies inside one cache block for BS >= 16; for BS = 8 it spans two (16 for BS = 1), so every lane
       // looks its own block up (tokens past the context are clamped onto the last one and masked below)
       const int tk = BS >= 16 ? t0 + c : min(t0 + c, ctx - 1);
       const int64_t phys = BS >= 16 ? bt[t0 / BS] : bt[tk / BS];
@@ -348,12 +361,21 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
     // A operand: V[dim 16 i + c][tokens t0 + 8 g .. + 7]
     const int tok = t0 + 8 * g;
     const bool live = tok < ctx;
-    const int64_t phys = live ? bt[tok / BS] : 0;
-    const int64_t vb = phys * a.kv_block_stride + (int64_t)c * BS + (tok % BS);
     const bool tail = t0 + 32 > ctx;                      // wave-uniform: mask stale tokens
     typename KF::Raw vr[DT];
+    if constexpr (BS >= 8) {
+      const int64_t phys = live ? bt[tok / BS] : 0;
+      const int64_t vb = phys * a.kv_block_stride + (int64_t)c * BS + (tok % BS);
 #pragma unroll
-    for (int i = 0; i < DT; ++i) vr[i] = live ? KF::load(a.v_cache, vb + (int64_t)i * 16 * BS) : KF::zero();
+      for (int i = 0; i < DT; ++i) vr[i] = live ? KF::load(a.v_cache, vb + (int64_t)i * 16 * BS) : KF::zero();
+    } else {
+      int64_t pe[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        pe[e] = tok + e < ctx ? (int64_t)bt[(tok + e) / BS] * a.kv_block_stride + (tok + e) % BS : -1;
+#pragma unroll
+      for (int i = 0; i < DT; ++i) vr[i] = KF::gather(a.v_cache, pe, (int64_t)(16 * i + c) * BS);
+    }
 #pragma unroll
     for (int i = 0; i < DT; ++i) {
       V8 vv = KF::convert(vr[i], a.v_scale);
@@ -556,11 +578,20 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
     auto load_v = [&](int pr, int bufi) {
       const int tok = tok_w0 + pr * 32 + 8 * g;
       const bool live = tok < ctx;
-      const int64_t phys = live ? bt[tok / BS] : 0;
-      const int64_t vb = phys * a.kv_block_stride + (int64_t)c * BS + (tok % BS);
+      if constexpr (BS >= 8) {
+        const int64_t phys = live ? bt[tok / BS] : 0;
+        const int64_t vb = phys * a.kv_block_stride + (int64_t)c * BS + (tok % BS);
 #pragma unroll
-      for (int i = 0; i < DT; ++i)
-        vv[bufi][i] = live ? KF::load(a.v_cache, vb + (int64_t)i * 16 * BS) : KF::zero();
+        for (int i = 0; i < DT; ++i)
+          vv[bufi][i] = live ? KF::load(a.v_cache, vb + (int64_t)i * 16 * BS) : KF::zero();
+      } else {
+        int64_t pe[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          pe[e] = tok + e < ctx ? (int64_t)bt[(tok + e) / BS] * a.kv_block_stride + (tok + e) % BS : -1;
+#pragma unroll
+        for (int i = 0; i < DT; ++i) vv[bufi][i] = KF::gather(a.v_cache, pe, (int64_t)(16 * i + c) * BS);
+      }
     };
     load_v(0, 0);
 #pragma unroll
@@ -969,6 +1000,7 @@ extern "C" int kvc_paged_attention_decode(const kvc_attention_params* p, kvc_str
     }
   }
   switch (combo) {
+    case 12801: return KVC_ATT(128, 1);
     case 6408: return KVC_ATT(64, 8);
     case 12808: return KVC_ATT(128, 8);
     case 6416: return KVC_ATT(64, 16);
@@ -984,7 +1016,7 @@ extern "C" int kvc_paged_attention_decode(const kvc_attention_params* p, kvc_str
 #undef KVC_ATT_F8
 #undef KVC_ATT_T
 #undef KVC_ATT
-  if (p->block_size != 8 && p->block_size != 16 && p->block_size != 32)
+  if (p->block_size != 1 && p->block_size != 8 && p->block_size != 16 && p->block_size != 32)
     return fail_invalid("Unsupported block size: " + std::to_string(p->block_size));
   return fail_invalid("Unsupported head size: " + std::to_string(p->head_size));
 }
