@@ -22,6 +22,9 @@ def test_config_presets_and_overrides():
     assert (a.kv_dtype, a.block_size, a.seq_len) == ("fp8", 32, 65536)
     a = bench.parse_args(["--config", "c4", "--batch", "4"])       # explicit flags win
     assert (a.layers, a.batch) == (80, 4)
+    a = bench.parse_args(["--config", "c3i"])                       # config 3, initial phase
+    assert (a.batch, a.keep, a.seq_len, a.steady_cap) == (16, 0.125, 32768, 0)
+    assert bench.parse_args([]).keep == 0.5 and bench.parse_args(["--config", "c3i", "--keep", "0.25"]).keep == 0.25
 
 
 def test_traffic_floor_of_a_small_move_list():
