@@ -1009,26 +1009,57 @@ __global__ __launch_bounds__(1024) void seq_select_topk_kernel(kvc_schedule_para
   }
   for (int lh = tid; lh < LH; lh += blockDim.x) cnt[lh] = 0;
   __syncthreads();
-  if (k > 0) {
-    for (int kk = 2; kk <= P2; kk <<= 1)
-      for (int j = kk >> 1; j > 0; j >>= 1) {
-        for (int t = tid; t < P2 / 2; t += blockDim.x) {
-          const int a = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-          const int b = a + j;
-          const bool up = (a & kk) == 0;
-          const uint64_t x = arr[a], y = arr[b];
-          if ((x > y) == up) { arr[a] = y; arr[b] = x; }
-        }
-        __syncthreads();
+  // the k'-th smallest entry by an MSB-first radix select over the 64-bit (threshold, head,
+  // chunk) values in LDS -- eight byte rounds of one histogram each (a full bitonic sort of the
+  // 4096 entries of 256 heads took 40 of this kernel's 54 us, for k' = 16)
+  __shared__ uint32_t sel_hist[RADIX];
+  __shared__ uint32_t sel_wtot[4];
+  __shared__ uint32_t sel_digit, sel_krem;
+  uint64_t vstar = ~0ull;
+  if (k > 0 && k <= (uint32_t)P2) {
+    uint64_t prefix = 0;
+    uint32_t krem = k;
+    for (int round = 0; round < 8; ++round) {
+      const int shift = 56 - 8 * round;
+      if (tid < RADIX) sel_hist[tid] = 0;
+      __syncthreads();
+      for (int e0 = 0; e0 < P2; e0 += blockDim.x) {          // uniform trip count (ballots inside)
+        const int e = e0 + tid;
+        const uint64_t v = e < P2 ? arr[e] : 0ull;
+        const bool in = e < P2 && (round == 0 || (v >> (shift + 8)) == prefix);
+        hist_add(sel_hist, in, (uint32_t)(v >> shift) & 0xFFu);
       }
-    for (uint32_t e = tid; e < k; e += blockDim.x) {
-      const uint64_t v = e < (uint32_t)P2 ? arr[e] : ~0ull;
-      if (v == ~0ull) atomicOr(ws.fallback, 1u);     // the records do not hold k' thresholds
-      else atomicAdd(&cnt[(uint32_t)v / (uint32_t)MCH], 1u);
+      __syncthreads();
+      uint32_t c = 0, inc = 0;
+      if (tid < RADIX) {
+        c = sel_hist[tid];
+        inc = wave_inclusive_scan(c);
+        if ((tid & 63) == 63) sel_wtot[tid >> 6] = inc;
+      }
+      __syncthreads();
+      if (tid < RADIX) {
+        uint32_t off = 0;
+        for (int q = 0; q < (tid >> 6); ++q) off += sel_wtot[q];
+        const uint32_t incl = off + inc, excl = incl - c;
+        if (krem > excl && krem <= incl) { sel_digit = (uint32_t)tid; sel_krem = krem - excl; }
+      }
+      __syncthreads();
+      prefix = (prefix << 8) | sel_digit;
+      krem = sel_krem;
     }
+    vstar = prefix;
+    // (k' > number of recorded thresholds: the select ends on the ~0 padding)
+    if (vstar == ~0ull) { if (tid == 0) atomicOr(ws.fallback, 1u); }
+    else
+      for (int e = tid; e < P2; e += blockDim.x) {
+        const uint64_t v = arr[e];
+        if (v <= vstar) atomicAdd(&cnt[(uint32_t)v / (uint32_t)MCH], 1u);
+      }
+  } else if (k > (uint32_t)P2) {
+    if (tid == 0) atomicOr(ws.fallback, 1u);             // the records do not hold k' thresholds
   }
   __syncthreads();
-  const uint32_t Tstar = (k > 0 && k <= (uint32_t)P2) ? (uint32_t)(arr[k - 1] >> 32) : 0u;
+  const uint32_t Tstar = vstar != ~0ull ? (uint32_t)(vstar >> 32) : 0u;
   if (tid == 0) ws.seq_prefix[i] = Tstar;
   for (int lh = tid; lh < LH; lh += blockDim.x) {
     const int64_t g = (int64_t)i * LH + lh;
@@ -1246,7 +1277,7 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     static bool attr_done = false;
     if (!attr_done) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_select_topk_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);   // + its static tables
       attr_done = true;
     }
     constexpr int TW = 4;
