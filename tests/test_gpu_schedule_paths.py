@@ -276,7 +276,7 @@ def test_block_tables_with_entries_outside_the_cache_fall_back():
 @pytest.mark.parametrize("bs,hd", [(4, 8), (8, 64), (16, 128), (32, 128)])
 def test_sparse_batch_in_a_large_cache(bs, hd):
     """an engine sizes its cache to HBM: most blocks do not belong to the batch.  The key pass then
-    takes its wave-organised form (one coalesced index read per 64 blocks, keys only for the
+    takes its compacting form (coalesced sweeps of the sequence indices, keys only for the
     batch's blocks); bulk and small evictions, both modes, against the oracle, end to end"""
     from tests.helpers import oracle_pipeline as pipe
     from vllm_kvcompress_amd import _custom_ops as ops

@@ -162,14 +162,18 @@ __global__ __launch_bounds__(256) void build_keys_kernel(kvc_schedule_params p, 
 }
 
 // The same pass for bs in {4, 8, 16, 32, 64} (16 B per thread), organised so that blocks OUTSIDE the
-// batch cost one coalesced 4 B read and nothing else: a wave looks at 64 consecutive blocks (one
-// sequence index per lane), ballots the ones that belong to the batch, compacts their lane
-// numbers with one ds_permute, and then groups of bs/4 lanes build the keys of one such block
-// each.  An engine sizes its cache to HBM: most blocks do not belong to the sequences being
-// compressed, and with one thread per 4 slots of EVERY block the pass was bound by the latency of
-// the per-thread index load (0.42 ms for a 32 M-block cache holding one 32k sequence).
-__global__ __launch_bounds__(256) void build_keys_wave_kernel(kvc_schedule_params p, SchedWs ws,
-                                                              unsigned data_blocks, uint4* zero16, int64_t zero_vecs) {
+// batch cost one coalesced 4 B read and nothing else.  An engine sizes its cache to HBM: most
+// blocks do not belong to the sequences being compressed.  A workgroup sweeps SPARSE_CHUNK
+// consecutive blocks: every thread requests its share of the sequence indices at once (one round
+// trip), the blocks of the batch are compacted into an LDS list, and the list is then worked off
+// densely, one thread per 4 slots like build_keys_kernel.  (History: one thread per 4 slots of
+// EVERY block 0.42 ms for a 32 M-block cache holding one 32k sequence, bound by the latency of the
+// per-thread index load; one wave per 64 blocks 0.18 ms, bound by the dependent loads of the few
+// batch blocks a wave finds; this form 0.07 ms.)
+constexpr int SPARSE_SCAN = 16;                       // index loads in flight per thread
+constexpr int SPARSE_CHUNK = 256 * SPARSE_SCAN;       // blocks per workgroup sweep
+__global__ __launch_bounds__(256) void build_keys_sparse_kernel(kvc_schedule_params p, SchedWs ws,
+                                                                unsigned data_blocks, uint4* zero16, int64_t zero_vecs) {
   if (gated_off(ws)) return;
   if (blockIdx.x >= data_blocks) {      // tail workgroups clear the counters of the later passes
     for (int64_t i = (int64_t)(blockIdx.x - data_blocks) * 256 + threadIdx.x; i < zero_vecs;
@@ -177,33 +181,45 @@ __global__ __launch_bounds__(256) void build_keys_wave_kernel(kvc_schedule_param
       zero16[i] = make_uint4(0u, 0u, 0u, 0u);
     return;
   }
+  __shared__ uint32_t list_s[SPARSE_CHUNK];           // (batch position of the sequence << 12) | block - chunk base
+  static_assert(SPARSE_CHUNK <= 4096, "12 bits of block offset");
+  __shared__ uint32_t n_s;
   const int bs = p.block_size;
-  const int per_blk = bs / 4;                        // lanes per block: 1, 2, 4, 8 or 16
-  const int groups = WAVE / per_blk;                 // blocks a wave builds at a time
-  const int lane = lane_id();
+  const int per_blk = bs / 4;
+  const int tid = threadIdx.x, lane = lane_id();
   const int L = p.num_layers, H = p.num_kv_heads, B = p.num_seqs;
-  const int64_t nwaves = (int64_t)data_blocks * 4;
-  for (int64_t blk0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * WAVE; blk0 < p.num_blocks; blk0 += nwaves * WAVE) {
-    const int64_t myb = blk0 + lane;
-    int i_mine = -1;
-    if (myb < p.num_blocks) {
-      const int s = p.seq_index_by_block[myb];
-      if (s >= 0 && s < p.seq_slot_len) i_mine = p.seq_slot_of_seq[s];
+  for (int64_t base = (int64_t)blockIdx.x * SPARSE_CHUNK; base < p.num_blocks; base += (int64_t)data_blocks * SPARSE_CHUNK) {
+    if (tid == 0) n_s = 0;
+    __syncthreads();
+    int sidx[SPARSE_SCAN];
+#pragma unroll
+    for (int u = 0; u < SPARSE_SCAN; ++u) {
+      const int64_t blk = base + u * 256 + tid;
+      sidx[u] = blk < p.num_blocks ? p.seq_index_by_block[blk] : -1;
     }
-    const unsigned long long mask = __ballot(i_mine >= 0);
-    if (mask == 0ull) continue;
-    const int nvalid = __popcll(mask);
-    // lane r receives the lane number of the r-th block of the batch (ascending)
-    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-    const int list = __builtin_amdgcn_ds_permute((i_mine >= 0 ? rank : WAVE - 1) * 4, lane);
-    for (int base = 0; base < nvalid; base += groups) {
-      const int k = base + lane / per_blk;
-      const bool on = k < nvalid;
-      const int src = __builtin_amdgcn_ds_bpermute((on ? k : 0) * 4, list);
-      const int i = __builtin_amdgcn_ds_bpermute(src * 4, i_mine);
-      if (!on) continue;
-      const int64_t blk = blk0 + src;
-      const int off = (lane % per_blk) * 4;
+#pragma unroll
+    for (int u = 0; u < SPARSE_SCAN; ++u) {
+      const int sq = sidx[u];
+      int i = -1;
+      if (sq >= 0 && sq < p.seq_slot_len) i = p.seq_slot_of_seq[sq];
+      const unsigned long long mask = __ballot(i >= 0);
+      if (mask == 0ull) continue;                     // wave-uniform
+      uint32_t wbase = 0;
+      if (lane == 0) wbase = atomicAdd(&n_s, (uint32_t)__popcll(mask));
+      wbase = (uint32_t)__shfl((int)wbase, 0, 64);
+      if (i >= 0) {
+        const uint32_t pos = wbase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        list_s[pos] = ((uint32_t)i << 12) | (uint32_t)(u * 256 + tid);
+      }
+    }
+    __syncthreads();
+    const int items = (int)n_s * per_blk;
+    for (int it = tid; it < items; it += 256) {
+      const int e = it / per_blk;
+      const int off = (it % per_blk) * 4;
+      const uint32_t ent = list_s[e];
+      const int64_t blk = base + (ent & 4095u);
+      const int i = (int)(ent >> 12);
       const float4 m = *reinterpret_cast<const float4*>(p.metrics + blk * bs + off);
       const int4 q = *reinterpret_cast<const int4*>(p.token_positions + blk * bs + off);
       const int l = p.layer_index_by_block[blk], h = p.head_index_by_block[blk];
@@ -221,6 +237,7 @@ __global__ __launch_bounds__(256) void build_keys_wave_kernel(kvc_schedule_param
       *reinterpret_cast<uint4*>(ws.keys + base_g + (int64_t)lbn * bs + off) = kq;
       if (off == 0) ws.chunk_phys[base_g / bs + lbn] = (int32_t)blk;
     }
+    __syncthreads();
   }
 }
 
@@ -1317,14 +1334,14 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     const unsigned db = (unsigned)db64;
     const int bsz = p.block_size;
     // blocks of the batch / blocks of the cache: a dense cache is faster with one independent thread
-    // per 4 slots (build_keys_kernel), a sparse one with the wave-organised sweep
+    // per 4 slots (build_keys_kernel), a sparse one with the compacting sweep
     const bool sparse = p.total_slots < (int64_t)p.num_blocks * bsz / 2;
     if (sparse && (bsz == 4 || bsz == 8 || bsz == 16 || bsz == 32 || bsz == 64)) {
-      // one wave per 64 blocks and sweep; at most ~8 sweeps of the resident waves
-      int64_t wb64 = (p.num_blocks + 255) / 256;
+      // one workgroup per SPARSE_CHUNK blocks (grid-stride when capped)
+      int64_t wb64 = (p.num_blocks + kvc::SPARSE_CHUNK - 1) / kvc::SPARSE_CHUNK;
       if (wb64 > cap) wb64 = cap;
       const unsigned wbk = (unsigned)(wb64 < 1 ? 1 : wb64);
-      hipLaunchKernelGGL(build_keys_wave_kernel, dim3(wbk + zb), dim3(256), 0, s, p, ws, wbk, z16, zv);
+      hipLaunchKernelGGL(build_keys_sparse_kernel, dim3(wbk + zb), dim3(256), 0, s, p, ws, wbk, z16, zv);
     } else if (p.block_size % 4 == 0)
       hipLaunchKernelGGL(build_keys_kernel<4>, dim3(db + zb), dim3(256), 0, s, p, ws, db, z16, zv);
     else
