@@ -180,19 +180,21 @@ typedef struct kvc_schedule_params {
                                                * the continual-compression steady state -- every key is
                                                * read once instead of five times.  Results
                                                * are identical either way; a wrong hint only costs time. */
-  const int32_t* block_tables;                /* optional (NULL = not given): BlockState.block_tables
-                                               * [L, max_num_seqs, H, block_tables_width] (block.py:95-126).
-                                               * The reference's schedule_evictions does not receive it;
-                                               * a caller that has it at hand (the fork's scheduler does)
-                                               * saves the small-eviction schedule its chunk-table pass
-                                               * (a scattered 4 B write per physical block).  Rows are
-                                               * indexed by the sequence index, seq_index_of_slot[i] for
-                                               * batch slot i; entries past ceil(ctx/bs) are ignored. */
-  const int32_t* seq_index_of_slot;           /* [B] with block_tables */
-  int32_t max_num_seqs, block_tables_width;   /* with block_tables */
+  const int32_t* block_tables;                /* accepted and ignored since ABI version 2 (BlockState.block_tables
+                                               * [L, max_num_seqs, H, block_tables_width]; the round-2
+                                               * small-eviction schedule gathered rows through it, the
+                                               * present one streams the store in physical order and
+                                               * needs no logical -> physical map at all) */
+  const int32_t* seq_index_of_slot;           /* [B] with block_tables (ignored) */
+  int32_t max_num_seqs, block_tables_width;   /* with block_tables (ignored) */
   int32_t schedule_path;                      /* 0 = choose by the hint, 1 = general pipeline only,
                                                * 2 = small-eviction schedule whenever the shapes allow
-                                               * (falls back on device when it cannot finish exactly) */
+                                               * (falls back on device when it cannot finish exactly),
+                                               * 3 = like 2, always streaming the position rows (tests) */
+  int32_t sample_stride;                      /* small-eviction schedule: its pivots come from a sample
+                                               * of one physical block in `sample_stride` (a power of
+                                               * two <= 256); 0 = chosen from the batch size.  Results
+                                               * do not depend on it (tests force several values). */
   /* outputs */
   int32_t* evicted_logical_indices;           /* [N] */
   int32_t* evicted_kv_count;                  /* [B,L,H] */

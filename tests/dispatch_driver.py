@@ -52,6 +52,20 @@ def main():
     assert np.array_equal(cmi.cpu().numpy(), want["cmi"]) and np.array_equal(cmc.cpu().numpy(), want["cmc"])
     assert np.array_equal(kd.cpu().numpy(), want["k"]) and np.array_equal(vd.cpu().numpy(), want["v"])
     assert np.array_equal(ds.cm.metrics.cpu().numpy(), want["metrics"])
+    # ---- the V1 scheduler pair: schemas present (csrc/torch_bindings.cpp:374-394), calls say where
+    # the live path is
+    t = torch.zeros(4, dtype=torch.int32, device=DEV)
+    v1 = []
+    for call in (lambda: torch.ops._C_kvc_ops.schedule_cache_evictions(
+                     t, t, t, t, t, t, t, t, t, t, t, t, t, t, t, t, 16, False, None, 0, 2147483000, False),
+                 lambda: torch.ops._C_kvc_ops.truncate_cache_evictions(t, t, t, t, t, 16, 0, 2147483000)):
+        try:
+            call()
+            v1.append("returned")
+        except RuntimeError as e:
+            v1.append("dead code in the reference" in str(e))
+    assert v1 == [True, True], v1
+    res["v1_schemas"] = "registered, raise"
     # ---- reshape_and_cache ("auto" and fp8)
     rng = np.random.default_rng(0)
     T, H, hd, nb = 37, 2, 128, 12

@@ -1,7 +1,7 @@
 """schedule_evictions has two schedules behind one entry point (kvc_schedule_params
 .schedule_path / .max_evicted_blocks_hint): the general radix-select pipeline and the
-small-eviction schedule of the continual-compression steady state (every key read once, per-head
-records), which raises a device flag and lets the general pipeline redo the work when it cannot
+small-eviction schedule of the continual-compression steady state (the metric store streamed once in
+physical order, per-head records of the keys below a sampled pivot), which raises a device flag and lets the general pipeline redo the work when it cannot
 finish exactly.  Both must give the oracle's result bit for bit; these tests also pin WHICH one
 produced it."""
 import numpy as np
@@ -119,8 +119,8 @@ def test_skewed_head_raises_the_fallback_and_the_result_stays_exact():
 
 
 def test_ragged_heads_sampled_pivot_and_candidate_overflow():
-    """heads longer than the candidate buffer take a sampled pivot (exact whatever the sample says);
-    a long head whose metrics are all tied overflows the buffer -> flag -> general pipeline"""
+    """ragged batches (long and tiny sequences side by side, a sequence that frees nothing); a long
+    head whose metrics are all tied overflows its record -> flag -> general pipeline"""
     for seed in range(4):
         st = synth.make_state(num_layers=1, num_kv_heads=2, block_size=16, seq_lens=[9000, 200, 3000, 200],
                               seed=seed, protected=3)
@@ -140,7 +140,7 @@ def test_ragged_heads_sampled_pivot_and_candidate_overflow():
         np.testing.assert_array_equal(got[key], want[key], err_msg=key)
 
 
-@pytest.mark.parametrize("path", [0, 1, 2])
+@pytest.mark.parametrize("path", [0, 1, 2, 3])
 def test_forced_paths_on_mixed_batches(path):
     """bulk and tiny evictions, compressed states, B > 1 quirk: whatever the path, the oracle's result"""
     cases = [
@@ -225,52 +225,99 @@ def test_config3_full_size_steady_state_properties():
 
 
 @pytest.mark.parametrize("mode", ["reference", "per_sequence"])
-def test_block_tables_input_replaces_the_chunk_table_pass(mode):
-    """optional extension: with BlockState.block_tables at hand the small-eviction schedule reads
-    the physical blocks from it (no chunk-table pass); identical results, also for a batch that is
-    a subset of the resident sequences (rows indexed by sequence index)"""
+def test_block_tables_argument_is_accepted_and_changes_nothing(mode):
+    """``block_tables=`` fed round 2's gathering schedule; the streaming one needs no logical ->
+    physical map.  The argument stays (callers pass it), is never dereferenced -- a table naming
+    blocks the cache does not have included -- and the result is the oracle's, also for a batch
+    that is a subset of the resident sequences"""
     st, evicted = _steady(3, 4, 16, 4, 512, 9)
     want = oracle_pipeline(st, evicted, mode=mode)
     ds = hdev.upload(st, DEV, mode=mode)
     args = (list(st.seq_indices), ds.seq_positions, evicted, ds.context_lens, ds.hanging_token_count,
             ds.evicted_kv_offsets, list(st.protected))
-    a = ds.cm.schedule_evictions(*args, total_slots=st.total_slots, block_tables=ds.block_tables)
-    assert ds.cm.last_schedule_path() == "small_eviction"
-    for got, key in zip(a, ("eli", "ekc", "ebc")):
-        np.testing.assert_array_equal(got.cpu().numpy(), want[key], err_msg=key)
-    # two of the four sequences, table rows of all four resident ones
+    bad = ds.block_tables.clone()
+    bad[1, 2, 3, 5] = st.num_blocks + 7
+    bad[0, 0, 0, 0] = 2 ** 31 - 1
+    for bt in (ds.block_tables, bad):
+        a = ds.cm.schedule_evictions(*args, total_slots=st.total_slots, block_tables=bt)
+        assert ds.cm.last_schedule_path() == "small_eviction"
+        for got, key in zip(a, ("eli", "ekc", "ebc")):
+            np.testing.assert_array_equal(got.cpu().numpy(), want[key], err_msg=key)
+    # two of the four sequences
     sub = [1, 3]
-    lh = st.num_layers * st.num_kv_heads
     ctx = ds.context_lens[:, sub].contiguous()
     hang = ds.hanging_token_count[sub].contiguous()
     offs_np = synth.kv_offsets(st.context_lens[:, sub], st.block_size)
     offs = torch.from_numpy(offs_np).to(DEV)
     n_sub = int(((st.context_lens[:, sub].astype(np.int64) + 15) // 16).sum()) * 16
+    ds.cm.schedule_path = 2
     b = ds.cm.schedule_evictions(sub, ds.seq_positions[sub].contiguous(), [evicted[i] for i in sub], ctx, hang, offs,
-                                 [st.protected[i] for i in sub], total_slots=n_sub, block_tables=ds.block_tables)
+                                 [st.protected[i] for i in sub], total_slots=n_sub)
     assert ds.cm.last_schedule_path() == "small_eviction"
+    ds.cm.schedule_path = 1
     c = ds.cm.schedule_evictions(sub, ds.seq_positions[sub].contiguous(), [evicted[i] for i in sub], ctx, hang, offs,
                                  [st.protected[i] for i in sub], total_slots=n_sub)
+    assert ds.cm.last_schedule_path() == "general"
     for x, y in zip(b, c):
         assert torch.equal(x, y)
 
 
-def test_block_tables_with_entries_outside_the_cache_fall_back():
-    """a caller's table naming blocks the cache does not have is never dereferenced: the
-    small-eviction schedule hands over to the general pipeline, which only reads the per-block
-    metadata, and the result is still the oracle's"""
-    st, evicted = _steady(3, 4, 16, 4, 512, 11)
-    want = oracle_pipeline(st, evicted, mode="per_sequence")
-    ds = hdev.upload(st, DEV, mode="per_sequence")
-    args = (list(st.seq_indices), ds.seq_positions, evicted, ds.context_lens, ds.hanging_token_count,
-            ds.evicted_kv_offsets, list(st.protected))
-    bad = ds.block_tables.clone()
-    bad[1, 2, 3, 5] = st.num_blocks + 7            # inside the head's chunk range
-    bad[0, 0, 0, 0] = 2 ** 31 - 1
-    a = ds.cm.schedule_evictions(*args, total_slots=st.total_slots, block_tables=bad)
-    assert ds.cm.last_schedule_path() == "small_eviction+fallback"
-    for got, key in zip(a, ("eli", "ekc", "ebc")):
-        np.testing.assert_array_equal(got.cpu().numpy(), want[key], err_msg=key)
+@pytest.mark.parametrize("path", [2, 3])
+@pytest.mark.parametrize("stride", [1, 2, 4, 8, 16, 64])
+@pytest.mark.parametrize("shape", ["perm", "decay", "oldest"])
+def test_sample_stride_never_changes_the_result(stride, shape, path):
+    """the pivots of the streaming schedule come from a sample of one physical block in `stride`;
+    whatever the sample says the records hold every key below the pivot, so the result is exact or
+    the flag is raised (and the general pipeline's result is exact).  Clustered metrics
+    (oldest-first: a head's lowest keys all sit in its first block) are the sample's worst case.
+    path 2: positions looked up for the candidates only (per_sequence mode); path 3: streamed."""
+    flagged = 0
+    for seed in range(3):
+        st, evicted = _steady(4, 4, 16, 3, 1024, 30 + seed, metric_shape=shape)
+        want = oracle_pipeline(st, evicted, mode="per_sequence")
+        ds = hdev.upload(st, DEV, mode="per_sequence")
+        ds.cm.schedule_path = path
+        ds.cm.sample_stride = stride
+        eli, ekc, ebc, cmi, cmc = hdev.schedule(ds, st, evicted)
+        how = ds.cm.last_schedule_path()
+        assert how.startswith("small_eviction")
+        flagged += how.endswith("+fallback")
+        for key, got in zip(KEYS, (eli, ekc, ebc, cmi, cmc)):
+            np.testing.assert_array_equal(got.cpu().numpy(), want[key], err_msg=f"{key} stride={stride} {shape} seed={seed}")
+    if shape == "perm" or stride == 1:
+        assert flagged == 0                       # unclustered metrics / a full sample never miss
+
+
+@pytest.mark.parametrize("path", [2, 3])
+@pytest.mark.parametrize("mode", ["per_sequence"])
+def test_overask_on_the_small_eviction_schedule(path, mode):
+    """asking for more chunks than a sequence has evictable ones (the reference silently
+    evicts fewer): with the positions looked up lazily nobody counted the evictable keys, the
+    records cannot list k thresholds and the general pipeline takes over; tiny heads whose every
+    key fits a record finish on their own when the keys were counted"""
+    st = synth.make_state(num_layers=2, num_kv_heads=2, block_size=16, seq_lens=[100, 60], seed=21, protected=20)
+    nblk = ((st.context_lens.astype(np.int64) + 15) // 16).sum(0).sum(-1)
+    for evicted in ([int(n) for n in nblk], [int(nblk[0]), 1], [0, int(nblk[1])], [int(nblk[0]) - 3, 2]):
+        want = oracle_pipeline(st, evicted, mode=mode)
+        got, how = _run(st, evicted, path, mode)
+        assert how.startswith("small_eviction")
+        for key in KEYS:
+            np.testing.assert_array_equal(got[key], want[key], err_msg=f"{key} {evicted} {how}")
+
+
+def test_missing_block_metadata_raises_the_fallback():
+    """a logical block of the batch that no physical block claims (its metadata row was detached;
+    outside what the reference defines): the streaming schedule counts the claims and hands over
+    to the general pipeline, which treats the chunk as not evictable -- one behaviour, whatever
+    the path"""
+    st, evicted = _steady(2, 4, 16, 2, 512, 13)
+    victim = int(st.block_tables[1, 1, 2, 3])
+    st.seq_index_by_block[victim] = -1
+    gen, how_gen = _run(st, evicted, 1, "per_sequence")
+    got, how = _run(st, evicted, 2, "per_sequence")
+    assert how_gen == "general" and how == "small_eviction+fallback"
+    for key in KEYS:
+        np.testing.assert_array_equal(got[key], gen[key], err_msg=key)
 
 
 @pytest.mark.parametrize("bs,hd", [(4, 8), (8, 64), (16, 128), (32, 128)])

@@ -253,14 +253,19 @@ def reshape_and_cache_kvc(
             float(k_scale), float(v_scale), _stream(key)))
 
 
+V1_DEAD_MESSAGE = ("schedule_cache_evictions (V1) is dead code in the reference; use "
+                   "vllm_kvcompress_amd.kvcompress.metrics.CompressionMetrics.schedule_evictions")
+
+
 def schedule_cache_evictions(*args, **kwargs):
     """reference vllm/_custom_ops.py:935-1006: the V1 CUDA scheduler.  It is dead code in
     the reference (vllm/kvcompress/scheduler.py:285 ``if False:``) and its wrapper
     dispatches to a namespace where the op is not registered; the live
-    path is ``CompressionMetrics.schedule_evictions``."""
-    raise NotImplementedError(
-        "schedule_cache_evictions (V1) is dead code in the reference; use "
-        "vllm_kvcompress_amd.kvcompress.metrics.CompressionMetrics.schedule_evictions")
+    path is ``CompressionMetrics.schedule_evictions``.  The dispatcher schemas
+    ``_C_kvc_ops::schedule_cache_evictions`` / ``truncate_cache_evictions``
+    (csrc/torch_bindings.cpp:374-394) are registered by ``torch_ops.register()`` and raise the
+    same message."""
+    raise NotImplementedError(V1_DEAD_MESSAGE)
 
 
 # ---------------------------------------------------------------------------------------

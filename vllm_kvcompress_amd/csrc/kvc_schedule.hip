@@ -27,11 +27,13 @@
 // seq_prepare_kernel for mode 0.
 #include "kvc_common.h"
 #include "../../include/kvc_mi355x.h"
+#include <atomic>
 
 namespace kvc {
 
 constexpr int RADIX = 256;
 
+struct SeqRec;
 struct SchedWs {
   uint32_t* keys;        // [N]      order-preserving metric keys, index off_g + lambda
   int32_t* chunk_phys;   // [N/bs]   physical block of logical chunk
@@ -44,10 +46,14 @@ struct SchedWs {
   int32_t* seq_k;        // [B]      chunks this sequence frees (k'), 0 = inactive
   int32_t* seq_tmp;      // [3B]     F (finite chunks), Cn (all chunks), offset
   // small-eviction schedule (section 7 below)
-  uint32_t* rec_key;     // [G,KREC] the KREC smallest keys of every head, ascending (canonical tie order)
-  uint32_t* rec_idx;     // [G,KREC] their logical slot indices
-  uint32_t* head_f;      // [G]      finite (evictable) keys of the head
-  uint32_t* seq_fcn;     // [2B]     per sequence: finite-threshold chunks, all chunks (accumulated by head_topk)
+  uint64_t* rec64;       // [G,KREC] per head: (key << 32 | physical slot) of every evictable key below the
+                         //          sequence's pivot; sorted ascending (canonical tie order) = the head's record
+  uint32_t* st_cnt;      // [G]      entries of that list (counts on beyond KREC: overflow)
+  uint32_t* st_def;      // [G]      masked / non-finite slots of the head's blocks
+  uint32_t* st_samp;     // [G]      sampled blocks of the head
+  uint32_t* st_claimed;  // [64 x 32] physical blocks that are logical blocks of the batch, sharded over 64 cache lines
+  struct SeqRec* st_seqrec;  // [B]  per sequence: position, protected window, pivot
+  uint32_t* head_fc;     // [2G]     per head: finite-threshold chunks, all chunks (stream_records)
   uint32_t* fallback;    // [1]      != 0: the small-eviction schedule could not finish exactly
   const uint32_t* gate;  // general-path kernels run only if gate == nullptr or *gate != 0
 };
@@ -501,30 +507,33 @@ __global__ __launch_bounds__(1024) void pick_round_kernel(kvc_schedule_params p,
 // ------------------------------------------------------------------ 5. per-head counts
 // chunks with threshold < T* are freed; chunks with threshold == T* are handed out in
 // (head, chunk) order until the sequence total is k'.           metrics.py:773-792
-__global__ __launch_bounds__(256) void finalize_heads_kernel(kvc_schedule_params p, SchedWs ws) {
-  if (gated_off(ws)) return;
-  __shared__ uint32_t wave_tot[4];
-  __shared__ uint32_t carry_s;
-  __shared__ uint32_t lt_total_s;
-  const int i = blockIdx.x;
+// (one workgroup of NW waves per sequence; wave_tot: NW words, carry_s / lt_total_s: one each)
+template <int NW>
+__device__ void finalize_body(const kvc_schedule_params& p, SchedWs& ws, int i, uint32_t* wave_tot,
+                              uint32_t* carry_s, uint32_t* lt_total_s) {
   const int LH = p.num_layers * p.num_kv_heads;
   const uint32_t bs = (uint32_t)p.block_size;
   const uint32_t k = (uint32_t)ws.seq_k[i];
   const int tid = threadIdx.x, lane = lane_id(), w = tid / WAVE;
   // pass 1: total of sure chunks
   uint32_t part = 0;
-  for (int lh = tid; lh < LH; lh += blockDim.x) {
+  for (int lh = tid; lh < LH; lh += NW * WAVE) {
     const int g = i * LH + lh;
     if (k) part += nchunks_freed(ws.less[g], (uint32_t)p.hanging_token_count[g], bs);
   }
   part = wave_reduce_sum(part);
+  __syncthreads();
   if (lane == 0) wave_tot[w] = part;
-  if (tid == 0) carry_s = 0;
+  if (tid == 0) *carry_s = 0;
   __syncthreads();
-  if (tid == 0) lt_total_s = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+  if (tid == 0) {
+    uint32_t t = 0;
+    for (int q = 0; q < NW; ++q) t += wave_tot[q];
+    *lt_total_s = t;
+  }
   __syncthreads();
-  const uint32_t need = k - (k ? lt_total_s : 0u);     // tie chunks still to hand out
-  for (int base = 0; base < LH; base += blockDim.x) {
+  const uint32_t need = k - (k ? *lt_total_s : 0u);     // tie chunks still to hand out
+  for (int base = 0; base < LH; base += NW * WAVE) {
     const int lh = base + tid;
     const int g = i * LH + lh;
     uint32_t n_lt = 0, e = 0, hang = 1;
@@ -541,7 +550,7 @@ __global__ __launch_bounds__(256) void finalize_heads_kernel(kvc_schedule_params
     __syncthreads();
     uint32_t woff = 0;
     for (int q = 0; q < w; ++q) woff += wave_tot[q];
-    const uint32_t excl = carry_s + woff + inc - e;
+    const uint32_t excl = *carry_s + woff + inc - e;
     if (lh < LH) {
       const uint32_t room = need > excl ? need - excl : 0u;
       const uint32_t n = n_lt + (e < room ? e : room);
@@ -549,8 +558,113 @@ __global__ __launch_bounds__(256) void finalize_heads_kernel(kvc_schedule_params
       p.evicted_kv_count[g] = n > 0 ? (int32_t)((n - 1) * bs + hang) : 0;
     }
     __syncthreads();
-    if (tid == blockDim.x - 1) carry_s = excl + e;
+    if (tid == NW * WAVE - 1) *carry_s = excl + e;
     __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void finalize_heads_kernel(kvc_schedule_params p, SchedWs ws) {
+  if (gated_off(ws)) return;
+  __shared__ uint32_t wave_tot[4];
+  __shared__ uint32_t carry_s, lt_total_s;
+  finalize_body<4>(p, ws, blockIdx.x, wave_tot, &carry_s, &lt_total_s);
+}
+
+// ------------------------------------------------------------------ 5a. scan + pick (+ totals, + counts) in one launch
+// One workgroup per sequence does what scan_round, (seq_totals, seq_prepare,) pick_round and -- in
+// the last round -- finalize_heads do in a launch each: its 16 waves scan the digit histograms of
+// the sequence's heads, the chunk counts per digit are summed in LDS (no [G,256] array), the digit
+// is picked and the heads' `less` / `eq` updated.  Round 0 also needs k': per sequence it is
+// min(k, finite-threshold chunks) -- what seq_prepare_body gives for mode 1 or a single sequence;
+// the reference's batch > 1 rule (mode 0) couples the sequences and keeps the separate launches.
+__global__ __launch_bounds__(1024) void scan_pick_kernel(kvc_schedule_params p, SchedWs ws, int round) {
+  if (gated_off(ws)) return;
+  __shared__ __attribute__((aligned(16))) uint32_t csum[16][RADIX];
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t carry_s, lt_total_s;
+  __shared__ int dstar_s;
+  __shared__ uint32_t k_s;
+  const int i = blockIdx.x, tid = threadIdx.x, lane = lane_id(), w = tid / WAVE;
+  const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
+  const int LH = p.num_layers * p.num_kv_heads;
+  const uint32_t bs = (uint32_t)p.block_size;
+  const bool active = round == 0 || ws.seq_k[i] != 0;
+  if (active) {
+    reinterpret_cast<uint4*>(csum[w])[lane] = make_uint4(0u, 0u, 0u, 0u);
+    // scan_round: a wave takes every 16th head, eight at a time (their loads, scans and stores
+    // are independent: with a single sequence this workgroup is alone on the chip and a round
+    // trip to the histograms -- last touched by atomics -- is what it waits for)
+    constexpr int SU = 8;
+    for (int lh0 = w; lh0 < LH; lh0 += 16 * SU) {
+      uint4 v[SU];
+      uint32_t less[SU], hang[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int lh = lh0 + 16 * u;
+        v[u] = make_uint4(0u, 0u, 0u, 0u); less[u] = 0; hang[u] = 1;
+        if (lh < LH) {                                 // wave-uniform
+          const int g = i * LH + lh;
+          v[u] = reinterpret_cast<uint4*>(ws.hist + (int64_t)g * RADIX)[lane];            // 4 bins per lane
+          less[u] = ws.less[g]; hang[u] = (uint32_t)p.hanging_token_count[g];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int lh = lh0 + 16 * u;
+        if (lh >= LH) break;                           // wave-uniform
+        const int g = i * LH + lh;
+        reinterpret_cast<uint4*>(ws.hist + (int64_t)g * RADIX)[lane] = make_uint4(0u, 0u, 0u, 0u);   // ready for the next round
+        v[u].y += v[u].x; v[u].z += v[u].y; v[u].w += v[u].z;
+        const uint32_t inc = wave_inclusive_scan(v[u].w);
+        const uint32_t ex = inc - v[u].w;
+        v[u].x += ex; v[u].y += ex; v[u].z += ex; v[u].w += ex;
+        reinterpret_cast<uint4*>(ws.cum + ((int64_t)round * G + g) * RADIX)[lane] = v[u];
+        uint4 c = reinterpret_cast<uint4*>(csum[w])[lane];
+        c.x += nchunks_freed(less[u] + v[u].x, hang[u], bs); c.y += nchunks_freed(less[u] + v[u].y, hang[u], bs);
+        c.z += nchunks_freed(less[u] + v[u].z, hang[u], bs); c.w += nchunks_freed(less[u] + v[u].w, hang[u], bs);
+        reinterpret_cast<uint4*>(csum[w])[lane] = c;
+      }
+    }
+    __syncthreads();
+    if (tid < RADIX) {                                 // chunks freed if the digit were d, over all heads
+      uint32_t t = 0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t += csum[q][tid];
+      csum[0][tid] = t;
+    }
+    if (tid == 0) dstar_s = 255;
+    __syncthreads();
+    if (round == 0 && tid == 0) {                      // seq_totals + seq_prepare, per sequence
+      const int kk = p.evicted_blocks_per_seq[i];
+      const uint32_t f = csum[0][255];                 // finite-threshold chunks
+      const uint32_t k = kk <= 0 ? 0u : ((uint32_t)kk < f ? (uint32_t)kk : f);
+      ws.seq_k[i] = (int32_t)k;
+      ws.seq_prefix[i] = 0;
+      k_s = k;
+    }
+    if (round != 0 && tid == 0) k_s = (uint32_t)ws.seq_k[i];
+    __syncthreads();
+    const uint32_t k = k_s;
+    if (k != 0) {                                      // pick_round
+      if (tid < RADIX) {
+        const uint32_t sd = csum[0][tid];
+        if (sd >= k && (tid == 0 || csum[0][tid - 1] < k)) dstar_s = tid;     // non-decreasing in d
+      }
+      __syncthreads();
+      const int ds = dstar_s;
+      if (tid == 0) ws.seq_prefix[i] = ((round == 0 ? 0u : ws.seq_prefix[i]) << 8) | (uint32_t)ds;
+      for (int h2 = tid; h2 < LH; h2 += blockDim.x) {
+        const int g = i * LH + h2;
+        const uint32_t* cum = ws.cum + ((int64_t)round * G + g) * RADIX;
+        const uint32_t below = ds > 0 ? cum[ds - 1] : 0u;
+        ws.less[g] += below;
+        if (round == 3) ws.eq[g] = cum[ds] - below;
+      }
+    }
+  }
+  if (round == 3) {
+    __syncthreads();                                   // (the heads' less / eq just written by this workgroup)
+    finalize_body<16>(p, ws, i, wave_tot, &carry_s, &lt_total_s);
   }
 }
 
@@ -766,25 +880,35 @@ __global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(kvc_schedule_p
 // Continual compression frees about one block per head and step, from thousands of short heads
 // (config 3: 65 536 heads of ~4 k slots).  The general pipeline above writes a key per slot and
 // then reads every key five times (four sequence-level digit rounds + the per-head select) to
-// evict 0.4 % of them.  Here the metrics are read ONCE and no key array exists:
-//   * chunk_table_kernel: block metadata -> physical block of every logical chunk (4 B / block);
-//   * head_topk_kernel: one wave per head gathers the head's metric / position rows through that
-//     table (64 B rows), turns them into keys on the fly, keeps the candidates below a pivot
-//     taken from a 128-key sample, sorts them in LDS and stores the KREC = 256 smallest
-//     (canonical tie order) as the head's record;
+// evict 0.4 % of them.  Here the metric store is read ONCE, in PHYSICAL block order -- a plain
+// coalesced stream -- and no key array, no chunk table exists:
+//   * stream_sample_kernel: a sample of the physical blocks (those whose index hashes to 0 modulo
+//     the stride; only their rows and metadata are touched), keys written to a dense per-head slot;
+//   * stream_pivot_kernel (one workgroup per sequence): a pivot P_i such that the sequence holds,
+//     with a wide margin, at least Tgt_i = k_i * bs + sum_g (hang_g - 1) evictable keys <= P_i --
+//     with that many the chunk thresholds <= P_i number at least k_i, whatever their spread over
+//     the heads (n_g = floor((R_g - hang_g) / bs) + 1 >= (R_g - hang_g + 1) / bs);
+//   * stream_collect_kernel: the one pass over metrics / (positions) / metadata: per block the keys
+//     are made on the fly, those <= P_i are queued in LDS and appended to their head's candidate
+//     list (one returning atomic per candidate, issued 64 at a time); blocks with masked slots
+//     add their number to the head's deficit (finite keys of a head = slots - deficit) -- or, when
+//     keys do not depend on positions and sequences not on each other (LAZY), the position rows
+//     are not streamed at all and only the candidates' positions are looked up;
+//   * stream_records_kernel (one wave per head): the list sorted by (key, physical slot) -- the
+//     canonical tie order -- is the head's record;
 //   * chunk thresholds are every bs-th entry of a record, so the sequence-level selection (one
-//     workgroup per sequence: a sort of the <= 256 / bs thresholds of each of its heads by
+//     workgroup per sequence: the k'-th smallest of the recorded thresholds of its heads by
 //     (threshold, head, chunk)) and the emission (the first cnt record entries, re-sorted by
 //     logical index) never touch the metrics again.
-// HBM: 1.25 B (metadata) + 8 B (metrics, positions) + 4 B (null padding of the output) per
-// candidate slot = the 12.75 B lower bound of SURVEY 8(d) + 0.5 B of records.
-// A record covers 256 / bs chunks of a head; if a sequence needs more from some head (its k-th
-// threshold reaches the end of a truncated record), a head's candidates overflow the LDS buffer
-// (e.g. all metrics tied) or a head is too long for the sample, `fallback` is raised and the
-// general pipeline -- enqueued behind, gated on that flag -- recomputes everything.  Chosen by the
-// host from kvc_schedule_params.max_evicted_blocks_hint (average <= 256 / bs / 8 blocks per head).
-
-constexpr int CAND_CAP = 1024;      // candidate (key, physical slot) pairs a wave keeps in LDS
+// HBM: 1 B (metadata) + 8 B (metrics, positions; 4 B when LAZY) + 4 B (null padding of the output)
+// per candidate slot = the 12.75 B lower bound of SURVEY 8(d) (LAZY: below it) + the sample.
+// Exactness never depends on the sample: a record holds EVERY evictable key <= P_i of its head,
+// every threshold it does not list is > P_i, so the selection is exact as soon as the records of a
+// sequence list k' thresholds.  If they do not (pivot too low), a head has more candidates than a
+// record holds (KREC; e.g. all metrics tied), or the per-block metadata does not cover every
+// logical block of the batch, `fallback` is raised and the general pipeline -- enqueued behind,
+// gated on that flag -- recomputes everything.  Chosen by the host from
+// kvc_schedule_params.max_evicted_blocks_hint (average <= 256 / bs / 8 blocks per head).
 
 // ascending bitonic sort of SZ (power of two >= 128) LDS elements by one wave
 template <typename T, int SZ>
@@ -803,215 +927,472 @@ __device__ void wave_bitonic_sort(T* a) {
     }
 }
 
-// physical block of every logical chunk of the selected sequences (the table build_keys also
-// fills); the tail workgroups clear the counters of the later passes
-__global__ __launch_bounds__(256) void chunk_table_kernel(kvc_schedule_params p, SchedWs ws, unsigned data_blocks,
-                                                          uint4* zero16, int64_t zero_vecs) {
-  if (blockIdx.x >= data_blocks) {
-    for (int64_t i = (int64_t)(blockIdx.x - data_blocks) * 256 + threadIdx.x; i < zero_vecs;
-         i += (int64_t)(gridDim.x - data_blocks) * 256)
-      zero16[i] = make_uint4(0u, 0u, 0u, 0u);
-    return;
-  }
-  const int64_t blk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (blk >= p.num_blocks) return;
-  const int s = p.seq_index_by_block[blk];
-  if (s < 0 || s >= p.seq_slot_len) return;
-  const int i = p.seq_slot_of_seq[s];
-  if (i < 0) return;
-  const int bs = p.block_size, L = p.num_layers, H = p.num_kv_heads, B = p.num_seqs;
-  const int l = p.layer_index_by_block[blk], h = p.head_index_by_block[blk];
-  const int lbn = p.logical_block_num_by_block[blk];
-  const int g = (i * L + l) * H + h;
-  const int ctx = p.context_lens[(l * B + i) * H + h];
-  if (lbn < 0 || lbn >= (ctx + bs - 1) / bs) return;       // not part of the head's slot range
-  ws.chunk_phys[p.evicted_kv_offsets[g] / bs + lbn] = (int32_t)blk;
+struct SeqRec { int32_t seq_pos, prot; uint32_t pivot_excl, pad; };   // candidates: key < pivot_excl
+constexpr int CLAIM_SHARDS = 64;     // counters of claimed blocks, 128 B apart
+
+__device__ __forceinline__ uint32_t strat_hash(uint32_t g, uint32_t j) {
+  uint32_t x = (g * 0x9E3779B1u) ^ ((j + 0x7F4A7C15u) * 0x85EBCA77u);
+  x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
+  return x;
 }
 
-// one wave per head: record = the KREC smallest (key, physical slot) pairs, ascending.
-// LDS per wave: CAND_CAP x 8 B candidates + 128 sorted sample keys
-template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void head_topk_kernel(kvc_schedule_params p, SchedWs ws) {
-  __shared__ __attribute__((aligned(16))) uint64_t cand_s[WAVES][CAND_CAP];
-  __shared__ uint32_t samp_s[WAVES][4 * WAVE];
+// per-block metadata of 64 consecutive blocks, one per lane, all four loads requested together
+struct BlockMeta { int s, l, h, lbn; };
+__device__ __forceinline__ BlockMeta load_meta(const kvc_schedule_params& p, int64_t blk, bool in) {
+  BlockMeta m{-1, 0, 0, 0};
+  if (in) {
+    m.s = p.seq_index_by_block[blk]; m.l = p.layer_index_by_block[blk];
+    m.h = p.head_index_by_block[blk]; m.lbn = p.logical_block_num_by_block[blk];
+  }
+  return m;
+}
+// The sample: every physical block whose index hashes to 0 mod 2^sshift -- no pass over the
+// metadata, and no pattern of the allocator or of the logical order can alias with it.  A wave
+// walks 64 block indices per step (arithmetic only), queues the chosen ones in LDS and works them
+// off 64 / (BS / 4) at a time, BS / 4 lanes per block: metadata -> owner -> a slot in the head's
+// sample (one returning atomic per block: keys[off_g + slot * bs ...], at most one slot per block
+// of the head) -> metric / position row -> keys.
+__device__ __forceinline__ bool block_sampled(uint32_t blk, uint32_t smask) {
+  return (strat_hash(blk, 0x51ED270Bu) & smask) == 0u;
+}
+
+template <int BS>
+__global__ __launch_bounds__(256) void stream_sample_kernel(kvc_schedule_params p, SchedWs ws, int sshift) {
+  constexpr int LPB = BS / 4, BPD = 64 / LPB;        // lanes per block, blocks per drain
+  constexpr int QCAP = 64 + BPD;
+  __shared__ uint32_t q_blk[4][QCAP];
+  const int lane = lane_id(), w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int64_t wave = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
+  const int L = p.num_layers, H = p.num_kv_heads;
+  const uint32_t smask = (1u << sshift) - 1u;
+  int qn = 0;
+  auto drain = [&](int n) {                          // pops the top n (<= BPD) queued blocks
+    wave_lds_sync();
+    const int e = qn - n + lane / LPB;
+    bool ok = lane / LPB < n;
+    const int64_t blk = ok ? (int64_t)q_blk[w][e] : 0;
+    const BlockMeta mt = load_meta(p, blk, ok);
+    ok = ok && mt.s >= 0 && mt.s < p.seq_slot_len;
+    int i = p.seq_slot_of_seq[ok ? mt.s : 0];
+    ok = ok && i >= 0 && mt.l >= 0 && mt.l < L && mt.h >= 0 && mt.h < H && mt.lbn >= 0;
+    const int l = ok ? mt.l : 0, h = ok ? mt.h : 0;
+    if (!ok) i = 0;
+    const int g = (i * L + l) * H + h;
+    const int ctx = p.context_lens[(l * p.num_seqs + i) * H + h];
+    const int64_t off = p.evicted_kv_offsets[g];
+    const int seq_pos = p.seq_positions[i], prot = p.num_protected[i];
+    const float4 m = reinterpret_cast<const float4*>(p.metrics + blk * BS)[lane % LPB];
+    const int4 q = reinterpret_cast<const int4*>(p.token_positions + blk * BS)[lane % LPB];
+    ok = ok && mt.lbn < (ctx + BS - 1) / BS;         // (else: not a logical block of its head)
+    uint32_t slot = 0;
+    if (ok && lane % LPB == 0) slot = atomicAdd(&ws.st_samp[g], 1u);
+    slot = (uint32_t)__shfl((int)slot, lane & ~(LPB - 1), 64);
+    if (ok) {
+      uint4 k;
+      k.x = slot_key(p, m.x, q.x, seq_pos, prot, l, h);
+      k.y = slot_key(p, m.y, q.y, seq_pos, prot, l, h);
+      k.z = slot_key(p, m.z, q.z, seq_pos, prot, l, h);
+      k.w = slot_key(p, m.w, q.w, seq_pos, prot, l, h);
+      reinterpret_cast<uint4*>(ws.keys + off + (int64_t)slot * BS)[lane % LPB] = k;
+    }
+    qn -= n;
+    wave_lds_sync();
+  };
+  for (int64_t b0 = wave * 64; b0 < p.num_blocks; b0 += nwaves * 64) {
+    const int64_t blk = b0 + lane;
+    const bool take = blk < p.num_blocks && block_sampled((uint32_t)blk, smask);
+    const unsigned long long bal = __ballot(take);
+    if (bal) {                                       // wave-uniform
+      if (take) q_blk[w][qn + __popcll(bal & ((1ull << lane) - 1ull))] = (uint32_t)blk;
+      qn += __popcll(bal);
+      while (qn >= BPD) drain(BPD);
+    }
+  }
+  while (qn > 0) drain(min(qn, BPD));
+}
+
+// one workgroup per sequence: the rho-th smallest evictable key of its sample, rho = the sample's
+// share of Tgt + 12 sigma + 8 (sigma^2 = that share: a binomial count, taken twice over for keys
+// that cluster by block); a sample that is everything (stride 1) gives the Tgt-th key itself.
+// The heads' samples (st_samp[g] blocks at keys[off_g ...]) form one flat key space through a
+// prefix sum in LDS; a thread finds the head of its flat index by bisection.  A sample of up to
+// PIV_R x 1024 keys is read ONCE into registers and the four digit rounds of the select run on
+// the registers; a longer one (a sequence far longer than the batch average) is re-read from L2
+// every round.
+constexpr int PIV_R = 48;
+constexpr int PIV_MAXLH = 1024;                      // heads per sequence (the host checked)
+__global__ __launch_bounds__(1024) void stream_pivot_kernel(kvc_schedule_params p, SchedWs ws, int sshift) {
+  __shared__ __attribute__((aligned(16))) uint32_t hist[RADIX];
+  __shared__ uint32_t bc[4];
+  __shared__ uint32_t tot_s[3];                      // blocks, sampled blocks, sum(hang - 1)
+  __shared__ uint32_t fin_s;
+  __shared__ uint32_t pre_s[PIV_MAXLH + 1];          // exclusive prefix of the heads' sample lengths (keys)
+  __shared__ uint32_t wsum_s[16];
+  const int i = blockIdx.x, tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+  const int B = p.num_seqs, H = p.num_kv_heads, LH = p.num_layers * H, bs = p.block_size;
+  if (tid < 3) tot_s[tid] = 0;
+  if (tid == 0) fin_s = 0;
+  __syncthreads();
+  {
+    uint32_t nb = 0, ns = 0, hs = 0;
+    if (tid < LH) {                                  // LH <= 1024 = blockDim
+      const int ctx = p.context_lens[((tid / H) * B + i) * H + (tid % H)];
+      const uint32_t nblk = (uint32_t)((ctx + bs - 1) / bs);
+      if (nblk) {
+        ns = ws.st_samp[i * LH + tid];
+        nb = nblk; hs = (uint32_t)p.hanging_token_count[i * LH + tid] - 1u;
+      }
+    }
+    // block-wide exclusive scan of ns * bs -> pre_s
+    const uint32_t len = ns * (uint32_t)bs;
+    const uint32_t inc = wave_inclusive_scan(len);
+    if (lane == WAVE - 1) wsum_s[w] = inc;
+    nb = wave_reduce_sum(nb); const uint32_t nss = wave_reduce_sum(ns); hs = wave_reduce_sum(hs);
+    if (lane == 0) { atomicAdd(&tot_s[0], nb); atomicAdd(&tot_s[1], nss); atomicAdd(&tot_s[2], hs); }
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int q = 0; q < w; ++q) woff += wsum_s[q];
+    if (tid < LH) pre_s[tid] = woff + inc - len;
+    if (tid == LH - 1) pre_s[LH] = woff + inc;
+  }
+  __syncthreads();
+  const uint32_t nb = tot_s[0], ns = tot_s[1], hs = tot_s[2], n_keys = pre_s[LH];
+  const int k = p.evicted_blocks_per_seq[i];
+  SeqRec rec;
+  rec.seq_pos = p.seq_positions[i]; rec.prot = p.num_protected[i]; rec.pivot_excl = 0u; rec.pad = 0u;
+  // flat index x < n_keys -> address in the key scratch
+  auto locate = [&](uint32_t x) {
+    int lo = 0, hi = LH;                             // pre_s[lo] <= x < pre_s[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (pre_s[mid] <= x) lo = mid; else hi = mid;
+    }
+    return (int64_t)p.evicted_kv_offsets[i * LH + lo] + (x - pre_s[lo]);
+  };
+  if (k > 0 && nb > 0) {
+    const double tgt = (double)k * bs + (double)hs;
+    double rho = tgt;
+    if (sshift > 0) {
+      const double x = tgt * (double)ns / (double)nb;
+      rho = ceil(x + 12.0 * sqrt(x) + 8.0);
+    }
+    if (n_keys == 0u) {
+      rec.pivot_excl = KEY_INF;                      // an empty sample: every evictable key is a candidate
+    } else if (n_keys <= (uint32_t)PIV_R * 1024u) {
+      // ---- the sample in registers
+      uint32_t key[PIV_R];
+#pragma unroll
+      for (int r = 0; r < PIV_R; ++r) {
+        const uint32_t x = (uint32_t)r * 1024u + (uint32_t)tid;
+        key[r] = 0xFFFFFFFFu;
+        if ((uint32_t)r * 1024u < n_keys) {          // (uniform)
+          if (x < n_keys) key[r] = ws.keys[locate(x)];
+        }
+      }
+      uint32_t prefix = 0, rank = 0;
+      bool all = false;
+      for (int round = 0; round < 4; ++round) {
+        const int shift = 24 - 8 * round;
+        if (tid < RADIX) hist[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < PIV_R; ++r) {
+          if ((uint32_t)r * 1024u >= n_keys) break;  // (uniform)
+          const bool valid = key[r] < KEY_INF && (round == 0 || (key[r] >> (shift + 8)) == prefix);
+          hist_add(hist, valid, (key[r] >> shift) & 0xFFu);
+        }
+        __syncthreads();
+        if (tid < WAVE) {                            // 256-bin inclusive scan, 4 bins per lane
+          uint4 q = reinterpret_cast<uint4*>(hist)[tid];
+          q.y += q.x; q.z += q.y; q.w += q.z;
+          const uint32_t inc = wave_inclusive_scan(q.w);
+          const uint32_t ex = inc - q.w;
+          uint32_t rk = rank;
+          if (round == 0) {                          // all evictable keys of the sample = the last bin's count
+            const uint32_t fin = (uint32_t)__shfl((int)inc, WAVE - 1, 64);
+            rk = (fin == 0u || rho >= (double)fin) ? 0u : (uint32_t)rho;
+            if (tid == 0) bc[2] = rk;
+          }
+          const uint32_t c[4] = {q.x + ex, q.y + ex, q.z + ex, q.w + ex};
+          uint32_t prev = ex;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            if (prev < rk && rk <= c[t]) { bc[0] = (uint32_t)tid * 4u + (uint32_t)t; bc[1] = prev; }
+            prev = c[t];
+          }
+        }
+        __syncthreads();
+        if (round == 0) {
+          rank = bc[2];
+          if (rank == 0u) { all = true; break; }     // (uniform) every evictable key is a candidate
+        }
+        prefix = (prefix << 8) | bc[0];
+        rank -= bc[1];
+        __syncthreads();
+      }
+      rec.pivot_excl = all ? KEY_INF : prefix + 1u;  // prefix < KEY_INF
+    } else {
+      // ---- a sample too long for the registers: every round re-reads it
+      auto pred = [&](int x) { return ws.keys[locate((uint32_t)x)] < KEY_INF; };
+      auto val = [&](int x) { return ws.keys[locate((uint32_t)x)]; };
+      const int n = (int)n_keys;
+      uint32_t fin = 0;
+      for (int x = tid; x < n; x += blockDim.x) fin += pred(x) ? 1u : 0u;
+      fin = wave_reduce_sum(fin);
+      if (lane == 0 && fin) atomicAdd(&fin_s, fin);
+      __syncthreads();
+      fin = fin_s;
+      if (fin == 0 || rho >= (double)fin) {
+        rec.pivot_excl = KEY_INF;                    // every evictable key is a candidate
+      } else {
+        uint32_t P, r2, e2;
+        block_radix_select(hist, bc, n, (uint32_t)rho, val, pred, P, r2, e2);
+        rec.pivot_excl = P + 1u;                     // P < KEY_INF
+      }
+    }
+  }
+  if (tid == 0) ws.st_seqrec[i] = rec;
+}
+
+// THE pass: metrics / positions / per-block metadata in physical order.  BS/4 lanes own a block's
+// row (16 B of each store per lane); the metadata of the 64 blocks of a wave iteration is loaded
+// once, coalesced, and handed to the row lanes by shuffles.  DENSE: the rows are requested before
+// the metadata is looked at (most blocks belong to the batch); otherwise only the rows of the
+// batch's blocks are touched (an engine-sized cache holding a small batch).
+// LAZY: the position rows are not streamed at all.  A key needs its position only for the mask
+// (no averaging, no position bias), and only the ~1 % of the slots whose METRIC lies below the
+// pivot can become candidates: their positions are fetched when the queue is drained (one 4 B
+// gather per entry, masked ones dropped there).  What is lost is the count of evictable keys per
+// head, which only says whether a sequence can free the k chunks it was asked for -- and that the
+// records answer themselves: k listed thresholds exist, or the flag is raised.  (The reference's
+// batch > 1 rule counts the inf thresholds of every sequence and keeps the full pass.)
+// 8 B + 1 B of the 12.75 B per candidate slot are then 4 B + 1 B.
+template <int BS, bool DENSE, bool LAZY>
+__global__ __launch_bounds__(256) void stream_collect_kernel(kvc_schedule_params p, SchedWs ws) {
+  constexpr int LPB = BS / 4;                        // lanes per block
+  constexpr int BPL = 64 / LPB;                      // blocks per wave load
+  constexpr int U = LPB >= 4 ? 4 : 64 / BPL;         // wave loads per iteration: 64 blocks (bs 8: 2 x 32)
+  constexpr int BPW = BPL * U;
+  static_assert(BPW <= 64, "one metadata load covers the iteration's blocks");
+  __shared__ uint32_t qk[4][128], qs[4][128], qg[4][128];
+  __shared__ int32_t ql[LAZY ? 4 : 1][128];          // LAZY: highest evictable position of the entry's sequence
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const int lane = lane_id(), w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int64_t wave = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
+  const int L = p.num_layers, H = p.num_kv_heads;
+  unsigned long long* lists = reinterpret_cast<unsigned long long*>(ws.rec64);
+  uint32_t claimed = 0;
+  int qn = 0;
+  auto drain = [&](int n) {                          // pops the top n (<= 64) queue entries
+    wave_lds_sync();
+    if (lane < n) {
+      const int e = qn - n + lane;
+      const uint32_t g = qg[w][e];
+      bool in_range = true;
+      if constexpr (LAZY) {                            // metrics.py:539-544, for the few that matter
+        const int tp = p.token_positions[qs[w][e]];
+        in_range = tp <= ql[w][e] && tp >= p.num_sinks;
+      }
+      if (in_range) {
+        const uint32_t pos = atomicAdd(&ws.st_cnt[g], 1u);
+        if (pos < (uint32_t)KREC) lists[(int64_t)g * KREC + pos] = ((unsigned long long)qk[w][e] << 32) | qs[w][e];
+      }
+    }
+    qn -= n;
+    wave_lds_sync();
+  };
+  for (int64_t b0 = wave * BPW; b0 < p.num_blocks; b0 += nwaves * BPW) {
+    f32x4 m[U];
+    i32x4 q[U];
+    auto load_rows = [&](unsigned long long want) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int src = u * BPL + lane / LPB;
+        int64_t blk = b0 + src;
+        if (blk >= p.num_blocks) blk = p.num_blocks - 1;
+        if (DENSE || ((want >> src) & 1ull)) {
+          m[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.metrics + blk * BS) + (lane % LPB));
+          if constexpr (!LAZY)
+            q[u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(p.token_positions + blk * BS) + (lane % LPB));
+          else
+            q[u] = i32x4{0, 0, 0, 0};
+        } else {
+          m[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          q[u] = i32x4{0, 0, 0, 0};
+        }
+      }
+    };
+    if constexpr (DENSE) load_rows(~0ull);
+    const int64_t mb = b0 + lane;
+    const BlockMeta mt = load_meta(p, mb, lane < BPW && mb < p.num_blocks);
+    bool ok = mt.s >= 0 && mt.s < p.seq_slot_len;
+    if constexpr (!DENSE) { if (__ballot(ok) == 0ull) continue; }   // wave-uniform: nothing of the batch here
+    int i = p.seq_slot_of_seq[ok ? mt.s : 0];
+    ok = ok && i >= 0 && mt.l >= 0 && mt.l < L && mt.h >= 0 && mt.h < H;
+    const int l = ok ? mt.l : 0, h = ok ? mt.h : 0;
+    if (!ok) i = 0;
+    const int ctx = p.context_lens[(l * p.num_seqs + i) * H + h];
+    const SeqRec r = ws.st_seqrec[i];
+    ok = ok && mt.lbn >= 0 && mt.lbn < (ctx + BS - 1) / BS;
+    const unsigned long long okm = __ballot(ok);
+    if (okm == 0ull) continue;                       // wave-uniform
+    claimed += (uint32_t)__popcll(okm);
+    if constexpr (!DENSE) load_rows(okm);
+    const int g = ok ? (i * L + l) * H + h : -1;
+    const int seq_pos = r.seq_pos, prot = r.prot;
+    const uint32_t pex = r.pivot_excl;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int src = u * BPL + lane / LPB;
+      const int gg = __shfl(g, src, 64);
+      const int spp = __shfl(seq_pos, src, 64), prr = __shfl(prot, src, 64);
+      const uint32_t pvv = (uint32_t)__shfl((int)pex, src, 64);
+      int ll = 0, hh = 0;
+      if (p.bias != nullptr) { ll = __shfl(l, src, 64); hh = __shfl(h, src, 64); }
+      const float mm[4] = {m[u].x, m[u].y, m[u].z, m[u].w};
+      const int qq[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+      const uint32_t slot0 = (uint32_t)((b0 + src) * BS + (lane % LPB) * 4);
+      int ninf = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t key = LAZY ? float_to_key(mm[k]) : slot_key(p, mm[k], qq[k], spp, prr, ll, hh);
+        ninf += (gg >= 0 && key >= KEY_INF) ? 1 : 0;
+        const bool c = gg >= 0 && key < pvv;         // (pvv <= KEY_INF)
+        const unsigned long long bal = __ballot(c);
+        if (bal) {                                   // wave-uniform
+          if (c) {
+            const int pos = qn + __popcll(bal & ((1ull << lane) - 1ull));
+            qk[w][pos] = key; qs[w][pos] = slot0 + (uint32_t)k; qg[w][pos] = (uint32_t)gg;
+            if constexpr (LAZY) ql[w][pos] = spp - prr;
+          }
+          qn += __popcll(bal);
+          if (qn >= 64) drain(64);
+        }
+      }
+      if constexpr (!LAZY) {
+        // masked / non-finite slots of the block (its LPB lanes are adjacent)
+#pragma unroll
+        for (int d = 1; d < LPB; d <<= 1) ninf += __shfl_xor(ninf, d, 64);
+        if (lane % LPB == 0 && ninf > 0) atomicAdd(&ws.st_def[gg], (uint32_t)ninf);
+      }
+    }
+  }
+  if (qn > 0) drain(qn);
+  // blocks that are logical blocks of the batch (every one must be there, else fallback): one
+  // atomic per workgroup, on one of CLAIM_SHARDS counters a cache line apart (a single word takes
+  // ~12 ns per atomic: 16 k waves on it would outlast the whole pass)
+  __shared__ uint32_t claimed_s;
+  if (threadIdx.x == 0) claimed_s = 0;
+  __syncthreads();
+  if (lane == 0 && claimed) atomicAdd(&claimed_s, claimed);
+  __syncthreads();
+  if (threadIdx.x == 0 && claimed_s) atomicAdd(&ws.st_claimed[(blockIdx.x % CLAIM_SHARDS) * 32], claimed_s);
+}
+
+// ascending sort of one 64-bit value per lane across the wave (bitonic, shuffles only)
+__device__ __forceinline__ uint64_t wave_sort64(uint64_t v) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int k = 2; k <= WAVE; k <<= 1)
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)v, j, 64);
+      const uint32_t ohi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), j, 64);
+      const uint64_t o = ((uint64_t)ohi << 32) | olo;
+      const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+      v = (lower == up) ? (v < o ? v : o) : (v > o ? v : o);
+    }
+  return v;
+}
+
+// The candidate list sorted by (key, physical slot) is the head's record.  A wave takes HPW
+// consecutive heads at once (their counts, lists and sorts are independent: one round trip and
+// interleaved shuffles instead of HPW of each); lists beyond 64 entries are sorted in LDS.
+template <int WAVES, int HPW>
+__global__ __launch_bounds__(64 * WAVES) void stream_records_kernel(kvc_schedule_params p, SchedWs ws, int lazy) {
+  __shared__ __attribute__((aligned(16))) uint64_t sort_s[WAVES][KREC];
   const int lane = lane_id();
   const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int L = p.num_layers, H = p.num_kv_heads, B = p.num_seqs;
   const int G = B * L * H;
-  const int g = blockIdx.x * WAVES + w;
-  if (g >= G) return;
-  uint64_t* cand = cand_s[w];
-  uint32_t* samp = samp_s[w];
-  const int bs = p.block_size;                       // 8, 16 or 32 (host)
-  const int bs_shift = 31 - __builtin_clz(bs);
-  const int i_seq = g / (L * H), l = (g / H) % L, h = g % H;
-  const int64_t base = p.evicted_kv_offsets[g];
-  const int64_t end = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : p.total_slots;
-  const int n = (int)(end - base);
-  const int nchunks = n / bs;
-  const int ctx = p.context_lens[(l * B + i_seq) * H + h];
-  const int seq_pos = p.seq_positions[i_seq], prot = p.num_protected[i_seq];
-  const uint32_t hang = (uint32_t)p.hanging_token_count[g];
-  const int bt_row = p.block_tables != nullptr ? p.seq_index_of_slot[i_seq] : 0;
-  if (p.block_tables != nullptr && (nchunks > p.block_tables_width || bt_row < 0 || bt_row >= p.max_num_seqs)) {
-    if (lane == 0) atomicOr(ws.fallback, 1u);        // inconsistent caller state: the general pipeline
-    return;                                          // (which reads the per-block metadata only) decides
+  const int g0 = (blockIdx.x * WAVES + w) * HPW;
+  if (g0 >= G) return;
+  const int bs = p.block_size;
+  if (g0 == 0) {                                     // a logical block of the batch has no physical block?
+    const uint32_t c = wave_reduce_sum(ws.st_claimed[lane * 32]);
+    static_assert(CLAIM_SHARDS == WAVE, "one shard per lane");
+    if (lane == 0 && (int64_t)c != p.total_slots / bs) atomicOr(ws.fallback, 1u);
   }
-  // physical block of every logical chunk: the caller's block table if it passed one, else the
-  // table chunk_table_kernel built from the per-block metadata
-  const int32_t* cphys = p.block_tables != nullptr
-      ? p.block_tables + (((int64_t)l * p.max_num_seqs + bt_row) * H + h) * p.block_tables_width
-      : ws.chunk_phys + base / bs;
-  // a caller's table may name blocks the cache does not have: never dereferenced, and the general
-  // pipeline (per-block metadata only) takes over
-  bool bad_entry = false;
-  auto table_entry = [&](int v) {
-    if (v >= (int)p.num_blocks || (v < 0 && p.block_tables != nullptr)) { bad_entry = true; return -1; }
-    return v;
-  };
-  // null padding of the head's output segment (emit_topk overwrites its first cnt entries)
-  if (!(p.lean & 1)) {
-    typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
-    i32x4* o4 = reinterpret_cast<i32x4*>(p.evicted_logical_indices + base);
-    const i32x4 nv = {p.null_value, p.null_value, p.null_value, p.null_value};
-    for (int i = lane; i < n / 4; i += WAVE) __builtin_nontemporal_store(nv, o4 + i);
-  }
-  // ---- pivot: heads that fit the candidate buffer take every evictable key; longer ones the
-  // rank of a 256-key sample (four slots of each of 64 evenly spaced chunks) that leaves about
-  // 1.6 x KREC candidates
-  constexpr int NSAMP = 4 * WAVE;
-  uint32_t pivot = KEY_INF - 1u;
-  int rank = NSAMP - 1;
-  if (n > CAND_CAP) {
-    const int phys = table_entry(cphys[(int)((int64_t)lane * nchunks / WAVE)]);
-    float sm[4];
-    int sq[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      sm[k] = 0.f; sq[k] = 0;
-      if (phys >= 0) {                               // (phys < 0: nobody claimed the chunk)
-        const int64_t sl = (int64_t)phys * bs + (lane * 5 + k * (bs / 4)) % bs;
-        sm[k] = p.metrics[sl];
-        sq[k] = p.token_positions[sl];
-      }
+  // lane q < HPW looks after head g0 + q: finite keys -> finite-threshold chunks of the head
+  uint32_t myC = 0;
+  if (lane < HPW && g0 + lane < G) {
+    const int g = g0 + lane;
+    const int i_seq = g / (L * H), l = (g / H) % L, h = g % H;
+    const int ctx = p.context_lens[(l * B + i_seq) * H + h];
+    const uint32_t nblk = (uint32_t)((ctx + bs - 1) / bs);
+    myC = ws.st_cnt[g];
+    if (!lazy) {                                     // (lazy: nobody counted the masked slots, nobody needs them)
+      const uint32_t F = nblk * (uint32_t)bs - ws.st_def[g];
+      ws.head_fc[g] = nchunks_freed(F, (uint32_t)p.hanging_token_count[g], (uint32_t)bs);   // finite-threshold chunks
+      ws.head_fc[G + g] = nblk;                                                              // all chunks
     }
+    if (myC > (uint32_t)KREC) atomicOr(ws.fallback, 1u);
+  }
+  uint32_t C[HPW];
+  uint64_t v[HPW];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      samp[k * WAVE + lane] = phys >= 0 ? slot_key(p, sm[k], sq[k], seq_pos, prot, l, h) : 0xFFFFFFFFu;
+  for (int q = 0; q < HPW; ++q) {
+    C[q] = (uint32_t)__shfl((int)myC, q, 64);
+    v[q] = ~0ull;
+    if (C[q] > 1u && C[q] <= (uint32_t)WAVE && (uint32_t)lane < C[q]) v[q] = ws.rec64[(int64_t)(g0 + q) * KREC + lane];
+  }
+#pragma unroll
+  for (int q = 0; q < HPW; ++q)
+    if (C[q] > 1u && C[q] <= (uint32_t)WAVE) v[q] = wave_sort64(v[q]);          // wave-uniform condition
+#pragma unroll
+  for (int q = 0; q < HPW; ++q)
+    if (C[q] > 1u && C[q] <= (uint32_t)WAVE && (uint32_t)lane < C[q]) ws.rec64[(int64_t)(g0 + q) * KREC + lane] = v[q];
+#pragma unroll
+  for (int q = 0; q < HPW; ++q) {
+    if (C[q] <= (uint32_t)WAVE || C[q] > (uint32_t)KREC) continue;              // wave-uniform
+    uint64_t* rec = ws.rec64 + (int64_t)(g0 + q) * KREC;
+    uint64_t* a = sort_s[w];
+    const int SZ = C[q] <= 128u ? 128 : 256;
     wave_lds_sync();
-    wave_bitonic_sort<uint32_t, NSAMP>(samp);
-    rank = (int)((int64_t)NSAMP * (KREC + KREC * 5 / 8) / n);
-    rank = rank < 4 ? 4 : (rank > NSAMP - 1 ? NSAMP - 1 : rank);
-    pivot = samp[rank];
-    if (pivot >= KEY_INF) pivot = KEY_INF - 1u;
-  }
-  // ---- gather pass(es): metric / position rows through the chunk table, keys on the fly,
-  // candidates (key <= pivot) compacted into LDS.  16 row pairs are requested before the first
-  // one is used (a wave has one head: the round trips, not the bytes, are what it waits for).
-  constexpr int UB = 16;
-  uint32_t F = 0, C = 0;
-  for (int attempt = 0;; ++attempt) {
-    F = 0; C = 0;
-    int my_phys = lane < nchunks ? table_entry(cphys[lane]) : -1;
-    for (int c0 = 0; c0 < nchunks; c0 += WAVE) {     // groups of 64 chunks
-      const int gch = min(WAVE, nchunks - c0);
-      const int iters = (gch * bs + WAVE - 1) / WAVE;
-      const int cnext = c0 + WAVE + lane;
-      const int next_phys = cnext < nchunks ? table_entry(cphys[cnext]) : -1;
-      for (int ib = 0; ib < iters; ib += UB) {
-        // branch-free on purpose: with control flow between the loads the compiler drains the
-        // whole queue (vmcnt(0)) in front of every shuffle, one round trip per iteration
-        float m[UB];
-        int q[UB], ph[UB];
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          const int sidx = (ib + u) * WAVE + lane;   // slot inside this group of chunks
-          const int cl = sidx >> bs_shift;
-          const int pv = __shfl(my_phys, cl & (WAVE - 1), 64);
-          ph[u] = (ib + u < iters && cl < gch) ? pv : -1;
-        }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          const int sidx = (ib + u) * WAVE + lane;
-          const int64_t sl = (int64_t)(ph[u] < 0 ? 0 : ph[u]) * bs + (sidx & (bs - 1));
-          m[u] = p.metrics[sl];
-          q[u] = p.token_positions[sl];
-        }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          const int sidx = (ib + u) * WAVE + lane;
-          const uint32_t k0 = slot_key(p, m[u], q[u], seq_pos, prot, l, h);
-          const uint32_t key = ph[u] >= 0 ? k0 : 0xFFFFFFFFu;          // (phys < 0: nobody claimed the chunk)
-          F += (uint32_t)__popcll(__ballot(key < KEY_INF));
-          const bool sel = key <= pivot && key < KEY_INF;
-          const unsigned long long bal = __ballot(sel);
-          const uint32_t pos = C + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-          if (sel && pos < (uint32_t)CAND_CAP)
-            cand[pos] = ((uint64_t)key << 32) | ((uint32_t)ph[u] * (uint32_t)bs + (uint32_t)(sidx & (bs - 1)));
-          C += (uint32_t)__popcll(bal);
-        }
-      }
-      my_phys = next_phys;
-    }
-    const uint32_t need = F < (uint32_t)KREC ? F : (uint32_t)KREC;
-    if (C >= need && C <= (uint32_t)CAND_CAP) break;
-    // the sample misjudged this head: too few candidates -> twice the rank, overflow -> half of it
-    // (rows now come from L2).  All metrics tied, or four misses: the general pipeline takes over.
-    const bool over = C > (uint32_t)CAND_CAP;
-    if (attempt >= 3 || (over && rank <= 1) || (!over && rank >= NSAMP - 1)) {
-      if (lane == 0) atomicOr(ws.fallback, 1u);
-      return;
-    }
-    rank = over ? rank / 2 : (rank * 2 < NSAMP - 1 ? rank * 2 : NSAMP - 1);
-    pivot = (rank >= NSAMP - 1 || n <= CAND_CAP) ? KEY_INF - 1u : samp[rank];
-    if (pivot >= KEY_INF) pivot = KEY_INF - 1u;
-  }
-  if (__ballot(bad_entry) != 0ull) {
-    if (lane == 0) atomicOr(ws.fallback, 1u);
-    return;
-  }
-  // ---- exact part: sort the candidates by (key, physical slot), keep the first KREC
-  wave_lds_sync();
-  const int SZ = C <= 256 ? 256 : (C <= 512 ? 512 : 1024);
-  for (int j = (int)C + lane; j < SZ; j += WAVE) cand[j] = ~0ull;
-  wave_lds_sync();
-  if (SZ == 256) wave_bitonic_sort<uint64_t, 256>(cand);
-  else if (SZ == 512) wave_bitonic_sort<uint64_t, 512>(cand);
-  else wave_bitonic_sort<uint64_t, 1024>(cand);
-  for (int j = lane; j < KREC; j += WAVE) {
-    const uint64_t e = cand[j];
-    uint32_t key = 0xFFFFFFFFu, idx = 0xFFFFFFFFu;
-    if (e != ~0ull) {
-      const uint32_t fk = (uint32_t)e;
-      key = (uint32_t)(e >> 32);
-      idx = (uint32_t)p.logical_block_num_by_block[fk / (uint32_t)bs] * (uint32_t)bs + fk % (uint32_t)bs;
-    }
-    ws.rec_key[(int64_t)g * KREC + j] = key;
-    ws.rec_idx[(int64_t)g * KREC + j] = idx;
-  }
-  if (lane == 0) {
-    ws.head_f[g] = F;
-    atomicAdd(&ws.seq_fcn[i_seq], nchunks_freed(F, hang, (uint32_t)bs));          // finite-threshold chunks
-    atomicAdd(&ws.seq_fcn[B + i_seq], (uint32_t)((ctx + bs - 1) / bs));          // all chunks
+    for (int j = lane; j < SZ; j += WAVE) a[j] = (uint32_t)j < C[q] ? rec[j] : ~0ull;
+    wave_lds_sync();
+    if (SZ == 128) wave_bitonic_sort<uint64_t, 128>(a);
+    else wave_bitonic_sort<uint64_t, 256>(a);
+    for (int j = lane; j < (int)C[q]; j += WAVE) rec[j] = a[j];
   }
 }
 
-// the k'_i of seq_prepare_body from the per-sequence chunk counts head_topk_kernel accumulated
-__global__ __launch_bounds__(1024) void seq_prepare_topk_kernel(kvc_schedule_params p, SchedWs ws) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t prep_lds[];
-  const int B = p.num_seqs;
-  int64_t* un_s = reinterpret_cast<int64_t*>(prep_lds);
-  int32_t* f_s = reinterpret_cast<int32_t*>(un_s + B);
-  int32_t* cn_s = f_s + B;
-  int32_t* off_s = cn_s + B;
-  int32_t* pinf_s = off_s + B;
-  for (int i = threadIdx.x; i < B; i += blockDim.x) { f_s[i] = (int32_t)ws.seq_fcn[i]; cn_s[i] = (int32_t)ws.seq_fcn[B + i]; }
-  seq_prepare_body(p, ws, un_s, f_s, cn_s, off_s, pinf_s);
+// per sequence: finite-threshold chunks and all chunks, from the per-head counts stream_records left
+// -> seq_tmp, where seq_prepare_kernel expects them (only the reference's batch > 1 rule needs this
+// and the launch behind it: otherwise seq_select_topk_kernel finds its k' itself)
+__global__ __launch_bounds__(256) void seq_sums_topk_kernel(kvc_schedule_params p, SchedWs ws) {
+  __shared__ uint32_t red[2][4];
+  const int B = p.num_seqs, LH = p.num_layers * p.num_kv_heads, G = B * LH;
+  const int i = blockIdx.x;
+  uint32_t f = 0, cn = 0;
+  for (int lh = threadIdx.x; lh < LH; lh += blockDim.x) {
+    f += ws.head_fc[(int64_t)i * LH + lh];
+    cn += ws.head_fc[(int64_t)G + (int64_t)i * LH + lh];
+  }
+  f = wave_reduce_sum(f);
+  cn = wave_reduce_sum(cn);
+  if (lane_id() == 0) { red[0][threadIdx.x / WAVE] = f; red[1][threadIdx.x / WAVE] = cn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ws.seq_tmp[i] = (int32_t)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    ws.seq_tmp[B + i] = (int32_t)(red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
 }
 
 // one workgroup per sequence: sort the recorded thresholds of its heads by (threshold, head,
 // chunk); the first k' are the freed chunks (metrics.py:704-729 + 773-792)
-__global__ __launch_bounds__(1024) void seq_select_topk_kernel(kvc_schedule_params p, SchedWs ws, int P2) {
+__global__ __launch_bounds__(1024) void seq_select_topk_kernel(kvc_schedule_params p, SchedWs ws, int P2, int coupled) {
   extern __shared__ __attribute__((aligned(16))) uint8_t sel_lds[];
   uint64_t* arr = reinterpret_cast<uint64_t*>(sel_lds);
   uint32_t* cnt = reinterpret_cast<uint32_t*>(arr + P2);
@@ -1019,17 +1400,40 @@ __global__ __launch_bounds__(1024) void seq_select_topk_kernel(kvc_schedule_para
   const int LH = p.num_layers * p.num_kv_heads;
   const uint32_t bs = (uint32_t)p.block_size;
   const int MCH = KREC / p.block_size;               // thresholds a record holds
-  const uint32_t k = (uint32_t)ws.seq_k[i];
   const int tid = threadIdx.x;
+  __shared__ uint32_t fsum_s;
+  if (coupled == 2) {
+    // lazy pass: the evictable keys were not counted.  k' = min(k, finite-threshold chunks) is k
+    // whenever the records list k thresholds (all of them finite); if they do not, the flag is
+    // raised below like for any record that falls short
+    if (tid == 0) ws.seq_k[i] = max(p.evicted_blocks_per_seq[i], 0);
+    __syncthreads();
+  } else if (!coupled) {
+    // k' = min(k, finite-threshold chunks of the sequence): what seq_prepare_body gives for
+    // mode 1 or a single sequence (the reference's batch > 1 rule ran seq_prepare_kernel instead)
+    if (tid == 0) fsum_s = 0;
+    __syncthreads();
+    uint32_t f = 0;
+    for (int lh = tid; lh < LH; lh += blockDim.x) f += ws.head_fc[(int64_t)i * LH + lh];
+    f = wave_reduce_sum(f);
+    if (lane_id() == 0 && f) atomicAdd(&fsum_s, f);
+    __syncthreads();
+    if (tid == 0) {
+      const int kk = p.evicted_blocks_per_seq[i];
+      ws.seq_k[i] = kk <= 0 ? 0 : (int32_t)((uint32_t)kk < fsum_s ? (uint32_t)kk : fsum_s);
+    }
+    __syncthreads();
+  }
+  const uint32_t k = (uint32_t)ws.seq_k[i];
   for (int e = tid; e < P2; e += blockDim.x) {
     const int lh = e / MCH, c = e % MCH;
     uint64_t v = ~0ull;
     if (lh < LH && k > 0) {
       const int64_t g = (int64_t)i * LH + lh;
       const uint32_t hang = (uint32_t)p.hanging_token_count[g];
-      const uint32_t have = min(ws.head_f[g], (uint32_t)KREC);
+      const uint32_t have = min(ws.st_cnt[g], (uint32_t)KREC);
       const uint32_t r = hang - 1u + (uint32_t)c * bs;          // rank - 1 of threshold c
-      if (hang >= 1u && r < have) v = ((uint64_t)ws.rec_key[g * KREC + r] << 32) | (uint32_t)e;
+      if (hang >= 1u && r < have) v = (ws.rec64[g * KREC + r] & 0xFFFFFFFF00000000ull) | (uint32_t)e;
     }
     arr[e] = v;
   }
@@ -1091,17 +1495,17 @@ __global__ __launch_bounds__(1024) void seq_select_topk_kernel(kvc_schedule_para
     const int64_t g = (int64_t)i * LH + lh;
     const uint32_t hang = (uint32_t)p.hanging_token_count[g];
     const uint32_t n = k > 0 ? cnt[lh] : 0u;
-    if (k > 0) {
-      // a head whose record is truncated must not reach the cut: every threshold it does not
-      // list is >= the record's last key, which therefore has to lie strictly above T*
-      const uint32_t F = ws.head_f[g];
-      if (F > (uint32_t)KREC && nchunks_freed(F, hang, bs) > nchunks_freed((uint32_t)KREC, hang, bs) &&
-          !(ws.rec_key[g * KREC + KREC - 1] > Tstar))
-        atomicOr(ws.fallback, 1u);
-    }
+    // (every threshold a record does not list is a key above the sequence's pivot, hence above
+    // every listed one: nothing to check here; a list that overflowed raised the flag already)
     p.evicted_block_count[g] = (int32_t)n;
     p.evicted_kv_count[g] = n > 0 ? (int32_t)((n - 1) * bs + hang) : 0;
   }
+}
+
+// logical slot index of a physical slot (the block's own metadata row)
+__device__ __forceinline__ uint32_t logical_of(const kvc_schedule_params& p, uint32_t phys_slot) {
+  const uint32_t bs = (uint32_t)p.block_size;
+  return (uint32_t)p.logical_block_num_by_block[phys_slot / bs] * bs + phys_slot % bs;
 }
 
 // one wave per head: the first cnt record entries, ascending by logical index  (metrics.py:822-834)
@@ -1119,7 +1523,8 @@ __global__ __launch_bounds__(64 * WAVES) void emit_topk_kernel(kvc_schedule_para
   int32_t* out = p.evicted_logical_indices + p.evicted_kv_offsets[g];
   if (cnt <= (uint32_t)WAVE) {
     // the usual case (a block or two per head): one index per lane, bitonic sort across the lanes
-    uint32_t v = (uint32_t)lane < cnt ? ws.rec_idx[(int64_t)g * KREC + lane] : 0xFFFFFFFFu;
+    uint32_t v = 0xFFFFFFFFu;
+    if ((uint32_t)lane < cnt) v = logical_of(p, (uint32_t)ws.rec64[(int64_t)g * KREC + lane]);
 #pragma unroll
     for (int k = 2; k <= WAVE; k <<= 1)
 #pragma unroll
@@ -1133,14 +1538,21 @@ __global__ __launch_bounds__(64 * WAVES) void emit_topk_kernel(kvc_schedule_para
   }
   uint32_t* a = sort_s[w];
   for (int j = lane; j < KREC; j += WAVE)
-    a[j] = (uint32_t)j < cnt ? ws.rec_idx[(int64_t)g * KREC + j] : 0xFFFFFFFFu;
+    a[j] = (uint32_t)j < cnt ? logical_of(p, (uint32_t)ws.rec64[(int64_t)g * KREC + j]) : 0xFFFFFFFFu;
   wave_lds_sync();
   wave_bitonic_sort<uint32_t, KREC>(a);
   for (int j = lane; j < (int)cnt; j += WAVE) out[j] = (int32_t)a[j];
 }
 
-// general pipeline behind the small-eviction schedule (gated): keys of chunks nobody claimed were
-// not cleared on that path
+// general pipeline behind the small-eviction schedule (gated): the chunk table is cleared by a gated
+// kernel instead of a memset (nothing runs unless the flag was raised), and the keys of chunks
+// nobody claimed, which no memset cleared on that path, are set afterwards
+__global__ __launch_bounds__(256) void clear_chunk_table_kernel(kvc_schedule_params p, SchedWs ws) {
+  if (gated_off(ws)) return;
+  const int64_t nchunks = p.total_slots / p.block_size;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += (int64_t)gridDim.x * blockDim.x)
+    ws.chunk_phys[c] = -1;
+}
 __global__ __launch_bounds__(256) void fix_unclaimed_kernel(kvc_schedule_params p, SchedWs ws) {
   if (gated_off(ws)) return;
   const int64_t nchunks = p.total_slots / p.block_size;
@@ -1154,9 +1566,20 @@ __global__ __launch_bounds__(256) void fix_unclaimed_kernel(kvc_schedule_params 
 // --------------------------------------------------------------------------- host side
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// > 64 KiB of dynamic LDS needs an opt-in per function AND per device (gfx950 has 160 KiB per CU):
+// done once per (function, device), whatever thread or device the caller is on
+static void allow_dynamic_lds(const void* fn, int bytes, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return;
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  done.fetch_or(bit, std::memory_order_release);
+}
+
 struct WsLayout {
   size_t keys, zero_begin, chunk_phys, hist, less, eq, seq_prefix, seq_k, zero_end, cum, chunkcnt,
-      seq_tmp, tz_begin, fallback, seq_fcn, tz_end, rec_key, rec_idx, head_f, total;
+      seq_tmp, tz_begin, fallback, st_claimed, st_cnt, st_def, st_samp, tz_end, st_seqrec, head_fc, rec64, total;
 };
 
 static WsLayout ws_layout(int64_t N, int32_t G, int32_t B, int32_t bs) {
@@ -1174,48 +1597,56 @@ static WsLayout ws_layout(int64_t N, int32_t G, int32_t B, int32_t bs) {
   l.cum = o;         o = align_up(o + (size_t)4 * G * kvc::RADIX * 4, 256);
   l.chunkcnt = o;    o = align_up(o + (size_t)G * kvc::RADIX * 4, 256);
   l.seq_tmp = o;     o = align_up(o + (size_t)B * 12, 256);
-  l.tz_begin = o;    // cleared by chunk_table_kernel's tail workgroups (small-eviction schedule)
+  l.tz_begin = o;    // one memset at the head of the small-eviction schedule
   l.fallback = o;    o = align_up(o + 16, 256);
-  l.seq_fcn = o;     o = align_up(o + (size_t)B * 8, 256);
+  l.st_claimed = o;  o = align_up(o + (size_t)kvc::CLAIM_SHARDS * 128, 256);
+  l.st_cnt = o;      o = align_up(o + (size_t)G * 4, 256);
+  l.st_def = o;      o = align_up(o + (size_t)G * 4, 256);
+  l.st_samp = o;     o = align_up(o + (size_t)G * 4, 256);
   l.tz_end = o;
-  l.rec_key = o;     o = align_up(o + (size_t)G * kvc::KREC * 4, 256);
-  l.rec_idx = o;     o = align_up(o + (size_t)G * kvc::KREC * 4, 256);
-  l.head_f = o;      o = align_up(o + (size_t)G * 4, 256);
+  l.st_seqrec = o;   o = align_up(o + (size_t)B * 16, 256);
+  l.head_fc = o;     o = align_up(o + (size_t)G * 8, 256);
+  l.rec64 = o;       o = align_up(o + (size_t)G * kvc::KREC * 8, 256);
   l.total = o;
   return l;
 }
 
 // small-eviction schedule (section 7) or not: the host knows how many blocks a sequence frees at
 // most (the reference passes a Python list); eligible when that is on average <= 1/8 of what a
-// head's record covers, the heads fit a wave's LDS staging buffer and a sequence's thresholds fit
-// one workgroup's LDS.  cap = keys staged per wave, p2 = padded threshold count per sequence.
-static void topk_plan(const kvc_schedule_params& p, int& cap, int& p2_out) {
-  cap = 0; p2_out = 0;
+// head's record covers and a sequence's thresholds fit one workgroup's LDS.
+// p2 = padded threshold count per sequence (0: not eligible), sshift = log2 of the sample stride.
+static void topk_plan(const kvc_schedule_params& p, int& p2_out, int& sshift) {
+  p2_out = 0; sshift = 0;
   const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
   if (G < 1 || p.total_slots <= 0) return;
   const int LH = p.num_layers * p.num_kv_heads;
-  const int64_t avg_head = p.total_slots / G;
   const int bsz = p.block_size;
-  if (!(bsz == 8 || bsz == 16 || bsz == 32) || avg_head > 8192 || p.schedule_path == 1) return;
+  if (!(bsz == 8 || bsz == 16 || bsz == 32) || p.schedule_path == 1) return;
+  // (per-head tables of the pivot kernel in LDS; a record entry packs the physical slot into 32 bits)
+  if (LH > kvc::PIV_MAXLH || p.num_seqs > 65535 ||
+      p.num_blocks * (int64_t)bsz >= (int64_t)1 << 32) return;
   const int mch = kvc::KREC / bsz;
   int p2 = 128;
   while (p2 < LH * mch && p2 <= 16384) p2 <<= 1;
   if (p2 > 16384) return;
-  const bool hint_ok = p.schedule_path == 2 ||
+  const bool hint_ok = p.schedule_path == 2 || p.schedule_path == 3 ||
       (p.max_evicted_blocks_hint >= 0 && (int64_t)p.max_evicted_blocks_hint * 8 <= (int64_t)mch * LH);
   if (!hint_ok) return;
-  const int64_t want = (avg_head + avg_head / 8 + 63) / 64 * 64 + 64;   // 12 % slack for ragged heads
-  cap = (int)(want < 1024 ? 1024 : want);
   p2_out = p2;
+  // sample stride: about 32 Ki sampled keys per sequence (a sequence's pivot is a low quantile of
+  // its sample, held in the registers of one workgroup); small sequences are sampled whole
+  int64_t stride = p.total_slots / p.num_seqs / 32768;
+  if (p.sample_stride > 0) stride = p.sample_stride;
+  while (sshift < 8 && (2ll << sshift) <= stride) ++sshift;
 }
 
 // introspection for tests and bench.py: 1 if a call with these parameters enqueues the
 // small-eviction schedule; byte offset of its `fallback` word inside the workspace (non-zero
 // after the call = the general pipeline behind it recomputed the result)
 extern "C" int32_t kvc_schedule_evictions_uses_small_eviction_schedule(const kvc_schedule_params* p) {
-  int cap = 0, p2 = 0;
-  if (p != nullptr) topk_plan(*p, cap, p2);
-  return cap > 0 ? 1 : 0;
+  int p2 = 0, sshift = 0;
+  if (p != nullptr) topk_plan(*p, p2, sshift);
+  return p2 > 0 ? 1 : 0;
 }
 static WsLayout ws_layout(int64_t N, int32_t G, int32_t B, int32_t bs);
 extern "C" size_t kvc_schedule_evictions_fallback_offset(int64_t total_slots, int32_t total_heads,
@@ -1262,11 +1693,14 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   ws.seq_prefix = reinterpret_cast<uint32_t*>(wb + l.seq_prefix);
   ws.seq_k = reinterpret_cast<int32_t*>(wb + l.seq_k);
   ws.seq_tmp = reinterpret_cast<int32_t*>(wb + l.seq_tmp);
-  ws.rec_key = reinterpret_cast<uint32_t*>(wb + l.rec_key);
-  ws.rec_idx = reinterpret_cast<uint32_t*>(wb + l.rec_idx);
-  ws.head_f = reinterpret_cast<uint32_t*>(wb + l.head_f);
+  ws.rec64 = reinterpret_cast<uint64_t*>(wb + l.rec64);
+  ws.st_cnt = reinterpret_cast<uint32_t*>(wb + l.st_cnt);
+  ws.st_def = reinterpret_cast<uint32_t*>(wb + l.st_def);
+  ws.st_samp = reinterpret_cast<uint32_t*>(wb + l.st_samp);
+  ws.st_claimed = reinterpret_cast<uint32_t*>(wb + l.st_claimed);
+  ws.st_seqrec = reinterpret_cast<SeqRec*>(wb + l.st_seqrec);
   ws.fallback = reinterpret_cast<uint32_t*>(wb + l.fallback);
-  ws.seq_fcn = reinterpret_cast<uint32_t*>(wb + l.seq_fcn);
+  ws.head_fc = reinterpret_cast<uint32_t*>(wb + l.head_fc);
   ws.gate = nullptr;
   if (p.total_slots == 0) {
     hipMemsetAsync(p.evicted_kv_count, 0, (size_t)G * 4, s);
@@ -1277,39 +1711,62 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   // no physical block claims (inconsistent metadata); histograms and counters are zeroed by
   // the tail workgroups of build_keys
   const int LH = p.num_layers * p.num_kv_heads;
-  int topk_cap = 0, topk_p2 = 0;
-  topk_plan(p, topk_cap, topk_p2);
-  const bool topk = topk_cap > 0;
+  int topk_p2 = 0, sshift = 0;
+  topk_plan(p, topk_p2, sshift);
+  const bool topk = topk_p2 > 0;
   const size_t prep_lds = (size_t)B * 24;
   if (prep_lds > 64 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_prepare_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_prepare_topk_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds);
+    static std::atomic<uint64_t> prep_done{0};
+    allow_dynamic_lds(reinterpret_cast<const void*>(seq_prepare_kernel), 160 * 1024 - 1024, prep_done);
   }
   if (topk) {
-    // ---- small-eviction schedule (section 7): 6 launches; the general pipeline is enqueued
-    // behind it and runs only if the flag was raised
-    if (p.block_tables != nullptr) {
-      // the caller's block table replaces the chunk-table pass; only the flag / totals are cleared
-      hipMemsetAsync(wb + l.tz_begin, 0, l.tz_end - l.tz_begin, s);
-    } else {
-      if (!(p.lean & 2)) hipMemsetAsync(ws.chunk_phys, 0xFF, l.zero_begin - l.chunk_phys, s);
-      uint4* z16 = reinterpret_cast<uint4*>(wb + l.tz_begin);
-      const int64_t zv = (int64_t)((l.tz_end - l.tz_begin) / 16);
-      const unsigned db = (unsigned)((p.num_blocks + 255) / 256);
-      hipLaunchKernelGGL(chunk_table_kernel, dim3(db + 1), dim3(256), 0, s, p, ws, db, z16, zv);
+    // ---- small-eviction schedule (section 7): two memsets, 6 launches (+ 2 for the reference's batch > 1 rule); the general
+    // pipeline is enqueued behind it and runs only if the flag was raised
+    hipMemsetAsync(wb + l.tz_begin, 0, l.tz_end - l.tz_begin, s);
+    if (!(p.lean & 1))
+      hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.evicted_logical_indices), p.null_value,
+                        (size_t)p.total_slots, s);
+    static std::atomic<uint64_t> sel_done{0};
+    allow_dynamic_lds(reinterpret_cast<const void*>(seq_select_topk_kernel), 156 * 1024, sel_done);   // + its static tables
+    // positions only for the slots whose metric lies below the pivot (stream_collect_kernel, LAZY):
+    // keys that do not depend on the position, sequences that do not need each other's inf counts
+    const bool lazy = !p.use_average && p.bias == nullptr && !(p.mode == 0 && B > 1) && p.schedule_path != 3;
+    {
+      int64_t sb = (p.num_blocks + 2047) / 2048;     // >= 8 steps of 64 block indices per wave
+      sb = sb < 1 ? 1 : (sb > 4096 ? 4096 : sb);
+      const dim3 grid((unsigned)sb), blk(256);
+      if (p.block_size == 8) hipLaunchKernelGGL(stream_sample_kernel<8>, grid, blk, 0, s, p, ws, sshift);
+      else if (p.block_size == 16) hipLaunchKernelGGL(stream_sample_kernel<16>, grid, blk, 0, s, p, ws, sshift);
+      else hipLaunchKernelGGL(stream_sample_kernel<32>, grid, blk, 0, s, p, ws, sshift);
     }
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(seq_select_topk_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);   // + its static tables
-      attr_done = true;
+    hipLaunchKernelGGL(stream_pivot_kernel, dim3(B), dim3(1024), 0, s, p, ws, sshift);
+    {
+      // blocks of the batch / blocks of the cache: a dense cache requests the rows before it has
+      // looked at the metadata, a sparse one (engine-sized cache, small batch) only the batch's rows
+      const bool dense = p.total_slots >= (int64_t)p.num_blocks * p.block_size / 2;
+      int64_t cb = (p.num_blocks + 255) / 256;
+      cb = cb < 1 ? 1 : (cb > 4096 ? 4096 : cb);
+      const dim3 grid((unsigned)cb), blk(256);
+#define KVC_COLLECT(BSV)                                                                                  \
+      if (lazy) {                                                                                         \
+        if (dense) hipLaunchKernelGGL((stream_collect_kernel<BSV, true, true>), grid, blk, 0, s, p, ws);  \
+        else hipLaunchKernelGGL((stream_collect_kernel<BSV, false, true>), grid, blk, 0, s, p, ws);       \
+      } else {                                                                                            \
+        if (dense) hipLaunchKernelGGL((stream_collect_kernel<BSV, true, false>), grid, blk, 0, s, p, ws); \
+        else hipLaunchKernelGGL((stream_collect_kernel<BSV, false, false>), grid, blk, 0, s, p, ws);      \
+      }
+      if (p.block_size == 8) { KVC_COLLECT(8); }
+      else if (p.block_size == 16) { KVC_COLLECT(16); }
+      else { KVC_COLLECT(32); }
+#undef KVC_COLLECT
     }
-    constexpr int TW = 4;
-    hipLaunchKernelGGL(head_topk_kernel<TW>, dim3((G + TW - 1) / TW), dim3(64 * TW), 0, s, p, ws);
-    hipLaunchKernelGGL(seq_prepare_topk_kernel, dim3(1), dim3(1024), prep_lds, s, p, ws);
-    hipLaunchKernelGGL(seq_select_topk_kernel, dim3(B), dim3(1024), (size_t)topk_p2 * 8 + (size_t)LH * 4, s, p, ws, topk_p2);
+    hipLaunchKernelGGL((stream_records_kernel<4, 4>), dim3((G + 15) / 16), dim3(256), 0, s, p, ws, lazy ? 1 : 0);
+    const int coupled_tk = (p.mode == 0 && B > 1) ? 1 : (lazy ? 2 : 0);
+    if (coupled_tk == 1) {
+      hipLaunchKernelGGL(seq_sums_topk_kernel, dim3(B), dim3(256), 0, s, p, ws);
+      hipLaunchKernelGGL(seq_prepare_kernel, dim3(1), dim3(1024), prep_lds, s, p, ws);
+    }
+    hipLaunchKernelGGL(seq_select_topk_kernel, dim3(B), dim3(1024), (size_t)topk_p2 * 8 + (size_t)LH * 4, s, p, ws, topk_p2, coupled_tk);
     hipLaunchKernelGGL(emit_topk_kernel<4>, dim3((G + 3) / 4), dim3(256), 0, s, p, ws);
     ws.gate = ws.fallback;
   }
@@ -1319,6 +1776,7 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   // the tail workgroups of build_keys.  Behind the small-eviction schedule (gated) the clear is a
   // gated kernel instead of a memset.
   if (!topk && !(p.lean & 2)) hipMemsetAsync(ws.keys, 0xFF, l.zero_begin - l.keys, s);
+  if (topk && !(p.lean & 2)) hipLaunchKernelGGL(clear_chunk_table_kernel, dim3(1024), dim3(256), 0, s, p, ws);
   {
     uint4* z16 = reinterpret_cast<uint4*>(wb + l.zero_begin);
     const int64_t zv = (int64_t)((l.zero_end - l.zero_begin) / 16);
@@ -1354,16 +1812,21 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   int64_t hgrid = htiles_all / 32;
   hgrid = hgrid < 1024 ? 1024 : (hgrid > 4096 ? 4096 : hgrid);
   const unsigned htiles = (unsigned)(htiles_all < hgrid ? htiles_all : hgrid);
+  // per round: the histograms, then ONE launch for scan + pick (round 0: + the chunk totals and k',
+  // round 3: + the per-head counts).  Only the reference's batch > 1 rule (mode 0, B > 1) couples
+  // the sequences in round 0 and keeps the four separate launches there.  10 launches + the memset.
+  const bool coupled = p.mode == 0 && B > 1;
   for (int round = 0; round < 4; ++round) {
     hipLaunchKernelGGL(hist_round_kernel, dim3(htiles), dim3(256), 0, s, p, ws, round);
-    hipLaunchKernelGGL(scan_round_kernel, dim3((G + 3) / 4), dim3(256), 0, s, p, ws, round);
-    if (round == 0) {
+    if (round == 0 && coupled) {
+      hipLaunchKernelGGL(scan_round_kernel, dim3((G + 3) / 4), dim3(256), 0, s, p, ws, round);
       hipLaunchKernelGGL(seq_totals_kernel, dim3(B), dim3(256), 0, s, p, ws);
       hipLaunchKernelGGL(seq_prepare_kernel, dim3(1), dim3(1024), prep_lds, s, p, ws);
+      hipLaunchKernelGGL(pick_round_kernel, dim3(B), dim3(1024), 0, s, p, ws, round);
+    } else {
+      hipLaunchKernelGGL(scan_pick_kernel, dim3(B), dim3(1024), 0, s, p, ws, round);
     }
-    hipLaunchKernelGGL(pick_round_kernel, dim3(B), dim3(1024), 0, s, p, ws, round);
   }
-  hipLaunchKernelGGL(finalize_heads_kernel, dim3(B), dim3(256), 0, s, p, ws);
   {
     // stage a head's keys in LDS when the average head fits with 25 % slack (ragged heads
     // that do not fit read from L2).  Small heads (the continual-compression steady state:
@@ -1378,12 +1841,8 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     if (avg <= 8192) {
       hipLaunchKernelGGL(select_emit_kernel<256>, dim3(G), dim3(256), (size_t)lds_cap * 4, s, p, ws, lds_cap);
     } else {
-      static bool attr_long = false;                 // once per process (per-function attribute)
-      if (!attr_long) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(select_emit_kernel<1024>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
-        attr_long = true;
-      }
+      static std::atomic<uint64_t> long_done{0};
+      allow_dynamic_lds(reinterpret_cast<const void*>(select_emit_kernel<1024>), 32768 * 4, long_done);
       hipLaunchKernelGGL(select_emit_kernel<1024>, dim3(G), dim3(1024), (size_t)lds_cap * 4, s, p, ws, lds_cap);
     }
   }

@@ -305,16 +305,47 @@ void kvcompress_paged_attention_v2(Tensor& out, Tensor& kv_metric_out, const Ten
                       v_scale, record_kv_metrics);
 }
 
+// The V1 scheduler pair (csrc/torch_bindings.cpp:374-394, csrc/kvcompress_eviction_kernels.cu
+// schedule_cache_evictions / truncate_cache_evictions): dead in the reference behind `if False:`
+// (vllm/kvcompress/scheduler.py:285) and mis-registered by its wrapper.  The
+// schemas are here so that the op surface is complete; calling them says where the live path is.
+constexpr const char* V1_DEAD =
+    "schedule_cache_evictions (V1) is dead code in the reference; use "
+    "vllm_kvcompress_amd.kvcompress.metrics.CompressionMetrics.schedule_evictions";
+
+void schedule_cache_evictions(Tensor&, Tensor&, Tensor&, Tensor&, const Tensor&, const Tensor&, const Tensor&,
+                              const Tensor&, const Tensor&, const Tensor&, const Tensor&, const Tensor&,
+                              const Tensor&, const Tensor&, const Tensor&, const Tensor&, int64_t, bool,
+                              const std::optional<Tensor>&, int64_t, int64_t, bool) {
+  TORCH_CHECK(false, V1_DEAD);
+}
+
+void truncate_cache_evictions(Tensor&, Tensor&, Tensor&, const Tensor&, const Tensor&, int64_t, int64_t, int64_t) {
+  TORCH_CHECK(false, V1_DEAD);
+}
+
 bool has_schema(const char* name) {
   return c10::Dispatcher::singleton().findSchema({name, ""}).has_value();
 }
 
 }  // namespace
 
-// Schemas: the fork's own (csrc/torch_bindings.cpp:52-80, 353-362, 395-418).  FRAGMENTs, and only
+// Schemas: the fork's own (csrc/torch_bindings.cpp:52-80, 353-362, 374-418).  FRAGMENTs, and only
 // for names nobody defined yet, so the library can be loaded next to an extension that already
 // carries the schemas; the kernels below are registered for the HIP (CUDA-key) backend either way.
 TORCH_LIBRARY_FRAGMENT(_C_kvc_ops, m) {
+  if (!has_schema("_C_kvc_ops::schedule_cache_evictions"))
+    m.def("schedule_cache_evictions(Tensor! evicted_kv_indices, Tensor! evicted_logical_indices, "
+          "Tensor! evicted_kv_count, Tensor! remaining_kv_count, Tensor evicted_kv_offsets, "
+          "Tensor sorted_indices, Tensor seq_block_offsets, Tensor layer_by_block, Tensor head_by_block, "
+          "Tensor virtual_block_num_by_block, Tensor evicted_blocks_per_seq, Tensor context_lens, "
+          "Tensor hanging_token_count, Tensor kv_position, Tensor last_position, "
+          "Tensor protected_window_size, int block_size, bool evict_evenly_per_layer, "
+          "Tensor? control_layers, int max_evicted_kv, int null_eviction_index, bool truncate) -> ()");
+  if (!has_schema("_C_kvc_ops::truncate_cache_evictions"))
+    m.def("truncate_cache_evictions(Tensor! evicted_kv_indices, Tensor! evicted_logical_indices, "
+          "Tensor! evicted_kv_count, Tensor evicted_kv_offsets, Tensor hanging_token_count, "
+          "int block_size, int max_evicted_kv, int null_eviction_index) -> ()");
   if (!has_schema("_C_kvc_ops::count_block_evictions"))
     m.def("count_block_evictions(Tensor! evicted_block_count, Tensor! evicted_logical_indices, "
           "Tensor evicted_kv_offsets, Tensor hanging_token_count, int block_size, int null_value) -> ()");
@@ -349,6 +380,8 @@ TORCH_LIBRARY_FRAGMENT(_C, m) {
 }
 
 TORCH_LIBRARY_IMPL(_C_kvc_ops, CUDA, m) {
+  m.impl("schedule_cache_evictions", &schedule_cache_evictions);
+  m.impl("truncate_cache_evictions", &truncate_cache_evictions);
   m.impl("count_block_evictions", &count_block_evictions);
   m.impl("schedule_t1_cache_moves", &schedule_t1_cache_moves);
   m.impl("execute_cache_moves", &execute_cache_moves);

@@ -129,6 +129,9 @@ class CompressionMetrics:
         # 0 = pick the schedule from the eviction counts, 1 = general pipeline only, 2 = small-eviction
         # schedule whenever the shapes allow (kvc_schedule_params.schedule_path; tests force both)
         self.schedule_path = int(os.environ.get("KVC_SCHEDULE_PATH", "0"))
+        # sample stride of the small-eviction schedule's pivots (0 = chosen from the batch size;
+        # results do not depend on it, tests force every value)
+        self.sample_stride = int(os.environ.get("KVC_SAMPLE_STRIDE", "0"))
         self.last_schedule = None      # (workspace, fallback offset, small-eviction schedule enqueued)
         self._small_cache = {}
 
@@ -373,6 +376,7 @@ class CompressionMetrics:
         else:
             p.max_evicted_blocks_hint = int(max(int(v) for v in evicted_blocks_per_seq))
         p.schedule_path = int(self.schedule_path)
+        p.sample_stride = int(self.sample_stride)
         if block_tables is not None:
             if (not block_tables.is_cuda or block_tables.dtype != torch.int32 or block_tables.dim() != 4
                     or not block_tables.is_contiguous() or block_tables.shape[0] != L or block_tables.shape[2] != H):

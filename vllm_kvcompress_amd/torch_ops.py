@@ -23,6 +23,21 @@ _KEEP = []          # Library objects must stay alive
 _REGISTERED = ""          # "" | "compiled" | "python"
 
 _KVC_SCHEMAS = {
+    # the V1 pair (csrc/torch_bindings.cpp:374-394): dead in the reference (scheduler.py:285
+    # ``if False:``), registered for surface completeness, raise when called
+    "schedule_cache_evictions":
+        "(Tensor(a!) evicted_kv_indices, Tensor(b!) evicted_logical_indices, "
+        "Tensor(c!) evicted_kv_count, Tensor(d!) remaining_kv_count, Tensor evicted_kv_offsets, "
+        "Tensor sorted_indices, Tensor seq_block_offsets, Tensor layer_by_block, "
+        "Tensor head_by_block, Tensor virtual_block_num_by_block, Tensor evicted_blocks_per_seq, "
+        "Tensor context_lens, Tensor hanging_token_count, Tensor kv_position, "
+        "Tensor last_position, Tensor protected_window_size, int block_size, "
+        "bool evict_evenly_per_layer, Tensor? control_layers, int max_evicted_kv, "
+        "int null_eviction_index, bool truncate) -> ()",
+    "truncate_cache_evictions":
+        "(Tensor(a!) evicted_kv_indices, Tensor(b!) evicted_logical_indices, "
+        "Tensor(c!) evicted_kv_count, Tensor evicted_kv_offsets, Tensor hanging_token_count, "
+        "int block_size, int max_evicted_kv, int null_eviction_index) -> ()",
     "count_block_evictions":
         "(Tensor(a!) evicted_block_count, Tensor(b!) evicted_logical_indices, "
         "Tensor evicted_kv_offsets, Tensor hanging_token_count, int block_size, "
@@ -62,6 +77,10 @@ _ATTN_SCHEMAS = {
         "Tensor? alibi_slopes, str kv_cache_dtype, float k_scale, float v_scale, "
         "bool record_kv_metrics) -> ()",
 }
+
+
+def _v1_dead(*args):
+    raise RuntimeError(ops.V1_DEAD_MESSAGE)
 
 
 def _count_block_evictions(ebc, eli, offs, hang, block_size, null_value):
@@ -127,6 +146,8 @@ def register(binding: str = "auto") -> str:
         _REGISTERED = "compiled"
         return _REGISTERED
     _bind("_C_kvc_ops", _KVC_SCHEMAS, {
+        "schedule_cache_evictions": _v1_dead,
+        "truncate_cache_evictions": _v1_dead,
         "count_block_evictions": _count_block_evictions,
         "schedule_t1_cache_moves": _schedule_t1_cache_moves,
         "execute_cache_moves": _execute_cache_moves,
