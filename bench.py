@@ -94,6 +94,8 @@ def parse_args(argv=None):
                     help="skip the second measurement of the same step in an HBM-filling cache")
     ap.add_argument("--engine-cache-frac", type=float, default=0.80,
                     help="fraction of the free HBM that second cache takes")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short runs of BASELINE configs[4] / configs[2] the default line carries")
     ap.add_argument("--no-probe", action="store_true",
                     help="skip the access-pattern ceiling probe (tools/libkvc_probe.so)")
     ap.add_argument("--traffic-json", default=os.path.join(REPO, "profiles", "traffic.json"),
@@ -304,27 +306,18 @@ def s0_stages(args, device):
     return out
 
 
-def engine_sized_cache_run(args, rank, device, steps=20, warmup=3):
-    """The SAME step with the sequence's blocks inside a cache sized the way an engine sizes it: to
-    the GPU's memory (vLLM's gpu_memory_utilization) instead of to the sequence.  Candidate, evicted
-    slots are identical to the main run and the moved ones differ by a fraction of a percent (another
-    seed's metrics); what changes is the number of (free) blocks in the cache tensor.  Reported next to the main line because random 4 KiB block traffic runs at
-    5.1 or 6.1 TB/s depending on where the blocks lie in HBM (DESIGN.md section 5)."""
-    import copy
+def measure_workload(a2, seed, device, steps, warmup, probe):
+    """One workload, timed like the main loop (HIP events on the launch stream around every stage
+    and around the compaction kernel): per-stage ms, whole-step rate, the compaction kernel's
+    roofline numbers.  Used for the engine-sized cache and for the other BASELINE configurations
+    the default run reports next to its headline.  Returns None if the workload does not fit."""
     import torch
     from vllm_kvcompress_amd import _custom_ops as ops
-    e = 1 if args.kv_dtype == "fp8" else 2
-    bs, hd = args.block_size, args.head_size
+    e = 1 if a2.kv_dtype == "fp8" else 2
+    bs, hd = a2.block_size, a2.head_size
     block_bytes = hd * bs * e
-    free, _ = torch.cuda.mem_get_info()
-    own = args.layers * args.kv_heads * args.batch * (args.seq_len // bs + 1)
-    nb_target = int(args.engine_cache_frac * free / (2 * block_bytes + 8 * bs + 16))
-    if nb_target < 8 * own:
-        return None
-    a2 = copy.copy(args)
-    a2.spare_blocks = nb_target / own - 1.0
     try:
-        st, ds, evicted, k_cache, v_cache = build_workload(a2, rank + 1000, device)
+        st, ds, evicted, k_cache, v_cache = build_workload(a2, seed, device)
     except torch.OutOfMemoryError:
         torch.cuda.empty_cache()
         return None
@@ -355,23 +348,109 @@ def engine_sized_cache_run(args, rank, device, steps=20, warmup=3):
     moved, evs = int(cmc.sum().item()), int(out["ekc"].sum().item())
     alg = moved * alg_bytes_per_move(hd, e) + 8 * st.total_heads
     floor = traffic_floor(cmi, cmc, ds.evicted_kv_offsets, bs, block_bytes)
+    s1 = ms(0, 1)
     res = {
-        "what": f"the same step, the sequence's blocks scattered over a cache that fills {args.engine_cache_frac:.0%} of the free HBM "
-                "(as an engine sizes it) instead of one sized to the sequence",
         "cache_blocks": st.num_blocks, "cache_GiB": 2 * st.num_blocks * block_bytes / 2 ** 30,
-        "evicted_slots": evs, "moved_slots": moved,
+        "candidate_slots": N, "evicted_slots": evs, "moved_slots": moved,
         "ms_per_step": step_ms, "value": (evs + moved) / (step_ms * 1e-3),
-        "stages_ms": {"S1_schedule_evictions": ms(0, 1), "S2_schedule_moves": ms(1, 2), "S3_execute_moves": ms(2, 4)},
+        "stages_ms": {"S1_schedule_evictions": s1, "S2_schedule_moves": ms(1, 2), "S3_execute_moves": ms(2, 4)},
+        "S1_schedule": ds.cm.last_schedule_path(),
+        # S1 against ITS lower bound (12.75 B per candidate slot)
+        "S1_lower_bound_GBps": N * 12.75 / (s1 * 1e-3) / 1e9,
+        "S1_frac_of_hbm_peak_at_lower_bound": N * 12.75 / (s1 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
         "roofline": {"avg_launch_ms": kernel_ms, "achieved": alg / (kernel_ms * 1e-3) / 1e9,
                      "frac": alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "floor_GBps": floor["bytes"] / (kernel_ms * 1e-3) / 1e9,
                      "frac_of_floor": floor["bytes"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                     "pattern_ceiling_GBps": None if args.no_probe else pattern_ceiling(k_cache, v_cache, block_bytes)},
+                     "pattern_ceiling_GBps": pattern_ceiling(k_cache, v_cache, block_bytes) if probe else None},
         "timing": f"{steps} steps after {warmup} warm-up steps, HIP events on the launch stream",
     }
     del k_cache, v_cache, ds, cmi, wm, wp
     torch.cuda.empty_cache()
     return res
+
+
+def engine_sized_cache_run(args, rank, device, steps=20, warmup=3):
+    """The SAME step with the sequence's blocks inside a cache sized the way an engine sizes it: to
+    the GPU's memory (vLLM's gpu_memory_utilization) instead of to the sequence.  Candidate, evicted
+    slots are identical to the main run and the moved ones differ by a fraction of a percent (another
+    seed's metrics); what changes is the number of (free) blocks in the cache tensor.  Reported next to the main line because random 4 KiB block traffic runs at
+    5.1 or 6.1 TB/s depending on where the blocks lie in HBM (DESIGN.md section 5)."""
+    import copy
+    import torch
+    e = 1 if args.kv_dtype == "fp8" else 2
+    bs, hd = args.block_size, args.head_size
+    block_bytes = hd * bs * e
+    free, _ = torch.cuda.mem_get_info()
+    own = args.layers * args.kv_heads * args.batch * (args.seq_len // bs + 1)
+    nb_target = int(args.engine_cache_frac * free / (2 * block_bytes + 8 * bs + 16))
+    if nb_target < 8 * own:
+        return None
+    a2 = copy.copy(args)
+    a2.spare_blocks = nb_target / own - 1.0
+    res = measure_workload(a2, rank + 1000, device, steps, warmup, not args.no_probe)
+    if res is None:
+        return None
+    res = {"what": f"the same step, the sequence's blocks scattered over a cache that fills {args.engine_cache_frac:.0%} of the free HBM "
+                   "(as an engine sizes it) instead of one sized to the sequence", **res}
+    # PMC traffic of this placement: a separately profiled run of the same step in a cache of 61 x the
+    # sequence's blocks (tools/collect_profiles.sh: bench.py --spare-blocks 60), committed
+    tj_path = os.path.join(REPO, "profiles", "traffic_engine.json")
+    if os.path.exists(tj_path):
+        try:
+            tj = json.load(open(tj_path))
+            t = tj.get("hbm_bytes_per_launch")
+            res["roofline"]["traffic"] = t
+            res["roofline"]["traffic_frac_of_peak"] = t / (res["roofline"]["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+            res["roofline"]["traffic_source"] = (
+                f"profiles/traffic_engine.json ({tj.get('tag', '?')}; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
+                "passes over `bench.py --spare-blocks 60`, the same step in a 222 GiB cache; 2 x FETCH + WRITE; a "
+                "separately profiled run, not a measurement of this one)")
+        except Exception:
+            pass
+    return res
+
+
+OTHER_CONFIGS = (("c5", 10, 2), ("c3", 10, 2))
+
+
+def other_configs_run(args, rank, device):
+    """BASELINE configs[4] (fp8, bs 32, 64k) and configs[2] (256 resident sequences in the continual
+    steady state -- or the largest power-of-two fraction that fits) with a few timed steps each, so
+    that the default line carries driver-run numbers for them: per-stage ms, the compaction
+    kernel's frac / frac_of_floor, S1 against its own lower bound."""
+    import copy
+    import torch
+    out = []
+    for name, steps, warmup in OTHER_CONFIGS:
+        a2 = copy.copy(args)
+        for key, default in (("layers", 32), ("block_size", 16), ("seq_len", 32768), ("batch", 1),
+                             ("kv_dtype", "fp16"), ("steady_cap", 0), ("keep", 0.5)):
+            setattr(a2, key, CONFIGS[name].get(key, default))
+        a2.config = name
+        batch = a2.batch
+        res = None
+        while res is None and batch >= 1:
+            a2.batch = batch
+            # K/V + metric store + move workspace + schedule workspace, roughly, against the free memory
+            e = 1 if a2.kv_dtype == "fp8" else 2
+            per_seq = a2.layers * a2.kv_heads * ((a2.steady_cap or a2.seq_len) // a2.block_size + 1)
+            need = per_seq * batch * (2 * a2.head_size * a2.block_size * e + a2.block_size * 36 + 64)
+            free, _ = torch.cuda.mem_get_info()
+            if need < 0.9 * free:
+                res = measure_workload(a2, rank + 2000, device, steps, warmup, False)
+            if res is None:
+                batch //= 2
+        if res is None:
+            out.append({"config": name, "skipped": "does not fit"})
+            continue
+        out.append({"config": name,
+                    "workload": f"L{a2.layers} H{a2.kv_heads} hd{a2.head_size}, {a2.seq_len}-token cache, bs {a2.block_size}, "
+                                f"batch {batch}" + (f" (asked for {CONFIGS[name].get('batch', 1)})" if batch != CONFIGS[name].get("batch", 1) else "")
+                                + f", {a2.kv_dtype} K/V, "
+                                + (f"continual steady state cap={a2.steady_cap}+1 token" if a2.steady_cap else f"compress_once keep={a2.keep}")
+                                + f", mode={a2.mode}", **res})
+    return out
 
 
 # --------------------------------------------------------------------------- CPU baseline
@@ -468,7 +547,13 @@ def cpu_baseline(args):
     same = T == args.seq_len and args.batch == 1 and not args.steady_cap
     total = s1 + s2 + s3
     return {
-        "value": units / total, "unit": "KV slots/s", "cores": cores, "kind": "port",
+        "value": units / total, "unit": "KV slots/s",
+        # threads actually used, per stage (S1 = torch's intra-op threads, S2 / S3 = OpenMP); `cores` = the most
+        # any stage used
+        "cores": max(cores, min(host_cpus, orc_c.max_threads())),
+        "threads_by_stage": {"S1_schedule": cores, "S2_moves": min(host_cpus, orc_c.max_threads()),
+                             "S3_compact": min(host_cpus, orc_c.max_threads())},
+        "kind": "port",
         "host_cpus": host_cpus, "torch_threads": torch_threads,
         "openmp_threads": min(host_cpus, orc_c.max_threads()),
         "S1_seconds_by_torch_threads": {str(k): v for k, v in scan.items()},
@@ -477,8 +562,9 @@ def cpu_baseline(args):
                   + f": L{L} H{H} hd{hd}, {T}-token cache, bs{bs}, B=1, keep={args.keep}, "
                   f"{args.metric_shape} metrics; S1 = the reference's six-sort torch formulation "
                   "(oracle/kvc_oracle_torch.py), S2/S3 = the C restatement of the serial kernels with the "
-                  f"head loop on all cores; 1 warm-up + 5 passes per stage, medians; `cores` = the torch thread "
-                  f"count S1 ran on (the faster of all {host_cpus} and 16); {units} slots per pass",
+                  f"head loop on all cores; 1 warm-up + 5 passes per stage, medians; S1 ran on {cores} torch threads "
+                  f"(the faster of all {host_cpus} and 16), S2 / S3 on {min(host_cpus, orc_c.max_threads())} OpenMP "
+                  f"threads (`threads_by_stage`); {units} slots per pass",
         "stage_seconds": {"S1_schedule": s1, "S2_moves": s2, "S3_compact": s3},
         "single_core_port": {"value": units / (t2 - t0), "cores": 1,
                              "stage_seconds": {"S1_schedule_numpy_lexsort": t1 - t0, "S2_S3_serial_C": t2 - t1},
@@ -663,7 +749,7 @@ def main():
                 "S3_moved_slots_per_s": moved_slots / (s3 * 1e-3),
             },
             "roofline": {
-                "kernel": f"kvc::compact_runs_kernel<{args.head_size},{bs},{e}> (execute_cache_moves)",
+                "kernel": f"kvc::compact_runs_kernel<{args.head_size},{bs},{e},4> (execute_cache_moves)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_move": bpm,
@@ -687,6 +773,12 @@ def main():
         if world == 1 and not args.no_s0:
             del cmi, work_metrics, work_pos
             res["stages_ms_S0"] = s0_stages(args, device)
+        if world == 1 and default_workload and not args.no_other_configs:
+            # (the main workload's K/V are not needed any more: the big configurations want the HBM)
+            del k_cache, v_cache
+            ds.cm.metrics = ds.cm.token_positions = None
+            torch.cuda.empty_cache()
+            res["other_configs"] = other_configs_run(args, rank, device)
         if world == 1 and not args.no_adjacent:
             # the producer of the metrics (row F3), one layer step at the continual-compression
             # shape; not part of `value`

@@ -18,7 +18,7 @@ export TMPDIR=/tmp
 cd "$REPO"
 timeout 900 python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
 cd /tmp
-BENCH="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-adjacent --no-s0 --no-probe --no-engine-cache"
+BENCH="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-adjacent --no-s0 --no-probe --no-engine-cache --no-other-configs"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" --output-format csv -- $BENCH > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/stats.log"
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" --output-format csv -- $BENCH > /dev/null 2> "$OUT/fetch.log"
 timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" --output-format csv -- $BENCH > /dev/null 2> "$OUT/write.log"
@@ -59,15 +59,51 @@ if dom:
 json.dump(summary, open(f"{out}/{tag}_traffic.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if k != "kernels"}))
 PY
+# 3b. the same two PMC passes for the step in an engine-sized cache (61 x the sequence's blocks, 222 GiB):
+#     bench.py's engine_sized_cache.roofline.traffic                      -> <tag>_traffic_engine.json
+BENCH_E="$BENCH --spare-blocks 60"
+timeout 600 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch_e" --output-format csv -- $BENCH_E > /dev/null 2> "$OUT/fetch_e.log"
+timeout 600 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write_e" --output-format csv -- $BENCH_E > /dev/null 2> "$OUT/write_e.log"
+python - "$OUT" "$TAG" <<'PY'
+import csv, glob, json, sys, collections
+out, tag = sys.argv[1], sys.argv[2]
+def pmc(kind, counter):
+    f = glob.glob(f"{out}/{kind}/*/*_counter_collection.csv")[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+fetch, write = pmc("fetch_e", "FETCH_SIZE"), pmc("write_e", "WRITE_SIZE")
+res = {}
+for k in sorted(set(fetch) | set(write)):
+    if "kvc::" in k:
+        fkb, wkb = fetch.get(k, 0.0), write.get(k, 0.0)
+        res[k[:100]] = {"FETCH_SIZE_KB_per_launch": fkb, "WRITE_SIZE_KB_per_launch": wkb,
+                        "hbm_bytes_per_launch": (2.0 * fkb + wkb) * 1024.0}
+dom = [k for k in res if "compact_runs_kernel" in k]
+summary = {"tag": tag, "command": "bench.py --steps 10 --warmup 2 --spare-blocks 60 (the default workload's step in a cache of 61 x its blocks)",
+           "kernels": res}
+if dom:
+    summary["dominant_kernel"] = dom[0]
+    summary["hbm_bytes_per_launch"] = res[dom[0]]["hbm_bytes_per_launch"]
+json.dump(summary, open(f"{out}/{tag}_traffic_engine.json", "w"), indent=1)
+print(json.dumps({k: v for k, v in summary.items() if k != "kernels"}))
+PY
+# 3c. config 3 at full size: kernel stats and PMC traffic of the small-eviction schedule
+"$REPO/tools/prof_bench.sh" "${TAG}_c3" --config c3 > "$OUT/${TAG}_c3_stats.txt" 2>&1
+cp "$REPO/gpurun_out/${TAG}_c3_kernel_stats.csv" "$OUT/" 2>/dev/null
+"$REPO/tools/collect_c3_pmc.sh" "$TAG" > "$OUT/${TAG}_c3_pmc.txt" 2>&1
+cp "$REPO/gpurun_out/${TAG}_c3_pmc.json" "$OUT/" 2>/dev/null
 cd "$REPO"
-B="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-adjacent --no-s0 --no-engine-cache"
+B="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-adjacent --no-s0 --no-engine-cache --no-other-configs"
 for shape in perm decay oldest; do
   for keep in 0.5 0.125 0.015625; do
     [ "$shape" = oldest ] && [ "$keep" = 0.015625 ] && continue
     timeout 300 $B --metric-shape $shape --keep $keep >> "$OUT/${TAG}_sweep.jsonl" 2>> "$OUT/sweep.err"
   done
 done
-for cfg in "--spare-blocks 30" "--spare-blocks 60" "--batch 4" "--batch 16 --steady-cap 4096" "--batch 64 --steady-cap 4096" "--config c3" "--config c3 --pass-block-tables" "--config c3 --lean" "--config c3i" "--config c4" "--config c5" "--layers 80 --seq-len 16384 --batch 4"; do
+for cfg in "--spare-blocks 30" "--spare-blocks 60" "--batch 4" "--batch 16 --steady-cap 4096" "--batch 64 --steady-cap 4096" "--config c3" "--config c3 --mode reference" "--config c3 --lean" "--config c3i" "--config c4" "--config c5" "--layers 80 --seq-len 16384 --batch 4"; do
   timeout 900 $B $cfg >> "$OUT/${TAG}_configs.jsonl" 2>> "$OUT/configs.err"
 done
 timeout 600 python tools/bench_attention.py > "$OUT/${TAG}_attention_bench.json" 2> "$OUT/attention.err"

@@ -1079,15 +1079,21 @@ __global__ __launch_bounds__(1024) void stream_pivot_kernel(kvc_schedule_params 
     if (n_keys == 0u) {
       rec.pivot_excl = KEY_INF;                      // an empty sample: every evictable key is a candidate
     } else if (n_keys <= (uint32_t)PIV_R * 1024u) {
-      // ---- the sample in registers
+      // ---- the sample in registers: a thread takes units of 8 consecutive keys (32 B; sample
+      // lengths are multiples of bs >= 8), one bisection per unit
       uint32_t key[PIV_R];
 #pragma unroll
-      for (int r = 0; r < PIV_R; ++r) {
-        const uint32_t x = (uint32_t)r * 1024u + (uint32_t)tid;
-        key[r] = 0xFFFFFFFFu;
-        if ((uint32_t)r * 1024u < n_keys) {          // (uniform)
-          if (x < n_keys) key[r] = ws.keys[locate(x)];
+      for (int r = 0; r < PIV_R; r += 8) {
+        const uint32_t x = ((uint32_t)(r / 8) * 1024u + (uint32_t)tid) * 8u;
+        uint4 k0 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu), k1 = k0;
+        if ((uint32_t)(r / 8) * 8192u < n_keys) {    // (uniform)
+          if (x < n_keys) {
+            const uint4* src = reinterpret_cast<const uint4*>(ws.keys + locate(x));
+            k0 = src[0]; k1 = src[1];
+          }
         }
+        key[r] = k0.x; key[r + 1] = k0.y; key[r + 2] = k0.z; key[r + 3] = k0.w;
+        key[r + 4] = k1.x; key[r + 5] = k1.y; key[r + 6] = k1.z; key[r + 7] = k1.w;
       }
       uint32_t prefix = 0, rank = 0;
       bool all = false;
@@ -1097,7 +1103,7 @@ __global__ __launch_bounds__(1024) void stream_pivot_kernel(kvc_schedule_params 
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < PIV_R; ++r) {
-          if ((uint32_t)r * 1024u >= n_keys) break;  // (uniform)
+          if ((uint32_t)(r / 8) * 8192u >= n_keys) break;  // (uniform)
           const bool valid = key[r] < KEY_INF && (round == 0 || (key[r] >> (shift + 8)) == prefix);
           hist_add(hist, valid, (key[r] >> shift) & 0xFFu);
         }
@@ -1566,6 +1572,42 @@ __global__ __launch_bounds__(256) void fix_unclaimed_kernel(kvc_schedule_params 
 // --------------------------------------------------------------------------- host side
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// The null padding of the output list is 4 B per candidate slot of pure HBM writes with nobody
+// waiting for it until the emission: on the small-eviction schedule it runs on a side stream,
+// forked off the caller's stream behind the sampling kernel and joined in front of emit_topk, so
+// that it runs next to the pivot kernel (registers and LDS: the HBM is idle) and into the start
+// of the collecting pass.  Measured at 256 x 1 M slots (step = S1 + S2 + S3): inline 1.92 ms;
+// forked at the very start 1.84 (the sampling pass lives on random accesses and is slowed down
+// as much as the fill is hidden); forked behind the sampling kernel 1.76; split with a part next
+// to the record / selection kernels 1.78-1.81 (S1 itself is 20 us shorter, but the list is then
+// still dirty in the caches when schedule_cache_moves starts, which pays 50 us for it).
+// One non-blocking stream and two events per (host thread, device), made on first use and kept;
+// never created under stream capture (a call that is being captured before any other gets the
+// fill inline).
+struct SideStream { hipStream_t s2 = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool failed = false; };
+static SideStream* side_stream(hipStream_t main) {
+  thread_local SideStream tab[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  SideStream& t = tab[dev & 63];
+  if (t.failed) return nullptr;
+  if (t.s2 == nullptr) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(main, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    if (hipStreamCreateWithFlags(&t.s2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&t.join, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      t.failed = true;
+      return nullptr;
+    }
+  }
+  return &t;
+}
+
 // > 64 KiB of dynamic LDS needs an opt-in per function AND per device (gfx950 has 160 KiB per CU):
 // done once per (function, device), whatever thread or device the caller is on
 static void allow_dynamic_lds(const void* fn, int bytes, std::atomic<uint64_t>& done) {
@@ -1633,9 +1675,11 @@ static void topk_plan(const kvc_schedule_params& p, int& p2_out, int& sshift) {
       (p.max_evicted_blocks_hint >= 0 && (int64_t)p.max_evicted_blocks_hint * 8 <= (int64_t)mch * LH);
   if (!hint_ok) return;
   p2_out = p2;
-  // sample stride: about 32 Ki sampled keys per sequence (a sequence's pivot is a low quantile of
-  // its sample, held in the registers of one workgroup); small sequences are sampled whole
-  int64_t stride = p.total_slots / p.num_seqs / 32768;
+  // sample stride: about 16 Ki sampled keys per sequence (a sequence's pivot is a low quantile of
+  // its sample, held in the registers of one workgroup; a sampled block costs ~9 random accesses,
+  // a candidate ~3: at 256 x 1 M slots stride 64 is where the two meet); small sequences are
+  // sampled whole
+  int64_t stride = p.total_slots / p.num_seqs / 16384;
   if (p.sample_stride > 0) stride = p.sample_stride;
   while (sshift < 8 && (2ll << sshift) <= stride) ++sshift;
 }
@@ -1723,9 +1767,13 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     // ---- small-eviction schedule (section 7): two memsets, 6 launches (+ 2 for the reference's batch > 1 rule); the general
     // pipeline is enqueued behind it and runs only if the flag was raised
     hipMemsetAsync(wb + l.tz_begin, 0, l.tz_end - l.tz_begin, s);
-    if (!(p.lean & 1))
-      hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.evicted_logical_indices), p.null_value,
-                        (size_t)p.total_slots, s);
+    SideStream* side = nullptr;
+    if (!(p.lean & 1)) {
+      if (p.total_slots >= (1 << 22)) side = side_stream(s);
+      if (side == nullptr)
+        hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.evicted_logical_indices), p.null_value,
+                          (size_t)p.total_slots, s);
+    }
     static std::atomic<uint64_t> sel_done{0};
     allow_dynamic_lds(reinterpret_cast<const void*>(seq_select_topk_kernel), 156 * 1024, sel_done);   // + its static tables
     // positions only for the slots whose metric lies below the pivot (stream_collect_kernel, LAZY):
@@ -1738,6 +1786,15 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
       if (p.block_size == 8) hipLaunchKernelGGL(stream_sample_kernel<8>, grid, blk, 0, s, p, ws, sshift);
       else if (p.block_size == 16) hipLaunchKernelGGL(stream_sample_kernel<16>, grid, blk, 0, s, p, ws, sshift);
       else hipLaunchKernelGGL(stream_sample_kernel<32>, grid, blk, 0, s, p, ws, sshift);
+    }
+    if (side != nullptr) {
+      if (hipEventRecord(side->fork, s) != hipSuccess || hipStreamWaitEvent(side->s2, side->fork, 0) != hipSuccess) {
+        (void)hipGetLastError();                     // (no side stream after all: inline)
+        side = nullptr;
+      }
+      hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.evicted_logical_indices), p.null_value,
+                        (size_t)p.total_slots, side != nullptr ? side->s2 : s);
+      if (side != nullptr) hipEventRecord(side->join, side->s2);
     }
     hipLaunchKernelGGL(stream_pivot_kernel, dim3(B), dim3(1024), 0, s, p, ws, sshift);
     {
@@ -1767,6 +1824,7 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
       hipLaunchKernelGGL(seq_prepare_kernel, dim3(1), dim3(1024), prep_lds, s, p, ws);
     }
     hipLaunchKernelGGL(seq_select_topk_kernel, dim3(B), dim3(1024), (size_t)topk_p2 * 8 + (size_t)LH * 4, s, p, ws, topk_p2, coupled_tk);
+    if (side != nullptr) hipStreamWaitEvent(s, side->join, 0);
     hipLaunchKernelGGL(emit_topk_kernel<4>, dim3((G + 3) / 4), dim3(256), 0, s, p, ws);
     ws.gate = ws.fallback;
   }
