@@ -94,3 +94,40 @@ def test_nccl_with_more_ranks_than_gpus_is_refused():
                           "--warmup", "0", "--seq-len", "1024"], capture_output=True, text=True,
                          timeout=600, cwd=REPO)
     assert out.returncode != 0 and "GPU(s)" in (out.stderr + out.stdout)
+
+
+def test_c4_preset_with_two_ranks_at_toy_size():
+    """BASELINE configs[3] (`--config c4`: the 70B shape as one of 8 GPUs sees it) goes through the
+    N > 1 path too, at a size two ranks sharing one GPU can hold: the preset's 80 layers and 32
+    sequences overridden by explicit flags, everything else -- rank-private caches, per-rank
+    shards, the all_gather of the two scalars -- as the driver will run it over RCCL"""
+    env = dict(os.environ, KVC_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--config", "c4",
+                          "--layers", "4", "--seq-len", "512", "--batch", "2", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and len(d["per_rank"]) == 2
+    assert d["config"]["workload"].startswith("c4:") and "batch 2/GPU" in d["config"]["workload"]
+    assert d["config"]["freed_blocks"] > 0 and all(r["units"] > 0 for r in d["per_rank"])
+
+
+def test_default_line_carries_the_other_configurations():
+    """the default workload also reports short runs of BASELINE configs[4] and configs[2] (here
+    with tiny step counts; bench.py shrinks a configuration that does not fit)"""
+    import bench
+    old = bench.OTHER_CONFIGS
+    out = subprocess.run([sys.executable, "-c",
+                          "import bench, sys; bench.OTHER_CONFIGS = (('c5', 2, 1), ('c3', 2, 1)); "
+                          "sys.argv = ['bench.py', '--steps', '3', '--warmup', '1', '--no-adjacent', '--no-s0', "
+                          "'--no-cpu-baseline', '--no-engine-cache', '--no-probe']; bench.main()"],
+                         capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    oc = {o["config"]: o for o in d["other_configs"]}
+    assert set(oc) == {"c5", "c3"} and old
+    for name, o in oc.items():
+        assert "skipped" not in o, o
+        assert o["stages_ms"]["S1_schedule_evictions"] > 0 and 0 < o["roofline"]["frac"] < 1
+        assert 0 < o["roofline"]["frac_of_floor"] < 1.2 and o["S1_lower_bound_GBps"] > 0
+    assert oc["c3"]["S1_schedule"] == "small_eviction" and oc["c5"]["S1_schedule"] == "general"

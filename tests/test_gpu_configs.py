@@ -145,6 +145,54 @@ def test_config5_full_query_range_prefill_metrics():
     np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-3, atol=1e-5)
 
 
+def test_config5_aggregation_at_its_own_size():
+    """BASELINE configs[4]'s aggregation half at ITS size: 65 536 keys, query blocks of
+    prefill_metric_collection_block_size = 1024, 32 query heads (reference
+    vllm/attention/backends/flash_attn.py:1122-1211).  (i) the A2c epilogue behind the library
+    GEMM + softmax and the fused collector (F4) agree on the last two query blocks (the tolerance
+    of tests/test_gpu_prefill_fused.py: the unfused path rounds its logits through fp16 einsum
+    output like the reference, the fused one reproduces that rounding); (ii) full query range, L1
+    metrics, no pooling, buffer 0: every query row hands out exactly 1, so a head's metrics sum to
+    the number of observed queries; (iii) SURVEY Q10: pooling happens per query block BEFORE the
+    accumulation -- two adjacent blocks pooled separately are not what one block of twice the
+    size gives, although their unpooled sums are identical."""
+    import gc
+    from vllm_kvcompress_amd.kvcompress.prefill import fused_kvc_attention, naive_kvc_attention
+    gc.collect()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 48 << 30:
+        pytest.skip("needs ~48 GiB of free HBM (one 1024 x 65536 x 32 probability tile is 8.6 GB)")
+    torch.manual_seed(5)
+    K, Hq, Hk, hd, qb = 65536, 32, 8, 128, 1024
+    q = (torch.randn(K, Hq, hd, device=DEV) * 0.7).half()
+    kk = (torch.randn(K, Hk, hd, device=DEV) * 0.7).half()
+    k_rep = kk.repeat_interleave(Hq // Hk, dim=1)
+    scale = hd ** -0.5
+    buf = torch.tensor([3], dtype=torch.int32)
+    # (i) two query blocks at the end of the sequence, L2 metrics, pooled
+    _, fused = fused_kvc_attention(q, kk, None, [K], scale, buf, n_observed=2 * qb, max_observed_block_size=qb)
+    _, naive = naive_kvc_attention(q, k_rep, None, [K], scale, buf, n_observed=2 * qb, max_observed_block_size=qb)
+    np.testing.assert_allclose(fused.cpu().numpy(), naive.cpu().numpy(), rtol=1e-2, atol=1e-4)
+    del naive, k_rep
+    torch.cuda.empty_cache()
+    # (iii) the same two blocks as ONE block of 2048 rows
+    _, one = fused_kvc_attention(q, kk, None, [K], scale, buf, n_observed=2 * qb, max_observed_block_size=2 * qb)
+    _, two_raw = fused_kvc_attention(q, kk, None, [K], scale, buf, n_observed=2 * qb, max_observed_block_size=qb,
+                                     use_maxpool=False)
+    _, one_raw = fused_kvc_attention(q, kk, None, [K], scale, buf, n_observed=2 * qb, max_observed_block_size=2 * qb,
+                                     use_maxpool=False)
+    np.testing.assert_allclose(two_raw.cpu().numpy(), one_raw.cpu().numpy(), rtol=2e-4, atol=1e-7)
+    assert bool((fused >= one * (1 - 1e-4)).all())    # max(a) + max(b) >= max(a + b)
+    assert float(((fused - one) / fused.clamp_min(1e-30)).max()) > 0.01     # and it does matter (values ~1e-6)
+    # (ii) full query range (64 query blocks), L1, unpooled, buffer 0
+    _, l1 = fused_kvc_attention(q, kk, None, [K], scale, torch.zeros(1, dtype=torch.int32), n_observed=K,
+                                max_observed_block_size=qb, use_l2=False, use_maxpool=False)
+    sums = l1.double().sum(0).cpu().numpy()
+    np.testing.assert_allclose(sums, np.full(Hq, float(K)), rtol=1e-4)
+    assert bool((l1 >= 0).all())
+
+
 @pytest.mark.parametrize("case", [0, 1, 2])
 def test_free_compressed_blocks_device(case):
     """F2 on device vs the reference-generated block-state vectors"""

@@ -267,3 +267,38 @@ def _multi_sequence_full_size(Lc, Hc, T, Bc, keep):
     coff = ((G + 2) * 4 + 15) // 16 * 16
     claims = ws[coff:coff + NB]
     assert int(claims.max()) == 1 and int((claims == 1).sum()) == (dst // BS).unique().numel()
+
+
+def test_one_process_drives_every_visible_device():
+    """Per-device state (the > 64 KiB dynamic-LDS opt-ins of select_emit / seq_select_topk, the
+    occupancy-sized grid of the compaction, the side stream of the small-eviction schedule, the
+    scratch caches) must be per device: ONE process runs the long-head pipeline (heads of 16 k
+    slots: 80 KiB of staged keys) and a steady-state step on cuda:0, cuda:1, ... in turn and
+    again in reverse order, each against the oracle."""
+    from tests.helpers import oracle_pipeline
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("one visible device (the 8-GPU node runs this)")
+    long_st = synth.make_state(num_layers=2, num_kv_heads=2, block_size=16, seq_lens=[16385], seed=3, protected=32)
+    long_ev = _evict(long_st, 0.5, 16384)
+    steady = synth.make_state(num_layers=4, num_kv_heads=4, block_size=16, seq_lens=[3000] * 2, seed=4,
+                              protected=17, steady_cap=1024, spare_block_frac=0.05)
+    steady_ev = [synth.evict_block_count(context_lens_lh=steady.context_lens[:, b, :], seq_len=3000, block_size=16,
+                                         protected_window_size=17, max_cache_tokens=1024) for b in range(2)]
+    k, v = synth.make_caches_u16(3, long_st.num_blocks, HD, BS)
+    want_long = oracle_pipeline(long_st, long_ev, k, v)
+    want_steady = oracle_pipeline(steady, steady_ev, mode="per_sequence")
+    for d in list(range(n)) + list(range(n - 1, -1, -1)):
+        dev = f"cuda:{d}"
+        with torch.cuda.device(dev):
+            ds = hdev.upload(long_st, dev)
+            eli, ekc, ebc, cmi, cmc = hdev.schedule(ds, long_st, long_ev)
+            kd, vd = torch.from_numpy(k.copy()).to(dev), torch.from_numpy(v.copy()).to(dev)
+            ops.execute_cache_moves(kd, vd, ds.cm.metrics, ds.cm.token_positions, cmi, cmc, ds.evicted_kv_offsets, 1, 16)
+            for name, got in (("eli", eli), ("ekc", ekc), ("cmi", cmi), ("cmc", cmc), ("k", kd), ("v", vd)):
+                np.testing.assert_array_equal(got.cpu().numpy(), want_long[name], err_msg=f"{name} on {dev}")
+            ds2 = hdev.upload(steady, dev, mode="per_sequence")
+            out = hdev.schedule(ds2, steady, steady_ev)
+            assert ds2.cm.last_schedule_path() == "small_eviction"
+            for name, got in zip(("eli", "ekc", "ebc", "cmi", "cmc"), out):
+                np.testing.assert_array_equal(got.cpu().numpy(), want_steady[name], err_msg=f"{name} on {dev}")
