@@ -98,7 +98,17 @@ def main():
             torch.from_numpy(last).to(DEV), torch.from_numpy(buf).to(DEV), 16, maxc, None, "auto", 1.0, 1.0, True)
     out1 = torch.zeros_like(q)
     km1 = torch.full((NB, 16, qpk), -1.0, device=DEV)
+    # start-up hooks reach the binding in effect: partitioned schedule forced (v1 then needs its
+    # scratch), scratch reserved -> the call itself allocates nothing
+    from vllm_kvcompress_amd import _custom_ops as ops2
+    ops2.set_attention_schedule(1)
+    ops2.reserve_attention_scratch(DEV, 3, 8, 128, 2, maxc)
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated()
     torch.ops._C.kvcompress_paged_attention_v1(out1, km1, q, kc.view(NB, 128 // 8, 16, 8), vc.view(NB, 128, 16), *args)
+    res["v1_allocated_bytes_after_reserve"] = torch.cuda.memory_allocated() - before
+    assert res["v1_allocated_bytes_after_reserve"] == 0, res
+    ops2.set_attention_schedule(0)
     parts = (maxc + 511) // 512
     es = torch.empty((3, 8, parts), device=DEV)
     ml = torch.empty_like(es)

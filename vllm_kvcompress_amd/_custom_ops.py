@@ -54,10 +54,22 @@ def workspace(device: torch.device, nbytes: int, tag: str) -> torch.Tensor:
     return buf
 
 
+def _compiled_binding() -> bool:
+    """True if the dispatcher ops come from libkvc_torch.so (torch_ops.register(): its C++ kernels
+    keep a scratch cache and an attention schedule of their own)"""
+    from . import torch_ops
+    return torch_ops._REGISTERED == "compiled"
+
+
 def reserve_workspace(device: torch.device, nbytes: int, tag: str) -> None:
     """Size a scratch buffer ahead of time (engine start-up / before HIP-graph capture) so that no
-    op ever allocates while serving."""
+    op ever allocates while serving -- the cache of this module and, when the compiled dispatcher
+    binding is the one registered, its cache as well (``_kvc_mi355x::reserve_workspace``)."""
     workspace(device, nbytes, tag)
+    if _compiled_binding():
+        like = torch.empty(0, dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            torch.ops._kvc_mi355x.reserve_workspace(like, int(nbytes), tag)
 
 
 def _contig(t: torch.Tensor, keep: list) -> torch.Tensor:
@@ -282,6 +294,8 @@ def set_attention_schedule(schedule: int) -> None:
     if schedule not in (0, 1, 2):
         raise ValueError("attention schedule must be 0, 1 or 2")
     _ATTENTION_SCHEDULE = int(schedule)
+    if _compiled_binding():       # the C++ kernels of libkvc_torch.so read their own copy
+        torch.ops._kvc_mi355x.set_attention_schedule(int(schedule))
 
 
 def _paged_attention_kvc(out, kv_metric_out, exp_sum, max_logits, tmp_out, tmp_kv_metric_out,

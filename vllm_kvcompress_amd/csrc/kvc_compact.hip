@@ -35,6 +35,7 @@
 // tiny planning kernels (tiles per head, exclusive scan, claims) let a fixed persistent
 // grid walk the tiles without host synchronisation.
 #include "kvc_common.h"
+#include <atomic>
 #include "../../include/kvc_mi355x.h"
 
 #ifndef KVC_RUNS_WGS
@@ -579,20 +580,20 @@ static int compact_check_args(int32_t total_heads, int64_t num_blocks, int32_t b
 // instantiation and device: LDS-bound, 2 block images per wave)
 template <int HD, int BS, int E, int WPB>
 static int compact_runs_grid() {
-  static int grid[64] = {0};
+  static std::atomic<int> grid[64];                  // (zero-initialised; any thread, any device)
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64) dev = 0;
-  if (grid[dev] == 0) {
+  if (grid[dev].load(std::memory_order_relaxed) == 0) {
     int per_cu = 0, cus = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, compact_runs_kernel<HD, BS, E, WPB>,
                                                      64 * WPB, 0) != hipSuccess || per_cu < 1)
       per_cu = 1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
       cus = 256;
-    grid[dev] = per_cu * cus;
+    grid[dev].store(per_cu * cus, std::memory_order_relaxed);
   }
-  return grid[dev];
+  return grid[dev].load(std::memory_order_relaxed);
 }
 
 }  // namespace kvc

@@ -16,6 +16,7 @@
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <optional>
@@ -61,6 +62,25 @@ Tensor workspace(const Tensor& like, size_t nbytes, const char* tag) {
     return buf;
   }
   return it->second;
+}
+
+// kvc_attention_params.schedule of the attention ops registered here (0 = automatic); set through
+// _kvc_mi355x::set_attention_schedule, like vllm_kvcompress_amd._custom_ops.set_attention_schedule
+// does for the Python-registered ops
+std::atomic<int> g_attention_schedule{0};
+
+// start-up hooks of this binding (vllm_kvcompress_amd._custom_ops.reserve_workspace /
+// reserve_attention_scratch / set_attention_schedule call them when this library is the one
+// registered): size a scratch buffer of THIS binding's cache ahead of time, so that its ops never
+// allocate while serving or inside a HIP-graph capture
+void reserve_workspace_op(const Tensor& like, int64_t nbytes, std::string tag) {
+  require(like, "like");
+  c10::DeviceGuard guard(like.device());
+  (void)workspace(like, (size_t)nbytes, tag.c_str());
+}
+void set_attention_schedule_op(int64_t schedule) {
+  TORCH_CHECK(schedule >= 0 && schedule <= 2, "attention schedule must be 0, 1 or 2");
+  g_attention_schedule.store((int)schedule);
 }
 
 // ------------------------------------------------------------------ _C_kvc_ops
@@ -253,6 +273,7 @@ void paged_attention_kvc(Tensor& out, Tensor& kv_metric_out, const Tensor* exp_s
   p.max_num_blocks_per_seq = (int32_t)bt.size(-1);
   p.max_context_len = (int32_t)max_context_len;
   p.dtype = dt; p.kv_cache_dtype = kvd; p.record_kv_metrics = record_kv_metrics ? 1 : 0;
+  p.schedule = g_attention_schedule.load();
   c10::DeviceGuard guard(query.device());
   Tensor scratch;                                   // v1: the small partition buffers the signature does not carry
   if (exp_sums != nullptr) {
@@ -263,7 +284,7 @@ void paged_attention_kvc(Tensor& out, Tensor& kv_metric_out, const Tensor* exp_s
     p.tmp_out = tmp_out->data_ptr();
     p.tmp_kv_metric_out = tmp_kv_metric_out->data_ptr<float>();
   } else if (kvc_paged_attention_decode_uses_partitions(p.num_seqs, p.num_heads, p.num_kv_heads, p.head_size,
-                                                        p.max_context_len, 0)) {
+                                                        p.max_context_len, p.schedule)) {
     const int64_t parts = (max_context_len + 511) / 512;
     const int64_t n = (int64_t)p.num_seqs * p.num_heads * parts;
     const size_t nbytes = (size_t)n * 8 + (size_t)n * p.head_size * query.element_size() + 256;
@@ -377,6 +398,12 @@ TORCH_LIBRARY_FRAGMENT(_C, m) {
           "int num_kv_heads, float scale, Tensor block_tables, Tensor context_lens, Tensor kv_position, "
           "Tensor last_position, Tensor kv_metric_buffer_len, int block_size, int max_context_len, "
           "Tensor? alibi_slopes, str kv_cache_dtype, float k_scale, float v_scale, bool record_kv_metrics) -> ()");
+}
+
+// not in the fork: the start-up hooks of this binding
+TORCH_LIBRARY_FRAGMENT(_kvc_mi355x, m) {
+  m.def("reserve_workspace(Tensor like, int nbytes, str tag) -> ()", &reserve_workspace_op);
+  m.def("set_attention_schedule(int schedule) -> ()", &set_attention_schedule_op);
 }
 
 TORCH_LIBRARY_IMPL(_C_kvc_ops, CUDA, m) {

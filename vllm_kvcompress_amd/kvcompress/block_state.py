@@ -27,7 +27,8 @@ def free_compressed_blocks(
     max_freed: Optional[int] = None,            # host-known upper bound: sum(evicted_blocks_per_seq)
 ) -> torch.Tensor:
     """Returns the freed physical blocks (int32, the reference's order).  ``max_freed`` sizes the
-    output list (default: every block of the batch, B*L*H*M entries)."""
+    output list (default: every block of the batch, B*L*H*M entries); a bound below what was
+    really freed raises instead of returning a truncated list."""
     lib = _lib.load()
     for n, t in (("block_tables", block_tables), ("context_lens", context_lens),
                  ("freed_block_count", freed_block_count), ("seq_index_by_block", seq_index_by_block)):
@@ -53,7 +54,13 @@ def free_compressed_blocks(
             context_lens.data_ptr(), seq_index_by_block.data_ptr(), fm_ptr, freed.data_ptr(), cap,
             total.data_ptr(), block_tables.data_ptr(), freed_block_count.data_ptr(), slots.data_ptr(),
             L, B, S, H, M, int(block_size), ws.data_ptr(), ws.numel(), _stream(block_tables)))
-    return freed[:int(total.item())]       # exact size like the reference (one host sync)
+    n = int(total.item())                  # exact size like the reference (one host sync)
+    if n > cap:
+        # the kernel freed n blocks (free_mask, metadata and context_lens say so) but could list only
+        # `cap` of them: an allocator fed from the list would leak the rest
+        raise RuntimeError(f"free_compressed_blocks: {n} blocks were freed but max_freed={cap} bounds the "
+                           "returned list; pass the true upper bound (sum of evicted_blocks_per_seq) or omit it")
+    return freed[:n]
 
 
 def append_slots(

@@ -144,6 +144,8 @@ def register(binding: str = "auto") -> str:
         _lib.load()                     # libkvc_mi355x.so first (and torch's HIP runtime before it)
         torch.ops.load_library(COMPILED_LIB)
         _REGISTERED = "compiled"
+        # the C++ kernels keep their own copy of the attention schedule
+        torch.ops._kvc_mi355x.set_attention_schedule(int(ops._ATTENTION_SCHEDULE))
         return _REGISTERED
     _bind("_C_kvc_ops", _KVC_SCHEMAS, {
         "schedule_cache_evictions": _v1_dead,
