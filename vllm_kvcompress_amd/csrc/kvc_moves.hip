@@ -128,6 +128,11 @@ __global__ __launch_bounds__(THREADS) void schedule_moves_heads_kernel(
   const int64_t seg_end = min((int64_t)rows, (g + 1 < G) ? (int64_t)offs[g + 1] : n_total);
   const int32_t* E = evicted + off;
   const int32_t* bt = block_tables + (int64_t)lbh * M;
+  // the zeros behind the head's cnt entries depend on nothing below: they go out first, so that
+  // the stores fly while the head's dependent loads (E, the block table) are still coming in --
+  // with thousands of short heads (one move each, 33 KB of zeros) the kernel was waiting for those
+  // loads with an idle store queue
+  if (zero_fill) zero_rows<THREADS>(mv2, off + cnt, seg_end, tid, THREADS);
   int nmoves = 0;
   const bool regular = cnt > 0 && E[cnt - 1] < ctx && (cnt + 31) / 32 <= BITMAP_WORDS;
   if (cnt > 0 && regular) {
@@ -186,7 +191,7 @@ __global__ __launch_bounds__(THREADS) void schedule_moves_heads_kernel(
     nmoves = lo;
   }
   if (tid == 0) count[g] = nmoves;
-  if (zero_fill) zero_rows<THREADS>(mv2, off + nmoves, seg_end, tid, THREADS);
+  if (zero_fill) zero_rows<THREADS>(mv2, off + nmoves, min(seg_end, off + cnt), tid, THREADS);
 }
 
 }  // namespace kvc

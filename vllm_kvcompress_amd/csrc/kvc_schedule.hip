@@ -738,14 +738,11 @@ __device__ void block_radix_select(uint32_t* hist, uint32_t* bc, int n, uint32_t
 
 // lds_cap = number of keys the dynamic LDS buffer can stage (0 = read keys from global/L2)
 template <int SEL_THREADS>
-__global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(kvc_schedule_params p, SchedWs ws, int lds_cap) {
-  if (gated_off(ws)) return;
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds_keys[];
+__device__ void select_emit_head(const kvc_schedule_params& p, SchedWs& ws, int lds_cap, int g, uint32_t* lds_keys) {
   __shared__ __attribute__((aligned(16))) uint32_t hist[RADIX];
   __shared__ uint32_t bc[4];
   __shared__ uint32_t scan_buf[8 * (SEL_THREADS / WAVE) + 1];
   const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
-  const int g = blockIdx.x;
   const int bs = p.block_size;
   const int64_t base = p.evicted_kv_offsets[g];
   const int64_t end = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : p.total_slots;
@@ -882,6 +879,20 @@ __global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(kvc_schedule_p
   }
   if (!(p.lean & 1))
     for (int idx = (int)cnt + tid; idx < n; idx += blockDim.x) out[idx] = p.null_value;
+}
+
+// one workgroup per head; behind the small-eviction schedule (gated: a launch that normally finds
+// the flag down) the grid is capped and a workgroup walks several heads -- 65 536 workgroups that
+// only read the flag took 15 us, a capped grid takes what every gated launch takes
+template <int SEL_THREADS>
+__global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(kvc_schedule_params p, SchedWs ws, int lds_cap) {
+  if (gated_off(ws)) return;
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_keys[];
+  const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
+  for (int g = blockIdx.x; g < G; g += gridDim.x) {
+    select_emit_head<SEL_THREADS>(p, ws, lds_cap, g, lds_keys);
+    __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------ 7. small-eviction schedule
@@ -1903,13 +1914,14 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     // (heads beyond 32k slots read their keys from L2: measured faster than one 144 KiB
     // staging workgroup per CU)
     const int lds_cap = (int)(want < 2048 ? 2048 : (want > 32768 ? 32768 : want));
+    const unsigned sel_grid = (unsigned)((topk && G > 2048) ? 2048 : G);   // (gated: see select_emit_kernel)
     // > 64 KiB of dynamic LDS needs the opt-in (gfx950 has 160 KiB per CU); per device, cheap
     if (avg <= 8192) {
-      hipLaunchKernelGGL(select_emit_kernel<256>, dim3(G), dim3(256), (size_t)lds_cap * 4, s, p, ws, lds_cap);
+      hipLaunchKernelGGL(select_emit_kernel<256>, dim3(sel_grid), dim3(256), (size_t)lds_cap * 4, s, p, ws, lds_cap);
     } else {
       static std::atomic<uint64_t> long_done{0};
       allow_dynamic_lds(reinterpret_cast<const void*>(select_emit_kernel<1024>), 32768 * 4, long_done);
-      hipLaunchKernelGGL(select_emit_kernel<1024>, dim3(G), dim3(1024), (size_t)lds_cap * 4, s, p, ws, lds_cap);
+      hipLaunchKernelGGL(select_emit_kernel<1024>, dim3(sel_grid), dim3(1024), (size_t)lds_cap * 4, s, p, ws, lds_cap);
     }
   }
   return check_launch("schedule_evictions");
