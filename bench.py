@@ -94,6 +94,9 @@ def parse_args(argv=None):
                     help="skip the second measurement of the same step in an HBM-filling cache")
     ap.add_argument("--engine-cache-frac", type=float, default=0.80,
                     help="fraction of the free HBM that second cache takes")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not run the two short rocprofv3 --pmc passes that measure roofline.traffic (the "
+                         "committed figure of profiles/traffic.json is reported instead)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short runs of BASELINE configs[4] / configs[2] the default line carries")
     ap.add_argument("--no-probe", action="store_true",
@@ -306,6 +309,45 @@ def s0_stages(args, device):
     return out
 
 
+def live_pmc_traffic(extra_flags, timeout=240):
+    """HBM bytes per launch of the compaction kernel from the TCC counters, measured NOW: two short
+    runs of this same script under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate
+    passes, no trace domain, as MI355X_MICROARCH.md prescribes; FETCH doubled for a wide streaming
+    kernel on gfx950).  None if rocprofv3 is missing or a pass fails -- the committed figure of
+    profiles/ is used then."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+           "--no-adjacent", "--no-s0", "--no-probe", "--no-engine-cache", "--no-other-configs",
+           "--no-live-traffic"] + list(extra_flags)
+    env = dict(os.environ, TMPDIR="/tmp")
+    vals = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            try:
+                r = subprocess.run([exe, "--pmc", counter, "-d", out, "--output-format", "csv", "--"] + cmd,
+                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+            except (subprocess.TimeoutExpired, OSError):
+                return None
+            files = glob.glob(os.path.join(out, "*", "*_counter_collection.csv"))
+            if r.returncode != 0 or not files:
+                return None
+            v = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                 if row["Counter_Name"] == counter and "compact_runs_kernel" in row["Kernel_Name"]]
+            if not v:
+                return None
+            vals[counter] = sum(v) / len(v)
+    return {"hbm_bytes_per_launch": (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
+            "FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"]}
+
+
 def measure_workload(a2, seed, device, steps, warmup, probe):
     """One workload, timed like the main loop (HIP events on the launch stream around every stage
     and around the compaction kernel): per-stage ms, whole-step rate, the compaction kernel's
@@ -393,10 +435,20 @@ def engine_sized_cache_run(args, rank, device, steps=20, warmup=3):
         return None
     res = {"what": f"the same step, the sequence's blocks scattered over a cache that fills {args.engine_cache_frac:.0%} of the free HBM "
                    "(as an engine sizes it) instead of one sized to the sequence", **res}
-    # PMC traffic of this placement: a separately profiled run of the same step in a cache of 61 x the
-    # sequence's blocks (tools/collect_profiles.sh: bench.py --spare-blocks 60), committed
+    # PMC traffic of this placement: measured now (two short rocprofv3 passes over the same step in a
+    # cache of the same size), else the committed figure of a separately profiled run in a cache of
+    # 61 x the sequence's blocks (tools/collect_profiles.sh: bench.py --spare-blocks 60)
+    live = None if args.no_live_traffic else live_pmc_traffic(["--spare-blocks", f"{a2.spare_blocks:.3f}"], timeout=300)
     tj_path = os.path.join(REPO, "profiles", "traffic_engine.json")
-    if os.path.exists(tj_path):
+    if live is not None:
+        t = live["hbm_bytes_per_launch"]
+        res["roofline"]["traffic"] = t
+        res["roofline"]["traffic_frac_of_peak"] = t / (res["roofline"]["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+        res["roofline"]["traffic_source"] = (
+            "measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over 3 steps of "
+            f"`bench.py --spare-blocks {a2.spare_blocks:.3f}` (the same step in a cache of the same size; 2 x FETCH + WRITE, "
+            f"FETCH_SIZE {live['FETCH_SIZE_KB']:.0f} KB, WRITE_SIZE {live['WRITE_SIZE_KB']:.0f} KB per launch)")
+    elif os.path.exists(tj_path):
         try:
             tj = json.load(open(tj_path))
             t = tj.get("hbm_bytes_per_launch")
@@ -701,7 +753,13 @@ def main():
                                 32, 8, 128, 16, 32768, 1, 0.5, 32, "perm", "fp16", 0, False, 0.02)
         # the committed PMC figure belongs to the default workload only; it is a separately
         # profiled run of the same kernel and workload, not a measurement of this run
-        if default_workload and os.path.exists(args.traffic_json):
+        live = live_pmc_traffic([]) if (default_workload and world == 1 and not args.no_live_traffic) else None
+        if live is not None:
+            traffic = live["hbm_bytes_per_launch"]
+            traffic_source = ("measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over 3 "
+                              "steps of this same workload (2 x FETCH + WRITE; FETCH_SIZE "
+                              f"{live['FETCH_SIZE_KB']:.0f} KB, WRITE_SIZE {live['WRITE_SIZE_KB']:.0f} KB per launch)")
+        elif default_workload and os.path.exists(args.traffic_json):
             try:
                 tj = json.load(open(args.traffic_json))
                 traffic = tj.get("hbm_bytes_per_launch")

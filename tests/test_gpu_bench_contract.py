@@ -23,7 +23,7 @@ def _last_json(stdout):
 
 def test_single_rank_line():
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "4", "--warmup", "1",
-                          "--seq-len", "4096", "--no-adjacent", "--engine-cache-frac", "0.02"],
+                          "--seq-len", "4096", "--no-adjacent", "--engine-cache-frac", "0.02", "--no-live-traffic"],
                          capture_output=True, text=True,
                          timeout=600, cwd=REPO)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -131,3 +131,22 @@ def test_default_line_carries_the_other_configurations():
         assert o["stages_ms"]["S1_schedule_evictions"] > 0 and 0 < o["roofline"]["frac"] < 1
         assert 0 < o["roofline"]["frac_of_floor"] < 1.2 and o["S1_lower_bound_GBps"] > 0
     assert oc["c3"]["S1_schedule"] == "small_eviction" and oc["c5"]["S1_schedule"] == "general"
+
+
+def test_engine_leg_traffic_is_measured_live():
+    """roofline.traffic of the engine-sized leg comes from two short rocprofv3 --pmc passes the
+    bench runs itself (FETCH_SIZE / WRITE_SIZE, separate passes); here at a small size.  The
+    measured bytes lie between the layout floor and twice it."""
+    import shutil
+    if shutil.which("rocprofv3") is None and not os.path.exists("/opt/rocm/bin/rocprofv3"):
+        pytest.skip("no rocprofv3 on this box")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "1",
+                          "--seq-len", "4096", "--no-adjacent", "--no-s0", "--no-cpu-baseline", "--no-probe",
+                          "--engine-cache-frac", "0.02"],
+                         capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    r = d["engine_sized_cache"]["roofline"]
+    assert r["traffic_source"].startswith("measured by this run"), r.get("traffic_source")
+    floor = r["floor_GBps"] * 1e9 * r["avg_launch_ms"] * 1e-3
+    assert 0.8 * floor < r["traffic"] < 2.0 * floor
