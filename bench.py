@@ -309,6 +309,21 @@ def s0_stages(args, device):
     return out
 
 
+def workload_flags(args):
+    """the command-line flags that reproduce this run's workload (for the PMC passes)"""
+    f = ["--config", args.config, "--layers", str(args.layers), "--kv-heads", str(args.kv_heads),
+         "--head-size", str(args.head_size), "--block-size", str(args.block_size), "--seq-len", str(args.seq_len),
+         "--batch", str(args.batch), "--keep", str(args.keep), "--protected", str(args.protected),
+         "--metric-shape", args.metric_shape, "--mode", args.mode, "--kv-dtype", args.kv_dtype]
+    if args.steady_cap:
+        f += ["--steady-cap", str(args.steady_cap)]
+    if args.contiguous_blocks:
+        f.append("--contiguous-blocks")
+    if args.lean:
+        f.append("--lean")
+    return f
+
+
 def live_pmc_traffic(extra_flags, timeout=240):
     """HBM bytes per launch of the compaction kernel from the TCC counters, measured NOW: two short
     runs of this same script under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate
@@ -438,7 +453,8 @@ def engine_sized_cache_run(args, rank, device, steps=20, warmup=3):
     # PMC traffic of this placement: measured now (two short rocprofv3 passes over the same step in a
     # cache of the same size), else the committed figure of a separately profiled run in a cache of
     # 61 x the sequence's blocks (tools/collect_profiles.sh: bench.py --spare-blocks 60)
-    live = None if args.no_live_traffic else live_pmc_traffic(["--spare-blocks", f"{a2.spare_blocks:.3f}"], timeout=300)
+    live = None if args.no_live_traffic else live_pmc_traffic(
+        workload_flags(args) + ["--spare-blocks", f"{a2.spare_blocks:.3f}"], timeout=300)
     tj_path = os.path.join(REPO, "profiles", "traffic_engine.json")
     if live is not None:
         t = live["hbm_bytes_per_launch"]
@@ -753,7 +769,8 @@ def main():
                                 32, 8, 128, 16, 32768, 1, 0.5, 32, "perm", "fp16", 0, False, 0.02)
         # the committed PMC figure belongs to the default workload only; it is a separately
         # profiled run of the same kernel and workload, not a measurement of this run
-        live = live_pmc_traffic([]) if (default_workload and world == 1 and not args.no_live_traffic) else None
+        live = (live_pmc_traffic(workload_flags(args) + ["--spare-blocks", str(args.spare_blocks)])
+                if (world == 1 and not args.no_live_traffic) else None)
         if live is not None:
             traffic = live["hbm_bytes_per_launch"]
             traffic_source = ("measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over 3 "
