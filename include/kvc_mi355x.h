@@ -135,6 +135,10 @@ int kvc_execute_cache_moves_apply(void* k_cache, void* v_cache, float* kv_metric
  * seq_slot_of_seq[s] = batch slot of sequence index s, or -1 (size seq_slot_len).
  * bias may be NULL (== the reference's default zero bias, metrics.py:166-173).
  * total_slots N = sum over heads of ceil(ctx/bs)*bs (== size of evicted_logical_indices).
+ * Asynchronous on `stream`.  The small-eviction schedule runs the null padding of
+ * evicted_logical_indices on a side stream of the library's own (created on first use per host
+ * thread and device, outside stream capture; forked off and joined back into `stream` inside
+ * the call, so the call's results are ordered on `stream` like every other entry point's).
  * --------------------------------------------------------------------------------- */
 typedef struct kvc_schedule_params {
   /* CompressionMetrics state (metrics.py:220-275) */
@@ -176,10 +180,11 @@ typedef struct kvc_schedule_params {
   int32_t max_evicted_blocks_hint;            /* host-known upper bound of evicted_blocks_per_seq (the
                                                * reference passes a Python list, scheduler.py:184-560),
                                                * or -1 if unknown.  Picks the schedule: when a step frees
-                                               * on average <= 2 blocks per head (bs 16) of short heads --
-                                               * the continual-compression steady state -- every key is
-                                               * read once instead of five times.  Results
-                                               * are identical either way; a wrong hint only costs time. */
+                                               * on average <= 2 blocks per head (bs 16) -- the continual-
+                                               * compression steady state -- the metric store is streamed
+                                               * once, in physical order, instead of a key per slot being
+                                               * written and read five times.  Results are
+                                               * identical either way; a wrong hint only costs time. */
   const int32_t* block_tables;                /* accepted and ignored since ABI version 2 (BlockState.block_tables
                                                * [L, max_num_seqs, H, block_tables_width]; the round-2
                                                * small-eviction schedule gathered rows through it, the
