@@ -980,6 +980,7 @@ __global__ __launch_bounds__(256) void stream_sample_kernel(kvc_schedule_params 
   constexpr int LPB = BS / 4, BPD = 64 / LPB;        // lanes per block, blocks per drain
   constexpr int QCAP = 64 + BPD;
   __shared__ uint32_t q_blk[4][QCAP];
+  __shared__ uint32_t q1_blk[4][128];                // first stage: hashed-in blocks, membership not looked at yet
   const int lane = lane_id(), w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int64_t wave = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
   const int L = p.num_layers, H = p.num_kv_heads;
@@ -1017,16 +1018,40 @@ __global__ __launch_bounds__(256) void stream_sample_kernel(kvc_schedule_params 
     qn -= n;
     wave_lds_sync();
   };
+  // First stage: 64 hashed-in blocks at a time, one per lane -- is the block's sequence in the
+  // batch at all?  (In an engine-sized cache most sampled blocks belong to other sequences or to
+  // nobody: the 4-lane drain with its four metadata gathers per block is for the batch's only.)
+  int q1n = 0;
+  auto filter = [&](int n) {                         // pops the top n (<= 64) first-stage entries
+    wave_lds_sync();
+    bool in = lane < n;
+    const uint32_t blk = in ? q1_blk[w][q1n - n + lane] : 0u;
+    int sq = -1;
+    if (in) sq = p.seq_index_by_block[blk];
+    in = in && sq >= 0 && sq < p.seq_slot_len;
+    int i = -1;
+    if (in) i = p.seq_slot_of_seq[sq];
+    in = in && i >= 0;
+    q1n -= n;
+    const unsigned long long bal = __ballot(in);
+    if (bal) {                                       // wave-uniform
+      if (in) q_blk[w][qn + __popcll(bal & ((1ull << lane) - 1ull))] = blk;
+      qn += __popcll(bal);
+      while (qn >= BPD) drain(BPD);
+    }
+    wave_lds_sync();
+  };
   for (int64_t b0 = wave * 64; b0 < p.num_blocks; b0 += nwaves * 64) {
     const int64_t blk = b0 + lane;
     const bool take = blk < p.num_blocks && block_sampled((uint32_t)blk, smask);
     const unsigned long long bal = __ballot(take);
     if (bal) {                                       // wave-uniform
-      if (take) q_blk[w][qn + __popcll(bal & ((1ull << lane) - 1ull))] = (uint32_t)blk;
-      qn += __popcll(bal);
-      while (qn >= BPD) drain(BPD);
+      if (take) q1_blk[w][q1n + __popcll(bal & ((1ull << lane) - 1ull))] = (uint32_t)blk;
+      q1n += __popcll(bal);
+      if (q1n >= 64) filter(64);
     }
   }
+  if (q1n > 0) filter(q1n);
   while (qn > 0) drain(min(qn, BPD));
 }
 
@@ -1201,10 +1226,11 @@ __global__ __launch_bounds__(256) void stream_collect_kernel(kvc_schedule_params
   static_assert(BPW <= 64, "one metadata load covers the iteration's blocks");
   __shared__ uint32_t qk[4][128], qs[4][128], qg[4][128];
   __shared__ int32_t ql[LAZY ? 4 : 1][128];          // LAZY: highest evictable position of the entry's sequence
+  __shared__ uint32_t list_s[DENSE ? 1 : SPARSE_CHUNK];   // !DENSE: (batch position << 12) | block - chunk base
+  __shared__ uint32_t n_s;
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   const int lane = lane_id(), w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int64_t wave = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
   const int L = p.num_layers, H = p.num_kv_heads;
   unsigned long long* lists = reinterpret_cast<unsigned long long*>(ws.rec64);
   uint32_t claimed = 0;
@@ -1227,16 +1253,17 @@ __global__ __launch_bounds__(256) void stream_collect_kernel(kvc_schedule_params
     qn -= n;
     wave_lds_sync();
   };
-  for (int64_t b0 = wave * BPW; b0 < p.num_blocks; b0 += nwaves * BPW) {
+  // One wave iteration: lane j < BPW looks after block mb (have: there is one); i_known >= 0: its
+  // batch position is known already (sparse sweep), else the sequence index is looked up here.
+  auto iteration = [&](int64_t mb, bool have, int i_known) {
     f32x4 m[U];
     i32x4 q[U];
     auto load_rows = [&](unsigned long long want) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int src = u * BPL + lane / LPB;
-        int64_t blk = b0 + src;
-        if (blk >= p.num_blocks) blk = p.num_blocks - 1;
-        if (DENSE || ((want >> src) & 1ull)) {
+        const int64_t blk = DENSE ? mb - lane + src : (int64_t)(uint32_t)__shfl((int)(uint32_t)mb, src, 64);
+        if ((want >> src) & 1ull) {
           m[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.metrics + blk * BS) + (lane % LPB));
           if constexpr (!LAZY)
             q[u] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(p.token_positions + blk * BS) + (lane % LPB));
@@ -1248,12 +1275,17 @@ __global__ __launch_bounds__(256) void stream_collect_kernel(kvc_schedule_params
         }
       }
     };
-    if constexpr (DENSE) load_rows(~0ull);
-    const int64_t mb = b0 + lane;
-    const BlockMeta mt = load_meta(p, mb, lane < BPW && mb < p.num_blocks);
-    bool ok = mt.s >= 0 && mt.s < p.seq_slot_len;
-    if constexpr (!DENSE) { if (__ballot(ok) == 0ull) continue; }   // wave-uniform: nothing of the batch here
-    int i = p.seq_slot_of_seq[ok ? mt.s : 0];
+    const unsigned long long havem = __ballot(have);
+    if constexpr (DENSE) load_rows(havem);           // the rows do not wait for the metadata
+    BlockMeta mt{-1, 0, 0, 0};
+    if constexpr (DENSE) {
+      mt = load_meta(p, mb, have);
+    } else if (have) {                               // (the sweep has looked at the sequence index already)
+      mt.l = p.layer_index_by_block[mb]; mt.h = p.head_index_by_block[mb];
+      mt.lbn = p.logical_block_num_by_block[mb];
+    }
+    bool ok = have && (i_known >= 0 || (mt.s >= 0 && mt.s < p.seq_slot_len));
+    int i = i_known >= 0 ? i_known : p.seq_slot_of_seq[ok ? mt.s : 0];
     ok = ok && i >= 0 && mt.l >= 0 && mt.l < L && mt.h >= 0 && mt.h < H;
     const int l = ok ? mt.l : 0, h = ok ? mt.h : 0;
     if (!ok) i = 0;
@@ -1261,7 +1293,7 @@ __global__ __launch_bounds__(256) void stream_collect_kernel(kvc_schedule_params
     const SeqRec r = ws.st_seqrec[i];
     ok = ok && mt.lbn >= 0 && mt.lbn < (ctx + BS - 1) / BS;
     const unsigned long long okm = __ballot(ok);
-    if (okm == 0ull) continue;                       // wave-uniform
+    if (okm == 0ull) return;                         // wave-uniform
     claimed += (uint32_t)__popcll(okm);
     if constexpr (!DENSE) load_rows(okm);
     const int g = ok ? (i * L + l) * H + h : -1;
@@ -1273,11 +1305,12 @@ __global__ __launch_bounds__(256) void stream_collect_kernel(kvc_schedule_params
       const int gg = __shfl(g, src, 64);
       const int spp = __shfl(seq_pos, src, 64), prr = __shfl(prot, src, 64);
       const uint32_t pvv = (uint32_t)__shfl((int)pex, src, 64);
+      const uint32_t blk32 = DENSE ? (uint32_t)(mb - lane + src) : (uint32_t)__shfl((int)(uint32_t)mb, src, 64);
       int ll = 0, hh = 0;
       if (p.bias != nullptr) { ll = __shfl(l, src, 64); hh = __shfl(h, src, 64); }
       const float mm[4] = {m[u].x, m[u].y, m[u].z, m[u].w};
       const int qq[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
-      const uint32_t slot0 = (uint32_t)((b0 + src) * BS + (lane % LPB) * 4);
+      const uint32_t slot0 = blk32 * (uint32_t)BS + (uint32_t)(lane % LPB) * 4u;
       int ninf = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -1300,6 +1333,59 @@ __global__ __launch_bounds__(256) void stream_collect_kernel(kvc_schedule_params
 #pragma unroll
         for (int d = 1; d < LPB; d <<= 1) ninf += __shfl_xor(ninf, d, 64);
         if (lane % LPB == 0 && ninf > 0) atomicAdd(&ws.st_def[gg], (uint32_t)ninf);
+      }
+    }
+  };
+  if constexpr (DENSE) {
+    const int64_t wave = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t b0 = wave * BPW; b0 < p.num_blocks; b0 += nwaves * BPW) {
+      const int64_t mb = b0 + lane;
+      iteration(mb, lane < BPW && mb < p.num_blocks, -1);
+    }
+  } else {
+    // An engine sizes its cache to HBM: most blocks do not belong to the batch.  A workgroup sweeps
+    // SPARSE_CHUNK consecutive blocks -- every thread requests its share of the sequence indices at
+    // once (one round trip), the batch's blocks are compacted into an LDS list -- and the list is
+    // then worked off densely, 64 blocks per wave iteration like above (the per-block chain of
+    // lookups run for every block of a 30 M-block cache cost 0.3 ms for a batch of 1 M blocks).
+    const int tid = threadIdx.x;
+    int sidx[SPARSE_SCAN], snext[SPARSE_SCAN];
+    auto request = [&](int64_t base, int* dst) {       // the chunk's sequence indices, one round trip
+#pragma unroll
+      for (int u = 0; u < SPARSE_SCAN; ++u) {
+        const int64_t blk = base + u * 256 + tid;
+        dst[u] = blk < p.num_blocks ? p.seq_index_by_block[blk] : -1;
+      }
+    };
+    const int64_t stride = (int64_t)gridDim.x * SPARSE_CHUNK;
+    int64_t base = (int64_t)blockIdx.x * SPARSE_CHUNK;
+    if (base < p.num_blocks) request(base, snext);
+    for (; base < p.num_blocks; base += stride) {
+      __syncthreads();
+      if (tid == 0) n_s = 0;
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < SPARSE_SCAN; ++u) sidx[u] = snext[u];
+      // the next chunk's indices are requested now and arrive while this chunk's list is worked off
+      if (base + stride < p.num_blocks) request(base + stride, snext);
+#pragma unroll
+      for (int u = 0; u < SPARSE_SCAN; ++u) {
+        const int sq = sidx[u];
+        int i = -1;
+        if (sq >= 0 && sq < p.seq_slot_len) i = p.seq_slot_of_seq[sq];
+        const unsigned long long mask = __ballot(i >= 0);
+        if (mask == 0ull) continue;                     // wave-uniform
+        uint32_t wbase = 0;
+        if (lane == 0) wbase = atomicAdd(&n_s, (uint32_t)__popcll(mask));
+        wbase = (uint32_t)__shfl((int)wbase, 0, 64);
+        if (i >= 0) list_s[wbase + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = ((uint32_t)i << 12) | (uint32_t)(u * 256 + tid);
+      }
+      __syncthreads();
+      const int n = (int)n_s;
+      for (int e0 = w * BPW; e0 < n; e0 += 4 * BPW) {
+        const bool have = lane < BPW && e0 + lane < n;
+        const uint32_t ent = have ? list_s[e0 + lane] : 0u;
+        iteration(base + (int64_t)(ent & 4095u), have, have ? (int)(ent >> 12) : -1);
       }
     }
   }
@@ -1820,7 +1906,7 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
       // blocks of the batch / blocks of the cache: a dense cache requests the rows before it has
       // looked at the metadata, a sparse one (engine-sized cache, small batch) only the batch's rows
       const bool dense = p.total_slots >= (int64_t)p.num_blocks * p.block_size / 2;
-      int64_t cb = (p.num_blocks + 255) / 256;
+      int64_t cb = dense ? (p.num_blocks + 255) / 256 : (p.num_blocks + kvc::SPARSE_CHUNK - 1) / kvc::SPARSE_CHUNK;
       cb = cb < 1 ? 1 : (cb > 4096 ? 4096 : cb);
       const dim3 grid((unsigned)cb), blk(256);
 #define KVC_COLLECT(BSV)                                                                                  \
