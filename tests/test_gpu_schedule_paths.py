@@ -346,3 +346,27 @@ def test_sparse_batch_in_a_large_cache(bs, hd):
                                  ("cmi", cmi, want["cmi"]), ("cmc", cmc, want["cmc"]), ("k", kd, want["k"]),
                                  ("v", vd, want["v"]), ("metrics", ds.cm.metrics, want["metrics"])):
                 np.testing.assert_array_equal(got.cpu().numpy(), w, err_msg=f"{name} bs={bs} seed={seed} {mode}")
+
+
+def test_a_raised_flag_sends_the_next_calls_to_the_general_schedule():
+    """host policy (CompressionMetrics): a small-eviction call that had to fall back costs the
+    streaming pass and the single-launch general pipeline; its flag reaches the host asynchronously
+    and the next automatic calls take the general schedule -- 1, then 2, 4 ... calls -- before the
+    small-eviction one is tried again.  Results never change."""
+    st, evicted = _steady(4, 4, 16, 1, 1024, 5)
+    blocks = np.nonzero((st.layer_index_by_block == 1) & (st.head_index_by_block == 2) & (st.seq_index_by_block == 0))[0]
+    st.metrics[blocks] -= np.float32(1e7)
+    evicted = [30]                  # <= 2 blocks per head (the hint admits it), all from one head: more than a record holds
+    want = oracle_pipeline(st, evicted, mode="per_sequence")
+    ds = hdev.upload(st, DEV, mode="per_sequence")
+    ds.cm.schedule_path = 0
+    args = (list(st.seq_indices), ds.seq_positions, evicted, ds.context_lens, ds.hanging_token_count,
+            ds.evicted_kv_offsets, list(st.protected))
+    hows = []
+    for _ in range(8):
+        out = ds.cm.schedule_evictions(*args, total_slots=st.total_slots)
+        hows.append(ds.cm.last_schedule_path())      # (synchronises: the flag copy has landed by the next call)
+        for got, key in zip(out, ("eli", "ekc", "ebc")):
+            np.testing.assert_array_equal(got.cpu().numpy(), want[key], err_msg=key)
+    assert hows == ["small_eviction+fallback", "general", "small_eviction+fallback", "general", "general",
+                    "small_eviction+fallback", "general", "general"], hows

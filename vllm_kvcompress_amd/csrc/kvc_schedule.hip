@@ -55,6 +55,7 @@ struct SchedWs {
   struct SeqRec* st_seqrec;  // [B]  per sequence: position, protected window, pivot
   uint32_t* head_fc;     // [2G]     per head: finite-threshold chunks, all chunks (stream_records)
   uint32_t* fallback;    // [1]      != 0: the small-eviction schedule could not finish exactly
+  uint32_t* bar;         // [1]      arrivals at the grid barrier of the single-launch fallback
   const uint32_t* gate;  // general-path kernels run only if gate == nullptr or *gate != 0
 };
 
@@ -117,20 +118,20 @@ __device__ __forceinline__ uint32_t slot_key(const kvc_schedule_params& p, float
 }
 
 // one thread per VEC consecutive slots of a physical block (VEC = 4: 16 B loads and stores)
+// the counters of the later passes <- 0 (workgroup bid of nb)
+__device__ __forceinline__ void zero_body(uint4* zero16, int64_t zero_vecs, unsigned bid, unsigned nb) {
+  for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < zero_vecs; i += (int64_t)nb * 256)
+    zero16[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// (bodies take the workgroup's index and the number of workgroups as arguments: the kernels below
+// pass blockIdx / gridDim, the single-launch fallback of the small-eviction schedule its own)
 template <int VEC>
-__global__ __launch_bounds__(256) void build_keys_kernel(kvc_schedule_params p, SchedWs ws,
-                                                         unsigned data_blocks, uint4* zero16, int64_t zero_vecs) {
-  if (gated_off(ws)) return;
-  if (blockIdx.x >= data_blocks) {      // tail workgroups clear the counters of the later passes
-    for (int64_t i = (int64_t)(blockIdx.x - data_blocks) * 256 + threadIdx.x; i < zero_vecs;
-         i += (int64_t)(gridDim.x - data_blocks) * 256)
-      zero16[i] = make_uint4(0u, 0u, 0u, 0u);
-    return;
-  }
+__device__ __forceinline__ void build_keys_body(const kvc_schedule_params& p, SchedWs& ws, unsigned bid, unsigned data_blocks) {
   const int bs = p.block_size;
   const int per_blk = bs / VEC;
   // (grid-stride: behind the small-eviction schedule this kernel is launched gated, with a small grid)
-  for (int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; tid < p.num_blocks * per_blk;
+  for (int64_t tid = (int64_t)bid * blockDim.x + threadIdx.x; tid < p.num_blocks * per_blk;
        tid += (int64_t)data_blocks * blockDim.x) {
   const int64_t blk = tid / per_blk;
   const int off = (int)(tid % per_blk) * VEC;
@@ -173,6 +174,17 @@ __global__ __launch_bounds__(256) void build_keys_kernel(kvc_schedule_params p, 
   }
 }
 
+template <int VEC>
+__global__ __launch_bounds__(256) void build_keys_kernel(kvc_schedule_params p, SchedWs ws,
+                                                         unsigned data_blocks, uint4* zero16, int64_t zero_vecs) {
+  if (gated_off(ws)) return;
+  if (blockIdx.x >= data_blocks) {      // tail workgroups clear the counters of the later passes
+    zero_body(zero16, zero_vecs, blockIdx.x - data_blocks, gridDim.x - data_blocks);
+    return;
+  }
+  build_keys_body<VEC>(p, ws, blockIdx.x, data_blocks);
+}
+
 // The same pass for bs in {4, 8, 16, 32, 64} (16 B per thread), organised so that blocks OUTSIDE the
 // batch cost one coalesced 4 B read and nothing else.  An engine sizes its cache to HBM: most
 // blocks do not belong to the sequences being compressed.  A workgroup sweeps SPARSE_CHUNK
@@ -184,15 +196,7 @@ __global__ __launch_bounds__(256) void build_keys_kernel(kvc_schedule_params p, 
 // batch blocks a wave finds; this form 0.07 ms.)
 constexpr int SPARSE_SCAN = 16;                       // index loads in flight per thread
 constexpr int SPARSE_CHUNK = 256 * SPARSE_SCAN;       // blocks per workgroup sweep
-__global__ __launch_bounds__(256) void build_keys_sparse_kernel(kvc_schedule_params p, SchedWs ws,
-                                                                unsigned data_blocks, uint4* zero16, int64_t zero_vecs) {
-  if (gated_off(ws)) return;
-  if (blockIdx.x >= data_blocks) {      // tail workgroups clear the counters of the later passes
-    for (int64_t i = (int64_t)(blockIdx.x - data_blocks) * 256 + threadIdx.x; i < zero_vecs;
-         i += (int64_t)(gridDim.x - data_blocks) * 256)
-      zero16[i] = make_uint4(0u, 0u, 0u, 0u);
-    return;
-  }
+__device__ __forceinline__ void build_keys_sparse_body(const kvc_schedule_params& p, SchedWs& ws, unsigned bid, unsigned data_blocks) {
   __shared__ uint32_t list_s[SPARSE_CHUNK];           // (batch position of the sequence << 12) | block - chunk base
   static_assert(SPARSE_CHUNK <= 4096, "12 bits of block offset");
   __shared__ uint32_t n_s;
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(256) void build_keys_sparse_kernel(kvc_schedule_par
   const int per_blk = bs / 4;
   const int tid = threadIdx.x, lane = lane_id();
   const int L = p.num_layers, H = p.num_kv_heads, B = p.num_seqs;
-  for (int64_t base = (int64_t)blockIdx.x * SPARSE_CHUNK; base < p.num_blocks; base += (int64_t)data_blocks * SPARSE_CHUNK) {
+  for (int64_t base = (int64_t)bid * SPARSE_CHUNK; base < p.num_blocks; base += (int64_t)data_blocks * SPARSE_CHUNK) {
     if (tid == 0) n_s = 0;
     __syncthreads();
     int sidx[SPARSE_SCAN];
@@ -253,6 +257,16 @@ __global__ __launch_bounds__(256) void build_keys_sparse_kernel(kvc_schedule_par
   }
 }
 
+__global__ __launch_bounds__(256) void build_keys_sparse_kernel(kvc_schedule_params p, SchedWs ws,
+                                                                unsigned data_blocks, uint4* zero16, int64_t zero_vecs) {
+  if (gated_off(ws)) return;
+  if (blockIdx.x >= data_blocks) {      // tail workgroups clear the counters of the later passes
+    zero_body(zero16, zero_vecs, blockIdx.x - data_blocks, gridDim.x - data_blocks);
+    return;
+  }
+  build_keys_sparse_body(p, ws, blockIdx.x, data_blocks);
+}
+
 // ------------------------------------------------------------------ 1. per-head histograms
 // flat tiles of TILE keys; a tile inside one head (the common case) accumulates in LDS.
 constexpr int HTILE = 2048;
@@ -260,15 +274,14 @@ constexpr int HSEG_MAX = 8;      // head segments of a tile handled by LDS passe
 // Persistent: every workgroup walks a contiguous range of HTILE-key tiles.  The head of the
 // first tile is found by one binary search, later tiles advance it incrementally; counts of
 // consecutive tiles of one head stay in LDS and are flushed once per head.
-__global__ __launch_bounds__(256) void hist_round_kernel(kvc_schedule_params p, SchedWs ws, int round) {
-  if (gated_off(ws)) return;
+__device__ __forceinline__ void hist_round_body(const kvc_schedule_params& p, SchedWs& ws, int round, unsigned bid, unsigned nb) {
   __shared__ uint32_t sh[RADIX];
   const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
   const int LH = p.num_layers * p.num_kv_heads;
   const int64_t N = p.total_slots;
   const int shift = 24 - 8 * round;
   const int64_t ntiles = (N + HTILE - 1) / HTILE;
-  const int64_t tb = ntiles * blockIdx.x / gridDim.x, te = ntiles * (blockIdx.x + 1) / gridDim.x;
+  const int64_t tb = ntiles * bid / nb, te = ntiles * (bid + 1) / nb;
   if (tb >= te) return;
   int g = upper_bound_minus1(p.evicted_kv_offsets, G, tb * HTILE);
   int64_t g_end = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : N;
@@ -353,6 +366,11 @@ __global__ __launch_bounds__(256) void hist_round_kernel(kvc_schedule_params p, 
   flush();
 }
 
+__global__ __launch_bounds__(256) void hist_round_kernel(kvc_schedule_params p, SchedWs ws, int round) {
+  if (gated_off(ws)) return;
+  hist_round_body(p, ws, round, blockIdx.x, gridDim.x);
+}
+
 // ------------------------------------------------------------------ 2. per-head scan
 // one wave per head: hist -> inclusive cumulative; chunkcnt[d] = chunks freed at digit d
 __global__ __launch_bounds__(256) void scan_round_kernel(kvc_schedule_params p, SchedWs ws, int round) {
@@ -403,7 +421,7 @@ __global__ __launch_bounds__(256) void seq_totals_kernel(kvc_schedule_params p, 
 
 // ... and from them the number of chunks k'_i each sequence really frees   metrics.py:704-729
 // (f_s = finite-threshold chunks, cn_s = all chunks of every sequence, already in LDS)
-__device__ void seq_prepare_body(const kvc_schedule_params& p, SchedWs& ws, int64_t* un_s,
+__device__ __forceinline__ void seq_prepare_body(const kvc_schedule_params& p, SchedWs& ws, int64_t* un_s,
                                  int32_t* f_s, int32_t* cn_s, int32_t* off_s, int32_t* pinf_s) {
   const int B = p.num_seqs;
   __syncthreads();
@@ -516,7 +534,7 @@ __global__ __launch_bounds__(1024) void pick_round_kernel(kvc_schedule_params p,
 // (head, chunk) order until the sequence total is k'.           metrics.py:773-792
 // (one workgroup of NW waves per sequence; wave_tot: NW words, carry_s / lt_total_s: one each)
 template <int NW>
-__device__ void finalize_body(const kvc_schedule_params& p, SchedWs& ws, int i, uint32_t* wave_tot,
+__device__ __forceinline__ void finalize_body(const kvc_schedule_params& p, SchedWs& ws, int i, uint32_t* wave_tot,
                               uint32_t* carry_s, uint32_t* lt_total_s) {
   const int LH = p.num_layers * p.num_kv_heads;
   const uint32_t bs = (uint32_t)p.block_size;
@@ -570,13 +588,6 @@ __device__ void finalize_body(const kvc_schedule_params& p, SchedWs& ws, int i, 
   }
 }
 
-__global__ __launch_bounds__(256) void finalize_heads_kernel(kvc_schedule_params p, SchedWs ws) {
-  if (gated_off(ws)) return;
-  __shared__ uint32_t wave_tot[4];
-  __shared__ uint32_t carry_s, lt_total_s;
-  finalize_body<4>(p, ws, blockIdx.x, wave_tot, &carry_s, &lt_total_s);
-}
-
 // ------------------------------------------------------------------ 5a. scan + pick (+ totals, + counts) in one launch
 // One workgroup per sequence does what scan_round, (seq_totals, seq_prepare,) pick_round and -- in
 // the last round -- finalize_heads do in a launch each: its 16 waves scan the digit histograms of
@@ -584,14 +595,15 @@ __global__ __launch_bounds__(256) void finalize_heads_kernel(kvc_schedule_params
 // is picked and the heads' `less` / `eq` updated.  Round 0 also needs k': per sequence it is
 // min(k, finite-threshold chunks) -- what seq_prepare_body gives for mode 1 or a single sequence;
 // the reference's batch > 1 rule (mode 0) couples the sequences and keeps the separate launches.
-__global__ __launch_bounds__(1024) void scan_pick_kernel(kvc_schedule_params p, SchedWs ws, int round) {
-  if (gated_off(ws)) return;
-  __shared__ __attribute__((aligned(16))) uint32_t csum[16][RADIX];
-  __shared__ uint32_t wave_tot[16];
+// (NW waves per workgroup: 16 in the kernel of its own, 4 inside the single-launch fallback)
+template <int NW, int SU>
+__device__ __forceinline__ void scan_pick_body(const kvc_schedule_params& p, SchedWs& ws, int round, int i) {
+  __shared__ __attribute__((aligned(16))) uint32_t csum[NW][RADIX];
+  __shared__ uint32_t wave_tot[NW];
   __shared__ uint32_t carry_s, lt_total_s;
   __shared__ int dstar_s;
   __shared__ uint32_t k_s;
-  const int i = blockIdx.x, tid = threadIdx.x, lane = lane_id(), w = tid / WAVE;
+  const int tid = threadIdx.x, lane = lane_id(), w = tid / WAVE;
   const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
   const int LH = p.num_layers * p.num_kv_heads;
   const uint32_t bs = (uint32_t)p.block_size;
@@ -602,13 +614,12 @@ __global__ __launch_bounds__(1024) void scan_pick_kernel(kvc_schedule_params p, 
     // scan_round: a wave takes every 16th head, eight at a time (their loads, scans and stores
     // are independent: with a single sequence this workgroup is alone on the chip and a round
     // trip to the histograms -- last touched by atomics -- is what it waits for)
-    constexpr int SU = 8;
-    for (int lh0 = w; lh0 < LH; lh0 += 16 * SU) {
+    for (int lh0 = w; lh0 < LH; lh0 += NW * SU) {
       uint4 v[SU];
       uint32_t less[SU], hang[SU];
 #pragma unroll
       for (int u = 0; u < SU; ++u) {
-        const int lh = lh0 + 16 * u;
+        const int lh = lh0 + NW * u;
         v[u] = make_uint4(0u, 0u, 0u, 0u); less[u] = 0; hang[u] = 1;
         if (lh < LH) {                                 // wave-uniform
           const int g = i * LH + lh;
@@ -618,7 +629,7 @@ __global__ __launch_bounds__(1024) void scan_pick_kernel(kvc_schedule_params p, 
       }
 #pragma unroll
       for (int u = 0; u < SU; ++u) {
-        const int lh = lh0 + 16 * u;
+        const int lh = lh0 + NW * u;
         if (lh >= LH) break;                           // wave-uniform
         const int g = i * LH + lh;
         reinterpret_cast<uint4*>(ws.hist + (int64_t)g * RADIX)[lane] = make_uint4(0u, 0u, 0u, 0u);   // ready for the next round
@@ -637,7 +648,7 @@ __global__ __launch_bounds__(1024) void scan_pick_kernel(kvc_schedule_params p, 
     if (tid < RADIX) {                                 // chunks freed if the digit were d, over all heads
       uint32_t t = 0;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) t += csum[q][tid];
+      for (int q = 0; q < NW; ++q) t += csum[q][tid];
       csum[0][tid] = t;
     }
     if (tid == 0) dstar_s = 255;
@@ -672,8 +683,13 @@ __global__ __launch_bounds__(1024) void scan_pick_kernel(kvc_schedule_params p, 
   }
   if (round == 3) {
     __syncthreads();                                   // (the heads' less / eq just written by this workgroup)
-    finalize_body<16>(p, ws, i, wave_tot, &carry_s, &lt_total_s);
+    finalize_body<NW>(p, ws, i, wave_tot, &carry_s, &lt_total_s);
   }
+}
+
+__global__ __launch_bounds__(1024) void scan_pick_kernel(kvc_schedule_params p, SchedWs ws, int round) {
+  if (gated_off(ws)) return;
+  scan_pick_body<16, 8>(p, ws, round, blockIdx.x);
 }
 
 // ------------------------------------------------------------------ 6. select + emit
@@ -685,7 +701,7 @@ __global__ __launch_bounds__(1024) void scan_pick_kernel(kvc_schedule_params p, 
 // (first_round, prefix0): the top first_round digits are already known to be prefix0 and
 // `rank` counts within that bucket; first_round == 4 returns prefix0 with out_eq untouched.
 template <typename ValF, typename PredF>
-__device__ void block_radix_select(uint32_t* hist, uint32_t* bc, int n, uint32_t rank, ValF val,
+__device__ __forceinline__ void block_radix_select(uint32_t* hist, uint32_t* bc, int n, uint32_t rank, ValF val,
                                    PredF pred, uint32_t& out_val, uint32_t& out_rank_in_eq,
                                    uint32_t& out_eq, int first_round = 0, uint32_t prefix0 = 0) {
   uint32_t prefix = prefix0;
@@ -738,7 +754,7 @@ __device__ void block_radix_select(uint32_t* hist, uint32_t* bc, int n, uint32_t
 
 // lds_cap = number of keys the dynamic LDS buffer can stage (0 = read keys from global/L2)
 template <int SEL_THREADS>
-__device__ void select_emit_head(const kvc_schedule_params& p, SchedWs& ws, int lds_cap, int g, uint32_t* lds_keys) {
+__device__ __forceinline__ void select_emit_head(const kvc_schedule_params& p, SchedWs& ws, int lds_cap, int g, uint32_t* lds_keys) {
   __shared__ __attribute__((aligned(16))) uint32_t hist[RADIX];
   __shared__ uint32_t bc[4];
   __shared__ uint32_t scan_buf[8 * (SEL_THREADS / WAVE) + 1];
@@ -1658,18 +1674,93 @@ __global__ __launch_bounds__(64 * WAVES) void emit_topk_kernel(kvc_schedule_para
 // general pipeline behind the small-eviction schedule (gated): the chunk table is cleared by a gated
 // kernel instead of a memset (nothing runs unless the flag was raised), and the keys of chunks
 // nobody claimed, which no memset cleared on that path, are set afterwards
+__device__ __forceinline__ void clear_chunk_table_body(const kvc_schedule_params& p, SchedWs& ws, unsigned bid, unsigned nb) {
+  const int64_t nchunks = p.total_slots / p.block_size;
+  for (int64_t c = (int64_t)bid * blockDim.x + threadIdx.x; c < nchunks; c += (int64_t)nb * blockDim.x)
+    ws.chunk_phys[c] = -1;
+}
+__device__ __forceinline__ void fix_unclaimed_body(const kvc_schedule_params& p, SchedWs& ws, unsigned bid, unsigned nb) {
+  const int64_t nchunks = p.total_slots / p.block_size;
+  for (int64_t c = (int64_t)bid * blockDim.x + threadIdx.x; c < nchunks; c += (int64_t)nb * blockDim.x)
+    if (ws.chunk_phys[c] < 0)
+      for (int o = 0; o < p.block_size; ++o) ws.keys[c * p.block_size + o] = 0xFFFFFFFFu;
+}
 __global__ __launch_bounds__(256) void clear_chunk_table_kernel(kvc_schedule_params p, SchedWs ws) {
   if (gated_off(ws)) return;
-  const int64_t nchunks = p.total_slots / p.block_size;
-  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += (int64_t)gridDim.x * blockDim.x)
-    ws.chunk_phys[c] = -1;
+  clear_chunk_table_body(p, ws, blockIdx.x, gridDim.x);
 }
 __global__ __launch_bounds__(256) void fix_unclaimed_kernel(kvc_schedule_params p, SchedWs ws) {
   if (gated_off(ws)) return;
-  const int64_t nchunks = p.total_slots / p.block_size;
-  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += (int64_t)gridDim.x * blockDim.x)
-    if (ws.chunk_phys[c] < 0)
-      for (int o = 0; o < p.block_size; ++o) ws.keys[c * p.block_size + o] = 0xFFFFFFFFu;
+  fix_unclaimed_body(p, ws, blockIdx.x, gridDim.x);
+}
+
+// ------------------------------------------------------------------ 8. the fallback in ONE launch
+// HIP has no conditional enqueue: behind the small-eviction schedule the general pipeline used to
+// be 13 launches that read the flag and return, ~4.6 us each -- 60 us of a 150 us schedule at 16
+// resident sequences.  This kernel is the whole general pipeline (for sequences that do not couple:
+// mode 1 or a single one) on a persistent grid that is resident at once, its phases separated by a
+// software grid barrier; with the flag down it is one launch that returns.  The barrier is the
+// release / acquire recipe of cdna_hip_programming.md Guideline 16: every wave's stores are
+// complete at the workgroup barrier, lane 0 writes the XCD's L2 back (release, agent scope),
+// arrives on a monotonic counter, polls it with relaxed loads and a sleep, invalidates the CU's L1
+// (acquire), and the workgroup barrier hands that to the other waves.  A wait that does not end
+// (a grid that is not resident: must not happen, the host sizes it from the occupancy query less
+// one workgroup per CU) gives up after two seconds of the 100 MHz wall clock and raises bit 1 of
+// the flag word instead of hanging the GPU.
+__device__ void grid_barrier(uint32_t* counter, uint32_t target, uint32_t* flag) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(16);
+      if (wall_clock64() - t0 > 200000000ull) { atomicOr(flag, 2u); break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256, 2) void fallback_general_kernel(kvc_schedule_params p, SchedWs ws, int sparse,
+                                                               uint4* zero16, int64_t zero_vecs) {
+  if (*ws.fallback == 0u) return;                    // flag down: this launch is all the fallback costs
+  const unsigned bid = blockIdx.x, nb = gridDim.x;
+  uint32_t phase = 0;
+  // (workgroup 0 leaves the 100 MHz wall clock of every phase end behind the counter: tools/fallback_cost.py)
+  auto sync = [&]() {
+    ++phase;
+    grid_barrier(ws.bar, phase * nb, ws.fallback);
+    if (bid == 0 && threadIdx.x == 0 && phase < 15) ws.bar[1 + phase] = (uint32_t)wall_clock64();
+  };
+  if (bid == 0 && threadIdx.x == 0) ws.bar[1] = (uint32_t)wall_clock64();
+  const int B = p.num_seqs, G = B * p.num_layers * p.num_kv_heads;
+  // every logical block of the batch has a physical block (the collecting pass counted them:
+  // the same for all workgroups) -> nothing to clear, nothing to fix: two phases less
+  uint32_t claimed = 0;
+  for (int q = 0; q < CLAIM_SHARDS; ++q) claimed += ws.st_claimed[q * 32];
+  const bool holes = (int64_t)claimed != p.total_slots / p.block_size && !(p.lean & 2);
+  zero_body(zero16, zero_vecs, bid, nb);
+  if (holes) { clear_chunk_table_body(p, ws, bid, nb); sync(); }
+  if (sparse) build_keys_sparse_body(p, ws, bid, nb);
+  else build_keys_body<4>(p, ws, bid, nb);
+  sync();
+  if (holes) { fix_unclaimed_body(p, ws, bid, nb); sync(); }
+  for (int round = 0; round < 4; ++round) {
+    hist_round_body(p, ws, round, bid, nb);
+    sync();
+    for (int i = (int)bid; i < B; i += (int)nb) {
+      scan_pick_body<4, 4>(p, ws, round, i);
+      __syncthreads();
+    }
+    sync();
+  }
+  for (int g = (int)bid; g < G; g += (int)nb) {
+    select_emit_head<256>(p, ws, 0, g, nullptr);
+    __syncthreads();
+  }
+  if (bid == 0 && threadIdx.x == 0) ws.bar[17] = (uint32_t)wall_clock64();     // (workgroup 0's own end)
 }
 
 }  // namespace kvc
@@ -1756,6 +1847,26 @@ static WsLayout ws_layout(int64_t N, int32_t G, int32_t B, int32_t bs) {
   l.rec64 = o;       o = align_up(o + (size_t)G * kvc::KREC * 8, 256);
   l.total = o;
   return l;
+}
+
+// grid of the single-launch fallback (section 8): what is resident at once, less one workgroup per
+// CU (the occupancy query can be one too high where SGPRs decide, MI355X_MICROARCH.md), at most 3
+// (4 per CU measured slower: the barrier's cost grows with the number of arrivers)
+// per CU; asked once per device
+static int fallback_grid() {
+  static std::atomic<int> grid[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (grid[dev].load(std::memory_order_relaxed) == 0) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kvc::fallback_general_kernel, 256, 0) != hipSuccess)
+      per_cu = 1;
+    per_cu = per_cu - 1 < 1 ? 1 : (per_cu - 1 > 3 ? 3 : per_cu - 1);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    grid[dev].store(per_cu * cus, std::memory_order_relaxed);
+  }
+  return grid[dev].load(std::memory_order_relaxed);
 }
 
 // small-eviction schedule (section 7) or not: the host knows how many blocks a sequence frees at
@@ -1849,6 +1960,7 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   ws.st_claimed = reinterpret_cast<uint32_t*>(wb + l.st_claimed);
   ws.st_seqrec = reinterpret_cast<SeqRec*>(wb + l.st_seqrec);
   ws.fallback = reinterpret_cast<uint32_t*>(wb + l.fallback);
+  ws.bar = reinterpret_cast<uint32_t*>(wb + l.fallback + 128);     // (its own cache line, same zeroed region)
   ws.head_fc = reinterpret_cast<uint32_t*>(wb + l.head_fc);
   ws.gate = nullptr;
   if (p.total_slots == 0) {
@@ -1932,6 +2044,14 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     if (side != nullptr) hipStreamWaitEvent(s, side->join, 0);
     hipLaunchKernelGGL(emit_topk_kernel<4>, dim3((G + 3) / 4), dim3(256), 0, s, p, ws);
     ws.gate = ws.fallback;
+  }
+  if (topk && !(p.mode == 0 && B > 1)) {
+    // ---- the general pipeline as ONE gated launch (section 8)
+    uint4* z16 = reinterpret_cast<uint4*>(wb + l.zero_begin);
+    const int64_t zv = (int64_t)((l.zero_end - l.zero_begin) / 16);
+    const int sparse = p.total_slots < (int64_t)p.num_blocks * p.block_size / 2 ? 1 : 0;
+    hipLaunchKernelGGL(fallback_general_kernel, dim3((unsigned)fallback_grid()), dim3(256), 0, s, p, ws, sparse, z16, zv);
+    return check_launch("schedule_evictions");
   }
   // ---- general pipeline
   // keys default to "not evictable" (0xFFFFFFFF > KEY_INF) and the chunk table to -1 for slots

@@ -133,6 +133,17 @@ class CompressionMetrics:
         # results do not depend on it, tests force every value)
         self.sample_stride = int(os.environ.get("KVC_SAMPLE_STRIDE", "0"))
         self.last_schedule = None      # (workspace, fallback offset, small-eviction schedule enqueued)
+        # host policy around the small-eviction schedule: a call whose flag was raised costs the
+        # streaming pass AND the general pipeline in its single-launch form (3 x the general
+        # pipeline at 16 sequences) -- fine as the exception, not as the rule.  The flag of every
+        # small-eviction call is copied to pinned memory asynchronously and looked at by the NEXT
+        # call (no synchronisation: a decode step lies in between); after a raised flag the general
+        # schedule is taken for 1, 2, 4 ... up to 64 calls before the small-eviction one is tried
+        # again.  Results are identical either way.
+        self._fb_pin = None
+        self._fb_event = None
+        self._fb_penalty = 0          # general-schedule calls the last raised flag cost
+        self._fb_backoff = 0          # of which still to go
         self._small_cache = {}
 
     # temp_metrics is handed to the attention kernels, which write into it; reading the
@@ -377,6 +388,15 @@ class CompressionMetrics:
             p.max_evicted_blocks_hint = int(max(int(v) for v in evicted_blocks_per_seq))
         p.schedule_path = int(self.schedule_path)
         p.sample_stride = int(self.sample_stride)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if self._fb_event is not None and not capturing and self._fb_event.query():
+            raised = int(self._fb_pin[0]) != 0
+            self._fb_event = None
+            self._fb_penalty = min(max(2 * self._fb_penalty, 1), 64) if raised else 0
+            self._fb_backoff = self._fb_penalty
+        if p.schedule_path == 0 and self._fb_backoff > 0 and not capturing:
+            self._fb_backoff -= 1
+            p.schedule_path = 1
         if block_tables is not None:
             if (not block_tables.is_cuda or block_tables.dtype != torch.int32 or block_tables.dim() != 4
                     or not block_tables.is_contiguous() or block_tables.shape[0] != L or block_tables.shape[2] != H):
@@ -401,6 +421,15 @@ class CompressionMetrics:
                                                   _stream(self.metrics)))
         self.last_schedule = (ws, int(lib.kvc_schedule_evictions_fallback_offset(N, B * L * H, B, bs)),
                               bool(lib.kvc_schedule_evictions_uses_small_eviction_schedule(ctypes.byref(p))))
+        if self.last_schedule[2] and not capturing and int(self.schedule_path) == 0:
+            off = self.last_schedule[1]
+            if self._fb_pin is None:
+                self._fb_pin = torch.zeros(1, dtype=torch.int32).pin_memory()
+            if self._fb_event is None:      # (one copy in flight at a time: the pinned word is read before it is reused)
+                with torch.cuda.device(dev):
+                    self._fb_pin.copy_(ws[off:off + 4].view(torch.int32), non_blocking=True)
+                    self._fb_event = torch.cuda.Event()
+                    self._fb_event.record()
         return out_idx, out_kv, out_blk
 
     def last_schedule_path(self) -> str:
@@ -411,6 +440,8 @@ class CompressionMetrics:
         if not small:
             return "general"
         flag = int(ws[off:off + 4].view(torch.int32).item())
+        if flag & 2:        # the single-launch fallback gave up waiting at its grid barrier: results are void
+            return "small_eviction+fallback+barrier_timeout"
         return "small_eviction" if flag == 0 else "small_eviction+fallback"
 
     def profile_schedule_evictions(self):
