@@ -84,8 +84,8 @@ def parse_args(argv=None):
                     help="extension: no MAX_INT padding / key-scratch clear in schedule_evictions and no "
                          "zero fill of the move workspace (outputs a consumer reads are unchanged)")
     ap.add_argument("--pass-block-tables", action="store_true",
-                    help="extension: hand BlockState.block_tables to schedule_evictions (not in the reference "
-                         "signature; saves the small-eviction schedule its chunk-table pass)")
+                    help="hand BlockState.block_tables to schedule_evictions (round 2's gathering schedule read it; "
+                         "still accepted, ignored by the streaming one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-adjacent", action="store_true",
                     help="skip the decode-attention (F3) side measurement")
@@ -809,7 +809,7 @@ def main():
                             + f"protected_window={args.protected}, "
                             f"metrics={args.metric_shape}, schedule mode={args.mode}"
                             + (", lean outputs (extension)" if args.lean else "")
-                            + (", block_tables passed to schedule_evictions (extension)" if args.pass_block_tables else "")
+                            + (", block_tables passed to schedule_evictions (ignored)" if args.pass_block_tables else "")
                             + ", physical blocks "
                             f"{'in allocation order' if args.contiguous_blocks else 'shuffled'}"
                             + (f" inside a cache of {st.num_blocks} blocks" if args.spare_blocks != 0.02 else ""),

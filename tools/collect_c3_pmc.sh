@@ -27,7 +27,8 @@ fetch, write = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
 line = json.loads(open(f"{out}/bench_fetch.json").read().strip().splitlines()[-1])
 slots = line["config"]["candidate_slots"]
 S1 = ("stream_", "seq_select_topk", "seq_sums_topk", "seq_prepare", "emit_topk", "scan_pick", "hist_round",
-      "build_keys", "clear_chunk_table", "fix_unclaimed", "select_emit", "scan_round", "pick_round", "seq_totals")
+      "build_keys", "clear_chunk_table", "fix_unclaimed", "select_emit", "scan_round", "pick_round", "seq_totals",
+      "fallback_general")
 res, s1_fetch, s1_write = {}, 0.0, 0.0
 for k in sorted(set(fetch) | set(write)):
     fkb, nf = fetch.get(k, (0.0, 0)); wkb, nw = write.get(k, (0.0, 0))

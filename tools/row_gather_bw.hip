@@ -1,6 +1,6 @@
 // How fast can randomly placed 64-byte rows (a bs-16 block's metric / position row) be gathered,
 // and does the cache policy of the load change what the L2 fetches for them?  (profiling aid)
-// Pattern of head_topk_kernel: a lane loads 4 B, 16 lanes cover one row, 16 rows requested before
+// Pattern of round 2's head_topk_kernel (replaced in round 3 by a physical-order stream): a lane loads 4 B, 16 lanes cover one row, 16 rows requested before
 // the first is used.  Variants: plain, nt, sc1, sc0 sc1, sc0 sc1 nt (inline asm), and 128-byte
 // rows (both halves of the line used) as the reference point.
 #include <hip/hip_runtime.h>
