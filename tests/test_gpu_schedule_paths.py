@@ -27,9 +27,9 @@ def _run(st, evicted, path, mode="reference", lean=False, **kw):
     return out, ds.cm.last_schedule_path()
 
 
-def _steady(L, H, bs, B, cap, seed, **kw):
+def _steady(L, H, bs, B, cap, seed, spare_block_frac=0.05, **kw):
     st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs, seq_lens=[3 * cap] * B, seed=seed,
-                          protected=bs + 1, steady_cap=cap, spare_block_frac=0.05, **kw)
+                          protected=bs + 1, steady_cap=cap, spare_block_frac=spare_block_frac, **kw)
     evicted = [synth.evict_block_count(context_lens_lh=st.context_lens[:, b, :], seq_len=3 * cap,
                                        block_size=bs, protected_window_size=bs + 1, max_cache_tokens=cap)
                for b in range(B)]
@@ -370,3 +370,34 @@ def test_a_raised_flag_sends_the_next_calls_to_the_general_schedule():
             np.testing.assert_array_equal(got.cpu().numpy(), want[key], err_msg=key)
     assert hows == ["small_eviction+fallback", "general", "small_eviction+fallback", "general", "general",
                     "small_eviction+fallback", "general", "general"], hows
+
+
+@pytest.mark.parametrize("path", [2, 3])
+@pytest.mark.parametrize("bs", [8, 16, 32])
+def test_small_eviction_schedule_in_a_sparse_cache(path, bs):
+    """an engine-sized cache: most blocks belong to other sequences or to nobody.  The collecting
+    pass then sweeps the sequence indices and works the batch's blocks off a compacted list, the
+    sampling drain sits behind a membership filter, and the single-launch fallback takes its
+    compacting key pass -- steady states (both modes), a batch that is a subset of the resident
+    sequences, and a skewed head that forces the fallback, against the oracle"""
+    for seed, mode in ((0, "per_sequence"), (1, "reference")):
+        st, evicted = _steady(3, 4, bs, 3, 16 * bs * 4, 40 + seed, spare_block_frac=5.0)
+        assert st.total_slots < st.num_blocks * bs // 2
+        # other sequences' blocks in between: a third of the free blocks get a foreign owner
+        free = np.nonzero(st.seq_index_by_block < 0)[0]
+        st.seq_index_by_block[free[::3]] = 7
+        want = oracle_pipeline(st, evicted, mode=mode)
+        got, how = _run(st, evicted, path, mode)
+        assert how == "small_eviction"
+        for key in KEYS:
+            np.testing.assert_array_equal(got[key], want[key], err_msg=f"{key} bs={bs} {mode}")
+    # forced fallback in the sparse cache
+    st, evicted = _steady(4, 4, bs, 1, 64 * bs, 50, spare_block_frac=5.0)
+    blocks = np.nonzero((st.layer_index_by_block == 1) & (st.head_index_by_block == 2) & (st.seq_index_by_block == 0))[0]
+    st.metrics[blocks] -= np.float32(1e7)
+    evicted = [2 * (256 // bs) + 3]                 # more chunks from one head than a record holds
+    want = oracle_pipeline(st, evicted, mode="per_sequence")
+    got, how = _run(st, evicted, path, "per_sequence")
+    assert how == "small_eviction+fallback"
+    for key in KEYS:
+        np.testing.assert_array_equal(got[key], want[key], err_msg=f"{key} bs={bs} fallback")

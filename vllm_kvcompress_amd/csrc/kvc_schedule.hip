@@ -37,9 +37,8 @@ struct SeqRec;
 struct SchedWs {
   uint32_t* keys;        // [N]      order-preserving metric keys, index off_g + lambda
   int32_t* chunk_phys;   // [N/bs]   physical block of logical chunk
-  uint32_t* hist;        // [G,256]  per-head digit histogram (re-zeroed by scan_round)
+  uint32_t* hist;        // [G,256]  per-head digit histogram (re-zeroed by the scan)
   uint32_t* cum;         // [4,G,256] inclusive cumulative counts of every round (select_emit reuses them)
-  uint32_t* chunkcnt;    // [G,256]  chunks freed if the digit were d
   uint32_t* less;        // [G]      keys strictly below the current prefix
   uint32_t* eq;          // [G]      keys equal to T* (after the last round)
   uint32_t* seq_prefix;  // [B]
@@ -371,54 +370,8 @@ __global__ __launch_bounds__(256) void hist_round_kernel(kvc_schedule_params p, 
   hist_round_body(p, ws, round, blockIdx.x, gridDim.x);
 }
 
-// ------------------------------------------------------------------ 2. per-head scan
-// one wave per head: hist -> inclusive cumulative; chunkcnt[d] = chunks freed at digit d
-__global__ __launch_bounds__(256) void scan_round_kernel(kvc_schedule_params p, SchedWs ws, int round) {
-  if (gated_off(ws)) return;
-  const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
-  const int g = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
-  if (g >= G) return;
-  const int lane = lane_id();
-  uint32_t* h = ws.hist + (int64_t)g * RADIX;
-  uint4 v = reinterpret_cast<uint4*>(h)[lane];            // 4 bins per lane
-  reinterpret_cast<uint4*>(h)[lane] = make_uint4(0u, 0u, 0u, 0u);   // ready for the next round
-  v.y += v.x; v.z += v.y; v.w += v.z;
-  const uint32_t inc = wave_inclusive_scan(v.w);
-  const uint32_t ex = inc - v.w;
-  v.x += ex; v.y += ex; v.z += ex; v.w += ex;
-  reinterpret_cast<uint4*>(ws.cum + ((int64_t)round * G + g) * RADIX)[lane] = v;
-  const uint32_t less = ws.less[g], hang = (uint32_t)p.hanging_token_count[g], bs = (uint32_t)p.block_size;
-  uint4 c;
-  const int bs_shift = (bs & (bs - 1u)) == 0u ? 31 - __builtin_clz(bs) : -1;
-  c.x = nchunks_freed_s(less + v.x, hang, bs, bs_shift); c.y = nchunks_freed_s(less + v.y, hang, bs, bs_shift);
-  c.z = nchunks_freed_s(less + v.z, hang, bs, bs_shift); c.w = nchunks_freed_s(less + v.w, hang, bs, bs_shift);
-  reinterpret_cast<uint4*>(ws.chunkcnt + (int64_t)g * RADIX)[lane] = c;
-}
-
-// ------------------------------------------------------------------ 3. chunks per sequence
-// after round 0's scan: F_i (finite-threshold chunks) and Cn_i (all chunks) ...
-__global__ __launch_bounds__(256) void seq_totals_kernel(kvc_schedule_params p, SchedWs ws) {
-  if (gated_off(ws)) return;
-  __shared__ uint32_t red[2][4];
-  const int B = p.num_seqs, H = p.num_kv_heads, LH = p.num_layers * H, bs = p.block_size;
-  const int i = blockIdx.x;
-  uint32_t f = 0, cn = 0;
-  for (int lh = threadIdx.x; lh < LH; lh += blockDim.x) {
-    const int g = i * LH + lh;
-    f += ws.chunkcnt[(int64_t)g * RADIX + 255];
-    const int ctx = p.context_lens[((lh / H) * B + i) * H + (lh % H)];
-    cn += (uint32_t)((ctx + bs - 1) / bs);
-  }
-  f = wave_reduce_sum(f);
-  cn = wave_reduce_sum(cn);
-  if (lane_id() == 0) { red[0][threadIdx.x / WAVE] = f; red[1][threadIdx.x / WAVE] = cn; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    ws.seq_tmp[i] = (int32_t)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-    ws.seq_tmp[B + i] = (int32_t)(red[1][0] + red[1][1] + red[1][2] + red[1][3]);
-  }
-}
-
+// ------------------------------------------------------------------ 2. chunks per sequence
+// (the per-head scan, the per-sequence totals and the pick of the digit live in scan_pick_body, 5a)
 // ... and from them the number of chunks k'_i each sequence really frees   metrics.py:704-729
 // (f_s = finite-threshold chunks, cn_s = all chunks of every sequence, already in LDS)
 __device__ __forceinline__ void seq_prepare_body(const kvc_schedule_params& p, SchedWs& ws, int64_t* un_s,
@@ -471,11 +424,9 @@ __device__ __forceinline__ void seq_prepare_body(const kvc_schedule_params& p, S
 // everything lives in LDS: the loops are O(B^2) over three small tables, and walking them in
 // global memory cost 117 us at 256 sequences.  Any number of sequences: tables of B entries in
 // dynamic LDS (24 B per sequence: up to 6500).
-__global__ __launch_bounds__(1024) void seq_prepare_kernel(kvc_schedule_params p, SchedWs ws) {
-  if (gated_off(ws)) return;
-  extern __shared__ __attribute__((aligned(16))) uint8_t prep_lds[];
+__device__ __forceinline__ void seq_prepare_tables(const kvc_schedule_params& p, SchedWs& ws, uint8_t* lds) {
   const int B = p.num_seqs;
-  int64_t* un_s = reinterpret_cast<int64_t*>(prep_lds);
+  int64_t* un_s = reinterpret_cast<int64_t*>(lds);
   int32_t* f_s = reinterpret_cast<int32_t*>(un_s + B);
   int32_t* cn_s = f_s + B;
   int32_t* off_s = cn_s + B;
@@ -483,50 +434,10 @@ __global__ __launch_bounds__(1024) void seq_prepare_kernel(kvc_schedule_params p
   for (int i = threadIdx.x; i < B; i += blockDim.x) { f_s[i] = ws.seq_tmp[i]; cn_s[i] = ws.seq_tmp[B + i]; }
   seq_prepare_body(p, ws, un_s, f_s, cn_s, off_s, pinf_s);
 }
-
-// ------------------------------------------------------------------ 4. pick the digit
-// one workgroup per sequence: 256 digits x 4 head partitions
-__global__ __launch_bounds__(1024) void pick_round_kernel(kvc_schedule_params p, SchedWs ws, int round) {
+__global__ __launch_bounds__(1024) void seq_prepare_kernel(kvc_schedule_params p, SchedWs ws) {
   if (gated_off(ws)) return;
-  __shared__ uint32_t part[4][RADIX];
-  __shared__ int dstar_s;
-  const int i = blockIdx.x;
-  const int LH = p.num_layers * p.num_kv_heads;
-  const uint32_t k = (uint32_t)ws.seq_k[i];
-  if (k == 0) return;
-  const int d = threadIdx.x & 255, pt = threadIdx.x >> 8;
-  const uint32_t* cc = ws.chunkcnt + (int64_t)i * LH * RADIX + d;
-  uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  int lh = pt;
-  for (; lh + 12 < LH; lh += 16) {
-    s0 += cc[(int64_t)lh * RADIX];
-    s1 += cc[(int64_t)(lh + 4) * RADIX];
-    s2 += cc[(int64_t)(lh + 8) * RADIX];
-    s3 += cc[(int64_t)(lh + 12) * RADIX];
-  }
-  for (; lh < LH; lh += 4) s0 += cc[(int64_t)lh * RADIX];
-  part[pt][d] = s0 + s1 + s2 + s3;
-  if (threadIdx.x == 0) dstar_s = 255;
-  __syncthreads();
-  if (pt == 0) {
-    const uint32_t s = part[0][d] + part[1][d] + part[2][d] + part[3][d];
-    part[0][d] = s;
-  }
-  __syncthreads();
-  if (pt == 0) {
-    const uint32_t s = part[0][d];
-    if (s >= k && (d == 0 || part[0][d - 1] < k)) dstar_s = d;     // S is non-decreasing in d
-  }
-  __syncthreads();
-  const int ds = dstar_s;
-  if (threadIdx.x == 0) ws.seq_prefix[i] = (ws.seq_prefix[i] << 8) | (uint32_t)ds;
-  for (int h2 = threadIdx.x; h2 < LH; h2 += blockDim.x) {
-    const int g = i * LH + h2;
-    const uint32_t* cum = ws.cum + ((int64_t)round * p.num_seqs * LH + g) * RADIX;
-    const uint32_t below = ds > 0 ? cum[ds - 1] : 0u;
-    ws.less[g] += below;
-    if (round == 3) ws.eq[g] = cum[ds] - below;
-  }
+  extern __shared__ __attribute__((aligned(16))) uint8_t prep_lds[];
+  seq_prepare_tables(p, ws, prep_lds);
 }
 
 // ------------------------------------------------------------------ 5. per-head counts
@@ -589,15 +500,19 @@ __device__ __forceinline__ void finalize_body(const kvc_schedule_params& p, Sche
 }
 
 // ------------------------------------------------------------------ 5a. scan + pick (+ totals, + counts) in one launch
-// One workgroup per sequence does what scan_round, (seq_totals, seq_prepare,) pick_round and -- in
-// the last round -- finalize_heads do in a launch each: its 16 waves scan the digit histograms of
+// One workgroup per sequence does what used to be a launch each -- the per-head scan, (the
+// sequence's totals, k',) the pick of the digit and, in the last round, the per-head counts: its 16 waves scan the digit histograms of
 // the sequence's heads, the chunk counts per digit are summed in LDS (no [G,256] array), the digit
 // is picked and the heads' `less` / `eq` updated.  Round 0 also needs k': per sequence it is
 // min(k, finite-threshold chunks) -- what seq_prepare_body gives for mode 1 or a single sequence;
-// the reference's batch > 1 rule (mode 0) couples the sequences and keeps the separate launches.
+// the reference's batch > 1 rule (mode 0) couples the sequences (parts 1 and 2 below).
 // (NW waves per workgroup: 16 in the kernel of its own, 4 inside the single-launch fallback)
+// part: 0 = everything in one go; the reference's batch > 1 rule (round 0, mode 0) needs every
+// sequence's totals before any k' exists, so its round 0 runs as part 1 (scan + the sequence's
+// chunk totals -> seq_tmp), seq_prepare, part 2 (the per-digit chunk counts once more from the
+// stored cumulative counts, pick, update)
 template <int NW, int SU>
-__device__ __forceinline__ void scan_pick_body(const kvc_schedule_params& p, SchedWs& ws, int round, int i) {
+__device__ __forceinline__ void scan_pick_body(const kvc_schedule_params& p, SchedWs& ws, int round, int i, int part = 0) {
   __shared__ __attribute__((aligned(16))) uint32_t csum[NW][RADIX];
   __shared__ uint32_t wave_tot[NW];
   __shared__ uint32_t carry_s, lt_total_s;
@@ -611,7 +526,7 @@ __device__ __forceinline__ void scan_pick_body(const kvc_schedule_params& p, Sch
   const bool active = round == 0 || ws.seq_k[i] != 0;
   if (active) {
     reinterpret_cast<uint4*>(csum[w])[lane] = make_uint4(0u, 0u, 0u, 0u);
-    // scan_round: a wave takes every 16th head, eight at a time (their loads, scans and stores
+    // the scan: a wave takes every NW-th head, eight at a time (their loads, scans and stores
     // are independent: with a single sequence this workgroup is alone on the chip and a round
     // trip to the histograms -- last touched by atomics -- is what it waits for)
     for (int lh0 = w; lh0 < LH; lh0 += NW * SU) {
@@ -623,7 +538,8 @@ __device__ __forceinline__ void scan_pick_body(const kvc_schedule_params& p, Sch
         v[u] = make_uint4(0u, 0u, 0u, 0u); less[u] = 0; hang[u] = 1;
         if (lh < LH) {                                 // wave-uniform
           const int g = i * LH + lh;
-          v[u] = reinterpret_cast<uint4*>(ws.hist + (int64_t)g * RADIX)[lane];            // 4 bins per lane
+          v[u] = part == 2 ? reinterpret_cast<const uint4*>(ws.cum + ((int64_t)round * G + g) * RADIX)[lane]
+                           : reinterpret_cast<uint4*>(ws.hist + (int64_t)g * RADIX)[lane];   // 4 bins per lane
           less[u] = ws.less[g]; hang[u] = (uint32_t)p.hanging_token_count[g];
         }
       }
@@ -632,12 +548,14 @@ __device__ __forceinline__ void scan_pick_body(const kvc_schedule_params& p, Sch
         const int lh = lh0 + NW * u;
         if (lh >= LH) break;                           // wave-uniform
         const int g = i * LH + lh;
-        reinterpret_cast<uint4*>(ws.hist + (int64_t)g * RADIX)[lane] = make_uint4(0u, 0u, 0u, 0u);   // ready for the next round
-        v[u].y += v[u].x; v[u].z += v[u].y; v[u].w += v[u].z;
-        const uint32_t inc = wave_inclusive_scan(v[u].w);
-        const uint32_t ex = inc - v[u].w;
-        v[u].x += ex; v[u].y += ex; v[u].z += ex; v[u].w += ex;
-        reinterpret_cast<uint4*>(ws.cum + ((int64_t)round * G + g) * RADIX)[lane] = v[u];
+        if (part != 2) {
+          reinterpret_cast<uint4*>(ws.hist + (int64_t)g * RADIX)[lane] = make_uint4(0u, 0u, 0u, 0u);   // ready for the next round
+          v[u].y += v[u].x; v[u].z += v[u].y; v[u].w += v[u].z;
+          const uint32_t inc = wave_inclusive_scan(v[u].w);
+          const uint32_t ex = inc - v[u].w;
+          v[u].x += ex; v[u].y += ex; v[u].z += ex; v[u].w += ex;
+          reinterpret_cast<uint4*>(ws.cum + ((int64_t)round * G + g) * RADIX)[lane] = v[u];
+        }
         uint4 c = reinterpret_cast<uint4*>(csum[w])[lane];
         c.x += nchunks_freed_s(less[u] + v[u].x, hang[u], bs, bs_shift); c.y += nchunks_freed_s(less[u] + v[u].y, hang[u], bs, bs_shift);
         c.z += nchunks_freed_s(less[u] + v[u].z, hang[u], bs, bs_shift); c.w += nchunks_freed_s(less[u] + v[u].w, hang[u], bs, bs_shift);
@@ -653,7 +571,22 @@ __device__ __forceinline__ void scan_pick_body(const kvc_schedule_params& p, Sch
     }
     if (tid == 0) dstar_s = 255;
     __syncthreads();
-    if (round == 0 && tid == 0) {                      // seq_totals + seq_prepare, per sequence
+    if (part == 1) {                                   // the sequence's totals, for seq_prepare
+      uint32_t cn = 0;
+      const int B = p.num_seqs, H = p.num_kv_heads;
+      for (int lh = tid; lh < LH; lh += blockDim.x) {
+        const int ctx = p.context_lens[((lh / H) * B + i) * H + (lh % H)];
+        cn += (uint32_t)((ctx + (int)bs - 1) / (int)bs);
+      }
+      cn = wave_reduce_sum(cn);
+      if (tid == 0) lt_total_s = 0;
+      __syncthreads();
+      if (lane == 0 && cn) atomicAdd(&lt_total_s, cn);
+      __syncthreads();
+      if (tid == 0) { ws.seq_tmp[i] = (int32_t)csum[0][255]; ws.seq_tmp[B + i] = (int32_t)lt_total_s; }
+      return;
+    }
+    if (round == 0 && part == 0 && tid == 0) {         // seq_totals + seq_prepare, per sequence
       const int kk = p.evicted_blocks_per_seq[i];
       const uint32_t f = csum[0][255];                 // finite-threshold chunks
       const uint32_t k = kk <= 0 ? 0u : ((uint32_t)kk < f ? (uint32_t)kk : f);
@@ -661,10 +594,10 @@ __device__ __forceinline__ void scan_pick_body(const kvc_schedule_params& p, Sch
       ws.seq_prefix[i] = 0;
       k_s = k;
     }
-    if (round != 0 && tid == 0) k_s = (uint32_t)ws.seq_k[i];
+    if ((round != 0 || part == 2) && tid == 0) k_s = (uint32_t)ws.seq_k[i];
     __syncthreads();
     const uint32_t k = k_s;
-    if (k != 0) {                                      // pick_round
+    if (k != 0) {                                      // the pick
       if (tid < RADIX) {
         const uint32_t sd = csum[0][tid];
         if (sd >= k && (tid == 0 || csum[0][tid - 1] < k)) dstar_s = tid;     // non-decreasing in d
@@ -687,9 +620,9 @@ __device__ __forceinline__ void scan_pick_body(const kvc_schedule_params& p, Sch
   }
 }
 
-__global__ __launch_bounds__(1024) void scan_pick_kernel(kvc_schedule_params p, SchedWs ws, int round) {
+__global__ __launch_bounds__(1024) void scan_pick_kernel(kvc_schedule_params p, SchedWs ws, int round, int part) {
   if (gated_off(ws)) return;
-  scan_pick_body<16, 8>(p, ws, round, blockIdx.x);
+  scan_pick_body<16, 8>(p, ws, round, blockIdx.x, part);
 }
 
 // ------------------------------------------------------------------ 6. select + emit
@@ -1723,9 +1656,12 @@ __device__ void grid_barrier(uint32_t* counter, uint32_t target, uint32_t* flag)
   __syncthreads();
 }
 
+constexpr int FB_MAX_COUPLED = 256;                  // sequences whose batch > 1 rule fits the static tables below
 __global__ __launch_bounds__(256, 2) void fallback_general_kernel(kvc_schedule_params p, SchedWs ws, int sparse,
                                                                uint4* zero16, int64_t zero_vecs) {
   if (*ws.fallback == 0u) return;                    // flag down: this launch is all the fallback costs
+  __shared__ __attribute__((aligned(16))) uint8_t prep_s[FB_MAX_COUPLED * 24];
+  const bool coupled = p.mode == 0 && p.num_seqs > 1;
   const unsigned bid = blockIdx.x, nb = gridDim.x;
   uint32_t phase = 0;
   // (workgroup 0 leaves the 100 MHz wall clock of every phase end behind the counter: tools/fallback_cost.py)
@@ -1750,9 +1686,17 @@ __global__ __launch_bounds__(256, 2) void fallback_general_kernel(kvc_schedule_p
   for (int round = 0; round < 4; ++round) {
     hist_round_body(p, ws, round, bid, nb);
     sync();
-    for (int i = (int)bid; i < B; i += (int)nb) {
-      scan_pick_body<4, 4>(p, ws, round, i);
-      __syncthreads();
+    if (round == 0 && coupled) {                       // the reference's batch > 1 rule: totals, k', then the pick
+      for (int i = (int)bid; i < B; i += (int)nb) { scan_pick_body<4, 4>(p, ws, 0, i, 1); __syncthreads(); }
+      sync();
+      if (bid == 0) seq_prepare_tables(p, ws, prep_s);
+      sync();
+      for (int i = (int)bid; i < B; i += (int)nb) { scan_pick_body<4, 4>(p, ws, 0, i, 2); __syncthreads(); }
+    } else {
+      for (int i = (int)bid; i < B; i += (int)nb) {
+        scan_pick_body<4, 4>(p, ws, round, i);
+        __syncthreads();
+      }
     }
     sync();
   }
@@ -1816,7 +1760,7 @@ static void allow_dynamic_lds(const void* fn, int bytes, std::atomic<uint64_t>& 
 }
 
 struct WsLayout {
-  size_t keys, zero_begin, chunk_phys, hist, less, eq, seq_prefix, seq_k, zero_end, cum, chunkcnt,
+  size_t keys, zero_begin, chunk_phys, hist, less, eq, seq_prefix, seq_k, zero_end, cum,
       seq_tmp, tz_begin, fallback, st_claimed, st_cnt, st_def, st_samp, tz_end, st_seqrec, head_fc, rec64, total;
 };
 
@@ -1833,7 +1777,6 @@ static WsLayout ws_layout(int64_t N, int32_t G, int32_t B, int32_t bs) {
   l.seq_k = o;       o = align_up(o + (size_t)B * 4, 256);
   l.zero_end = o;
   l.cum = o;         o = align_up(o + (size_t)4 * G * kvc::RADIX * 4, 256);
-  l.chunkcnt = o;    o = align_up(o + (size_t)G * kvc::RADIX * 4, 256);
   l.seq_tmp = o;     o = align_up(o + (size_t)B * 12, 256);
   l.tz_begin = o;    // one memset at the head of the small-eviction schedule
   l.fallback = o;    o = align_up(o + 16, 256);
@@ -1947,7 +1890,6 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   ws.chunk_phys = reinterpret_cast<int32_t*>(wb + l.chunk_phys);
   ws.hist = reinterpret_cast<uint32_t*>(wb + l.hist);
   ws.cum = reinterpret_cast<uint32_t*>(wb + l.cum);
-  ws.chunkcnt = reinterpret_cast<uint32_t*>(wb + l.chunkcnt);
   ws.less = reinterpret_cast<uint32_t*>(wb + l.less);
   ws.eq = reinterpret_cast<uint32_t*>(wb + l.eq);
   ws.seq_prefix = reinterpret_cast<uint32_t*>(wb + l.seq_prefix);
@@ -2045,7 +1987,7 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     hipLaunchKernelGGL(emit_topk_kernel<4>, dim3((G + 3) / 4), dim3(256), 0, s, p, ws);
     ws.gate = ws.fallback;
   }
-  if (topk && !(p.mode == 0 && B > 1)) {
+  if (topk && !(p.mode == 0 && B > kvc::FB_MAX_COUPLED)) {
     // ---- the general pipeline as ONE gated launch (section 8)
     uint4* z16 = reinterpret_cast<uint4*>(wb + l.zero_begin);
     const int64_t zv = (int64_t)((l.zero_end - l.zero_begin) / 16);
@@ -2097,17 +2039,17 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   const unsigned htiles = (unsigned)(htiles_all < hgrid ? htiles_all : hgrid);
   // per round: the histograms, then ONE launch for scan + pick (round 0: + the chunk totals and k',
   // round 3: + the per-head counts).  Only the reference's batch > 1 rule (mode 0, B > 1) couples
-  // the sequences in round 0 and keeps the four separate launches there.  10 launches + the memset.
+  // the sequences in round 0 and takes three launches there (totals | k' | pick).  10 (12) launches
+  // + the memset.
   const bool coupled = p.mode == 0 && B > 1;
   for (int round = 0; round < 4; ++round) {
     hipLaunchKernelGGL(hist_round_kernel, dim3(htiles), dim3(256), 0, s, p, ws, round);
     if (round == 0 && coupled) {
-      hipLaunchKernelGGL(scan_round_kernel, dim3((G + 3) / 4), dim3(256), 0, s, p, ws, round);
-      hipLaunchKernelGGL(seq_totals_kernel, dim3(B), dim3(256), 0, s, p, ws);
+      hipLaunchKernelGGL(scan_pick_kernel, dim3(B), dim3(1024), 0, s, p, ws, 0, 1);
       hipLaunchKernelGGL(seq_prepare_kernel, dim3(1), dim3(1024), prep_lds, s, p, ws);
-      hipLaunchKernelGGL(pick_round_kernel, dim3(B), dim3(1024), 0, s, p, ws, round);
+      hipLaunchKernelGGL(scan_pick_kernel, dim3(B), dim3(1024), 0, s, p, ws, 0, 2);
     } else {
-      hipLaunchKernelGGL(scan_pick_kernel, dim3(B), dim3(1024), 0, s, p, ws, round);
+      hipLaunchKernelGGL(scan_pick_kernel, dim3(B), dim3(1024), 0, s, p, ws, round, 0);
     }
   }
   {
