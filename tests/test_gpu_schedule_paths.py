@@ -74,6 +74,7 @@ def test_steady_state_takes_the_small_eviction_schedule(L, H, bs, B, cap, mode):
 def test_hint_decides_and_a_device_tensor_means_unknown():
     st, evicted = _steady(2, 4, 16, 2, 512, 3)
     ds = hdev.upload(st, DEV)
+    ds.cm.schedule_path = 0                 # (this test is about the automatic choice: KVC_SCHEDULE_PATH must not decide)
     args = (ds.context_lens, ds.hanging_token_count, ds.evicted_kv_offsets, list(st.protected))
     a = ds.cm.schedule_evictions(list(st.seq_indices), ds.seq_positions, evicted, *args, total_slots=st.total_slots)
     assert ds.cm.last_schedule_path() == "small_eviction"
@@ -190,6 +191,7 @@ def test_config3_full_size_steady_state_properties():
         pytest.skip("needs ~40 GB of free HBM")
     st, evicted = _steady(L, H, bs, B, cap, 11)
     ds = hdev.upload(st, DEV, mode="per_sequence")
+    ds.cm.schedule_path = 0                 # (this test is about the automatic choice: KVC_SCHEDULE_PATH must not decide)
     args = (list(st.seq_indices), ds.seq_positions, evicted, ds.context_lens, ds.hanging_token_count,
             ds.evicted_kv_offsets, list(st.protected))
     eli, ekc, ebc = ds.cm.schedule_evictions(*args, total_slots=st.total_slots)
@@ -233,6 +235,7 @@ def test_block_tables_argument_is_accepted_and_changes_nothing(mode):
     st, evicted = _steady(3, 4, 16, 4, 512, 9)
     want = oracle_pipeline(st, evicted, mode=mode)
     ds = hdev.upload(st, DEV, mode=mode)
+    ds.cm.schedule_path = 0                 # (this test is about the automatic choice: KVC_SCHEDULE_PATH must not decide)
     args = (list(st.seq_indices), ds.seq_positions, evicted, ds.context_lens, ds.hanging_token_count,
             ds.evicted_kv_offsets, list(st.protected))
     bad = ds.block_tables.clone()
