@@ -1923,8 +1923,9 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     allow_dynamic_lds(reinterpret_cast<const void*>(seq_prepare_kernel), 160 * 1024 - 1024, prep_done);
   }
   if (topk) {
-    // ---- small-eviction schedule (section 7): two memsets, 6 launches (+ 2 for the reference's batch > 1 rule); the general
-    // pipeline is enqueued behind it and runs only if the flag was raised
+    // ---- small-eviction schedule (section 7): one memset of its counters, the output fill (side
+    // stream), 6 launches (+ 2 for the reference's batch > 1 rule); the general pipeline is enqueued
+    // behind it -- one gated launch (section 8) -- and runs only if the flag was raised
     hipMemsetAsync(wb + l.tz_begin, 0, l.tz_end - l.tz_begin, s);
     SideStream* side = nullptr;
     if (!(p.lean & 1)) {
