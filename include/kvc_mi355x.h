@@ -195,7 +195,12 @@ typedef struct kvc_schedule_params {
   int32_t schedule_path;                      /* 0 = choose by the hint, 1 = general pipeline only,
                                                * 2 = small-eviction schedule whenever the shapes allow
                                                * (falls back on device when it cannot finish exactly),
-                                               * 3 = like 2, always streaming the position rows (tests) */
+                                               * 3 = like 2, always streaming the position rows (tests),
+                                               * 4 = bracket schedule whenever the shapes allow: bulk
+                                               * evictions of sequences that do not couple, T* from a
+                                               * bracket around a sample's quantile and ONE counting pass
+                                               * instead of four digit rounds (0 takes it from 64 Ki slots
+                                               * per sequence on; falls back on device like 2) */
   int32_t sample_stride;                      /* small-eviction schedule: its pivots come from a sample
                                                * of one physical block in `sample_stride` (a power of
                                                * two <= 256); 0 = chosen from the batch size.  Results
@@ -214,6 +219,9 @@ int kvc_schedule_evictions(const kvc_schedule_params* p, void* workspace,
  * schedule; and the byte offset inside the workspace of that schedule's `fallback` word -- non-zero
  * after the call if it could not finish exactly and the general pipeline recomputed the result. */
 int32_t kvc_schedule_evictions_uses_small_eviction_schedule(const kvc_schedule_params* p);
+/* which schedule a call with these parameters enqueues: 0 = the digit rounds (general pipeline),
+ * 1 = small-eviction, 2 = bracket; 1 and 2 leave the `fallback` word behind */
+int32_t kvc_schedule_evictions_plan(const kvc_schedule_params* p);
 size_t kvc_schedule_evictions_fallback_offset(int64_t total_slots, int32_t total_heads,
                                               int32_t num_seqs, int32_t block_size);
 

@@ -121,7 +121,8 @@ def test_default_line_carries_the_other_configurations():
                           "import bench, sys; bench.OTHER_CONFIGS = (('c5', 2, 1), ('c3', 2, 1)); "
                           "sys.argv = ['bench.py', '--steps', '3', '--warmup', '1', '--no-adjacent', '--no-s0', "
                           "'--no-cpu-baseline', '--no-engine-cache', '--no-probe', '--no-live-traffic']; bench.main()"],
-                         capture_output=True, text=True, timeout=900, cwd=REPO)
+                         capture_output=True, text=True, timeout=900, cwd=REPO,
+                         env={k: v for k, v in os.environ.items() if k != "KVC_SCHEDULE_PATH"})   # (the automatic choice is asserted below)
     assert out.returncode == 0, out.stderr[-3000:]
     d = _last_json(out.stdout)
     oc = {o["config"]: o for o in d["other_configs"]}
@@ -130,7 +131,7 @@ def test_default_line_carries_the_other_configurations():
         assert "skipped" not in o, o
         assert o["stages_ms"]["S1_schedule_evictions"] > 0 and 0 < o["roofline"]["frac"] < 1
         assert 0 < o["roofline"]["frac_of_floor"] < 1.2 and o["S1_lower_bound_GBps"] > 0
-    assert oc["c3"]["S1_schedule"] == "small_eviction" and oc["c5"]["S1_schedule"] == "general"
+    assert oc["c3"]["S1_schedule"] == "small_eviction" and oc["c5"]["S1_schedule"] == "bracket"
 
 
 def test_engine_leg_traffic_is_measured_live():

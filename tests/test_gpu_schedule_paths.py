@@ -141,7 +141,7 @@ def test_ragged_heads_sampled_pivot_and_candidate_overflow():
         np.testing.assert_array_equal(got[key], want[key], err_msg=key)
 
 
-@pytest.mark.parametrize("path", [0, 1, 2, 3])
+@pytest.mark.parametrize("path", [0, 1, 2, 3, 4])
 def test_forced_paths_on_mixed_batches(path):
     """bulk and tiny evictions, compressed states, B > 1 quirk: whatever the path, the oracle's result"""
     cases = [

@@ -53,6 +53,9 @@ struct SchedWs {
   uint32_t* st_claimed;  // [64 x 32] physical blocks that are logical blocks of the batch, sharded over 64 cache lines
   struct SeqRec* st_seqrec;  // [B]  per sequence: position, protected window, pivot
   uint32_t* head_fc;     // [2G]     per head: finite-threshold chunks, all chunks (stream_records)
+  uint32_t* bsample;     // [B, BR_CELLS] bracket schedule: the sample build_keys leaves behind (nullptr: none wanted)
+  uint32_t* bthr;        // [N / bs] bracket schedule: per head (from its first chunk on) its listed thresholds, ascending
+  uint32_t* blist;       // [N / 8 + 32 G]  bracket schedule: per head the keys inside the sequence's bracket (then sorted)
   uint32_t* fallback;    // [1]      != 0: the small-eviction schedule could not finish exactly
   uint32_t* bar;         // [1]      arrivals at the grid barrier of the single-launch fallback
   const uint32_t* gate;  // general-path kernels run only if gate == nullptr or *gate != 0
@@ -67,6 +70,36 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// bracket schedule (section 9): the bracket list of head g (its slots start at off_g) lives at
+// blist + off_g / BR_DIV + g * BR_PAD and holds an eighth of the head's slots plus BR_PAD entries,
+// BR_SORT_MAX at most (what one workgroup sorts in LDS); the lists of neighbours do not overlap
+constexpr int BR_DIV = 8;
+constexpr int BR_PAD = 32;
+constexpr uint32_t BR_SORT_MAX = 4096;
+__device__ __forceinline__ uint32_t bracket_cap(uint32_t head_slots) {
+  const uint32_t c = head_slots / BR_DIV + BR_PAD;
+  return c < BR_SORT_MAX ? c : BR_SORT_MAX;
+}
+__device__ __forceinline__ int64_t bracket_list_at(int64_t head_base, int g) {
+  return head_base / BR_DIV + (int64_t)g * BR_PAD;
+}
+// the bracket's sample: a sequence's slots in at most BR_CELLS cells of 2^k >= 4 slots (the four
+// slots a build_keys thread writes lie in one cell), one sampled slot per cell at a hashed place
+// inside it (no pattern of the layout aliases with the sample); build_keys leaves its key in
+// bsample[seq * BR_CELLS + cell]
+constexpr uint32_t BR_CELLS = 32768;
+// log2 of the cell size: the power of two (>= 4) that covers the sequence with at most BR_CELLS cells
+__device__ __forceinline__ int bracket_stride_log2(uint32_t seq_slots) {
+  const uint32_t per = (seq_slots + BR_CELLS - 1u) / BR_CELLS;
+  const int lg = per <= 1u ? 0 : 32 - __builtin_clz(per - 1u);
+  return lg < 2 ? 2 : lg;
+}
+__device__ __forceinline__ uint32_t bracket_cell_slot(uint32_t cell, uint32_t seq, int stride_log2) {
+  uint32_t x = (cell * 0x9E3779B1u) ^ ((seq + 0x7F4A7C15u) * 0x85EBCA77u);
+  x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
+  return (cell << stride_log2) + (x & ((1u << stride_log2) - 1u));
 }
 
 __device__ __forceinline__ uint32_t nchunks_freed(uint32_t r, uint32_t hang, uint32_t bs) {
@@ -123,6 +156,27 @@ __device__ __forceinline__ void zero_body(uint4* zero16, int64_t zero_vecs, unsi
     zero16[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
+// bracket schedule: the key of a cell's sampled slot, if it is one of the four (the one) just built at dst
+__device__ __forceinline__ void sample_keys(const kvc_schedule_params& p, SchedWs& ws, int i, int64_t dst, const uint4& k) {
+  const int LH = p.num_layers * p.num_kv_heads;
+  const int64_t sb = p.evicted_kv_offsets[i * LH];
+  const int64_t se = i + 1 < p.num_seqs ? (int64_t)p.evicted_kv_offsets[(i + 1) * LH] : p.total_slots;
+  const int lg = bracket_stride_log2((uint32_t)(se - sb));
+  const uint32_t at0 = (uint32_t)(dst - sb);
+  const uint32_t cell = at0 >> lg;
+  const uint32_t t = bracket_cell_slot(cell, (uint32_t)i, lg) - at0;
+  if (t < 4u) ws.bsample[(int64_t)i * BR_CELLS + cell] = t == 0u ? k.x : (t == 1u ? k.y : (t == 2u ? k.z : k.w));
+}
+__device__ __forceinline__ void sample_key(const kvc_schedule_params& p, SchedWs& ws, int i, int64_t dst, uint32_t k) {
+  const int LH = p.num_layers * p.num_kv_heads;
+  const int64_t sb = p.evicted_kv_offsets[i * LH];
+  const int64_t se = i + 1 < p.num_seqs ? (int64_t)p.evicted_kv_offsets[(i + 1) * LH] : p.total_slots;
+  const int lg = bracket_stride_log2((uint32_t)(se - sb));
+  const uint32_t at = (uint32_t)(dst - sb);
+  const uint32_t cell = at >> lg;
+  if (bracket_cell_slot(cell, (uint32_t)i, lg) == at) ws.bsample[(int64_t)i * BR_CELLS + cell] = k;
+}
+
 // (bodies take the workgroup's index and the number of workgroups as arguments: the kernels below
 // pass blockIdx / gridDim, the single-launch fallback of the small-eviction schedule its own)
 template <int VEC>
@@ -166,8 +220,11 @@ __device__ __forceinline__ void build_keys_body(const kvc_schedule_params& p, Sc
     k.z = slot_key(p, m.z, q.z, seq_pos, prot, l, h);
     k.w = slot_key(p, m.w, q.w, seq_pos, prot, l, h);
     *reinterpret_cast<uint4*>(ws.keys + dst) = k;
+    if (ws.bsample != nullptr) sample_keys(p, ws, i, dst, k);
   } else {
-    ws.keys[dst] = slot_key(p, p.metrics[src], p.token_positions[src], seq_pos, prot, l, h);
+    const uint32_t k1 = slot_key(p, p.metrics[src], p.token_positions[src], seq_pos, prot, l, h);
+    ws.keys[dst] = k1;
+    if (ws.bsample != nullptr) sample_key(p, ws, i, dst, k1);
   }
   if (off == 0) ws.chunk_phys[base / bs + lbn] = (int32_t)blk;
   }
@@ -250,6 +307,7 @@ __device__ __forceinline__ void build_keys_sparse_body(const kvc_schedule_params
       kq.z = slot_key(p, m.z, q.z, seq_pos, prot, l, h);
       kq.w = slot_key(p, m.w, q.w, seq_pos, prot, l, h);
       *reinterpret_cast<uint4*>(ws.keys + base_g + (int64_t)lbn * bs + off) = kq;
+      if (ws.bsample != nullptr) sample_keys(p, ws, i, base_g + (int64_t)lbn * bs + off, kq);
       if (off == 0) ws.chunk_phys[base_g / bs + lbn] = (int32_t)blk;
     }
     __syncthreads();
@@ -686,8 +744,10 @@ __device__ __forceinline__ void block_radix_select(uint32_t* hist, uint32_t* bc,
 }
 
 // lds_cap = number of keys the dynamic LDS buffer can stage (0 = read keys from global/L2)
+// bracket = 1 (section 9): M comes from the head's sorted bracket list instead of the digit rounds
 template <int SEL_THREADS>
-__device__ __forceinline__ void select_emit_head(const kvc_schedule_params& p, SchedWs& ws, int lds_cap, int g, uint32_t* lds_keys) {
+__device__ __forceinline__ void select_emit_head(const kvc_schedule_params& p, SchedWs& ws, int lds_cap, int g, uint32_t* lds_keys,
+                                                 int bracket = 0) {
   __shared__ __attribute__((aligned(16))) uint32_t hist[RADIX];
   __shared__ uint32_t bc[4];
   __shared__ uint32_t scan_buf[8 * (SEL_THREADS / WAVE) + 1];
@@ -724,7 +784,32 @@ __device__ __forceinline__ void select_emit_head(const kvc_schedule_params& p, S
   // T*: find the first round r* whose below-T* count L_r reaches cnt, read M's digit r* off
   // the stored histogram, and only run the remaining rounds r*+1..3 over the keys.
   uint32_t M, take, eqn = 0;
-  {
+  bool from_list = false;
+  if (bracket) {
+    // the cnt-th smallest key of the head lies in its bracket list (keys in [lo, hi], sorted; `below`
+    // keys of the head are smaller than lo) unless the head frees only chunks below the bracket
+    const uint32_t below = ws.st_def[g];
+    const uint32_t m = min(ws.st_cnt[g], bracket_cap((uint32_t)n));
+    const uint32_t* list = ws.blist + bracket_list_at(base, g);
+    if (cnt > below && cnt - 1u - below < m) {
+      from_list = true;
+      M = list[cnt - 1u - below];
+      uint32_t lt = 0, eq = 0;                       // entries below M / equal to M: one parallel pass over the list
+      for (uint32_t j = tid; j < m; j += SEL_THREADS) { const uint32_t v = list[j]; lt += v < M; eq += v == M; }
+      lt = wave_reduce_sum(lt); eq = wave_reduce_sum(eq);
+      if (tid == 0) { bc[0] = 0; bc[1] = 0; }
+      __syncthreads();
+      if (lane == 0) { atomicAdd(&bc[0], lt); atomicAdd(&bc[1], eq); }
+      __syncthreads();
+      eqn = bc[1];
+      take = cnt - below - bc[0];
+      __syncthreads();
+    } else {
+      block_radix_select(hist, bc, n, cnt, key_at, [&](int) { return true; }, M, take, eqn);
+      from_list = true;
+    }
+  }
+  if (!from_list) {
     const int i_seq = g / (p.num_layers * p.num_kv_heads);
     const uint32_t Tstar = ws.seq_prefix[i_seq];
     if (tid < 4) {                                   // the four lookups in parallel (latency)
@@ -834,12 +919,13 @@ __device__ __forceinline__ void select_emit_head(const kvc_schedule_params& p, S
 // the flag down) the grid is capped and a workgroup walks several heads -- 65 536 workgroups that
 // only read the flag took 15 us, a capped grid takes what every gated launch takes
 template <int SEL_THREADS>
-__global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(kvc_schedule_params p, SchedWs ws, int lds_cap) {
+__global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(kvc_schedule_params p, SchedWs ws, int lds_cap, int bracket) {
   if (gated_off(ws)) return;
+  if (bracket && *ws.fallback != 0u) return;         // the bracket missed: the gated pipeline behind writes everything
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_keys[];
   const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
   for (int g = blockIdx.x; g < G; g += gridDim.x) {
-    select_emit_head<SEL_THREADS>(p, ws, lds_cap, g, lds_keys);
+    select_emit_head<SEL_THREADS>(p, ws, lds_cap, g, lds_keys, bracket);
     __syncthreads();
   }
 }
@@ -1627,6 +1713,684 @@ __global__ __launch_bounds__(256) void fix_unclaimed_kernel(kvc_schedule_params 
   fix_unclaimed_body(p, ws, blockIdx.x, gridDim.x);
 }
 
+// ------------------------------------------------------------------ 9. bracket schedule (bulk evictions)
+// The digit rounds of the general pipeline read every key four times to find T*, the k'-th smallest
+// chunk threshold of a sequence, although a SAMPLE of the keys already says where T* lies to within
+// a percent of the keys: with n_g = floor((R_g - hang_g) / bs) + 1 chunks freed by R_g keys, the
+// keys at or below T* number k' * bs + sum(hang) - LH * (bs + 1) / 2 give or take LH * bs / 2,
+// whatever the heads look like.  So, for sequences that do not couple (mode 1 or a single one):
+//   * build_keys leaves a sample behind: the sequence's slots in <= 32 Ki cells of 2^k slots, one
+//     hashed slot per cell (sample_keys: four instructions and a hash in a pass that waits for HBM);
+//   * bracket_kernel (a workgroup per sequence): the sample in registers, two order statistics of it
+//     -> [lo, hi] around T*: the rank above -+ (4.5 sigma of the sample + 8), a block and a half per
+//     head further down so that every head's last freed threshold is listed too;
+//   * count_collect_kernel: ONE pass over the keys (logical order, as the histograms take them):
+//     per head the keys below lo are counted, the keys inside the bracket go to the head's list
+//     (LDS queue, one returning atomic per head and 64 entries, nobody waiting for it);
+//   * bracket_records_kernel (a workgroup per head): the list, sorted (buckets over the bracket's
+//     range: five barriers); the thresholds inside the bracket are every bs-th entry from the first
+//     rank >= `below` that is a threshold rank, copied side by side for the next kernel;
+//   * bracket_select_kernel (a workgroup per sequence): thresholds below the bracket are freed for
+//     sure; the (k' - sure)-th smallest listed threshold is T* (digit rounds in LDS over the
+//     bracket's range); per-head counts, ties in (head, chunk) order as finalize_body hands them out;
+//   * select_emit with M = the cnt-th smallest key read off the sorted list: no digit rounds.
+// keys 8 + 4 B, one counting pass 4 B, emit 4 + 4 B per slot instead of 40; 7 launches instead of
+// 10, none of them a memset.  Exact whenever T* lies inside the bracket -- checked: sure < k' <=
+// sure + listed, lists within their capacity (a head whose M lies below the bracket selects it from
+// its keys) -- else the flag is raised and the digit rounds run (the single gated launch of section
+// 8, over the keys that exist already).  Measured (MI355X, S1 of one call): config 2 (256 heads x
+// 32 Ki) 189 -> 126 us, config 5 (256 x 64 Ki, bs 32) 299 -> 192, 8 x config 2 938 -> 687,
+// 1 x 256 heads x 1 Ki 111 -> 57, config 4's shape 4 x 640 heads x 16 Ki 700 -> 476.
+// What the kernels that are ONE workgroup per sequence cost was found with phase stamps
+// (-DKVC_BR_STAMPS, tools/bracket_stamps.py), and three of the findings are general:
+//   * LDS adds to one address serialise at about a lane per 8 cycles: histograms of metric keys
+//     (top byte = sign and seven exponent bits) must not be taken on the raw digits -- the rounds
+//     run on (key - min) << clz(max - min) (bracket_kernel 48 -> 33 us, bracket_select 29 -> 24);
+//   * one CU moves ~100 GB/s: 13.8 k thresholds at a 64-byte stride were 9 us of the selection
+//     kernel; the per-head kernel now leaves them side by side (2.8 us);
+//   * a 55-step bitonic network over 1024 LDS keys is 12 us even with wave-local steps ordered by
+//     wave barriers; a bucket sort over the bracket's range is 3.3 us.
+struct BrRec { int32_t seq_pos, prot; uint32_t lo, hi; };    // (same slot as SeqRec: st_seqrec)
+
+// -DKVC_BR_STAMPS (experiment builds, tools/bracket_stamps.py): workgroup 0 of the per-sequence
+// kernels leaves the 100 MHz wall clock of its phases in head_fc (unused by this schedule)
+#ifdef KVC_BR_STAMPS
+#define BR_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) ws.head_fc[k] = (uint32_t)wall_clock64(); } while (0)
+#else
+#define BR_STAMP(k) do { } while (0)
+#endif
+
+// Digit histogram of a 1024-thread workgroup's values in wave-private LDS tables (plain LDS adds:
+// the digits of a bracket are spread; the leader election of hist_add costs more than the
+// conflicts it saves here), summed into hist[256].  PRIV_STRIDE = 257 words: the same digit of
+// different waves lies in different banks, and so do neighbouring digits of one wave in the sum.
+constexpr int PRIV_STRIDE = RADIX + 1;
+constexpr int PRIV_WORDS = 16 * PRIV_STRIDE;
+__device__ __forceinline__ void priv_clear(uint32_t* priv, int sets) {
+  for (int j = threadIdx.x; j < sets * PRIV_WORDS; j += 1024) priv[j] = 0u;
+}
+__device__ __forceinline__ void priv_sum(const uint32_t* priv, uint32_t* hist, int sets) {
+  const int tid = threadIdx.x;
+  if (tid < sets * RADIX) {
+    const uint32_t* src = priv + (tid >> 8) * PRIV_WORDS + (tid & 255);
+    uint32_t t = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += src[q * PRIV_STRIDE];
+    hist[tid] = t;
+  }
+}
+// digit of the rank-th (1-based) entry of hist[256], the count below that digit and the digit's own,
+// by one wave -> bc[0], bc[1], bc[2]
+__device__ __forceinline__ void wave_pick_digit(const uint32_t* hist, uint32_t rank, uint32_t* bc) {
+  const int l = lane_id();
+  uint4 q = reinterpret_cast<const uint4*>(hist)[l];
+  q.y += q.x; q.z += q.y; q.w += q.z;
+  const uint32_t inc = wave_inclusive_scan(q.w);
+  const uint32_t ex = inc - q.w;
+  const uint32_t c[4] = {q.x + ex, q.y + ex, q.z + ex, q.w + ex};
+  uint32_t prev = ex;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (prev < rank && rank <= c[t]) { bc[0] = (uint32_t)l * 4u + (uint32_t)t; bc[1] = prev; bc[2] = c[t] - prev; }
+    prev = c[t];
+  }
+}
+
+// wave-wide minimum / maximum in every lane's reach (lane 63 holds it, read back as a scalar): row
+// rotations and the two row broadcasts of GFX9's DPP instead of six LDS-routed shuffles
+template <bool MAX>
+__device__ __forceinline__ uint32_t wave_reduce_minmax(uint32_t v) {
+  auto op = [](uint32_t x, uint32_t y) { return MAX ? max(x, y) : min(x, y); };
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xF, 0xF, false));   // row_ror:4
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, false));   // row_ror:8
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2, 3
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// the rank_a-th and rank_b-th smallest (1-based, rank_a <= rank_b <= their number) evictable keys
+// among the R x 1024 register-resident keys of a 1024-thread workgroup: digit rounds on the
+// registers, both ranks at once (they share the histogram as long as they share the prefix) -- or
+// rather a value at most the one, at least the other and at most four sample keys off: the rounds
+// stop when the buckets are that small.
+// The digits of a metric key are badly spread (a sign, an exponent: most keys share the top byte, and
+// LDS adds to one address serialise): the rounds run on (key - min) << clz(max - min) instead, as
+// many of them as max - min has bytes.  finmask: which of the thread's keys are evictable; kmin, kmax:
+// the thread's own extremes of those.  The keys are overwritten.
+template <int R>
+__device__ __forceinline__ void reg_rank_select2(uint32_t (&key)[R], uint32_t finmask, uint32_t kmin, uint32_t kmax,
+                                                 uint32_t rank_a, uint32_t rank_b,
+                                                 uint32_t* priv /*[2][PRIV_WORDS]*/, uint32_t* hist /*[2][RADIX]*/,
+                                                 uint32_t* bc /*[6]*/, uint32_t& out_a, uint32_t& out_b, SchedWs& ws) {
+  const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+  kmin = wave_reduce_minmax<false>(kmin);
+  kmax = wave_reduce_minmax<true>(kmax);
+  __syncthreads();
+  if (lane == 0) { hist[w] = kmin; hist[16 + w] = kmax; }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { kmin = min(kmin, hist[q]); kmax = max(kmax, hist[16 + q]); }
+  __syncthreads();
+  if (kmin >= kmax) { out_a = kmin; out_b = kmin; return; }             // (uniform)
+  BR_STAMP(24);
+  const int sh = __builtin_clz(kmax - kmin);
+  const int rounds = (32 - sh + 7) / 8;
+#pragma unroll
+  for (int r = 0; r < R; ++r) key[r] = (key[r] - kmin) << sh;
+  uint32_t pa = 0, pb = 0;
+  int done = 0;
+  for (int round = 0; round < rounds; ++round) {
+    const int shift = 24 - 8 * round;
+    const bool split = pa != pb;                     // (uniform)
+    priv_clear(priv, split ? 2 : 1);
+    __syncthreads();
+    uint32_t* ha = priv + w * PRIV_STRIDE;
+    uint32_t* hb = priv + PRIV_WORDS + w * PRIV_STRIDE;
+    if (!split) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (((finmask >> r) & 1u) && (round == 0 || (key[r] >> (shift + 8)) == pa)) atomicAdd(&ha[(key[r] >> shift) & 0xFFu], 1u);
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t top = key[r] >> (shift + 8);
+        if (((finmask >> r) & 1u) && (top == pa || top == pb))
+          atomicAdd(&(top == pa ? ha : hb)[(key[r] >> shift) & 0xFFu], 1u);
+      }
+    }
+    BR_STAMP(25 + 4 * round);
+    __syncthreads();
+    BR_STAMP(26 + 4 * round);
+    priv_sum(priv, hist, split ? 2 : 1);
+    __syncthreads();
+    if (w == 0) wave_pick_digit(hist, rank_a, bc);
+    if (w == 1) wave_pick_digit(hist + (split ? RADIX : 0), rank_b, bc + 3);
+    __syncthreads();                                 // (bc is next written three barriers on)
+    pa = (pa << 8) | bc[0]; rank_a -= bc[1];
+    pb = (pb << 8) | bc[3]; rank_b -= bc[4];
+    const bool fine = bc[2] <= 4u && bc[5] <= 4u;    // (uniform) both buckets hold a few sample keys: near enough
+    ++done;
+    BR_STAMP(27 + 4 * round);
+    if (fine) break;
+  }
+  // the bucket's lower end for a, its upper end for b (after all the rounds the bits below are zero)
+  const int tail = 32 - 8 * done;
+  out_a = kmin + ((pa << tail) >> sh);
+  out_b = kmin + (((pb << tail) | (tail ? (1u << tail) - 1u : 0u)) >> sh);
+  if (out_b > kmax) out_b = kmax;
+}
+
+// One workgroup per sequence: the sample build_keys left behind (one key per cell, R x 1024 cells),
+// the number of keys a k-chunk eviction takes (k bs + sum(hang) less half a block per head: the last
+// threshold of a head lies anywhere inside its next block) in sample units, and the sample's keys
+// at the ranks a few sigma around it: [lo, hi] holds T* unless the sample misleads (then the lists
+// run over or T* is not among the listed thresholds: fallback).  Below T* the bracket reaches a
+// block and a half per head further: every head's last freed threshold M, at most bs keys below
+// T* in the head's own order, should be listed as well.  Also clears the counters of the passes
+// behind it (the heads' three, the flag and the barrier words).
+constexpr int BR_R = BR_CELLS / 1024;                // sample keys per thread
+__global__ __launch_bounds__(1024) void bracket_kernel(kvc_schedule_params p, SchedWs ws) {
+  __shared__ __attribute__((aligned(16))) uint32_t priv[2 * PRIV_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t hist[2 * RADIX];
+  __shared__ uint32_t bc[6];
+  __shared__ uint32_t red_s[3];
+  const int i = blockIdx.x, tid = threadIdx.x, lane = lane_id();
+  const int B = p.num_seqs, H = p.num_kv_heads, LH = p.num_layers * H, bs = p.block_size;
+  const int64_t base = p.evicted_kv_offsets[i * LH];
+  const int64_t end = i + 1 < B ? (int64_t)p.evicted_kv_offsets[(i + 1) * LH] : p.total_slots;
+  const uint32_t n = (uint32_t)(end - base);
+  BR_STAMP(0);
+  if (tid < 3) red_s[tid] = 0;
+  if (i == 0 && tid < 64) ws.fallback[tid] = 0u;     // the flag, the barrier's counter and stamps
+  __syncthreads();
+  {
+    uint32_t hs = 0, la = 0;                         // sum of hang, heads that hold anything
+    for (int lh = tid; lh < LH; lh += blockDim.x) {
+      const int g = i * LH + lh;
+      ws.st_cnt[g] = 0u; ws.st_def[g] = 0u;
+      const int ctx = p.context_lens[((lh / H) * B + i) * H + (lh % H)];
+      if (ctx > 0) { hs += (uint32_t)p.hanging_token_count[g]; la += 1u; }
+    }
+    hs = wave_reduce_sum(hs); la = wave_reduce_sum(la);
+    if (lane == 0) { atomicAdd(&red_s[0], hs); atomicAdd(&red_s[1], la); }
+  }
+  BR_STAMP(1);
+  const int lg = bracket_stride_log2(n);
+  const uint32_t stride = 1u << lg;
+  const uint32_t* samp = ws.bsample + (int64_t)i * BR_CELLS;
+  uint32_t key[BR_R];
+  uint32_t fin = 0, finmask = 0, kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+  for (int r = 0; r < BR_R; ++r) {
+    const uint32_t x = (uint32_t)r * 1024u + (uint32_t)tid;
+    // (a cell whose sampled slot lies beyond the sequence holds nothing, or something stale)
+    const uint64_t c0 = (uint64_t)x << lg;
+    const bool have = c0 + stride <= n || (c0 < n && bracket_cell_slot(x, (uint32_t)i, lg) < n);
+    key[r] = have ? samp[x] : 0xFFFFFFFFu;
+  }
+#pragma unroll
+  for (int r = 0; r < BR_R; ++r)
+    if (key[r] < KEY_INF) { finmask |= 1u << r; kmin = min(kmin, key[r]); kmax = max(kmax, key[r]); }
+  fin = wave_reduce_sum((uint32_t)__popc(finmask));
+  static_assert(BR_R <= 32, "finmask");
+  if (lane == 0 && fin) atomicAdd(&red_s[2], fin);
+  __syncthreads();
+  fin = red_s[2];
+  BR_STAMP(2);
+  const double hs = red_s[0], la = red_s[1];
+  const int k = p.evicted_blocks_per_seq[i];
+  BrRec rec;
+  rec.seq_pos = p.seq_positions[i]; rec.prot = p.num_protected[i];
+  rec.lo = 1u; rec.hi = 0u;                          // empty bracket: nothing is listed
+  if (k > 0 && fin > 0u) {                           // (uniform)
+    const double rstar = ((double)k * bs + hs - la * (bs + 1) * 0.5) / (double)stride;
+    const double rho = rstar < 1.0 ? 1.0 : (rstar > (double)fin ? (double)fin : rstar);   // (over-ask: the top of the sample)
+    const double sig = 4.5 * sqrt(rho * (1.0 - rho / ((double)fin + 1.0)) + 1.0) + 8.0;
+    const double rlo = rho - sig - (la * bs * 1.5) / (double)stride;
+    const double rhi = rho + sig + (la * bs * 0.5) / (double)stride;
+    const bool open_lo = rlo < 1.0, open_hi = rhi >= (double)fin;
+    uint32_t ka = 0, kb = 0;
+    if (!(open_lo && open_hi)) {
+      const uint32_t ra = open_lo ? 1u : (uint32_t)rlo;
+      uint32_t rb = open_hi ? fin : (uint32_t)ceil(rhi);
+      if (rb < ra) rb = ra;
+      reg_rank_select2<BR_R>(key, finmask, kmin, kmax, ra, rb, priv, hist, bc, ka, kb, ws);
+    }
+    rec.lo = open_lo ? 0u : ka;
+    rec.hi = open_hi ? KEY_INF - 1u : kb;
+  }
+  BR_STAMP(3);
+  if (tid == 0) reinterpret_cast<BrRec*>(ws.st_seqrec)[i] = rec;
+}
+
+// ONE pass over the keys, tiles of HTILE keys on a persistent grid like hist_round, four consecutive
+// keys per lane: per head the keys below lo (-> st_def) are counted in a register per lane and summed
+// when the head changes (through LDS: one global add per workgroup and head); keys inside [lo, hi]
+// are queued in LDS (their places from one wave scan per 256 keys) and appended to their heads'
+// lists 64 at a time, one atomic per head and batch (st_cnt counts on beyond the capacity: overflow).
+// (a ballot-compacted key per lane and step was 0.8 instructions per key: 11 us of VALU time at 8 M keys)
+constexpr int CC_RUN = 256;                          // keys per wave step
+constexpr int CC_QUEUE = 64 + CC_RUN;
+__global__ __launch_bounds__(256) void count_collect_kernel(kvc_schedule_params p, SchedWs ws) {
+  __shared__ uint32_t qk[4][CC_QUEUE], qg[4][CC_QUEUE];
+  __shared__ uint32_t wg_below[8];                   // the workgroup's first eight heads: one global add each
+  const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
+  const int LH = p.num_layers * p.num_kv_heads;
+  const int64_t N = p.total_slots;
+  const int lane = lane_id(), w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const BrRec* recs = reinterpret_cast<const BrRec*>(ws.st_seqrec);
+  const int64_t ntiles = (N + HTILE - 1) / HTILE;
+  const int64_t tb = ntiles * blockIdx.x / gridDim.x, te = ntiles * (blockIdx.x + 1) / gridDim.x;
+  if (tb >= te) return;                              // (the whole workgroup)
+  if (threadIdx.x < 8) wg_below[threadIdx.x] = 0u;
+  __syncthreads();
+  int qn = 0;
+  // the queue's first n entries leave (they are in head order: runs of one head): one returning add
+  // per run reserves their places.  Nobody waits for it here: the entries stay in registers and are
+  // stored when the next batch leaves (or at the end) -- the round trip of the add, and of the
+  // head's slot range the store needs, is then long over.
+  bool pend = false;
+  uint32_t p_key = 0, p_g = 0, p_pos0 = 0;
+  int p_s0 = 0;
+  int64_t p_b = 0, p_en = 0;
+  auto complete = [&]() {
+    if (!pend) return;                               // (uniform)
+    const uint32_t pos0 = __shfl(p_pos0, p_s0, 64);
+    if (p_g != 0xFFFFFFFFu) {
+      const uint32_t pos = pos0 + (uint32_t)(lane - p_s0);
+      if (pos < bracket_cap((uint32_t)(p_en - p_b))) ws.blist[bracket_list_at(p_b, (int)p_g) + pos] = p_key;
+    }
+    pend = false;
+  };
+  auto drain = [&](int n) {
+    complete();
+    wave_lds_sync();
+    const bool have = lane < n;
+    const uint32_t g = have ? qg[w][lane] : 0xFFFFFFFFu;
+    const uint32_t gp = (have && lane > 0) ? qg[w][lane - 1] : 0xFFFFFFFEu;
+    const unsigned long long starts = __ballot(have && g != gp);
+    const unsigned long long le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);      // lanes up to mine
+    const int s0 = 63 - __builtin_clzll((starts & le) | 1ull);                        // my run's first lane
+    p_pos0 = 0;
+    if (have && lane == s0) {
+      const unsigned long long nxt = starts & ~le;                                    // the next run's start
+      const int e1 = nxt ? __ffsll((long long)nxt) - 1 : n;
+      p_pos0 = atomicAdd(&ws.st_cnt[g], (uint32_t)(e1 - lane));
+    }
+    p_key = have ? qk[w][lane] : 0u;
+    p_g = g; p_s0 = s0;
+    if (have) {
+      p_b = p.evicted_kv_offsets[g];
+      p_en = ((int)g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : N;
+    }
+    pend = true;
+    // what stays moves to the front (rest <= CC_RUN: up to CC_RUN / 64 entries per lane)
+    const int rest = qn - n;
+    uint32_t mk[CC_RUN / 64], mg[CC_RUN / 64];
+#pragma unroll
+    for (int q = 0; q < CC_RUN / 64; ++q)
+      if (q * 64 + lane < rest) { mk[q] = qk[w][n + q * 64 + lane]; mg[q] = qg[w][n + q * 64 + lane]; }
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < CC_RUN / 64; ++q)
+      if (q * 64 + lane < rest) { qk[w][q * 64 + lane] = mk[q]; qg[w][q * 64 + lane] = mg[q]; }
+    qn = rest;
+    wave_lds_sync();
+  };
+  constexpr int U = HTILE / (4 * CC_RUN);
+  static_assert(U >= 1 && HTILE % (4 * CC_RUN) == 0, "a tile is U steps of four waves");
+  // heads change rarely: the head of the last step, its slot range and its sequence's bracket stay in
+  // (scalar) registers
+  int g = upper_bound_minus1(p.evicted_kv_offsets, G, tb * HTILE);
+  int64_t g_beg = p.evicted_kv_offsets[g];
+  int64_t g_end = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : N;
+  BrRec rc = recs[g / LH];
+  const int g0 = g;                                  // (the same in every wave)
+  int acc_g = -1;
+  uint32_t acc_b = 0;                                // (per lane)
+  auto flush = [&]() {
+    const uint32_t tot = wave_reduce_sum(acc_b);
+    if (acc_g >= 0 && lane == 0 && tot) {
+      if ((unsigned)(acc_g - g0) < 8u) atomicAdd(&wg_below[acc_g - g0], tot);
+      else atomicAdd(&ws.st_def[acc_g], tot);
+    }
+    acc_b = 0;
+  };
+  // the lane's four keys idx0 .. idx0 + 3, as far as they lie in [sb, se), belong to head gs (bracket lo .. hi)
+  auto segment = [&](int gs, const uint4& k4, int64_t idx0, int64_t sb, int64_t se, uint32_t lo, uint32_t hi) {
+    if (gs != acc_g) { flush(); acc_g = gs; }
+    const uint32_t kx[4] = {k4.x, k4.y, k4.z, k4.w};
+    bool in[4];
+    uint32_t nin = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bool mine = idx0 + c >= sb && idx0 + c < se;
+      acc_b += (mine && kx[c] < lo) ? 1u : 0u;
+      in[c] = mine && kx[c] >= lo && kx[c] <= hi;
+      nin += in[c] ? 1u : 0u;
+    }
+    if (__ballot(nin != 0u)) {
+      const uint32_t inc = wave_inclusive_scan(nin);
+      int pos = qn + (int)(inc - nin);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (in[c]) { qk[w][pos] = kx[c]; qg[w][pos] = (uint32_t)gs; ++pos; }
+      qn += (int)__shfl(inc, 63, 64);
+      while (qn >= 64) drain(64);
+    }
+  };
+  uint4 kv[U], kn[U];
+  auto load_tile = [&](uint4 (&dst)[U], int64_t t) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t idx0 = t * HTILE + (int64_t)(u * 4 + w) * CC_RUN + 4 * lane;
+      if (idx0 + 3 < N) {
+        dst[u] = *reinterpret_cast<const uint4*>(ws.keys + idx0);
+      } else {
+        dst[u].x = idx0 < N ? ws.keys[idx0] : 0xFFFFFFFFu;
+        dst[u].y = idx0 + 1 < N ? ws.keys[idx0 + 1] : 0xFFFFFFFFu;
+        dst[u].z = idx0 + 2 < N ? ws.keys[idx0 + 2] : 0xFFFFFFFFu;
+        dst[u].w = 0xFFFFFFFFu;
+      }
+    }
+  };
+  load_tile(kn, tb);
+  for (int64_t t = tb; t < te; ++t) {
+    const int64_t t0 = t * HTILE;
+#pragma unroll
+    for (int u = 0; u < U; ++u) kv[u] = kn[u];
+    if (t + 1 < te) load_tile(kn, t + 1);            // the next tile's keys are on their way meanwhile
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r0 = t0 + (int64_t)(u * 4 + w) * CC_RUN;             // the step's first key
+      if (r0 >= N) break;                                                // (wave-uniform)
+      const int64_t r1 = min(N, r0 + CC_RUN);
+      const int64_t idx0 = r0 + 4 * lane;
+      if (r0 >= g_beg && r1 <= g_end) {                                  // inside the head of the last step
+        segment(g, kv[u], idx0, r0, r1, rc.lo, rc.hi);
+        continue;
+      }
+      // head of the step's first key (scalar walk from the last one), then one segment per head inside the step
+      while (g + 1 < G && (int64_t)p.evicted_kv_offsets[g + 1] <= r0) ++g;
+      while (g > 0 && (int64_t)p.evicted_kv_offsets[g] > r0) --g;
+      int64_t sb = r0;
+      for (;;) {
+        g_beg = p.evicted_kv_offsets[g];
+        g_end = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : N;
+        rc = recs[g / LH];
+        const int64_t se = min(r1, g_end);
+        if (se > sb) {
+          segment(g, kv[u], idx0, sb, se, rc.lo, rc.hi);
+          sb = se;
+        }
+        if (sb >= r1) break;
+        ++g;
+      }
+    }
+  }
+  flush();
+  if (qn > 0) drain(qn);
+  complete();
+  __syncthreads();
+  if (threadIdx.x < 8 && wg_below[threadIdx.x]) atomicAdd(&ws.st_def[g0 + threadIdx.x], wg_below[threadIdx.x]);
+}
+
+// Ascending sort of the m keys a[0..m) (LDS; m <= SZ <= BR_SORT_MAX, SZ a power of two >= 2) by a
+// 512-thread workgroup, all of them inside [lo, hi]: SZ buckets by the top bits of
+// (key - lo) << clz(hi - lo) -- about one key per bucket when the bracket is a narrow quantile
+// range -- an exclusive scan of the bucket counts, a scatter, and the order inside a bucket by
+// counting (equal keys in the order they arrived: any order of equal keys is the sorted list).
+// Five barriers instead of the 55 steps of a bitonic network (12 us at 1024 keys).  The result is in
+// a[0..m); tmp[SZ] and cnt[SZ + 1] are scratch.
+__device__ __forceinline__ void block_bucket_sort(uint32_t* a, uint32_t* tmp, uint32_t* cnt, uint32_t* wtot /*[8]*/,
+                                                  int m, int SZ, uint32_t lo, uint32_t hi) {
+  const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+  if (hi <= lo) return;                              // (uniform) one value
+  const int sh = __builtin_clz(hi - lo);
+  const int down = 32 - (31 - __builtin_clz((uint32_t)SZ));             // 32 - log2(SZ)
+  auto bucket = [&](uint32_t key) { return ((key - lo) << sh) >> down; };
+  for (int j = tid; j <= SZ; j += 512) cnt[j] = 0u;
+  __syncthreads();
+  constexpr int E = BR_SORT_MAX / 512;
+  uint32_t slot[E];
+#pragma unroll
+  for (int u = 0; u < E; ++u) {
+    const int e = tid + u * 512;
+    slot[u] = e < m ? atomicAdd(&cnt[bucket(a[e])], 1u) : 0u;
+  }
+  __syncthreads();
+  {                                                  // exclusive scan of the SZ counts, in place; cnt[SZ] = m
+    const int per = (SZ + 511) / 512;
+    const int b0 = tid * per;
+    uint32_t sum = 0;
+    for (int q = 0; q < per; ++q) if (b0 + q < SZ) sum += cnt[b0 + q];
+    const uint32_t inc = wave_inclusive_scan(sum);
+    if (lane == WAVE - 1) wtot[w] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (int q = 0; q < w; ++q) run += wtot[q];
+    for (int q = 0; q < per; ++q)
+      if (b0 + q < SZ) { const uint32_t c = cnt[b0 + q]; cnt[b0 + q] = run; run += c; }
+    if (tid == 0) cnt[SZ] = (uint32_t)m;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < E; ++u) {
+    const int e = tid + u * 512;
+    if (e < m) { const uint32_t key = a[e]; tmp[cnt[bucket(key)] + slot[u]] = key; }
+  }
+  __syncthreads();
+  for (int q = tid; q < m; q += 512) {
+    const uint32_t key = tmp[q];
+    const uint32_t b = bucket(key);
+    const uint32_t s = cnt[b], e = cnt[b + 1];
+    uint32_t r = 0;
+    for (uint32_t j = s; j < e; ++j) { const uint32_t v = tmp[j]; r += (v < key) || (v == key && j < (uint32_t)q); }
+    a[s + r] = key;
+  }
+  __syncthreads();
+}
+
+// listed thresholds of a head: list entries first, first + bs, ... (< m)
+__device__ __forceinline__ void bracket_thresholds(uint32_t below, uint32_t m, uint32_t hang, uint32_t bs,
+                                                   uint32_t& first, uint32_t& tcnt) {
+  // smallest c with c * bs + hang - 1 >= below
+  const uint32_t c0 = below + 1u > hang ? (below + 1u - hang + bs - 1u) / bs : 0u;
+  first = c0 * bs + hang - 1u - below;
+  tcnt = first < m ? (m - first + bs - 1u) / bs : 0u;
+}
+
+// one workgroup per head: its list sorted in place, and its thresholds (every bs-th entry from the
+// first threshold rank on) side by side in bthr from the head's first chunk on -- the selection
+// kernel is one workgroup per sequence and would fetch a 64-byte line per threshold otherwise
+// (9 us at config 2's 13.8 k thresholds)
+__global__ __launch_bounds__(512) void bracket_records_kernel(kvc_schedule_params p, SchedWs ws) {
+  __shared__ uint32_t a[BR_SORT_MAX], tmp[BR_SORT_MAX], cnt[BR_SORT_MAX + 1];
+  __shared__ uint32_t wtot[8];
+  const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
+  const int g = blockIdx.x;
+  BR_STAMP(16);
+  const int64_t base = p.evicted_kv_offsets[g];
+  const int64_t end = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : p.total_slots;
+  const uint32_t m = ws.st_cnt[g];
+  const uint32_t below = ws.st_def[g];
+  const uint32_t hang = (uint32_t)p.hanging_token_count[g];
+  const BrRec rc = reinterpret_cast<const BrRec*>(ws.st_seqrec)[g / (p.num_layers * p.num_kv_heads)];
+  if (m > bracket_cap((uint32_t)(end - base))) {     // the list overflowed: the digit rounds take over
+    if (threadIdx.x == 0) atomicOr(ws.fallback, 1u);
+    return;
+  }
+  if (m == 0u) return;
+  uint32_t* list = ws.blist + bracket_list_at(base, g);
+  int SZ = 2;
+  while ((uint32_t)SZ < m) SZ <<= 1;
+  for (int j = threadIdx.x; j < (int)m; j += blockDim.x) a[j] = list[j];
+  __syncthreads();
+  BR_STAMP(17);
+  if (m > 1u) block_bucket_sort(a, tmp, cnt, wtot, (int)m, SZ, rc.lo, rc.hi);
+  BR_STAMP(18);
+  if (m > 1u)
+    for (int j = threadIdx.x; j < (int)m; j += blockDim.x) list[j] = a[j];
+  uint32_t first, tcnt;
+  bracket_thresholds(below, m, hang, (uint32_t)p.block_size, first, tcnt);
+  uint32_t* thr = ws.bthr + base / p.block_size;
+  for (uint32_t j = threadIdx.x; j < tcnt; j += blockDim.x) thr[j] = a[first + j * (uint32_t)p.block_size];
+  BR_STAMP(19);
+}
+
+// One workgroup per sequence: k', the chunks below the bracket, T* = the (k' - those)-th smallest
+// of the listed thresholds (four digit rounds over them in LDS), and the per-head counts: chunks
+// with a threshold below T*, then the ones equal to it in (head, chunk) order until the total is
+// k' -- finalize_body's rule.                                        metrics.py:671-729, 773-792
+// dynamic LDS: arr[P] thresholds, head-major; tpre[LH + 1]
+__global__ __launch_bounds__(1024) void bracket_select_kernel(kvc_schedule_params p, SchedWs ws, int P) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t sel_lds[];
+  uint32_t* arr = reinterpret_cast<uint32_t*>(sel_lds);
+  uint32_t* tpre = arr + P;                                             // [LH + 1] exclusive prefix of the heads' listed thresholds
+  uint32_t* hsrc = tpre + (p.num_layers * p.num_kv_heads + 1);          // [LH] where the head's listed thresholds are (in bthr)
+  __shared__ __attribute__((aligned(16))) uint32_t priv[PRIV_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t sel_hist[RADIX];
+  __shared__ uint32_t bc[3];
+  __shared__ uint32_t red_s[1];
+  __shared__ uint32_t wsum_s[16], wsum2_s[16];
+  const int i = blockIdx.x, tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+  const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
+  const int LH = p.num_layers * p.num_kv_heads;
+  const uint32_t bs = (uint32_t)p.block_size;
+  BR_STAMP(8);
+  if (tid == 0) red_s[0] = 0;
+  __syncthreads();
+  // per head (LH <= 1024 = blockDim: one thread each): list geometry, the chunks below the bracket
+  uint32_t hang = 1, first = 0, tc = 0, sure = 0;
+  int64_t hchunk = 0;                                // the head's first chunk: where its thresholds are in bthr
+  if (tid < LH) {
+    const int g = i * LH + tid;
+    const int64_t b = p.evicted_kv_offsets[g];
+    const int64_t e = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : p.total_slots;
+    const uint32_t below = ws.st_def[g];
+    const uint32_t m = min(ws.st_cnt[g], bracket_cap((uint32_t)(e - b)));
+    hang = (uint32_t)p.hanging_token_count[g];
+    hchunk = b / bs;
+    if (e > b) {
+      bracket_thresholds(below, m, hang, bs, first, tc);
+      sure = nchunks_freed(below, hang, bs);                             // thresholds of rank < below
+    }
+  }
+  uint32_t my_pre;
+  {
+    const uint32_t inc = wave_inclusive_scan(tc);
+    if (lane == WAVE - 1) wsum_s[w] = inc;
+    const uint32_t s1 = wave_reduce_sum(sure);
+    if (lane == 0 && s1) atomicAdd(&red_s[0], s1);
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int q = 0; q < w; ++q) woff += wsum_s[q];
+    my_pre = woff + inc - tc;
+    if (tid < LH) { tpre[tid] = my_pre; hsrc[tid] = (uint32_t)hchunk; }
+    if (tid == LH - 1) tpre[LH] = woff + inc;
+  }
+  __syncthreads();
+  const uint32_t T = tpre[LH];
+  BR_STAMP(9);
+  const int kk = p.evicted_blocks_per_seq[i];
+  const uint32_t sure_all = red_s[0];
+  const BrRec rc = reinterpret_cast<const BrRec*>(ws.st_seqrec)[i];
+  // k' = min(k, finite-threshold chunks): a bracket that is open above lists every threshold from
+  // lo on, so the finite-threshold chunks are the sure ones and the listed ones
+  uint32_t need = 0;
+  bool active = kk > 0;
+  if (active) {                                      // (uniform)
+    bool ok = (uint32_t)kk > sure_all && T <= (uint32_t)P;
+    if (ok) {
+      need = (uint32_t)kk - sure_all;
+      if (need > T) { if (rc.hi >= KEY_INF - 1u) need = T; else ok = false; }
+    } else if ((uint32_t)kk == sure_all && T == 0u && rc.hi >= KEY_INF - 1u) {
+      ok = true;                                     // exactly the chunks below an open bracket
+    }
+    if (!ok) {
+      if (tid == 0) atomicOr(ws.fallback, 1u);       // T* is not among the listed thresholds
+      return;
+    }
+  }
+  uint32_t lt = 0, eq = 0;                           // my head's listed thresholds below T*, equal to it
+  uint32_t need_eq = 0;
+  if (active && need > 0u) {
+    // the listed thresholds into LDS, head-major: a group of threads per head
+    int tph = 1;
+    while (tph * 2 * LH <= 1024) tph <<= 1;          // threads per head
+    {
+      const int lh = tid / tph, sub = tid % tph;
+      if (lh < LH) {
+        const uint32_t n_h = tpre[lh + 1] - tpre[lh];
+        const uint32_t* src = ws.bthr + hsrc[lh];
+        uint32_t* dst = arr + tpre[lh];
+        for (uint32_t j = (uint32_t)sub; j < n_h; j += (uint32_t)tph) dst[j] = src[j];
+      }
+    }
+    __syncthreads();
+    BR_STAMP(10);
+    // every listed threshold lies in [lo, hi]: the rounds run on (v - lo) << clz(hi - lo), whose
+    // digits are spread (the bytes of the keys themselves are nearly constant over a bracket, and
+    // LDS adds to one address serialise)
+    const int sh = rc.hi > rc.lo ? __builtin_clz(rc.hi - rc.lo) : 32;
+    const int rounds = (32 - sh + 7) / 8;
+    uint32_t prefix = 0, krem = need;
+    for (int round = 0; round < rounds; ++round) {
+      const int shift = 24 - 8 * round;
+      priv_clear(priv, 1);
+      __syncthreads();
+      uint32_t* hw = priv + w * PRIV_STRIDE;
+      for (int e = tid; e < (int)T; e += blockDim.x) {
+        const uint32_t v = (arr[e] - rc.lo) << sh;
+        if (round == 0 || (v >> (shift + 8)) == prefix) atomicAdd(&hw[(v >> shift) & 0xFFu], 1u);
+      }
+      __syncthreads();
+      priv_sum(priv, sel_hist, 1);
+      __syncthreads();
+      if (w == 0) wave_pick_digit(sel_hist, krem, bc);
+      __syncthreads();                               // (bc is next written three barriers on)
+      prefix = (prefix << 8) | bc[0];
+      krem -= bc[1];
+    }
+    const uint32_t Tstar = rounds > 0 ? rc.lo + ((prefix << (32 - 8 * rounds)) >> sh) : rc.lo;
+    BR_STAMP(11);
+    need_eq = krem;                                  // thresholds equal to T* still to hand out
+    if (tid < LH && tc > 0u) {                       // my head's thresholds ascend: two bisections
+      const uint32_t* mine = arr + my_pre;
+      uint32_t lo = 0, hi = tc;                      // first entry >= T*
+      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (mine[mid] < Tstar) lo = mid + 1u; else hi = mid; }
+      lt = lo;
+      hi = tc;                                       // first entry > T*
+      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (mine[mid] <= Tstar) lo = mid + 1u; else hi = mid; }
+      eq = lo - lt;
+    }
+  }
+  BR_STAMP(12);
+  // ties in (head, chunk) order: exclusive scan of eq over the heads
+  {
+    const uint32_t inc = wave_inclusive_scan(eq);
+    __syncthreads();
+    if (lane == WAVE - 1) wsum2_s[w] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int q = 0; q < w; ++q) woff += wsum2_s[q];
+    const uint32_t excl = woff + inc - eq;
+    if (tid < LH) {
+      const int g = i * LH + tid;
+      uint32_t nfree = 0;
+      if (active) {
+        const uint32_t room = need_eq > excl ? need_eq - excl : 0u;
+        nfree = sure + lt + (eq < room ? eq : room);
+      }
+      p.evicted_block_count[g] = (int32_t)nfree;
+      p.evicted_kv_count[g] = nfree > 0 ? (int32_t)((nfree - 1u) * bs + hang) : 0;
+    }
+  }
+  BR_STAMP(13);
+}
+
 // ------------------------------------------------------------------ 8. the fallback in ONE launch
 // HIP has no conditional enqueue: behind the small-eviction schedule the general pipeline used to
 // be 13 launches that read the flag and return, ~4.6 us each -- 60 us of a 150 us schedule at 16
@@ -1657,8 +2421,9 @@ __device__ void grid_barrier(uint32_t* counter, uint32_t target, uint32_t* flag)
 }
 
 constexpr int FB_MAX_COUPLED = 256;                  // sequences whose batch > 1 rule fits the static tables below
+// have_keys: the key pass ran already (the bracket schedule's) -- straight to the digit rounds
 __global__ __launch_bounds__(256, 2) void fallback_general_kernel(kvc_schedule_params p, SchedWs ws, int sparse,
-                                                               uint4* zero16, int64_t zero_vecs) {
+                                                               uint4* zero16, int64_t zero_vecs, int have_keys) {
   if (*ws.fallback == 0u) return;                    // flag down: this launch is all the fallback costs
   __shared__ __attribute__((aligned(16))) uint8_t prep_s[FB_MAX_COUPLED * 24];
   const bool coupled = p.mode == 0 && p.num_seqs > 1;
@@ -1674,15 +2439,19 @@ __global__ __launch_bounds__(256, 2) void fallback_general_kernel(kvc_schedule_p
   const int B = p.num_seqs, G = B * p.num_layers * p.num_kv_heads;
   // every logical block of the batch has a physical block (the collecting pass counted them:
   // the same for all workgroups) -> nothing to clear, nothing to fix: two phases less
-  uint32_t claimed = 0;
-  for (int q = 0; q < CLAIM_SHARDS; ++q) claimed += ws.st_claimed[q * 32];
-  const bool holes = (int64_t)claimed != p.total_slots / p.block_size && !(p.lean & 2);
   zero_body(zero16, zero_vecs, bid, nb);
-  if (holes) { clear_chunk_table_body(p, ws, bid, nb); sync(); }
-  if (sparse) build_keys_sparse_body(p, ws, bid, nb);
-  else build_keys_body<4>(p, ws, bid, nb);
-  sync();
-  if (holes) { fix_unclaimed_body(p, ws, bid, nb); sync(); }
+  if (have_keys) {
+    sync();
+  } else {
+    uint32_t claimed = 0;
+    for (int q = 0; q < CLAIM_SHARDS; ++q) claimed += ws.st_claimed[q * 32];
+    const bool holes = (int64_t)claimed != p.total_slots / p.block_size && !(p.lean & 2);
+    if (holes) { clear_chunk_table_body(p, ws, bid, nb); sync(); }
+    if (sparse) build_keys_sparse_body(p, ws, bid, nb);
+    else build_keys_body<4>(p, ws, bid, nb);
+    sync();
+    if (holes) { fix_unclaimed_body(p, ws, bid, nb); sync(); }
+  }
   for (int round = 0; round < 4; ++round) {
     hist_round_body(p, ws, round, bid, nb);
     sync();
@@ -1760,15 +2529,16 @@ static void allow_dynamic_lds(const void* fn, int bytes, std::atomic<uint64_t>& 
 }
 
 struct WsLayout {
-  size_t keys, zero_begin, chunk_phys, hist, less, eq, seq_prefix, seq_k, zero_end, cum,
-      seq_tmp, tz_begin, fallback, st_claimed, st_cnt, st_def, st_samp, tz_end, st_seqrec, head_fc, rec64, total;
+  size_t keys, zero_begin, chunk_phys, bsample, hist, less, eq, seq_prefix, seq_k, zero_end, cum,
+      seq_tmp, tz_begin, fallback, st_claimed, st_cnt, st_def, st_samp, tz_end, st_seqrec, head_fc, rec64, blist, bthr, total;
 };
 
 static WsLayout ws_layout(int64_t N, int32_t G, int32_t B, int32_t bs) {
   WsLayout l;
   size_t o = 0;
-  l.keys = o;        o = align_up(o + (size_t)N * 4, 256);      // keys + chunk_phys: ONE 0xFF memset
+  l.keys = o;        o = align_up(o + (size_t)N * 4, 256);      // keys + chunk_phys + bsample: ONE 0xFF memset
   l.chunk_phys = o;  o = align_up(o + (size_t)(N / bs + 1) * 4, 256);
+  l.bsample = o;     o = align_up(o + (size_t)B * kvc::BR_CELLS * 4, 256);   // (bracket schedule; inside the 0xFF memset)
   l.zero_begin = o;  // everything up to zero_end is cleared by build_keys' tail workgroups
   l.hist = o;        o = align_up(o + (size_t)G * kvc::RADIX * 4, 256);
   l.less = o;        o = align_up(o + (size_t)G * 4, 256);
@@ -1788,6 +2558,8 @@ static WsLayout ws_layout(int64_t N, int32_t G, int32_t B, int32_t bs) {
   l.st_seqrec = o;   o = align_up(o + (size_t)B * 16, 256);
   l.head_fc = o;     o = align_up(o + (size_t)G * 8, 256);
   l.rec64 = o;       o = align_up(o + (size_t)G * kvc::KREC * 8, 256);
+  l.blist = o;       o = align_up(o + (size_t)(N / kvc::BR_DIV + (int64_t)G * kvc::BR_PAD + 4) * 4, 256);
+  l.bthr = o;        o = align_up(o + (size_t)(N / bs + 1) * 4, 256);
   l.total = o;
   return l;
 }
@@ -1822,7 +2594,7 @@ static void topk_plan(const kvc_schedule_params& p, int& p2_out, int& sshift) {
   if (G < 1 || p.total_slots <= 0) return;
   const int LH = p.num_layers * p.num_kv_heads;
   const int bsz = p.block_size;
-  if (!(bsz == 8 || bsz == 16 || bsz == 32) || p.schedule_path == 1) return;
+  if (!(bsz == 8 || bsz == 16 || bsz == 32) || p.schedule_path == 1 || p.schedule_path == 4) return;
   // (per-head tables of the pivot kernel in LDS; a record entry packs the physical slot into 32 bits)
   if (LH > kvc::PIV_MAXLH || p.num_seqs > 65535 ||
       p.num_blocks * (int64_t)bsz >= (int64_t)1 << 32) return;
@@ -1843,6 +2615,30 @@ static void topk_plan(const kvc_schedule_params& p, int& p2_out, int& sshift) {
   while (sshift < 8 && (2ll << sshift) <= stride) ++sshift;
 }
 
+// bracket schedule (section 9) or the digit rounds, for calls the small-eviction schedule does not
+// take: sequences that do not couple, a head per thread of one workgroup, list indices in 32 bits.
+// Chosen by itself from 64 Ki slots per sequence and 64 blocks per head on: below that the digit
+// rounds are as fast, and a head's list (an eighth of its slots) gets too short for the bracket.
+static bool bracket_plan(const kvc_schedule_params& p) {
+  const int LH = p.num_layers * p.num_kv_heads;
+  const int64_t G = (int64_t)p.num_seqs * LH;
+  if (G < 1 || p.total_slots <= 0 || p.block_size < 1) return false;
+  if (p.schedule_path != 0 && p.schedule_path != 4) return false;
+  if ((p.mode == 0 && p.num_seqs > 1) || LH > kvc::PIV_MAXLH || p.total_slots >= (int64_t)1 << 32) return false;
+  if (p.schedule_path == 4) return true;
+  return p.total_slots / p.num_seqs >= 65536 && p.total_slots / G >= 64 * (int64_t)p.block_size;
+}
+
+// introspection for tests and bench.py: which schedule a call with these parameters enqueues
+// (0 = the digit rounds, 1 = small-eviction, 2 = bracket)
+extern "C" int32_t kvc_schedule_evictions_plan(const kvc_schedule_params* p) {
+  if (p == nullptr) return 0;
+  int p2 = 0, sshift = 0;
+  topk_plan(*p, p2, sshift);
+  if (p2 > 0) return 1;
+  return bracket_plan(*p) ? 2 : 0;
+}
+
 // introspection for tests and bench.py: 1 if a call with these parameters enqueues the
 // small-eviction schedule; byte offset of its `fallback` word inside the workspace (non-zero
 // after the call = the general pipeline behind it recomputed the result)
@@ -1857,6 +2653,12 @@ extern "C" size_t kvc_schedule_evictions_fallback_offset(int64_t total_slots, in
   if (block_size < 1) return 0;
   return ws_layout(total_slots, total_heads, num_seqs, block_size).fallback;
 }
+
+#ifdef KVC_BR_STAMPS
+extern "C" size_t kvc_br_stamps_offset(int64_t total_slots, int32_t total_heads, int32_t num_seqs, int32_t block_size) {
+  return ws_layout(total_slots, total_heads, num_seqs, block_size).head_fc;
+}
+#endif
 
 extern "C" size_t kvc_schedule_evictions_workspace_bytes(int64_t total_slots, int32_t total_heads,
                                                          int32_t num_seqs, int32_t block_size) {
@@ -1888,6 +2690,7 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   SchedWs ws;
   ws.keys = reinterpret_cast<uint32_t*>(wb + l.keys);
   ws.chunk_phys = reinterpret_cast<int32_t*>(wb + l.chunk_phys);
+  ws.bsample = nullptr;
   ws.hist = reinterpret_cast<uint32_t*>(wb + l.hist);
   ws.cum = reinterpret_cast<uint32_t*>(wb + l.cum);
   ws.less = reinterpret_cast<uint32_t*>(wb + l.less);
@@ -1904,6 +2707,8 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   ws.fallback = reinterpret_cast<uint32_t*>(wb + l.fallback);
   ws.bar = reinterpret_cast<uint32_t*>(wb + l.fallback + 128);     // (its own cache line, same zeroed region)
   ws.head_fc = reinterpret_cast<uint32_t*>(wb + l.head_fc);
+  ws.blist = reinterpret_cast<uint32_t*>(wb + l.blist);
+  ws.bthr = reinterpret_cast<uint32_t*>(wb + l.bthr);
   ws.gate = nullptr;
   if (p.total_slots == 0) {
     hipMemsetAsync(p.evicted_kv_count, 0, (size_t)G * 4, s);
@@ -1993,7 +2798,7 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     uint4* z16 = reinterpret_cast<uint4*>(wb + l.zero_begin);
     const int64_t zv = (int64_t)((l.zero_end - l.zero_begin) / 16);
     const int sparse = p.total_slots < (int64_t)p.num_blocks * p.block_size / 2 ? 1 : 0;
-    hipLaunchKernelGGL(fallback_general_kernel, dim3((unsigned)fallback_grid()), dim3(256), 0, s, p, ws, sparse, z16, zv);
+    hipLaunchKernelGGL(fallback_general_kernel, dim3((unsigned)fallback_grid()), dim3(256), 0, s, p, ws, sparse, z16, zv, 0);
     return check_launch("schedule_evictions");
   }
   // ---- general pipeline
@@ -2001,7 +2806,11 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   // no physical block claims (inconsistent metadata); histograms and counters are zeroed by
   // the tail workgroups of build_keys.  Behind the small-eviction schedule (gated) the clear is a
   // gated kernel instead of a memset.
+  // bulk evictions of sequences that do not couple: T* from a bracket around a sample's quantile
+  // instead of four digit rounds (section 9, bracket_plan)
+  const bool bracket = !topk && bracket_plan(p);
   if (!topk && !(p.lean & 2)) hipMemsetAsync(ws.keys, 0xFF, l.zero_begin - l.keys, s);
+  if (bracket) ws.bsample = reinterpret_cast<uint32_t*>(wb + l.bsample);   // build_keys leaves the sample behind
   if (topk && !(p.lean & 2)) hipLaunchKernelGGL(clear_chunk_table_kernel, dim3(1024), dim3(256), 0, s, p, ws);
   {
     uint4* z16 = reinterpret_cast<uint4*>(wb + l.zero_begin);
@@ -2038,6 +2847,36 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   int64_t hgrid = htiles_all / 32;
   hgrid = hgrid < 1024 ? 1024 : (hgrid > 4096 ? 4096 : hgrid);
   const unsigned htiles = (unsigned)(htiles_all < hgrid ? htiles_all : hgrid);
+  if (bracket) {
+    // ---- bracket schedule (section 9) over the keys just built; the digit rounds behind it as the
+    // single gated launch of section 8
+    static std::atomic<uint64_t> bsel_done{0};
+    allow_dynamic_lds(reinterpret_cast<const void*>(bracket_select_kernel), 140 * 1024, bsel_done);   // (+ 17.7 KiB static)
+    int p2 = 1024;
+    while (p2 < LH * 128 && p2 < 32768) p2 <<= 1;      // room for ~128 listed thresholds per head
+    const size_t sel_lds = (size_t)p2 * 4 + (size_t)(2 * LH + 1) * 4;
+    hipLaunchKernelGGL(bracket_kernel, dim3(B), dim3(1024), 0, s, p, ws);
+    hipLaunchKernelGGL(count_collect_kernel, dim3(htiles), dim3(256), 0, s, p, ws);
+    hipLaunchKernelGGL(bracket_records_kernel, dim3(G), dim3(512), 0, s, p, ws);
+    hipLaunchKernelGGL(bracket_select_kernel, dim3(B), dim3(1024), sel_lds, s, p, ws, p2);
+    {
+      const int64_t avg = p.total_slots / G;
+      int64_t want = (avg + avg / 4 + 2047) / 2048 * 2048;
+      const int lds_cap = (int)(want < 2048 ? 2048 : (want > 32768 ? 32768 : want));
+      if (avg <= 8192) {
+        hipLaunchKernelGGL(select_emit_kernel<256>, dim3(G), dim3(256), (size_t)lds_cap * 4, s, p, ws, lds_cap, 1);
+      } else {
+        static std::atomic<uint64_t> long_done_b{0};
+        allow_dynamic_lds(reinterpret_cast<const void*>(select_emit_kernel<1024>), 32768 * 4, long_done_b);
+        hipLaunchKernelGGL(select_emit_kernel<1024>, dim3(G), dim3(1024), (size_t)lds_cap * 4, s, p, ws, lds_cap, 1);
+      }
+    }
+    ws.gate = ws.fallback;
+    uint4* z16 = reinterpret_cast<uint4*>(wb + l.zero_begin);
+    const int64_t zv = (int64_t)((l.zero_end - l.zero_begin) / 16);
+    hipLaunchKernelGGL(fallback_general_kernel, dim3((unsigned)fallback_grid()), dim3(256), 0, s, p, ws, 0, z16, zv, 1);
+    return check_launch("schedule_evictions");
+  }
   // per round: the histograms, then ONE launch for scan + pick (round 0: + the chunk totals and k',
   // round 3: + the per-head counts).  Only the reference's batch > 1 rule (mode 0, B > 1) couples
   // the sequences in round 0 and takes three launches there (totals | k' | pick).  10 (12) launches
@@ -2066,11 +2905,11 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     const unsigned sel_grid = (unsigned)((topk && G > 2048) ? 2048 : G);   // (gated: see select_emit_kernel)
     // > 64 KiB of dynamic LDS needs the opt-in (gfx950 has 160 KiB per CU); per device, cheap
     if (avg <= 8192) {
-      hipLaunchKernelGGL(select_emit_kernel<256>, dim3(sel_grid), dim3(256), (size_t)lds_cap * 4, s, p, ws, lds_cap);
+      hipLaunchKernelGGL(select_emit_kernel<256>, dim3(sel_grid), dim3(256), (size_t)lds_cap * 4, s, p, ws, lds_cap, 0);
     } else {
       static std::atomic<uint64_t> long_done{0};
       allow_dynamic_lds(reinterpret_cast<const void*>(select_emit_kernel<1024>), 32768 * 4, long_done);
-      hipLaunchKernelGGL(select_emit_kernel<1024>, dim3(sel_grid), dim3(1024), (size_t)lds_cap * 4, s, p, ws, lds_cap);
+      hipLaunchKernelGGL(select_emit_kernel<1024>, dim3(sel_grid), dim3(1024), (size_t)lds_cap * 4, s, p, ws, lds_cap, 0);
     }
   }
   return check_launch("schedule_evictions");

@@ -132,7 +132,7 @@ class CompressionMetrics:
         # sample stride of the small-eviction schedule's pivots (0 = chosen from the batch size;
         # results do not depend on it, tests force every value)
         self.sample_stride = int(os.environ.get("KVC_SAMPLE_STRIDE", "0"))
-        self.last_schedule = None      # (workspace, fallback offset, small-eviction schedule enqueued)
+        self.last_schedule = None      # (workspace, fallback offset, plan: 0 general, 1 small-eviction, 2 bracket)
         # host policy around the small-eviction schedule: a call whose flag was raised costs the
         # streaming pass AND the general pipeline in its single-launch form (3 x the general
         # pipeline at 16 sequences) -- fine as the exception, not as the rule.  The flag of every
@@ -420,7 +420,7 @@ class CompressionMetrics:
             _lib.check(lib.kvc_schedule_evictions(ctypes.byref(p), ws.data_ptr(), ws.numel(),
                                                   _stream(self.metrics)))
         self.last_schedule = (ws, int(lib.kvc_schedule_evictions_fallback_offset(N, B * L * H, B, bs)),
-                              bool(lib.kvc_schedule_evictions_uses_small_eviction_schedule(ctypes.byref(p))))
+                              int(lib.kvc_schedule_evictions_plan(ctypes.byref(p))))
         if self.last_schedule[2] and not capturing and int(self.schedule_path) == 0:
             off = self.last_schedule[1]
             if self._fb_pin is None:
@@ -434,15 +434,16 @@ class CompressionMetrics:
 
     def last_schedule_path(self) -> str:
         """Which schedule produced the last ``schedule_evictions`` result (synchronises; tests and
-        bench.py): "general", "small_eviction", or "small_eviction+fallback" when the
-        small-eviction schedule could not finish exactly and the general pipeline redid the work."""
-        ws, off, small = self.last_schedule
-        if not small:
+        bench.py): "general", "small_eviction" or "bracket" -- the latter two with "+fallback" when
+        the schedule could not finish exactly and the general pipeline behind it redid the work."""
+        ws, off, plan = self.last_schedule
+        if not plan:
             return "general"
+        name = {1: "small_eviction", 2: "bracket"}[plan]
         flag = int(ws[off:off + 4].view(torch.int32).item())
         if flag & 2:        # the single-launch fallback gave up waiting at its grid barrier: results are void
-            return "small_eviction+fallback+barrier_timeout"
-        return "small_eviction" if flag == 0 else "small_eviction+fallback"
+            return name + "+fallback+barrier_timeout"
+        return name if flag == 0 else name + "+fallback"
 
     def profile_schedule_evictions(self):
         """reference metrics.py:277-335: peak extra device memory of one
