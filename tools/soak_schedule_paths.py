@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak of schedule_evictions' two schedules: random continual-compression-like states (bs 8 / 16 /
+"""Soak of schedule_evictions' schedules: random continual-compression-like states (bs 8 / 16 /
 32, caps 128 .. 8192, 1 .. 6 sequences, ragged survivor counts, ties, skewed heads, both modes,
 optional caller block tables) through the small-eviction schedule (forced) and the general one;
 both must equal the oracle; the small-eviction schedule with its positions looked up lazily (path 2,
@@ -57,12 +57,15 @@ def main():
         ds = hdev.upload(st, DEV, mode=mode)
         args = (list(st.seq_indices), ds.seq_positions, evicted, ds.context_lens, ds.hanging_token_count,
                 ds.evicted_kv_offsets, list(st.protected))
-        for path in (2, 3, 1):
+        for path in (2, 3, 1, 4):
             ds.cm.schedule_path = path
             ds.cm.sample_stride = int(rng.choice([0, 0, 1, 2, 4, 8, 16, 32, 64]))
             bt = ds.block_tables if (path == 2 and seed % 3 == 0) else None
             got = ds.cm.schedule_evictions(*args, total_slots=st.total_slots, block_tables=bt)
-            if path != 1:
+            if path == 4:
+                key = f"path4: {ds.cm.last_schedule_path()}"
+                how[key] = how.get(key, 0) + 1
+            elif path != 1:
                 key = f"path{path} stride={'auto' if ds.cm.sample_stride == 0 else 'forced'}: {ds.cm.last_schedule_path()}"
                 how[key] = how.get(key, 0) + 1
             for name, g, w in zip(("eli", "ekc", "ebc"), got, (eli, ekc, ebc)):
@@ -70,7 +73,7 @@ def main():
                     print(f"MISMATCH seed={seed} path={path} key={name} mode={mode} L={L} H={H} bs={bs} B={B} cap={cap} "
                           f"ties={ties} compressed={compressed} evicted={evicted} how={ds.cm.last_schedule_path()}")
                     sys.exit(1)
-    print(f"soak ok: {n} states x 3 schedule paths identical to the oracle in {time.time() - t0:.1f} s; forced small-eviction: {how}")
+    print(f"soak ok: {n} states x 4 schedule paths identical to the oracle in {time.time() - t0:.1f} s; forced small-eviction: {how}")
 
 
 if __name__ == "__main__":
