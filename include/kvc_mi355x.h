@@ -197,7 +197,7 @@ typedef struct kvc_schedule_params {
                                                * (falls back on device when it cannot finish exactly),
                                                * 3 = like 2, always streaming the position rows (tests),
                                                * 4 = bracket schedule whenever the shapes allow: bulk
-                                               * evictions of sequences that do not couple, T* from a
+                                               * evictions, T* from a
                                                * bracket around a sample's quantile and ONE counting pass
                                                * instead of four digit rounds (0 takes it from 64 Ki slots
                                                * per sequence on; falls back on device like 2) */

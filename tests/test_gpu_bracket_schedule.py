@@ -1,5 +1,5 @@
 """schedule_evictions' third schedule (kvc_schedule_params.schedule_path 4, chosen by itself for bulk
-evictions of sequences that do not couple): T* from a bracket around a quantile of a sample of the
+evictions): T* from a bracket around a quantile of a sample of the
 keys, one counting / collecting pass, per-head sorted lists -- instead of four digit rounds over all
 the keys.  Exact or not at all: when the bracket misses (lists run over, T* not among the listed
 thresholds) a device flag is raised and the digit rounds behind it redo the work.  The oracle's
@@ -32,6 +32,7 @@ def _blocks(st):
     return ((st.context_lens.astype(np.int64) + bs - 1) // bs).sum(0).sum(-1)
 
 
+@pytest.mark.parametrize("mode", ["per_sequence", "reference"])
 @pytest.mark.parametrize("frac", [0.03, 0.3, 0.5, 0.9, 1.0])
 @pytest.mark.parametrize("L,H,bs,seq_lens,compressed,shape", [
     (4, 8, 16, [2100], False, "perm"),
@@ -40,13 +41,17 @@ def _blocks(st):
     (3, 4, 8, [1100, 900, 1300], True, "perm"),
     (8, 8, 16, [1040], False, "oldest"),
 ])
-def test_bracket_schedule_equals_the_oracle(L, H, bs, seq_lens, compressed, shape, frac):
+def test_bracket_schedule_equals_the_oracle(L, H, bs, seq_lens, compressed, shape, frac, mode):
+    """(mode "reference" with more than one sequence: the batch > 1 rule, k' of every sequence from
+    the key pass's counts before the brackets are placed)"""
     st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs, seq_lens=seq_lens, seed=11,
                           protected=[bs + 3 + 5 * i for i in range(len(seq_lens))], compressed=compressed,
                           metric_shape=shape)
     evicted = [int(n * frac) for n in _blocks(st)]
-    want = oracle_pipeline(st, evicted, mode="per_sequence")
-    got, how = _run(st, evicted, 4)
+    if mode == "reference" and len(seq_lens) > 1:
+        evicted = [int(e * (0.6 + 0.2 * i)) for i, e in enumerate(evicted)]      # uneven asks: later sequences un-evict earlier ones
+    want = oracle_pipeline(st, evicted, mode=mode)
+    got, how = _run(st, evicted, 4, mode=mode)
     assert how.startswith("bracket"), how
     for key in KEYS:
         np.testing.assert_array_equal(got[key], want[key], err_msg=f"{key} {how}")
@@ -65,13 +70,12 @@ def test_bracket_finishes_on_its_own_on_bulk_evictions():
 
 
 def test_automatic_choice():
-    """64 Ki slots per sequence and 64 blocks per head on, sequences that do not couple: the bracket;
-    smaller calls and the reference's batch > 1 rule: the digit rounds"""
+    """64 Ki slots per sequence and 64 blocks per head on: the bracket; smaller calls: the digit rounds"""
     big = synth.make_state(num_layers=4, num_kv_heads=8, block_size=16, seq_lens=[2100], seed=1, protected=32)
     two = synth.make_state(num_layers=4, num_kv_heads=8, block_size=16, seq_lens=[2100, 2500], seed=1, protected=32)
     small = synth.make_state(num_layers=4, num_kv_heads=8, block_size=16, seq_lens=[500], seed=1, protected=32)
     for st, mode, expect in ((big, "reference", "bracket"), (two, "per_sequence", "bracket"),
-                             (two, "reference", "general"), (small, "reference", "general")):
+                             (two, "reference", "bracket"), (small, "reference", "general")):
         evicted = [int(n * 0.5) for n in _blocks(st)]
         want = oracle_pipeline(st, evicted, mode=mode)
         got, how = _run(st, evicted, 0, mode=mode)
@@ -123,6 +127,42 @@ def test_zero_and_overasked_sequences():
         assert how_a.startswith("bracket") and how_b == "general"
         for key in ("eli", "ekc", "ebc"):
             np.testing.assert_array_equal(a[key], b[key], err_msg=f"{key} {evicted} {how_a}")
+
+
+def test_batch_rule_with_zero_and_uneven_asks_against_the_digit_rounds():
+    """the reference's batch > 1 rule (k' of a sequence depends on the inf-threshold chunks of the
+    ones in front and on the asks of the ones behind), bracket against digit rounds"""
+    st = synth.make_state(num_layers=4, num_kv_heads=4, block_size=16, seq_lens=[4100, 3000, 4100, 2000], seed=14,
+                          protected=[40, 20, 17, 33])
+    nb = _blocks(st)
+    for evicted in ([int(nb[0] * 0.5), 0, int(nb[2] * 0.9), int(nb[3] * 0.1)], [int(n) for n in nb], [0, 0, 0, int(nb[3] * 0.5)],
+                    [int(nb[0] * 0.2), int(nb[1] * 0.2), int(nb[2] * 0.2), 3]):
+        a, how_a = _run(st, evicted, 4, mode="reference")
+        b, how_b = _run(st, evicted, 1, mode="reference")
+        assert how_a.startswith("bracket") and how_b == "general"
+        for key in ("eli", "ekc", "ebc"):
+            np.testing.assert_array_equal(a[key], b[key], err_msg=f"{key} {evicted} {how_a}")
+
+
+def test_batch_rule_with_a_chunk_nobody_claims():
+    """a logical block without a physical one (metadata detached; outside what the reference
+    defines): its keys were never written and never counted -- the counting pass meets them,
+    raises the flag, and the digit rounds give their answer: one behaviour whatever the schedule"""
+    st = synth.make_state(num_layers=2, num_kv_heads=4, block_size=16, seq_lens=[4100, 3000], seed=15, protected=32)
+    victim = int(st.block_tables[1, 1, 2, 3])
+    st.seq_index_by_block[victim] = -1
+    evicted = [int(n * 0.5) for n in _blocks(st)]
+    a, how_a = _run(st, evicted, 4, mode="reference")
+    b, how_b = _run(st, evicted, 1, mode="reference")
+    assert how_a == "bracket+fallback" and how_b == "general", how_a
+    for key in KEYS:
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    # sequences that do not couple need no count of the evictable keys: no fallback, the same answer
+    c, how_c = _run(st, evicted, 4, mode="per_sequence")
+    d, _ = _run(st, evicted, 1, mode="per_sequence")
+    assert how_c == "bracket", how_c
+    for key in KEYS:
+        np.testing.assert_array_equal(c[key], d[key], err_msg=key)
 
 
 def test_a_skewed_head_absorbs_the_eviction():

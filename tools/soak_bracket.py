@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak and timing of schedule_evictions' bracket schedule (schedule_path 4): random bulk-eviction
-states (1 .. 4 sequences that do not couple, bs 8 / 16 / 32, heads of 0.5 k .. 16 k slots, first and
+states (1 .. 4 sequences in both modes, bs 8 / 16 / 32, heads of 0.5 k .. 16 k slots, first and
 second compressions, ties, a skewed head, eviction fractions 2 .. 98 % and over-asks) through the
 bracket schedule and the digit rounds (schedule_path 1, itself pinned to the oracle by the suite);
 the small states also against the oracle.  Prints how often the bracket finished on its own, then
@@ -40,7 +40,7 @@ def soak(n):
         T = int(rng.choice([512, 1024, 4096, 8192, 16384]))
         ties = int(rng.integers(1, 40)) if rng.random() < 0.25 else None
         compressed = bool(rng.random() < 0.4)
-        mode = "reference" if B == 1 and seed % 2 == 0 else "per_sequence"
+        mode = "reference" if seed % 2 == 0 else "per_sequence"      # (B > 1 in reference mode: the batch > 1 rule)
         st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs,
                               seq_lens=[T + int(rng.integers(0, 3 * bs)) for _ in range(B)], seed=seed,
                               protected=[int(rng.integers(1, 3 * bs)) for _ in range(B)], compressed=compressed,
@@ -83,11 +83,14 @@ def timing():
                                       ("1 x 4k", 32, 8, 4096, 16, 1, 0.5), ("1 x 8k", 32, 8, 8192, 16, 1, 0.5),
                                       ("16 x 2k", 32, 8, 2048, 16, 16, 0.5), ("16 x 4k", 32, 8, 4096, 16, 16, 0.5),
                                       ("64 x 1k", 32, 8, 1024, 16, 64, 0.5),
-                                      ("c4 shape, 4 x 16k", 80, 8, 16384, 16, 4, 0.5)):
+                                      ("c4 shape, 4 x 16k", 80, 8, 16384, 16, 4, 0.5),
+                                      ("16 x 4k, the reference's batch > 1 rule", 32, 8, 4096, 16, 16, 0.5),
+                                      ("c4 shape, 4 x 16k, batch > 1 rule", 80, 8, 16384, 16, 4, 0.5)):
+        mode = "reference" if "rule" in name else "per_sequence"
         st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs, seq_lens=[T + 1] * B, seed=1, protected=32)
         evicted = [synth.evict_block_count(context_lens_lh=st.context_lens[:, b, :], seq_len=T + 1, block_size=bs,
                                            protected_window_size=32, max_cache_tokens=int(T * keep)) for b in range(B)]
-        ds = hdev.upload(st, DEV, mode="per_sequence")
+        ds = hdev.upload(st, DEV, mode=mode)
         res = {}
         for path in (1, 4):
             outs = run(ds, st, evicted, path)

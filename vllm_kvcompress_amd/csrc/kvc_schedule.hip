@@ -54,6 +54,10 @@ struct SchedWs {
   struct SeqRec* st_seqrec;  // [B]  per sequence: position, protected window, pivot
   uint32_t* head_fc;     // [2G]     per head: finite-threshold chunks, all chunks (stream_records)
   uint32_t* bsample;     // [B, BR_CELLS] bracket schedule: the sample build_keys leaves behind (nullptr: none wanted)
+  uint32_t* bnonfin;     // [G] bracket schedule under the batch > 1 rule: build_keys counts the head's keys that are
+                         //     not evictable here (= st_samp; nullptr: not wanted)
+  const int32_t* bk;     // [B] bracket schedule: chunks a sequence frees -- the caller's k (k' = min(k, finite) is found
+                         //     on the way) or, under the batch > 1 rule, seq_k = k' itself
   uint32_t* bthr;        // [N / bs] bracket schedule: per head (from its first chunk on) its listed thresholds, ascending
   uint32_t* blist;       // [N / 8 + 32 G]  bracket schedule: per head the keys inside the sequence's bracket (then sorted)
   uint32_t* fallback;    // [1]      != 0: the small-eviction schedule could not finish exactly
@@ -221,10 +225,15 @@ __device__ __forceinline__ void build_keys_body(const kvc_schedule_params& p, Sc
     k.w = slot_key(p, m.w, q.w, seq_pos, prot, l, h);
     *reinterpret_cast<uint4*>(ws.keys + dst) = k;
     if (ws.bsample != nullptr) sample_keys(p, ws, i, dst, k);
+    if (ws.bnonfin != nullptr) {
+      const uint32_t c = (k.x >= KEY_INF) + (k.y >= KEY_INF) + (k.z >= KEY_INF) + (k.w >= KEY_INF);
+      if (c) atomicAdd(&ws.bnonfin[g], c);
+    }
   } else {
     const uint32_t k1 = slot_key(p, p.metrics[src], p.token_positions[src], seq_pos, prot, l, h);
     ws.keys[dst] = k1;
     if (ws.bsample != nullptr) sample_key(p, ws, i, dst, k1);
+    if (ws.bnonfin != nullptr && k1 >= KEY_INF) atomicAdd(&ws.bnonfin[g], 1u);
   }
   if (off == 0) ws.chunk_phys[base / bs + lbn] = (int32_t)blk;
   }
@@ -308,6 +317,10 @@ __device__ __forceinline__ void build_keys_sparse_body(const kvc_schedule_params
       kq.w = slot_key(p, m.w, q.w, seq_pos, prot, l, h);
       *reinterpret_cast<uint4*>(ws.keys + base_g + (int64_t)lbn * bs + off) = kq;
       if (ws.bsample != nullptr) sample_keys(p, ws, i, base_g + (int64_t)lbn * bs + off, kq);
+      if (ws.bnonfin != nullptr) {
+        const uint32_t c = (kq.x >= KEY_INF) + (kq.y >= KEY_INF) + (kq.z >= KEY_INF) + (kq.w >= KEY_INF);
+        if (c) atomicAdd(&ws.bnonfin[g], c);
+      }
       if (off == 0) ws.chunk_phys[base_g / bs + lbn] = (int32_t)blk;
     }
     __syncthreads();
@@ -1718,7 +1731,7 @@ __global__ __launch_bounds__(256) void fix_unclaimed_kernel(kvc_schedule_params 
 // chunk threshold of a sequence, although a SAMPLE of the keys already says where T* lies to within
 // a percent of the keys: with n_g = floor((R_g - hang_g) / bs) + 1 chunks freed by R_g keys, the
 // keys at or below T* number k' * bs + sum(hang) - LH * (bs + 1) / 2 give or take LH * bs / 2,
-// whatever the heads look like.  So, for sequences that do not couple (mode 1 or a single one):
+// whatever the heads look like.  So (the reference's batch > 1 rule: bracket_totals_kernel below):
 //   * build_keys leaves a sample behind: the sequence's slots in <= 32 Ki cells of 2^k slots, one
 //     hashed slot per cell (sample_keys: four instructions and a hash in a pass that waits for HBM);
 //   * bracket_kernel (a workgroup per sequence): the sample in registers, two order statistics of it
@@ -1882,6 +1895,35 @@ __device__ __forceinline__ void reg_rank_select2(uint32_t (&key)[R], uint32_t fi
   if (out_b > kmax) out_b = kmax;
 }
 
+// The reference's batch > 1 rule (mode 0, B > 1) couples the sequences: k' of one needs the
+// finite-threshold and all chunks of every one (seq_prepare_body) -- before the bracket, which is
+// placed by k'.  build_keys counted the keys of every head that are not evictable; a workgroup per
+// sequence sums the chunk counts that follow (seq_tmp: F, Cn), seq_prepare_kernel makes k' of them.
+// (A chunk no physical block claims keeps its 0xFFFFFFFF keys, which nobody counted: count_collect
+// raises the flag when it meets one, and the digit rounds redo the call.)
+__global__ __launch_bounds__(256) void bracket_totals_kernel(kvc_schedule_params p, SchedWs ws) {
+  __shared__ uint32_t red_s[2];
+  const int i = blockIdx.x, tid = threadIdx.x, lane = lane_id();
+  const int B = p.num_seqs, H = p.num_kv_heads, LH = p.num_layers * H, bs = p.block_size;
+  const int G = B * LH;
+  if (tid < 2) red_s[tid] = 0;
+  __syncthreads();
+  uint32_t f = 0, cn = 0;
+  for (int lh = tid; lh < LH; lh += blockDim.x) {
+    const int g = i * LH + lh;
+    const int64_t b = p.evicted_kv_offsets[g];
+    const int64_t e = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : p.total_slots;
+    const uint32_t slots = (uint32_t)(e - b), nonfin = ws.bnonfin[g];
+    const int ctx = p.context_lens[((lh / H) * B + i) * H + (lh % H)];
+    f += nchunks_freed(slots > nonfin ? slots - nonfin : 0u, (uint32_t)p.hanging_token_count[g], (uint32_t)bs);
+    cn += (uint32_t)((ctx + bs - 1) / bs);
+  }
+  f = wave_reduce_sum(f); cn = wave_reduce_sum(cn);
+  if (lane == 0) { atomicAdd(&red_s[0], f); atomicAdd(&red_s[1], cn); }
+  __syncthreads();
+  if (tid == 0) { ws.seq_tmp[i] = (int32_t)red_s[0]; ws.seq_tmp[B + i] = (int32_t)red_s[1]; }
+}
+
 // One workgroup per sequence: the sample build_keys left behind (one key per cell, R x 1024 cells),
 // the number of keys a k-chunk eviction takes (k bs + sum(hang) less half a block per head: the last
 // threshold of a head lies anywhere inside its next block) in sample units, and the sample's keys
@@ -1940,7 +1982,7 @@ __global__ __launch_bounds__(1024) void bracket_kernel(kvc_schedule_params p, Sc
   fin = red_s[2];
   BR_STAMP(2);
   const double hs = red_s[0], la = red_s[1];
-  const int k = p.evicted_blocks_per_seq[i];
+  const int k = ws.bk[i];
   BrRec rec;
   rec.seq_pos = p.seq_positions[i]; rec.prot = p.num_protected[i];
   rec.lo = 1u; rec.hi = 0u;                          // empty bracket: nothing is listed
@@ -2064,13 +2106,16 @@ __global__ __launch_bounds__(256) void count_collect_kernel(kvc_schedule_params 
     const uint32_t kx[4] = {k4.x, k4.y, k4.z, k4.w};
     bool in[4];
     uint32_t nin = 0;
+    bool hole = false;                               // a key nobody wrote (see bracket_totals_kernel)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const bool mine = idx0 + c >= sb && idx0 + c < se;
+      hole = hole || (mine && kx[c] == 0xFFFFFFFFu);
       acc_b += (mine && kx[c] < lo) ? 1u : 0u;
       in[c] = mine && kx[c] >= lo && kx[c] <= hi;
       nin += in[c] ? 1u : 0u;
     }
+    if (ws.bnonfin != nullptr && __ballot(hole) && lane == 0) atomicOr(ws.fallback, 1u);
     if (__ballot(nin != 0u)) {
       const uint32_t inc = wave_inclusive_scan(nin);
       int pos = qn + (int)(inc - nin);
@@ -2294,7 +2339,7 @@ __global__ __launch_bounds__(1024) void bracket_select_kernel(kvc_schedule_param
   __syncthreads();
   const uint32_t T = tpre[LH];
   BR_STAMP(9);
-  const int kk = p.evicted_blocks_per_seq[i];
+  const int kk = ws.bk[i];
   const uint32_t sure_all = red_s[0];
   const BrRec rc = reinterpret_cast<const BrRec*>(ws.st_seqrec)[i];
   // k' = min(k, finite-threshold chunks): a bracket that is open above lists every threshold from
@@ -2616,7 +2661,7 @@ static void topk_plan(const kvc_schedule_params& p, int& p2_out, int& sshift) {
 }
 
 // bracket schedule (section 9) or the digit rounds, for calls the small-eviction schedule does not
-// take: sequences that do not couple, a head per thread of one workgroup, list indices in 32 bits.
+// take: a head per thread of one workgroup, list indices in 32 bits.
 // Chosen by itself from 64 Ki slots per sequence and 64 blocks per head on: below that the digit
 // rounds are as fast, and a head's list (an eighth of its slots) gets too short for the bracket.
 static bool bracket_plan(const kvc_schedule_params& p) {
@@ -2624,7 +2669,8 @@ static bool bracket_plan(const kvc_schedule_params& p) {
   const int64_t G = (int64_t)p.num_seqs * LH;
   if (G < 1 || p.total_slots <= 0 || p.block_size < 1) return false;
   if (p.schedule_path != 0 && p.schedule_path != 4) return false;
-  if ((p.mode == 0 && p.num_seqs > 1) || LH > kvc::PIV_MAXLH || p.total_slots >= (int64_t)1 << 32) return false;
+  // (the reference's batch > 1 rule: as many sequences as the single-launch fallback has tables for)
+  if ((p.mode == 0 && p.num_seqs > kvc::FB_MAX_COUPLED) || LH > kvc::PIV_MAXLH || p.total_slots >= (int64_t)1 << 32) return false;
   if (p.schedule_path == 4) return true;
   return p.total_slots / p.num_seqs >= 65536 && p.total_slots / G >= 64 * (int64_t)p.block_size;
 }
@@ -2691,6 +2737,8 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   ws.keys = reinterpret_cast<uint32_t*>(wb + l.keys);
   ws.chunk_phys = reinterpret_cast<int32_t*>(wb + l.chunk_phys);
   ws.bsample = nullptr;
+  ws.bnonfin = nullptr;
+  ws.bk = p.evicted_blocks_per_seq;
   ws.hist = reinterpret_cast<uint32_t*>(wb + l.hist);
   ws.cum = reinterpret_cast<uint32_t*>(wb + l.cum);
   ws.less = reinterpret_cast<uint32_t*>(wb + l.less);
@@ -2806,11 +2854,17 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   // no physical block claims (inconsistent metadata); histograms and counters are zeroed by
   // the tail workgroups of build_keys.  Behind the small-eviction schedule (gated) the clear is a
   // gated kernel instead of a memset.
-  // bulk evictions of sequences that do not couple: T* from a bracket around a sample's quantile
+  // bulk evictions: T* from a bracket around a sample's quantile
   // instead of four digit rounds (section 9, bracket_plan)
   const bool bracket = !topk && bracket_plan(p);
   if (!topk && !(p.lean & 2)) hipMemsetAsync(ws.keys, 0xFF, l.zero_begin - l.keys, s);
+  const bool bracket_coupled = bracket && p.mode == 0 && B > 1;
   if (bracket) ws.bsample = reinterpret_cast<uint32_t*>(wb + l.bsample);   // build_keys leaves the sample behind
+  if (bracket_coupled) {                             // ... and counts the keys that are not evictable
+    hipMemsetAsync(wb + l.tz_begin, 0, l.tz_end - l.tz_begin, s);
+    ws.bnonfin = ws.st_samp;
+    ws.bk = ws.seq_k;
+  }
   if (topk && !(p.lean & 2)) hipLaunchKernelGGL(clear_chunk_table_kernel, dim3(1024), dim3(256), 0, s, p, ws);
   {
     uint4* z16 = reinterpret_cast<uint4*>(wb + l.zero_begin);
@@ -2855,6 +2909,10 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     int p2 = 1024;
     while (p2 < LH * 128 && p2 < 32768) p2 <<= 1;      // room for ~128 listed thresholds per head
     const size_t sel_lds = (size_t)p2 * 4 + (size_t)(2 * LH + 1) * 4;
+    if (bracket_coupled) {                           // k' of every sequence first (the batch > 1 rule)
+      hipLaunchKernelGGL(bracket_totals_kernel, dim3(B), dim3(256), 0, s, p, ws);
+      hipLaunchKernelGGL(seq_prepare_kernel, dim3(1), dim3(1024), prep_lds, s, p, ws);
+    }
     hipLaunchKernelGGL(bracket_kernel, dim3(B), dim3(1024), 0, s, p, ws);
     hipLaunchKernelGGL(count_collect_kernel, dim3(htiles), dim3(256), 0, s, p, ws);
     hipLaunchKernelGGL(bracket_records_kernel, dim3(G), dim3(512), 0, s, p, ws);
