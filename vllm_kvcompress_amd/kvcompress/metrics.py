@@ -126,8 +126,9 @@ class CompressionMetrics:
         # clear of the key scratch (the engine keeps block metadata consistent); saves two
         # N x 4 B passes per call, which is 12 % of the schedule at 256 resident sequences
         self.lean_outputs = False
-        # 0 = pick the schedule from the eviction counts, 1 = general pipeline only, 2 = small-eviction
-        # schedule whenever the shapes allow (kvc_schedule_params.schedule_path; tests force both)
+        # 0 = pick the schedule from the eviction counts and the shapes, 1 = digit rounds only, 2 / 3 =
+        # small-eviction schedule, 4 = bracket schedule whenever the shapes allow
+        # (kvc_schedule_params.schedule_path; tests force each)
         self.schedule_path = int(os.environ.get("KVC_SCHEDULE_PATH", "0"))
         # sample stride of the small-eviction schedule's pivots (0 = chosen from the batch size;
         # results do not depend on it, tests force every value)
