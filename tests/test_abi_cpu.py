@@ -113,3 +113,34 @@ def test_sources_are_gfx950_only():
                     assert b not in src, (f, b)
     build = open(os.path.join(pkg, "csrc", "build.sh")).read()
     assert build.count("--offload-arch=gfx950") == build.count("--offload-arch") >= 1
+
+
+def test_schedule_plan_is_a_host_decision():
+    """kvc_schedule_evictions_plan: which schedule a call enqueues follows from the parameters alone
+    (no device needed): 1 = small-eviction (the hint admits it), 2 = bracket (bulk, >= 64 Ki slots per
+    sequence and 64 blocks per head, <= 1024 heads per sequence, the reference's batch > 1 rule up to
+    256 sequences), 0 = the digit rounds"""
+    import ctypes
+    lib = kvc.load()
+
+    def plan(B=1, L=32, H=8, bs=16, slots_per_head=32768, mode=0, hint=-1, path=0):
+        p = _lib.KvcScheduleParams()
+        p.num_seqs, p.num_layers, p.num_kv_heads, p.block_size = B, L, H, bs
+        p.total_slots = B * L * H * slots_per_head
+        p.num_blocks = p.total_slots // bs
+        p.mode, p.max_evicted_blocks_hint, p.schedule_path = mode, hint, path
+        return int(lib.kvc_schedule_evictions_plan(ctypes.byref(p)))
+
+    assert plan() == 2                                            # config 2
+    assert plan(bs=32, slots_per_head=65536) == 2                 # config 5
+    assert plan(hint=200) == 1                                    # <= 2 blocks per head on average: small-eviction
+    assert plan(hint=200, path=1) == 0 and plan(path=1) == 0      # digit rounds forced
+    assert plan(hint=200, path=4) == 2                            # bracket forced
+    assert plan(slots_per_head=128) == 0                          # 32 Ki slots in the sequence
+    assert plan(L=80, slots_per_head=512) == 0                    # heads of 32 blocks
+    assert plan(slots_per_head=128, path=4) == 2                  # ... unless forced
+    assert plan(B=16, mode=0, slots_per_head=4096) == 2           # the reference's batch > 1 rule
+    assert plan(B=300, mode=0, slots_per_head=4096, L=4) == 0     # more coupled sequences than the gated launch has tables for
+    assert plan(B=300, mode=1, slots_per_head=4096, L=4) == 2     # sequences that do not couple: any number
+    assert plan(L=160, H=8, slots_per_head=2048) == 0             # 1280 heads per sequence
+    assert plan(L=160, H=8, slots_per_head=2048, path=4) == 0
