@@ -422,6 +422,28 @@ def measure_workload(a2, seed, device, steps, warmup, probe):
                      "pattern_ceiling_GBps": pattern_ceiling(k_cache, v_cache, block_bytes) if probe else None},
         "timing": f"{steps} steps after {warmup} warm-up steps, HIP events on the launch stream",
     }
+    if st.total_slots < st.num_blocks * bs // 2 and ds.cm.last_schedule_path() != "small_eviction":
+        # the batch is sparse in its cache: the same steps once more with BlockState.block_tables handed
+        # to schedule_evictions (optional argument: the key pass then goes through the tables instead
+        # of sweeping every block's metadata) -- S1 only, the other stages are untouched by it
+        n2 = min(steps, 10)
+        m2 = [[ev(), ev()] for _ in range(n2)]
+        for i in range(-2, n2):
+            if i >= 0: m2[i][0].record()
+            eli, ekc, ebc = ds.cm.schedule_evictions(seq_idx, ds.seq_positions, evicted, ds.context_lens,
+                                                     ds.hanging_token_count, ds.evicted_kv_offsets, prot, total_slots=N,
+                                                     block_tables=ds.block_tables)
+            if i >= 0: m2[i][1].record()
+            ops.schedule_cache_moves(cmi, cmc, eli, ekc, ds.evicted_kv_offsets, ds.block_tables, ds.context_lens, bs)
+            ops._execute_cache_moves(k_cache, v_cache, wm, wp, cmi, cmc, ds.evicted_kv_offsets, "plan")
+            ops._execute_cache_moves(k_cache, v_cache, wm, wp, cmi, cmc, ds.evicted_kv_offsets, "apply")
+        torch.cuda.synchronize()
+        same = bool(torch.equal(ekc, out["ekc"]))
+        res["S1_with_block_tables"] = {
+            "ms": sum(a.elapsed_time(b) for a, b in m2) / n2, "steps": n2, "used": bool(ds.cm.last_used_block_tables),
+            "same_counts": same,
+            "what": "schedule_evictions(..., block_tables=BlockState.block_tables): an extension of the reference's "
+                    "signature (INTEGRATION.md); every other figure of this entry is measured without it"}
     del k_cache, v_cache, ds, cmi, wm, wp
     torch.cuda.empty_cache()
     return res

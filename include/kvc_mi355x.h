@@ -185,13 +185,20 @@ typedef struct kvc_schedule_params {
                                                * once, in physical order, instead of a key per slot being
                                                * written and read five times.  Results are
                                                * identical either way; a wrong hint only costs time. */
-  const int32_t* block_tables;                /* accepted and ignored since ABI version 2 (BlockState.block_tables
-                                               * [L, max_num_seqs, H, block_tables_width]; the round-2
-                                               * small-eviction schedule gathered rows through it, the
-                                               * present one streams the store in physical order and
-                                               * needs no logical -> physical map at all) */
-  const int32_t* seq_index_of_slot;           /* [B] with block_tables (ignored) */
-  int32_t max_num_seqs, block_tables_width;   /* with block_tables (ignored) */
+  const int32_t* block_tables;                /* optional (NULL: none): BlockState.block_tables
+                                               * [L, max_num_seqs, H, block_tables_width].  ABI version 3: when
+                                               * the batch takes less than half of the cache (an engine sizes
+                                               * its cache to HBM) the keys are built in logical order through
+                                               * these tables instead of by a sweep over every block's metadata
+                                               * (3 scattered accesses per block of the batch instead of 7, no
+                                               * sweep).  They must be the tables the per-block metadata was
+                                               * written from; a listed block whose metadata no longer names
+                                               * the sequence counts as not there, as in the sweep.  The
+                                               * small-eviction schedule streams the store in physical order
+                                               * and ignores them (version 2 ignored them everywhere, round
+                                               * 2's schedule gathered rows through them). */
+  const int32_t* seq_index_of_slot;           /* [B] with block_tables: the sequences' indices into dimension 1 */
+  int32_t max_num_seqs, block_tables_width;   /* with block_tables */
   int32_t schedule_path;                      /* 0 = choose by the hint, 1 = general pipeline only,
                                                * 2 = small-eviction schedule whenever the shapes allow
                                                * (falls back on device when it cannot finish exactly),
@@ -222,6 +229,8 @@ int32_t kvc_schedule_evictions_uses_small_eviction_schedule(const kvc_schedule_p
 /* which schedule a call with these parameters enqueues: 0 = the digit rounds (general pipeline),
  * 1 = small-eviction, 2 = bracket; 1 and 2 leave the `fallback` word behind */
 int32_t kvc_schedule_evictions_plan(const kvc_schedule_params* p);
+/* 1 if a call with these parameters builds its keys through block_tables (see there) */
+int32_t kvc_schedule_evictions_uses_block_tables(const kvc_schedule_params* p);
 size_t kvc_schedule_evictions_fallback_offset(int64_t total_slots, int32_t total_heads,
                                               int32_t num_seqs, int32_t block_size);
 

@@ -43,6 +43,8 @@ def test_single_rank_line():
     assert ec["evicted_slots"] == d["config"]["evicted_slots"]
     assert abs(ec["moved_slots"] / d["config"]["moved_slots"] - 1) < 0.02      # another seed's metrics
     assert ec["cache_blocks"] > 8 * 32 * 8 * 257 and 0 < ec["roofline"]["frac"] < 1
+    bt = ec["S1_with_block_tables"]    # the optional argument, measured next to the drop-in figure
+    assert bt["used"] is True and bt["same_counts"] is True and 0 < bt["ms"] < 10 * ec["stages_ms"]["S1_schedule_evictions"]
     s0 = d["stages_ms_S0"]
     assert {"S0_aggregate_decode", "S0_aggregate_decode_fused_clear", "S0_aggregate_prefill",
             "S0_prefill_epilogue"} <= set(s0) and all(v["ms"] > 0 for v in s0.values())

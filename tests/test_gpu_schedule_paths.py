@@ -229,9 +229,10 @@ def test_config3_full_size_steady_state_properties():
 @pytest.mark.parametrize("mode", ["reference", "per_sequence"])
 def test_block_tables_argument_is_accepted_and_changes_nothing(mode):
     """``block_tables=`` fed round 2's gathering schedule; the streaming one needs no logical ->
-    physical map.  The argument stays (callers pass it), is never dereferenced -- a table naming
-    blocks the cache does not have included -- and the result is the oracle's, also for a batch
-    that is a subset of the resident sequences"""
+    physical map, and a batch that fills its cache builds its keys from the per-block metadata.
+    The argument is not dereferenced there -- a table naming blocks the cache does not have
+    included -- and the result is the oracle's, also for a batch that is a subset of the resident
+    sequences"""
     st, evicted = _steady(3, 4, 16, 4, 512, 9)
     want = oracle_pipeline(st, evicted, mode=mode)
     ds = hdev.upload(st, DEV, mode=mode)
@@ -404,3 +405,49 @@ def test_small_eviction_schedule_in_a_sparse_cache(path, bs):
     assert how == "small_eviction+fallback"
     for key in KEYS:
         np.testing.assert_array_equal(got[key], want[key], err_msg=f"{key} bs={bs} fallback")
+
+
+@pytest.mark.parametrize("path", [0, 1, 4])
+@pytest.mark.parametrize("bs", [8, 16, 32])
+def test_sparse_batch_builds_its_keys_through_the_callers_block_tables(path, bs):
+    """a batch that takes less than half of its cache (an engine sizes the cache to HBM) and a
+    caller that hands over BlockState.block_tables: the keys are built in logical order through the
+    tables instead of by a sweep over every block's metadata.  The oracle's result, on every
+    schedule that writes keys, for the whole batch and for a subset of the resident sequences; a
+    block whose metadata no longer names its sequence counts as not there on both routes"""
+    for seed, (compressed, frac) in enumerate([(False, 0.5), (True, 0.6), (False, 0.1)]):
+        st = synth.make_state(num_layers=2, num_kv_heads=4, block_size=bs, seq_lens=[70 * bs, 13 * bs + 5, 150 * bs],
+                              seed=40 + seed, protected=[bs + 1, 3, 2 * bs], compressed=compressed, spare_block_frac=4.0)
+        assert st.total_slots < st.num_blocks * bs // 2
+        evicted = [int(n * frac) for n in ((st.context_lens.astype(np.int64) + bs - 1) // bs).sum(0).sum(-1)]
+        for mode in ("reference", "per_sequence"):
+            want = oracle_pipeline(st, evicted, mode=mode)
+            ds = hdev.upload(st, DEV, mode=mode)
+            ds.cm.schedule_path = path
+            args = (list(st.seq_indices), ds.seq_positions, evicted, ds.context_lens, ds.hanging_token_count,
+                    ds.evicted_kv_offsets, list(st.protected))
+            for bt in (ds.block_tables, None):
+                got = ds.cm.schedule_evictions(*args, total_slots=st.total_slots, block_tables=bt)
+                assert ds.cm.last_used_block_tables == (bt is not None and not ds.cm.last_schedule_path().startswith("small"))
+                for g, key in zip(got, ("eli", "ekc", "ebc")):
+                    np.testing.assert_array_equal(g.cpu().numpy(), want[key], err_msg=f"{key} {mode} tables={bt is not None}")
+    # two of the three sequences, and a detached block: with and without the tables
+    st = synth.make_state(num_layers=2, num_kv_heads=4, block_size=bs, seq_lens=[70 * bs, 40 * bs, 150 * bs], seed=44,
+                          protected=bs + 1, spare_block_frac=4.0)
+    st.seq_index_by_block[int(st.block_tables[1, 2, 3, 5])] = -1
+    ds = hdev.upload(st, DEV, mode="per_sequence")
+    ds.cm.schedule_path = path
+    sub = [0, 2]
+    ctx = ds.context_lens[:, sub].contiguous()
+    hang = ds.hanging_token_count[sub].contiguous()
+    offs = torch.from_numpy(synth.kv_offsets(st.context_lens[:, sub], bs)).to(DEV)
+    n_sub = int(((st.context_lens[:, sub].astype(np.int64) + bs - 1) // bs).sum()) * bs
+    ev = [int(n * 0.5) for n in ((st.context_lens[:, sub].astype(np.int64) + bs - 1) // bs).sum(0).sum(-1)]
+    res = []
+    for bt in (ds.block_tables, None):
+        out = ds.cm.schedule_evictions([int(st.seq_indices[i]) for i in sub], ds.seq_positions[sub].contiguous(), ev, ctx, hang,
+                                       offs, [st.protected[i] for i in sub], total_slots=n_sub, block_tables=bt)
+        res.append([t.clone() for t in out])
+    assert ds.cm.last_used_block_tables is False
+    for x, y in zip(*res):
+        assert torch.equal(x, y)

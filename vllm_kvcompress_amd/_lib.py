@@ -88,6 +88,7 @@ SYMBOLS = {
                                          c_void_p]),
     "kvc_schedule_evictions_uses_small_eviction_schedule": (c_int32, [ctypes.POINTER(KvcScheduleParams)]),
     "kvc_schedule_evictions_plan": (c_int32, [ctypes.POINTER(KvcScheduleParams)]),
+    "kvc_schedule_evictions_uses_block_tables": (c_int32, [ctypes.POINTER(KvcScheduleParams)]),
     "kvc_schedule_evictions_fallback_offset": (c_size_t, [c_int64, c_int32, c_int32, c_int32]),
     "kvc_aggregate_decode": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
                                        c_void_p]),

@@ -337,6 +337,56 @@ __global__ __launch_bounds__(256) void build_keys_sparse_kernel(kvc_schedule_par
   build_keys_sparse_body(p, ws, blockIdx.x, data_blocks);
 }
 
+// The same keys in LOGICAL order through the caller's block tables (kvc_schedule_params.block_tables,
+// optional): a thread takes four consecutive slots of a head, looks its physical block up and reads
+// the two rows.  For a batch that is sparse in its cache -- an engine sizes the cache to HBM -- this
+// replaces the sweep over every block's sequence index and the five scattered accesses per batch
+// block that follow it (layer, head, logical number; key and chunk-table stores) by two row reads
+// and one 4-byte check (the block must still name the sequence as its owner: a detached block is an
+// unclaimed chunk, as in the sweep); keys, chunk table and sample are written side by side and
+// completely, so nothing has to be cleared first.  (108 -> 36 us for one 32k sequence in a 222 GiB cache.)
+__global__ __launch_bounds__(256) void build_keys_tables_kernel(kvc_schedule_params p, SchedWs ws, unsigned data_blocks,
+                                                                uint4* zero16, int64_t zero_vecs) {
+  if (gated_off(ws)) return;
+  if (blockIdx.x >= data_blocks) {      // tail workgroups clear the counters of the later passes
+    zero_body(zero16, zero_vecs, blockIdx.x - data_blocks, gridDim.x - data_blocks);
+    return;
+  }
+  const int H = p.num_kv_heads, LH = p.num_layers * H, G = p.num_seqs * LH, bs = p.block_size;
+  const int64_t N = p.total_slots;
+  for (int64_t t0 = (int64_t)blockIdx.x * 1024; t0 < N; t0 += (int64_t)data_blocks * 1024) {
+    const int64_t idx0 = t0 + 4 * threadIdx.x;
+    if (idx0 >= N) continue;
+    int g = upper_bound_minus1(p.evicted_kv_offsets, G, t0);       // (the same walk in every thread of the workgroup)
+    while (g + 1 < G && (int64_t)p.evicted_kv_offsets[g + 1] <= idx0) ++g;
+    const int64_t base = p.evicted_kv_offsets[g];
+    const int lbn = (int)((idx0 - base) / bs), off = (int)((idx0 - base) % bs);
+    const int i = g / LH, l = (g % LH) / H, h = g % H;
+    const int sq = p.seq_index_of_slot[i];
+    int64_t blk = -1;
+    if (lbn < p.block_tables_width && sq >= 0 && sq < p.max_num_seqs)
+      blk = p.block_tables[(((int64_t)l * p.max_num_seqs + sq) * H + h) * p.block_tables_width + lbn];
+    const bool ok = blk >= 0 && blk < p.num_blocks && p.seq_index_by_block[blk] == sq;
+    uint4 k = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    if (ok) {
+      const float4 m = *reinterpret_cast<const float4*>(p.metrics + blk * bs + off);
+      const int4 q = *reinterpret_cast<const int4*>(p.token_positions + blk * bs + off);
+      const int seq_pos = p.seq_positions[i], prot = p.num_protected[i];
+      k.x = slot_key(p, m.x, q.x, seq_pos, prot, l, h);
+      k.y = slot_key(p, m.y, q.y, seq_pos, prot, l, h);
+      k.z = slot_key(p, m.z, q.z, seq_pos, prot, l, h);
+      k.w = slot_key(p, m.w, q.w, seq_pos, prot, l, h);
+      if (ws.bnonfin != nullptr) {
+        const uint32_t c = (k.x >= KEY_INF) + (k.y >= KEY_INF) + (k.z >= KEY_INF) + (k.w >= KEY_INF);
+        if (c) atomicAdd(&ws.bnonfin[g], c);
+      }
+    }
+    *reinterpret_cast<uint4*>(ws.keys + idx0) = k;
+    if (ws.bsample != nullptr) sample_keys(p, ws, i, idx0, k);
+    if (off == 0) ws.chunk_phys[base / bs + lbn] = ok ? (int32_t)blk : -1;
+  }
+}
+
 // ------------------------------------------------------------------ 1. per-head histograms
 // flat tiles of TILE keys; a tile inside one head (the common case) accumulates in LDS.
 constexpr int HTILE = 2048;
@@ -2685,6 +2735,19 @@ extern "C" int32_t kvc_schedule_evictions_plan(const kvc_schedule_params* p) {
   return bracket_plan(*p) ? 2 : 0;
 }
 
+// the key pass through the caller's block tables (build_keys_tables_kernel) or from the per-block
+// metadata: tables given, a batch that takes less than half of the cache, 16-byte rows
+static bool tables_plan(const kvc_schedule_params& p) {
+  return p.block_tables != nullptr && p.seq_index_of_slot != nullptr && p.block_tables_width > 0 && p.max_num_seqs > 0 &&
+         p.block_size >= 4 && p.block_size % 4 == 0 && p.total_slots < (int64_t)p.num_blocks * p.block_size / 2;
+}
+extern "C" int32_t kvc_schedule_evictions_uses_block_tables(const kvc_schedule_params* p) {
+  if (p == nullptr || !tables_plan(*p)) return 0;
+  int p2 = 0, sshift = 0;
+  topk_plan(*p, p2, sshift);
+  return p2 > 0 ? 0 : 1;                             // (the small-eviction schedule streams the store: no tables)
+}
+
 // introspection for tests and bench.py: 1 if a call with these parameters enqueues the
 // small-eviction schedule; byte offset of its `fallback` word inside the workspace (non-zero
 // after the call = the general pipeline behind it recomputed the result)
@@ -2857,7 +2920,10 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   // bulk evictions: T* from a bracket around a sample's quantile
   // instead of four digit rounds (section 9, bracket_plan)
   const bool bracket = !topk && bracket_plan(p);
-  if (!topk && !(p.lean & 2)) hipMemsetAsync(ws.keys, 0xFF, l.zero_begin - l.keys, s);
+  // a batch that is sparse in its cache, with the caller's block tables at hand: the keys in logical
+  // order through the tables (build_keys_tables_kernel; every slot is written: no clearing)
+  const bool by_tables = !topk && tables_plan(p);
+  if (!topk && !(p.lean & 2) && !by_tables) hipMemsetAsync(ws.keys, 0xFF, l.zero_begin - l.keys, s);
   const bool bracket_coupled = bracket && p.mode == 0 && B > 1;
   if (bracket) ws.bsample = reinterpret_cast<uint32_t*>(wb + l.bsample);   // build_keys leaves the sample behind
   if (bracket_coupled) {                             // ... and counts the keys that are not evictable
@@ -2883,7 +2949,12 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     // blocks of the batch / blocks of the cache: a dense cache is faster with one independent thread
     // per 4 slots (build_keys_kernel), a sparse one with the compacting sweep
     const bool sparse = p.total_slots < (int64_t)p.num_blocks * bsz / 2;
-    if (sparse && (bsz == 4 || bsz == 8 || bsz == 16 || bsz == 32 || bsz == 64)) {
+    if (by_tables) {
+      int64_t tb64 = (p.total_slots + 1023) / 1024;
+      if (tb64 > cap) tb64 = cap;
+      const unsigned tbk = (unsigned)(tb64 < 1 ? 1 : tb64);
+      hipLaunchKernelGGL(build_keys_tables_kernel, dim3(tbk + zb), dim3(256), 0, s, p, ws, tbk, z16, zv);
+    } else if (sparse && (bsz == 4 || bsz == 8 || bsz == 16 || bsz == 32 || bsz == 64)) {
       // one workgroup per SPARSE_CHUNK blocks (grid-stride when capped)
       int64_t wb64 = (p.num_blocks + kvc::SPARSE_CHUNK - 1) / kvc::SPARSE_CHUNK;
       if (wb64 > cap) wb64 = cap;

@@ -134,6 +134,7 @@ class CompressionMetrics:
         # results do not depend on it, tests force every value)
         self.sample_stride = int(os.environ.get("KVC_SAMPLE_STRIDE", "0"))
         self.last_schedule = None      # (workspace, fallback offset, plan: 0 general, 1 small-eviction, 2 bracket)
+        self.last_used_block_tables = False   # the last call built its keys through block_tables= (sparse batch)
         # host policy around the small-eviction schedule: a call whose flag was raised costs the
         # streaming pass AND the general pipeline in its single-launch form (3 x the general
         # pipeline at 16 sequences) -- fine as the exception, not as the rule.  The flag of every
@@ -420,6 +421,7 @@ class CompressionMetrics:
         with torch.cuda.device(dev):
             _lib.check(lib.kvc_schedule_evictions(ctypes.byref(p), ws.data_ptr(), ws.numel(),
                                                   _stream(self.metrics)))
+        self.last_used_block_tables = bool(lib.kvc_schedule_evictions_uses_block_tables(ctypes.byref(p)))
         self.last_schedule = (ws, int(lib.kvc_schedule_evictions_fallback_offset(N, B * L * H, B, bs)),
                               int(lib.kvc_schedule_evictions_plan(ctypes.byref(p))))
         if self.last_schedule[2] and not capturing and int(self.schedule_path) == 0:
