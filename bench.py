@@ -84,8 +84,8 @@ def parse_args(argv=None):
                     help="extension: no MAX_INT padding / key-scratch clear in schedule_evictions and no "
                          "zero fill of the move workspace (outputs a consumer reads are unchanged)")
     ap.add_argument("--pass-block-tables", action="store_true",
-                    help="hand BlockState.block_tables to schedule_evictions (round 2's gathering schedule read it; "
-                         "still accepted, ignored by the streaming one)")
+                    help="hand BlockState.block_tables to schedule_evictions (optional argument: bulk evictions of a batch "
+                         "that is sparse in its cache build their keys through it; the streaming schedule ignores it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-adjacent", action="store_true",
                     help="skip the decode-attention (F3) side measurement")
@@ -831,7 +831,7 @@ def main():
                             + f"protected_window={args.protected}, "
                             f"metrics={args.metric_shape}, schedule mode={args.mode}"
                             + (", lean outputs (extension)" if args.lean else "")
-                            + (", block_tables passed to schedule_evictions (ignored)" if args.pass_block_tables else "")
+                            + (", block_tables passed to schedule_evictions (read only when the batch is sparse in its cache)" if args.pass_block_tables else "")
                             + ", physical blocks "
                             f"{'in allocation order' if args.contiguous_blocks else 'shuffled'}"
                             + (f" inside a cache of {st.num_blocks} blocks" if args.spare_blocks != 0.02 else ""),
