@@ -422,7 +422,7 @@ def measure_workload(a2, seed, device, steps, warmup, probe):
                      "pattern_ceiling_GBps": pattern_ceiling(k_cache, v_cache, block_bytes) if probe else None},
         "timing": f"{steps} steps after {warmup} warm-up steps, HIP events on the launch stream",
     }
-    if st.total_slots < st.num_blocks * bs // 2 and ds.cm.last_schedule_path() != "small_eviction":
+    if st.total_slots < st.num_blocks * bs // 2 and not ds.cm.last_schedule_path().startswith("small_eviction"):
         # the batch is sparse in its cache: the same steps once more with BlockState.block_tables handed
         # to schedule_evictions (optional argument: the key pass then goes through the tables instead
         # of sweeping every block's metadata) -- S1 only, the other stages are untouched by it

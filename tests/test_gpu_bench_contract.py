@@ -24,8 +24,8 @@ def _last_json(stdout):
 def test_single_rank_line():
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "4", "--warmup", "1",
                           "--seq-len", "4096", "--no-adjacent", "--engine-cache-frac", "0.02", "--no-live-traffic"],
-                         capture_output=True, text=True,
-                         timeout=600, cwd=REPO)
+                         capture_output=True, text=True, timeout=600, cwd=REPO,
+                         env={k: v for k, v in os.environ.items() if k != "KVC_SCHEDULE_PATH"})   # (the automatic choice is asserted below)
     assert out.returncode == 0, out.stderr[-2000:]
     d = _last_json(out.stdout)
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1
