@@ -199,15 +199,15 @@ typedef struct kvc_schedule_params {
                                                * 2's schedule gathered rows through them). */
   const int32_t* seq_index_of_slot;           /* [B] with block_tables: the sequences' indices into dimension 1 */
   int32_t max_num_seqs, block_tables_width;   /* with block_tables */
-  int32_t schedule_path;                      /* 0 = choose by the hint, 1 = general pipeline only,
+  int32_t schedule_path;                      /* 0 = choose by the hint and the shapes, 1 = digit rounds only,
                                                * 2 = small-eviction schedule whenever the shapes allow
                                                * (falls back on device when it cannot finish exactly),
                                                * 3 = like 2, always streaming the position rows (tests),
                                                * 4 = bracket schedule whenever the shapes allow: bulk
-                                               * evictions, T* from a
-                                               * bracket around a sample's quantile and ONE counting pass
-                                               * instead of four digit rounds (0 takes it from 64 Ki slots
-                                               * per sequence on; falls back on device like 2) */
+                                               * evictions, T* from a bracket around a sample's quantile
+                                               * and ONE counting pass instead of four digit rounds (0
+                                               * takes it from 64 Ki slots per sequence and 64 blocks per
+                                               * head on; falls back on device like 2) */
   int32_t sample_stride;                      /* small-eviction schedule: its pivots come from a sample
                                                * of one physical block in `sample_stride` (a power of
                                                * two <= 256); 0 = chosen from the batch size.  Results
