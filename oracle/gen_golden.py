@@ -175,6 +175,15 @@ def case_grid():
                   seq_lens=[1536] * 3, seed=22, protected=33, steady_cap=512), "cap512", {}))
     cases.append(("b1_bs8_steady128", dict(num_layers=3, num_kv_heads=2, block_size=8,
                   seq_lens=[384], seed=23, protected=9, steady_cap=128), "cap128", {}))
+    # bulk evictions big enough for the HIP path's bracket schedule to be the automatic choice
+    # (>= 64 Ki candidate slots per sequence, heads of >= 64 blocks): one sequence, two sequences
+    # under the batch > 1 rule with uneven asks, a second compression at bs 32
+    cases.append(("b1_bs16_bulk64k", dict(num_layers=4, num_kv_heads=8, block_size=16,
+                  seq_lens=[2100], seed=31, protected=32), "mid", dict(hd=16)))
+    cases.append(("b2_bs16_bulk64k_rule", dict(num_layers=4, num_kv_heads=8, block_size=16,
+                  seq_lens=[2100, 2500], seed=32, protected=[32, 17]), "uneven", dict(hd=16)))
+    cases.append(("b1_bs32_bulk64k_compressed", dict(num_layers=2, num_kv_heads=8, block_size=32,
+                  seq_lens=[9000], seed=33, protected=40, compressed=True), "mid", dict(hd=16)))
     return cases
 
 
@@ -202,6 +211,8 @@ def eviction_spec(st, spec, rng):
             k = limit // 2
         elif spec == "mixed":
             k = [limit // 2, 0, limit][b % 3]
+        elif spec == "uneven":
+            k = [limit // 2, limit // 3, 2 * limit // 3][b % 3]
         else:
             raise ValueError(spec)
         out.append(int(k))
@@ -211,11 +222,14 @@ def eviction_spec(st, spec, rng):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    ap.add_argument("--only", default="", help="write only the cases whose name contains this")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     ops, met = import_reference()
     rng = np.random.default_rng(1234)
     for name, mk, spec, extra in case_grid():
+        if args.only not in name:
+            continue
         st = synth.make_state(**mk)
         evicted = eviction_spec(st, spec, rng)
         sched_kw = {}
