@@ -212,6 +212,13 @@ typedef struct kvc_schedule_params {
                                                * of one physical block in `sample_stride` (a power of
                                                * two <= 256); 0 = chosen from the batch size.  Results
                                                * do not depend on it (tests force several values). */
+  int32_t fallback_grid;                      /* ABI version 4.  Workgroups of the single launch that redoes a
+                                               * small-eviction / bracket call on the general pipeline when
+                                               * its flag was raised; 0 = what the occupancy query says is
+                                               * resident at once.  Results do not depend on it: the phases
+                                               * of that launch wait for work, not for workgroups, so a grid
+                                               * that is not resident at once (tests force one) only runs
+                                               * slower. */
   /* outputs */
   int32_t* evicted_logical_indices;           /* [N] */
   int32_t* evicted_kv_count;                  /* [B,L,H] */
@@ -227,8 +234,31 @@ int kvc_schedule_evictions(const kvc_schedule_params* p, void* workspace,
  * after the call if it could not finish exactly and the general pipeline recomputed the result. */
 int32_t kvc_schedule_evictions_uses_small_eviction_schedule(const kvc_schedule_params* p);
 /* which schedule a call with these parameters enqueues: 0 = the digit rounds (general pipeline),
- * 1 = small-eviction, 2 = bracket; 1 and 2 leave the `fallback` word behind */
+ * 1 = small-eviction, 2 = bracket; 1 and 2 leave the `fallback` word behind: 0 = the schedule
+ * finished exactly, bit 0 = it could not and the general pipeline behind it recomputed the result,
+ * bit 1 (sticky) = that recomputation gave up a wait after ten seconds -- a device fault -- and the
+ * outputs were overwritten with the schedule that evicts nothing; callers must treat bit 1 as an
+ * error (CompressionMetrics raises RuntimeError). */
 int32_t kvc_schedule_evictions_plan(const kvc_schedule_params* p);
+/* ... and why (ABI version 4): bits 0-7 = why the call does not take the small-eviction schedule,
+ * bits 8-15 = why it does not take the bracket schedule either (only meaningful when bits 0-7 are
+ * non-zero), bits 16-23 = KVC_WHY_COUPLED_BATCH when a taken schedule keeps the gated launch chain
+ * as its fallback instead of the single launch.  0 = the small-eviction schedule with the single
+ * launch behind it. */
+enum {
+  KVC_WHY_TAKEN = 0,
+  KVC_WHY_FORCED_PATH = 1,     /* schedule_path asks for another schedule */
+  KVC_WHY_BLOCK_SIZE = 2,      /* small-eviction: block_size not in {8, 16, 32} */
+  KVC_WHY_HINT_UNKNOWN = 3,    /* small-eviction: max_evicted_blocks_hint < 0 (counts passed as a device tensor) */
+  KVC_WHY_BULK = 4,            /* small-eviction: the hint says a step frees more than 1/8 of what the heads' records hold */
+  KVC_WHY_HEADS_PER_SEQ = 5,   /* num_layers * num_kv_heads > 1024 (per-head tables of one workgroup) */
+  KVC_WHY_THRESHOLDS_LDS = 6,  /* small-eviction: L*H*(256/bs) recorded thresholds per sequence > 16384 */
+  KVC_WHY_COUPLED_BATCH = 7,   /* mode 0 (the reference's batch > 1 rule) over more than 256 sequences */
+  KVC_WHY_INDEX_RANGE = 8,     /* > 65535 sequences, or >= 2^32 slots */
+  KVC_WHY_SMALL_BATCH = 9,     /* bracket: < 64 Ki slots per sequence or < 64 blocks per head (digit rounds are as fast) */
+  KVC_WHY_EMPTY = 10           /* nothing to schedule */
+};
+int32_t kvc_schedule_evictions_plan_reason(const kvc_schedule_params* p);
 /* 1 if a call with these parameters builds its keys through block_tables (see there) */
 int32_t kvc_schedule_evictions_uses_block_tables(const kvc_schedule_params* p);
 size_t kvc_schedule_evictions_fallback_offset(int64_t total_slots, int32_t total_heads,

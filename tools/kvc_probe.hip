@@ -74,3 +74,21 @@ extern "C" int kvc_probe_block_stream(void* k, void* v, const int32_t* runs, int
 #undef PROBE
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }
+
+// Test aid (tests/test_gpu_fallback_residency.py): hold compute units for a while -- `workgroups`
+// workgroups of 256 threads with `lds_bytes` of LDS each (<= 64 KiB) that spin until `usec`
+// microseconds of the 100 MHz wall clock have passed.  With 2 x 64 KiB per CU on every CU a kernel
+// launched next to it on another stream gets a fraction of the chip.  Asynchronous on `stream`.
+__global__ __launch_bounds__(256) void probe_occupy_kernel(unsigned long long ticks, uint32_t* sink) {
+  extern __shared__ uint32_t occ_s[];
+  occ_s[threadIdx.x] = threadIdx.x;
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+  if (sink != nullptr && occ_s[(threadIdx.x + 1) & 255] == 0xFFFFFFFFu) *sink = 1u;
+}
+extern "C" int kvc_probe_occupy(int32_t workgroups, int32_t lds_bytes, int64_t usec, void* stream) {
+  if (workgroups < 1 || lds_bytes < 1024 || lds_bytes > 65536 || usec < 0 || usec > 2000000) return 1;
+  hipLaunchKernelGGL(probe_occupy_kernel, dim3((unsigned)workgroups), dim3(256), (size_t)lds_bytes, (hipStream_t)stream,
+                     (unsigned long long)usec * 100ull, (uint32_t*)nullptr);
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}

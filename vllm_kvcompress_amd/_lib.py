@@ -16,6 +16,11 @@ LIB_PATH = os.environ.get("KVC_MI355X_LIB", os.path.join(_HERE, "libkvc_mi355x.s
 
 MAX_INT = 2147483000  # reference vllm/kvcompress/metrics.py:12
 
+# KVC_WHY_* of include/kvc_mi355x.h (kvc_schedule_evictions_plan_reason)
+WHY = {0: "taken", 1: "forced_path", 2: "block_size", 3: "hint_unknown", 4: "bulk_eviction",
+       5: "heads_per_seq", 6: "thresholds_lds", 7: "coupled_batch", 8: "index_range",
+       9: "small_batch", 10: "empty"}
+
 
 class KvcScheduleParams(ctypes.Structure):
     """mirror of ``kvc_schedule_params`` (include/kvc_mi355x.h)"""
@@ -37,7 +42,7 @@ class KvcScheduleParams(ctypes.Structure):
         ("max_evicted_blocks_hint", c_int32),
         ("block_tables", c_void_p), ("seq_index_of_slot", c_void_p),
         ("max_num_seqs", c_int32), ("block_tables_width", c_int32),
-        ("schedule_path", c_int32), ("sample_stride", c_int32),
+        ("schedule_path", c_int32), ("sample_stride", c_int32), ("fallback_grid", c_int32),
         ("evicted_logical_indices", c_void_p), ("evicted_kv_count", c_void_p),
         ("evicted_block_count", c_void_p),
     ]
@@ -88,6 +93,7 @@ SYMBOLS = {
                                          c_void_p]),
     "kvc_schedule_evictions_uses_small_eviction_schedule": (c_int32, [ctypes.POINTER(KvcScheduleParams)]),
     "kvc_schedule_evictions_plan": (c_int32, [ctypes.POINTER(KvcScheduleParams)]),
+    "kvc_schedule_evictions_plan_reason": (c_int32, [ctypes.POINTER(KvcScheduleParams)]),
     "kvc_schedule_evictions_uses_block_tables": (c_int32, [ctypes.POINTER(KvcScheduleParams)]),
     "kvc_schedule_evictions_fallback_offset": (c_size_t, [c_int64, c_int32, c_int32, c_int32]),
     "kvc_aggregate_decode": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,

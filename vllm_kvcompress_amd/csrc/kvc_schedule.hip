@@ -61,7 +61,7 @@ struct SchedWs {
   uint32_t* bthr;        // [N / bs] bracket schedule: per head (from its first chunk on) its listed thresholds, ascending
   uint32_t* blist;       // [N / 8 + 32 G]  bracket schedule: per head the keys inside the sequence's bracket (then sorted)
   uint32_t* fallback;    // [1]      != 0: the small-eviction schedule could not finish exactly
-  uint32_t* bar;         // [1]      arrivals at the grid barrier of the single-launch fallback
+  uint32_t* bar;         // [32+64]  single-launch fallback: phase stamps, then claim / done counters of its phases
   const uint32_t* gate;  // general-path kernels run only if gate == nullptr or *gate != 0
 };
 
@@ -1995,7 +1995,7 @@ __global__ __launch_bounds__(1024) void bracket_kernel(kvc_schedule_params p, Sc
   const uint32_t n = (uint32_t)(end - base);
   BR_STAMP(0);
   if (tid < 3) red_s[tid] = 0;
-  if (i == 0 && tid < 64) ws.fallback[tid] = 0u;     // the flag, the barrier's counter and stamps
+  if (i == 0 && tid < 128) ws.fallback[tid] = 0u;    // the flag, the stamps and the phase counters of the fallback
   __syncthreads();
   {
     uint32_t hs = 0, la = 0;                         // sum of hang, heads that hold anything
@@ -2490,83 +2490,160 @@ __global__ __launch_bounds__(1024) void bracket_select_kernel(kvc_schedule_param
 // HIP has no conditional enqueue: behind the small-eviction schedule the general pipeline used to
 // be 13 launches that read the flag and return, ~4.6 us each -- 60 us of a 150 us schedule at 16
 // resident sequences.  This kernel is the whole general pipeline (for sequences that do not couple:
-// mode 1 or a single one) on a persistent grid that is resident at once, its phases separated by a
-// software grid barrier; with the flag down it is one launch that returns.  The barrier is the
-// release / acquire recipe of cdna_hip_programming.md Guideline 16: every wave's stores are
-// complete at the workgroup barrier, lane 0 writes the XCD's L2 back (release, agent scope),
-// arrives on a monotonic counter, polls it with relaxed loads and a sleep, invalidates the CU's L1
-// (acquire), and the workgroup barrier hands that to the other waves.  A wait that does not end
-// (a grid that is not resident: must not happen, the host sizes it from the occupancy query less
-// one workgroup per CU) gives up after two seconds of the 100 MHz wall clock and raises bit 1 of
-// the flag word instead of hanging the GPU.
-__device__ void grid_barrier(uint32_t* counter, uint32_t target, uint32_t* flag) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(16);
-      if (wall_clock64() - t0 > 200000000ull) { atomicOr(flag, 2u); break; }
+// mode 1 or a single one; the batch > 1 rule up to FB_MAX_COUPLED sequences) in ONE launch; with
+// the flag down it is one launch that returns.
+//
+// Its phases depend on each other across workgroups, and nothing guarantees that a grid is resident
+// at once (another stream, another process or a CU mask may hold compute units whatever the
+// occupancy query says): a barrier that waits for every WORKGROUP to arrive can wait for one that
+// has not started.  So the phases do not wait for workgroups, they wait for WORK: a phase is cut
+// into V virtual workgroups (the bodies take their index and count as arguments), the real
+// workgroups claim them from a counter until none is left and then wait until V of them are done.
+// Whatever is resident does all of the work; a workgroup that starts late finds the counters of
+// the finished phases full and falls through them.  Every claimed piece is being executed by a
+// workgroup that runs, so every wait ends: correctness does not depend on co-residency, only speed
+// does (the host still sizes the grid to what the occupancy query says is resident at once).
+// Publishing a piece is the release / acquire recipe of cdna_hip_programming.md Guideline 16: every
+// wave's stores are complete at the workgroup barrier, lane 0 writes the XCD's L2 back (release,
+// agent scope) and adds to the phase's done counter; a waiter polls it with relaxed loads and a
+// sleep, invalidates the CU's L1 (acquire), and the workgroup barrier hands that to the other waves.
+// A wait that does not end within ten seconds of the 100 MHz wall clock (a device that lost a
+// workgroup: must not happen) raises bit 1 of the flag word, which is sticky: every workgroup that
+// sees it stops and overwrites the outputs with the schedule that evicts NOTHING (zero counts, a
+// null list) -- never a partial one -- and the host raises when it reads the bit (metrics.py).
+constexpr int FB_PHASES = 32;                        // claim / done counters (14 phases at most)
+constexpr uint32_t FB_TIMEOUT_BIT = 2u;
+struct FbSync {
+  uint32_t* claim;       // [FB_PHASES] virtual workgroups handed out
+  uint32_t* done;        // [FB_PHASES] ... finished
+  uint32_t* flag;        // the schedule's flag word (bit 1: a wait timed out, results void)
+};
+
+// runs body(v, V) for the virtual workgroups v this workgroup can claim, then waits for all V;
+// false = the wait was given up (or somebody else gave up): stop
+template <typename F>
+__device__ __forceinline__ bool fb_phase(const FbSync& fs, uint32_t phase, uint32_t V, uint32_t* word_s, F&& body) {
+  uint32_t* claim = fs.claim + phase;
+  uint32_t* done = fs.done + phase;
+  for (;;) {
+    __syncthreads();                                 // (word_s and the body's LDS are free again)
+    if (threadIdx.x == 0) *word_s = __hip_atomic_fetch_add(claim, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const uint32_t v = *word_s;
+    if (v >= V) break;
+    body(v, V);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t ok = 1u;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < V) {
+      __builtin_amdgcn_s_sleep(16);
+      if (__hip_atomic_load(fs.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & FB_TIMEOUT_BIT) { ok = 0u; break; }
+      if (wall_clock64() - t0 > 1000000000ull) { atomicOr(fs.flag, FB_TIMEOUT_BIT); ok = 0u; break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *word_s = ok;
+  }
+  __syncthreads();
+  return *word_s != 0u;
+}
+
+// the schedule that evicts nothing (what a call leaves behind when a wait was given up)
+__device__ __forceinline__ void fb_void_outputs(const kvc_schedule_params& p, unsigned bid, unsigned nb) {
+  const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
+  for (int64_t g = (int64_t)bid * 256 + threadIdx.x; g < G; g += (int64_t)nb * 256) {
+    p.evicted_kv_count[g] = 0;
+    p.evicted_block_count[g] = 0;
+  }
+  for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < p.total_slots; i += (int64_t)nb * 256)
+    p.evicted_logical_indices[i] = p.null_value;
 }
 
 constexpr int FB_MAX_COUPLED = 256;                  // sequences whose batch > 1 rule fits the static tables below
 // have_keys: the key pass ran already (the bracket schedule's) -- straight to the digit rounds
+// vgrid: virtual workgroups of the streaming phases (the grid the host would like to be resident)
 __global__ __launch_bounds__(256, 2) void fallback_general_kernel(kvc_schedule_params p, SchedWs ws, int sparse,
-                                                               uint4* zero16, int64_t zero_vecs, int have_keys) {
-  if (*ws.fallback == 0u) return;                    // flag down: this launch is all the fallback costs
+                                                               uint4* zero16, int64_t zero_vecs, int have_keys,
+                                                               unsigned vgrid) {
+  const uint32_t flag0 = __hip_atomic_load(ws.fallback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (flag0 == 0u) return;                           // flag down: this launch is all the fallback costs
   __shared__ __attribute__((aligned(16))) uint8_t prep_s[FB_MAX_COUPLED * 24];
+  __shared__ uint32_t word_s;
   const bool coupled = p.mode == 0 && p.num_seqs > 1;
   const unsigned bid = blockIdx.x, nb = gridDim.x;
+  if (flag0 & FB_TIMEOUT_BIT) { fb_void_outputs(p, bid, nb); return; }
+  FbSync fs;
+  fs.claim = ws.bar + 32;
+  fs.done = ws.bar + 32 + FB_PHASES;
+  fs.flag = ws.fallback;
   uint32_t phase = 0;
+  bool alive = true;
   // (workgroup 0 leaves the 100 MHz wall clock of every phase end behind the counter: tools/fallback_cost.py)
-  auto sync = [&]() {
+  auto run = [&](uint32_t V, auto&& body) {
+    if (!alive) return;
+    alive = fb_phase(fs, phase, V, &word_s, body);
     ++phase;
-    grid_barrier(ws.bar, phase * nb, ws.fallback);
     if (bid == 0 && threadIdx.x == 0 && phase < 15) ws.bar[1 + phase] = (uint32_t)wall_clock64();
   };
   if (bid == 0 && threadIdx.x == 0) ws.bar[1] = (uint32_t)wall_clock64();
   const int B = p.num_seqs, G = B * p.num_layers * p.num_kv_heads;
-  // every logical block of the batch has a physical block (the collecting pass counted them:
-  // the same for all workgroups) -> nothing to clear, nothing to fix: two phases less
-  zero_body(zero16, zero_vecs, bid, nb);
+  const uint32_t VS = (uint32_t)B < 4u * vgrid ? (uint32_t)B : 4u * vgrid;     // per-sequence phases
+  const uint32_t VH = (uint32_t)G < 8u * vgrid ? (uint32_t)G : 8u * vgrid;     // the per-head phase
   if (have_keys) {
-    sync();
+    run(vgrid, [&](unsigned v, unsigned V) { zero_body(zero16, zero_vecs, v, V); });
   } else {
+    // every logical block of the batch has a physical block (the collecting pass counted them:
+    // the same for all workgroups) -> nothing to clear, nothing to fix: two phases less
     uint32_t claimed = 0;
     for (int q = 0; q < CLAIM_SHARDS; ++q) claimed += ws.st_claimed[q * 32];
     const bool holes = (int64_t)claimed != p.total_slots / p.block_size && !(p.lean & 2);
-    if (holes) { clear_chunk_table_body(p, ws, bid, nb); sync(); }
-    if (sparse) build_keys_sparse_body(p, ws, bid, nb);
-    else build_keys_body<4>(p, ws, bid, nb);
-    sync();
-    if (holes) { fix_unclaimed_body(p, ws, bid, nb); sync(); }
+    auto keys = [&](unsigned v, unsigned V) {
+      if (sparse) build_keys_sparse_body(p, ws, v, V);
+      else build_keys_body<4>(p, ws, v, V);
+    };
+    if (holes) {
+      run(vgrid, [&](unsigned v, unsigned V) { zero_body(zero16, zero_vecs, v, V); clear_chunk_table_body(p, ws, v, V); });
+      run(vgrid, keys);
+      run(vgrid, [&](unsigned v, unsigned V) { fix_unclaimed_body(p, ws, v, V); });
+    } else {
+      run(vgrid, [&](unsigned v, unsigned V) { zero_body(zero16, zero_vecs, v, V); keys(v, V); });
+    }
   }
   for (int round = 0; round < 4; ++round) {
-    hist_round_body(p, ws, round, bid, nb);
-    sync();
+    run(vgrid, [&](unsigned v, unsigned V) { hist_round_body(p, ws, round, v, V); });
     if (round == 0 && coupled) {                       // the reference's batch > 1 rule: totals, k', then the pick
-      for (int i = (int)bid; i < B; i += (int)nb) { scan_pick_body<4, 4>(p, ws, 0, i, 1); __syncthreads(); }
-      sync();
-      if (bid == 0) seq_prepare_tables(p, ws, prep_s);
-      sync();
-      for (int i = (int)bid; i < B; i += (int)nb) { scan_pick_body<4, 4>(p, ws, 0, i, 2); __syncthreads(); }
+      run(VS, [&](unsigned v, unsigned V) {
+        for (int i = (int)v; i < B; i += (int)V) { scan_pick_body<4, 4>(p, ws, 0, i, 1); __syncthreads(); }
+      });
+      run(1u, [&](unsigned, unsigned) { seq_prepare_tables(p, ws, prep_s); });
+      run(VS, [&](unsigned v, unsigned V) {
+        for (int i = (int)v; i < B; i += (int)V) { scan_pick_body<4, 4>(p, ws, 0, i, 2); __syncthreads(); }
+      });
     } else {
-      for (int i = (int)bid; i < B; i += (int)nb) {
-        scan_pick_body<4, 4>(p, ws, round, i);
-        __syncthreads();
-      }
+      run(VS, [&](unsigned v, unsigned V) {
+        for (int i = (int)v; i < B; i += (int)V) { scan_pick_body<4, 4>(p, ws, round, i); __syncthreads(); }
+      });
     }
-    sync();
   }
-  for (int g = (int)bid; g < G; g += (int)nb) {
-    select_emit_head<256>(p, ws, 0, g, nullptr);
+  if (!alive) { fb_void_outputs(p, bid, nb); return; }
+  // the last phase: nobody waits for it (the kernel's end does)
+  for (;;) {
     __syncthreads();
+    if (threadIdx.x == 0) word_s = __hip_atomic_fetch_add(fs.claim + phase, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const uint32_t v = word_s;
+    if (v >= VH) break;
+    for (int g = (int)v; g < G; g += (int)VH) {
+      select_emit_head<256>(p, ws, 0, g, nullptr);
+      __syncthreads();
+    }
   }
   if (bid == 0 && threadIdx.x == 0) ws.bar[17] = (uint32_t)wall_clock64();     // (workgroup 0's own end)
 }
@@ -2644,7 +2721,7 @@ static WsLayout ws_layout(int64_t N, int32_t G, int32_t B, int32_t bs) {
   l.cum = o;         o = align_up(o + (size_t)4 * G * kvc::RADIX * 4, 256);
   l.seq_tmp = o;     o = align_up(o + (size_t)B * 12, 256);
   l.tz_begin = o;    // one memset at the head of the small-eviction schedule
-  l.fallback = o;    o = align_up(o + 16, 256);
+  l.fallback = o;    o = align_up(o + 512, 256);   // flag word | +128: stamps | +256: claim / done counters of the fallback's phases
   l.st_claimed = o;  o = align_up(o + (size_t)kvc::CLAIM_SHARDS * 128, 256);
   l.st_cnt = o;      o = align_up(o + (size_t)G * 4, 256);
   l.st_def = o;      o = align_up(o + (size_t)G * 4, 256);
@@ -2659,10 +2736,11 @@ static WsLayout ws_layout(int64_t N, int32_t G, int32_t B, int32_t bs) {
   return l;
 }
 
-// grid of the single-launch fallback (section 8): what is resident at once, less one workgroup per
-// CU (the occupancy query can be one too high where SGPRs decide, MI355X_MICROARCH.md), at most 3
-// (4 per CU measured slower: the barrier's cost grows with the number of arrivers)
-// per CU; asked once per device
+// grid of the single-launch fallback (section 8): what is resident at once on an idle device, less
+// one workgroup per CU (the occupancy query can be one too high where SGPRs decide,
+// MI355X_MICROARCH.md), at most 3 per CU (4 measured slower: the cost of a phase end grows with the
+// number of waiters); asked once per device.  Only speed depends on it: the kernel's phases wait for
+// work, not for workgroups (kvc_schedule_params.fallback_grid launches any other number: tests)
 static int fallback_grid() {
   static std::atomic<int> grid[64];
   int dev = 0;
@@ -2682,24 +2760,27 @@ static int fallback_grid() {
 // small-eviction schedule (section 7) or not: the host knows how many blocks a sequence frees at
 // most (the reference passes a Python list); eligible when that is on average <= 1/8 of what a
 // head's record covers and a sequence's thresholds fit one workgroup's LDS.
-// p2 = padded threshold count per sequence (0: not eligible), sshift = log2 of the sample stride.
-static void topk_plan(const kvc_schedule_params& p, int& p2_out, int& sshift) {
+// p2 = padded threshold count per sequence (0: not eligible), sshift = log2 of the sample stride;
+// returns why not (KVC_WHY_*, include/kvc_mi355x.h; KVC_WHY_TAKEN = eligible)
+static int topk_plan(const kvc_schedule_params& p, int& p2_out, int& sshift) {
   p2_out = 0; sshift = 0;
   const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
-  if (G < 1 || p.total_slots <= 0) return;
+  if (G < 1 || p.total_slots <= 0) return KVC_WHY_EMPTY;
   const int LH = p.num_layers * p.num_kv_heads;
   const int bsz = p.block_size;
-  if (!(bsz == 8 || bsz == 16 || bsz == 32) || p.schedule_path == 1 || p.schedule_path == 4) return;
+  if (p.schedule_path == 1 || p.schedule_path == 4) return KVC_WHY_FORCED_PATH;
+  if (!(bsz == 8 || bsz == 16 || bsz == 32)) return KVC_WHY_BLOCK_SIZE;
   // (per-head tables of the pivot kernel in LDS; a record entry packs the physical slot into 32 bits)
-  if (LH > kvc::PIV_MAXLH || p.num_seqs > 65535 ||
-      p.num_blocks * (int64_t)bsz >= (int64_t)1 << 32) return;
+  if (LH > kvc::PIV_MAXLH) return KVC_WHY_HEADS_PER_SEQ;
+  if (p.num_seqs > 65535 || p.num_blocks * (int64_t)bsz >= (int64_t)1 << 32) return KVC_WHY_INDEX_RANGE;
   const int mch = kvc::KREC / bsz;
   int p2 = 128;
   while (p2 < LH * mch && p2 <= 16384) p2 <<= 1;
-  if (p2 > 16384) return;
-  const bool hint_ok = p.schedule_path == 2 || p.schedule_path == 3 ||
-      (p.max_evicted_blocks_hint >= 0 && (int64_t)p.max_evicted_blocks_hint * 8 <= (int64_t)mch * LH);
-  if (!hint_ok) return;
+  if (p2 > 16384) return KVC_WHY_THRESHOLDS_LDS;
+  if (p.schedule_path != 2 && p.schedule_path != 3) {
+    if (p.max_evicted_blocks_hint < 0) return KVC_WHY_HINT_UNKNOWN;
+    if ((int64_t)p.max_evicted_blocks_hint * 8 > (int64_t)mch * LH) return KVC_WHY_BULK;
+  }
   p2_out = p2;
   // sample stride: about 16 Ki sampled keys per sequence (a sequence's pivot is a low quantile of
   // its sample, held in the registers of one workgroup; a sampled block costs ~9 random accesses,
@@ -2708,22 +2789,28 @@ static void topk_plan(const kvc_schedule_params& p, int& p2_out, int& sshift) {
   int64_t stride = p.total_slots / p.num_seqs / 16384;
   if (p.sample_stride > 0) stride = p.sample_stride;
   while (sshift < 8 && (2ll << sshift) <= stride) ++sshift;
+  return KVC_WHY_TAKEN;
 }
 
 // bracket schedule (section 9) or the digit rounds, for calls the small-eviction schedule does not
 // take: a head per thread of one workgroup, list indices in 32 bits.
 // Chosen by itself from 64 Ki slots per sequence and 64 blocks per head on: below that the digit
 // rounds are as fast, and a head's list (an eighth of its slots) gets too short for the bracket.
-static bool bracket_plan(const kvc_schedule_params& p) {
+// Returns why not (KVC_WHY_TAKEN = the bracket schedule).
+static int bracket_why(const kvc_schedule_params& p) {
   const int LH = p.num_layers * p.num_kv_heads;
   const int64_t G = (int64_t)p.num_seqs * LH;
-  if (G < 1 || p.total_slots <= 0 || p.block_size < 1) return false;
-  if (p.schedule_path != 0 && p.schedule_path != 4) return false;
+  if (G < 1 || p.total_slots <= 0 || p.block_size < 1) return KVC_WHY_EMPTY;
+  if (p.schedule_path != 0 && p.schedule_path != 4) return KVC_WHY_FORCED_PATH;
   // (the reference's batch > 1 rule: as many sequences as the single-launch fallback has tables for)
-  if ((p.mode == 0 && p.num_seqs > kvc::FB_MAX_COUPLED) || LH > kvc::PIV_MAXLH || p.total_slots >= (int64_t)1 << 32) return false;
-  if (p.schedule_path == 4) return true;
-  return p.total_slots / p.num_seqs >= 65536 && p.total_slots / G >= 64 * (int64_t)p.block_size;
+  if (p.mode == 0 && p.num_seqs > kvc::FB_MAX_COUPLED) return KVC_WHY_COUPLED_BATCH;
+  if (LH > kvc::PIV_MAXLH) return KVC_WHY_HEADS_PER_SEQ;
+  if (p.total_slots >= (int64_t)1 << 32) return KVC_WHY_INDEX_RANGE;
+  if (p.schedule_path == 4) return KVC_WHY_TAKEN;
+  if (!(p.total_slots / p.num_seqs >= 65536 && p.total_slots / G >= 64 * (int64_t)p.block_size)) return KVC_WHY_SMALL_BATCH;
+  return KVC_WHY_TAKEN;
 }
+static bool bracket_plan(const kvc_schedule_params& p) { return bracket_why(p) == KVC_WHY_TAKEN; }
 
 // introspection for tests and bench.py: which schedule a call with these parameters enqueues
 // (0 = the digit rounds, 1 = small-eviction, 2 = bracket)
@@ -2733,6 +2820,19 @@ extern "C" int32_t kvc_schedule_evictions_plan(const kvc_schedule_params* p) {
   topk_plan(*p, p2, sshift);
   if (p2 > 0) return 1;
   return bracket_plan(*p) ? 2 : 0;
+}
+
+// ... and why: bits 0-7 why not the small-eviction schedule, bits 8-15 why not the bracket schedule
+// (looked at only when the small-eviction one is not taken), bits 16-23 the form of the fallback
+// behind a taken schedule (0 = the single launch of section 8, KVC_WHY_COUPLED_BATCH = the gated
+// launch chain: the reference's batch > 1 rule over more sequences than its tables hold)
+extern "C" int32_t kvc_schedule_evictions_plan_reason(const kvc_schedule_params* p) {
+  if (p == nullptr) return KVC_WHY_EMPTY | (KVC_WHY_EMPTY << 8);
+  int p2 = 0, sshift = 0;
+  const int w1 = topk_plan(*p, p2, sshift);
+  if (w1 == KVC_WHY_TAKEN)
+    return (p->mode == 0 && p->num_seqs > kvc::FB_MAX_COUPLED) ? (KVC_WHY_COUPLED_BATCH << 16) : 0;
+  return w1 | (bracket_why(*p) << 8);
 }
 
 // the key pass through the caller's block tables (build_keys_tables_kernel) or from the per-block
@@ -2816,7 +2916,7 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   ws.st_claimed = reinterpret_cast<uint32_t*>(wb + l.st_claimed);
   ws.st_seqrec = reinterpret_cast<SeqRec*>(wb + l.st_seqrec);
   ws.fallback = reinterpret_cast<uint32_t*>(wb + l.fallback);
-  ws.bar = reinterpret_cast<uint32_t*>(wb + l.fallback + 128);     // (its own cache line, same zeroed region)
+  ws.bar = reinterpret_cast<uint32_t*>(wb + l.fallback + 128);     // (stamps; +128 / +256 the phase counters: same zeroed region)
   ws.head_fc = reinterpret_cast<uint32_t*>(wb + l.head_fc);
   ws.blist = reinterpret_cast<uint32_t*>(wb + l.blist);
   ws.bthr = reinterpret_cast<uint32_t*>(wb + l.bthr);
@@ -2909,7 +3009,9 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     uint4* z16 = reinterpret_cast<uint4*>(wb + l.zero_begin);
     const int64_t zv = (int64_t)((l.zero_end - l.zero_begin) / 16);
     const int sparse = p.total_slots < (int64_t)p.num_blocks * p.block_size / 2 ? 1 : 0;
-    hipLaunchKernelGGL(fallback_general_kernel, dim3((unsigned)fallback_grid()), dim3(256), 0, s, p, ws, sparse, z16, zv, 0);
+    const unsigned vgrid = (unsigned)fallback_grid();
+    hipLaunchKernelGGL(fallback_general_kernel, dim3(p.fallback_grid > 0 ? (unsigned)p.fallback_grid : vgrid), dim3(256), 0, s,
+                       p, ws, sparse, z16, zv, 0, vgrid);
     return check_launch("schedule_evictions");
   }
   // ---- general pipeline
@@ -3003,7 +3105,9 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     ws.gate = ws.fallback;
     uint4* z16 = reinterpret_cast<uint4*>(wb + l.zero_begin);
     const int64_t zv = (int64_t)((l.zero_end - l.zero_begin) / 16);
-    hipLaunchKernelGGL(fallback_general_kernel, dim3((unsigned)fallback_grid()), dim3(256), 0, s, p, ws, 0, z16, zv, 1);
+    const unsigned vgrid = (unsigned)fallback_grid();
+    hipLaunchKernelGGL(fallback_general_kernel, dim3(p.fallback_grid > 0 ? (unsigned)p.fallback_grid : vgrid), dim3(256), 0, s,
+                       p, ws, 0, z16, zv, 1, vgrid);
     return check_launch("schedule_evictions");
   }
   // per round: the histograms, then ONE launch for scan + pick (round 0: + the chunk totals and k',

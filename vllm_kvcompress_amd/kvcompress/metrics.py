@@ -133,7 +133,14 @@ class CompressionMetrics:
         # sample stride of the small-eviction schedule's pivots (0 = chosen from the batch size;
         # results do not depend on it, tests force every value)
         self.sample_stride = int(os.environ.get("KVC_SAMPLE_STRIDE", "0"))
+        # workgroups of the single launch that redoes a call whose flag was raised (0 = what is resident
+        # at once; results do not depend on it, tests launch grids that are not resident)
+        self.fallback_grid = int(os.environ.get("KVC_FALLBACK_GRID", "0"))
+        # KVC_STRICT_FALLBACK=1: read the flag word back after every small-eviction / bracket call
+        # (one synchronisation per call) instead of one call later
+        self.strict_fallback = os.environ.get("KVC_STRICT_FALLBACK", "0") not in ("", "0")
         self.last_schedule = None      # (workspace, fallback offset, plan: 0 general, 1 small-eviction, 2 bracket)
+        self.last_schedule_reason = ""  # why the last call took the schedule it took (kvc_schedule_evictions_plan_reason)
         self.last_used_block_tables = False   # the last call built its keys through block_tables= (sparse batch)
         # host policy around the small-eviction schedule: a call whose flag was raised costs the
         # streaming pass AND the general pipeline in its single-launch form (3 x the general
@@ -146,6 +153,7 @@ class CompressionMetrics:
         self._fb_event = None
         self._fb_penalty = 0          # general-schedule calls the last raised flag cost
         self._fb_backoff = 0          # of which still to go
+        self._fb_fault = False        # a fallback launch gave up a wait (device fault): digit rounds only from now on
         self._small_cache = {}
 
     # temp_metrics is handed to the attention kernels, which write into it; reading the
@@ -317,8 +325,14 @@ class CompressionMetrics:
 
         ``block_tables`` (optional, not in the reference signature): ``BlockState.block_tables``
         ``[L, max_num_seqs, H, M]`` (rows indexed by sequence index).  The fork's scheduler has it
-        next to the ``context_lens`` it already passes; with it the small-eviction schedule skips
-        its chunk-table pass (kvc_schedule_params.block_tables).  Results are identical."""
+        next to the ``context_lens`` it already passes.  The digit-round and bracket schedules build
+        their keys in logical order through it when the batch takes less than half of the cache (an
+        engine-sized cache): three scattered accesses per block of the batch instead of a sweep over
+        every block's metadata; the small-eviction schedule streams the store in physical order and
+        ignores it (kvc_schedule_params.block_tables, ABI version 3).  Contract: the tables must be
+        the ones the per-block metadata (seq / layer / head / logical block number) was written
+        from -- only the owning sequence of a listed block is checked, so stale tables give
+        different evictions without an error.  With consistent state the results are identical."""
         assert len(seq_indices) > 0
         assert list(sorted(seq_indices)) == list(seq_indices), (
             "schedule_evictions input not ordered by ascending index")
@@ -391,12 +405,18 @@ class CompressionMetrics:
         p.schedule_path = int(self.schedule_path)
         p.sample_stride = int(self.sample_stride)
         capturing = torch.cuda.is_current_stream_capturing()
+        p.fallback_grid = int(self.fallback_grid)
         if self._fb_event is not None and not capturing and self._fb_event.query():
-            raised = int(self._fb_pin[0]) != 0
+            word = int(self._fb_pin[0])
             self._fb_event = None
-            self._fb_penalty = min(max(2 * self._fb_penalty, 1), 64) if raised else 0
-            self._fb_backoff = self._fb_penalty
-        if p.schedule_path == 0 and self._fb_backoff > 0 and not capturing:
+            if word & 2:
+                self._raise_fallback_fault("an earlier")
+            if int(self.schedule_path) == 0:
+                self._fb_penalty = min(max(2 * self._fb_penalty, 1), 64) if word else 0
+                self._fb_backoff = self._fb_penalty
+        if self._fb_fault:
+            p.schedule_path = 1        # the launch chain of the digit rounds has no device-side waits
+        elif p.schedule_path == 0 and self._fb_backoff > 0 and not capturing:
             self._fb_backoff -= 1
             p.schedule_path = 1
         if block_tables is not None:
@@ -424,7 +444,18 @@ class CompressionMetrics:
         self.last_used_block_tables = bool(lib.kvc_schedule_evictions_uses_block_tables(ctypes.byref(p)))
         self.last_schedule = (ws, int(lib.kvc_schedule_evictions_fallback_offset(N, B * L * H, B, bs)),
                               int(lib.kvc_schedule_evictions_plan(ctypes.byref(p))))
-        if self.last_schedule[2] and not capturing and int(self.schedule_path) == 0:
+        self.last_schedule_reason = self._describe_plan(
+            self.last_schedule[2], int(lib.kvc_schedule_evictions_plan_reason(ctypes.byref(p))),
+            backoff=int(p.schedule_path) == 1 and int(self.schedule_path) != 1)
+        if self.last_schedule[2] and self.strict_fallback and not capturing:
+            off = self.last_schedule[1]
+            word = int(ws[off:off + 4].view(torch.int32).item())
+            if word & 2:
+                self._raise_fallback_fault("this")
+            if int(self.schedule_path) == 0:
+                self._fb_penalty = min(max(2 * self._fb_penalty, 1), 64) if word else 0
+                self._fb_backoff = self._fb_penalty
+        elif self.last_schedule[2] and not capturing:
             off = self.last_schedule[1]
             if self._fb_pin is None:
                 self._fb_pin = torch.zeros(1, dtype=torch.int32).pin_memory()
@@ -435,6 +466,33 @@ class CompressionMetrics:
                     self._fb_event.record()
         return out_idx, out_kv, out_blk
 
+    def _raise_fallback_fault(self, which: str) -> None:
+        """Bit 1 of the flag word: the single launch that redoes a call on the general pipeline gave
+        up a wait (ten seconds without progress: a device fault, not contention -- its phases wait
+        for work, not for co-residency) and overwrote that call's outputs with the schedule that
+        evicts nothing.  The reference always returns a valid schedule (metrics.py:441-847); the
+        closest a faulting device allows is to say so, and to keep to the launch chain afterwards."""
+        self._fb_fault = True
+        self._fb_backoff = self._fb_penalty = 0
+        raise RuntimeError(
+            f"schedule_evictions: the on-device fallback of {which} call gave up a wait (device fault); "
+            "that call's outputs were replaced by an empty schedule (nothing evicted). Further calls "
+            "use the digit-round launch chain only.")
+
+    @staticmethod
+    def _describe_plan(plan: int, reason: int, backoff: bool) -> str:
+        """Human-readable form of kvc_schedule_evictions_plan_reason (include/kvc_mi355x.h)."""
+        why = _lib.WHY
+        if plan == 1:
+            tail = " (fallback: gated launch chain, coupled_batch)" if (reason >> 16) & 0xFF else ""
+            return "small_eviction" + tail
+        small = why.get(reason & 0xFF, "?")
+        if backoff and small == "forced_path":
+            small = "backoff_after_fallback"
+        if plan == 2:
+            return f"bracket (small_eviction: {small})"
+        return f"general (small_eviction: {small}; bracket: {why.get((reason >> 8) & 0xFF, '?')})"
+
     def last_schedule_path(self) -> str:
         """Which schedule produced the last ``schedule_evictions`` result (synchronises; tests and
         bench.py): "general", "small_eviction" or "bracket" -- the latter two with "+fallback" when
@@ -444,8 +502,8 @@ class CompressionMetrics:
             return "general"
         name = {1: "small_eviction", 2: "bracket"}[plan]
         flag = int(ws[off:off + 4].view(torch.int32).item())
-        if flag & 2:        # the single-launch fallback gave up waiting at its grid barrier: results are void
-            return name + "+fallback+barrier_timeout"
+        if flag & 2:        # the single-launch fallback gave up a wait (device fault): the outputs evict nothing
+            return name + "+fallback+wait_timeout"
         return name if flag == 0 else name + "+fallback"
 
     def profile_schedule_evictions(self):
