@@ -144,3 +144,47 @@ def test_schedule_plan_is_a_host_decision():
     assert plan(B=300, mode=1, slots_per_head=4096, L=4) == 2     # sequences that do not couple: any number
     assert plan(L=160, H=8, slots_per_head=2048) == 0             # 1280 heads per sequence
     assert plan(L=160, H=8, slots_per_head=2048, path=4) == 0
+
+
+def test_schedule_plan_says_why():
+    """kvc_schedule_evictions_plan_reason: one case per KVC_WHY_* code (include/kvc_mi355x.h) -- which
+    static limit sent a call to which schedule, and the form of the fallback behind a taken one"""
+    import ctypes
+    from vllm_kvcompress_amd.kvcompress.metrics import CompressionMetrics
+    lib = kvc.load()
+    header = open(os.path.join(REPO, "include", "kvc_mi355x.h")).read()
+    codes = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"KVC_WHY_([A-Z_]+) = (\d+)", header)}
+    assert set(codes.values()) == set(_lib.WHY), "the Python names must cover the header's codes"
+
+    def why(B=1, L=32, H=8, bs=16, slots_per_head=32768, mode=0, hint=-1, path=0, total=None, num_blocks=None):
+        p = _lib.KvcScheduleParams()
+        p.num_seqs, p.num_layers, p.num_kv_heads, p.block_size = B, L, H, bs
+        p.total_slots = B * L * H * slots_per_head if total is None else total
+        p.num_blocks = p.total_slots // max(bs, 1) if num_blocks is None else num_blocks
+        p.mode, p.max_evicted_blocks_hint, p.schedule_path = mode, hint, path
+        plan = int(lib.kvc_schedule_evictions_plan(ctypes.byref(p)))
+        r = int(lib.kvc_schedule_evictions_plan_reason(ctypes.byref(p)))
+        return plan, _lib.WHY[r & 0xFF], _lib.WHY[(r >> 8) & 0xFF], _lib.WHY[(r >> 16) & 0xFF]
+
+    assert why(hint=200) == (1, "taken", "taken", "taken")
+    assert why(hint=8, B=300, L=4, slots_per_head=4096) == (1, "taken", "taken", "coupled_batch")
+    assert why(hint=8, B=300, L=4, slots_per_head=4096, mode=1) == (1, "taken", "taken", "taken")
+    assert why() == (2, "hint_unknown", "taken", "taken")                       # a device tensor of counts: bracket
+    assert why(hint=100000) == (2, "bulk_eviction", "taken", "taken")          # compress_once
+    assert why(hint=200, path=1) == (0, "forced_path", "forced_path", "taken")
+    assert why(hint=200, path=4) == (2, "forced_path", "taken", "taken")
+    assert why(hint=1, bs=4, slots_per_head=64) == (0, "block_size", "small_batch", "taken")
+    assert why(hint=1, L=160, slots_per_head=2048) == (0, "heads_per_seq", "heads_per_seq", "taken")
+    assert why(hint=1, L=128, H=8, bs=8, slots_per_head=256) == (0, "thresholds_lds", "small_batch", "taken")
+    assert why(hint=1, B=70000, L=1, H=1, slots_per_head=16, mode=1)[1] == "index_range"
+    assert why(hint=1, num_blocks=1 << 29, slots_per_head=64) == (0, "index_range", "small_batch", "taken")
+    assert why(hint=100000, B=300, L=4, slots_per_head=4096) == (0, "bulk_eviction", "coupled_batch", "taken")
+    assert why(slots_per_head=128) == (0, "hint_unknown", "small_batch", "taken")
+    assert why(total=0)[1:3] == ("empty", "empty")
+    # ... and the sentence CompressionMetrics.last_schedule_reason makes of it
+    d = CompressionMetrics._describe_plan
+    assert d(1, 0, False) == "small_eviction"
+    assert d(1, 7 << 16, False) == "small_eviction (fallback: gated launch chain, coupled_batch)"
+    assert d(2, 3, False) == "bracket (small_eviction: hint_unknown)"
+    assert d(0, 3 | (9 << 8), False) == "general (small_eviction: hint_unknown; bracket: small_batch)"
+    assert d(0, 1 | (1 << 8), True) == "general (small_eviction: backoff_after_fallback; bracket: forced_path)"
