@@ -87,6 +87,9 @@ def parse_args(argv=None):
                     help="hand BlockState.block_tables to schedule_evictions (optional argument: bulk evictions of a batch "
                          "that is sparse in its cache build their keys through it; the streaming schedule ignores it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-gate", action="store_true",
+                    help="skip the oracle comparison of the timed workload's results (profiling passes that "
+                         "bench.py starts for its own counters use this; a reported line never does)")
     ap.add_argument("--no-adjacent", action="store_true",
                     help="skip the decode-attention (F3) side measurement")
     ap.add_argument("--no-s0", action="store_true", help="skip the S0 (metric aggregation) stage timings")
@@ -181,6 +184,126 @@ def build_workload_that_fits(args, seed, device, batch):
             batch //= 2
 
 
+# --------------------------------------------------------------------------- parity gate
+PARITY_ORACLE_MAX_SLOTS = 1 << 25       # the oracle's schedule takes seconds up to here (C2: 8.4 M, C5: 16.8 M)
+PARITY_HOST_KV_MAX_BYTES = 9 << 30      # K/V that may be copied to the host for the oracle's compaction
+
+
+def parity_snapshot(k_cache, v_cache, device_check_rows=None):
+    """The cache as it is BEFORE the first step, for the gate below: a host copy when it is small
+    enough for the oracle's compaction to run on it, otherwise nothing (the gate then checks the
+    compaction on the device: every moved slot equals its source, read before the step)."""
+    nbytes = 2 * k_cache.numel() * k_cache.element_size()
+    if nbytes > PARITY_HOST_KV_MAX_BYTES:
+        return None
+    import torch
+    it = torch.uint8 if k_cache.element_size() == 1 else torch.int16
+    return k_cache.view(it).cpu().numpy(), v_cache.view(it).cpu().numpy()
+
+
+def parity_gate(args, st, ds, evicted, mode, gpu, snap, k_cache, v_cache, wm, wp, lean=False):
+    """no number is reported for results that differ from the reference's.
+    The oracle (oracle/: NumPy restatement of schedule_evictions pinned to reference-generated
+    vectors, C restatement of the serial move / compaction kernels) runs on the SAME seeded state
+    the timed steps ran on; evicted indices, counts, the move list and -- when the cache fits on the
+    host -- the compacted K / V / metrics / positions must be bit-identical
+    (the reference's twin-equality pattern, tests/kernels/test_kvcompress_eviction.py:900-901, 967,
+    1007-1008).  The checker is never inside the timed region.  Returns the `parity_checked` object;
+    `bit_exact` False makes bench.py exit non-zero without printing a line."""
+    import hashlib
+    import torch
+    from oracle import kvc_oracle as orc
+    from oracle import kvc_oracle_c as orc_c
+    N = st.total_slots
+    if N > PARITY_ORACLE_MAX_SLOTS:
+        return {"bit_exact": None, "skipped": f"{N} candidate slots: the oracle's sorts take minutes at this size "
+                                              "(this shape is parity-tested at oracle sizes in tests/)"}
+    t0 = time.perf_counter()
+    bs = st.block_size
+    eli, ekc, ebc = orc.schedule_evictions(
+        metrics=st.metrics, token_positions=st.token_positions, seq_index_by_block=st.seq_index_by_block,
+        layer_index_by_block=st.layer_index_by_block, head_index_by_block=st.head_index_by_block,
+        logical_block_num_by_block=st.logical_block_num_by_block, block_size=bs, num_layers=st.num_layers,
+        num_kv_heads=st.num_kv_heads, seq_indices=st.seq_indices, seq_positions=st.seq_positions,
+        evicted_blocks_per_seq=evicted, context_lens=st.context_lens,
+        hanging_token_count=st.hanging_token_count, evicted_kv_offsets=st.evicted_kv_offsets,
+        num_protected=st.protected, mode=mode)
+    cmi = np.zeros((N, 2), np.int32)
+    cmc = np.zeros(ekc.shape, np.int32)
+    orc_c.set_threads(min(os.cpu_count() or 1, orc_c.max_threads()))
+    orc_c.schedule_cache_moves(cmi, cmc, eli, ekc, st.evicted_kv_offsets, np.ascontiguousarray(st.block_tables),
+                               np.ascontiguousarray(st.context_lens), bs)
+    offs = st.evicted_kv_offsets.reshape(-1).astype(np.int64)
+
+    def defined(counts):        # rows a consumer reads: [off_g, off_g + count_g) of every head
+        c = counts.reshape(-1).astype(np.int64)
+        return np.repeat(offs - (np.cumsum(c) - c), c) + np.arange(int(c.sum()))
+
+    compared, bad = [], []
+
+    def cmp(name, got, want, rows=None):
+        got = got.cpu().numpy() if hasattr(got, "cpu") else got
+        if rows is not None:
+            got, want = got[rows], want[rows]
+        compared.append(name)
+        if got.shape != want.shape or not np.array_equal(got, want):
+            bad.append(name)
+
+    cmp("evicted_kv_count", gpu["ekc"], ekc)
+    cmp("evicted_block_count", gpu["ebc"], ebc)
+    cmp("evicted_logical_indices", gpu["eli"], eli, defined(ekc) if lean else None)
+    cmp("cache_moves_count", gpu["cmc"], cmc)
+    cmp("cache_moves_idx", gpu["cmi"], cmi, defined(cmc) if lean else None)
+    out = {"workload": "the timed workload itself (same seeded state, same eviction counts)",
+           "oracle": "oracle/kvc_oracle.py schedule_evictions + oracle/kvc_oracle.c schedule_t1_cache_moves / "
+                     "execute_cache_moves", "mode": mode}
+    m, p = st.metrics.copy(), st.token_positions.copy()
+    if snap is not None:
+        k, v = snap
+        orc_c.execute_cache_moves(k, v, m, p, cmi, cmc, st.evicted_kv_offsets)
+        it = torch.uint8 if k_cache.element_size() == 1 else torch.int16
+        gk, gv = k_cache.view(it).cpu().numpy(), v_cache.view(it).cpu().numpy()
+        cmp("k_cache", gk, k)
+        cmp("v_cache", gv, v)
+        h = hashlib.sha256()
+        h.update(gk.data)
+        h.update(gv.data)
+        out["kv_sha256"] = h.hexdigest()
+        h = hashlib.sha256()
+        h.update(k.data)
+        h.update(v.data)
+        out["kv_sha256_oracle"] = h.hexdigest()
+        if out["kv_sha256"] != out["kv_sha256_oracle"] and "k_cache" not in bad and "v_cache" not in bad:
+            bad.append("kv_sha256")
+        out["kv_bytes"] = int(gk.nbytes + gv.nbytes)
+        del gk, gv
+    else:
+        # a cache that fills the HBM: the compaction is checked where it ran -- metrics / positions (which
+        # travel with every slot) against the oracle's, K / V rows of every moved slot against their
+        # sources (sources are never written: reading them after the steps is reading them before)
+        rows = torch.from_numpy(defined(cmc)).to(gpu["cmi"].device)
+        mv = gpu["cmi"][rows].long()
+        m2, p2 = torch.from_numpy(st.metrics).to(mv.device), torch.from_numpy(st.token_positions).to(mv.device)
+        m2.view(-1)[mv[:, 0]] = m2.view(-1)[mv[:, 1]]
+        p2.view(-1)[mv[:, 0]] = p2.view(-1)[mv[:, 1]]
+        m, p = m2.cpu().numpy(), p2.cpu().numpy()
+        ok_kv = True
+        it = torch.uint8 if k_cache.element_size() == 1 else torch.int16      # (bits, not floats: random bits hold NaNs)
+        kb, vb = k_cache.view(it), v_cache.view(it)
+        for lo in range(0, mv.shape[0], 1 << 20):
+            d, s_ = mv[lo:lo + (1 << 20), 0], mv[lo:lo + (1 << 20), 1]
+            ok_kv &= bool(torch.equal(kb[d // bs, :, d % bs, :], kb[s_ // bs, :, s_ % bs, :]))
+            ok_kv &= bool(torch.equal(vb[d // bs, :, d % bs], vb[s_ // bs, :, s_ % bs]))
+        compared.append("k_cache/v_cache rows of every moved slot == their sources (on the device)")
+        if not ok_kv:
+            bad.append("k_cache/v_cache moved rows")
+    cmp("kv_metrics", wm, m)
+    cmp("kv_position", wp, p)
+    out.update({"bit_exact": not bad, "compared": compared, "mismatched": bad,
+                "seconds": time.perf_counter() - t0})
+    return out
+
+
 # --------------------------------------------------------------------------- roofline helpers
 def traffic_floor(cmi, cmc, offs, bs, block_bytes):
     """HBM bytes the cache LAYOUT forces for this move list: a destination block is
@@ -204,6 +327,28 @@ def traffic_floor(cmi, cmc, offs, bs, block_bytes):
     img = 2 * block_bytes + 8 * bs                       # K + V images + metric / position rows
     return {"bytes": (d - full) * img + d * img + s * img + total * 8,
             "dst_blocks": d, "dst_blocks_fully_overwritten": full, "src_blocks": s}
+
+
+PATTERN_CEILING_TYPICAL_GBPS = 5100.0     # random 4 KiB images inside one 64 GiB region (6100 across regions)
+
+
+def frac_ceiling(alg_bytes, floor, ceiling, frac):
+    """What `frac` (algorithmic bytes / time / 8 TB/s) CAN reach for this move list in the reference's
+    cache layout: the layout forces `traffic_floor_bytes` through HBM for `algorithmic_bytes` of
+    payload (one V element per 32 B sector, one K piece per 16 B: a block that receives one slot is
+    read and rewritten whole), and randomly placed block images stream at the pattern ceiling, not
+    at the 8 TB/s of a linear stream.  alg_frac_ceiling = alg / floor x pattern ceiling / peak."""
+    if not floor or not floor.get("bytes"):
+        return {"alg_frac_ceiling": None, "frac_of_ceiling": None}
+    rmw = floor["dst_blocks_fully_overwritten"] * 2 < floor["dst_blocks"]
+    if ceiling:
+        pc, src = ceiling["rmw_2R1W" if rmw else "copy_1R1W"], "measured on this run's cache (pattern_ceiling_GBps)"
+    else:
+        pc, src = PATTERN_CEILING_TYPICAL_GBPS, "typical figure (no probe in this run)"
+    c = alg_bytes / floor["bytes"] * pc / HBM_PEAK_GBPS
+    return {"alg_frac_ceiling": c, "frac_of_ceiling": frac / c if c > 0 else None,
+            "layout_amplification": floor["bytes"] / alg_bytes if alg_bytes else None,
+            "alg_frac_ceiling_pattern_GBps": pc, "alg_frac_ceiling_source": src}
 
 
 def pattern_ceiling(k_cache, v_cache, block_bytes, iters=6):
@@ -340,7 +485,7 @@ def live_pmc_traffic(extra_flags, timeout=240):
         return None
     cmd = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
            "--no-adjacent", "--no-s0", "--no-probe", "--no-engine-cache", "--no-other-configs",
-           "--no-live-traffic"] + list(extra_flags)
+           "--no-live-traffic", "--no-parity-gate"] + list(extra_flags)
     env = dict(os.environ, TMPDIR="/tmp")
     vals = {}
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
@@ -383,6 +528,7 @@ def measure_workload(a2, seed, device, steps, warmup, probe):
     cmi = torch.empty((N, 2), dtype=torch.int32, device=device)
     cmc = torch.empty((st.num_seqs, st.num_layers, st.num_kv_heads), dtype=torch.int32, device=device)
     seq_idx, prot = list(st.seq_indices), list(st.protected)
+    snap = parity_snapshot(k_cache, v_cache) if N <= PARITY_ORACLE_MAX_SLOTS else None
     ev = lambda: torch.cuda.Event(enable_timing=True)
     marks = [[ev() for _ in range(5)] for _ in range(steps)]
     out = {}
@@ -398,8 +544,13 @@ def measure_workload(a2, seed, device, steps, warmup, probe):
         if rec: marks[i][3].record()
         ops._execute_cache_moves(k_cache, v_cache, wm, wp, cmi, cmc, ds.evicted_kv_offsets, "apply")
         if rec: marks[i][4].record()
-        out["ekc"] = ekc
+        out["ekc"], out["ebc"], out["eli"] = ekc, ebc, eli
     torch.cuda.synchronize()
+    parity = parity_gate(a2, st, ds, evicted, a2.mode, dict(eli=out["eli"], ekc=out["ekc"], ebc=out["ebc"], cmi=cmi, cmc=cmc),
+                         snap, k_cache, v_cache, wm, wp, lean=bool(a2.lean))
+    del snap
+    if parity["bit_exact"] is False:
+        raise SystemExit(f"bench.py: PARITY GATE FAILED ({a2.config}): {json.dumps(parity)}")
     ms = lambda a, b: sum(m[a].elapsed_time(m[b]) for m in marks) / steps
     kernel_ms, step_ms = ms(3, 4), ms(0, 4)
     moved, evs = int(cmc.sum().item()), int(out["ekc"].sum().item())
@@ -421,7 +572,9 @@ def measure_workload(a2, seed, device, steps, warmup, probe):
                      "frac_of_floor": floor["bytes"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "pattern_ceiling_GBps": pattern_ceiling(k_cache, v_cache, block_bytes) if probe else None},
         "timing": f"{steps} steps after {warmup} warm-up steps, HIP events on the launch stream",
+        "parity_checked": parity,
     }
+    res["roofline"].update(frac_ceiling(alg, floor, res["roofline"]["pattern_ceiling_GBps"], res["roofline"]["frac"]))
     if st.total_slots < st.num_blocks * bs // 2 and not ds.cm.last_schedule_path().startswith("small_eviction"):
         # the batch is sparse in its cache: the same steps once more with BlockState.block_tables handed
         # to schedule_evictions (optional argument: the key pass then goes through the tables instead
@@ -711,6 +864,8 @@ def main():
     cmc = torch.empty((st.num_seqs, st.num_layers, st.num_kv_heads), dtype=torch.int32, device=device)
     seq_idx = list(st.seq_indices)
     prot = list(st.protected)
+    # the cache as it is before the first step, for the parity gate behind the timed region
+    snap = parity_snapshot(k_cache, v_cache) if (rank == 0 and N <= PARITY_ORACLE_MAX_SLOTS and not args.no_parity_gate) else None
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     # marks: S1 start, S2 start, S3 start (plan half), data kernel start, end.  All events are
@@ -740,7 +895,7 @@ def main():
         ops._execute_cache_moves(k_cache, v_cache, work_metrics, work_pos, cmi, cmc,
                                  ds.evicted_kv_offsets, "apply")
         if i is not None: marks[i][4].record()
-        out["ekc"], out["ebc"] = ekc, ebc
+        out["ekc"], out["ebc"], out["eli"] = ekc, ebc, eli
 
     for _ in range(args.warmup):
         step()
@@ -776,6 +931,17 @@ def main():
         per_rank = [{"units": u, "seconds": sec} for u, sec in
                     zip(red["per_rank_units"], red["per_rank_seconds"])]
 
+    parity = None
+    if rank == 0 and not args.no_parity_gate:
+        # parity gates before any number is reported
+        parity = parity_gate(args, st, ds, evicted, args.mode, dict(eli=out["eli"], ekc=out["ekc"], ebc=out["ebc"], cmi=cmi, cmc=cmc),
+                             snap, k_cache, v_cache, work_metrics, work_pos, lean=bool(args.lean))
+        del snap
+        if parity["bit_exact"] is False:
+            print(f"bench.py: PARITY GATE FAILED, no number reported: {json.dumps(parity)}", file=sys.stderr, flush=True)
+            if world > 1:
+                dist.destroy_process_group()
+            sys.exit(3)
     if rank == 0:
         e = 1 if args.kv_dtype == "fp8" else 2
         block_bytes = args.head_size * bs * e
@@ -838,8 +1004,10 @@ def main():
                 "candidate_slots": N, "evicted_slots": evicted_slots, "moved_slots": moved_slots,
                 "freed_blocks": freed_blocks,
             },
+            "parity_checked": parity,
             "stages_ms": {"S1_schedule_evictions": s1, "S2_schedule_moves": s2, "S3_execute_moves": s3},
             "S1_schedule": ds.cm.last_schedule_path(),
+            "S1_schedule_reason": ds.cm.last_schedule_reason,
             "stage_rates": {
                 "S1_candidate_slots_per_s": N / (s1 * 1e-3),
                 "S2_moves_per_s": moved_slots / (s2 * 1e-3),
@@ -861,6 +1029,7 @@ def main():
                 "floor_frac_of_pattern_ceiling": (
                     floor_gbps / (ceiling["rmw_2R1W"] if floor["dst_blocks_fully_overwritten"] * 2 < floor["dst_blocks"]
                                   else ceiling["copy_1R1W"]) if ceiling else None),
+                **frac_ceiling(alg_bytes, floor, ceiling, achieved / HBM_PEAK_GBPS),
             },
         }
         if per_rank:

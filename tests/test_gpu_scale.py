@@ -3,7 +3,8 @@
 * C1 (Llama-3-8B shape, 4k cache, 1 M slots): complete oracle comparison (NumPy schedule +
   C move/compaction restatement), bit-exact.
 * C2 (fp16, bs16, 32k cache, 8.4 M slots, 4 GiB of K/V) and C5 (fp8, bs32, 64k cache,
-  16.8 M slots, 4 GiB): size-independent properties, after the
+  16.8 M slots, 4 GiB): complete oracle comparison at their own size as well (a few seconds of
+  oracle each), and size-independent properties, after the
   reference's own test (tests/kernels/test_kvcompress_eviction.py:906-924, 1107-1218,
   1224-1226): freed blocks == requested; per-head evicted indices ascending + padded; no
   evicted KV is a move source; EVERY surviving KV is bit-equal at its final slot (K/V are
@@ -66,6 +67,68 @@ def test_c1_full_oracle_parity():
                             ("cmi", g_cmi, cmi), ("cmc", g_cmc, cmc), ("k", k, wk), ("v", v, wv),
                             ("metrics", ds.cm.metrics, wm), ("positions", ds.cm.token_positions, wp)):
         assert np.array_equal(got.cpu().numpy(), want), name
+
+
+FULL_ORACLE_CASES = [
+    # BASELINE configs[1] (the headline: fp16, bs 16, 32k, 8.4 M slots) and configs[4] (fp8, bs 32, 64k,
+    # 16.8 M slots) at their own size; the reference's 1 / 8 keep ratio of the headline as well
+    ("c2_keep_half", 32768, 16, np.uint16, 0.5, "reference"),
+    ("c2_keep_eighth", 32768, 16, np.uint16, 0.125, "per_sequence"),
+    ("c5_fp8_bs32", 65536, 32, np.uint8, 0.5, "reference"),
+]
+
+
+@pytest.mark.parametrize("name,T,bs,cdtype,keep,mode", FULL_ORACLE_CASES, ids=[c[0] for c in FULL_ORACLE_CASES])
+def test_full_size_oracle_parity(name, T, bs, cdtype, keep, mode):
+    """the headline configuration and the fp8 one, compared with the oracle AT THEIR OWN SIZE, every
+    output bit for bit: evicted indices, counts, the move list, 4 GiB of compacted K / V, metrics
+    and positions (the reference's twin-equality pattern, tests/kernels/
+    test_kvcompress_eviction.py:900-901, 967, 1007-1008; the oracle needs ~4 s for the schedule and
+    ~1 s for the moves and the compaction on the host's cores)"""
+    st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs, seq_lens=[T + 1], seed=2,
+                          protected=32, spare_block_frac=0.02)
+    evicted = [synth.evict_block_count(context_lens_lh=st.context_lens[:, 0, :], seq_len=T + 1, block_size=bs,
+                                       protected_window_size=32, max_cache_tokens=int(T * keep))]
+    e = np.dtype(cdtype).itemsize
+    x = 16 // e
+    rng = np.random.default_rng(7)
+    k_np = rng.integers(0, 1 << (8 * e), size=(st.num_blocks, HD // x, bs, x), dtype=cdtype)
+    v_np = rng.integers(0, 1 << (8 * e), size=(st.num_blocks, HD, bs), dtype=cdtype)
+    tdt = torch.uint8 if e == 1 else torch.int16
+    k = torch.from_numpy(k_np.view(np.uint8 if e == 1 else np.int16)).to(DEV)
+    v = torch.from_numpy(v_np.view(np.uint8 if e == 1 else np.int16)).to(DEV)
+    if e == 2:
+        k, v = k.view(torch.float16), v.view(torch.float16)
+    ds = hdev.upload(st, DEV, mode=mode)
+    g_eli, g_ekc, g_ebc, g_cmi, g_cmc = hdev.schedule(ds, st, evicted)
+    how = ds.cm.last_schedule_path()
+    ops.execute_cache_moves(k, v, ds.cm.metrics, ds.cm.token_positions, g_cmi, g_cmc, ds.evicted_kv_offsets, 1, 16)
+    torch.cuda.synchronize()
+    assert how.startswith("bracket"), how   # the schedule the bench line is measured on
+
+    eli, ekc, ebc = orc.schedule_evictions(
+        metrics=st.metrics, token_positions=st.token_positions,
+        seq_index_by_block=st.seq_index_by_block, layer_index_by_block=st.layer_index_by_block,
+        head_index_by_block=st.head_index_by_block,
+        logical_block_num_by_block=st.logical_block_num_by_block, block_size=bs, num_layers=L,
+        num_kv_heads=H, seq_indices=st.seq_indices, seq_positions=st.seq_positions,
+        evicted_blocks_per_seq=evicted, context_lens=st.context_lens,
+        hanging_token_count=st.hanging_token_count, evicted_kv_offsets=st.evicted_kv_offsets,
+        num_protected=st.protected, mode=mode)
+    cmi = np.zeros((st.total_slots, 2), np.int32)
+    cmc = np.zeros(ekc.shape, np.int32)
+    orc_c.set_threads(orc_c.max_threads())
+    orc_c.schedule_cache_moves(cmi, cmc, eli, ekc, st.evicted_kv_offsets, np.ascontiguousarray(st.block_tables),
+                               np.ascontiguousarray(st.context_lens), bs)
+    wm, wp = st.metrics.copy(), st.token_positions.copy()
+    orc_c.execute_cache_moves(k_np, v_np, wm, wp, cmi, cmc, st.evicted_kv_offsets)      # (in place: k_np / v_np are the expectation now)
+    orc_c.set_threads(1)
+    assert int(ebc.sum()) == evicted[0] and int(cmc.sum()) > 100000
+    for nm, got, want in (("eli", g_eli, eli), ("ekc", g_ekc, ekc), ("ebc", g_ebc, ebc), ("cmi", g_cmi, cmi),
+                          ("cmc", g_cmc, cmc), ("metrics", ds.cm.metrics, wm), ("positions", ds.cm.token_positions, wp)):
+        assert np.array_equal(got.cpu().numpy(), want), nm
+    assert np.array_equal(k.view(tdt).cpu().numpy().view(cdtype), k_np), "k_cache"
+    assert np.array_equal(v.view(tdt).cpu().numpy().view(cdtype), v_np), "v_cache"
 
 
 def _hash16(ids, salt):
