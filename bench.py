@@ -525,7 +525,9 @@ def measure_workload(a2, seed, device, steps, warmup, probe):
         return None
     N = st.total_slots
     wm, wp = ds.cm.metrics.clone(), ds.cm.token_positions.clone()
-    cmi = torch.empty((N, 2), dtype=torch.int32, device=device)
+    # the move workspace, held the way CompressionScheduler holds its own (reference scheduler.py:74-86: one
+    # persistent table; registered, so that the wrapper's per-call fill_(0) clears only what the previous call wrote)
+    cmi = ops.track_move_table(torch.empty((N, 2), dtype=torch.int32, device=device))
     cmc = torch.empty((st.num_seqs, st.num_layers, st.num_kv_heads), dtype=torch.int32, device=device)
     seq_idx, prot = list(st.seq_indices), list(st.protected)
     snap = parity_snapshot(k_cache, v_cache) if N <= PARITY_ORACLE_MAX_SLOTS else None
@@ -860,7 +862,9 @@ def main():
     N = st.total_slots
     work_metrics = ds.cm.metrics.clone()
     work_pos = ds.cm.token_positions.clone()
-    cmi = torch.empty((N, 2), dtype=torch.int32, device=device)
+    # the move workspace, held the way CompressionScheduler holds its own (reference scheduler.py:74-86: one
+    # persistent table; registered, so that the wrapper's per-call fill_(0) clears only what the previous call wrote)
+    cmi = ops.track_move_table(torch.empty((N, 2), dtype=torch.int32, device=device))
     cmc = torch.empty((st.num_seqs, st.num_layers, st.num_kv_heads), dtype=torch.int32, device=device)
     seq_idx = list(st.seq_indices)
     prot = list(st.protected)

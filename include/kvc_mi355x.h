@@ -75,6 +75,35 @@ int kvc_schedule_t1_cache_moves(int32_t* cache_moves_idx,            /* [rows,2]
                                 int32_t num_seqs, int32_t num_layers, int32_t num_kv_heads,
                                 int32_t max_num_blocks_per_seq, int32_t block_size,
                                 int32_t zero_fill, kvc_stream_t stream);
+/* ABI version 4: the same op with two optional by-products.
+ *
+ * zero_fill = 2 + dirty_map: the wrapper's fill_(0) without writing the zeros again.  The reference clears
+ *   the WHOLE table in front of every call (8 B per candidate slot -- 2.2 GB per decode step at 256
+ *   resident sequences) although the table it clears is its own persistent workspace
+ *   (vllm/kvcompress/scheduler.py:74-86), zero everywhere except where the previous call wrote moves.
+ *   dirty_map (kvc_cache_moves_dirty_map_bytes(rows, block_size) bytes, owned by whoever owns the table)
+ *   holds one bit per chunk of block_size rows that may be non-zero.  With zero_fill = 2 only marked
+ *   chunks are cleared and the map is rewritten for the moves of this call: the table ends up exactly
+ *   as after fill_(0) + the bare op.  With zero_fill = 1 and a map that the caller has cleared, every
+ *   row without a move is written 0 and the map is set up (first use of a table, or after anybody
+ *   else wrote to it).  dirty_map may be NULL with zero_fill 0 / 1.
+ *
+ * plan_out (kvc_cache_moves_plan_bytes() bytes, 16-byte aligned, or NULL): how the moves spread over
+ *   the heads, in the form kvc_execute_cache_moves_planned takes: execute_cache_moves of exactly this
+ *   move list is then ONE launch (no planning pass over the list, no per-block claim table: a list
+ *   made here writes every destination block from one run of consecutive moves). */
+size_t kvc_cache_moves_dirty_map_bytes(int64_t cache_moves_rows, int32_t block_size);
+size_t kvc_cache_moves_plan_bytes(void);
+int kvc_schedule_t1_cache_moves_ex(int32_t* cache_moves_idx, int64_t cache_moves_rows,
+                                   int32_t* cache_moves_count,
+                                   const int32_t* evicted_logical_indices,
+                                   const int32_t* evicted_kv_count,
+                                   const int32_t* evicted_kv_offsets,
+                                   const int32_t* block_tables, const int32_t* context_lens,
+                                   int32_t num_seqs, int32_t num_layers, int32_t num_kv_heads,
+                                   int32_t max_num_blocks_per_seq, int32_t block_size,
+                                   int32_t zero_fill, uint32_t* dirty_map, size_t dirty_map_bytes,
+                                   int32_t* plan_out, kvc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * A6  execute_cache_moves  (the K/V gather/scatter compaction)
@@ -93,12 +122,17 @@ int kvc_schedule_t1_cache_moves(int32_t* cache_moves_idx,            /* [rows,2]
  * blocks_per_head / threads_per_head of the reference signature are launch hints of the
  * CUDA kernel and have no meaning here (the Python wrapper accepts and ignores them).
  * workspace: kvc_execute_cache_moves_workspace_bytes(total_heads, num_blocks) bytes of
- * device memory, 16-byte aligned (tile prefix sums + one claim byte per physical block);
+ * device memory, 16-byte aligned (the list's plan + one claim byte per physical block);
  * no need to clear it, the planning kernel does.
  * The op is two halves that may also be called separately on the same stream with the same
  * move list and workspace (what bench.py does to time the data kernel alone with events on
  * the caller's stream): _plan = the two small planning launches (reads only the move list),
  * _apply = the compaction kernel.  kvc_execute_cache_moves == _plan followed by _apply.
+ * _planned (ABI version 4) = the compaction kernel alone over the plan that
+ * kvc_schedule_t1_cache_moves_ex left behind for exactly this (cache_moves_idx, cache_moves_count,
+ * evicted_kv_offsets), none of them modified since -- the caller vouches for that (the Python
+ * and C++ bindings check tensor identity and version counters and take the self-contained op
+ * otherwise).
  * --------------------------------------------------------------------------------- */
 size_t kvc_execute_cache_moves_workspace_bytes(int32_t total_heads, int64_t num_blocks);
 int kvc_execute_cache_moves(void* k_cache, void* v_cache, float* kv_metrics,
@@ -121,6 +155,13 @@ int kvc_execute_cache_moves_apply(void* k_cache, void* v_cache, float* kv_metric
                                   int64_t num_blocks, int32_t block_size, int32_t head_size,
                                   int32_t elem_bytes, int32_t vec_size, void* workspace,
                                   size_t workspace_bytes, kvc_stream_t stream);
+int kvc_execute_cache_moves_planned(void* k_cache, void* v_cache, float* kv_metrics,
+                                    int32_t* kv_position, const int32_t* cache_moves_idx,
+                                    const int32_t* cache_moves_count,
+                                    const int32_t* evicted_kv_offsets, int32_t total_heads,
+                                    int64_t num_blocks, int32_t block_size, int32_t head_size,
+                                    int32_t elem_bytes, int32_t vec_size, const int32_t* plan,
+                                    kvc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * A3  CompressionMetrics.schedule_evictions  (mask -> select -> count -> emit)

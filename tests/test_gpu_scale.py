@@ -229,9 +229,15 @@ def test_full_size_properties(T, BS, cdtype, keep):
     moved_dst[dst] = True
     assert bool((ds.cm.token_positions.reshape(-1)[~moved_dst] == pos0.reshape(-1)[~moved_dst]).all())
 
-    # the block (fast) path was taken for every destination block
-    ws = ops.workspace(torch.device(dev), 0, "execute_cache_moves")   # the buffer the op just used
-    coff = ((G + 2) * 4 + 15) // 16 * 16          # [tile prefix, padded to 16 B][claim bytes]
+    # The op ran on the plan schedule_cache_moves left behind: one launch, every run taken as the only
+    # writer of its destination block.  That this holds for the list is checked with the planning
+    # pass a list of unknown origin gets (a copy of the same list): it counts the runs per block.
+    from vllm_kvcompress_amd import _lib
+    assert ops._plan_of(k, cmi, cmc, ds.evicted_kv_offsets, G, BS) is not None
+    ops._execute_cache_moves(k, v, ds.cm.metrics, ds.cm.token_positions, cmi[:], cmc[:],
+                             ds.evicted_kv_offsets[:], "plan")
+    ws = ops.workspace(torch.device(dev), 0, "execute_cache_moves")   # the buffer the planning pass just filled
+    coff = int(_lib.load().kvc_cache_moves_plan_bytes())              # [plan][claim bytes]
     claims = ws[coff:coff + NB]
     assert int(claims.max()) == 1
     assert int((claims == 1).sum()) == (dst // BS).unique().numel()
@@ -326,8 +332,13 @@ def _multi_sequence_full_size(Lc, Hc, T, Bc, keep):
     final_ids = ids1[live_slot]
     assert final_ids.numel() == int(ds.context_lens.long().sum() - cnt.sum())
     assert final_ids.unique().numel() == final_ids.numel()
+    # one run per destination block: counted by the planning pass a list of unknown origin gets (views of
+    # the same list: other tensor objects, so the plan schedule_cache_moves left behind does not vouch for them)
+    from vllm_kvcompress_amd import _lib
+    assert ops._plan_of(k, cmi, cmc, ds.evicted_kv_offsets, G, BS) is not None
+    ops._execute_cache_moves(k, v, ds.cm.metrics, ds.cm.token_positions, cmi[:], cmc[:], ds.evicted_kv_offsets[:], "plan")
     ws = ops.workspace(dev, 0, "execute_cache_moves")
-    coff = ((G + 2) * 4 + 15) // 16 * 16
+    coff = int(_lib.load().kvc_cache_moves_plan_bytes())              # [plan][claim bytes]
     claims = ws[coff:coff + NB]
     assert int(claims.max()) == 1 and int((claims == 1).sum()) == (dst // BS).unique().numel()
 

@@ -10,6 +10,7 @@ raises instead of silently reading garbage.
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional
 
 import torch
@@ -110,6 +111,46 @@ def count_block_evictions(
             _stream(eli)))
 
 
+# ---- move tables whose contents the package knows -------------------------------------------
+# The reference clears the whole [max_kv_per_compression, 2] table in front of every
+# schedule_t1_cache_moves (vllm/_custom_ops.py:1168) although that table is the scheduler's own
+# persistent workspace (vllm/kvcompress/scheduler.py:74-86): all zeros except the rows the previous
+# call wrote.  A table registered here carries a device-side dirty map (one bit per block_size rows);
+# schedule_cache_moves then clears only the marked rows -- the table ends up exactly as after the
+# reference's fill_(0) + op.  Anything else that writes to the tensor through torch bumps its
+# version counter, which sends the next call back to the full fill.
+class _TrackedTable:
+    __slots__ = ("ref", "ptr", "dirty_map", "block_size", "version")
+
+    def __init__(self, t):
+        self.ref, self.ptr = weakref.ref(t), t.data_ptr()
+        self.dirty_map, self.block_size, self.version = None, 0, -1
+
+
+_TRACKED_TABLES = {}
+_LAST_PLAN = {}      # (device index, stream) -> provenance of the plan the last schedule_cache_moves left there
+
+
+def track_move_table(table: torch.Tensor) -> torch.Tensor:
+    """Declare ``table`` ([rows, 2] int32, contiguous) a persistent move workspace that only
+    ``schedule_cache_moves`` writes to -- what ``CompressionScheduler.cache_move_indices`` is
+    (reference scheduler.py:74-86).  Returns the tensor itself."""
+    _require(table, "table", torch.int32)
+    if table.dim() != 2 or table.shape[1] != 2 or not table.is_contiguous():
+        raise RuntimeError("track_move_table: expected a contiguous [rows, 2] int32 tensor")
+    for key in [k for k, r in _TRACKED_TABLES.items() if r.ref() is None]:
+        del _TRACKED_TABLES[key]
+    _TRACKED_TABLES[id(table)] = _TrackedTable(table)
+    return table
+
+
+def _tracked(table: torch.Tensor):
+    rec = _TRACKED_TABLES.get(id(table))
+    if rec is None or rec.ref() is not table or rec.ptr != table.data_ptr():
+        return None
+    return rec
+
+
 def schedule_cache_moves(
     out_cache_moves_indices: torch.Tensor,
     out_cache_moves_count: torch.Tensor,
@@ -140,15 +181,53 @@ def _schedule_t1_cache_moves(cache_moves_idx, cache_moves_count, evicted_logical
         raise RuntimeError("schedule_cache_moves: output tensors must be contiguous")
     num_seqs, num_layers, num_kv_heads = evicted_kv_count.shape
     keep = []
-    with torch.cuda.device(cache_moves_idx.device):
-        _lib.check(lib.kvc_schedule_t1_cache_moves(
-            cache_moves_idx.data_ptr(), cache_moves_idx.shape[0], cache_moves_count.data_ptr(),
+    dev = cache_moves_idx.device
+    rows, bs = cache_moves_idx.shape[0], int(block_size)
+    mode, dmap, dmap_bytes = (1 if zero_fill else 0), None, 0
+    rec = _tracked(cache_moves_idx) if zero_fill else None
+    if rec is not None and bs >= 1:
+        dmap_bytes = int(lib.kvc_cache_moves_dirty_map_bytes(rows, bs))
+        known = (rec.dirty_map is not None and rec.block_size == bs and rec.dirty_map.numel() >= dmap_bytes
+                 and rec.version == cache_moves_idx._version)
+        if known:
+            mode = 2                      # zero everywhere but where the map says: clear just that
+        else:                             # first use, or somebody else wrote to the table: the full fill
+            if rec.dirty_map is None or rec.dirty_map.numel() < dmap_bytes:
+                rec.dirty_map = torch.zeros(dmap_bytes, dtype=torch.uint8, device=dev)
+            else:
+                rec.dirty_map.zero_()
+            rec.block_size = bs
+        dmap = rec.dirty_map
+    plan = workspace(dev, int(lib.kvc_cache_moves_plan_bytes()), "cache_moves_plan")
+    with torch.cuda.device(dev):
+        _lib.check(lib.kvc_schedule_t1_cache_moves_ex(
+            cache_moves_idx.data_ptr(), rows, cache_moves_count.data_ptr(),
             _contig(evicted_logical_indices, keep).data_ptr(),
             _contig(evicted_kv_count, keep).data_ptr(),
             _contig(evicted_kv_offsets, keep).data_ptr(),
             _contig(block_tables, keep).data_ptr(), _contig(context_lens, keep).data_ptr(),
-            num_seqs, num_layers, num_kv_heads, block_tables.shape[3], int(block_size),
-            1 if zero_fill else 0, _stream(cache_moves_idx)))
+            num_seqs, num_layers, num_kv_heads, block_tables.shape[3], bs,
+            mode, _ptr(dmap), dmap_bytes, plan.data_ptr(), _stream(cache_moves_idx)))
+    if rec is not None:
+        rec.version = cache_moves_idx._version
+    # the plan belongs to exactly these three tensors as they are now (execute_cache_moves checks)
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    _LAST_PLAN[(index, _stream(cache_moves_idx))] = (
+        plan, tuple((weakref.ref(t), t._version) for t in (cache_moves_idx, cache_moves_count, evicted_kv_offsets)),
+        num_seqs * num_layers * num_kv_heads, bs)
+
+
+def _plan_of(k_cache, cmi, cmc, offs, total_heads, block_size):
+    """the plan schedule_cache_moves left behind for exactly (cmi, cmc, offs) on this stream, or None"""
+    dev = k_cache.device
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    rec = _LAST_PLAN.get((index, _stream(k_cache)))
+    if rec is None or rec[2] != total_heads or rec[3] != block_size:
+        return None
+    for (ref, version), t in zip(rec[1], (cmi, cmc, offs)):
+        if ref() is not t or t._version != version:
+            return None
+    return rec[0]
 
 
 def execute_cache_moves(
@@ -195,6 +274,17 @@ def _execute_cache_moves(k_cache, v_cache, kv_metrics, kv_position, cache_moves_
     cmc = cache_moves_count.contiguous()
     offs = evicted_kv_offsets.contiguous()
     total_heads = cmc.numel()
+    # a list that schedule_cache_moves made on this stream and nobody touched since brings its plan
+    # along: ONE launch (no planning pass, no claim table); any other list plans for itself
+    plan = _plan_of(k_cache, cache_moves_indices, cache_moves_count, evicted_kv_offsets, total_heads, block_size)
+    if plan is not None:
+        if half != "plan":
+            with torch.cuda.device(k_cache.device):
+                _lib.check(lib.kvc_execute_cache_moves_planned(
+                    k_cache.data_ptr(), v_cache.data_ptr(), kv_metrics.data_ptr(), kv_position.data_ptr(),
+                    cmi.data_ptr(), cmc.data_ptr(), offs.data_ptr(), total_heads, num_blocks, block_size,
+                    head_size, k_cache.element_size(), vec, plan.data_ptr(), _stream(k_cache)))
+        return
     ws_bytes = lib.kvc_execute_cache_moves_workspace_bytes(total_heads, num_blocks)
     ws = workspace(k_cache.device, ws_bytes, "execute_cache_moves")
     shape = (total_heads, num_blocks, block_size, head_size, k_cache.element_size(), vec,

@@ -77,6 +77,15 @@ SYMBOLS = {
     "kvc_schedule_t1_cache_moves": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_void_p, c_void_p, c_int32, c_int32,
                                               c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "kvc_cache_moves_dirty_map_bytes": (c_size_t, [c_int64, c_int32]),
+    "kvc_cache_moves_plan_bytes": (c_size_t, []),
+    "kvc_schedule_t1_cache_moves_ex": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                                 c_void_p, c_void_p, c_void_p, c_int32, c_int32,
+                                                 c_int32, c_int32, c_int32, c_int32, c_void_p, c_size_t,
+                                                 c_void_p, c_void_p]),
+    "kvc_execute_cache_moves_planned": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                  c_void_p, c_void_p, c_int32, c_int64, c_int32,
+                                                  c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "kvc_execute_cache_moves_workspace_bytes": (c_size_t, [c_int32, c_int64]),
     "kvc_execute_cache_moves": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32,

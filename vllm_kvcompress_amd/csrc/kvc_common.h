@@ -74,4 +74,23 @@ __device__ __forceinline__ int upper_bound_minus1(const int32_t* __restrict__ a,
   return lo;
 }
 
+// order LDS traffic between the lanes of one wave (no other wave shares the buffer)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// A move list's PLAN: how many move tiles the heads of every workgroup of schedule_t1_cache_moves
+// hold -- all execute_cache_moves needs to spread the tiles over its waves (a wave finds its first
+// tile with three wave-wide scans: the workgroups' sums, one workgroup's heads, done).  At most
+// MOVES_PLAN_WGS workgroups; two tile sizes side by side (the compaction's block path takes
+// 64 - bs moves per tile, its byte-wise path 32) because the move scheduler does not know the cache's shape.
+constexpr int MOVES_PLAN_WGS = 4096;
+inline __host__ __device__ void moves_plan_shape(int total_heads, int& nwg, int& heads_per_wg) {
+  heads_per_wg = (total_heads + MOVES_PLAN_WGS - 1) / MOVES_PLAN_WGS;
+  if (heads_per_wg < 1) heads_per_wg = 1;
+  nwg = (total_heads + heads_per_wg - 1) / heads_per_wg;
+}
+
 }  // namespace kvc

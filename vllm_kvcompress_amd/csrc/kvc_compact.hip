@@ -51,84 +51,98 @@ constexpr int KVC_TM_GENERIC = 32;    // moves per tile of the generic (byte-wis
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------- planning
-// workgroup 0: exclusive scan of ceil(count/tm) -> prefix[0..G]; every other workgroup
-// zeroes a slice of the claim table (one launch instead of a memset + two kernels)
-__global__ __launch_bounds__(1024) void compact_plan_kernel(int32_t* __restrict__ prefix,
-                                                            const int32_t* __restrict__ count, int G,
-                                                            int tm, u32x4* __restrict__ claims16,
-                                                            int64_t claim_vecs) {
-  if (blockIdx.x > 0) {
+// A move list's plan (kvc_common.h: moves_plan_shape) = the number of move tiles held by the heads
+// of each of <= MOVES_PLAN_WGS groups of consecutive heads.  schedule_t1_cache_moves leaves it behind
+// for its own lists; for any other list this kernel makes it: a thread per group, the other
+// workgroups zero a slice of the claim table (one launch instead of a memset + two kernels).
+__global__ __launch_bounds__(256) void compact_plan_kernel(int32_t* __restrict__ wg_tiles,
+                                                           const int32_t* __restrict__ count, int G,
+                                                           int tm, int nwg, int heads_per_wg, int plan_blocks,
+                                                           u32x4* __restrict__ claims16, int64_t claim_vecs) {
+  if ((int)blockIdx.x >= plan_blocks) {
     const u32x4 z = {0u, 0u, 0u, 0u};
-    for (int64_t i = (int64_t)(blockIdx.x - 1) * 1024 + threadIdx.x; i < claim_vecs;
-         i += (int64_t)(gridDim.x - 1) * 1024)
+    for (int64_t i = (int64_t)(blockIdx.x - plan_blocks) * 256 + threadIdx.x; i < claim_vecs;
+         i += (int64_t)(gridDim.x - plan_blocks) * 256)
       claims16[i] = z;
     return;
   }
-  // chunks of 8192 heads staged in LDS: coalesced loads (8 in flight per thread), every thread
-  // scans 8 consecutive entries, one workgroup scan per chunk, coalesced stores (a loop of
-  // 1024-wide scans took 92 us for the 65 536 heads of 256 resident sequences)
-  constexpr int PER = 8, CH = PER * 1024;
-  __shared__ uint32_t vals[CH + CH / 32];             // one pad word per 32: conflict-free 8-strides
-  __shared__ uint32_t wave_tot[16];
-  __shared__ uint32_t carry_s;
-  const int tid = threadIdx.x, lane = lane_id(), w = tid / WAVE;
-  auto at = [](int i) { return i + (i >> 5); };
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < G; base += CH) {
-    uint32_t v[PER];
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int idx = base + j * 1024 + tid;
-      v[j] = idx < G ? (uint32_t)((count[idx] + tm - 1) / tm) : 0u;
+  // a wave per group when the groups are wide (coalesced reads of `count`), else a thread per group
+  if (heads_per_wg >= 16) {
+    const int lane = lane_id();
+    for (int wg = blockIdx.x * 4 + threadIdx.x / WAVE; wg < nwg; wg += plan_blocks * 4) {
+      const int gb = wg * heads_per_wg, ge = min(G, gb + heads_per_wg);
+      uint32_t t = 0;
+      for (int g = gb + lane; g < ge; g += WAVE) t += (uint32_t)((count[g] + tm - 1) / tm);
+      t = wave_reduce_sum(t);
+      if (lane == 0) wg_tiles[wg] = (int32_t)t;
     }
-#pragma unroll
-    for (int j = 0; j < PER; ++j) vals[at(j * 1024 + tid)] = v[j];
-    __syncthreads();
-    uint32_t local = 0;
-#pragma unroll
-    for (int q = 0; q < PER; ++q) local += vals[at(tid * PER + q)];
-    const uint32_t inc = wave_inclusive_scan(local);
-    if (lane == 63) wave_tot[w] = inc;
-    __syncthreads();
-    uint32_t run = carry_s + inc - local;
-    for (int k = 0; k < w; ++k) run += wave_tot[k];
-#pragma unroll
-    for (int q = 0; q < PER; ++q) {                   // exclusive prefixes, in place
-      const uint32_t x = vals[at(tid * PER + q)];
-      vals[at(tid * PER + q)] = run;
-      run += x;
+  } else {
+    for (int wg = blockIdx.x * 256 + threadIdx.x; wg < nwg; wg += plan_blocks * 256) {
+      const int gb = wg * heads_per_wg, ge = min(G, gb + heads_per_wg);
+      int t = 0;
+      for (int g = gb; g < ge; ++g) t += (count[g] + tm - 1) / tm;
+      wg_tiles[wg] = t;
     }
-    __syncthreads();
-    if (tid == 1023) carry_s = run;                   // total so far
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int idx = base + j * 1024 + tid;
-      if (idx < G) prefix[idx] = (int32_t)vals[at(j * 1024 + tid)];
-    }
-    __syncthreads();
   }
-  if (tid == 0) prefix[G] = (int32_t)carry_s;
 }
 
-// one wave per tile: every run start claims its destination block
+// The tiles [t_begin, t_end) of wave `wid` of `nw`, the head g that holds tile t_begin and the
+// index g_first of that head's first tile -- found by the wave's 64 lanes with three scans (the
+// groups' sums, 64 at a time per lane; the groups of the lane that holds t_begin; the heads of the
+// group) instead of a binary search over a prefix array somebody had to scan first.
+// false: no tiles for this wave.
+__device__ __forceinline__ bool locate_tiles(const int32_t* __restrict__ wg_tiles, int nwg, int heads_per_wg,
+                                             const int32_t* __restrict__ count, int G, int tm, int wid, int nw,
+                                             int lane, int& t_begin, int& t_end, int& g_out, int& g_first_out) {
+  const int per = (nwg + WAVE - 1) / WAVE;
+  const int e0 = lane * per, e1 = min(nwg, e0 + per);
+  uint32_t s1 = 0;
+  for (int e = e0; e < e1; ++e) s1 += (uint32_t)wg_tiles[e];
+  const uint32_t inc1 = wave_inclusive_scan(s1);
+  const int total = (int)__shfl((int)inc1, 63, 64);
+  t_begin = (int)((int64_t)total * wid / nw);
+  t_end = (int)((int64_t)total * (wid + 1) / nw);
+  if (t_begin >= t_end) return false;
+  const int l1 = __ffsll((long long)__ballot((int)inc1 > t_begin)) - 1;
+  int base = __shfl((int)(inc1 - s1), l1, 64);
+  const int eb = l1 * per;
+  const uint32_t s2 = (lane < per && eb + lane < nwg) ? (uint32_t)wg_tiles[eb + lane] : 0u;
+  const uint32_t inc2 = wave_inclusive_scan(s2);
+  const unsigned long long m2 = __ballot(base + (int)inc2 > t_begin);
+  if (!m2) return false;                             // (a plan that does not belong to these counts)
+  const int l2 = __ffsll((long long)m2) - 1;
+  base += __shfl((int)(inc2 - s2), l2, 64);
+  const int gb0 = (eb + l2) * heads_per_wg, ge = min(G, gb0 + heads_per_wg);
+  for (int gb = gb0; gb < ge; gb += WAVE) {
+    const uint32_t s3 = gb + lane < ge ? (uint32_t)((count[gb + lane] + tm - 1) / tm) : 0u;
+    const uint32_t inc3 = wave_inclusive_scan(s3);
+    const unsigned long long m3 = __ballot(base + (int)inc3 > t_begin);
+    if (m3) {
+      const int l3 = __ffsll((long long)m3) - 1;
+      g_out = gb + l3;
+      g_first_out = base + __shfl((int)(inc3 - s3), l3, 64);
+      return true;
+    }
+    base += __shfl((int)inc3, 63, 64);
+  }
+  return false;
+}
+
+// one wave per contiguous range of tiles: every run start claims its destination block
 // (claims: 4 one-byte counters per word; a block has at most bs <= 255 claimants)
 __global__ __launch_bounds__(256) void compact_plan_claims_kernel(
     uint32_t* __restrict__ claims, const int32_t* __restrict__ moves,
     const int32_t* __restrict__ count, const int32_t* __restrict__ offs,
-    const int32_t* __restrict__ tile_prefix, int G, int bs, int tm) {
-  const int total_tiles = tile_prefix[G];
+    const int32_t* __restrict__ wg_tiles, int nwg, int heads_per_wg, int G, int bs, int tm) {
   const int lane = lane_id();
   const int nw = gridDim.x * (blockDim.x / WAVE);
   const int wv = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
-  // contiguous tile range per wave: one binary search, then the head advances incrementally
-  const int tb = (int)((int64_t)total_tiles * wv / nw), te = (int)((int64_t)total_tiles * (wv + 1) / nw);
-  if (tb >= te) return;
-  int g = upper_bound_minus1(tile_prefix, G, tb);
-  int g_first = tile_prefix[g], g_next = tile_prefix[g + 1];
+  int tb, te, g, g_first;
+  if (!locate_tiles(wg_tiles, nwg, heads_per_wg, count, G, tm, wv, nw, lane, tb, te, g, g_first)) return;
+  int cnt = count[g];
+  int g_next = g_first + (cnt + tm - 1) / tm;
   for (int t = tb; t < te; ++t) {
-    while (t >= g_next) { ++g; g_first = g_next; g_next = tile_prefix[g + 1]; }
-    const int cnt = count[g];
+    while (t >= g_next && g + 1 < G) { ++g; g_first = g_next; cnt = count[g]; g_next = g_first + (cnt + tm - 1) / tm; }
     const int j = (t - g_first) * tm + lane;
     const int2* mv = reinterpret_cast<const int2*>(moves) + offs[g];
     const bool in = lane < tm && j < cnt;
@@ -219,8 +233,8 @@ __global__ __launch_bounds__(64 * WPB) void compact_runs_kernel(
     uint8_t* __restrict__ k_cache, uint8_t* __restrict__ v_cache, float* __restrict__ metrics,
     int32_t* __restrict__ positions, const int32_t* __restrict__ moves,
     const int32_t* __restrict__ count, const int32_t* __restrict__ offs,
-    const uint32_t* __restrict__ claims, const int32_t* __restrict__ tile_prefix, int G,
-    int tm) {
+    const uint32_t* __restrict__ claims, const int32_t* __restrict__ wg_tiles, int nwg, int heads_per_wg,
+    int G, int tm) {
   static_assert(BS <= 32 && (BS & (BS - 1)) == 0, "block size must be a power of two <= 32");
   constexpr int BLOCK_BYTES = HD * BS * E;
   constexpr int NPL = BLOCK_BYTES / 16 / 64;                 // 16 B pieces per lane
@@ -242,20 +256,18 @@ __global__ __launch_bounds__(64 * WPB) void compact_runs_kernel(
   const int kgrp16 = (lane & ~(BS - 1)) * 16;                // byte offset of this lane's K row group
   const int vrow = (lane / PR) * RB;                         // byte offset of this lane's V row
   const int vfirst = (lane & (PR - 1)) * EP;                 // first slot of this lane's V pieces
-  const int total_tiles = tile_prefix[G];
   const int nw = gridDim.x * WPB;
   const int wid = blockIdx.x * WPB + wib;
-  const int t_begin = (int)((int64_t)total_tiles * wid / nw);
-  const int t_end = (int)((int64_t)total_tiles * (wid + 1) / nw);
-  if (t_begin >= t_end) return;
+  int t_begin, t_end, g, g_first;
+  if (!locate_tiles(wg_tiles, nwg, heads_per_wg, count, G, tm, wid, nw, lane, t_begin, t_end, g, g_first)) return;
 
   // ---- tile fetch: incremental head walk + this lane's move (lane q <-> move jbase + q: one
   // look-behind, tm moves of the tile, BS-1 look-ahead)
-  int g = upper_bound_minus1(tile_prefix, G, t_begin);
-  int g_first = tile_prefix[g], g_next = tile_prefix[g + 1];
+  int g_cnt = count[g];
+  int g_next = g_first + (g_cnt + tm - 1) / tm;
   auto fetch_moves = [&](int t, int& jbase_o, int& j1_o, int& mvx_o, int& mvy_o) {
-    while (t >= g_next) { ++g; g_first = g_next; g_next = tile_prefix[g + 1]; }
-    const int cnt = count[g];
+    while (t >= g_next && g + 1 < G) { ++g; g_first = g_next; g_cnt = count[g]; g_next = g_first + (g_cnt + tm - 1) / tm; }
+    const int cnt = g_cnt;
     const int j0 = (t - g_first) * tm;
     const int2* __restrict__ mv = reinterpret_cast<const int2*>(moves) + offs[g];
     jbase_o = j0 - 1;
@@ -266,12 +278,15 @@ __global__ __launch_bounds__(64 * WPB) void compact_runs_kernel(
   };
   // claim word of a move's destination block (4 one-byte run counters; 1 = the run is the block's
   // only writer).  The byte is extracted at the point of use so that issuing the load never waits.
+  // claims == nullptr: the list comes from schedule_t1_cache_moves, which writes every destination
+  // block from ONE run (ascending destinations, a block belongs to one head) -- no table to read.
+  const bool counted = claims != nullptr;
   auto claim_word = [&](int mx) -> uint32_t {
     uint32_t w = 0u;
-    if (mx >= 0) w = claims[(mx / BS) >> 2];
+    if (counted && mx >= 0) w = claims[(mx / BS) >> 2];
     return w;
   };
-  auto claim_of = [&](uint32_t w, int mx) -> int { return (int)((w >> (8 * ((mx / BS) & 3))) & 0xFFu); };
+  auto claim_of = [&](uint32_t w, int mx) -> int { return counted ? (int)((w >> (8 * ((mx / BS) & 3))) & 0xFFu) : 1; };
 
   BlockImg<NPL> kd, vd;
 #pragma unroll
@@ -501,16 +516,27 @@ __global__ __launch_bounds__(256) void compact_generic_kernel(
     uint8_t* __restrict__ k_cache, uint8_t* __restrict__ v_cache, float* __restrict__ metrics,
     int32_t* __restrict__ positions, const int32_t* __restrict__ moves,
     const int32_t* __restrict__ count, const int32_t* __restrict__ offs,
-    const int32_t* __restrict__ tile_prefix, int G, int bs, int hd, int e, int x) {
+    const int32_t* __restrict__ wg_tiles, int nwg, int heads_per_wg, int G, int bs, int hd, int e, int x) {
+  __shared__ int loc_s[5];
   const int tid = threadIdx.x;
-  const int total_tiles = tile_prefix[G];
   const int kgroups = hd / x;                 // K vectors per slot
   const int kvec_bytes = x * e;
   const int64_t block_bytes = (int64_t)hd * bs * e;
-  for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
-    const int g = upper_bound_minus1(tile_prefix, G, t);
-    const int cnt = count[g];
-    const int j0 = (t - tile_prefix[g]) * KVC_TM_GENERIC;
+  // a contiguous range of tiles per workgroup, found by its first wave
+  if (tid < WAVE) {
+    int tb = 0, te = 0, g0 = 0, gf = 0;
+    const bool any = locate_tiles(wg_tiles, nwg, heads_per_wg, count, G, KVC_TM_GENERIC, blockIdx.x, gridDim.x, tid,
+                                  tb, te, g0, gf);
+    if (tid == 0) { loc_s[0] = any ? 1 : 0; loc_s[1] = tb; loc_s[2] = te; loc_s[3] = g0; loc_s[4] = gf; }
+  }
+  __syncthreads();
+  if (!loc_s[0]) return;
+  int g = loc_s[3], g_first = loc_s[4];
+  int cnt = count[g];
+  int g_next = g_first + (cnt + KVC_TM_GENERIC - 1) / KVC_TM_GENERIC;
+  for (int t = loc_s[1]; t < loc_s[2]; ++t) {
+    while (t >= g_next && g + 1 < G) { ++g; g_first = g_next; cnt = count[g]; g_next = g_first + (cnt + KVC_TM_GENERIC - 1) / KVC_TM_GENERIC; }
+    const int j0 = (t - g_first) * KVC_TM_GENERIC;
     const int j1 = min(cnt, j0 + KVC_TM_GENERIC);
     const int2* __restrict__ mv = reinterpret_cast<const int2*>(moves) + offs[g];
     for (int j = j0 + tid; j < j1; j += blockDim.x) {
@@ -542,11 +568,14 @@ __global__ __launch_bounds__(256) void compact_generic_kernel(
 
 // one byte per block, in whole 16 B vectors
 static size_t claims_bytes(int64_t num_blocks) { return (size_t)((num_blocks + 15) / 16 + 1) * 16; }
-// [prefix: (heads + 1) int32, padded to 16 B][claims]
-static size_t claims_offset(int32_t total_heads) { return ((size_t)((int64_t)total_heads + 2) * sizeof(int32_t) + 15) / 16 * 16; }
+// [plan: 2 x MOVES_PLAN_WGS int32][claims]
+static size_t claims_offset() { return (size_t)2 * kvc::MOVES_PLAN_WGS * sizeof(int32_t); }
+
+extern "C" size_t kvc_cache_moves_plan_bytes(void) { return claims_offset(); }
 
 extern "C" size_t kvc_execute_cache_moves_workspace_bytes(int32_t total_heads, int64_t num_blocks) {
-  return claims_offset(total_heads) + claims_bytes(num_blocks);
+  (void)total_heads;
+  return claims_offset() + claims_bytes(num_blocks);
 }
 
 namespace kvc {
@@ -603,7 +632,8 @@ static int compact_runs_grid() {
                             // 4-wave workgroups, one wave per SIMD, beat single-wave workgroups by 5-7 %)
 #endif
 
-// planning half: tile prefix sums + destination-block claim counts (2 small launches)
+// planning half (move lists of unknown origin): tiles per group of heads + destination-block claim
+// counts (2 small launches)
 extern "C" int kvc_execute_cache_moves_plan(const int32_t* cache_moves_idx,
                                             const int32_t* cache_moves_count,
                                             const int32_t* evicted_kv_offsets, int32_t total_heads,
@@ -616,38 +646,35 @@ extern "C" int kvc_execute_cache_moves_plan(const int32_t* cache_moves_idx,
                                   workspace, workspace_bytes)) return rc;
   if (total_heads <= 0) return KVC_OK;
   hipStream_t s = (hipStream_t)stream;
-  int32_t* prefix = reinterpret_cast<int32_t*>(workspace);
-  uint32_t* claims = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(workspace) + claims_offset(total_heads));
+  const bool fast = compact_shape_fast(head_size, block_size, elem_bytes, vec_size);
+  int32_t* wg_tiles = reinterpret_cast<int32_t*>(workspace) + (fast ? 0 : MOVES_PLAN_WGS);
+  uint32_t* claims = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(workspace) + claims_offset());
   const int G = total_heads;
+  int nwg, hpw;
+  moves_plan_shape(G, nwg, hpw);
   // a wave holds one move per lane: tile + look-behind + (bs-1) look-ahead <= 64 lanes
-  const int tm = compact_shape_fast(head_size, block_size, elem_bytes, vec_size) ? 64 - block_size : KVC_TM_GENERIC;
+  const int tm = fast ? 64 - block_size : KVC_TM_GENERIC;
   const int64_t claim_vecs = (int64_t)(claims_bytes(num_blocks) / 16);
-  const int64_t zb = (claim_vecs + 4095) / 4096;                 // 4 stores per thread
-  hipLaunchKernelGGL(compact_plan_kernel, dim3(1 + (unsigned)(zb < 1 ? 1 : (zb > 1024 ? 1024 : zb))),
-                     dim3(1024), 0, s, prefix, cache_moves_count, G, tm,
+  const int64_t zb = (claim_vecs + 1023) / 1024;                 // 4 stores per thread
+  const int plan_blocks = hpw >= 16 ? (nwg + 3) / 4 : (nwg + 255) / 256;
+  hipLaunchKernelGGL(compact_plan_kernel, dim3(plan_blocks + (unsigned)(zb < 1 ? 1 : (zb > 4096 ? 4096 : zb))),
+                     dim3(256), 0, s, wg_tiles, cache_moves_count, G, tm, nwg, hpw, plan_blocks,
                      reinterpret_cast<u32x4*>(claims), claim_vecs);
   hipLaunchKernelGGL(compact_plan_claims_kernel, dim3(256 * 8), dim3(256), 0, s, claims, cache_moves_idx,
-                     cache_moves_count, evicted_kv_offsets, prefix, G, block_size, tm);
+                     cache_moves_count, evicted_kv_offsets, wg_tiles, nwg, hpw, G, block_size, tm);
   return check_launch("execute_cache_moves (plan)");
 }
 
-// data half: the compaction kernel itself, on a workspace filled by _plan for the same move list
-extern "C" int kvc_execute_cache_moves_apply(void* k_cache, void* v_cache, float* kv_metrics,
-                                             int32_t* kv_position, const int32_t* cache_moves_idx,
-                                             const int32_t* cache_moves_count,
-                                             const int32_t* evicted_kv_offsets, int32_t total_heads,
-                                             int64_t num_blocks, int32_t block_size,
-                                             int32_t head_size, int32_t elem_bytes, int32_t vec_size,
-                                             void* workspace, size_t workspace_bytes,
-                                             kvc_stream_t stream) {
-  using namespace kvc;
-  if (int rc = compact_check_args(total_heads, num_blocks, block_size, head_size, elem_bytes, vec_size,
-                                  workspace, workspace_bytes)) return rc;
-  if (total_heads <= 0) return KVC_OK;
-  hipStream_t s = (hipStream_t)stream;
-  const int32_t* prefix = reinterpret_cast<const int32_t*>(workspace);
-  const uint32_t* claims = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(workspace) + claims_offset(total_heads));
+namespace kvc {
+// the compaction kernel over a plan; claims == nullptr: every run is the only writer of its block
+static int launch_compaction(void* k_cache, void* v_cache, float* kv_metrics, int32_t* kv_position,
+                             const int32_t* cache_moves_idx, const int32_t* cache_moves_count,
+                             const int32_t* evicted_kv_offsets, int32_t total_heads, int32_t block_size,
+                             int32_t head_size, int32_t elem_bytes, int32_t vec_size, const int32_t* plan,
+                             const uint32_t* claims, hipStream_t s) {
   const int G = total_heads;
+  int nwg, hpw;
+  moves_plan_shape(G, nwg, hpw);
   uint8_t* k = reinterpret_cast<uint8_t*>(k_cache);
   uint8_t* v = reinterpret_cast<uint8_t*>(v_cache);
   // a wave's two LDS source slots take 4 block images: 4 waves per workgroup for 4 KiB images
@@ -657,7 +684,7 @@ extern "C" int kvc_execute_cache_moves_apply(void* k_cache, void* v_cache, float
   hipLaunchKernelGGL((compact_runs_kernel<HD, BS, E, KVC_WPB(HD, BS, E)>),                          \
                      dim3(compact_runs_grid<HD, BS, E, KVC_WPB(HD, BS, E)>()),                      \
                      dim3(64 * KVC_WPB(HD, BS, E)), 0, s, k, v, kv_metrics, kv_position,            \
-                     cache_moves_idx, cache_moves_count, evicted_kv_offsets, claims, prefix, G, 64 - BS)
+                     cache_moves_idx, cache_moves_count, evicted_kv_offsets, claims, plan, nwg, hpw, G, 64 - BS)
   bool fast = compact_shape_fast(head_size, block_size, elem_bytes, vec_size);
   if (!fast) {}
   else if (head_size == 128 && block_size == 16 && elem_bytes == 2) KVC_RUNS(128, 16, 2);
@@ -672,10 +699,51 @@ extern "C" int kvc_execute_cache_moves_apply(void* k_cache, void* v_cache, float
 #undef KVC_WPB
   if (!fast) {
     hipLaunchKernelGGL(compact_generic_kernel, dim3(256 * 8), dim3(256), 0, s, k, v, kv_metrics,
-                       kv_position, cache_moves_idx, cache_moves_count, evicted_kv_offsets, prefix,
-                       G, block_size, head_size, elem_bytes, vec_size);
+                       kv_position, cache_moves_idx, cache_moves_count, evicted_kv_offsets,
+                       plan + MOVES_PLAN_WGS, nwg, hpw, G, block_size, head_size, elem_bytes, vec_size);
   }
   return check_launch("execute_cache_moves");
+}
+}  // namespace kvc
+
+// data half: the compaction kernel itself, on a workspace filled by _plan for the same move list
+extern "C" int kvc_execute_cache_moves_apply(void* k_cache, void* v_cache, float* kv_metrics,
+                                             int32_t* kv_position, const int32_t* cache_moves_idx,
+                                             const int32_t* cache_moves_count,
+                                             const int32_t* evicted_kv_offsets, int32_t total_heads,
+                                             int64_t num_blocks, int32_t block_size,
+                                             int32_t head_size, int32_t elem_bytes, int32_t vec_size,
+                                             void* workspace, size_t workspace_bytes,
+                                             kvc_stream_t stream) {
+  using namespace kvc;
+  if (int rc = compact_check_args(total_heads, num_blocks, block_size, head_size, elem_bytes, vec_size,
+                                  workspace, workspace_bytes)) return rc;
+  if (total_heads <= 0) return KVC_OK;
+  const int32_t* plan = reinterpret_cast<const int32_t*>(workspace);
+  const uint32_t* claims = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(workspace) + claims_offset());
+  return launch_compaction(k_cache, v_cache, kv_metrics, kv_position, cache_moves_idx, cache_moves_count,
+                           evicted_kv_offsets, total_heads, block_size, head_size, elem_bytes, vec_size, plan,
+                           claims, (hipStream_t)stream);
+}
+
+// execute_cache_moves for a move list that kvc_schedule_t1_cache_moves_ex produced together with `plan`
+// (and that nobody has touched since): ONE launch, no planning pass, no claim table
+extern "C" int kvc_execute_cache_moves_planned(void* k_cache, void* v_cache, float* kv_metrics,
+                                               int32_t* kv_position, const int32_t* cache_moves_idx,
+                                               const int32_t* cache_moves_count,
+                                               const int32_t* evicted_kv_offsets, int32_t total_heads,
+                                               int64_t num_blocks, int32_t block_size,
+                                               int32_t head_size, int32_t elem_bytes, int32_t vec_size,
+                                               const int32_t* plan, kvc_stream_t stream) {
+  using namespace kvc;
+  if (plan == nullptr) return fail_invalid("execute_cache_moves: no plan");
+  if ((reinterpret_cast<uintptr_t>(plan) & 15) != 0) return fail_invalid("execute_cache_moves: plan must be 16-byte aligned");
+  if (int rc = compact_check_args(total_heads, num_blocks, block_size, head_size, elem_bytes, vec_size,
+                                  plan, kvc_execute_cache_moves_workspace_bytes(total_heads, num_blocks))) return rc;
+  if (total_heads <= 0) return KVC_OK;
+  return launch_compaction(k_cache, v_cache, kv_metrics, kv_position, cache_moves_idx, cache_moves_count,
+                           evicted_kv_offsets, total_heads, block_size, head_size, elem_bytes, vec_size, plan,
+                           nullptr, (hipStream_t)stream);
 }
 
 extern "C" int kvc_execute_cache_moves(void* k_cache, void* v_cache, float* kv_metrics,

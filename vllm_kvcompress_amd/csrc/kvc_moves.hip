@@ -67,19 +67,29 @@ __device__ __forceinline__ int move_iteration(const MoveHead& h, int j) {
   return i;
 }
 
-// One workgroup per head (plus a few that clear the rows behind the last head).
-//
-// Regular heads (every evicted index is a real slot, E[cnt-1] < ctx -- always true when
-// protected_window >= 1): the walk degenerates to "the j-th hole below new_len = ctx-cnt
-// receives the j-th surviving slot of the tail [new_len, ctx), counted from the top".  The
-// tail's evicted slots are marked in an LDS bitmap, the tail is scanned top-down with
-// ballot prefix sums, and M = #holes below new_len moves are written, coalesced.
-// Irregular heads (SURVEY.md Q3) and tails beyond the bitmap use the closed form above.
-constexpr int MOVE_BITMAP_WORDS = 16384;
+// What the kernel does about the rows of the [rows, 2] table that hold no move (the reference's
+// wrapper clears the WHOLE table before the op, vllm/_custom_ops.py:1168 -- 8 B per candidate slot,
+// 2.2 GB at 256 resident sequences, every decode step):
+//   ZF_NONE  nothing (the bare op)
+//   ZF_ALL   every row without a move <- (0, 0)
+//   ZF_DIRTY the table is known to be zero except where the dirty map says otherwise: only those
+//            rows are cleared.  The map holds one bit per chunk of `bs` rows (head segments start
+//            at multiples of bs) and is rewritten to describe the table after this call; with
+//            ZF_ALL it is written as well (from all zeros: the caller cleared it), so that the next
+//            call can be a ZF_DIRTY one.  Observable result: identical to ZF_ALL.
+constexpr int ZF_NONE = 0, ZF_ALL = 1, ZF_DIRTY = 2;
 
-// rows [b, e) of the move workspace <- (0, 0): 16 B stores (the wrapper's fill_(0) is
-// most of this op's bytes: 8 B per candidate slot, 2.2 GB at 256 resident sequences)
-template <int THREADS>
+struct MovesArgs {
+  int32_t* moves; int64_t rows; int32_t* count;
+  const int32_t* evicted; const int32_t* ekc; const int32_t* offs;
+  const int32_t* block_tables; const int32_t* context_lens;
+  int B, L, H, M, bs, zero_fill;
+  uint32_t* dirty;       // [ceil(rows / bs / 32) + 1] or nullptr
+  int32_t* plan;         // [2 * MOVES_PLAN_WGS] or nullptr: tiles per workgroup, (64 - bs)-move and 32-move tiles
+  int nwg, heads_per_wg; // moves_plan_shape(G)
+};
+
+// rows [b, e) of the move workspace <- (0, 0): 16 B stores
 __device__ __forceinline__ void zero_rows(int2* mv2, int64_t b, int64_t e, int tid, int nthreads) {
   typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
   if (b >= e) return;
@@ -94,104 +104,307 @@ __device__ __forceinline__ void zero_rows(int2* mv2, int64_t b, int64_t e, int t
   // compaction behind it 0.06 ms faster -- a loss)
   for (int64_t i = tid; i < pairs; i += nthreads) m4[i] = z;
   if (((e - b) & 1) && tid == 0) mv2[e - 1] = make_int2(0, 0);
-}      // 512 Ki tail slots per head in LDS (64 KiB)
+}
+
+// The dirty map over the chunks [c0, c1) of one owner (a head's segment, or a piece of the rows
+// behind the last head): thread `tid` of `nthreads` takes every nthreads-th word.  Old bits (ZF_DIRTY)
+// name chunks whose rows from `keep_from` on are cleared; the first `new_chunks` chunks are marked
+// for the next call.  Words that straddle the owner's ends are shared with the neighbours, who do
+// the same to THEIR bits at the same time: those go through atomics, the others are plain.
+__device__ __forceinline__ void dirty_update(uint32_t* map, int2* mv2, int64_t c0, int64_t c1, int64_t new_chunks,
+                                             int64_t keep_from, int64_t rows, int bs, bool read_old, int tid, int nthreads) {
+  if (c0 >= c1) return;
+  const int64_t w0 = c0 >> 5, w1 = (c1 - 1) >> 5;
+  const int64_t cn = c0 + new_chunks;                // chunks [c0, cn) hold moves after this call
+  for (int64_t w = w0 + tid; w <= w1; w += nthreads) {
+    const int64_t lo = max(c0, w << 5), hi = min(c1, (w + 1) << 5);         // this word's chunks of ours
+    const uint32_t mask = (hi - lo >= 32) ? 0xFFFFFFFFu : (((1u << (hi - lo)) - 1u) << (lo & 31));
+    const int64_t nh = min(hi, cn);
+    const uint32_t fresh = nh > lo ? ((nh - lo >= 32) ? 0xFFFFFFFFu : (((1u << (nh - lo)) - 1u) << (lo & 31))) : 0u;
+    uint32_t old = 0u;
+    if (mask == 0xFFFFFFFFu) {
+      if (read_old) old = map[w];
+      if (old != fresh || !read_old) map[w] = fresh;
+    } else {
+      if (read_old) old = atomicAnd(&map[w], ~mask) & mask;
+      if (fresh) atomicOr(&map[w], fresh);
+    }
+    while (old) {                                    // chunks that held moves before this call
+      const int bit = __ffs((int)old) - 1;
+      old &= old - 1u;
+      const int64_t rb = max(((w << 5) + bit) * (int64_t)bs, keep_from);
+      const int64_t re = min((((w << 5) + bit) + 1) * (int64_t)bs, rows);
+      zero_rows(mv2, rb, re, 0, 1);
+    }
+  }
+}
+
+// first index in [0, cnt) with E[idx] >= x (cnt if none), by the 64 lanes of a wave: two or three
+// rounds of 64 probes instead of log2(cnt) dependent loads
+__device__ __forceinline__ int wave_lower_bound(const int32_t* __restrict__ E, int cnt, int x, int lane) {
+  int lo = 0, len = cnt;                             // the answer lies in [lo, lo + len]
+  while (len > WAVE) {
+    const int step = (len + WAVE - 1) / WAVE;        // piece p = [lo + p*step, lo + min(len, (p+1)*step))
+    const int npieces = (len + step - 1) / step;
+    bool below = false;
+    if (lane < npieces) below = E[lo + min(len, (lane + 1) * step) - 1] < x;   // the piece's last element
+    const int full = __popcll(__ballot(below));      // pieces entirely below x: a prefix (E ascends)
+    if (full == npieces) return lo + len;
+    const int end = lo + len;
+    lo += full * step;
+    len = min(step, end - lo);                       // inside piece `full`, whose last element is >= x
+  }
+  const bool below = lane < len && E[lo + lane] < x;
+  return lo + __popcll(__ballot(below));
+}
+
+// One workgroup per `heads_per_wg` consecutive heads (plus a few that see to the rows behind the
+// last head).  Heads that evict little -- the continual-compression steady state: tens of
+// thousands of heads with a move or two each -- take ONE LANE each (up to LANE_HEAD_MAX evictions)
+// or ONE WAVE each, the lanes / waves of a workgroup working on different heads at once (a
+// workgroup per head was 0.11 ms of dependent-load latency for 65 536 heads); a head beyond
+// WAVE_HEAD_MAX evictions takes the whole workgroup.
+//
+// Regular heads (every evicted index is a real slot, E[cnt-1] < ctx -- always true when
+// protected_window >= 1): the walk degenerates to "the j-th hole below new_len = ctx-cnt
+// receives the j-th surviving slot of the tail [new_len, ctx), counted from the top".  The
+// tail's evicted slots are marked in an LDS bitmap, the tail is scanned top-down with
+// ballot prefix sums, and M = #holes below new_len moves are written, coalesced.
+// Irregular heads (SURVEY.md Q3) and tails beyond the bitmap use the closed form above.
+//
+// The same launch leaves behind what execute_cache_moves needs to spread this move list over its
+// waves without a pass of its own: the number of move tiles of every workgroup's heads (`plan`).
+constexpr int MOVE_BITMAP_WORDS = 15000;             // 480 k tail slots per head in LDS (next to the waves' own bitmaps: < 64 KiB)
+constexpr int WAVE_HEAD_MAX = 2048;                  // evictions a single wave takes (64 words of bitmap)
+constexpr int LANE_HEAD_MAX = 32;                    // evictions a single lane walks serially
 
 template <int THREADS, int BITMAP_WORDS>
-__global__ __launch_bounds__(THREADS) void schedule_moves_heads_kernel(
-    int32_t* __restrict__ moves, int64_t rows, int32_t* __restrict__ count,
-    const int32_t* __restrict__ evicted, const int32_t* __restrict__ ekc,
-    const int32_t* __restrict__ offs, const int32_t* __restrict__ block_tables,
-    const int32_t* __restrict__ context_lens, int B, int L, int H, int M, int bs, int zero_fill) {
+__global__ __launch_bounds__(THREADS) void schedule_moves_heads_kernel(MovesArgs a) {
+  constexpr int NWAVES = THREADS / WAVE;
   __shared__ uint32_t bitmap[BITMAP_WORDS];       // 64 KiB for long heads, 4 KiB for short ones (occupancy)
-  __shared__ uint32_t wave_tot[2][THREADS / WAVE];
+  __shared__ uint32_t wbitmap[NWAVES][WAVE_HEAD_MAX / 32];
+  __shared__ uint32_t wave_tot[2][NWAVES];
+  __shared__ uint32_t tiles_s[2];
+  const int B = a.B, L = a.L, H = a.H, M = a.M, bs = a.bs;
   const int G = B * L * H;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  int2* mv2 = reinterpret_cast<int2*>(moves);
+  int2* mv2 = reinterpret_cast<int2*>(a.moves);
+  const int64_t rows = a.rows;
+  const bool with_map = a.dirty != nullptr && a.zero_fill != ZF_NONE;
   // slots of the last head -> total number of rows that belong to heads
   const int lastg = G - 1;
   const int lb = lastg / (L * H), llh = lastg % (L * H);
-  const int last_ctx = context_lens[((llh / H) * B + lb) * H + (llh % H)];
-  const int64_t n_total = (int64_t)offs[lastg] + (int64_t)((last_ctx + bs - 1) / bs) * bs;
-  if ((int)blockIdx.x >= G) {                       // rows behind the last head: zeros
-    if (!zero_fill) return;
-    const int64_t nt = gridDim.x - G, part = (rows - n_total + nt - 1) / nt;   // one contiguous piece per workgroup
-    const int64_t b = n_total + (int64_t)(blockIdx.x - G) * part;
-    zero_rows<THREADS>(mv2, b, min(rows, b + part), tid, THREADS);
+  const int last_ctx = a.context_lens[((llh / H) * B + lb) * H + (llh % H)];
+  const int64_t n_total = (int64_t)a.offs[lastg] + (int64_t)((last_ctx + bs - 1) / bs) * bs;
+  if ((int)blockIdx.x >= a.nwg) {                   // rows behind the last head
+    if (a.zero_fill == ZF_NONE || n_total >= rows) return;
+    const int64_t nt = gridDim.x - a.nwg;
+    if (a.zero_fill == ZF_ALL) {
+      const int64_t part = (rows - n_total + nt - 1) / nt;        // one contiguous piece per workgroup
+      const int64_t b = n_total + (int64_t)(blockIdx.x - a.nwg) * part;
+      zero_rows(mv2, b, min(rows, b + part), tid, THREADS);
+    } else {                                         // only what the map marks (n_total is a multiple of bs)
+      const int64_t c0 = n_total / bs, c1 = (rows + bs - 1) / bs;
+      const int64_t part = ((c1 - c0 + nt - 1) / nt + 31) / 32 * 32;
+      const int64_t b = c0 + (int64_t)(blockIdx.x - a.nwg) * part;
+      dirty_update(a.dirty, mv2, b, min(c1, b + part), 0, 0, rows, bs, true, tid, THREADS);
+    }
     return;
   }
-  const int g = blockIdx.x;
-  const int b = g / (L * H), lh = g % (L * H), l = lh / H, hh = lh % H;
-  const int lbh = (l * B + b) * H + hh;
-  const int cnt = ekc[g];
-  const int ctx = context_lens[lbh];
-  const int64_t off = offs[g];
-  const int64_t seg_end = min((int64_t)rows, (g + 1 < G) ? (int64_t)offs[g + 1] : n_total);
-  const int32_t* E = evicted + off;
-  const int32_t* bt = block_tables + (int64_t)lbh * M;
-  // the zeros behind the head's cnt entries depend on nothing below: they go out first, so that
-  // the stores fly while the head's dependent loads (E, the block table) are still coming in --
-  // with thousands of short heads (one move each, 33 KB of zeros) the kernel was waiting for those
-  // loads with an idle store queue
-  if (zero_fill) zero_rows<THREADS>(mv2, off + cnt, seg_end, tid, THREADS);
-  int nmoves = 0;
-  const bool regular = cnt > 0 && E[cnt - 1] < ctx && (cnt + 31) / 32 <= BITMAP_WORDS;
-  if (cnt > 0 && regular) {
-    const int new_len = ctx - cnt;
-    // holes below new_len = lower_bound(E, new_len)
-    int lo = 0, hi = cnt;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (E[mid] < new_len) lo = mid + 1; else hi = mid; }
-    nmoves = lo;
-    const int words = (cnt + 31) / 32;
-    for (int i = tid; i < words; i += THREADS) bitmap[i] = 0;
-    __syncthreads();
-    for (int k = nmoves + tid; k < cnt; k += THREADS) {       // evicted slots inside the tail
-      const int t = E[k] - new_len;
-      atomicOr(&bitmap[t >> 5], 1u << (t & 31));
-    }
-    __syncthreads();
-    uint32_t carry = 0;
-    int buf = 0;
-    for (int base = 0; base < cnt; base += THREADS) {         // i-th slot from the top
-      const int i = base + tid;
-      bool surv = false;
-      int slot = 0;
-      if (i < cnt) {
-        slot = ctx - 1 - i;
-        const int t = slot - new_len;
-        surv = !((bitmap[t >> 5] >> (t & 31)) & 1u);
-      }
-      const unsigned long long bal = __ballot(surv);
-      const uint32_t lane_ex = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-      if (lane == 0) wave_tot[buf][w] = (uint32_t)__popcll(bal);
-      __syncthreads();
-      uint32_t woff = 0, tot = 0;
-#pragma unroll
-      for (int q = 0; q < THREADS / WAVE; ++q) { const uint32_t c = wave_tot[buf][q]; if (q < w) woff += c; tot += c; }
-      if (surv) {
-        const int j = (int)(carry + woff + lane_ex);
-        const int dst = E[j];
-        if (off + j < rows)
-          mv2[off + j] = make_int2(bt[dst / bs] * bs + dst % bs, bt[slot / bs] * bs + slot % bs);
-      }
-      carry += tot;
-      buf ^= 1;
-    }
-  } else if (cnt > 0) {
-    MoveHead h{E, cnt, ctx};
-    for (int j = tid; j < cnt; j += THREADS) {
-      const int i = move_iteration(h, j);
-      if (i >= 0) {
-        const int src = ctx - 1 - i, dst = E[j];
-        if (off + j < rows)
-          mv2[off + j] = make_int2(bt[dst / bs] * bs + dst % bs, bt[src / bs] * bs + src % bs);
+  if (tid < 2) tiles_s[tid] = 0;
+  __syncthreads();
+  const int g_begin = blockIdx.x * a.heads_per_wg, g_end = min(G, g_begin + a.heads_per_wg);
+  const int tm_fast = bs <= 32 ? 64 - bs : 32;
+  auto head_geometry = [&](int g, int& lbh, int64_t& off, int64_t& seg_end) {
+    const int b = g / (L * H), lh = g % (L * H), l = lh / H, hh = lh % H;
+    lbh = (l * B + b) * H + hh;
+    off = a.offs[g];
+    seg_end = min(rows, (g + 1 < G) ? (int64_t)a.offs[g + 1] : n_total);
+  };
+  auto finish_head = [&](int g, int64_t off, int64_t seg_end, int cnt, int nmoves, int t, int nt) {
+    // (t of nt threads: a wave's lanes or the whole workgroup)
+    if (t == 0) {
+      a.count[g] = nmoves;
+      if (a.plan != nullptr && nmoves > 0) {
+        atomicAdd(&tiles_s[0], (uint32_t)((nmoves + tm_fast - 1) / tm_fast));
+        atomicAdd(&tiles_s[1], (uint32_t)((nmoves + 31) / 32));
       }
     }
-    int lo = 0, hi = cnt;                                    // first j that is not a move
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (move_iteration(h, mid) >= 0) lo = mid + 1; else hi = mid; }
-    nmoves = lo;
+    if (a.zero_fill == ZF_ALL) zero_rows(mv2, off + nmoves, min(seg_end, off + cnt), t, nt);
+    if (with_map)
+      dirty_update(a.dirty, mv2, off / bs, (seg_end + bs - 1) / bs, (min((int64_t)nmoves, max(seg_end - off, (int64_t)0)) + bs - 1) / bs,
+                   off + nmoves, rows, bs, a.zero_fill == ZF_DIRTY, t, nt);
+  };
+
+  // the zeros behind every head's cnt entries depend on nothing below: they go out first, by the
+  // whole workgroup, so that the stores fly while the heads' dependent loads (E, the block table)
+  // are still coming in
+  if (a.zero_fill == ZF_ALL) {
+    for (int g = g_begin; g < g_end; ++g) {
+      int lbh; int64_t off, seg_end;
+      head_geometry(g, lbh, off, seg_end);
+      zero_rows(mv2, off + a.ekc[g], seg_end, tid, THREADS);
+    }
   }
-  if (tid == 0) count[g] = nmoves;
-  if (zero_fill) zero_rows<THREADS>(mv2, off + nmoves, min(seg_end, off + cnt), tid, THREADS);
+
+  // ---- heads a single lane takes: the reference's own serial walk (kvcompress_eviction_kernels.cu:
+  // 256-272), one head per lane -- in the continual-compression steady state a head evicts a block's
+  // hanging tokens (a handful of indices) and what a step costs is the chain of dependent loads,
+  // which the heads of a workgroup now walk side by side
+  for (int g = g_begin + tid; g < g_end; g += THREADS) {
+    const int cnt = a.ekc[g];
+    if (cnt > LANE_HEAD_MAX) continue;
+    int lbh; int64_t off, seg_end;
+    head_geometry(g, lbh, off, seg_end);
+    const int ctx = a.context_lens[lbh];
+    const int32_t* E = a.evicted + off;
+    const int32_t* bt = a.block_tables + (int64_t)lbh * M;
+    int mc = 0, ec = 0;
+    for (int i = 0; i < cnt; ++i) {
+      const int src = ctx - 1 - i;
+      const int stop = E[cnt - 1 - ec];
+      const int dst = E[mc];
+      if (dst >= src) break;
+      if (src <= stop) { ++ec; continue; }
+      if (off + mc < rows)
+        mv2[off + mc] = make_int2(bt[dst / bs] * bs + dst % bs, bt[src / bs] * bs + src % bs);
+      ++mc;
+    }
+    finish_head(g, off, seg_end, cnt, mc, 0, 1);
+  }
+
+  // ---- heads a wave takes
+  for (int g = g_begin + w; g < g_end; g += NWAVES) {
+    const int cnt = a.ekc[g];
+    if (cnt <= LANE_HEAD_MAX || cnt > WAVE_HEAD_MAX) continue;     // (wave-uniform)
+    int lbh; int64_t off, seg_end;
+    head_geometry(g, lbh, off, seg_end);
+    const int ctx = a.context_lens[lbh];
+    const int32_t* E = a.evicted + off;
+    const int32_t* bt = a.block_tables + (int64_t)lbh * M;
+    int nmoves = 0;
+    if (cnt > 0 && E[cnt - 1] < ctx) {               // regular
+      const int new_len = ctx - cnt;
+      nmoves = wave_lower_bound(E, cnt, new_len, lane);
+      if (nmoves > 0) {
+        uint32_t* bm = wbitmap[w];
+        bm[lane] = 0u;                               // WAVE_HEAD_MAX / 32 = 64 words: one per lane
+        wave_lds_sync();
+        for (int k = nmoves + lane; k < cnt; k += WAVE) {           // evicted slots inside the tail
+          const int t = E[k] - new_len;
+          atomicOr(&bm[t >> 5], 1u << (t & 31));
+        }
+        wave_lds_sync();
+        int carry = 0;
+        for (int base = 0; base < cnt && carry < nmoves; base += WAVE) {   // i-th slot from the top
+          const int i = base + lane;
+          bool surv = false;
+          int slot = 0;
+          if (i < cnt) {
+            slot = ctx - 1 - i;
+            const int t = slot - new_len;
+            surv = !((bm[t >> 5] >> (t & 31)) & 1u);
+          }
+          const unsigned long long bal = __ballot(surv);
+          const int j = carry + __popcll(bal & ((1ull << lane) - 1ull));
+          if (surv && j < nmoves) {
+            const int dst = E[j];
+            if (off + j < rows)
+              mv2[off + j] = make_int2(bt[dst / bs] * bs + dst % bs, bt[slot / bs] * bs + slot % bs);
+          }
+          carry += __popcll(bal);
+        }
+      }
+    } else if (cnt > 0) {
+      MoveHead h{E, cnt, ctx};
+      for (int j = lane; j < cnt; j += WAVE) {
+        const int i = move_iteration(h, j);
+        if (i >= 0) {
+          const int src = ctx - 1 - i, dst = E[j];
+          if (off + j < rows)
+            mv2[off + j] = make_int2(bt[dst / bs] * bs + dst % bs, bt[src / bs] * bs + src % bs);
+        }
+      }
+      int lo = 0, hi = cnt;                                    // first j that is not a move
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (move_iteration(h, mid) >= 0) lo = mid + 1; else hi = mid; }
+      nmoves = lo;
+    }
+    finish_head(g, off, seg_end, cnt, nmoves, lane, WAVE);
+  }
+
+  // ---- heads the whole workgroup takes, one after the other
+  for (int g = g_begin; g < g_end; ++g) {
+    const int cnt = a.ekc[g];
+    if (cnt <= WAVE_HEAD_MAX) continue;              // (uniform)
+    int lbh; int64_t off, seg_end;
+    head_geometry(g, lbh, off, seg_end);
+    const int ctx = a.context_lens[lbh];
+    const int32_t* E = a.evicted + off;
+    const int32_t* bt = a.block_tables + (int64_t)lbh * M;
+    int nmoves = 0;
+    const bool regular = E[cnt - 1] < ctx && (cnt + 31) / 32 <= BITMAP_WORDS;
+    if (regular) {
+      const int new_len = ctx - cnt;
+      // holes below new_len = lower_bound(E, new_len)
+      int lo = 0, hi = cnt;
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (E[mid] < new_len) lo = mid + 1; else hi = mid; }
+      nmoves = lo;
+      const int words = (cnt + 31) / 32;
+      __syncthreads();                               // (the bitmap of the head before)
+      for (int i = tid; i < words; i += THREADS) bitmap[i] = 0;
+      __syncthreads();
+      for (int k = nmoves + tid; k < cnt; k += THREADS) {       // evicted slots inside the tail
+        const int t = E[k] - new_len;
+        atomicOr(&bitmap[t >> 5], 1u << (t & 31));
+      }
+      __syncthreads();
+      uint32_t carry = 0;
+      int buf = 0;
+      for (int base = 0; base < cnt; base += THREADS) {         // i-th slot from the top
+        const int i = base + tid;
+        bool surv = false;
+        int slot = 0;
+        if (i < cnt) {
+          slot = ctx - 1 - i;
+          const int t = slot - new_len;
+          surv = !((bitmap[t >> 5] >> (t & 31)) & 1u);
+        }
+        const unsigned long long bal = __ballot(surv);
+        const uint32_t lane_ex = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[buf][w] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+#pragma unroll
+        for (int q = 0; q < NWAVES; ++q) { const uint32_t c = wave_tot[buf][q]; if (q < w) woff += c; tot += c; }
+        if (surv) {
+          const int j = (int)(carry + woff + lane_ex);
+          const int dst = E[j];
+          if (off + j < rows)
+            mv2[off + j] = make_int2(bt[dst / bs] * bs + dst % bs, bt[slot / bs] * bs + slot % bs);
+        }
+        carry += tot;
+        buf ^= 1;
+      }
+    } else {
+      MoveHead h{E, cnt, ctx};
+      for (int j = tid; j < cnt; j += THREADS) {
+        const int i = move_iteration(h, j);
+        if (i >= 0) {
+          const int src = ctx - 1 - i, dst = E[j];
+          if (off + j < rows)
+            mv2[off + j] = make_int2(bt[dst / bs] * bs + dst % bs, bt[src / bs] * bs + src % bs);
+        }
+      }
+      int lo = 0, hi = cnt;                                    // first j that is not a move
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (move_iteration(h, mid) >= 0) lo = mid + 1; else hi = mid; }
+      nmoves = lo;
+    }
+    finish_head(g, off, seg_end, cnt, nmoves, tid, THREADS);
+  }
+  if (a.plan != nullptr) {
+    __syncthreads();
+    if (tid < 2) a.plan[tid * MOVES_PLAN_WGS + blockIdx.x] = (int32_t)tiles_s[tid];
+  }
 }
 
 }  // namespace kvc
@@ -213,6 +426,45 @@ extern "C" int kvc_count_block_evictions(int32_t* evicted_block_count,
   return kvc::check_launch("count_block_evictions");
 }
 
+extern "C" size_t kvc_cache_moves_dirty_map_bytes(int64_t cache_moves_rows, int32_t block_size) {
+  if (block_size < 1 || cache_moves_rows < 0) return 0;
+  const int64_t chunks = (cache_moves_rows + block_size - 1) / block_size;
+  return (size_t)((chunks + 31) / 32 + 1) * 4;
+}
+
+extern "C" int kvc_schedule_t1_cache_moves_ex(
+    int32_t* cache_moves_idx, int64_t cache_moves_rows, int32_t* cache_moves_count,
+    const int32_t* evicted_logical_indices, const int32_t* evicted_kv_count,
+    const int32_t* evicted_kv_offsets, const int32_t* block_tables,
+    const int32_t* context_lens, int32_t num_seqs, int32_t num_layers, int32_t num_kv_heads,
+    int32_t max_num_blocks_per_seq, int32_t block_size, int32_t zero_fill,
+    uint32_t* dirty_map, size_t dirty_map_bytes, int32_t* plan_out, kvc_stream_t stream) {
+  if (block_size < 1) return kvc::fail_invalid("Unsupported block size: " + std::to_string(block_size));
+  if (zero_fill < 0 || zero_fill > 2) return kvc::fail_invalid("schedule_t1_cache_moves: zero_fill must be 0, 1 or 2");
+  if (zero_fill == kvc::ZF_DIRTY && dirty_map == nullptr)
+    return kvc::fail_invalid("schedule_t1_cache_moves: zero_fill 2 needs the table's dirty map");
+  if (dirty_map != nullptr && dirty_map_bytes < kvc_cache_moves_dirty_map_bytes(cache_moves_rows, block_size))
+    return kvc::fail_invalid("schedule_t1_cache_moves: dirty map too small");
+  const int G = num_seqs * num_layers * num_kv_heads;
+  if (G <= 0) return KVC_OK;
+  hipStream_t s = (hipStream_t)stream;
+  kvc::MovesArgs a;
+  a.moves = cache_moves_idx; a.rows = cache_moves_rows; a.count = cache_moves_count;
+  a.evicted = evicted_logical_indices; a.ekc = evicted_kv_count; a.offs = evicted_kv_offsets;
+  a.block_tables = block_tables; a.context_lens = context_lens;
+  a.B = num_seqs; a.L = num_layers; a.H = num_kv_heads; a.M = max_num_blocks_per_seq; a.bs = block_size;
+  a.zero_fill = zero_fill; a.dirty = dirty_map; a.plan = plan_out;
+  kvc::moves_plan_shape(G, a.nwg, a.heads_per_wg);
+  // extra workgroups see to the rows behind the last head's segment
+  const int tail_wgs = zero_fill ? 64 : 0;
+  const int64_t rows_per_head = cache_moves_rows / G;
+  if (rows_per_head >= 8192)
+    hipLaunchKernelGGL((kvc::schedule_moves_heads_kernel<1024, kvc::MOVE_BITMAP_WORDS>), dim3(a.nwg + tail_wgs), dim3(1024), 0, s, a);
+  else
+    hipLaunchKernelGGL((kvc::schedule_moves_heads_kernel<256, 1024>), dim3(a.nwg + tail_wgs), dim3(256), 0, s, a);
+  return kvc::check_launch("schedule_t1_cache_moves");
+}
+
 extern "C" int kvc_schedule_t1_cache_moves(
     int32_t* cache_moves_idx, int64_t cache_moves_rows, int32_t* cache_moves_count,
     const int32_t* evicted_logical_indices, const int32_t* evicted_kv_count,
@@ -220,20 +472,8 @@ extern "C" int kvc_schedule_t1_cache_moves(
     const int32_t* context_lens, int32_t num_seqs, int32_t num_layers, int32_t num_kv_heads,
     int32_t max_num_blocks_per_seq, int32_t block_size, int32_t zero_fill,
     kvc_stream_t stream) {
-  if (block_size < 1) return kvc::fail_invalid("Unsupported block size: " + std::to_string(block_size));
-  const int G = num_seqs * num_layers * num_kv_heads;
-  if (G <= 0) return KVC_OK;
-  hipStream_t s = (hipStream_t)stream;
-  // extra workgroups clear the rows behind the last head's segment (wrapper zero fill)
-  const int tail_wgs = zero_fill ? 64 : 0;
-  const int64_t rows_per_head = cache_moves_rows / G;
-#define KVC_LAUNCH_HEADS(T, W)                                                                 \
-  hipLaunchKernelGGL((kvc::schedule_moves_heads_kernel<T, W>), dim3(G + tail_wgs), dim3(T), 0, s,     \
-                     cache_moves_idx, cache_moves_rows, cache_moves_count,                      \
-                     evicted_logical_indices, evicted_kv_count, evicted_kv_offsets,             \
-                     block_tables, context_lens, num_seqs, num_layers, num_kv_heads,            \
-                     max_num_blocks_per_seq, block_size, zero_fill)
-  if (rows_per_head >= 8192) KVC_LAUNCH_HEADS(1024, kvc::MOVE_BITMAP_WORDS); else KVC_LAUNCH_HEADS(256, 1024);
-#undef KVC_LAUNCH_HEADS
-  return kvc::check_launch("schedule_t1_cache_moves");
+  return kvc_schedule_t1_cache_moves_ex(cache_moves_idx, cache_moves_rows, cache_moves_count, evicted_logical_indices,
+                                        evicted_kv_count, evicted_kv_offsets, block_tables, context_lens, num_seqs,
+                                        num_layers, num_kv_heads, max_num_blocks_per_seq, block_size,
+                                        zero_fill ? 1 : 0, nullptr, 0, nullptr, stream);
 }

@@ -69,13 +69,6 @@ constexpr int KREC = 256;   // record length of the small-eviction schedule (key
 
 __device__ __forceinline__ bool gated_off(const SchedWs& ws) { return ws.gate != nullptr && *ws.gate == 0u; }
 
-// order LDS traffic between the lanes of one wave (no other wave shares the buffer)
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // bracket schedule (section 9): the bracket list of head g (its slots start at off_g) lives at
 // blist + off_g / BR_DIV + g * BR_PAD and holds an eighth of the head's slots plus BR_PAD entries,
 // BR_SORT_MAX at most (what one workgroup sorts in LDS); the lists of neighbours do not overlap

@@ -85,9 +85,11 @@ class CompressionScheduler:
         self.iteration_count = 0
         self.new_tokens = 0
         self._iters_since_compression: Dict[int, int] = {}
-        # persistent move workspace (reference scheduler.py:74-86)
-        self.cache_move_indices = torch.empty((max_kv_per_compression, 2), dtype=torch.int32,
-                                              device=self.device)
+        # persistent move workspace (reference scheduler.py:74-86).  Registered with the op surface:
+        # the wrapper's per-call fill_(0) of the whole table (vllm/_custom_ops.py:1168) then only
+        # clears the rows the previous call wrote -- the table's contents are the same
+        self.cache_move_indices = ops.track_move_table(
+            torch.empty((max_kv_per_compression, 2), dtype=torch.int32, device=self.device))
 
     # ---- reference scheduler.py:100-181 ---------------------------------------------------
     def schedule_seq_evictions(self, req: SeqCompressionRequest):
