@@ -260,6 +260,18 @@ typedef struct kvc_schedule_params {
                                                * of that launch wait for work, not for workgroups, so a grid
                                                * that is not resident at once (tests force one) only runs
                                                * slower. */
+  uint32_t* eli_dirty_map;                    /* ABI version 4, optional (NULL: none).  The small-eviction schedule
+                                               * writes a handful of indices per head and then pads 4 B per
+                                               * candidate slot with null_value -- 1.08 GB per decode step at 256
+                                               * resident sequences, the largest single item of that schedule.  A
+                                               * caller that keeps evicted_logical_indices between calls passes the
+                                               * buffer's dirty map (one bit per block_size entries, (entries /
+                                               * block_size + 31) / 32 + 1 words; all zero for a buffer that is
+                                               * null_value everywhere): only what earlier calls left behind is
+                                               * cleared, and the map is rewritten.  Contents after the call are
+                                               * identical to the padded list.  Ignored by the other schedules
+                                               * (they write every entry; a call that falls back from the
+                                               * small-eviction schedule keeps the map right). */
   /* outputs */
   int32_t* evicted_logical_indices;           /* [N] */
   int32_t* evicted_kv_count;                  /* [B,L,H] */

@@ -451,3 +451,63 @@ def test_sparse_batch_builds_its_keys_through_the_callers_block_tables(path, bs)
     assert ds.cm.last_used_block_tables is False
     for x, y in zip(*res):
         assert torch.equal(x, y)
+
+
+def test_output_buffer_kept_between_calls_holds_the_padded_list():
+    """the small-eviction schedule returns evicted_logical_indices in a buffer CompressionMetrics keeps
+    (only what earlier calls left behind is padded again): over 60 calls with changing batch
+    composition, eviction sizes and a call that falls back in the middle, the returned list equals
+    the reference's fully padded one entry for entry; a result somebody still holds is never
+    overwritten"""
+    from tests.test_gpu_move_table import _sub_state
+    L, H, bs = 2, 4, 16
+    seq_lens = [3 * 1024] * 5
+    st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs, seq_lens=seq_lens, seed=8, protected=bs + 1,
+                          steady_cap=1024, spare_block_frac=0.05)
+    ds = hdev.upload(st, DEV, mode="per_sequence")
+    cm = ds.cm
+    cm.schedule_path = 2
+    assert cm.reuse_output_buffer
+    rng = np.random.default_rng(4)
+    B = len(seq_lens)
+    ptrs, held = set(), []
+    for step in range(60):
+        k = int(rng.integers(1, B + 1))
+        sel = sorted(rng.choice(B, size=k, replace=False).tolist())
+        sub = _sub_state(st, sel)
+        evicted = [int(rng.integers(0, 9)) for _ in sel]
+        skew = step == 30
+        if skew:                                       # one head absorbs the eviction: record overflow -> fallback
+            blocks = np.nonzero((st.layer_index_by_block == 1) & (st.head_index_by_block == 2)
+                                & (st.seq_index_by_block == sel[0]))[0]
+            saved = cm.metrics[torch.from_numpy(blocks).to(DEV)].clone()
+            m2 = st.metrics.copy()
+            m2[blocks] -= np.float32(1e7)
+            cm.metrics.copy_(torch.from_numpy(m2))
+            sub.metrics = m2
+            evicted[0] = 24
+        want = oracle_pipeline(sub, evicted, mode="per_sequence")
+        out = cm.schedule_evictions(sel, torch.from_numpy(sub.seq_positions).to(DEV), evicted,
+                                    ds.context_lens[:, sel].contiguous(),
+                                    torch.from_numpy(sub.hanging_token_count).to(DEV),
+                                    torch.from_numpy(sub.evicted_kv_offsets).to(DEV), sub.protected,
+                                    total_slots=sub.total_slots)
+        how = cm.last_schedule_path()
+        assert how == ("small_eviction+fallback" if skew else "small_eviction"), (step, how)
+        for got, key in zip(out, ("eli", "ekc", "ebc")):
+            np.testing.assert_array_equal(got.cpu().numpy(), want[key], err_msg=f"step {step}: {key}")
+        ptrs.add(out[0].data_ptr())
+        if step % 10 == 3:
+            held.append((out[0], want["eli"].copy()))    # somebody keeps this result
+        if skew:
+            cm.metrics.copy_(torch.from_numpy(st.metrics))
+        del out
+    for t, want_eli in held:                             # ... and finds it unchanged at the end
+        np.testing.assert_array_equal(t.cpu().numpy(), want_eli)
+    assert len(ptrs) <= 1 + len(held) + B, "the buffer is kept between calls unless a result is still held or it must grow"
+    cm.reuse_output_buffer = False
+    args = ([0], torch.from_numpy(st.seq_positions[:1]).to(DEV), [2], ds.context_lens[:, [0]].contiguous(),
+            ds.hanging_token_count[[0]].contiguous(), ds.evicted_kv_offsets[[0]].contiguous(), st.protected[:1])
+    a = cm.schedule_evictions(*args)
+    b = cm.schedule_evictions(*args)
+    assert a[0].data_ptr() != b[0].data_ptr() and torch.equal(a[0], b[0])

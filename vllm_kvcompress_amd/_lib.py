@@ -43,6 +43,7 @@ class KvcScheduleParams(ctypes.Structure):
         ("block_tables", c_void_p), ("seq_index_of_slot", c_void_p),
         ("max_num_seqs", c_int32), ("block_tables_width", c_int32),
         ("schedule_path", c_int32), ("sample_stride", c_int32), ("fallback_grid", c_int32),
+        ("eli_dirty_map", c_void_p),
         ("evicted_logical_indices", c_void_p), ("evicted_kv_count", c_void_p),
         ("evicted_block_count", c_void_p),
     ]

@@ -109,6 +109,42 @@ __device__ __forceinline__ uint32_t nchunks_freed_s(uint32_t r, uint32_t hang, u
   return (bs_shift >= 0 ? (r - hang) >> bs_shift : (r - hang) / bs) + 1u;
 }
 
+// evicted_logical_indices as a buffer the caller keeps between calls (kvc_schedule_params.
+// eli_dirty_map): null everywhere except the leading entries of the head segments the last call wrote.
+// One bit per chunk of bs entries (head segments start at multiples of bs) says where; the owner of
+// the chunks [c0, c1) -- a head -- marks its first new_chunks chunks, clears the rest and, with
+// fill_old, writes null over what older calls left behind from entry keep_from on.  Words that
+// straddle the owner's ends are shared with the neighbouring heads, who do the same to their bits
+// at the same time: atomics there, plain accesses inside.
+__device__ __forceinline__ void eli_dirty_update(uint32_t* map, int32_t* eli, int64_t c0, int64_t c1, int64_t new_chunks,
+                                                 int64_t keep_from, int bs, int32_t null_value, bool fill_old,
+                                                 int tid, int nthreads) {
+  if (c0 >= c1) return;
+  const int64_t w0 = c0 >> 5, w1 = (c1 - 1) >> 5;
+  const int64_t cn = c0 + new_chunks;
+  for (int64_t w = w0 + tid; w <= w1; w += nthreads) {
+    const int64_t lo = max(c0, w << 5), hi = min(c1, (w + 1) << 5);
+    const uint32_t mask = (hi - lo >= 32) ? 0xFFFFFFFFu : (((1u << (hi - lo)) - 1u) << (lo & 31));
+    const int64_t nh = min(hi, cn);
+    const uint32_t fresh = nh > lo ? ((nh - lo >= 32) ? 0xFFFFFFFFu : (((1u << (nh - lo)) - 1u) << (lo & 31))) : 0u;
+    uint32_t old;
+    if (mask == 0xFFFFFFFFu) {
+      old = map[w];
+      if (old != fresh) map[w] = fresh;
+    } else {
+      old = atomicAnd(&map[w], ~mask) & mask;
+      if (fresh) atomicOr(&map[w], fresh);
+    }
+    if (!fill_old) continue;
+    while (old) {
+      const int bit = __ffs((int)old) - 1;
+      old &= old - 1u;
+      const int64_t eb = max(((w << 5) + bit) * (int64_t)bs, keep_from), ee = (((w << 5) + bit) + 1) * (int64_t)bs;
+      for (int64_t e = eb; e < ee; ++e) eli[e] = null_value;
+    }
+  }
+}
+
 // wave-aggregated shared-memory histogram add: metric keys are often degenerate in their
 // top digits (all lanes hit one bin), which would serialise 64 LDS atomics; up to two
 // leader-elected groups are folded into one atomic each, the rest go one by one.
@@ -816,6 +852,11 @@ __device__ __forceinline__ void select_emit_head(const kvc_schedule_params& p, S
   const uint32_t* gkeys = ws.keys + base;
   int32_t* out = p.evicted_logical_indices + base;
   const int tid = threadIdx.x, lane = lane_id(), w = tid / WAVE;
+  // (a call on a tracked output buffer that ended up here -- the small-eviction schedule fell back --
+  // writes the whole segment like any other; the map only has to say what it holds afterwards)
+  if (p.eli_dirty_map != nullptr && !(p.lean & 1))
+    eli_dirty_update(p.eli_dirty_map, p.evicted_logical_indices, base / bs, end / bs, ((int64_t)cnt + bs - 1) / bs, 0, bs,
+                     p.null_value, false, tid, SEL_THREADS);
   if (cnt == 0) {
     if (!(p.lean & 1))
       for (int idx = tid; idx < n; idx += blockDim.x) out[idx] = p.null_value;
@@ -1721,6 +1762,15 @@ __global__ __launch_bounds__(64 * WAVES) void emit_topk_kernel(kvc_schedule_para
   const int g = blockIdx.x * WAVES + w;
   if (g >= G) return;
   const uint32_t cnt = (uint32_t)p.evicted_kv_count[g];
+  if (p.eli_dirty_map != nullptr && !(p.lean & 1)) {
+    // a tracked output buffer: no null fill of the whole list -- what earlier calls left behind in
+    // this head's segment beyond the cnt entries written below is cleared here, and marked
+    const int64_t off = p.evicted_kv_offsets[g];
+    const int64_t end = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : p.total_slots;
+    const int bsz = p.block_size;
+    eli_dirty_update(p.eli_dirty_map, p.evicted_logical_indices, off / bsz, end / bsz, ((int64_t)cnt + bsz - 1) / bsz,
+                     off + cnt, bsz, p.null_value, true, lane, WAVE);
+  }
   if (cnt == 0) return;
   int32_t* out = p.evicted_logical_indices + p.evicted_kv_offsets[g];
   if (cnt <= (uint32_t)WAVE) {
@@ -2937,7 +2987,7 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     // behind it -- one gated launch (section 8) -- and runs only if the flag was raised
     hipMemsetAsync(wb + l.tz_begin, 0, l.tz_end - l.tz_begin, s);
     SideStream* side = nullptr;
-    if (!(p.lean & 1)) {
+    if (!(p.lean & 1) && p.eli_dirty_map == nullptr) {
       if (p.total_slots >= (1 << 22)) side = side_stream(s);
       if (side == nullptr)
         hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.evicted_logical_indices), p.null_value,

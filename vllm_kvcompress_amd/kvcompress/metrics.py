@@ -154,6 +154,16 @@ class CompressionMetrics:
         self._fb_penalty = 0          # general-schedule calls the last raised flag cost
         self._fb_backoff = 0          # of which still to go
         self._fb_fault = False        # a fallback launch gave up a wait (device fault): digit rounds only from now on
+        # evicted_logical_indices of the small-eviction schedule: a handful of indices per head and 4 B
+        # of MAX_INT padding per candidate slot (1.08 GB per decode step at 256 resident sequences).
+        # The list is returned in a buffer this object keeps, with a device-side map of where earlier
+        # calls left indices behind, so that a call pads only those places -- the returned tensor holds
+        # exactly what the reference's holds.  The buffer is used again only when nothing else refers
+        # to its storage any more (the caller dropped the previous result, as the reference's scheduler
+        # does, scheduler.py:492-523); otherwise a new one is made, so a result stays valid for as long
+        # as somebody holds it.  False = a fresh tensor and the full padding every call.
+        self.reuse_output_buffer = os.environ.get("KVC_REUSE_OUTPUT_BUFFER", "1") not in ("", "0")
+        self._eli_buf = None          # (buffer, dirty map, block size, storage use count when only we hold it, stream)
         self._small_cache = {}
 
     # temp_metrics is handed to the attention kernels, which write into it; reading the
@@ -360,7 +370,7 @@ class CompressionMetrics:
         prot = self._as_i32(num_protected)
         k_per_seq = self._as_i32(evicted_blocks_per_seq)
 
-        out_idx = torch.empty((N,), dtype=torch.int32, device=dev)
+        out_idx = None                 # (made below, once the schedule is known)
         out_kv = torch.empty((B, L, H), dtype=torch.int32, device=dev)
         out_blk = torch.empty((B, L, H), dtype=torch.int32, device=dev)
 
@@ -432,6 +442,12 @@ class CompressionMetrics:
         else:
             p.block_tables, p.seq_index_of_slot = None, None
             p.max_num_seqs, p.block_tables_width = 0, 0
+        p.eli_dirty_map = None
+        if (self.reuse_output_buffer and not self.lean_outputs and N > 0
+                and int(lib.kvc_schedule_evictions_plan(ctypes.byref(p))) == 1):
+            out_idx = self._tracked_output(N, bs, p)
+        if out_idx is None:
+            out_idx = torch.empty((N,), dtype=torch.int32, device=dev)
         p.evicted_logical_indices = out_idx.data_ptr()
         p.evicted_kv_count = out_kv.data_ptr()
         p.evicted_block_count = out_blk.data_ptr()
@@ -465,6 +481,27 @@ class CompressionMetrics:
                     self._fb_event = torch.cuda.Event()
                     self._fb_event.record()
         return out_idx, out_kv, out_blk
+
+    @staticmethod
+    def _storage_refs(t: torch.Tensor) -> int:
+        return int(torch._C._storage_Use_Count(t.untyped_storage()._cdata))
+
+    def _tracked_output(self, N: int, bs: int, p) -> torch.Tensor:
+        """evicted_logical_indices [N] as a view of the buffer this object keeps for the small-eviction
+        schedule (see __init__), with its dirty map in ``p.eli_dirty_map``."""
+        rec = self._eli_buf
+        stream = _stream(self.metrics)
+        if rec is not None:
+            buf, dmap, rec_bs, refs, rec_stream = rec
+            if buf.numel() < N or rec_bs != bs or rec_stream != stream or self._storage_refs(buf) != refs:
+                rec = None              # too small, another block size / stream, or a previous result is still alive
+        if rec is None:
+            cap = (N + N // 16 + 4095) // 4096 * 4096          # the batch grows and shrinks by blocks: some slack
+            buf = torch.full((cap,), MAX_INT, dtype=torch.int32, device=self.device)
+            dmap = torch.zeros(((cap // bs + 31) // 32 + 1,), dtype=torch.int32, device=self.device)
+            rec = self._eli_buf = (buf, dmap, bs, self._storage_refs(buf), stream)
+        p.eli_dirty_map = rec[1].data_ptr()
+        return rec[0][:N]
 
     def _raise_fallback_fault(self, which: str) -> None:
         """Bit 1 of the flag word: the single launch that redoes a call on the general pipeline gave
