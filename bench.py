@@ -534,8 +534,11 @@ def measure_workload(a2, seed, device, steps, warmup, probe):
     ev = lambda: torch.cuda.Event(enable_timing=True)
     marks = [[ev() for _ in range(5)] for _ in range(steps)]
     out = {}
+    eli = ekc = ebc = None
     for i in range(-warmup, steps):
         rec = i >= 0
+        out.clear()
+        del eli, ekc, ebc              # (the previous step's results go out of scope, as in the engine's loop)
         if rec: marks[i][0].record()
         eli, ekc, ebc = ds.cm.schedule_evictions(seq_idx, ds.seq_positions, evicted, ds.context_lens,
                                                  ds.hanging_token_count, ds.evicted_kv_offsets, prot, total_slots=N)
@@ -878,6 +881,7 @@ def main():
     out = {}
 
     def step(i=None):
+        out.clear()                    # (the previous step's results go out of scope, as in the engine's loop)
         if i is not None: marks[i][0].record()
         eli, ekc, ebc = ds.cm.schedule_evictions(seq_idx, ds.seq_positions, evicted,
                                                  ds.context_lens, ds.hanging_token_count,

@@ -1139,6 +1139,13 @@ __global__ __launch_bounds__(256) void stream_sample_kernel(kvc_schedule_params 
     uint32_t slot = 0;
     if (ok && lane % LPB == 0) slot = atomicAdd(&ws.st_samp[g], 1u);
     slot = (uint32_t)__shfl((int)slot, lane & ~(LPB - 1), 64);
+    // more physical blocks naming a head than the head has logical blocks (duplicate or stale
+    // metadata; consistent state cannot get here): the head's sample region holds nblk blocks --
+    // the surplus is dropped and the call handed to the general pipeline
+    if (ok && slot >= (uint32_t)((ctx + BS - 1) / BS)) {
+      if (lane % LPB == 0) atomicOr(ws.fallback, 1u);
+      ok = false;
+    }
     if (ok) {
       uint4 k;
       k.x = slot_key(p, m.x, q.x, seq_pos, prot, l, h);
@@ -1195,6 +1202,9 @@ __global__ __launch_bounds__(256) void stream_sample_kernel(kvc_schedule_params 
 // PIV_R x 1024 keys is read ONCE into registers and the four digit rounds of the select run on
 // the registers; a longer one (a sequence far longer than the batch average) is re-read from L2
 // every round.
+#ifndef KVC_PIV_SIGMAS
+#define KVC_PIV_SIGMAS 12.0                          // (experiment builds: tools/)
+#endif
 constexpr int PIV_R = 48;
 constexpr int PIV_MAXLH = 1024;                      // heads per sequence (the host checked)
 __global__ __launch_bounds__(1024) void stream_pivot_kernel(kvc_schedule_params p, SchedWs ws, int sshift) {
@@ -1215,7 +1225,7 @@ __global__ __launch_bounds__(1024) void stream_pivot_kernel(kvc_schedule_params 
       const int ctx = p.context_lens[((tid / H) * B + i) * H + (tid % H)];
       const uint32_t nblk = (uint32_t)((ctx + bs - 1) / bs);
       if (nblk) {
-        ns = ws.st_samp[i * LH + tid];
+        ns = min(ws.st_samp[i * LH + tid], nblk);    // (the counter counts on past what the sampling pass stored)
         nb = nblk; hs = (uint32_t)p.hanging_token_count[i * LH + tid] - 1u;
       }
     }
@@ -1250,7 +1260,7 @@ __global__ __launch_bounds__(1024) void stream_pivot_kernel(kvc_schedule_params 
     double rho = tgt;
     if (sshift > 0) {
       const double x = tgt * (double)ns / (double)nb;
-      rho = ceil(x + 12.0 * sqrt(x) + 8.0);
+      rho = ceil(x + KVC_PIV_SIGMAS * sqrt(x) + 8.0);
     }
     if (n_keys == 0u) {
       rec.pivot_excl = KEY_INF;                      // an empty sample: every evictable key is a candidate
@@ -2705,9 +2715,11 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // as much as the fill is hidden); forked behind the sampling kernel 1.76; split with a part next
 // to the record / selection kernels 1.78-1.81 (S1 itself is 20 us shorter, but the list is then
 // still dirty in the caches when schedule_cache_moves starts, which pays 50 us for it).
-// One non-blocking stream and two events per (host thread, device), made on first use and kept;
-// never created under stream capture (a call that is being captured before any other gets the
-// fill inline).
+// One non-blocking stream and two events per (host thread, device), made on first use and kept for
+// the life of the thread (they are not destroyed at thread exit: by then the HIP runtime may be
+// unloading); never created under stream capture (a call that is being captured before any other
+// gets the fill inline).  Any failure of the fork / join calls is answered by doing without the
+// side stream (the fill inline, or waited for on the host) -- never by an unordered fill.
 struct SideStream { hipStream_t s2 = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool failed = false; };
 static SideStream* side_stream(hipStream_t main) {
   thread_local SideStream tab[64];
@@ -2751,9 +2763,9 @@ struct WsLayout {
 static WsLayout ws_layout(int64_t N, int32_t G, int32_t B, int32_t bs) {
   WsLayout l;
   size_t o = 0;
-  l.keys = o;        o = align_up(o + (size_t)N * 4, 256);      // keys + chunk_phys + bsample: ONE 0xFF memset
+  l.keys = o;        o = align_up(o + (size_t)N * 4, 256);      // keys + chunk_phys (+ bsample on the bracket schedule): ONE 0xFF memset
   l.chunk_phys = o;  o = align_up(o + (size_t)(N / bs + 1) * 4, 256);
-  l.bsample = o;     o = align_up(o + (size_t)B * kvc::BR_CELLS * 4, 256);   // (bracket schedule; inside the 0xFF memset)
+  l.bsample = o;     o = align_up(o + (size_t)B * kvc::BR_CELLS * 4, 256);   // (bracket schedule only; the memset's tail)
   l.zero_begin = o;  // everything up to zero_end is cleared by build_keys' tail workgroups
   l.hist = o;        o = align_up(o + (size_t)G * kvc::RADIX * 4, 256);
   l.less = o;        o = align_up(o + (size_t)G * 4, 256);
@@ -3013,7 +3025,14 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
       }
       hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.evicted_logical_indices), p.null_value,
                         (size_t)p.total_slots, side != nullptr ? side->s2 : s);
-      if (side != nullptr) hipEventRecord(side->join, side->s2);
+      if (side != nullptr && hipEventRecord(side->join, side->s2) != hipSuccess) {
+        // no event to wait for: the fill is waited for here and now (a later wait on `join` would
+        // refer to an earlier call's record), and this thread fills inline from now on
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(side->s2);
+        side->failed = true;
+        side = nullptr;
+      }
     }
     hipLaunchKernelGGL(stream_pivot_kernel, dim3(B), dim3(1024), 0, s, p, ws, sshift);
     {
@@ -3043,7 +3062,11 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
       hipLaunchKernelGGL(seq_prepare_kernel, dim3(1), dim3(1024), prep_lds, s, p, ws);
     }
     hipLaunchKernelGGL(seq_select_topk_kernel, dim3(B), dim3(1024), (size_t)topk_p2 * 8 + (size_t)LH * 4, s, p, ws, topk_p2, coupled_tk);
-    if (side != nullptr) hipStreamWaitEvent(s, side->join, 0);
+    if (side != nullptr && hipStreamWaitEvent(s, side->join, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipStreamSynchronize(side->s2);          // (the emission below must not race the fill)
+      side->failed = true;
+    }
     hipLaunchKernelGGL(emit_topk_kernel<4>, dim3((G + 3) / 4), dim3(256), 0, s, p, ws);
     ws.gate = ws.fallback;
   }
@@ -3068,7 +3091,9 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   // a batch that is sparse in its cache, with the caller's block tables at hand: the keys in logical
   // order through the tables (build_keys_tables_kernel; every slot is written: no clearing)
   const bool by_tables = !topk && tables_plan(p);
-  if (!topk && !(p.lean & 2) && !by_tables) hipMemsetAsync(ws.keys, 0xFF, l.zero_begin - l.keys, s);
+  // (the bracket's sample -- 128 KiB per sequence -- lies behind the keys and the chunk table: cleared with them
+  // only when that schedule runs)
+  if (!topk && !(p.lean & 2) && !by_tables) hipMemsetAsync(ws.keys, 0xFF, (bracket ? l.zero_begin : l.bsample) - l.keys, s);
   const bool bracket_coupled = bracket && p.mode == 0 && B > 1;
   if (bracket) ws.bsample = reinterpret_cast<uint32_t*>(wb + l.bsample);   // build_keys leaves the sample behind
   if (bracket_coupled) {                             // ... and counts the keys that are not evictable
