@@ -278,6 +278,27 @@ def test_dispatcher_path():
     np.testing.assert_array_equal(cmi.cpu().numpy(), want["cmi"])
     np.testing.assert_array_equal(kd.cpu().numpy(), want["k"])
     np.testing.assert_array_equal(vd.cpu().numpy(), want["v"])
+    if torch_ops._REGISTERED == "compiled":
+        # the compiled kernels: the list schedule_t1_cache_moves just made runs on its plan (one launch);
+        # once anything touched it through torch, or for a copy of it, the op plans for itself
+        n0 = torch.ops._kvc_mi355x.planned_compactions()
+        torch.ops._C_kvc_ops.schedule_t1_cache_moves(cmi, cmc, eli, ekc, ds.evicted_kv_offsets,
+                                                     ds.block_tables, ds.context_lens, 16)
+        for args, planned in (((cmi, cmc, ds.evicted_kv_offsets), 1), ((cmi.clone(), cmc, ds.evicted_kv_offsets), 0)):
+            kd2, vd2 = torch.from_numpy(k.copy()).to(DEV), torch.from_numpy(v.copy()).to(DEV)
+            m2, p2 = torch.from_numpy(st.metrics.copy()).to(DEV), torch.from_numpy(st.token_positions.copy()).to(DEV)
+            torch.ops._C_kvc_ops.execute_cache_moves(kd2, vd2, m2, p2, *args, 1, 16)
+            assert torch.ops._kvc_mi355x.planned_compactions() - n0 == planned
+            n0 += planned
+            np.testing.assert_array_equal(kd2.cpu().numpy(), want["k"])
+            np.testing.assert_array_equal(vd2.cpu().numpy(), want["v"])
+            np.testing.assert_array_equal(m2.cpu().numpy(), want["metrics"])
+        cmc.add_(0)
+        kd2, vd2 = torch.from_numpy(k.copy()).to(DEV), torch.from_numpy(v.copy()).to(DEV)
+        m2, p2 = torch.from_numpy(st.metrics.copy()).to(DEV), torch.from_numpy(st.token_positions.copy()).to(DEV)
+        torch.ops._C_kvc_ops.execute_cache_moves(kd2, vd2, m2, p2, cmi, cmc, ds.evicted_kv_offsets, 1, 16)
+        assert torch.ops._kvc_mi355x.planned_compactions() == n0
+        np.testing.assert_array_equal(kd2.cpu().numpy(), want["k"])
 
 
 # ---------------------------------------------------------------------------------------

@@ -71,6 +71,39 @@ def test_fused_collector_exact_logits(cfg):
     assert torch.equal(got, got2)
 
 
+@pytest.mark.parametrize("cfg", [
+    ([300], 300, 128, [0], 4, 4, 64, (True, False, True)),
+    ([129, 64], 1000, 64, [4, 0], 8, 2, 128, (True, True, True)),
+    ([513], 200, 200, [17], 4, 1, 128, (False, False, False)),
+    ([200, 333], 150, 64, [0, 9], 8, 8, 128, (True, False, False)),
+])
+def test_fused_collector_exact_logits_bf16(cfg):
+    """the same with bfloat16 inputs: integers in [-2, 2] are bf16 values, q.k is an integer of
+    magnitude far below 256 (exact in bf16 as well as in fp32), so the logits every implementation
+    rounds to bf16 are the same numbers -- the fp32 softmax / column-sum pipeline must then agree to
+    2e-5 like the fp16 one, which the 4e-2 of the reference-output fixtures (bf16 logits of random
+    inputs: 8 bits of mantissa, summation-order dependent) cannot show"""
+    from vllm_kvcompress_amd.kvcompress.prefill import fused_kvc_attention
+    lens, n_obs, blk, buf, Hq, Hk, hd, (l2, avg, pool) = cfg
+    rng = np.random.default_rng(len(lens) * 77 + hd + Hq)
+    T = sum(lens)
+    qf = rng.integers(-2, 3, size=(T, Hq, hd)).astype(np.float32)
+    kf = rng.integers(-2, 3, size=(T, Hk, hd)).astype(np.float32)
+    assert float(np.abs(np.einsum("thd,shd->hts", qf[:64], np.repeat(kf, Hq // Hk, axis=1)[:64])).max()) < 256
+    bits = lambda a: (a.view(np.uint32) >> np.uint32(16)).astype(np.uint16).view(np.int16)   # exact: small integers
+    k_rep = np.repeat(kf, Hq // Hk, axis=1)
+    g = dict(q=bits(qf), k=bits(k_rep), prompt_lens=np.asarray(lens, np.int32), dtype=np.asarray("bf16"),
+             buffer_len=np.asarray(buf, np.int32), n_observed=np.int32(n_obs), block=np.int32(blk),
+             use_l2=np.int32(l2), use_average=np.int32(avg), use_maxpool=np.int32(pool))
+    want = reference_prefill_metrics_numpy(g)
+    qt = torch.from_numpy(qf).to(DEV).to(torch.bfloat16)
+    kt = torch.from_numpy(kf).to(DEV).to(torch.bfloat16)
+    _, got = fused_kvc_attention(qt, kt, None, lens, hd ** -0.5, torch.tensor(buf, dtype=torch.int32),
+                                 n_observed=n_obs, max_observed_block_size=blk, use_l2=l2, use_average=avg,
+                                 use_maxpool=pool)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-5, atol=1e-7)
+
+
 def test_fused_collector_vs_unfused_path_and_properties():
     """K = 8192 keys, all queries observed in blocks of 1024 (config-5 style, scaled to what
     the unfused path can materialise): fused vs library-GEMM path, and properties: with L1

@@ -103,6 +103,58 @@ void count_block_evictions(Tensor& evicted_block_count, Tensor& evicted_logical_
                                   current_stream(evicted_logical_indices)));
 }
 
+// The move list schedule_t1_cache_moves made last on a (device, stream) brings its plan along
+// (kvc_schedule_t1_cache_moves_ex / kvc_execute_cache_moves_planned, include/kvc_mi355x.h):
+// execute_cache_moves of exactly those three tensors, untouched since, is then ONE launch.  "Exactly
+// those, untouched": the same TensorImpl objects (held weakly: an address that was freed and handed
+// out again does not pass) at the same version counters -- anything that wrote to them through
+// torch has bumped those.  Whatever does not pass takes the self-contained op.
+struct PlanRecord {
+  Tensor plan;
+  c10::weak_intrusive_ptr<c10::TensorImpl> who[3] = {
+      c10::weak_intrusive_ptr<c10::TensorImpl>(c10::intrusive_ptr<c10::TensorImpl>()),
+      c10::weak_intrusive_ptr<c10::TensorImpl>(c10::intrusive_ptr<c10::TensorImpl>()),
+      c10::weak_intrusive_ptr<c10::TensorImpl>(c10::intrusive_ptr<c10::TensorImpl>())};
+  int64_t version[3] = {-1, -1, -1};
+  int32_t total_heads = 0, block_size = 0;
+};
+std::mutex g_plan_mu;
+std::map<std::pair<int, void*>, PlanRecord> g_plans;
+std::atomic<int64_t> g_planned_compactions{0};
+
+bool version_of(const Tensor& t, int64_t& v) {
+  try { v = (int64_t)t._version(); return true; } catch (const c10::Error&) { return false; }
+}
+
+void remember_plan(const Tensor& plan, const Tensor* const (&t)[3], int32_t total_heads, int32_t block_size) {
+  PlanRecord r;
+  r.plan = plan;
+  for (int i = 0; i < 3; ++i) {
+    if (!version_of(*t[i], r.version[i])) return;            // (no version counter: nothing to vouch with)
+    r.who[i] = c10::weak_intrusive_ptr<c10::TensorImpl>(t[i]->getIntrusivePtr());
+  }
+  r.total_heads = total_heads; r.block_size = block_size;
+  std::lock_guard<std::mutex> g(g_plan_mu);
+  g_plans.insert_or_assign(std::make_pair((int)plan.get_device(), current_stream(plan)), std::move(r));
+}
+
+// the plan that vouches for (cmi, cmc, offs) on the current stream, or an undefined tensor
+Tensor plan_of(const Tensor& like, const Tensor* const (&t)[3], int32_t total_heads, int32_t block_size) {
+  std::lock_guard<std::mutex> g(g_plan_mu);
+  auto it = g_plans.find(std::make_pair((int)like.get_device(), current_stream(like)));
+  if (it == g_plans.end()) return Tensor();
+  const PlanRecord& r = it->second;
+  if (r.total_heads != total_heads || r.block_size != block_size) return Tensor();
+  for (int i = 0; i < 3; ++i) {
+    int64_t v = -1;
+    if (!version_of(*t[i], v) || v != r.version[i]) return Tensor();
+    auto alive = r.who[i].lock();
+    if (!alive || alive.get() != t[i]->unsafeGetTensorImpl()) return Tensor();
+  }
+  return r.plan;
+}
+int64_t planned_compactions_op() { return g_planned_compactions.load(); }
+
 // the bare op: rows that hold no move are left untouched (the Python wrapper of the reference
 // zero-fills the workspace in front of it, vllm/_custom_ops.py:1168)
 void schedule_t1_cache_moves(Tensor& cache_moves_idx, Tensor& cache_moves_count,
@@ -123,12 +175,15 @@ void schedule_t1_cache_moves(Tensor& cache_moves_idx, Tensor& cache_moves_count,
                offs = evicted_kv_offsets.contiguous(), bt = block_tables.contiguous(),
                ctx = context_lens.contiguous();
   c10::DeviceGuard guard(cache_moves_idx.device());
-  check(kvc_schedule_t1_cache_moves(cache_moves_idx.data_ptr<int32_t>(), cache_moves_idx.size(0),
-                                    cache_moves_count.data_ptr<int32_t>(), eli.data_ptr<int32_t>(),
-                                    ekc.data_ptr<int32_t>(), offs.data_ptr<int32_t>(), bt.data_ptr<int32_t>(),
-                                    ctx.data_ptr<int32_t>(), (int32_t)ekc.size(0), (int32_t)ekc.size(1),
-                                    (int32_t)ekc.size(2), (int32_t)bt.size(3), (int32_t)block_size, 0,
-                                    current_stream(cache_moves_idx)));
+  Tensor plan = workspace(cache_moves_idx, kvc_cache_moves_plan_bytes(), "cache_moves_plan");
+  check(kvc_schedule_t1_cache_moves_ex(cache_moves_idx.data_ptr<int32_t>(), cache_moves_idx.size(0),
+                                       cache_moves_count.data_ptr<int32_t>(), eli.data_ptr<int32_t>(),
+                                       ekc.data_ptr<int32_t>(), offs.data_ptr<int32_t>(), bt.data_ptr<int32_t>(),
+                                       ctx.data_ptr<int32_t>(), (int32_t)ekc.size(0), (int32_t)ekc.size(1),
+                                       (int32_t)ekc.size(2), (int32_t)bt.size(3), (int32_t)block_size, 0, nullptr, 0,
+                                       reinterpret_cast<int32_t*>(plan.data_ptr()), current_stream(cache_moves_idx)));
+  const Tensor* const who[3] = {&cache_moves_idx, &cache_moves_count, &evicted_kv_offsets};
+  remember_plan(plan, who, (int32_t)ekc.numel(), (int32_t)block_size);
 }
 
 void execute_cache_moves(Tensor& k_cache, Tensor& v_cache, Tensor& kv_metrics, Tensor& kv_position,
@@ -151,8 +206,20 @@ void execute_cache_moves(Tensor& k_cache, Tensor& v_cache, Tensor& kv_metrics, T
                offs = evicted_kv_offsets.contiguous();
   const int64_t num_blocks = v_cache.size(0), head_size = v_cache.size(1), block_size = v_cache.size(2);
   const int32_t total_heads = (int32_t)cmc.numel();
-  const size_t ws_bytes = kvc_execute_cache_moves_workspace_bytes(total_heads, num_blocks);
   c10::DeviceGuard guard(k_cache.device());
+  const Tensor* const who[3] = {&cache_moves_idx, &cache_moves_count, &evicted_kv_offsets};
+  const Tensor plan = plan_of(k_cache, who, total_heads, (int32_t)block_size);
+  if (plan.defined()) {
+    check(kvc_execute_cache_moves_planned(k_cache.data_ptr(), v_cache.data_ptr(), kv_metrics.data_ptr<float>(),
+                                          kv_position.data_ptr<int32_t>(), cmi.data_ptr<int32_t>(),
+                                          cmc.data_ptr<int32_t>(), offs.data_ptr<int32_t>(), total_heads, num_blocks,
+                                          (int32_t)block_size, (int32_t)head_size, (int32_t)k_cache.element_size(),
+                                          (int32_t)k_cache.size(3), reinterpret_cast<const int32_t*>(plan.data_ptr()),
+                                          current_stream(k_cache)));
+    g_planned_compactions.fetch_add(1);
+    return;
+  }
+  const size_t ws_bytes = kvc_execute_cache_moves_workspace_bytes(total_heads, num_blocks);
   Tensor ws = workspace(k_cache, ws_bytes, "execute_cache_moves");
   check(kvc_execute_cache_moves(k_cache.data_ptr(), v_cache.data_ptr(), kv_metrics.data_ptr<float>(),
                                 kv_position.data_ptr<int32_t>(), cmi.data_ptr<int32_t>(),
@@ -404,6 +471,8 @@ TORCH_LIBRARY_FRAGMENT(_C, m) {
 TORCH_LIBRARY_FRAGMENT(_kvc_mi355x, m) {
   m.def("reserve_workspace(Tensor like, int nbytes, str tag) -> ()", &reserve_workspace_op);
   m.def("set_attention_schedule(int schedule) -> ()", &set_attention_schedule_op);
+  // how many execute_cache_moves calls ran on the plan of the schedule_t1_cache_moves before them (tests)
+  m.def("planned_compactions() -> int", &planned_compactions_op);
 }
 
 TORCH_LIBRARY_IMPL(_C_kvc_ops, CUDA, m) {
