@@ -534,6 +534,9 @@ def measure_workload(a2, seed, device, steps, warmup, probe):
     ev = lambda: torch.cuda.Event(enable_timing=True)
     marks = [[ev() for _ in range(5)] for _ in range(steps)]
     out = {}
+    import gc
+    gc.collect()
+    gc.disable()                       # (see main(): the collector's pauses are the host's, not the path's)
     eli = ekc = ebc = None
     for i in range(-warmup, steps):
         rec = i >= 0
@@ -551,6 +554,7 @@ def measure_workload(a2, seed, device, steps, warmup, probe):
         if rec: marks[i][4].record()
         out["ekc"], out["ebc"], out["eli"] = ekc, ebc, eli
     torch.cuda.synchronize()
+    gc.enable()
     parity = parity_gate(a2, st, ds, evicted, a2.mode, dict(eli=out["eli"], ekc=out["ekc"], ebc=out["ebc"], cmi=cmi, cmc=cmc),
                          snap, k_cache, v_cache, wm, wp, lean=bool(a2.lean))
     del snap
@@ -880,13 +884,17 @@ def main():
     marks = [[ev() for _ in range(5)] for _ in range(args.steps)]
     out = {}
 
+    host_t = []
+
     def step(i=None):
         out.clear()                    # (the previous step's results go out of scope, as in the engine's loop)
         if i is not None: marks[i][0].record()
+        host_t.append(time.perf_counter())
         eli, ekc, ebc = ds.cm.schedule_evictions(seq_idx, ds.seq_positions, evicted,
                                                  ds.context_lens, ds.hanging_token_count,
                                                  ds.evicted_kv_offsets, prot, total_slots=N,
                                                  block_tables=ds.block_tables if args.pass_block_tables else None)
+        host_t.append(time.perf_counter())
         if i is not None: marks[i][1].record()
         if args.lean:
             ops._schedule_t1_cache_moves(cmi, cmc, eli, ekc, ds.evicted_kv_offsets, ds.block_tables,
@@ -910,13 +918,27 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # (the interpreter's cyclic collector stays out of the timed region: with torch imported a full
+    # collection is a 35-40 ms host pause, which at 0.2 ms per step lands inside one of the steps and
+    # reads as that step's first stage -- it is the host's, not the path's)
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    if os.environ.get("KVC_BENCH_DUMP_STEPS"):
+        import faulthandler
+        for i in range(args.steps):
+            faulthandler.dump_traceback_later(0.005, exit=False)      # where the host is when a step takes > 5 ms
+            step(i)
+            faulthandler.cancel_dump_traceback_later()
+    else:
+        for i in range(args.steps):
+            step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
+    gc.enable()
     elapsed = t1 - t0
     kernel_ms = sum(m[3].elapsed_time(m[4]) for m in marks) / args.steps
 
@@ -925,6 +947,12 @@ def main():
     freed_blocks = int(out["ebc"].sum().item())
     if args.mode == "per_sequence" or batch == 1:   # the reference's batch>1 quirk frees fewer
         assert freed_blocks == sum(evicted), (freed_blocks, sum(evicted))
+    if os.environ.get("KVC_BENCH_DUMP_STEPS"):       # per-step stage times (diagnostics: a one-off stall shows here)
+        for i, m in enumerate(marks):
+            h = host_t[2 * (args.warmup + i):2 * (args.warmup + i) + 2]
+            print(f"step {i}: S1 {m[0].elapsed_time(m[1]):.3f} S2 {m[1].elapsed_time(m[2]):.3f} "
+                  f"S3 {m[2].elapsed_time(m[4]):.3f} ms; host in schedule_evictions {1e3 * (h[1] - h[0]):.3f} ms, "
+                  f"at {1e3 * (h[0] - host_t[2 * args.warmup]):.2f}", file=sys.stderr)
     s1 = sum(m[0].elapsed_time(m[1]) for m in marks) / args.steps
     s2 = sum(m[1].elapsed_time(m[2]) for m in marks) / args.steps
     s3 = sum(m[2].elapsed_time(m[4]) for m in marks) / args.steps

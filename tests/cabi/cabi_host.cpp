@@ -97,8 +97,36 @@ int main() {
             same(d_moves, w_moves, "cache_moves_idx") & same(d_cnt, w_cnt, "cache_moves_count") &
             same(d_k, wk, "k_cache") & same(d_v, wv, "v_cache") & same(d_met, wm, "kv_metrics") &
             same(d_pos, wp, "kv_position");
+  int rc = 0;
+  // ---- ABI version 4: the move table with its dirty map (full fill, then only what the map marks) and the
+  // compaction on the plan the move scheduler leaves behind (one launch, no workspace)
+  {
+    const size_t mapb = kvc_cache_moves_dirty_map_bytes(N, bs), planb = kvc_cache_moves_plan_bytes();
+    uint32_t* d_map; int32_t* d_plan;
+    CK(hipMalloc(&d_map, mapb)); CK(hipMalloc(&d_plan, planb));
+    CK(hipMemset(d_map, 0, mapb));
+    CK(hipMemset(d_moves, 0x55, (size_t)N * 8));                    // junk: zero_fill 1 clears all of it
+    KV(kvc_schedule_t1_cache_moves_ex(d_moves, N, d_cnt, d_eli, d_ekc, d_offs, d_bt, d_ctx, B, L, H, M, bs, 1, d_map, mapb,
+                                      d_plan, s));
+    CK(hipStreamSynchronize(s));
+    ok = ok & same(d_moves, w_moves, "cache_moves_idx (zero_fill 1 + map)");
+    KV(kvc_schedule_t1_cache_moves_ex(d_moves, N, d_cnt, d_eli, d_ekc, d_offs, d_bt, d_ctx, B, L, H, M, bs, 2, d_map, mapb,
+                                      d_plan, s));
+    CK(hipMemcpyAsync(d_k, k.data(), k.size(), hipMemcpyHostToDevice, s));
+    CK(hipMemcpyAsync(d_v, v.data(), v.size(), hipMemcpyHostToDevice, s));
+    CK(hipMemcpyAsync(d_met, met.data(), met.size() * 4, hipMemcpyHostToDevice, s));
+    CK(hipMemcpyAsync(d_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice, s));
+    KV(kvc_execute_cache_moves_planned(d_k, d_v, d_met, d_pos, d_moves, d_cnt, d_offs, G, NB, bs, hd, e, x, d_plan, s));
+    CK(hipStreamSynchronize(s));
+    ok = ok & same(d_moves, w_moves, "cache_moves_idx (zero_fill 2)") & same(d_cnt, w_cnt, "cache_moves_count (ex)") &
+         same(d_k, wk, "k_cache (planned)") & same(d_v, wv, "v_cache (planned)") &
+         same(d_met, wm, "kv_metrics (planned)") & same(d_pos, wp, "kv_position (planned)");
+    rc = kvc_schedule_t1_cache_moves_ex(d_moves, N, d_cnt, d_eli, d_ekc, d_offs, d_bt, d_ctx, B, L, H, M, bs, 2, nullptr, 0,
+                                        nullptr, s);
+    ok = ok && rc == 1 && strstr(kvc_last_error(), "dirty map") != nullptr;
+  }
   // error convention: unsupported block size -> rc 1 + message
-  int rc = kvc_count_block_evictions(d_ebc, d_eli, d_offs, d_hang, G, N, 0, NUL, s);
+  rc = kvc_count_block_evictions(d_ebc, d_eli, d_offs, d_hang, G, N, 0, NUL, s);
   ok = ok && rc == 1 && strstr(kvc_last_error(), "Unsupported block size") != nullptr;
   // ---- F3 through the struct ABI: one sequence, 2 KV heads x 4 query heads, 200 / 37 keys
   {

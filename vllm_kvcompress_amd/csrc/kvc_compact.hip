@@ -228,6 +228,16 @@ __device__ __forceinline__ uint32_t lds_elem(const uint8_t* p) {
 #ifndef KVC_CHUNK_MAX
 #define KVC_CHUNK_MAX 3
 #endif
+// A run of <= KVC_DSTK_SPARSE_MAX moves (the continual-compression steady state: ONE slot moved into
+// a block) does not read the destination's K image at all and stores only the moved 16 B pieces
+// (16 x hd*e/16 of them per slot) -- the V image, where every 32 B sector holds an element of every
+// slot, is still rewritten whole.  0 = off.  Measured at 256 resident sequences in the steady state
+// (66 k single-move runs per step): compaction kernel 0.278 -> 0.216 ms.  (For the 8-move runs of a
+// bulk eviction the same idea lost: 128 partial-line writes per run against one 4 KiB image,
+// profiles/r2_compact_variants.md; runs of two and more keep the image path.)
+#ifndef KVC_DSTK_SPARSE_MAX
+#define KVC_DSTK_SPARSE_MAX 1
+#endif
 template <int HD, int BS, int E, int WPB>
 __global__ __launch_bounds__(64 * WPB) void compact_runs_kernel(
     uint8_t* __restrict__ k_cache, uint8_t* __restrict__ v_cache, float* __restrict__ metrics,
@@ -339,6 +349,8 @@ __global__ __launch_bounds__(64 * WPB) void compact_runs_kernel(
         // a run that overwrites all BS slots (distinct dst slots of one block) leaves nothing
         // of the old block alive: no read-modify-write, the block is only written
         bool want_dst = (qe - qr) != BS;
+        const bool sparse_k = (qe - qr) <= KVC_DSTK_SPARSE_MAX;     // (wave-uniform)
+        bool ktaken = false;
         // segments = maximal stretches of the run fed by one source block
         unsigned long long segs = __ballot(lane >= qr && lane < qe && (lane == qr || mysb != sleft));
         while (segs) {
@@ -370,7 +382,7 @@ __global__ __launch_bounds__(64 * WPB) void compact_runs_kernel(
           const uint8_t* kb_p = k_cache + (int64_t)sb * BLOCK_BYTES;
           // ---- issue every load of the round trip
           if (want_dst) {
-            img_load<NPL>(kd, kd_p, lane);
+            if (!sparse_k) img_load<NPL>(kd, kd_p, lane);
             img_load<NPL>(vd, vd_p, lane);
             if (lane < BS) { md = metrics[(int64_t)dblk * BS + lane]; pd = positions[(int64_t)dblk * BS + lane]; }
             want_dst = false;
@@ -437,6 +449,7 @@ __global__ __launch_bounds__(64 * WPB) void compact_runs_kernel(
           auto patch = [&](const uint8_t* ls, uint32_t tk, const uint32_t (&tw)[TW], bool chunky,
                            const BlockImg<NPL>& kc, float ms, int ps) {
             const bool take = (tk & 0x80u) != 0u;
+            ktaken = ktaken || take;
             const int ksl = kgrp16 + (int)(tk & 0x7Fu) * 16;
             if (chunky) {
               if (take) {
@@ -482,7 +495,15 @@ __global__ __launch_bounds__(64 * WPB) void compact_runs_kernel(
         // their destination blocks (behind the last LDS read of the patch: the compiler drains
         // every outstanding load in front of the first LDS read that follows an LDS-DMA)
         if (clm_pending) { n_clw = claim_word(n_mvx); clm_pending = false; }
-        img_store<NPL>(kd, kd_p, lane);
+        if (sparse_k) {
+          if (ktaken) {
+#pragma unroll
+            for (int i = 0; i < NPL; ++i)
+              *reinterpret_cast<u32x4*>(kd_p + ((int64_t)i * 64 + lane) * 16) = kd.p[i];
+          }
+        } else {
+          img_store<NPL>(kd, kd_p, lane);
+        }
         img_store<NPL>(vd, vd_p, lane);
         if (lane < BS) { metrics[(int64_t)dblk * BS + lane] = md; positions[(int64_t)dblk * BS + lane] = pd; }
       } else {

@@ -411,7 +411,7 @@ class CompressionMetrics:
         if isinstance(evicted_blocks_per_seq, torch.Tensor) and evicted_blocks_per_seq.is_cuda:
             p.max_evicted_blocks_hint = -1
         else:
-            p.max_evicted_blocks_hint = int(max(int(v) for v in evicted_blocks_per_seq))
+            p.max_evicted_blocks_hint = int(max(evicted_blocks_per_seq))
         p.schedule_path = int(self.schedule_path)
         p.sample_stride = int(self.sample_stride)
         capturing = torch.cuda.is_current_stream_capturing()
