@@ -10,7 +10,7 @@ OUT="$REPO/gpurun_out/pmc_$TAG"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $REPO/bench.py --config c3 --steps 4 --warmup 1 --no-cpu-baseline --no-adjacent --no-s0 --no-probe --no-other-configs --no-live-traffic $*"
+BENCH="python $REPO/bench.py --config c3 --steps 6 --warmup 1 --no-cpu-baseline --no-adjacent --no-s0 --no-probe --no-other-configs --no-live-traffic --no-parity-gate $*"
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" --output-format csv -- $BENCH > "$OUT/bench_fetch.json" 2> "$OUT/fetch.log"
 timeout 600 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" --output-format csv -- $BENCH > /dev/null 2> "$OUT/write.log"
 python - "$OUT" "$TAG" "$REPO" "$*" <<'PY'
@@ -22,6 +22,9 @@ def pmc(kind, counter):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
             agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    # (the first launch of a kernel is left out when there are several: the first step of a run sets up the
+    # tracked move table / output buffer with their one-time full fills -- the steady state is what is counted)
+    agg = {k: (v[1:] if len(v) >= 3 else v) for k, v in agg.items()}
     return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
 fetch, write = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
 line = json.loads(open(f"{out}/bench_fetch.json").read().strip().splitlines()[-1])

@@ -18,7 +18,7 @@ export TMPDIR=/tmp
 cd "$REPO"
 timeout 900 python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
 cd /tmp
-BENCH="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-adjacent --no-s0 --no-probe --no-engine-cache --no-other-configs --no-live-traffic"
+BENCH="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-adjacent --no-s0 --no-probe --no-engine-cache --no-other-configs --no-live-traffic --no-parity-gate"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" --output-format csv -- $BENCH > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/stats.log"
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" --output-format csv -- $BENCH > /dev/null 2> "$OUT/fetch.log"
 timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" --output-format csv -- $BENCH > /dev/null 2> "$OUT/write.log"
@@ -96,7 +96,7 @@ cp "$REPO/gpurun_out/${TAG}_c3_kernel_stats.csv" "$OUT/" 2>/dev/null
 "$REPO/tools/collect_c3_pmc.sh" "$TAG" > "$OUT/${TAG}_c3_pmc.txt" 2>&1
 cp "$REPO/gpurun_out/${TAG}_c3_pmc.json" "$OUT/" 2>/dev/null
 cd "$REPO"
-B="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-adjacent --no-s0 --no-engine-cache --no-other-configs --no-live-traffic"
+B="python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-adjacent --no-s0 --no-engine-cache --no-other-configs --no-live-traffic --no-parity-gate"
 for shape in perm decay oldest; do
   for keep in 0.5 0.125 0.015625; do
     [ "$shape" = oldest ] && [ "$keep" = 0.015625 ] && continue
