@@ -179,7 +179,7 @@ constexpr int WAVE_HEAD_MAX = 2048;                  // evictions a single wave 
 constexpr int LANE_HEAD_MAX = 32;                    // evictions a single lane walks serially
 
 template <int THREADS, int BITMAP_WORDS>
-__global__ __launch_bounds__(THREADS) void schedule_moves_heads_kernel(MovesArgs a) {
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void schedule_moves_heads_kernel(MovesArgs a) {
   constexpr int NWAVES = THREADS / WAVE;
   __shared__ uint32_t bitmap[BITMAP_WORDS];       // 64 KiB for long heads, 4 KiB for short ones (occupancy)
   __shared__ uint32_t wbitmap[NWAVES][WAVE_HEAD_MAX / 32];
