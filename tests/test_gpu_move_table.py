@@ -188,3 +188,27 @@ def test_compression_scheduler_workspace_is_tracked_and_exact_over_steps():
         np.testing.assert_array_equal(out.cache_moves.count.cpu().numpy(), want["cmc"], err_msg=f"step {step}")
         bad = np.nonzero((got != expect).any(axis=1))[0]
         assert bad.size == 0, f"step {step}: {bad.size} rows differ, first {bad[:5]}"
+
+
+@pytest.mark.parametrize("protected", [33, 0])
+def test_move_scheduler_by_eviction_count(protected):
+    """the three ways a head is walked (a lane up to 32 evictions, a wave up to 2048, the workgroup
+    beyond) at their borders, regular heads and the protected = 0 quirk (an empty tail slot
+    evictable), one head and several per workgroup, both instantiations"""
+    bs = 16
+    for L, H, seq_len in ((1, 1, 5001), (1, 1, 5008), (1, 1, 5016), (2, 3, 5001), (1, 2, 40001)):
+        st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs, seq_lens=[seq_len], seed=seq_len + L,
+                              protected=protected, spare_block_frac=0.05)
+        ds = hdev.upload(st, DEV, mode="per_sequence")
+        nblk = int(((st.context_lens.astype(np.int64) + bs - 1) // bs).sum())
+        for k in (1, 2, 3, 4, 5, 6, 127, 128, 129, 130, 131, 200, 257, nblk // 2, nblk - 3 * L * H):
+            k = int(k) * (L * H if k < 300 else 1)
+            if k <= 0 or k > nblk:
+                continue
+            want = oracle_pipeline(st, [k], mode="per_sequence")
+            eli, ekc, ebc, cmi, cmc = hdev.schedule(ds, st, [k])
+            np.testing.assert_array_equal(ekc.cpu().numpy(), want["ekc"], err_msg=f"{seq_len} {k}")
+            np.testing.assert_array_equal(cmc.cpu().numpy(), want["cmc"], err_msg=f"{seq_len} {k} counts")
+            np.testing.assert_array_equal(cmi.cpu().numpy(), want["cmi"], err_msg=f"{seq_len} {k} moves")
+        counts = sorted(set(int(c) for c in want["ekc"].reshape(-1)))
+        assert counts, counts
