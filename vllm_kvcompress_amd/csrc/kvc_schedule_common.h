@@ -1,0 +1,143 @@
+// kvc_schedule_common.h -- A3 schedule_evictions: the scratch layout every schedule shares, small device helpers
+// (one translation unit: included by kvc_schedule.hip in this order; see the overview there)
+#pragma once
+#include "kvc_common.h"
+#include "../../include/kvc_mi355x.h"
+
+namespace kvc {
+
+constexpr int RADIX = 256;
+
+struct SeqRec;
+struct SchedWs {
+  uint32_t* keys;        // [N]      order-preserving metric keys, index off_g + lambda
+  int32_t* chunk_phys;   // [N/bs]   physical block of logical chunk
+  uint32_t* hist;        // [G,256]  per-head digit histogram (re-zeroed by the scan)
+  uint32_t* cum;         // [4,G,256] inclusive cumulative counts of every round (select_emit reuses them)
+  uint32_t* less;        // [G]      keys strictly below the current prefix
+  uint32_t* eq;          // [G]      keys equal to T* (after the last round)
+  uint32_t* seq_prefix;  // [B]
+  int32_t* seq_k;        // [B]      chunks this sequence frees (k'), 0 = inactive
+  int32_t* seq_tmp;      // [3B]     F (finite chunks), Cn (all chunks), offset
+  // small-eviction schedule (section 7 below)
+  uint64_t* rec64;       // [G,KREC] per head: (key << 32 | physical slot) of every evictable key below the
+                         //          sequence's pivot; sorted ascending (canonical tie order) = the head's record
+  uint32_t* st_cnt;      // [G]      entries of that list (counts on beyond KREC: overflow)
+  uint32_t* st_def;      // [G]      masked / non-finite slots of the head's blocks
+  uint32_t* st_samp;     // [G]      sampled blocks of the head
+  uint32_t* st_claimed;  // [64 x 32] physical blocks that are logical blocks of the batch, sharded over 64 cache lines
+  struct SeqRec* st_seqrec;  // [B]  per sequence: position, protected window, pivot
+  uint32_t* head_fc;     // [2G]     per head: finite-threshold chunks, all chunks (stream_records)
+  uint32_t* bsample;     // [B, BR_CELLS] bracket schedule: the sample build_keys leaves behind (nullptr: none wanted)
+  uint32_t* bnonfin;     // [G] bracket schedule under the batch > 1 rule: build_keys counts the head's keys that are
+                         //     not evictable here (= st_samp; nullptr: not wanted)
+  const int32_t* bk;     // [B] bracket schedule: chunks a sequence frees -- the caller's k (k' = min(k, finite) is found
+                         //     on the way) or, under the batch > 1 rule, seq_k = k' itself
+  uint32_t* bthr;        // [N / bs] bracket schedule: per head (from its first chunk on) its listed thresholds, ascending
+  uint32_t* blist;       // [N / 8 + 32 G]  bracket schedule: per head the keys inside the sequence's bracket (then sorted)
+  uint32_t* fallback;    // [1]      != 0: the small-eviction schedule could not finish exactly
+  uint32_t* bar;         // [32+64]  single-launch fallback: phase stamps, then claim / done counters of its phases
+  const uint32_t* gate;  // general-path kernels run only if gate == nullptr or *gate != 0
+};
+
+constexpr int KREC = 256;   // record length of the small-eviction schedule (keys per head)
+
+__device__ __forceinline__ bool gated_off(const SchedWs& ws) { return ws.gate != nullptr && *ws.gate == 0u; }
+
+// bracket schedule (section 9): the bracket list of head g (its slots start at off_g) lives at
+// blist + off_g / BR_DIV + g * BR_PAD and holds an eighth of the head's slots plus BR_PAD entries,
+// BR_SORT_MAX at most (what one workgroup sorts in LDS); the lists of neighbours do not overlap
+constexpr int BR_DIV = 8;
+constexpr int BR_PAD = 32;
+constexpr uint32_t BR_SORT_MAX = 4096;
+__device__ __forceinline__ uint32_t bracket_cap(uint32_t head_slots) {
+  const uint32_t c = head_slots / BR_DIV + BR_PAD;
+  return c < BR_SORT_MAX ? c : BR_SORT_MAX;
+}
+__device__ __forceinline__ int64_t bracket_list_at(int64_t head_base, int g) {
+  return head_base / BR_DIV + (int64_t)g * BR_PAD;
+}
+// the bracket's sample: a sequence's slots in at most BR_CELLS cells of 2^k >= 4 slots (the four
+// slots a build_keys thread writes lie in one cell), one sampled slot per cell at a hashed place
+// inside it (no pattern of the layout aliases with the sample); build_keys leaves its key in
+// bsample[seq * BR_CELLS + cell]
+constexpr uint32_t BR_CELLS = 32768;
+// log2 of the cell size: the power of two (>= 4) that covers the sequence with at most BR_CELLS cells
+__device__ __forceinline__ int bracket_stride_log2(uint32_t seq_slots) {
+  const uint32_t per = (seq_slots + BR_CELLS - 1u) / BR_CELLS;
+  const int lg = per <= 1u ? 0 : 32 - __builtin_clz(per - 1u);
+  return lg < 2 ? 2 : lg;
+}
+__device__ __forceinline__ uint32_t bracket_cell_slot(uint32_t cell, uint32_t seq, int stride_log2) {
+  uint32_t x = (cell * 0x9E3779B1u) ^ ((seq + 0x7F4A7C15u) * 0x85EBCA77u);
+  x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;
+  return (cell << stride_log2) + (x & ((1u << stride_log2) - 1u));
+}
+
+__device__ __forceinline__ uint32_t nchunks_freed(uint32_t r, uint32_t hang, uint32_t bs) {
+  return r >= hang ? (r - hang) / bs + 1u : 0u;
+}
+// the same with the division as a shift when bs is a power of two (bs_shift >= 0): the scans do
+// four of these per lane and head, and a 32-bit division is ~40 instructions
+__device__ __forceinline__ uint32_t nchunks_freed_s(uint32_t r, uint32_t hang, uint32_t bs, int bs_shift) {
+  if (r < hang) return 0u;
+  return (bs_shift >= 0 ? (r - hang) >> bs_shift : (r - hang) / bs) + 1u;
+}
+
+// evicted_logical_indices as a buffer the caller keeps between calls (kvc_schedule_params.
+// eli_dirty_map): null everywhere except the leading entries of the head segments the last call wrote.
+// One bit per chunk of bs entries (head segments start at multiples of bs) says where; the owner of
+// the chunks [c0, c1) -- a head -- marks its first new_chunks chunks, clears the rest and, with
+// fill_old, writes null over what older calls left behind from entry keep_from on.  Words that
+// straddle the owner's ends are shared with the neighbouring heads, who do the same to their bits
+// at the same time: atomics there, plain accesses inside.
+__device__ __forceinline__ void eli_dirty_update(uint32_t* map, int32_t* eli, int64_t c0, int64_t c1, int64_t new_chunks,
+                                                 int64_t keep_from, int bs, int32_t null_value, bool fill_old,
+                                                 int tid, int nthreads) {
+  if (c0 >= c1) return;
+  const int64_t w0 = c0 >> 5, w1 = (c1 - 1) >> 5;
+  const int64_t cn = c0 + new_chunks;
+  for (int64_t w = w0 + tid; w <= w1; w += nthreads) {
+    const int64_t lo = max(c0, w << 5), hi = min(c1, (w + 1) << 5);
+    const uint32_t mask = (hi - lo >= 32) ? 0xFFFFFFFFu : (((1u << (hi - lo)) - 1u) << (lo & 31));
+    const int64_t nh = min(hi, cn);
+    const uint32_t fresh = nh > lo ? ((nh - lo >= 32) ? 0xFFFFFFFFu : (((1u << (nh - lo)) - 1u) << (lo & 31))) : 0u;
+    uint32_t old;
+    if (mask == 0xFFFFFFFFu) {
+      old = map[w];
+      if (old != fresh) map[w] = fresh;
+    } else {
+      old = atomicAnd(&map[w], ~mask) & mask;
+      if (fresh) atomicOr(&map[w], fresh);
+    }
+    if (!fill_old) continue;
+    while (old) {
+      const int bit = __ffs((int)old) - 1;
+      old &= old - 1u;
+      const int64_t eb = max(((w << 5) + bit) * (int64_t)bs, keep_from), ee = (((w << 5) + bit) + 1) * (int64_t)bs;
+      for (int64_t e = eb; e < ee; ++e) eli[e] = null_value;
+    }
+  }
+}
+
+// wave-aggregated shared-memory histogram add: metric keys are often degenerate in their
+// top digits (all lanes hit one bin), which would serialise 64 LDS atomics; up to two
+// leader-elected groups are folded into one atomic each, the rest go one by one.
+// (also used on global memory with digit = head * 256 + digit)
+__device__ __forceinline__ void hist_add(uint32_t* hist, bool valid, uint32_t digit) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const unsigned long long act = __ballot(valid);
+    if (!act) return;
+    const int leader = __ffsll((long long)act) - 1;
+    const uint32_t d0 = __shfl(digit, leader, 64);
+    const bool same = valid && digit == d0;
+    const unsigned long long grp = __ballot(same);
+    if (lane_id() == leader) atomicAdd(&hist[d0], (uint32_t)__popcll(grp));
+    valid = valid && !same;
+  }
+  if (valid) atomicAdd(&hist[digit], 1u);
+}
+
+
+}  // namespace kvc
