@@ -100,6 +100,7 @@ def test_full_size_oracle_parity(name, T, bs, cdtype, keep, mode):
     if e == 2:
         k, v = k.view(torch.float16), v.view(torch.float16)
     ds = hdev.upload(st, DEV, mode=mode)
+    ds.cm.schedule_path = 0            # (the automatic choice is what the bench line runs on: KVC_SCHEDULE_PATH must not decide)
     g_eli, g_ekc, g_ebc, g_cmi, g_cmc = hdev.schedule(ds, st, evicted)
     how = ds.cm.last_schedule_path()
     ops.execute_cache_moves(k, v, ds.cm.metrics, ds.cm.token_positions, g_cmi, g_cmc, ds.evicted_kv_offsets, 1, 16)
