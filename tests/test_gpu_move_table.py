@@ -39,7 +39,7 @@ def _sub_state(st, sel):
         seq_positions=np.ascontiguousarray(st.seq_positions[sel]), protected=[st.protected[i] for i in sel])
 
 
-@pytest.mark.parametrize("bs,rows_mode", [(16, "large"), (32, "large"), (16, "odd"), (8, "tight")])
+@pytest.mark.parametrize("bs,rows_mode", [(16, "large"), (32, "large"), (16, "odd"), (8, "tight"), (16, "short")])
 def test_tracked_table_holds_what_the_reference_table_holds(bs, rows_mode):
     L, H = 3, 4
     seq_lens = [700, 260, 1500, 90, 410, 1100]
@@ -48,7 +48,8 @@ def test_tracked_table_holds_what_the_reference_table_holds(bs, rows_mode):
     ds = hdev.upload(st, DEV, mode="per_sequence")
     ctx_full, bt_full = ds.context_lens, ds.block_tables
     n_all = st.total_slots
-    rows = {"large": n_all + 5000, "odd": n_all + 13, "tight": n_all}[rows_mode]
+    # ("short": a table smaller than the largest batch -- moves beyond its end are dropped, as in the reference's kernel)
+    rows = {"large": n_all + 5000, "odd": n_all + 13, "tight": n_all, "short": n_all - 9001}[rows_mode]
     table = ops.track_move_table(torch.empty((rows, 2), dtype=torch.int32, device=DEV))
     table.fill_(-3)                                      # junk: the first call must clear all of it
     rng = np.random.default_rng(bs)
@@ -75,6 +76,9 @@ def test_tracked_table_holds_what_the_reference_table_holds(bs, rows_mode):
         want = oracle_pipeline(sub, evicted, mode="per_sequence")
         if step in (11, 37):                              # somebody else writes to the table through torch
             table[int(rng.integers(0, rows))] = 123
+        if step in (25, 26):                              # ... or the bare op does (no fill: rows the map does not know)
+            junk_cmc = torch.empty_like(ekc_prev)
+            ops._schedule_t1_cache_moves(table, junk_cmc, *prev_args, zero_fill=False)
         sub_ds = hdev.DeviceState(cm=ds.cm, context_lens=ctx_full[:, sel].contiguous(),
                                   block_tables=bt_full[:, sel].contiguous(),
                                   hanging_token_count=torch.from_numpy(sub.hanging_token_count).to(DEV),
@@ -84,6 +88,7 @@ def test_tracked_table_holds_what_the_reference_table_holds(bs, rows_mode):
                                                  sub_ds.hanging_token_count, sub_ds.evicted_kv_offsets, sub.protected,
                                                  total_slots=sub.total_slots)
         cmc = torch.empty_like(ekc)
+        ekc_prev, prev_args = ekc, (eli, ekc, sub_ds.evicted_kv_offsets, sub_ds.block_tables, sub_ds.context_lens, bs)
         rec = ops._tracked(table)
         modes_seen.add(2 if (rec.dirty_map is not None and rec.version == table._version and rec.block_size == bs) else 1)
         ops.schedule_cache_moves(table, cmc, eli, ekc, sub_ds.evicted_kv_offsets, sub_ds.block_tables,

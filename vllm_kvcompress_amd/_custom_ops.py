@@ -184,7 +184,10 @@ def _schedule_t1_cache_moves(cache_moves_idx, cache_moves_count, evicted_logical
     dev = cache_moves_idx.device
     rows, bs = cache_moves_idx.shape[0], int(block_size)
     mode, dmap, dmap_bytes = (1 if zero_fill else 0), None, 0
-    rec = _tracked(cache_moves_idx) if zero_fill else None
+    rec = _tracked(cache_moves_idx)
+    if rec is not None and not zero_fill:
+        rec.version = -1                  # the bare op leaves rows behind that the map does not know: full fill next time
+        rec = None
     if rec is not None and bs >= 1:
         dmap_bytes = int(lib.kvc_cache_moves_dirty_map_bytes(rows, bs))
         known = (rec.dirty_map is not None and rec.block_size == bs and rec.dirty_map.numel() >= dmap_bytes
