@@ -216,6 +216,8 @@ def parity_gate(args, st, ds, evicted, mode, gpu, snap, k_cache, v_cache, wm, wp
     from oracle import kvc_oracle_c as orc_c
     N = st.total_slots
     if N > PARITY_ORACLE_MAX_SLOTS:
+        if mode == "per_sequence" and st.num_seqs > 1 and not lean:
+            return parity_gate_sampled(args, st, evicted, gpu, k_cache, v_cache, wm, wp)
         return {"bit_exact": None, "skipped": f"{N} candidate slots: the oracle's sorts take minutes at this size "
                                               "(this shape is parity-tested at oracle sizes in tests/)"}
     t0 = time.perf_counter()
@@ -302,6 +304,87 @@ def parity_gate(args, st, ds, evicted, mode, gpu, snap, k_cache, v_cache, wm, wp
     out.update({"bit_exact": not bad, "compared": compared, "mismatched": bad,
                 "seconds": time.perf_counter() - t0})
     return out
+
+
+def parity_gate_sampled(args, st, evicted, gpu, k_cache, v_cache, wm, wp, num_sampled=8):
+    """The gate for a batch too large for the oracle's sorts (configs[2]: 256 sequences, 270 M slots).
+    In per_sequence mode every sequence is scheduled as if alone, so the oracle runs on a sub-batch of
+    `num_sampled` sequences spread over the batch and every output of THEIR heads -- evicted indices,
+    counts, move rows -- must equal the corresponding piece of the full batch's outputs bit for bit;
+    the compaction of the WHOLE batch is checked on the device (K / V rows of every moved slot equal
+    their sources; metrics / positions against torch's own scatter of the move list)."""
+    import torch
+    from oracle import kvc_oracle as orc
+    from oracle import kvc_oracle_c as orc_c
+    from vllm_kvcompress_amd.harness import synth
+    t0 = time.perf_counter()
+    bs, L, H, B = st.block_size, st.num_layers, st.num_kv_heads, st.num_seqs
+    sel = sorted(set(int(x) for x in np.linspace(0, B - 1, num_sampled).round()))
+    ctx = np.ascontiguousarray(st.context_lens[:, sel, :])
+    offs_s = synth.kv_offsets(ctx, bs)
+    hang_s = synth.hanging_tokens(ctx.transpose(1, 0, 2), bs)
+    eli, ekc, ebc = orc.schedule_evictions(
+        metrics=st.metrics, token_positions=st.token_positions, seq_index_by_block=st.seq_index_by_block,
+        layer_index_by_block=st.layer_index_by_block, head_index_by_block=st.head_index_by_block,
+        logical_block_num_by_block=st.logical_block_num_by_block, block_size=bs, num_layers=L, num_kv_heads=H,
+        seq_indices=[st.seq_indices[i] for i in sel], seq_positions=np.ascontiguousarray(st.seq_positions[sel]),
+        evicted_blocks_per_seq=[evicted[i] for i in sel], context_lens=ctx, hanging_token_count=hang_s,
+        evicted_kv_offsets=offs_s, num_protected=[st.protected[i] for i in sel], mode="per_sequence")
+    n_s = int(((ctx.astype(np.int64) + bs - 1) // bs).sum()) * bs
+    cmi = np.zeros((n_s, 2), np.int32)
+    cmc = np.zeros(ekc.shape, np.int32)
+    orc_c.set_threads(min(os.cpu_count() or 1, orc_c.max_threads()))
+    orc_c.schedule_cache_moves(cmi, cmc, eli, ekc, offs_s, np.ascontiguousarray(st.block_tables[:, sel]), ctx, bs)
+    dev = gpu["eli"].device
+    compared, bad = [], []
+
+    def cmp(name, got, want):
+        compared.append(name)
+        if tuple(got.shape) != tuple(want.shape) or not np.array_equal(got, want):
+            bad.append(name)
+
+    idx = torch.tensor(sel, device=dev)
+    cmp("evicted_kv_count", gpu["ekc"][idx].cpu().numpy(), ekc)
+    cmp("evicted_block_count", gpu["ebc"][idx].cpu().numpy(), ebc)
+    cmp("cache_moves_count", gpu["cmc"][idx].cpu().numpy(), cmc)
+    # the heads' segments: [off, off + nblk * bs) in the full batch's lists against the sub-batch's
+    lens = (((ctx.astype(np.int64) + bs - 1) // bs) * bs).transpose(1, 0, 2).reshape(-1)          # (b, l, h) order
+    off_full = st.evicted_kv_offsets[sel].reshape(-1).astype(np.int64)
+    off_sub = offs_s.reshape(-1).astype(np.int64)
+    start = np.cumsum(lens) - lens
+    within = np.arange(int(lens.sum())) - np.repeat(start, lens)
+    rows_full = torch.from_numpy(np.repeat(off_full, lens) + within).to(dev)
+    rows_sub = np.repeat(off_sub, lens) + within
+    cmp("evicted_logical_indices", gpu["eli"][rows_full].cpu().numpy(), eli[rows_sub])
+    cmp("cache_moves_idx", gpu["cmi"][rows_full].cpu().numpy(), cmi[rows_sub])
+    # the compaction, all sequences, on the device
+    cnt = gpu["cmc"].reshape(-1).long()
+    o = torch.from_numpy(st.evicted_kv_offsets.reshape(-1).astype(np.int64)).to(dev)
+    st_ = torch.cumsum(cnt, 0) - cnt
+    mrows = torch.repeat_interleave(o - st_, cnt) + torch.arange(int(cnt.sum()), device=dev)
+    mv = gpu["cmi"][mrows].long()
+    it = torch.uint8 if k_cache.element_size() == 1 else torch.int16
+    kb, vb = k_cache.view(it), v_cache.view(it)
+    ok_kv = True
+    for lo in range(0, mv.shape[0], 1 << 20):
+        d, s_ = mv[lo:lo + (1 << 20), 0], mv[lo:lo + (1 << 20), 1]
+        ok_kv &= bool(torch.equal(kb[d // bs, :, d % bs, :], kb[s_ // bs, :, s_ % bs, :]))
+        ok_kv &= bool(torch.equal(vb[d // bs, :, d % bs], vb[s_ // bs, :, s_ % bs]))
+    compared.append("k_cache/v_cache rows of every moved slot == their sources (on the device)")
+    if not ok_kv:
+        bad.append("k_cache/v_cache moved rows")
+    m2, p2 = torch.from_numpy(st.metrics).to(dev), torch.from_numpy(st.token_positions).to(dev)
+    m2.view(-1)[mv[:, 0]] = m2.view(-1)[mv[:, 1]]
+    p2.view(-1)[mv[:, 0]] = p2.view(-1)[mv[:, 1]]
+    compared += ["kv_metrics", "kv_position"]
+    if not torch.equal(m2, wm): bad.append("kv_metrics")
+    if not torch.equal(p2, wp): bad.append("kv_position")
+    return {"workload": "the timed workload itself", "mode": "per_sequence", "bit_exact": not bad,
+            "sampled_sequences": sel,
+            "what": f"the oracle on a sub-batch of {len(sel)} of the {B} sequences (per_sequence: a sequence's schedule does not "
+                    "depend on the others): every output of their heads against the full batch's; the compaction of all "
+                    "sequences checked on the device",
+            "compared": compared, "mismatched": bad, "seconds": time.perf_counter() - t0}
 
 
 # --------------------------------------------------------------------------- roofline helpers
