@@ -319,6 +319,7 @@ def parity_gate_sampled(args, st, evicted, gpu, k_cache, v_cache, wm, wp, num_sa
     from vllm_kvcompress_amd.harness import synth
     t0 = time.perf_counter()
     bs, L, H, B = st.block_size, st.num_layers, st.num_kv_heads, st.num_seqs
+    num_sampled = max(1, min(num_sampled, PARITY_ORACLE_MAX_SLOTS // max(1, st.total_slots // B)))   # (seconds of oracle)
     sel = sorted(set(int(x) for x in np.linspace(0, B - 1, num_sampled).round()))
     ctx = np.ascontiguousarray(st.context_lens[:, sel, :])
     offs_s = synth.kv_offsets(ctx, bs)
