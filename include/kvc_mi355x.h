@@ -260,6 +260,13 @@ typedef struct kvc_schedule_params {
                                                * of that launch wait for work, not for workgroups, so a grid
                                                * that is not resident at once (tests force one) only runs
                                                * slower. */
+  int32_t uniform_evict;                      /* ABI version 4.  != 0: the reference's other selection rule
+                                               * (metrics.py:639-666, `uniform_evict=True`; its scheduler never
+                                               * passes it): every head of sequence i frees
+                                               * evicted_blocks_per_seq[i] / (L*H) chunks -- its own lowest --
+                                               * at most its finite-threshold chunks (the reference asserts
+                                               * they are finite, and needs heads of equal length for a
+                                               * reshape; neither is required here). */
   uint32_t* eli_dirty_map;                    /* ABI version 4, optional (NULL: none).  The small-eviction schedule
                                                * writes a handful of indices per head and then pads 4 B per
                                                * candidate slot with null_value -- 1.08 GB per decode step at 256
@@ -309,7 +316,8 @@ enum {
   KVC_WHY_COUPLED_BATCH = 7,   /* mode 0 (the reference's batch > 1 rule) over more than 256 sequences */
   KVC_WHY_INDEX_RANGE = 8,     /* > 65535 sequences, or >= 2^32 slots */
   KVC_WHY_SMALL_BATCH = 9,     /* bracket: < 64 Ki slots per sequence or < 64 blocks per head (digit rounds are as fast) */
-  KVC_WHY_EMPTY = 10           /* nothing to schedule */
+  KVC_WHY_EMPTY = 10,          /* nothing to schedule */
+  KVC_WHY_UNIFORM = 11         /* uniform_evict: its own three launches */
 };
 int32_t kvc_schedule_evictions_plan_reason(const kvc_schedule_params* p);
 /* 1 if a call with these parameters builds its keys through block_tables (see there) */

@@ -54,8 +54,11 @@ def main():
         B = int(rng.integers(1, 5))
         seq_lens = [int(rng.integers(2, 12 * bs + 8)) for _ in range(B)]
         prot = [int(rng.integers(1, 2 * bs + 2)) for _ in range(B)]
+        # (a quarter of the cases on the reference's other selection rule, uniform_evict: needs heads of
+        # equal length, i.e. an uncompressed state)
+        uniform = bool(rng.random() < 0.25)
         st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs, seq_lens=seq_lens,
-                              seed=seed, protected=prot, compressed=bool(rng.random() < 0.5))
+                              seed=seed, protected=prot, compressed=bool(rng.random() < 0.5) and not uniform)
         nblk = ((st.context_lens.astype(np.int64) + bs - 1) // bs).sum(0).sum(-1)
         evicted = [int(rng.integers(0, int(x) + 1)) for x in nblk]
         kw = {}
@@ -67,6 +70,8 @@ def main():
         elif r < 0.6:
             kw.update(bias=(rng.normal(size=(L, H, 3)) * 20).astype(np.float32),
                       position_bins=np.array([0, 5, 17], dtype=np.int32), bias_weight=0.5)
+        if uniform:
+            kw["uniform_evict"] = True
         try:
             eli, ekc, ebc = gg.run_reference_schedule(met, st, evicted, **kw)
         except AssertionError:

@@ -60,7 +60,7 @@ def import_reference():
 
 
 def run_reference_schedule(met, st: synth.PagedState, evicted_blocks, *, use_average=False,
-                           num_sinks=0, bias=None, position_bins=None, bias_weight=0.0):
+                           num_sinks=0, bias=None, position_bins=None, bias_weight=0.0, uniform_evict=False):
     import torch
     L, H, bs = st.num_layers, st.num_kv_heads, st.block_size
     with contextlib.redirect_stdout(io.StringIO()):
@@ -85,6 +85,7 @@ def run_reference_schedule(met, st: synth.PagedState, evicted_blocks, *, use_ave
             torch.from_numpy(st.hanging_token_count.copy()),
             torch.from_numpy(st.evicted_kv_offsets.copy()),
             list(st.protected),
+            uniform_evict=uniform_evict,
         )
     return eli.numpy().astype(np.int32), ekc.numpy().astype(np.int32), ebc.numpy().astype(np.int32)
 
@@ -184,6 +185,14 @@ def case_grid():
                   seq_lens=[2100, 2500], seed=32, protected=[32, 17]), "uneven", dict(hd=16)))
     cases.append(("b1_bs32_bulk64k_compressed", dict(num_layers=2, num_kv_heads=8, block_size=32,
                   seq_lens=[9000], seed=33, protected=40, compressed=True), "mid", dict(hd=16)))
+    # the reference's other selection rule, uniform_evict (metrics.py:639-666: the same number of chunks
+    # from every head; heads of equal length, i.e. prefill states)
+    cases.append(("b1_bs4_uniform", dict(num_layers=2, num_kv_heads=2, block_size=4,
+                  seq_lens=[41], seed=41, protected=3), "mid", dict(uniform=True)))
+    cases.append(("b2_bs16_uniform", dict(num_layers=2, num_kv_heads=4, block_size=16,
+                  seq_lens=[300, 171], seed=42, protected=[32, 5]), "uneven", dict(uniform=True, hd=16)))
+    cases.append(("b1_bs16_uniform_bulk64k", dict(num_layers=4, num_kv_heads=8, block_size=16,
+                  seq_lens=[2100], seed=43, protected=32), "mid", dict(uniform=True, hd=16)))
     return cases
 
 
@@ -243,6 +252,8 @@ def main():
             sched_kw["use_average"] = True
         if extra.get("num_sinks"):
             sched_kw["num_sinks"] = extra["num_sinks"]
+        if extra.get("uniform"):
+            sched_kw["uniform_evict"] = True
         eli, ekc, ebc = run_reference_schedule(met, st, evicted, **sched_kw)
         # caches: tiny head dim for the small cases; every element distinct is not
         # needed for bitwise parity -- random 16-bit patterns
@@ -256,6 +267,7 @@ def main():
             use_average=np.int32(bool(extra.get("use_average"))),
             num_sinks=np.int32(extra.get("num_sinks", 0)),
             bias_weight=np.float32(sched_kw.get("bias_weight", 0.0)),
+            uniform_evict=np.int32(bool(extra.get("uniform"))),
             ref_evicted_logical_indices=eli, ref_evicted_kv_count=ekc,
             ref_evicted_block_count=ebc,
             cache_seed=np.int64(cache_seed), head_size=np.int32(hd),

@@ -89,10 +89,17 @@ def schedule_evictions(
     context_lens, hanging_token_count, evicted_kv_offsets, num_protected,
     use_average=False, num_sinks=0,
     bias=None, position_bins=None, bias_weight=0.0,
-    mode="reference",
+    mode="reference", uniform_evict=False,
 ):
     """Returns (evicted_logical_indices [N] i32, evicted_kv_count [B,L,H] i32,
     evicted_block_count [B,L,H] i32).
+
+    uniform_evict        the reference's other selection rule (metrics.py:639-666; its scheduler
+                         never passes it, scheduler.py:492-501): every head of sequence i frees
+                         evicted_blocks_per_seq[i] // (L*H) chunks -- its own lowest ones --
+                         instead of the sequence's lowest chunks wherever they lie.  The
+                         reference needs the heads of a sequence to hold equally many blocks
+                         (a reshape) and asserts the freed thresholds finite.
 
     mode="reference"     bit-exact to the reference including its batch>1
                          inf-count quirk (metrics.py:718-721).
@@ -162,6 +169,17 @@ def schedule_evictions(
     seq_sorted_thr = thr[corder]
     keep_mask_sorted = np.zeros(nchunks, dtype=bool)             # True = NOT evicted
     offset = 0
+    if uniform_evict:                                            # metrics.py:639-666
+        keep_chunk = np.zeros(nchunks, dtype=bool)               # chunks are in (head, metric) order here
+        for i, k in enumerate(evicted_blocks_per_seq):
+            per_head = max(k, 0) // (L * H)                      # :649
+            end_offset = offset + int(total_blocks_per_seq[i])
+            assert (end_offset - offset) % (L * H) == 0, "uniform_evict: heads of unequal length (the reference's reshape fails)"
+            cur = keep_chunk[offset:end_offset].reshape(L * H, -1)
+            cur[:, per_head:] = True                             # :656
+            assert np.all(thr[offset:end_offset].reshape(L * H, -1)[:, :per_head] < INF32)   # :660
+            offset = end_offset
+        evicted_blocks_per_seq = []                              # (the variable-rate loop below is the else branch)
     for i, k in enumerate(evicted_blocks_per_seq):
         end_offset = offset + int(total_blocks_per_seq[i])
         un = offset + k
@@ -176,8 +194,9 @@ def schedule_evictions(
         keep_mask_sorted[un:end_offset] = True                   # :723
         assert np.all(seq_sorted_thr[offset:un] < INF32)         # :725
         offset = end_offset
-    keep_chunk = np.zeros(nchunks, dtype=bool)
-    keep_chunk[corder] = keep_mask_sorted                        # :755 (remap)
+    if not uniform_evict:
+        keep_chunk = np.zeros(nchunks, dtype=bool)
+        keep_chunk[corder] = keep_mask_sorted                    # :755 (remap)
     sorted_lam[keep_chunk, :] = MAX_INT
     flat = sorted_lam.reshape(-1).astype(np.int32)
 

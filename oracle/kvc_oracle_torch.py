@@ -37,7 +37,7 @@ def schedule_evictions(*, metrics, token_positions, seq_index_by_block, layer_in
                        head_index_by_block, logical_block_num_by_block, block_size, num_layers,
                        num_kv_heads, seq_indices, seq_positions, evicted_blocks_per_seq,
                        context_lens, hanging_token_count, evicted_kv_offsets, num_protected,
-                       use_average=False, num_sinks=0, mode="reference"):
+                       use_average=False, num_sinks=0, mode="reference", uniform_evict=False):
     """NumPy arrays in (the layouts of harness/synth.PagedState), NumPy arrays out:
     (evicted_logical_indices [N] i32, evicted_kv_count [B,L,H] i32, evicted_block_count [B,L,H] i32).
     Bias is not restated here (the bench never uses it; kvc_oracle.py covers it)."""
@@ -85,6 +85,15 @@ def schedule_evictions(*, metrics, token_positions, seq_index_by_block, layer_in
     # ---- 3. per-sequence selection                                           :604-755
     s_lam = lam.reshape(-1)[order].view(-1, bs).clone()
     blocks_per_seq = ((t(np.ascontiguousarray(context_lens)).long() + bs - 1) // bs).sum(0).sum(-1)
+    if uniform_evict:                                                          # :639-666 (no chunk sorts)
+        offset = 0
+        for i, k in enumerate(int(x) for x in np.asarray(evicted_blocks_per_seq).reshape(-1)):
+            end = offset + int(blocks_per_seq[i])
+            cur = s_lam[offset:end].reshape(L * H, -1, bs)                    # (heads of equal length)
+            cur[:, max(k, 0) // (L * H):] = MAX_INT
+            s_lam[offset:end] = cur.view(-1, bs)
+            offset = end
+        evicted_blocks_per_seq = []
     v_thr, by_thr = thr.sort()                                                 # :669
     chunk_seq = seq_of[order.view(-1, bs)[:, 0] // bs][by_thr]                 # :670-677
     _, by_seq = chunk_seq.sort(stable=True)                                    # :678
@@ -99,7 +108,8 @@ def schedule_evictions(*, metrics, token_positions, seq_index_by_block, layer_in
         un -= int((seq_thr[lo:un] == float("inf")).sum())
         seq_lam[un:end] = MAX_INT
         offset = end
-    s_lam[seq_chunks] = seq_lam                                                # :755
+    if not uniform_evict:
+        s_lam[seq_chunks] = seq_lam                                            # :755
     flat = s_lam.reshape(-1).numpy()
     # ---- count_block_evictions + KV counts                                   :773-792
     ebc = np.empty_like(evicted_kv_offsets, dtype=np.int32)

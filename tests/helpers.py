@@ -35,6 +35,8 @@ def sched_kwargs(g):
     if "bias" in g:
         kw.update(bias=g["bias"], position_bins=g["position_bins"],
                   bias_weight=float(g["bias_weight"]))
+    if "uniform_evict" in g and int(g["uniform_evict"]):
+        kw.update(uniform_evict=True)
     return kw
 
 

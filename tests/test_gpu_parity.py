@@ -38,9 +38,9 @@ def _state_from_golden(g):
         protected=[int(p) for p in g["protected"]])
 
 
-def _gpu_pipeline(st, evicted, k_np=None, v_np=None, mode="reference", **kw):
+def _gpu_pipeline(st, evicted, k_np=None, v_np=None, mode="reference", uniform_evict=False, **kw):
     ds = hdev.upload(st, DEV, mode=mode, **kw)
-    eli, ekc, ebc, cmi, cmc = hdev.schedule(ds, st, evicted)
+    eli, ekc, ebc, cmi, cmc = hdev.schedule(ds, st, evicted, uniform_evict=uniform_evict)
     out = dict(eli=eli.cpu().numpy(), ekc=ekc.cpu().numpy(), ebc=ebc.cpu().numpy(),
                cmi=cmi.cpu().numpy(), cmc=cmc.cpu().numpy())
     if k_np is not None:
@@ -63,6 +63,8 @@ def test_golden_end_to_end(name):
     if "bias" in g:
         kw.update(bias=g["bias"], position_bins=g["position_bins"],
                   bias_weight=float(g["bias_weight"]))
+    if "uniform_evict" in g and int(g["uniform_evict"]):
+        kw.update(uniform_evict=True)          # the reference's other selection rule (metrics.py:639-666)
     k, v = golden_caches(g)
     out = _gpu_pipeline(st, g["evicted_blocks_per_seq"], k, v, **kw)
     np.testing.assert_array_equal(out["eli"], g["ref_evicted_logical_indices"])
@@ -118,6 +120,37 @@ def test_random_states_vs_oracle(case, mode):
         got = _gpu_pipeline(st, evicted, k, v, mode=mode)
         for key in ("eli", "ekc", "ebc", "cmi", "cmc", "k", "v", "metrics", "positions"):
             np.testing.assert_array_equal(got[key], want[key], err_msg=f"{key} seed={seed}")
+
+
+@pytest.mark.parametrize("L,H,bs,seq_lens,prot", [(2, 2, 4, [37], 2), (3, 2, 16, [300, 171, 90], [32, 5, 17]),
+                                                  (1, 1, 16, [9000], 3), (2, 4, 32, [700, 40], 33), (2, 2, 1, [40, 9], 2)])
+def test_uniform_evict_vs_oracle(L, H, bs, seq_lens, prot):
+    """uniform_evict (metrics.py:639-666): the same number of chunks from every head, random prefill
+    states against the oracle, from nothing to every finite-threshold chunk; heads of unequal length
+    (which the reference's reshape cannot take) against the per-head definition"""
+    st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs, seq_lens=seq_lens, seed=len(seq_lens) + bs,
+                          protected=prot)
+    ds = hdev.upload(st, DEV)
+    TH = L * H
+    for frac in (0.0, 0.3, 0.6, 0.9):
+        evicted = [int(x * frac) // TH * TH + (TH - 1 if frac else 0) for x in _limit(st, 1.0)]   # (k need not divide by L*H)
+        want = oracle_pipeline(st, evicted, uniform_evict=True)
+        eli, ekc, ebc, cmi, cmc = hdev.schedule(ds, st, evicted, uniform_evict=True)
+        assert ds.cm.last_schedule_path() == "general" and "uniform_evict" in ds.cm.last_schedule_reason
+        for key, got in (("eli", eli), ("ekc", ekc), ("ebc", ebc), ("cmi", cmi), ("cmc", cmc)):
+            np.testing.assert_array_equal(got.cpu().numpy(), want[key], err_msg=f"{key} frac={frac}")
+        assert int(ebc.sum()) == sum(e // TH * TH for e in evicted)
+    # a compressed state: heads of different lengths (the reference's reshape cannot take them) -- every
+    # head frees min(k / (L*H), its finite-threshold chunks)
+    st2 = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs, seq_lens=seq_lens, seed=7, protected=prot,
+                           compressed=True)
+    ds2 = hdev.upload(st2, DEV)
+    B = len(seq_lens)
+    finite = hdev.schedule(ds2, st2, [10 ** 6] * B, uniform_evict=True)[2]
+    two = hdev.schedule(ds2, st2, [TH * 2 + TH - 1] * B, uniform_evict=True)[2]
+    assert torch.equal(two, torch.clamp(finite, max=2))
+    nblk = (ds2.context_lens + bs - 1) // bs
+    assert bool((finite <= nblk.permute(1, 0, 2)).all()) and int(finite.sum()) > 0
 
 
 def test_overask_and_zero_evictions():

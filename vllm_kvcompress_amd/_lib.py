@@ -19,7 +19,7 @@ MAX_INT = 2147483000  # reference vllm/kvcompress/metrics.py:12
 # KVC_WHY_* of include/kvc_mi355x.h (kvc_schedule_evictions_plan_reason)
 WHY = {0: "taken", 1: "forced_path", 2: "block_size", 3: "hint_unknown", 4: "bulk_eviction",
        5: "heads_per_seq", 6: "thresholds_lds", 7: "coupled_batch", 8: "index_range",
-       9: "small_batch", 10: "empty"}
+       9: "small_batch", 10: "empty", 11: "uniform_evict"}
 
 
 class KvcScheduleParams(ctypes.Structure):
@@ -43,6 +43,7 @@ class KvcScheduleParams(ctypes.Structure):
         ("block_tables", c_void_p), ("seq_index_of_slot", c_void_p),
         ("max_num_seqs", c_int32), ("block_tables_width", c_int32),
         ("schedule_path", c_int32), ("sample_stride", c_int32), ("fallback_grid", c_int32),
+        ("uniform_evict", c_int32),
         ("eli_dirty_map", c_void_p),
         ("evicted_logical_indices", c_void_p), ("evicted_kv_count", c_void_p),
         ("evicted_block_count", c_void_p),

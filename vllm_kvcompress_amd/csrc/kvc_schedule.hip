@@ -164,6 +164,7 @@ static int topk_plan(const kvc_schedule_params& p, int& p2_out, int& sshift) {
   if (G < 1 || p.total_slots <= 0) return KVC_WHY_EMPTY;
   const int LH = p.num_layers * p.num_kv_heads;
   const int bsz = p.block_size;
+  if (p.uniform_evict) return KVC_WHY_UNIFORM;
   if (p.schedule_path == 1 || p.schedule_path == 4) return KVC_WHY_FORCED_PATH;
   if (!(bsz == 8 || bsz == 16 || bsz == 32)) return KVC_WHY_BLOCK_SIZE;
   // (per-head tables of the pivot kernel in LDS; a record entry packs the physical slot into 32 bits)
@@ -197,6 +198,7 @@ static int bracket_why(const kvc_schedule_params& p) {
   const int LH = p.num_layers * p.num_kv_heads;
   const int64_t G = (int64_t)p.num_seqs * LH;
   if (G < 1 || p.total_slots <= 0 || p.block_size < 1) return KVC_WHY_EMPTY;
+  if (p.uniform_evict) return KVC_WHY_UNIFORM;
   if (p.schedule_path != 0 && p.schedule_path != 4) return KVC_WHY_FORCED_PATH;
   // (the reference's batch > 1 rule: as many sequences as the single-launch fallback has tables for)
   if (p.mode == 0 && p.num_seqs > kvc::FB_MAX_COUPLED) return KVC_WHY_COUPLED_BATCH;
@@ -517,6 +519,23 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     const unsigned vgrid = (unsigned)fallback_grid();
     hipLaunchKernelGGL(fallback_general_kernel, dim3(p.fallback_grid > 0 ? (unsigned)p.fallback_grid : vgrid), dim3(256), 0, s,
                        p, ws, 0, z16, zv, 1, vgrid);
+    return check_launch("schedule_evictions");
+  }
+  if (p.uniform_evict) {
+    // ---- the reference's uniform_evict rule (section 5b): keys, one histogram round (the heads'
+    // evictable keys), the per-head counts, select + emit with every head's own select
+    hipLaunchKernelGGL(hist_round_kernel, dim3(htiles), dim3(256), 0, s, p, ws, 0);
+    hipLaunchKernelGGL(uniform_counts_kernel, dim3((G + 3) / 4), dim3(256), 0, s, p, ws);
+    const int64_t avg = p.total_slots / G;
+    int64_t want = (avg + avg / 4 + 2047) / 2048 * 2048;
+    const int lds_cap = (int)(want < 2048 ? 2048 : (want > 32768 ? 32768 : want));
+    if (avg <= 8192) {
+      hipLaunchKernelGGL(select_emit_kernel<256>, dim3(G), dim3(256), (size_t)lds_cap * 4, s, p, ws, lds_cap, 2);
+    } else {
+      static std::atomic<uint64_t> long_done_u{0};
+      allow_dynamic_lds(reinterpret_cast<const void*>(select_emit_kernel<1024>), 32768 * 4, long_done_u);
+      hipLaunchKernelGGL(select_emit_kernel<1024>, dim3(G), dim3(1024), (size_t)lds_cap * 4, s, p, ws, lds_cap, 2);
+    }
     return check_launch("schedule_evictions");
   }
   // per round: the histograms, then ONE launch for scan + pick (round 0: + the chunk totals and k',

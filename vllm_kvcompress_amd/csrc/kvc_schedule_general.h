@@ -618,6 +618,29 @@ __global__ __launch_bounds__(1024) void scan_pick_kernel(kvc_schedule_params p, 
   scan_pick_body<16, 8>(p, ws, round, blockIdx.x, part);
 }
 
+// ------------------------------------------------------------------ 5b. uniform_evict: per-head counts
+// The reference's other selection rule (metrics.py:639-666; its scheduler never passes it): every
+// head of sequence i frees evicted_blocks_per_seq[i] / (L*H) chunks, its own lowest ones.  The
+// reference asserts that those thresholds are finite (:660); here a head frees at most its
+// finite-threshold chunks.  One wave per head over the round-0 histogram (the head's evictable keys).
+__global__ __launch_bounds__(256) void uniform_counts_kernel(kvc_schedule_params p, SchedWs ws) {
+  const int LH = p.num_layers * p.num_kv_heads, G = p.num_seqs * LH;
+  const int g = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  if (g >= G) return;
+  const int lane = lane_id();
+  const uint4 v = reinterpret_cast<const uint4*>(ws.hist + (int64_t)g * RADIX)[lane];
+  const uint32_t finite = wave_reduce_sum(v.x + v.y + v.z + v.w);
+  if (lane == 0) {
+    const int k = p.evicted_blocks_per_seq[g / LH];
+    const uint32_t per_head = k > 0 ? (uint32_t)k / (uint32_t)LH : 0u;
+    const uint32_t hang = (uint32_t)p.hanging_token_count[g], bs = (uint32_t)p.block_size;
+    const uint32_t f = nchunks_freed(finite, hang, bs);
+    const uint32_t n = per_head < f ? per_head : f;
+    p.evicted_block_count[g] = (int32_t)n;
+    p.evicted_kv_count[g] = n > 0 ? (int32_t)((n - 1) * bs + hang) : 0;
+  }
+}
+
 // ------------------------------------------------------------------ 6. select + emit
 // one workgroup per head: cnt-th smallest (key, physical slot) by radix select, then the
 // ascending logical indices of everything at or below it.       metrics.py:822-834
@@ -725,7 +748,11 @@ __device__ __forceinline__ void select_emit_head(const kvc_schedule_params& p, S
   // the stored histogram, and only run the remaining rounds r*+1..3 over the keys.
   uint32_t M, take, eqn = 0;
   bool from_list = false;
-  if (bracket) {
+  if (bracket == 2) {
+    // uniform_evict: no sequence-level T* exists -- the head's own cnt-th smallest key, by a full select
+    block_radix_select(hist, bc, n, cnt, key_at, [&](int) { return true; }, M, take, eqn);
+    from_list = true;
+  } else if (bracket) {
     // the cnt-th smallest key of the head lies in its bracket list (keys in [lo, hi], sorted; `below`
     // keys of the head are smaller than lo) unless the head frees only chunks below the bracket
     const uint32_t below = ws.st_def[g];
@@ -861,7 +888,7 @@ __device__ __forceinline__ void select_emit_head(const kvc_schedule_params& p, S
 template <int SEL_THREADS>
 __global__ __launch_bounds__(SEL_THREADS) void select_emit_kernel(kvc_schedule_params p, SchedWs ws, int lds_cap, int bracket) {
   if (gated_off(ws)) return;
-  if (bracket && *ws.fallback != 0u) return;         // the bracket missed: the gated pipeline behind writes everything
+  if (bracket == 1 && *ws.fallback != 0u) return;    // the bracket missed: the gated pipeline behind writes everything
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_keys[];
   const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
   for (int g = blockIdx.x; g < G; g += gridDim.x) {

@@ -55,13 +55,14 @@ def upload(st: PagedState, device="cuda:0", num_queries_per_kv: int = 1, *, use_
     )
 
 
-def schedule(ds: DeviceState, st: PagedState, evicted_blocks, move_rows: Optional[int] = None):
+def schedule(ds: DeviceState, st: PagedState, evicted_blocks, move_rows: Optional[int] = None,
+             uniform_evict: bool = False):
     """A3 -> A5.  Returns (eli, ekc, ebc, cache_moves_idx, cache_moves_count)."""
     eli, ekc, ebc = ds.cm.schedule_evictions(
         list(st.seq_indices), ds.seq_positions,
         [int(x) for x in np.asarray(evicted_blocks).reshape(-1)],     # a host list, like the reference scheduler's
         ds.context_lens, ds.hanging_token_count, ds.evicted_kv_offsets, list(st.protected),
-        total_slots=ds.total_slots)
+        uniform_evict=uniform_evict, total_slots=ds.total_slots)
     rows = ds.total_slots if move_rows is None else move_rows
     cmi = torch.full((rows, 2), 77, dtype=torch.int32, device=ds.cm.device)
     cmc = torch.empty_like(ekc)

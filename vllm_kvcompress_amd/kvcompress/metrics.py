@@ -346,9 +346,6 @@ class CompressionMetrics:
         assert len(seq_indices) > 0
         assert list(sorted(seq_indices)) == list(seq_indices), (
             "schedule_evictions input not ordered by ascending index")
-        if uniform_evict:
-            raise NotImplementedError("uniform_evict is never used by the reference scheduler "
-                                      "(vllm/kvcompress/scheduler.py:492-501)")
         lib = _lib.load()
         bs, L, H, B = self.block_size, self.num_layers, self.num_kv_heads, len(seq_indices)
         dev = self.device
@@ -416,6 +413,8 @@ class CompressionMetrics:
         p.sample_stride = int(self.sample_stride)
         capturing = torch.cuda.is_current_stream_capturing()
         p.fallback_grid = int(self.fallback_grid)
+        # the reference's other selection rule (metrics.py:639-666; its scheduler never passes it)
+        p.uniform_evict = 1 if uniform_evict else 0
         if self._fb_event is not None and not capturing and self._fb_event.query():
             word = int(self._fb_pin[0])
             self._fb_event = None
