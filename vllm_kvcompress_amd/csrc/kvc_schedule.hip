@@ -320,8 +320,8 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   ws.bthr = reinterpret_cast<uint32_t*>(wb + l.bthr);
   ws.gate = nullptr;
   if (p.total_slots == 0) {
-    hipMemsetAsync(p.evicted_kv_count, 0, (size_t)G * 4, s);
-    hipMemsetAsync(p.evicted_block_count, 0, (size_t)G * 4, s);
+    fill32_async(p.evicted_kv_count, 0u, (size_t)G * 4, s);
+    fill32_async(p.evicted_block_count, 0u, (size_t)G * 4, s);
     return check_launch("schedule_evictions(empty)");
   }
   // keys default to "not evictable" (0xFFFFFFFF > KEY_INF) and the chunk table to -1 for slots
@@ -340,13 +340,12 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     // ---- small-eviction schedule (section 7): one memset of its counters, the output fill (side
     // stream), 6 launches (+ 2 for the reference's batch > 1 rule); the general pipeline is enqueued
     // behind it -- one gated launch (section 8) -- and runs only if the flag was raised
-    hipMemsetAsync(wb + l.tz_begin, 0, l.tz_end - l.tz_begin, s);
+    fill32_async(wb + l.tz_begin, 0u, l.tz_end - l.tz_begin, s);
     SideStream* side = nullptr;
     if (!(p.lean & 1) && p.eli_dirty_map == nullptr) {
       if (p.total_slots >= (1 << 22)) side = side_stream(s);
       if (side == nullptr)
-        hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.evicted_logical_indices), p.null_value,
-                          (size_t)p.total_slots, s);
+        fill32_async(p.evicted_logical_indices, (uint32_t)p.null_value, (size_t)p.total_slots * 4, s);
     }
     static std::atomic<uint64_t> sel_done{0};
     allow_dynamic_lds(reinterpret_cast<const void*>(seq_select_topk_kernel), 156 * 1024, sel_done);   // + its static tables
@@ -366,8 +365,7 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
         (void)hipGetLastError();                     // (no side stream after all: inline)
         side = nullptr;
       }
-      hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.evicted_logical_indices), p.null_value,
-                        (size_t)p.total_slots, side != nullptr ? side->s2 : s);
+      fill32_async(p.evicted_logical_indices, (uint32_t)p.null_value, (size_t)p.total_slots * 4, side != nullptr ? side->s2 : s);
       if (side != nullptr && hipEventRecord(side->join, side->s2) != hipSuccess) {
         // no event to wait for: the fill is waited for here and now (a later wait on `join` would
         // refer to an earlier call's record), and this thread fills inline from now on
@@ -436,11 +434,11 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   const bool by_tables = !topk && tables_plan(p);
   // (the bracket's sample -- 128 KiB per sequence -- lies behind the keys and the chunk table: cleared with them
   // only when that schedule runs)
-  if (!topk && !(p.lean & 2) && !by_tables) hipMemsetAsync(ws.keys, 0xFF, (bracket ? l.zero_begin : l.bsample) - l.keys, s);
+  if (!topk && !(p.lean & 2) && !by_tables) fill32_async(ws.keys, 0xFFFFFFFFu, (bracket ? l.zero_begin : l.bsample) - l.keys, s);
   const bool bracket_coupled = bracket && p.mode == 0 && B > 1;
   if (bracket) ws.bsample = reinterpret_cast<uint32_t*>(wb + l.bsample);   // build_keys leaves the sample behind
   if (bracket_coupled) {                             // ... and counts the keys that are not evictable
-    hipMemsetAsync(wb + l.tz_begin, 0, l.tz_end - l.tz_begin, s);
+    fill32_async(wb + l.tz_begin, 0u, l.tz_end - l.tz_begin, s);
     ws.bnonfin = ws.st_samp;
     ws.bk = ws.seq_k;
   }

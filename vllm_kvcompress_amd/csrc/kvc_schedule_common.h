@@ -120,6 +120,30 @@ __device__ __forceinline__ void eli_dirty_update(uint32_t* map, int32_t* eli, in
   }
 }
 
+// Fills (`bytes` a multiple of 4, `dst` 4-byte aligned) as KERNEL launches, not hipMemsetAsync: on
+// ROCm 7.2 a memset node recorded into a HIP graph fills its range on the first replay only (later
+// replays leave it partly or wholly untouched: measured, tests/test_gpu_configs.py replays the
+// captured step several times) -- and every schedule starts by clearing its counters.
+__global__ __launch_bounds__(256) void fill32_kernel(uint32_t* __restrict__ dst, uint32_t value, int64_t words) {
+  // leading words up to 16-byte alignment, 16-byte stores, trailing words
+  const int64_t head = min(words, (int64_t)(((16u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u) >> 2));
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nthreads = (int64_t)gridDim.x * 256;
+  if (tid < head) dst[tid] = value;
+  uint4* d16 = reinterpret_cast<uint4*>(dst + head);
+  const int64_t vecs = (words - head) >> 2;
+  const uint4 v = make_uint4(value, value, value, value);
+  for (int64_t i = tid; i < vecs; i += nthreads) d16[i] = v;
+  const int64_t tail0 = head + (vecs << 2);
+  if (tail0 + tid < words) dst[tail0 + tid] = value;          // (< 4 words)
+}
+inline void fill32_async(void* dst, uint32_t value, size_t bytes, hipStream_t s) {
+  const int64_t words = (int64_t)(bytes >> 2);
+  if (words <= 0) return;
+  int64_t blocks = (words / 4 + 255) / 256;                    // one 16-byte store per thread up to 16 Ki workgroups
+  blocks = blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks);
+  hipLaunchKernelGGL(fill32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<uint32_t*>(dst), value, words);
+}
+
 // wave-aggregated shared-memory histogram add: metric keys are often degenerate in their
 // top digits (all lanes hit one bin), which would serialise 64 LDS atomics; up to two
 // leader-elected groups are folded into one atomic each, the rest go one by one.
