@@ -511,3 +511,31 @@ def test_output_buffer_kept_between_calls_holds_the_padded_list():
     a = cm.schedule_evictions(*args)
     b = cm.schedule_evictions(*args)
     assert a[0].data_ptr() != b[0].data_ptr() and torch.equal(a[0], b[0])
+
+
+def test_block_tables_debug_check(monkeypatch):
+    """KVC_DEBUG_TABLES=1: schedule_evictions(block_tables=...) verifies the tables against all four
+    per-block metadata rows of the batch (the key pass through the tables itself only checks the owning
+    sequence): consistent tables pass, a table pointing at another head's block, a stale logical block
+    number and an out-of-range block each raise with the offending entry named"""
+    st, evicted = _steady(2, 4, 16, 3, 512, 4)
+    ds = hdev.upload(st, DEV, mode="per_sequence")
+    args = (list(st.seq_indices), ds.seq_positions, evicted, ds.context_lens, ds.hanging_token_count,
+            ds.evicted_kv_offsets, list(st.protected))
+    monkeypatch.setenv("KVC_DEBUG_TABLES", "1")
+    ds.cm.schedule_evictions(*args, total_slots=st.total_slots, block_tables=ds.block_tables)       # consistent: fine
+    ds.cm.check_block_tables(ds.block_tables, list(st.seq_indices), ds.context_lens)
+    bad = ds.block_tables.clone()
+    bad[1, 2, 3, 5], bad[1, 2, 0, 5] = ds.block_tables[1, 2, 0, 5], ds.block_tables[1, 2, 3, 5]     # two heads' blocks swapped
+    with pytest.raises(RuntimeError, match=r"block_tables\[1, seq 2, [03], 5\]"):
+        ds.cm.schedule_evictions(*args, total_slots=st.total_slots, block_tables=bad)
+    bad = ds.block_tables.clone()
+    bad[0, 1, 1, 2], bad[0, 1, 1, 3] = ds.block_tables[0, 1, 1, 3], ds.block_tables[0, 1, 1, 2]     # logical order swapped
+    with pytest.raises(RuntimeError, match="not the ones the metadata was written from"):
+        ds.cm.check_block_tables(bad, list(st.seq_indices), ds.context_lens)
+    bad = ds.block_tables.clone()
+    bad[0, 0, 0, 0] = st.num_blocks + 5
+    with pytest.raises(RuntimeError, match=r"block_tables\[0, seq 0, 0, 0\]"):
+        ds.cm.check_block_tables(bad, list(st.seq_indices), ds.context_lens)
+    monkeypatch.delenv("KVC_DEBUG_TABLES")
+    ds.cm.schedule_evictions(*args, total_slots=st.total_slots, block_tables=bad)                     # (not checked without the switch)

@@ -435,6 +435,8 @@ class CompressionMetrics:
                                    "[L, max_num_seqs, H, M]")
             if max(seq_indices) >= block_tables.shape[1]:
                 raise RuntimeError("schedule_evictions: a sequence index lies outside block_tables")
+            if os.environ.get("KVC_DEBUG_TABLES", "0") not in ("", "0"):
+                self.check_block_tables(block_tables, seq_indices, context_lens)
             p.block_tables = block_tables.data_ptr()
             p.seq_index_of_slot = self._as_i32([int(s) for s in seq_indices]).data_ptr()
             p.max_num_seqs, p.block_tables_width = int(block_tables.shape[1]), int(block_tables.shape[3])
@@ -501,6 +503,34 @@ class CompressionMetrics:
             rec = self._eli_buf = (buf, dmap, bs, self._storage_refs(buf), stream)
         p.eli_dirty_map = rec[1].data_ptr()
         return rec[0][:N]
+
+    def check_block_tables(self, block_tables: torch.Tensor, seq_indices, context_lens: torch.Tensor) -> None:
+        """Debug aid (``KVC_DEBUG_TABLES=1`` runs it inside every ``schedule_evictions(block_tables=...)``;
+        synchronises): the contract of the optional ``block_tables=`` argument is that the tables are the
+        ones the per-block metadata was written from -- the key pass through the tables only checks the
+        owning sequence of a listed block.  Here every listed block of the batch is checked against all
+        four metadata rows (sequence, layer, head, logical block number); raises ``RuntimeError`` with the
+        first offender."""
+        L, H, bs = self.num_layers, self.num_kv_heads, self.block_size
+        M = block_tables.shape[3]
+        sel = torch.tensor([int(s) for s in seq_indices], device=self.device, dtype=torch.long)
+        bt = block_tables[:, sel].long()                                        # [L, B, H, M]
+        nblk = ((context_lens.long() + bs - 1) // bs)                            # [L, B, H]
+        live = torch.arange(M, device=self.device)[None, None, None, :] < nblk[..., None]
+        blk = bt[live]
+        l_i, b_i, h_i, m_i = torch.nonzero(live, as_tuple=True)
+        ok = ((blk >= 0) & (blk < self.num_blocks))
+        safe = blk.clamp(0, self.num_blocks - 1)
+        ok &= self.seq_index_by_block[safe].long() == sel[b_i]
+        ok &= self.layer_index_by_block[safe].long() == l_i
+        ok &= self.head_index_by_block[safe].long() == h_i
+        ok &= self.logical_block_num_by_block[safe].long() == m_i
+        if not bool(ok.all()):
+            j = int(torch.nonzero(~ok)[0])
+            raise RuntimeError(
+                f"block_tables[{int(l_i[j])}, seq {int(sel[b_i[j]])}, {int(h_i[j])}, {int(m_i[j])}] = {int(blk[j])} does not "
+                "match that block's metadata (sequence / layer / head / logical block number): the tables passed to "
+                "schedule_evictions are not the ones the metadata was written from")
 
     def _raise_fallback_fault(self, which: str) -> None:
         """Bit 1 of the flag word: the single launch that redoes a call on the general pipeline gave
