@@ -126,8 +126,12 @@ __device__ __forceinline__ void dirty_update(uint32_t* map, int2* mv2, int64_t c
       if (read_old) old = map[w];
       if (old != fresh || !read_old) map[w] = fresh;
     } else {
-      if (read_old) old = atomicAnd(&map[w], ~mask) & mask;
-      if (fresh) atomicOr(&map[w], fresh);
+      // (only this owner changes these bits, so a plain look at them is safe next to the neighbours'
+      // atomics on theirs; in the steady state they already are what they should be: no atomic at all)
+      const uint32_t mine = map[w] & mask;
+      if (read_old) old = mine;
+      if (mine & ~fresh) atomicAnd(&map[w], ~(mine & ~fresh));
+      if (fresh & ~mine) atomicOr(&map[w], fresh & ~mine);
     }
     while (old) {                                    // chunks that held moves before this call
       const int bit = __ffs((int)old) - 1;

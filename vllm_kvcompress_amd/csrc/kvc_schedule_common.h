@@ -107,8 +107,11 @@ __device__ __forceinline__ void eli_dirty_update(uint32_t* map, int32_t* eli, in
       old = map[w];
       if (old != fresh) map[w] = fresh;
     } else {
-      old = atomicAnd(&map[w], ~mask) & mask;
-      if (fresh) atomicOr(&map[w], fresh);
+      // (only this owner changes these bits: a plain look at them is safe next to the neighbours'
+      // atomics on theirs, and in the steady state nothing has to change)
+      old = map[w] & mask;
+      if (old & ~fresh) atomicAnd(&map[w], ~(old & ~fresh));
+      if (fresh & ~old) atomicOr(&map[w], fresh & ~old);
     }
     if (!fill_old) continue;
     while (old) {
