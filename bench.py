@@ -306,7 +306,7 @@ def parity_gate(args, st, ds, evicted, mode, gpu, snap, k_cache, v_cache, wm, wp
     return out
 
 
-def parity_gate_sampled(args, st, evicted, gpu, k_cache, v_cache, wm, wp, num_sampled=8):
+def parity_gate_sampled(args, st, evicted, gpu, k_cache, v_cache, wm, wp, num_sampled=8, schedule_only=False):
     """The gate for a batch too large for the oracle's sorts (configs[2]: 256 sequences, 270 M slots).
     In per_sequence mode every sequence is scheduled as if alone, so the oracle runs on a sub-batch of
     `num_sampled` sequences spread over the batch and every output of THEIR heads -- evicted indices,
@@ -358,6 +358,9 @@ def parity_gate_sampled(args, st, evicted, gpu, k_cache, v_cache, wm, wp, num_sa
     rows_sub = np.repeat(off_sub, lens) + within
     cmp("evicted_logical_indices", gpu["eli"][rows_full].cpu().numpy(), eli[rows_sub])
     cmp("cache_moves_idx", gpu["cmi"][rows_full].cpu().numpy(), cmi[rows_sub])
+    if schedule_only:
+        return {"mode": "per_sequence", "bit_exact": not bad, "sampled_sequences": sel, "compared": compared,
+                "mismatched": bad, "seconds": time.perf_counter() - t0}
     # the compaction, all sequences, on the device
     cnt = gpu["cmc"].reshape(-1).long()
     o = torch.from_numpy(st.evicted_kv_offsets.reshape(-1).astype(np.int64)).to(dev)
@@ -690,9 +693,115 @@ def measure_workload(a2, seed, device, steps, warmup, probe):
             "same_counts": same,
             "what": "schedule_evictions(..., block_tables=BlockState.block_tables): an extension of the reference's "
                     "signature (INTEGRATION.md); every other figure of this entry is measured without it"}
+    if a2.steady_cap and res["S1_schedule"] == "small_eviction" and a2.mode == "per_sequence" and not a2.lean:
+        del wm, wp
+        res["decode_step"] = decode_step_compare(a2, st, ds, evicted, k_cache, v_cache, cmi, cmc, device,
+                                                 steps=min(steps, 12), warmup=3)
+        if res["decode_step"].get("parity_checked", {}).get("bit_exact") is False:
+            raise SystemExit(f"bench.py: PARITY GATE FAILED ({a2.config}, decode step): {json.dumps(res['decode_step'])}")
+        wm = wp = None
     del k_cache, v_cache, ds, cmi, wm, wp
     torch.cuda.empty_cache()
     return res
+
+
+def decode_step_compare(a2, st, ds, evicted, k_cache, v_cache, cmi, cmc, device, steps, warmup):
+    """The WHOLE decode step of the continual steady state -- S0 aggregate_decode (reference metrics.py:429-439: the
+    whole store, every step; 4 * qpk + 8 B per slot) + S1 + S2 + S3 -- timed twice from the same state with the same
+    attention mass: as the TWO SWEEPS of the store the reference's flow implies (aggregate_decode, then
+    schedule_evictions' own collecting pass) and HARVEST-AHEAD (CompressionMetrics.aggregate_decode_and_harvest: the
+    sums are looked at while they pass through registers, the schedule call does not stream the store again;
+    include/kvc_mi355x.h ABI version 5).  Both variants must leave the same store and the same schedule; the final
+    state is checked against the oracle on a sample of the sequences.  The state is static apart from the metrics
+    (nobody frees the evicted blocks between bench steps), so the harvest's pivots also cover the keys an engine
+    would have freed the step before: the harvest measured here is ~1.4 x as long as an engine's."""
+    import gc
+    import torch
+    from vllm_kvcompress_amd import _custom_ops as ops
+    cm = ds.cm
+    qpk, N, bs = 4, st.total_slots, st.block_size
+    slots = st.num_blocks * bs
+    g = torch.Generator(device=device)
+    g.manual_seed(99)
+    try:
+        # attention mass per (slot, query head): sum_q t^2 ~ 3 per step, next to metrics that are a permutation of
+        # 0 .. slots-per-sequence: a key near the pivot drifts by a few ranks per step
+        temp = torch.rand((st.num_blocks, bs, qpk), dtype=torch.float32, device=device, generator=g) * 1.5
+        m0 = cm.metrics.clone()
+        wm, wp = cm.metrics.clone(), cm.token_positions.clone()
+    except torch.OutOfMemoryError:
+        torch.cuda.empty_cache()
+        return {"skipped": "does not fit"}
+    saved = (cm.num_queries_per_kv, cm._temp_metrics, cm.harvest_ahead)
+    cm.num_queries_per_kv, cm._temp_metrics = qpk, temp
+    seq_idx, prot = list(st.seq_indices), list(st.protected)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    out, keep = {}, {}
+    for variant in ("two_sweeps", "harvest_ahead"):
+        cm.metrics.copy_(m0)
+        cm.harvest_ahead = variant == "harvest_ahead"
+        cm._hv = cm._hv_lists = None
+        misses0, used = cm.harvest_misses, 0
+        marks = [[ev() for _ in range(5)] for _ in range(steps)]
+        gc.collect()
+        gc.disable()
+        eli = ekc = ebc = None
+        for i in range(-warmup, steps):
+            rec = i >= 0
+            del eli, ekc, ebc
+            if rec: marks[i][0].record()
+            if cm.harvest_ahead:
+                cm.aggregate_decode_and_harvest(seq_idx, ds.seq_positions, prot, ds.context_lens, total_slots=N, fuse_clear=False)
+            else:
+                cm.aggregate_decode(fuse_clear=False)
+            if rec: marks[i][1].record()
+            eli, ekc, ebc = cm.schedule_evictions(seq_idx, ds.seq_positions, evicted, ds.context_lens,
+                                                  ds.hanging_token_count, ds.evicted_kv_offsets, prot, total_slots=N)
+            used += int(rec and cm.last_harvest_used)
+            if rec: marks[i][2].record()
+            ops.schedule_cache_moves(cmi, cmc, eli, ekc, ds.evicted_kv_offsets, ds.block_tables, ds.context_lens, bs)
+            if rec: marks[i][3].record()
+            ops.execute_cache_moves(k_cache, v_cache, wm, wp, cmi, cmc, ds.evicted_kv_offsets, 1, 16)
+            if rec: marks[i][4].record()
+        torch.cuda.synchronize()
+        gc.enable()
+        ms = lambda a, b: sum(m[a].elapsed_time(m[b]) for m in marks) / steps
+        out[variant] = {
+            "ms_per_step": ms(0, 4),
+            "stages_ms": {"S0_aggregate_decode": ms(0, 1), "S1_schedule_evictions": ms(1, 2), "S2_schedule_moves": ms(2, 3),
+                          "S3_execute_moves": ms(3, 4)},
+            "S0_GBps": slots * (4 * qpk + 8) / (ms(0, 1) * 1e-3) / 1e9,
+            "S1_schedule": cm.last_schedule_path(), "harvested_steps": used, "harvest_misses": cm.harvest_misses - misses0}
+        keep[variant] = (cm.metrics.clone(), eli.clone(), ekc.clone(), ebc.clone(), cmc.clone(),
+                         torch.cat([cmi[o:o + int(c)] for o, c in zip(st.evicted_kv_offsets.reshape(-1)[:64].tolist(),
+                                                                      cmc.reshape(-1)[:64].tolist())]) if N else cmi[:0])
+    a, b = keep["two_sweeps"], keep["harvest_ahead"]
+    names = ("metrics", "evicted_logical_indices", "evicted_kv_count", "evicted_block_count", "cache_moves_count",
+             "cache_moves_idx (first 64 heads)")
+    differ = [n for n, x, y in zip(names, a, b) if not torch.equal(x.view(torch.int32) if x.dtype == torch.float32 else x,
+                                                                   y.view(torch.int32) if y.dtype == torch.float32 else y)]
+    # the oracle on the final state (the harvested variant ran last: its outputs are the live ones)
+    import copy as _copy
+    st2 = _copy.copy(st)
+    st2.metrics = cm.metrics.cpu().numpy()
+    parity = parity_gate_sampled(a2, st2, evicted, dict(eli=eli, ekc=ekc, ebc=ebc, cmi=cmi, cmc=cmc), k_cache, v_cache,
+                                 None, None, schedule_only=True)
+    parity["variants_agree"] = not differ
+    parity["variants_differ_in"] = differ
+    parity["bit_exact"] = bool(parity["bit_exact"]) and not differ
+    parity["what"] = ("both variants from the same store with the same attention mass: the stores and the last step's outputs must "
+                      "be equal; the last step of the harvested variant against the oracle's schedule of that store on a sample of "
+                      "the sequences (S0's sums against the oracle: tests/test_gpu_harvest.py, tests/test_gpu_parity.py)")
+    cm.metrics.copy_(m0)
+    cm.num_queries_per_kv, cm._temp_metrics, cm.harvest_ahead = saved
+    cm._hv = cm._hv_lists = None
+    out["saved_ms_per_step"] = out["two_sweeps"]["ms_per_step"] - out["harvest_ahead"]["ms_per_step"]
+    out["what"] = ("S0 + S1 + S2 + S3 per decode step; num_queries_per_kv 4, aggregate_decode without the fused clear "
+                   f"(24 B per slot over {slots} slots); {steps} steps after {warmup} warm-up steps")
+    out["parity_checked"] = parity
+    del temp, m0, wm, wp, keep
+    torch.cuda.empty_cache()
+    return out
 
 
 def engine_sized_cache_run(args, rank, device, steps=20, warmup=3):

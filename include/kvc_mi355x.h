@@ -279,6 +279,26 @@ typedef struct kvc_schedule_params {
                                                * identical to the padded list.  Ignored by the other schedules
                                                * (they write every entry; a call that falls back from the
                                                * small-eviction schedule keeps the map right). */
+  void* harvest_buf;                          /* ABI version 5, optional (NULL: none).  Harvest-ahead (DESIGN.md 3.1,
+                                               * "one sweep per decode step"): kvc_harvest_buffer_bytes() bytes the
+                                               * caller keeps between kvc_aggregate_decode_harvest and this call --
+                                               * per-sequence pivots, per-head candidate lists. */
+  int32_t harvest;                            /* bit 0: harvest_buf holds the candidate lists
+                                               *   kvc_aggregate_decode_harvest made for EXACTLY this call (same
+                                               *   batch, context_lens, positions, protected windows; the store
+                                               *   untouched since): the small-eviction schedule does not stream
+                                               *   the metric store again.  Exactness does not depend on the
+                                               *   pivots the lists were made with: lists that do not cover the
+                                               *   selection raise the `fallback` flag like any short record.
+                                               * bit 1: leave in harvest_buf the pivots for the harvest of the
+                                               *   NEXT decode step (this call's sample, aimed at what this call
+                                               *   evicts + what the next one will need: evicted_blocks_per_seq
+                                               *   taken as the next step's too, times 1 + harvest_widen).
+                                               * Both are ignored (bit 0: an error) unless the call takes the
+                                               * small-eviction schedule in its position-lazy form
+                                               * (kvc_harvest_eligible). */
+  float harvest_widen;                        /* bit 1: allowance for keys that drift above the pivot during one
+                                               * decode step, as a fraction of the step's target (0.25) */
   /* outputs */
   int32_t* evicted_logical_indices;           /* [N] */
   int32_t* evicted_kv_count;                  /* [B,L,H] */
@@ -287,6 +307,24 @@ typedef struct kvc_schedule_params {
 
 size_t kvc_schedule_evictions_workspace_bytes(int64_t total_slots, int32_t total_heads,
                                               int32_t num_seqs, int32_t block_size);
+/* Harvest-ahead (ABI version 5).  Continual compression streams the whole metric store twice per
+ * decode step: aggregate_decode adds the step's attention to it, and a moment later the
+ * small-eviction schedule reads it all again to find the ~1 % of the keys that lie below each
+ * sequence's pivot.  kvc_aggregate_decode_harvest is kvc_aggregate_decode (same arithmetic, bit
+ * for bit, over the whole cache) that looks at every sum while it is in registers: keys of the
+ * batch `p` describes (the schedule call that will follow: metadata, seq_slot_of_seq, seq_positions,
+ * num_protected, context_lens, block_size ...; the outputs and evicted_blocks_per_seq are not read)
+ * that lie below the pivot the PREVIOUS schedule call left in p->harvest_buf (harvest bit 1) are
+ * appended to their head's candidate list there.  kvc_schedule_evictions with harvest bit 0 then
+ * runs records -> selection -> emission on these lists.  The result is exact or the flag is raised
+ * (fallback on device), exactly as when the lists come from the schedule's own collecting pass.
+ * Eligible: the small-eviction schedule in its position-lazy form (no use_average, no bias, mode 1
+ * or one sequence), block size 8 / 16 / 32, num_queries_per_kv 4 or 8. */
+size_t kvc_harvest_buffer_bytes(int32_t total_heads, int32_t num_seqs);
+int32_t kvc_harvest_eligible(const kvc_schedule_params* p, int32_t num_queries_per_kv);
+int kvc_aggregate_decode_harvest(const kvc_schedule_params* p, float* temp_metrics,
+                                 int32_t num_queries_per_kv, int32_t use_l2, int32_t clear_temp,
+                                 kvc_stream_t stream);
 int kvc_schedule_evictions(const kvc_schedule_params* p, void* workspace,
                            size_t workspace_bytes, kvc_stream_t stream);
 /* introspection (tests, bench.py): 1 if a call with these parameters enqueues the small-eviction

@@ -1,0 +1,214 @@
+"""Harvest-ahead: ``CompressionMetrics.aggregate_decode_and_harvest`` + the ``schedule_evictions`` that
+follows (kvc_aggregate_decode_harvest / kvc_schedule_params.harvest, ABI version 5).
+
+The aggregation pass of a decode step (reference metrics.py:429-439) also makes the small-eviction
+schedule's candidate lists, with pivots the previous schedule call left behind.  Whatever those
+pivots are worth, every step must give (a) the reference's sums, bit for bit -- the oracle's
+``aggregate_decode`` -- and (b) the oracle's schedule of the aggregated store (reference
+metrics.py:441-847): lists that fall short are redone on the device, lists that no longer belong
+to the call (another batch, a store somebody wrote to) are not used.  Driven through many decode
+steps of the continual steady state with the host-side block-state simulator."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kvc_oracle as orc
+from tests.helpers import oracle_pipeline
+from vllm_kvcompress_amd import _lib
+from vllm_kvcompress_amd.harness import device as hdev
+from vllm_kvcompress_amd.harness import synth
+from vllm_kvcompress_amd.harness.engine_sim import EngineSim
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+KEYS = ("eli", "ekc", "ebc")
+
+
+class Loop:
+    """one CompressionMetrics kept over the steps; the host state (oracle side) is copied into its
+    tensors in front of every step"""
+
+    def __init__(self, L, H, bs, seq_lens, cap, qpk=4, seed=3, use_l2=True, stride=0):
+        self.L, self.H, self.bs, self.cap, self.qpk, self.use_l2 = L, H, bs, cap, qpk, use_l2
+        self.seq_lens = list(seq_lens)
+        self.st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs, seq_lens=seq_lens, seed=seed,
+                                   protected=bs + 1, spare_block_frac=0.6, steady_cap=cap)
+        self.sim = EngineSim(self.st, seq_lens)
+        self.ds = hdev.upload(self.st, DEV, num_queries_per_kv=qpk, mode="per_sequence")
+        self.cm = self.ds.cm
+        self.cm.use_l2 = use_l2
+        self.cm.harvest_ahead = True
+        self.cm.strict_fallback = True          # (the flag word is looked at in the call itself)
+        self.cm.sample_stride = stride
+        self.k_np, self.v_np = synth.make_caches_u16(seed, self.st.num_blocks, 32, bs)
+        self.rng = np.random.default_rng(seed)
+        self.step_no = 0
+
+    def sub_state(self, sel):
+        st = self.st
+        if sel == list(range(len(self.seq_lens))):
+            return st
+        ctx = np.ascontiguousarray(st.context_lens[:, sel, :])
+        return synth.PagedState(
+            block_size=st.block_size, num_layers=st.num_layers, num_kv_heads=st.num_kv_heads, num_seqs=len(sel),
+            num_blocks=st.num_blocks, metrics=st.metrics, token_positions=st.token_positions,
+            seq_index_by_block=st.seq_index_by_block, layer_index_by_block=st.layer_index_by_block,
+            head_index_by_block=st.head_index_by_block, logical_block_num_by_block=st.logical_block_num_by_block,
+            context_lens=ctx, block_tables=np.ascontiguousarray(st.block_tables[:, sel]),
+            hanging_token_count=synth.hanging_tokens(ctx.transpose(1, 0, 2), st.block_size),
+            evicted_kv_offsets=synth.kv_offsets(ctx, st.block_size), seq_indices=list(sel),
+            seq_positions=np.ascontiguousarray(st.seq_positions[sel]), protected=[st.protected[i] for i in sel])
+
+    def step(self, sel=None, between=None, before_harvest=None, scale=1.0, plain=False):
+        """one decode step: attention mass -> aggregate (+ harvest) -> schedule; both sides compared;
+        then the host state is carried on (compaction, freed blocks, one more token per head)"""
+        st, cm, bs = self.st, self.cm, self.bs
+        B = len(self.seq_lens)
+        sel = list(range(B)) if sel is None else sel
+        sub = self.sub_state(sel)
+        temp = (self.rng.random((st.num_blocks, bs, self.qpk)) * scale).astype(np.float32)
+        # ---- device: the state in front of the step
+        cm.metrics.copy_(torch.from_numpy(st.metrics))
+        cm.token_positions.copy_(torch.from_numpy(st.token_positions))
+        cm.seq_index_by_block.copy_(torch.from_numpy(st.seq_index_by_block))
+        cm.layer_index_by_block.copy_(torch.from_numpy(st.layer_index_by_block))
+        cm.head_index_by_block.copy_(torch.from_numpy(st.head_index_by_block))
+        cm.logical_block_num_by_block.copy_(torch.from_numpy(st.logical_block_num_by_block))
+        cm.temp_metrics.copy_(torch.from_numpy(temp))
+        ctx_t = torch.from_numpy(sub.context_lens).to(DEV)
+        hang_t = torch.from_numpy(sub.hanging_token_count).to(DEV)
+        offs_t = torch.from_numpy(sub.evicted_kv_offsets).to(DEV)
+        pos_t = torch.from_numpy(sub.seq_positions).to(DEV)
+        seqs, prot = list(sub.seq_indices), list(sub.protected)
+        # ---- oracle: the sums
+        orc.aggregate_decode(st.metrics, temp, use_l2=self.use_l2)
+        if before_harvest is not None:
+            before_harvest()
+        if plain:
+            cm.aggregate_decode()
+            harvested = False
+        else:
+            harvested = cm.aggregate_decode_and_harvest(seqs, pos_t, prot, ctx_t, total_slots=sub.total_slots)
+        np.testing.assert_array_equal(cm.metrics.cpu().numpy(), st.metrics, err_msg=f"step {self.step_no}: sums")
+        assert not bool(cm._temp_metrics.any()), "the fused clear"
+        if between is not None:
+            between()
+        evicted = [synth.evict_block_count(context_lens_lh=sub.context_lens[:, b, :], seq_len=int(self.sim.seq_lens[s]),
+                                           block_size=bs, protected_window_size=bs + 1, max_cache_tokens=self.cap)
+                   for b, s in enumerate(sel)]
+        want = oracle_pipeline(sub, evicted, self.k_np, self.v_np, mode="per_sequence")
+        eli, ekc, ebc = cm.schedule_evictions(seqs, pos_t, evicted, ctx_t, hang_t, offs_t, prot, total_slots=sub.total_slots)
+        got = dict(eli=eli.cpu().numpy(), ekc=ekc.cpu().numpy(), ebc=ebc.cpu().numpy())
+        for key in KEYS:
+            np.testing.assert_array_equal(got[key], want[key], err_msg=f"step {self.step_no} (sel {sel}, k {evicted}): {key}")
+        info = dict(harvested=harvested, used=cm.last_harvest_used, path=cm.last_schedule_path(), evicted=evicted)
+        # ---- carry the host state on (the oracle's compaction; only the selected sequences were compressed)
+        st.metrics, st.token_positions = want["metrics"].copy(), want["positions"].copy()
+        self.k_np, self.v_np = want["k"], want["v"]
+        full_kv = np.zeros((B, self.L, self.H), np.int32)
+        full_bc = np.zeros((B, self.L, self.H), np.int32)
+        full_kv[sel], full_bc[sel] = want["ekc"], want["ebc"]
+        self.sim.apply_compression(full_kv, full_bc)
+        self.sim.append_token()
+        self.step_no += 1
+        return info
+
+
+@pytest.mark.parametrize("bs,qpk,use_l2,stride", [(16, 4, True, 0), (16, 4, False, 2), (32, 8, True, 0), (8, 4, True, 0),
+                                                   (16, 8, True, 4)])
+def test_continual_steps_on_harvested_lists(bs, qpk, use_l2, stride):
+    lp = Loop(L=2, H=4, bs=bs, seq_lens=[40 * bs + 5, 25 * bs, 33 * bs + 9], cap=20 * bs, qpk=qpk, use_l2=use_l2,
+              stride=stride, seed=bs + qpk)
+    first = lp.step()
+    assert not first["harvested"] and not first["used"], "nothing to harvest with before the first schedule call"
+    assert first["path"].startswith("small_eviction"), first
+    used = clean = 0
+    for it in range(36):
+        info = lp.step()
+        assert info["used"] == info["harvested"] or not info["used"]
+        used += info["used"]
+        clean += info["used"] and info["path"] == "small_eviction"
+        assert info["path"].startswith("small_eviction"), info
+    # (a step is not harvested when it frees more than the pivots were made for, or right after a miss)
+    assert used >= 18, f"harvested lists were used in {used} of 36 steps"
+    if stride == 0:
+        assert clean >= used - 4, f"{used - clean} of {used} harvested steps had to be redone on the device"
+
+
+def test_lists_are_dropped_when_they_no_longer_belong_to_the_call():
+    lp = Loop(L=2, H=4, bs=16, seq_lens=[700, 420, 555, 610], cap=320)
+    cm = lp.cm
+    lp.step()
+    assert lp.step()["used"]
+    # the store written through torch between the two calls
+    info = lp.step(between=lambda: cm.metrics[0, 0].add_(0.0))
+    assert info["harvested"] and not info["used"] and info["path"] == "small_eviction"
+    assert lp.step()["used"]
+    # block metadata written through the object
+    info = lp.step(between=lambda: cm.remove_metadata(torch.empty((0,), dtype=torch.long, device=DEV)))
+    assert info["harvested"] and not info["used"]
+    assert lp.step()["used"]
+    # another batch: the pivots were made for all four sequences
+    info = lp.step(sel=[0, 2, 3])
+    assert not info["harvested"] and not info["used"]
+    info = lp.step(sel=[0, 2, 3])
+    assert info["used"]
+    info = lp.step()                       # (the sequence that sat out has more to free: maybe a bulk call, no pivots)
+    assert not info["harvested"]
+    lp.step()
+    # a plain aggregate_decode in between: nothing to use, and the call leaves pivots again
+    assert lp.step()["used"]
+    info = lp.step(plain=True)
+    assert not info["used"]
+    assert lp.step()["used"]
+
+
+def test_lists_that_fall_short_are_redone_on_the_device():
+    lp = Loop(L=2, H=4, bs=16, seq_lens=[700, 420, 555], cap=320)
+    cm = lp.cm
+    lp.step()
+    assert lp.step()["path"] == "small_eviction"
+    lib = _lib.load()
+    B, G = 3, 3 * 2 * 4
+    assert cm._hv_buf.numel() == lib.kvc_harvest_buffer_bytes(G, B)
+
+    def no_pivots():                       # pivot 0: no key lies below it -> empty lists
+        cm._hv_buf[256:256 + 4 * B] = 0
+
+    misses, widen = cm.harvest_misses, cm.harvest_widen
+    info = lp.step(before_harvest=no_pivots)
+    assert info["used"] and info["path"] == "small_eviction+fallback", info
+    assert cm.harvest_misses == misses + 1 and cm.harvest_widen > widen
+    info = lp.step()                       # the pivots are made anew by a usual pass
+    assert not info["harvested"] and info["path"] == "small_eviction"
+    assert lp.step()["used"]
+
+
+def test_attention_mass_that_lifts_every_key_over_the_pivot():
+    """increments far larger than the pivots' allowance: short lists now and then, never a wrong schedule"""
+    lp = Loop(L=2, H=4, bs=16, seq_lens=[900, 640], cap=384, seed=11)
+    lp.step()
+    paths = [lp.step(scale=40.0 if it % 3 == 0 else 1.0)["path"] for it in range(18)]
+    assert all(p.startswith("small_eviction") for p in paths)
+
+
+def test_not_eligible_calls_aggregate_as_before():
+    """use_average keys depend on the position: no lazy form, no harvest -- the plain sums, the usual schedule"""
+    st = synth.make_state(num_layers=2, num_kv_heads=4, block_size=16, seq_lens=[600, 300], seed=3, protected=17)
+    ds = hdev.upload(st, DEV, num_queries_per_kv=4, mode="per_sequence", use_average=True)
+    cm = ds.cm
+    cm.harvest_ahead = True
+    temp = np.random.default_rng(0).random((st.num_blocks, 16, 4)).astype(np.float32)
+    for it in range(3):
+        cm.temp_metrics.copy_(torch.from_numpy(temp))
+        orc.aggregate_decode(st.metrics, temp, use_l2=True)
+        assert not cm.aggregate_decode_and_harvest(list(st.seq_indices), ds.seq_positions, list(st.protected),
+                                                   ds.context_lens, total_slots=st.total_slots)
+        np.testing.assert_array_equal(cm.metrics.cpu().numpy(), st.metrics)
+        want = oracle_pipeline(st, [2, 1], mode="per_sequence", use_average=True)
+        eli, ekc, ebc, cmi, cmc = hdev.schedule(ds, st, [2, 1])
+        assert not cm.last_harvest_used
+        np.testing.assert_array_equal(eli.cpu().numpy(), want["eli"])
+        np.testing.assert_array_equal(ekc.cpu().numpy(), want["ekc"])

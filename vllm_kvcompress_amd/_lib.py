@@ -45,6 +45,7 @@ class KvcScheduleParams(ctypes.Structure):
         ("schedule_path", c_int32), ("sample_stride", c_int32), ("fallback_grid", c_int32),
         ("uniform_evict", c_int32),
         ("eli_dirty_map", c_void_p),
+        ("harvest_buf", c_void_p), ("harvest", c_int32), ("harvest_widen", c_float),
         ("evicted_logical_indices", c_void_p), ("evicted_kv_count", c_void_p),
         ("evicted_block_count", c_void_p),
     ]
@@ -107,6 +108,10 @@ SYMBOLS = {
     "kvc_schedule_evictions_plan_reason": (c_int32, [ctypes.POINTER(KvcScheduleParams)]),
     "kvc_schedule_evictions_uses_block_tables": (c_int32, [ctypes.POINTER(KvcScheduleParams)]),
     "kvc_schedule_evictions_fallback_offset": (c_size_t, [c_int64, c_int32, c_int32, c_int32]),
+    "kvc_harvest_buffer_bytes": (c_size_t, [c_int32, c_int32]),
+    "kvc_harvest_eligible": (c_int32, [ctypes.POINTER(KvcScheduleParams), c_int32]),
+    "kvc_aggregate_decode_harvest": (c_int32, [ctypes.POINTER(KvcScheduleParams), c_void_p, c_int32, c_int32,
+                                               c_int32, c_void_p]),
     "kvc_aggregate_decode": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
                                        c_void_p]),
     "kvc_aggregate_prefill": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,

@@ -35,12 +35,14 @@
 //   kvc_schedule_common.h    scratch layout (SchedWs), key order, dirty-map and histogram helpers
 //   kvc_schedule_general.h   sections 0-6: keys, digit rounds, scan + pick, select + emit
 //   kvc_schedule_small.h     section 7: the small-eviction schedule (sample, pivot, collect, records, select, emit)
+//   kvc_schedule_harvest.h   section 10: aggregate_decode that harvests section 7's candidate lists on its way
 //   kvc_schedule_bracket.h   section 9: the bracket schedule (bracket, count + collect, records, select)
 //   kvc_schedule_fallback.h  section 8: the general pipeline as one gated launch, phases ordered by work counters
 // This file: the host side -- workspace layout, which schedule a call takes (and why), the launches.
 #include "kvc_schedule_common.h"
 #include "kvc_schedule_general.h"
 #include "kvc_schedule_small.h"
+#include "kvc_schedule_harvest.h"
 #include "kvc_schedule_bracket.h"
 #include "kvc_schedule_fallback.h"
 
@@ -187,6 +189,25 @@ static int topk_plan(const kvc_schedule_params& p, int& p2_out, int& sshift) {
   if (p.sample_stride > 0) stride = p.sample_stride;
   while (sshift < 8 && (2ll << sshift) <= stride) ++sshift;
   return KVC_WHY_TAKEN;
+}
+
+// the small-eviction schedule's position-lazy form (stream_collect_kernel, LAZY): keys that do not
+// depend on the position, sequences that do not need each other's inf counts
+static bool lazy_plan(const kvc_schedule_params& p) {
+  return !p.use_average && p.bias == nullptr && !(p.mode == 0 && p.num_seqs > 1) && p.schedule_path != 3;
+}
+// harvest-ahead (section 10): the call takes that form, and the aggregation kernel has the shape
+static bool harvest_plan(const kvc_schedule_params& p) {
+  int p2 = 0, sshift = 0;
+  return topk_plan(p, p2, sshift) == KVC_WHY_TAKEN && lazy_plan(p);
+}
+extern "C" int32_t kvc_harvest_eligible(const kvc_schedule_params* p, int32_t num_queries_per_kv) {
+  if (p == nullptr || !(num_queries_per_kv == 4 || num_queries_per_kv == 8)) return 0;
+  return harvest_plan(*p) ? 1 : 0;
+}
+extern "C" size_t kvc_harvest_buffer_bytes(int32_t total_heads, int32_t num_seqs) {
+  if (total_heads < 1 || num_seqs < 1) return 0;
+  return kvc::hv_layout(total_heads, num_seqs).total;
 }
 
 // bracket schedule (section 9) or the digit rounds, for calls the small-eviction schedule does not
@@ -351,8 +372,26 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     allow_dynamic_lds(reinterpret_cast<const void*>(seq_select_topk_kernel), 156 * 1024, sel_done);   // + its static tables
     // positions only for the slots whose metric lies below the pivot (stream_collect_kernel, LAZY):
     // keys that do not depend on the position, sequences that do not need each other's inf counts
-    const bool lazy = !p.use_average && p.bias == nullptr && !(p.mode == 0 && B > 1) && p.schedule_path != 3;
-    {
+    const bool lazy = lazy_plan(p);
+    // harvest-ahead (section 10): the lists were made by the aggregation pass / a pivot is wanted for the next one
+    const bool hv_ok = p.harvest_buf != nullptr && harvest_plan(p);
+    if ((p.harvest & 1) && !hv_ok)
+      return fail_invalid("schedule_evictions: harvested lists with a call that is not eligible (kvc_harvest_eligible)");
+    const bool harvested = (p.harvest & 1) != 0;
+    uint32_t* hv_pivot = nullptr;
+    if (hv_ok && (p.harvest & 3)) {
+      if ((reinterpret_cast<uintptr_t>(p.harvest_buf) & 15) != 0) return fail_invalid("schedule_evictions: harvest_buf must be 16-byte aligned");
+      uint8_t* hb = reinterpret_cast<uint8_t*>(p.harvest_buf);
+      const HvLayout hl = hv_layout(G, B);
+      if (p.harvest & 2) hv_pivot = reinterpret_cast<uint32_t*>(hb + hl.pivot);
+      if (harvested) {
+        ws.st_claimed = reinterpret_cast<uint32_t*>(hb + hl.claimed);
+        ws.st_cnt = reinterpret_cast<uint32_t*>(hb + hl.cnt);
+        ws.rec64 = reinterpret_cast<uint64_t*>(hb + hl.rec64);
+      }
+    }
+    float hv_mult = 2.0f + (p.harvest_widen > 0.0f ? p.harvest_widen : 0.25f);
+    if (!harvested || hv_pivot != nullptr) {
       int64_t sb = (p.num_blocks + 2047) / 2048;     // >= 8 steps of 64 block indices per wave
       sb = sb < 1 ? 1 : (sb > 4096 ? 4096 : sb);
       const dim3 grid((unsigned)sb), blk(256);
@@ -375,8 +414,9 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
         side = nullptr;
       }
     }
-    hipLaunchKernelGGL(stream_pivot_kernel, dim3(B), dim3(1024), 0, s, p, ws, sshift);
-    {
+    if (!harvested || hv_pivot != nullptr)
+      hipLaunchKernelGGL(stream_pivot_kernel, dim3(B), dim3(1024), 0, s, p, ws, sshift, hv_pivot, hv_mult, harvested ? 0 : 1);
+    if (!harvested) {
       // blocks of the batch / blocks of the cache: a dense cache requests the rows before it has
       // looked at the metadata, a sparse one (engine-sized cache, small batch) only the batch's rows
       const bool dense = p.total_slots >= (int64_t)p.num_blocks * p.block_size / 2;
@@ -572,4 +612,41 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     }
   }
   return check_launch("schedule_evictions");
+}
+
+// A2a with section 10's harvest: `p` describes the schedule call that will follow
+extern "C" int kvc_aggregate_decode_harvest(const kvc_schedule_params* pp, float* temp_metrics, int32_t num_queries_per_kv,
+                                            int32_t use_l2, int32_t clear_temp, kvc_stream_t stream) {
+  using namespace kvc;
+  if (pp == nullptr || temp_metrics == nullptr) return fail_invalid("aggregate_decode_harvest: null argument");
+  const kvc_schedule_params p = *pp;
+  if (p.harvest_buf == nullptr || (reinterpret_cast<uintptr_t>(p.harvest_buf) & 15) != 0)
+    return fail_invalid("aggregate_decode_harvest: harvest_buf must be a 16-byte aligned buffer of kvc_harvest_buffer_bytes()");
+  if (!kvc_harvest_eligible(pp, num_queries_per_kv))
+    return fail_invalid("aggregate_decode_harvest: the call that follows is not eligible (kvc_harvest_eligible)");
+  if (p.num_blocks <= 0) return KVC_OK;
+  const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
+  const HvLayout hl = hv_layout(G, p.num_seqs);
+  uint8_t* hb = reinterpret_cast<uint8_t*>(p.harvest_buf);
+  hipStream_t s = (hipStream_t)stream;
+  SchedWs ws{};
+  ws.st_claimed = reinterpret_cast<uint32_t*>(hb + hl.claimed);
+  ws.st_cnt = reinterpret_cast<uint32_t*>(hb + hl.cnt);
+  ws.rec64 = reinterpret_cast<uint64_t*>(hb + hl.rec64);
+  const uint32_t* hv_pivot = reinterpret_cast<const uint32_t*>(hb + hl.pivot);
+  fill32_async(hb + hl.claimed, 0u, hl.rec64 - hl.claimed, s);       // claimed | cnt
+  // a wave iteration covers 64 blocks; at most 4096 workgroups of 4 waves (grid-stride beyond)
+  int64_t cb = (p.num_blocks + 255) / 256;
+  cb = cb < 1 ? 1 : (cb > 4096 ? 4096 : cb);
+  const dim3 grid((unsigned)cb), blk(256);
+#define KVC_HARVEST(BSV)                                                                                             \
+  if (num_queries_per_kv == 4)                                                                                       \
+    hipLaunchKernelGGL((aggregate_harvest_kernel<BSV, 1>), grid, blk, 0, s, p, ws, temp_metrics, hv_pivot, use_l2, clear_temp); \
+  else                                                                                                               \
+    hipLaunchKernelGGL((aggregate_harvest_kernel<BSV, 2>), grid, blk, 0, s, p, ws, temp_metrics, hv_pivot, use_l2, clear_temp);
+  if (p.block_size == 8) { KVC_HARVEST(8); }
+  else if (p.block_size == 16) { KVC_HARVEST(16); }
+  else { KVC_HARVEST(32); }
+#undef KVC_HARVEST
+  return check_launch("aggregate_decode_harvest");
 }

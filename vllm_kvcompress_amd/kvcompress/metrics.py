@@ -165,6 +165,22 @@ class CompressionMetrics:
         self.reuse_output_buffer = os.environ.get("KVC_REUSE_OUTPUT_BUFFER", "1") not in ("", "0")
         self._eli_buf = None          # (buffer, dirty map, block size, storage use count when only we hold it, stream)
         self._small_cache = {}
+        # harvest-ahead (include/kvc_mi355x.h, ABI version 5): with compression every decode
+        # step the metric store is swept twice per step -- by aggregate_decode and, a moment later, by the
+        # small-eviction schedule's collecting pass.  ``aggregate_decode_and_harvest`` is the first sweep
+        # that also makes the second one's candidate lists (with the pivots the previous
+        # ``schedule_evictions`` left behind); the ``schedule_evictions`` that follows with the SAME batch
+        # arguments, the store untouched in between, uses them.  Anything else -- another batch, a store
+        # somebody wrote to, a larger eviction than the pivots were made for -- takes the usual pass.  Results
+        # are identical either way (lists that fall short raise the flag like any short record).
+        self.harvest_ahead = os.environ.get("KVC_HARVEST_AHEAD", "0") not in ("", "0")
+        self.harvest_widen = float(os.environ.get("KVC_HARVEST_WIDEN", "0.25"))
+        self.last_harvest_used = False     # the last schedule_evictions ran on harvested lists
+        self.harvest_misses = 0            # harvested calls whose lists fell short (flag raised, redone on device)
+        self._hv_buf = None                # pivots + lists (kvc_harvest_buffer_bytes)
+        self._hv = None                    # pivots in _hv_buf: the batch and eviction sizes they were made for
+        self._hv_lists = None              # lists in _hv_buf: the call they were made for
+        self._fb_was_harvested = False     # the flag word in flight belongs to a harvested call
 
     # temp_metrics is handed to the attention kernels, which write into it; reading the
     # attribute therefore marks it dirty so that the fused clear in aggregate_decode stays
@@ -187,6 +203,7 @@ class CompressionMetrics:
 
     def clear_kv_metadata(self) -> None:
         """reference metrics.py:205-214"""
+        self._hv = self._hv_lists = None
         self.num_blocks = None
         self.metrics = None
         self._temp_metrics = None
@@ -234,6 +251,7 @@ class CompressionMetrics:
     def insert_metadata(self, metadata) -> None:
         """reference metrics.py:344-364 (``metadata`` is a BlockMetadata-like object)"""
         pb = metadata.physical_blocks
+        self._hv_lists = None
         self.seq_index_by_block[pb] = metadata.seq_indices
         self.logical_block_num_by_block[pb] = metadata.logical_blocks.type(torch.int)
         self.layer_index_by_block[pb] = metadata.layer_indices
@@ -242,10 +260,12 @@ class CompressionMetrics:
 
     def remove_metadata(self, physical_blocks: torch.Tensor) -> None:
         """reference metrics.py:366-370"""
+        self._hv_lists = None
         self.seq_index_by_block[physical_blocks] = -1
 
     def randomize_metric_slots(self, slot_mapping: torch.Tensor) -> None:
         flat_indices = slot_mapping.flatten().type(torch.long)
+        self._hv_lists = None
         self.metrics.view(-1)[flat_indices] = torch.rand(
             flat_indices.shape, dtype=torch.float32, device=self.device)
 
@@ -254,6 +274,7 @@ class CompressionMetrics:
         """reference metrics.py:396-427: metrics[slot[t,h]] += sum_q prefill[t, h*qpk+q]"""
         if self.random:
             return
+        self._hv_lists = None
         seq_len, nq = prefill_metrics.shape
         assert nq % self.num_kv_heads == 0
         qpk = nq // self.num_kv_heads
@@ -275,6 +296,7 @@ class CompressionMetrics:
         ``clear_temp_metrics()`` free."""
         if self.random or not self.record_decoding_metrics:
             return
+        self._hv_lists = None
         lib = _lib.load()
         with torch.cuda.device(self.device):
             _lib.check(lib.kvc_aggregate_decode(
@@ -282,6 +304,141 @@ class CompressionMetrics:
                 self.num_queries_per_kv, 1 if self.use_l2 else 0, 1 if fuse_clear else 0,
                 _stream(self.metrics)))
         self._temp_clean = bool(fuse_clear)
+
+    # ------------------------------------------------------------------ harvest-ahead
+    def _store_versions(self):
+        return tuple(t._version for t in (self.metrics, self.token_positions, self.seq_index_by_block,
+                                          self.layer_index_by_block, self.head_index_by_block,
+                                          self.logical_block_num_by_block))
+
+    @staticmethod
+    def _arg_record(x):
+        """a batch argument as remembered between the harvest and its schedule call: a tensor by identity
+        and version (held, so that neither can be reused), a list by value"""
+        if isinstance(x, torch.Tensor):
+            return (x, x._version)
+        return (tuple(int(v) for v in x), None)
+
+    @staticmethod
+    def _arg_same(rec, x) -> bool:
+        if isinstance(x, torch.Tensor):
+            return rec[0] is x and rec[1] == x._version
+        return not isinstance(rec[0], torch.Tensor) and rec[0] == tuple(int(v) for v in x)
+
+    def _store_params(self, p, seq_indices, seq_pos, prot, context_lens, N: int) -> None:
+        """the fields of kvc_schedule_params that describe the store and the batch"""
+        bs, L, H, B = self.block_size, self.num_layers, self.num_kv_heads, len(seq_indices)
+        slot_of_seq = self._slot_map(seq_indices)
+        p.metrics = self.metrics.data_ptr()
+        p.token_positions = self.token_positions.data_ptr()
+        p.seq_index_by_block = self.seq_index_by_block.data_ptr()
+        p.layer_index_by_block = self.layer_index_by_block.data_ptr()
+        p.head_index_by_block = self.head_index_by_block.data_ptr()
+        p.logical_block_num_by_block = self.logical_block_num_by_block.data_ptr()
+        p.num_blocks = self.num_blocks
+        p.block_size, p.num_layers, p.num_kv_heads, p.num_seqs = bs, L, H, B
+        p.seq_slot_of_seq = slot_of_seq.data_ptr()
+        p.seq_slot_len = slot_of_seq.numel()
+        p.seq_positions = seq_pos.data_ptr()
+        p.num_protected = prot.data_ptr()
+        p.context_lens = context_lens.data_ptr()
+        p.total_slots = N
+        p.use_average = 1 if self.use_average else 0
+        p.num_sinks = int(self.num_sinks)
+        if self._has_bias or float(self.kv_metric_bias_weight) != 0.0:
+            hb = self.kv_metric_head_bias
+            self._bias_keepalive = (hb.bias.contiguous(), hb.position_bins.contiguous())
+            p.bias = self._bias_keepalive[0].data_ptr()
+            p.position_bins = self._bias_keepalive[1].data_ptr()
+            p.num_bins = self._bias_keepalive[1].numel()
+        else:
+            p.bias, p.position_bins, p.num_bins = None, None, 0
+        p.bias_weight = float(self.kv_metric_bias_weight)
+        p.mode = {"reference": 0, "per_sequence": 1}[self.schedule_mode]
+        p.null_value = MAX_INT
+        p.lean = 3 if self.lean_outputs else 0
+        p.sample_stride = int(self.sample_stride)
+        p.fallback_grid = int(self.fallback_grid)
+
+    def aggregate_decode_and_harvest(self, seq_indices: List[int], seq_positions: IntsLike, num_protected: IntsLike,
+                                     context_lens: torch.Tensor, total_slots: Optional[int] = None,
+                                     fuse_clear: bool = True) -> bool:
+        """``aggregate_decode`` (reference metrics.py:429-439; the same sums, bit for bit) for a decode step
+        whose ``schedule_evictions(seq_indices, seq_positions, ..., context_lens, ..., num_protected)``
+        follows: the pass that adds the step's attention to the store also lists, per head, the keys that
+        fall below the pivots the previous ``schedule_evictions`` left behind, and the call that follows does
+        not stream the store again (kvc_aggregate_decode_harvest, include/kvc_mi355x.h).  Not in the
+        reference's surface; opt-in (``harvest_ahead`` / ``KVC_HARVEST_AHEAD=1``).
+
+        The lists are used only by a ``schedule_evictions`` with these very arguments (tensors: the same
+        objects, unmodified; lists: equal values), evictions no larger than the ones the pivots were made
+        for, and the store (metrics, positions, block metadata) not written through this object or torch in
+        between -- a writer that goes around both (a custom kernel on ``metrics.data_ptr()``) must not run
+        between the two calls.  In every other case this is ``aggregate_decode`` and the schedule call
+        takes its usual pass.  Returns whether lists were made."""
+        if self.random or not self.record_decoding_metrics:
+            return False
+        self._poll_fallback(torch.cuda.is_current_stream_capturing())
+        hv = self._hv
+        self._hv_lists = None
+        stream = _stream(self.metrics)
+        ok = (self.harvest_ahead and hv is not None and hv["seqs"] == tuple(int(s) for s in seq_indices)
+              and hv["buf"] is self._hv_buf and hv["stream"] == stream and not self._fb_fault
+              and isinstance(context_lens, torch.Tensor) and context_lens.is_cuda and context_lens.dtype == torch.int32
+              and context_lens.is_contiguous()
+              and tuple(context_lens.shape) == (self.num_layers, len(seq_indices), self.num_kv_heads)
+              and not torch.cuda.is_current_stream_capturing())
+        p = None
+        if ok:
+            lib = _lib.load()
+            seq_pos, prot = self._as_i32(seq_positions), self._as_i32(num_protected)
+            p = KvcScheduleParams()
+            self._store_params(p, seq_indices, seq_pos, prot, context_lens, int(total_slots) if total_slots else hv["N"])
+            p.max_evicted_blocks_hint = max(hv["k"])
+            p.schedule_path = int(self.schedule_path)
+            p.harvest_buf = self._hv_buf.data_ptr()
+            ok = bool(lib.kvc_harvest_eligible(ctypes.byref(p), self.num_queries_per_kv))
+        if not ok:
+            self.aggregate_decode(fuse_clear)
+            return False
+        with torch.cuda.device(self.device):
+            _lib.check(lib.kvc_aggregate_decode_harvest(
+                ctypes.byref(p), self._temp_metrics.data_ptr(), self.num_queries_per_kv,
+                1 if self.use_l2 else 0, 1 if fuse_clear else 0, stream))
+        self._temp_clean = bool(fuse_clear)
+        self._hv_lists = dict(seqs=hv["seqs"], seq_pos=self._arg_record(seq_positions), prot=self._arg_record(num_protected),
+                              ctx=self._arg_record(context_lens), store=self._store_versions(), k=hv["k"],
+                              stream=stream, buf=self._hv_buf)
+        return True
+
+    def _lists_usable(self, hl, seq_indices, seq_positions, num_protected, context_lens, k_list, stream) -> bool:
+        return (hl is not None and hl["buf"] is self._hv_buf and hl["stream"] == stream
+                and hl["seqs"] == tuple(int(s) for s in seq_indices)
+                and self._arg_same(hl["seq_pos"], seq_positions) and self._arg_same(hl["prot"], num_protected)
+                and self._arg_same(hl["ctx"], context_lens) and hl["store"] == self._store_versions()
+                and len(k_list) == len(hl["k"]) and all(a <= b for a, b in zip(k_list, hl["k"])))
+
+    def _poll_fallback(self, capturing: bool) -> None:
+        """The flag word of an earlier small-eviction / bracket call, copied to pinned memory behind it:
+        looked at (never waited for) by the next call of this object."""
+        if self._fb_event is None or capturing or not self._fb_event.query():
+            return
+        word = int(self._fb_pin[0])
+        self._fb_event = None
+        if word & 2:
+            self._raise_fallback_fault("an earlier")
+        self._note_flag(word, self._fb_was_harvested)
+
+    def _note_flag(self, word: int, harvested: bool) -> None:
+        if harvested:
+            # lists that fell short (the device redid the call): wider pivots, made anew by a usual pass
+            if word:
+                self.harvest_misses += 1
+                self.harvest_widen = min(8.0, max(0.5, 2.0 * self.harvest_widen))
+                self._hv = self._hv_lists = None
+        elif int(self.schedule_path) == 0:
+            self._fb_penalty = min(max(2 * self._fb_penalty, 1), 64) if word else 0
+            self._fb_backoff = self._fb_penalty
 
     # ------------------------------------------------------------------ scheduling
     def _as_i32(self, x: IntsLike) -> torch.Tensor:
@@ -362,7 +519,6 @@ class CompressionMetrics:
             total_slots = int((((context_lens + (bs - 1)) // bs).sum(dtype=torch.int64) * bs).item())
         N = int(total_slots)
 
-        slot_of_seq = self._slot_map(seq_indices)
         seq_pos = self._as_i32(seq_positions)
         prot = self._as_i32(num_protected)
         k_per_seq = self._as_i32(evicted_blocks_per_seq)
@@ -372,37 +528,10 @@ class CompressionMetrics:
         out_blk = torch.empty((B, L, H), dtype=torch.int32, device=dev)
 
         p = KvcScheduleParams()
-        p.metrics = self.metrics.data_ptr()
-        p.token_positions = self.token_positions.data_ptr()
-        p.seq_index_by_block = self.seq_index_by_block.data_ptr()
-        p.layer_index_by_block = self.layer_index_by_block.data_ptr()
-        p.head_index_by_block = self.head_index_by_block.data_ptr()
-        p.logical_block_num_by_block = self.logical_block_num_by_block.data_ptr()
-        p.num_blocks = self.num_blocks
-        p.block_size, p.num_layers, p.num_kv_heads, p.num_seqs = bs, L, H, B
-        p.seq_slot_of_seq = slot_of_seq.data_ptr()
-        p.seq_slot_len = slot_of_seq.numel()
-        p.seq_positions = seq_pos.data_ptr()
-        p.num_protected = prot.data_ptr()
+        self._store_params(p, seq_indices, seq_pos, prot, context_lens, N)
         p.evicted_blocks_per_seq = k_per_seq.data_ptr()
-        p.context_lens = context_lens.data_ptr()
         p.hanging_token_count = hanging_token_count.data_ptr()
         p.evicted_kv_offsets = evicted_kv_offsets.data_ptr()
-        p.total_slots = N
-        p.use_average = 1 if self.use_average else 0
-        p.num_sinks = int(self.num_sinks)
-        if self._has_bias or float(self.kv_metric_bias_weight) != 0.0:
-            hb = self.kv_metric_head_bias
-            self._bias_keepalive = (hb.bias.contiguous(), hb.position_bins.contiguous())
-            p.bias = self._bias_keepalive[0].data_ptr()
-            p.position_bins = self._bias_keepalive[1].data_ptr()
-            p.num_bins = self._bias_keepalive[1].numel()
-        else:
-            p.bias, p.position_bins, p.num_bins = None, None, 0
-        p.bias_weight = float(self.kv_metric_bias_weight)
-        p.mode = {"reference": 0, "per_sequence": 1}[self.schedule_mode]
-        p.null_value = MAX_INT
-        p.lean = 3 if self.lean_outputs else 0
         # the reference scheduler passes a Python list (scheduler.py:184-560): its maximum picks the
         # schedule (include/kvc_mi355x.h); a device tensor would cost a sync to inspect -> unknown
         if isinstance(evicted_blocks_per_seq, torch.Tensor) and evicted_blocks_per_seq.is_cuda:
@@ -410,19 +539,10 @@ class CompressionMetrics:
         else:
             p.max_evicted_blocks_hint = int(max(evicted_blocks_per_seq))
         p.schedule_path = int(self.schedule_path)
-        p.sample_stride = int(self.sample_stride)
         capturing = torch.cuda.is_current_stream_capturing()
-        p.fallback_grid = int(self.fallback_grid)
         # the reference's other selection rule (metrics.py:639-666; its scheduler never passes it)
         p.uniform_evict = 1 if uniform_evict else 0
-        if self._fb_event is not None and not capturing and self._fb_event.query():
-            word = int(self._fb_pin[0])
-            self._fb_event = None
-            if word & 2:
-                self._raise_fallback_fault("an earlier")
-            if int(self.schedule_path) == 0:
-                self._fb_penalty = min(max(2 * self._fb_penalty, 1), 64) if word else 0
-                self._fb_backoff = self._fb_penalty
+        self._poll_fallback(capturing)
         if self._fb_fault:
             p.schedule_path = 1        # the launch chain of the digit rounds has no device-side waits
         elif p.schedule_path == 0 and self._fb_backoff > 0 and not capturing:
@@ -443,6 +563,25 @@ class CompressionMetrics:
         else:
             p.block_tables, p.seq_index_of_slot = None, None
             p.max_num_seqs, p.block_tables_width = 0, 0
+        # harvest-ahead: lists made by aggregate_decode_and_harvest for exactly this call / pivots for the next one
+        hl, self._hv_lists = self._hv_lists, None
+        p.harvest_buf, p.harvest, p.harvest_widen = None, 0, float(self.harvest_widen)
+        stream = _stream(self.metrics)
+        if (self.harvest_ahead and not capturing and p.max_evicted_blocks_hint >= 0
+                and lib.kvc_harvest_eligible(ctypes.byref(p), self.num_queries_per_kv)):
+            need = int(lib.kvc_harvest_buffer_bytes(B * L * H, B))
+            if self._hv_buf is None or self._hv_buf.numel() != need:
+                self._hv_buf = torch.zeros((need,), dtype=torch.uint8, device=dev)
+                self._hv = hl = None
+            k_list = [int(v) for v in evicted_blocks_per_seq]
+            p.harvest_buf = self._hv_buf.data_ptr()
+            p.harvest = 2
+            if self._lists_usable(hl, seq_indices, seq_positions, num_protected, context_lens, k_list, stream):
+                p.harvest |= 1
+            self._hv = dict(seqs=tuple(int(x) for x in seq_indices), k=k_list, N=N, buf=self._hv_buf, stream=stream)
+        else:
+            self._hv = None
+        self.last_harvest_used = bool(p.harvest & 1)
         p.eli_dirty_map = None
         if (self.reuse_output_buffer and not self.lean_outputs and N > 0
                 and int(lib.kvc_schedule_evictions_plan(ctypes.byref(p))) == 1):
@@ -469,9 +608,7 @@ class CompressionMetrics:
             word = int(ws[off:off + 4].view(torch.int32).item())
             if word & 2:
                 self._raise_fallback_fault("this")
-            if int(self.schedule_path) == 0:
-                self._fb_penalty = min(max(2 * self._fb_penalty, 1), 64) if word else 0
-                self._fb_backoff = self._fb_penalty
+            self._note_flag(word, bool(p.harvest & 1))
         elif self.last_schedule[2] and not capturing:
             off = self.last_schedule[1]
             if self._fb_pin is None:
@@ -479,6 +616,7 @@ class CompressionMetrics:
             if self._fb_event is None:      # (one copy in flight at a time: the pinned word is read before it is reused)
                 with torch.cuda.device(dev):
                     self._fb_pin.copy_(ws[off:off + 4].view(torch.int32), non_blocking=True)
+                    self._fb_was_harvested = bool(p.harvest & 1)
                     self._fb_event = torch.cuda.Event()
                     self._fb_event.record()
         return out_idx, out_kv, out_blk
