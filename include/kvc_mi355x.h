@@ -291,14 +291,17 @@ typedef struct kvc_schedule_params {
                                                *   pivots the lists were made with: lists that do not cover the
                                                *   selection raise the `fallback` flag like any short record.
                                                * bit 1: leave in harvest_buf the pivots for the harvest of the
-                                               *   NEXT decode step (this call's sample, aimed at what this call
-                                               *   evicts + what the next one will need: evicted_blocks_per_seq
-                                               *   taken as the next step's too, times 1 + harvest_widen).
+                                               *   NEXT decode step, made from what is left of this call's lists
+                                               *   (its own collecting pass's or harvested ones: all keys below the
+                                               *   pivot they were made with) once the selection has said what
+                                               *   leaves: the (1 + harvest_widen) * Tgt-th smallest remaining key,
+                                               *   Tgt = k * bs + sum(hang - 1) with this call's k and hang taken as
+                                               *   the next step's; extrapolated upwards when fewer are left.
                                                * Both are ignored (bit 0: an error) unless the call takes the
                                                * small-eviction schedule in its position-lazy form
                                                * (kvc_harvest_eligible). */
-  float harvest_widen;                        /* bit 1: allowance for keys that drift above the pivot during one
-                                               * decode step, as a fraction of the step's target (0.25) */
+  float harvest_widen;                        /* bit 1: allowance for keys that the next step's attention lifts over
+                                               * the pivot, as a fraction of Tgt (<= 0: 0.25) */
   /* outputs */
   int32_t* evicted_logical_indices;           /* [N] */
   int32_t* evicted_kv_count;                  /* [B,L,H] */

@@ -39,7 +39,7 @@ class Loop:
         self.ds = hdev.upload(self.st, DEV, num_queries_per_kv=qpk, mode="per_sequence")
         self.cm = self.ds.cm
         self.cm.use_l2 = use_l2
-        self.cm.harvest_ahead = True
+        assert self.cm.harvest_ahead is None     # (the first aggregate_decode_and_harvest turns it on)
         self.cm.strict_fallback = True          # (the flag word is looked at in the call itself)
         self.cm.sample_stride = stride
         self.k_np, self.v_np = synth.make_caches_u16(seed, self.st.num_blocks, 32, bs)
@@ -212,3 +212,105 @@ def test_not_eligible_calls_aggregate_as_before():
         assert not cm.last_harvest_used
         np.testing.assert_array_equal(eli.cpu().numpy(), want["eli"])
         np.testing.assert_array_equal(ekc.cpu().numpy(), want["ekc"])
+
+
+def test_switched_off_by_the_environment_variable(monkeypatch):
+    monkeypatch.setenv("KVC_HARVEST_AHEAD", "0")
+    st = synth.make_state(num_layers=2, num_kv_heads=4, block_size=16, seq_lens=[600, 300], seed=3, protected=17, steady_cap=160)
+    ds = hdev.upload(st, DEV, num_queries_per_kv=4, mode="per_sequence")
+    cm = ds.cm
+    assert cm.harvest_ahead is False
+    temp = np.random.default_rng(0).random((st.num_blocks, 16, 4)).astype(np.float32)
+    for it in range(3):
+        cm.temp_metrics.copy_(torch.from_numpy(temp))
+        orc.aggregate_decode(st.metrics, temp, use_l2=True)
+        assert not cm.aggregate_decode_and_harvest(list(st.seq_indices), ds.seq_positions, list(st.protected),
+                                                   ds.context_lens, total_slots=st.total_slots)
+        np.testing.assert_array_equal(cm.metrics.cpu().numpy(), st.metrics)
+        want = oracle_pipeline(st, [8, 8], mode="per_sequence")
+        eli, ekc, ebc, cmi, cmc = hdev.schedule(ds, st, [8, 8])
+        assert not cm.last_harvest_used and cm._hv is None
+        np.testing.assert_array_equal(eli.cpu().numpy(), want["eli"])
+
+
+class _Engine:
+    """the block state of a few resident sequences on the device, stepped with the package's own ops
+    (scheduler -> compaction -> append_slots), as the fork's engine steps its own"""
+
+    def __init__(self, st, seq_lens, cap, qpk, deferred):
+        from vllm_kvcompress_amd.kvcompress.scheduler import CompressionScheduler
+        self.bs, self.L, self.H, self.cap, self.deferred = st.block_size, st.num_layers, st.num_kv_heads, cap, deferred
+        self.ds = hdev.upload(st, DEV, num_queries_per_kv=qpk, mode="per_sequence")
+        self.cm = self.ds.cm
+        B, M = len(seq_lens), st.block_tables.shape[3] + 4
+        bt = np.zeros((self.L, B, self.H, M), np.int32)
+        bt[..., :st.block_tables.shape[3]] = st.block_tables
+        self.bt = torch.from_numpy(bt).to(DEV)
+        self.ctx = torch.from_numpy(st.context_lens.copy()).to(DEV)
+        self.fm = torch.from_numpy(st.seq_index_by_block < 0).to(DEV)
+        self.lens = np.asarray(seq_lens, np.int64).copy()
+        self.sched = CompressionScheduler(self.bs, self.L, self.H, 4 * st.total_slots, self.cm, device=DEV)
+        hd = 32
+        k_np, v_np = synth.make_caches_u16(1, st.num_blocks, hd, self.bs)
+        self.k, self.v = torch.from_numpy(k_np).to(DEV), torch.from_numpy(v_np).to(DEV)
+
+    def step(self, temp, sel):
+        from vllm_kvcompress_amd import _custom_ops as ops
+        from vllm_kvcompress_amd.kvcompress.block_state import append_slots
+        from vllm_kvcompress_amd.kvcompress.scheduler import SeqCompressionRequest
+        cm, bs = self.cm, self.bs
+        cm.temp_metrics.copy_(temp)                      # (the decode attention's output)
+        if not self.deferred:
+            cm.aggregate_decode()                        # reference order: llm_engine.py:1634
+        # the next iteration: slots for the sampled token first (block_manager.py:269-294) ...
+        self.lens += 1
+        append_slots(self.bt, self.ctx, list(range(len(self.lens))), [int(n) - 2 for n in self.lens], self.fm, cm, bs,
+                     write_token_position=True)
+        # ... then the compression of this iteration (scheduler.py:184-560)
+        ctx_h = self.ctx.cpu().numpy().astype(np.int64)
+        reqs = [SeqCompressionRequest(seq_id=100 + i, slot_index=i, seq_len=int(self.lens[i]),
+                                      block_count=int(((ctx_h[:, i] + bs - 1) // bs).sum()), kv_count=int(ctx_h[:, i].sum()),
+                                      max_cache_tokens=self.cap, protected_window_size=bs + 1) for i in sel]
+        out = self.sched.schedule_compression(reqs, self.bt, self.ctx, force=True, free_mask=self.fm,
+                                              aggregate_decode=self.deferred)
+        res = dict(metrics=cm.metrics.clone(), used=cm.last_harvest_used if out is not None else None)
+        if out is not None:
+            res.update(cmc=out.cache_moves.count.clone(), cmi=out.cache_moves.index.clone(), freed=out.freed_blocks.clone()
+                       if hasattr(out, "freed_blocks") else None, slots=list(out.slot_indices))
+            ops.execute_cache_moves(self.k, self.v, cm.metrics, cm.token_positions, out.cache_moves.index,
+                                    out.cache_moves.count, out.cache_moves.offsets, 1, 16)
+        res.update(ctx=self.ctx.clone(), seq=cm.seq_index_by_block.clone(), after=cm.metrics.clone(),
+                   pos=cm.token_positions.clone(), k=self.k.clone())
+        return res
+
+
+def test_scheduler_that_was_left_the_aggregate_gives_what_the_reference_order_gives():
+    """``CompressionScheduler.schedule_compression(..., aggregate_decode=True)``: the engine leaves the
+    decode step's aggregate_decode to the next reader of the metrics, the compression of the next
+    iteration, where it runs as the harvesting pass (or as the plain one when nothing is compressed).
+    Two engines on the device, one in the reference's order (llm_engine.py:1634 then scheduler.py:492),
+    stepped with the same attention mass: every piece of state equal after every step."""
+    L, H, bs, cap, qpk = 2, 4, 16, 320, 4
+    seq_lens = [700, 420, 555, 610]
+    st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs, seq_lens=seq_lens, seed=8, protected=bs + 1,
+                          spare_block_frac=0.8, steady_cap=cap)
+    a = _Engine(copy.deepcopy(st), seq_lens, cap, qpk, deferred=False)
+    b = _Engine(copy.deepcopy(st), seq_lens, cap, qpk, deferred=True)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(5)
+    used = 0
+    for it in range(30):
+        temp = torch.rand((st.num_blocks, bs, qpk), device=DEV, generator=g)
+        sel = [0, 1, 2, 3] if it % 7 != 5 else [1, 3]          # (now and then only some sequences compress)
+        if it == 20:
+            sel = []                                             # ... or none: the plain pass, once
+        ra, rb = a.step(temp, sel), b.step(temp, sel)
+        for key in ("metrics", "cmc", "cmi", "ctx", "seq", "after", "pos", "k"):
+            if ra.get(key) is None:
+                assert rb.get(key) is None, key
+                continue
+            assert torch.equal(ra[key].view(torch.int32) if ra[key].dtype == torch.float32 else ra[key],
+                               rb[key].view(torch.int32) if rb[key].dtype == torch.float32 else rb[key]), f"step {it}: {key}"
+        assert not ra["used"]
+        used += bool(rb["used"])
+    assert used >= 15, used

@@ -25,6 +25,15 @@ def _stream(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+def _written(*tensors: torch.Tensor) -> None:
+    """The kernels write through raw pointers, which torch's version counters do not see; consumers that
+    ask "has anybody written to this tensor since?" (CompressionMetrics' harvest-ahead lists, the tracked
+    move table) get the answer they would get after an in-place torch op."""
+    for t in tensors:
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -280,6 +289,8 @@ def _execute_cache_moves(k_cache, v_cache, kv_metrics, kv_position, cache_moves_
     # a list that schedule_cache_moves made on this stream and nobody touched since brings its plan
     # along: ONE launch (no planning pass, no claim table); any other list plans for itself
     plan = _plan_of(k_cache, cache_moves_indices, cache_moves_count, evicted_kv_offsets, total_heads, block_size)
+    if half != "plan":
+        _written(kv_metrics, kv_position)
     if plan is not None:
         if half != "plan":
             with torch.cuda.device(k_cache.device):
@@ -331,6 +342,7 @@ def reshape_and_cache_kvc(
     block_size = key_cache.shape[2]
     sm = slot_mapping.contiguous()
     hb = kv_metric_head_bias.contiguous()
+    _written(kv_metrics)
     if kv_cache_dtype == "auto":
         if key.dtype != key_cache.dtype or value.dtype != value_cache.dtype:
             raise RuntimeError("reshape_and_cache_kvc: kv_cache_dtype 'auto' needs cache dtype == "
@@ -537,6 +549,7 @@ def paged_attention_kvc_fused_metrics(out, metrics, query, key_cache, value_cach
             raise RuntimeError("paged_attention_kvc_fused_metrics: temp_metrics must be contiguous "
                                "with at least num_blocks * block_size * qpk elements")
         tm = temp_metrics
+    _written(metrics)
     _paged_attention_kvc(out, None, es, ml, to, tm, query, key_cache, value_cache, num_kv_heads,
                          scale, block_tables, context_lens, kv_position, last_position,
                          kv_metric_buffer_len, block_size, max_context_len, alibi_slopes,

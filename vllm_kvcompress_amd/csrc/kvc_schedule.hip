@@ -390,8 +390,8 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
         ws.rec64 = reinterpret_cast<uint64_t*>(hb + hl.rec64);
       }
     }
-    float hv_mult = 2.0f + (p.harvest_widen > 0.0f ? p.harvest_widen : 0.25f);
-    if (!harvested || hv_pivot != nullptr) {
+    const float hv_widen = p.harvest_widen > 0.0f ? p.harvest_widen : 0.25f;
+    if (!harvested) {
       int64_t sb = (p.num_blocks + 2047) / 2048;     // >= 8 steps of 64 block indices per wave
       sb = sb < 1 ? 1 : (sb > 4096 ? 4096 : sb);
       const dim3 grid((unsigned)sb), blk(256);
@@ -414,8 +414,7 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
         side = nullptr;
       }
     }
-    if (!harvested || hv_pivot != nullptr)
-      hipLaunchKernelGGL(stream_pivot_kernel, dim3(B), dim3(1024), 0, s, p, ws, sshift, hv_pivot, hv_mult, harvested ? 0 : 1);
+    if (!harvested) hipLaunchKernelGGL(stream_pivot_kernel, dim3(B), dim3(1024), 0, s, p, ws, sshift);
     if (!harvested) {
       // blocks of the batch / blocks of the cache: a dense cache requests the rows before it has
       // looked at the metadata, a sparse one (engine-sized cache, small batch) only the batch's rows
@@ -443,6 +442,8 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
       hipLaunchKernelGGL(seq_prepare_kernel, dim3(1), dim3(1024), prep_lds, s, p, ws);
     }
     hipLaunchKernelGGL(seq_select_topk_kernel, dim3(B), dim3(1024), (size_t)topk_p2 * 8 + (size_t)LH * 4, s, p, ws, topk_p2, coupled_tk);
+    // the pivots for the next decode step's harvest, from what is left of this call's lists (section 10)
+    if (hv_pivot != nullptr) hipLaunchKernelGGL(harvest_pivot_kernel, dim3(B), dim3(1024), 0, s, p, ws, hv_pivot, harvested ? 1 : 0, hv_widen);
     if (side != nullptr && hipStreamWaitEvent(s, side->join, 0) != hipSuccess) {
       (void)hipGetLastError();
       (void)hipStreamSynchronize(side->s2);          // (the emission below must not race the fill)

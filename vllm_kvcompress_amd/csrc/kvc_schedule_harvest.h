@@ -13,19 +13,32 @@ namespace kvc {
 // (reference metrics.py:429-439: metrics += sum_q temp^2, the whole cache, 4 * qpk + 8 B per slot)
 // and, right behind it, stream_collect_kernel (section 7: 4 + 1 B per candidate slot, to find the
 // ~1 % of the keys below each sequence's pivot).  The sums pass through registers in the first
-// sweep: this kernel is aggregate_decode_kernel with section 7's harvest behind the add -- the
-// second sweep disappears.  What it cannot know is the pivot, a quantile of the sums it is making;
-// it uses the one the PREVIOUS schedule call left in the harvest buffer (stream_pivot_kernel,
-// aimed past what that call evicts at what this one will need).  Exactness does not depend on how
-// good that guess is: the records made from these lists hold EVERY evictable key below the pivot
-// that was used, so the selection is exact as soon as they list k' thresholds -- or the flag is
-// raised, as for any record that falls short (section 7).
+// sweep: aggregate_harvest_kernel is aggregate_decode_kernel with section 7's harvest behind the
+// add -- the second sweep disappears.  What it cannot know is the pivot, a quantile of the sums it
+// is making; it uses the one the PREVIOUS schedule call left in the harvest buffer.  Exactness
+// does not depend on how good that guess is: the records made from these lists hold EVERY
+// evictable key below the pivot that was used, so the selection is exact as soon as they list k'
+// thresholds -- or the flag is raised, as for any record that falls short (section 7).
 //
-// Layout: the plain kernel's -- a lane per slot, rows of 64 consecutive slots, the temp row as
-// qpk / 4 16-byte loads per lane -- so that the arithmetic (and its order) is the plain kernel's.
-// A wave iteration covers 64 blocks = BS rows: lane b looks after the metadata of block b (one
-// coalesced load per table, as in section 7) and hands pivot / head / position bound to the rows'
-// lanes by shuffles; U = 4 rows are in flight at a time.
+// The next pivot comes from the lists themselves (harvest_pivot_kernel, one workgroup per sequence
+// behind the selection): a call's lists -- its own collecting pass's or harvested ones -- are ALL
+// the sequence's evictable keys below the pivot they were made with, sorted per head, and the
+// selection has just said which of them leave.  Metrics only grow (sums of squares / of softmax
+// weights), so what lies below a pivot at the next step is what is left of the list, less the
+// keys the step's attention lifts over it, plus the keys that leave the protected window.  With
+// target = (1 + widen) x Tgt (Tgt = k * bs + sum(hang - 1): the count that guarantees k listed
+// thresholds, section 7):  enough keys left -> the pivot is the target-th smallest of them (an
+// exact count, no sample, no margin for a sample's error: a 1/64 sample needs 2.6 x Tgt for the
+// same safety);  fewer -> the old pivot moved up by the width the missing keys would take at the
+// density of the list's upper quarter, twice over (overshoot is corrected by the next step's exact
+// count; metrics space, not key space: linear where the density is).  No sampling pass and no
+// pivot kernel on harvested steps.
+//
+// Layout of the aggregation: the plain kernel's -- a lane per slot, rows of 64 consecutive slots,
+// the temp row as qpk / 4 16-byte loads per lane -- so that the arithmetic (and its order) is the
+// plain kernel's.  A wave iteration covers 64 blocks = BS rows: lane b looks after the metadata of
+// block b (one coalesced load per table, as in section 7) and hands pivot / head / position bound
+// to the rows' lanes by shuffles; U = 4 rows are in flight at a time.
 struct HvLayout { size_t pivot, claimed, cnt, rec64, total; };
 inline HvLayout hv_layout(int32_t G, int32_t B) {
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
@@ -155,6 +168,101 @@ __global__ __launch_bounds__(256) void aggregate_harvest_kernel(kvc_schedule_par
   if (lane == 0 && claimed) atomicAdd(&claimed_s, claimed);
   __syncthreads();
   if (threadIdx.x == 0 && claimed_s) atomicAdd(&ws.st_claimed[(blockIdx.x % CLAIM_SHARDS) * 32], claimed_s);
+}
+
+__device__ __forceinline__ float key_to_float(uint32_t k) {      // inverse of float_to_key
+  return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
+}
+
+constexpr int HVP_LDS_KEYS = 12288;                  // keys of a sequence staged in LDS (more: read from L2 every round)
+
+// One workgroup per sequence, behind seq_select_topk_kernel: the pivot for the harvest of the next
+// decode step from what is left of this call's lists (see the head of this section).
+//   used_pivot: the pivots the lists were made with (the harvest buffer's own for harvested lists
+//   -- read before they are overwritten -- or nullptr: st_seqrec's, this call's collecting pass)
+__global__ __launch_bounds__(1024) void harvest_pivot_kernel(kvc_schedule_params p, SchedWs ws, uint32_t* hv_pivot,
+                                                              int from_harvest, float widen) {
+  __shared__ __attribute__((aligned(16))) uint32_t hist[RADIX];
+  __shared__ uint32_t bc[4];
+  __shared__ uint32_t pre_s[PIV_MAXLH + 1];          // exclusive prefix of the heads' remaining entries
+  __shared__ uint16_t start_s[PIV_MAXLH];            // first remaining entry of a head's record (= its evicted count)
+  __shared__ uint32_t wsum_s[16];
+  __shared__ uint32_t hang_s;
+  __shared__ __attribute__((aligned(16))) uint32_t keys_s[HVP_LDS_KEYS];
+  const int i = blockIdx.x, tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+  const int LH = p.num_layers * p.num_kv_heads, bs = p.block_size;
+  if (tid == 0) hang_s = 0;
+  __syncthreads();
+  {
+    uint32_t r = 0, hs = 0;
+    if (tid < LH) {                                  // LH <= 1024 = blockDim
+      const int64_t g = (int64_t)i * LH + tid;
+      const uint32_t C = min(ws.st_cnt[g], (uint32_t)KREC);
+      const uint32_t cnt = min((uint32_t)max(p.evicted_kv_count[g], 0), C);
+      r = C - cnt;
+      start_s[tid] = (uint16_t)cnt;
+      const uint32_t hang = (uint32_t)p.hanging_token_count[g];
+      hs = hang >= 1u ? hang - 1u : 0u;
+    }
+    const uint32_t inc = wave_inclusive_scan(r);
+    if (lane == WAVE - 1) wsum_s[w] = inc;
+    hs = wave_reduce_sum(hs);
+    if (lane == 0 && hs) atomicAdd(&hang_s, hs);
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int q = 0; q < w; ++q) woff += wsum_s[q];
+    if (tid < LH) pre_s[tid] = woff + inc - r;
+    if (tid == LH - 1) pre_s[LH] = woff + inc;
+  }
+  __syncthreads();
+  const uint32_t R = pre_s[LH];
+  const int k = p.evicted_blocks_per_seq[i];
+  const uint32_t used = from_harvest ? hv_pivot[i] : ws.st_seqrec[i].pivot_excl;
+  if (k <= 0) {                                      // nothing asked of this sequence: lists made for nothing say nothing new
+    if (tid == 0 && !from_harvest) hv_pivot[i] = 0u;
+    return;
+  }
+  __syncthreads();                                   // (everybody has read the old pivot before it is written below)
+  auto key_at = [&](uint32_t x) -> uint32_t {        // flat index x < R -> the key of that remaining entry
+    int lo = 0, hi = LH;                             // pre_s[lo] <= x < pre_s[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (pre_s[mid] <= x) lo = mid; else hi = mid;
+    }
+    const int64_t e = ((int64_t)i * LH + lo) * KREC + start_s[lo] + (x - pre_s[lo]);
+    return (uint32_t)(ws.rec64[e] >> 32);
+  };
+  const bool staged = R <= (uint32_t)HVP_LDS_KEYS;
+  if (staged) {
+    for (uint32_t x = tid; x < R; x += 1024u) keys_s[x] = key_at(x);
+    __syncthreads();
+  }
+  auto val = [&](int x) -> uint32_t { return staged ? keys_s[x] : key_at((uint32_t)x); };
+  auto all = [&](int) { return true; };
+  const double tgt = (double)k * bs + (double)hang_s;
+  const double want = ceil(tgt * (1.0 + (double)widen)) + 8.0;
+  const uint32_t target = want < 4.0e9 ? (uint32_t)want : 0xFFFFFFFFu;
+  uint32_t next;
+  if (R >= target) {
+    uint32_t P, r2, e2;
+    block_radix_select(hist, bc, (int)R, target, val, all, P, r2, e2);
+    next = P + 1u;                                   // (P < used <= KEY_INF)
+  } else if (used >= KEY_INF) {
+    next = KEY_INF;                                  // every evictable key was a candidate, and they are fewer than the target
+  } else if (R < 2u || used == 0u) {
+    next = used;                                     // (nothing to measure a density on)
+  } else {
+    const uint32_t m = max(R / 4u, 1u);
+    uint32_t Kq, r2, e2;
+    block_radix_select(hist, bc, (int)R, R - m, val, all, Kq, r2, e2);
+    const float fH = key_to_float(used - 1u), fq = key_to_float(Kq);
+    float df = (fH - fq) * ((float)(target - R) / (float)m) * 2.0f;
+    if (!(df > 0.0f)) df = fabsf(fH) * 1e-3f + 1e-30f;           // (ties at the top of the list)
+    const float fn = fH + df;
+    next = (fn == fn && fn < __builtin_inff()) ? min(float_to_key(fn) + 1u, KEY_INF) : KEY_INF;
+    if (next < used) next = used;
+  }
+  if (tid == 0) hv_pivot[i] = next;
 }
 
 }  // namespace kvc

@@ -187,11 +187,7 @@ __global__ __launch_bounds__(256) void stream_sample_kernel(kvc_schedule_params 
 #endif
 constexpr int PIV_R = 48;
 constexpr int PIV_MAXLH = 1024;                      // heads per sequence (the host checked)
-__global__ __launch_bounds__(1024) void stream_pivot_kernel(kvc_schedule_params p, SchedWs ws, int sshift,
-                                                            uint32_t* hv_out, float hv_mult, int want_cur) {
-  // hv_out (harvest-ahead, section 10): a second pivot per sequence for the harvest of the NEXT decode
-  // step, the same quantile rule aimed at hv_mult x this call's target (what this call evicts is still
-  // in the sample); want_cur = 0: this call's own pivot is not needed (its lists were harvested)
+__global__ __launch_bounds__(1024) void stream_pivot_kernel(kvc_schedule_params p, SchedWs ws, int sshift) {
   __shared__ __attribute__((aligned(16))) uint32_t hist[RADIX];
   __shared__ uint32_t bc[4];
   __shared__ uint32_t tot_s[3];                      // blocks, sampled blocks, sum(hang - 1)
@@ -230,7 +226,6 @@ __global__ __launch_bounds__(1024) void stream_pivot_kernel(kvc_schedule_params 
   const int k = p.evicted_blocks_per_seq[i];
   SeqRec rec;
   rec.seq_pos = p.seq_positions[i]; rec.prot = p.num_protected[i]; rec.pivot_excl = 0u; rec.pad = 0u;
-  uint32_t hv_piv = 0u;                              // (0: nothing lies below it)
   // flat index x < n_keys -> address in the key scratch
   auto locate = [&](uint32_t x) {
     int lo = 0, hi = LH;                             // pre_s[lo] <= x < pre_s[hi]
@@ -240,19 +235,15 @@ __global__ __launch_bounds__(1024) void stream_pivot_kernel(kvc_schedule_params 
     }
     return (int64_t)p.evicted_kv_offsets[i * LH + lo] + (x - pre_s[lo]);
   };
-  // rank in the sample for a target of tgt evictable keys in the sequence
-  auto rank_for = [&](double tgt) {
-    if (sshift == 0) return tgt;
-    const double x = tgt * (double)ns / (double)nb;
-    return ceil(x + KVC_PIV_SIGMAS * sqrt(x) + 8.0);
-  };
   if (k > 0 && nb > 0) {
     const double tgt = (double)k * bs + (double)hs;
-    const double rho = rank_for(tgt);
-    const double rho_hv = rank_for(tgt * (double)hv_mult);
+    double rho = tgt;
+    if (sshift > 0) {
+      const double x = tgt * (double)ns / (double)nb;
+      rho = ceil(x + KVC_PIV_SIGMAS * sqrt(x) + 8.0);
+    }
     if (n_keys == 0u) {
       rec.pivot_excl = KEY_INF;                      // an empty sample: every evictable key is a candidate
-      hv_piv = KEY_INF;
     } else if (n_keys <= (uint32_t)PIV_R * 1024u) {
       // ---- the sample in registers: a thread takes units of 8 consecutive keys (32 B; sample
       // lengths are multiples of bs >= 8), one bisection per unit
@@ -270,54 +261,48 @@ __global__ __launch_bounds__(1024) void stream_pivot_kernel(kvc_schedule_params 
         key[r] = k0.x; key[r + 1] = k0.y; key[r + 2] = k0.z; key[r + 3] = k0.w;
         key[r + 4] = k1.x; key[r + 5] = k1.y; key[r + 6] = k1.z; key[r + 7] = k1.w;
       }
-      // the rho-th smallest evictable key of the registers' sample (+ 1: exclusive), KEY_INF if there are not that many
-      auto select_regs = [&](double rho_v) -> uint32_t {
-        uint32_t prefix = 0, rank = 0;
-        bool all = false;
-        for (int round = 0; round < 4; ++round) {
-          const int shift = 24 - 8 * round;
-          if (tid < RADIX) hist[tid] = 0;
-          __syncthreads();
+      uint32_t prefix = 0, rank = 0;
+      bool all = false;
+      for (int round = 0; round < 4; ++round) {
+        const int shift = 24 - 8 * round;
+        if (tid < RADIX) hist[tid] = 0;
+        __syncthreads();
 #pragma unroll
-          for (int r = 0; r < PIV_R; ++r) {
-            if ((uint32_t)(r / 8) * 8192u >= n_keys) break;  // (uniform)
-            const bool valid = key[r] < KEY_INF && (round == 0 || (key[r] >> (shift + 8)) == prefix);
-            hist_add(hist, valid, (key[r] >> shift) & 0xFFu);
-          }
-          __syncthreads();
-          if (tid < WAVE) {                            // 256-bin inclusive scan, 4 bins per lane
-            uint4 q = reinterpret_cast<uint4*>(hist)[tid];
-            q.y += q.x; q.z += q.y; q.w += q.z;
-            const uint32_t inc = wave_inclusive_scan(q.w);
-            const uint32_t ex = inc - q.w;
-            uint32_t rk = rank;
-            if (round == 0) {                          // all evictable keys of the sample = the last bin's count
-              const uint32_t fin = (uint32_t)__shfl((int)inc, WAVE - 1, 64);
-              rk = (fin == 0u || rho_v >= (double)fin) ? 0u : (uint32_t)rho_v;
-              if (tid == 0) bc[2] = rk;
-            }
-            const uint32_t c[4] = {q.x + ex, q.y + ex, q.z + ex, q.w + ex};
-            uint32_t prev = ex;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              if (prev < rk && rk <= c[t]) { bc[0] = (uint32_t)tid * 4u + (uint32_t)t; bc[1] = prev; }
-              prev = c[t];
-            }
-          }
-          __syncthreads();
-          if (round == 0) {
-            rank = bc[2];
-            if (rank == 0u) { all = true; break; }     // (uniform) every evictable key is a candidate
-          }
-          prefix = (prefix << 8) | bc[0];
-          rank -= bc[1];
-          __syncthreads();
+        for (int r = 0; r < PIV_R; ++r) {
+          if ((uint32_t)(r / 8) * 8192u >= n_keys) break;  // (uniform)
+          const bool valid = key[r] < KEY_INF && (round == 0 || (key[r] >> (shift + 8)) == prefix);
+          hist_add(hist, valid, (key[r] >> shift) & 0xFFu);
         }
-        __syncthreads();                               // (bc is written again by a second select)
-        return all ? KEY_INF : prefix + 1u;            // prefix < KEY_INF
-      };
-      if (want_cur) rec.pivot_excl = select_regs(rho);
-      if (hv_out != nullptr) hv_piv = select_regs(rho_hv);
+        __syncthreads();
+        if (tid < WAVE) {                            // 256-bin inclusive scan, 4 bins per lane
+          uint4 q = reinterpret_cast<uint4*>(hist)[tid];
+          q.y += q.x; q.z += q.y; q.w += q.z;
+          const uint32_t inc = wave_inclusive_scan(q.w);
+          const uint32_t ex = inc - q.w;
+          uint32_t rk = rank;
+          if (round == 0) {                          // all evictable keys of the sample = the last bin's count
+            const uint32_t fin = (uint32_t)__shfl((int)inc, WAVE - 1, 64);
+            rk = (fin == 0u || rho >= (double)fin) ? 0u : (uint32_t)rho;
+            if (tid == 0) bc[2] = rk;
+          }
+          const uint32_t c[4] = {q.x + ex, q.y + ex, q.z + ex, q.w + ex};
+          uint32_t prev = ex;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            if (prev < rk && rk <= c[t]) { bc[0] = (uint32_t)tid * 4u + (uint32_t)t; bc[1] = prev; }
+            prev = c[t];
+          }
+        }
+        __syncthreads();
+        if (round == 0) {
+          rank = bc[2];
+          if (rank == 0u) { all = true; break; }     // (uniform) every evictable key is a candidate
+        }
+        prefix = (prefix << 8) | bc[0];
+        rank -= bc[1];
+        __syncthreads();
+      }
+      rec.pivot_excl = all ? KEY_INF : prefix + 1u;  // prefix < KEY_INF
     } else {
       // ---- a sample too long for the registers: every round re-reads it
       auto pred = [&](int x) { return ws.keys[locate((uint32_t)x)] < KEY_INF; };
@@ -329,21 +314,16 @@ __global__ __launch_bounds__(1024) void stream_pivot_kernel(kvc_schedule_params 
       if (lane == 0 && fin) atomicAdd(&fin_s, fin);
       __syncthreads();
       fin = fin_s;
-      auto select_long = [&](double rho_v) -> uint32_t {
-        if (fin == 0 || rho_v >= (double)fin) return KEY_INF;   // every evictable key is a candidate
+      if (fin == 0 || rho >= (double)fin) {
+        rec.pivot_excl = KEY_INF;                    // every evictable key is a candidate
+      } else {
         uint32_t P, r2, e2;
-        block_radix_select(hist, bc, n, (uint32_t)rho_v, val, pred, P, r2, e2);
-        __syncthreads();
-        return P + 1u;                                 // P < KEY_INF
-      };
-      if (want_cur) rec.pivot_excl = select_long(rho);
-      if (hv_out != nullptr) hv_piv = select_long(rho_hv);
+        block_radix_select(hist, bc, n, (uint32_t)rho, val, pred, P, r2, e2);
+        rec.pivot_excl = P + 1u;                     // P < KEY_INF
+      }
     }
   }
-  if (tid == 0) {
-    ws.st_seqrec[i] = rec;
-    if (hv_out != nullptr) hv_out[i] = hv_piv;
-  }
+  if (tid == 0) ws.st_seqrec[i] = rec;
 }
 
 // THE pass: metrics / positions / per-block metadata in physical order.  BS/4 lanes own a block's

@@ -49,6 +49,8 @@ def free_compressed_blocks(
         fm_ptr = free_mask.data_ptr()
     ws_bytes = lib.kvc_free_compressed_blocks_workspace_bytes(L, B, H)
     ws = workspace(dev, ws_bytes, "free_compressed_blocks")
+    for t in (context_lens, seq_index_by_block):       # (written through raw pointers: tell the version counters)
+        torch.autograd.graph.increment_version(t)
     with torch.cuda.device(dev):
         _lib.check(lib.kvc_free_compressed_blocks(
             context_lens.data_ptr(), seq_index_by_block.data_ptr(), fm_ptr, freed.data_ptr(), cap,
@@ -97,6 +99,10 @@ def append_slots(
     ws_bytes = lib.kvc_append_slots_workspace_bytes(L, B, H, NB)
     ws = workspace(dev, ws_bytes, "append_slots")
     cm = kv_metrics
+    # (written through raw pointers: say so to whoever asks the tensors' version counters)
+    for t in (cm.seq_index_by_block, cm.layer_index_by_block, cm.head_index_by_block, cm.logical_block_num_by_block,
+              cm.token_positions, context_lens, block_tables):
+        torch.autograd.graph.increment_version(t)
     with torch.cuda.device(dev):
         _lib.check(lib.kvc_append_slots(
             context_lens.data_ptr(), block_tables.data_ptr(), free_mask.data_ptr(),

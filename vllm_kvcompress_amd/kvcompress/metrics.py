@@ -173,7 +173,10 @@ class CompressionMetrics:
         # arguments, the store untouched in between, uses them.  Anything else -- another batch, a store
         # somebody wrote to, a larger eviction than the pivots were made for -- takes the usual pass.  Results
         # are identical either way (lists that fall short raise the flag like any short record).
-        self.harvest_ahead = os.environ.get("KVC_HARVEST_AHEAD", "0") not in ("", "0")
+        # None = from the first aggregate_decode_and_harvest on (the schedule calls of an engine that never
+        # harvests do not pay for pivots nobody uses); KVC_HARVEST_AHEAD=0 / 1 = never / from the first call on
+        env = os.environ.get("KVC_HARVEST_AHEAD", "")
+        self.harvest_ahead = None if env == "" else env != "0"
         self.harvest_widen = float(os.environ.get("KVC_HARVEST_WIDEN", "0.25"))
         self.last_harvest_used = False     # the last schedule_evictions ran on harvested lists
         self.harvest_misses = 0            # harvested calls whose lists fell short (flag raised, redone on device)
@@ -368,7 +371,7 @@ class CompressionMetrics:
         follows: the pass that adds the step's attention to the store also lists, per head, the keys that
         fall below the pivots the previous ``schedule_evictions`` left behind, and the call that follows does
         not stream the store again (kvc_aggregate_decode_harvest, include/kvc_mi355x.h).  Not in the
-        reference's surface; opt-in (``harvest_ahead`` / ``KVC_HARVEST_AHEAD=1``).
+        reference's surface: calling it is the opt-in (``KVC_HARVEST_AHEAD=0`` makes it a plain ``aggregate_decode``).
 
         The lists are used only by a ``schedule_evictions`` with these very arguments (tensors: the same
         objects, unmodified; lists: equal values), evictions no larger than the ones the pivots were made
@@ -378,6 +381,8 @@ class CompressionMetrics:
         takes its usual pass.  Returns whether lists were made."""
         if self.random or not self.record_decoding_metrics:
             return False
+        if self.harvest_ahead is None:
+            self.harvest_ahead = True
         self._poll_fallback(torch.cuda.is_current_stream_capturing())
         hv = self._hv
         self._hv_lists = None
@@ -406,6 +411,7 @@ class CompressionMetrics:
                 ctypes.byref(p), self._temp_metrics.data_ptr(), self.num_queries_per_kv,
                 1 if self.use_l2 else 0, 1 if fuse_clear else 0, stream))
         self._temp_clean = bool(fuse_clear)
+        torch.autograd.graph.increment_version(self.metrics)     # (written through a raw pointer)
         self._hv_lists = dict(seqs=hv["seqs"], seq_pos=self._arg_record(seq_positions), prot=self._arg_record(num_protected),
                               ctx=self._arg_record(context_lens), store=self._store_versions(), k=hv["k"],
                               stream=stream, buf=self._hv_buf)

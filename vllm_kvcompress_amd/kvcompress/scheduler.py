@@ -133,18 +133,27 @@ class CompressionScheduler:
     # ---- reference scheduler.py:565-574 ---------------------------------------------------
     def schedule_compression(self, requests: List[SeqCompressionRequest],
                              block_tables: torch.Tensor, context_lens: torch.Tensor,
-                             force: bool = False, free_mask: Optional[torch.Tensor] = None
-                             ) -> Optional[CompressionOutputs]:
+                             force: bool = False, free_mask: Optional[torch.Tensor] = None,
+                             aggregate_decode: bool = False) -> Optional[CompressionOutputs]:
+        """``aggregate_decode=True`` (not in the reference's signature): the last decode step's
+        ``kv_metrics.aggregate_decode()`` (llm_engine.py:1634) has NOT run yet -- the engine left it to
+        this call, which is the next reader of the metrics.  It then runs here exactly once: as
+        ``aggregate_decode_and_harvest`` with the batch of the ``schedule_evictions`` right behind it
+        (one sweep of the metric store instead of two), or as the plain pass when
+        nothing is compressed this iteration.  The sums, and everything computed from them, are the
+        same as with the reference's order."""
         self.iteration_count += 1
         if force or (self.iteration_count >= self.compression_interval
                      or (self.new_token_limit > -1 and self.new_tokens > self.new_token_limit)):
             self.iteration_count = 0
             self.new_tokens = 0
-            return self._schedule_compression(requests, block_tables, context_lens, free_mask)
+            return self._schedule_compression(requests, block_tables, context_lens, free_mask, aggregate_decode)
+        if aggregate_decode:
+            self.compression_metrics.aggregate_decode()
         return None
 
     # ---- reference scheduler.py:184-560 ---------------------------------------------------
-    def _schedule_compression(self, requests, block_tables, context_lens, free_mask):
+    def _schedule_compression(self, requests, block_tables, context_lens, free_mask, aggregate_decode=False):
         bs, L, H = self.block_size, self.num_layers, self.num_kv_heads
         total_kv_count = 0
         chosen: List[SeqCompressionRequest] = []
@@ -161,6 +170,8 @@ class CompressionScheduler:
             chosen.append(req)
             evicted_blocks.append(n)
         if not chosen:
+            if aggregate_decode:
+                self.compression_metrics.aggregate_decode()
             return None
         order = sorted(range(len(chosen)), key=lambda i: chosen[i].slot_index)   # :235-238
         chosen = [chosen[i] for i in order]
@@ -177,11 +188,14 @@ class CompressionScheduler:
         total_slots = int(per_head[-1].item())
         offsets = (torch.cat([torch.zeros_like(per_head[:1]), per_head[:-1]])
                    .reshape(B, L, H).type(torch.int32).contiguous())
+        protected = [r.protected_window_size for r in chosen]
+        if aggregate_decode:
+            self.compression_metrics.aggregate_decode_and_harvest(slots, last_token_positions, protected, ctx,
+                                                                  total_slots=total_slots)
         if total_slots > self.max_kv_per_compression:
             raise RuntimeError("compression batch exceeds max_kv_per_compression")
         eli, ekc, ebc = self.compression_metrics.schedule_evictions(
-            slots, last_token_positions, evicted_blocks, ctx, hanging, offsets,
-            [r.protected_window_size for r in chosen], total_slots=total_slots)
+            slots, last_token_positions, evicted_blocks, ctx, hanging, offsets, protected, total_slots=total_slots)
         cache_moves_count = torch.empty((B, L, H), dtype=torch.int32, device=self.device)
         if self.zero_fill_moves:
             ops.schedule_cache_moves(self.cache_move_indices, cache_moves_count, eli, ekc, offsets,
