@@ -134,6 +134,12 @@ def test_default_line_carries_the_other_configurations():
         assert o["stages_ms"]["S1_schedule_evictions"] > 0 and 0 < o["roofline"]["frac"] < 1
         assert 0 < o["roofline"]["frac_of_floor"] < 1.2 and o["S1_lower_bound_GBps"] > 0
     assert oc["c3"]["S1_schedule"] == "small_eviction" and oc["c5"]["S1_schedule"] == "bracket"
+    # ... and configs[2] as a whole decode step (S0 + S1 + S2 + S3): two sweeps of the store against harvest-ahead
+    ds = oc["c3"]["decode_step"]
+    assert ds["parity_checked"]["bit_exact"] is True and ds["parity_checked"]["variants_agree"] is True
+    assert ds["two_sweeps"]["harvested_steps"] == 0 and ds["harvest_ahead"]["harvested_steps"] == 2
+    assert ds["harvest_ahead"]["stages_ms"]["S1_schedule_evictions"] < ds["two_sweeps"]["stages_ms"]["S1_schedule_evictions"]
+    assert "decode_step" not in oc["c5"]
 
 
 def test_engine_leg_traffic_is_measured_live():

@@ -374,8 +374,8 @@ class CompressionMetrics:
         reference's surface: calling it is the opt-in (``KVC_HARVEST_AHEAD=0`` makes it a plain ``aggregate_decode``).
 
         The lists are used only by a ``schedule_evictions`` with these very arguments (tensors: the same
-        objects, unmodified; lists: equal values), evictions no larger than the ones the pivots were made
-        for, and the store (metrics, positions, block metadata) not written through this object or torch in
+        objects, unmodified; lists: equal values), evictions at most widen / 2 larger than the ones the
+        pivots were made for, and the store (metrics, positions, block metadata) not written through this object or torch in
         between -- a writer that goes around both (a custom kernel on ``metrics.data_ptr()``) must not run
         between the two calls.  In every other case this is ``aggregate_decode`` and the schedule call
         takes its usual pass.  Returns whether lists were made."""
@@ -422,7 +422,10 @@ class CompressionMetrics:
                 and hl["seqs"] == tuple(int(s) for s in seq_indices)
                 and self._arg_same(hl["seq_pos"], seq_positions) and self._arg_same(hl["prot"], num_protected)
                 and self._arg_same(hl["ctx"], context_lens) and hl["store"] == self._store_versions()
-                and len(k_list) == len(hl["k"]) and all(a <= b for a, b in zip(k_list, hl["k"])))
+                and len(k_list) == len(hl["k"])
+                # (the pivots aim at (1 + widen) x what the step before needed: half of that allowance may go to a
+                # sequence that frees more blocks than it did then, the rest is for the keys the attention lifts)
+                and all(a <= b or a <= int(b * (1.0 + 0.5 * self.harvest_widen)) for a, b in zip(k_list, hl["k"])))
 
     def _poll_fallback(self, capturing: bool) -> None:
         """The flag word of an earlier small-eviction / bracket call, copied to pinned memory behind it:
