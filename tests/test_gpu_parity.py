@@ -335,6 +335,33 @@ def test_dispatcher_path():
 
 
 # ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("slots,clear,l2", [((1 << 21) + 16 * 37, False, True), ((1 << 21) + 16 * 37, True, True),
+                                            ((1 << 20) + 2048 * 3 + 5, False, False),
+                                            ((1 << 28) + 16 * 5, False, True), ((1 << 28) + 16 * 5, True, True)])
+def test_aggregate_decode_on_large_stores(slots, clear, l2):
+    """the forms kvc_aggregate_decode takes for qpk 4 on large stores (csrc/kvc_aggregate.hip: tiles of eight rows
+    from 1 M slots on, a non-temporal stream from 1 GiB of metrics on, each with a tail): the same sums in the same
+    order -- the oracle where it takes seconds, the same float32 additions spelled out in torch (separate
+    elementwise kernels: no contraction) at config 3's size"""
+    from vllm_kvcompress_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device=DEV)
+    g.manual_seed(slots % 1000)
+    m = torch.rand((slots,), device=DEV, generator=g) * 100.0
+    t = torch.rand((slots, 4), device=DEV, generator=g)
+    v = t * t if l2 else t
+    want = m + ((((0.0 + v[:, 0]) + v[:, 1]) + v[:, 2]) + v[:, 3])
+    if slots < 1 << 24:
+        m_np = m.cpu().numpy().copy()
+        orc.aggregate_decode(m_np, t.cpu().numpy(), use_l2=l2)
+        np.testing.assert_array_equal(want.cpu().numpy(), m_np)      # (the torch spelling is the oracle's)
+    del v
+    _lib.check(lib.kvc_aggregate_decode(m.data_ptr(), t.data_ptr(), slots, 4, 1 if l2 else 0, 1 if clear else 0,
+                                        torch.cuda.current_stream().cuda_stream))
+    assert torch.equal(m.view(torch.int32), want.view(torch.int32))
+    assert bool(t.any()) != clear
+
+
 def test_aggregate_decode_and_clear():
     from vllm_kvcompress_amd.kvcompress.metrics import CompressionMetrics
     rng = np.random.default_rng(1)

@@ -64,6 +64,72 @@ __global__ __launch_bounds__(256) void aggregate_decode_kernel(float* __restrict
   }
 }
 
+// qpk == 4 without the fused clear -- the pass of every decode step -- in the two forms that measured best
+// on stores of every size (tools/agg_bw.hip; 24 B per slot):
+//   TILE   a workgroup takes contiguous tiles of 8 x 256 slots (eight adjacent rows in flight per
+//          wave), tiles a grid stride apart, up to 16 Ki workgroups: 5.65 TB/s at 275 M slots (the
+//          four-rows-a-grid-stride-apart loop above at 4 Ki workgroups: 5.37), 7.1 against 6.0 at 67 M,
+//          where part of the store stays in the 256 MiB Infinity Cache between passes;
+//   STREAM for a store several times that cache (>= 1 GiB of metrics: config 3): the grid-stride loop
+//          with the metrics loaded and stored non-temporally -- nothing of them can stay anywhere --
+//          at 16 Ki workgroups: 5.89 TB/s at 275 M slots (1.120 ms against 1.229); on smaller stores it
+//          loses (5.1 against 6.0 at 67 M: what it pushes out is what the next pass wants).  With the
+//          fused clear (40 B per slot; the zeros stored non-temporally as well) 2.069 ms against the
+//          2.285 of one slot per trip at 4 Ki workgroups.
+// The additions and their order are the loop's above.
+__device__ __forceinline__ float row_sum4(float4 v, int use_l2) {
+  if (use_l2) { v.x = __fmul_rn(v.x, v.x); v.y = __fmul_rn(v.y, v.y); v.z = __fmul_rn(v.z, v.z); v.w = __fmul_rn(v.w, v.w); }
+  return __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(0.0f, v.x), v.y), v.z), v.w);
+}
+template <bool STREAM>
+__global__ __launch_bounds__(256) void aggregate_decode_q4_kernel(float* __restrict__ metrics, float* __restrict__ temp,
+                                                                  int64_t num_slots, int use_l2, int clear_temp) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  constexpr int U = STREAM ? 4 : 8;
+  f32x4* temp4 = reinterpret_cast<f32x4*>(temp);
+  int64_t done;                                      // slots below this index are covered by the unrolled part
+  if constexpr (STREAM) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t s0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    done = num_slots / (U * stride) * (U * stride);
+    for (; s0 < done; s0 += U * stride) {
+      f32x4 t[U];
+      float m[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        t[u] = __builtin_nontemporal_load(temp4 + (s0 + u * stride));
+        m[u] = __builtin_nontemporal_load(metrics + (s0 + u * stride));
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        __builtin_nontemporal_store(__fadd_rn(m[u], row_sum4(make_float4(t[u].x, t[u].y, t[u].z, t[u].w), use_l2)),
+                                    metrics + (s0 + u * stride));
+        if (clear_temp) __builtin_nontemporal_store(f32x4{0.f, 0.f, 0.f, 0.f}, temp4 + (s0 + u * stride));
+      }
+    }
+  } else {
+    const int64_t tile = 256 * U, ntiles = num_slots / tile;
+    done = ntiles * tile;
+    for (int64_t ti = blockIdx.x; ti < ntiles; ti += gridDim.x) {
+      const int64_t base = ti * tile + threadIdx.x;
+      f32x4 t[U];
+      float m[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        t[u] = __builtin_nontemporal_load(temp4 + (base + u * 256));
+        m[u] = metrics[base + u * 256];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        metrics[base + u * 256] = __fadd_rn(m[u], row_sum4(make_float4(t[u].x, t[u].y, t[u].z, t[u].w), use_l2));
+    }
+  }
+  for (int64_t s = done + (int64_t)blockIdx.x * 256 + threadIdx.x; s < num_slots; s += (int64_t)gridDim.x * 256) {
+    metrics[s] = __fadd_rn(metrics[s], row_sum4(reinterpret_cast<const float4*>(temp)[s], use_l2));
+    if (clear_temp) temp4[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
 // ------------------------------------------------------------------ A2b
 // reference: vllm/kvcompress/metrics.py:396-427
 __global__ __launch_bounds__(256) void aggregate_prefill_kernel(float* __restrict__ metrics,
@@ -425,7 +491,16 @@ extern "C" int kvc_aggregate_decode(float* metrics, float* temp_metrics, int64_t
   const int64_t want = (num_slots + 255) / 256;
   const unsigned grid = (unsigned)(want < 256 * 16 ? want : 256 * 16);
   hipStream_t s = (hipStream_t)stream;
-  if (num_queries_per_kv == 4)
+  const bool big = num_slots >= (int64_t)1 << 28;                 // >= 1 GiB of metrics
+  if (num_queries_per_kv == 4 && (big || (!clear_temp && num_slots >= (int64_t)1 << 20))) {
+    const int64_t per_wg = big ? 256 * 4 : 256 * 8;
+    const int64_t w2 = (num_slots + per_wg - 1) / per_wg;
+    const unsigned g2 = (unsigned)(w2 < 16384 ? w2 : 16384);
+    if (big)
+      hipLaunchKernelGGL(aggregate_decode_q4_kernel<true>, dim3(g2), dim3(256), 0, s, metrics, temp_metrics, num_slots, use_l2, clear_temp);
+    else
+      hipLaunchKernelGGL(aggregate_decode_q4_kernel<false>, dim3(g2), dim3(256), 0, s, metrics, temp_metrics, num_slots, use_l2, 0);
+  } else if (num_queries_per_kv == 4)
     hipLaunchKernelGGL(aggregate_decode_kernel<4>, dim3(grid), dim3(256), 0, s, metrics, temp_metrics,
                        num_slots, 4, use_l2, clear_temp);
   else

@@ -636,18 +636,22 @@ extern "C" int kvc_aggregate_decode_harvest(const kvc_schedule_params* pp, float
   ws.rec64 = reinterpret_cast<uint64_t*>(hb + hl.rec64);
   const uint32_t* hv_pivot = reinterpret_cast<const uint32_t*>(hb + hl.pivot);
   fill32_async(hb + hl.claimed, 0u, hl.rec64 - hl.claimed, s);       // claimed | cnt
-  // a wave iteration covers 64 blocks; at most 4096 workgroups of 4 waves (grid-stride beyond)
+  // a wave iteration covers 64 blocks; at most 16 Ki workgroups of 4 waves (grid-stride beyond)
   int64_t cb = (p.num_blocks + 255) / 256;
-  cb = cb < 1 ? 1 : (cb > 4096 ? 4096 : cb);
+  cb = cb < 1 ? 1 : (cb > 16384 ? 16384 : cb);
   const dim3 grid((unsigned)cb), blk(256);
-#define KVC_HARVEST(BSV)                                                                                             \
-  if (num_queries_per_kv == 4)                                                                                       \
-    hipLaunchKernelGGL((aggregate_harvest_kernel<BSV, 1>), grid, blk, 0, s, p, ws, temp_metrics, hv_pivot, use_l2, clear_temp); \
+  const bool big = p.num_blocks * (int64_t)p.block_size >= (int64_t)1 << 28;        // >= 1 GiB of metrics
+#define KVC_HARVEST2(BSV, QVV)                                                                                      \
+  if (big)                                                                                                           \
+    hipLaunchKernelGGL((aggregate_harvest_kernel<BSV, QVV, true>), grid, blk, 0, s, p, ws, temp_metrics, hv_pivot, use_l2, clear_temp); \
   else                                                                                                               \
-    hipLaunchKernelGGL((aggregate_harvest_kernel<BSV, 2>), grid, blk, 0, s, p, ws, temp_metrics, hv_pivot, use_l2, clear_temp);
+    hipLaunchKernelGGL((aggregate_harvest_kernel<BSV, QVV, false>), grid, blk, 0, s, p, ws, temp_metrics, hv_pivot, use_l2, clear_temp);
+#define KVC_HARVEST(BSV)                                                                                             \
+  if (num_queries_per_kv == 4) { KVC_HARVEST2(BSV, 1) } else { KVC_HARVEST2(BSV, 2) }
   if (p.block_size == 8) { KVC_HARVEST(8); }
   else if (p.block_size == 16) { KVC_HARVEST(16); }
   else { KVC_HARVEST(32); }
+#undef KVC_HARVEST2
 #undef KVC_HARVEST
   return check_launch("aggregate_decode_harvest");
 }

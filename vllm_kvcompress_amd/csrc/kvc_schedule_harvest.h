@@ -38,7 +38,9 @@ namespace kvc {
 // the temp row as qpk / 4 16-byte loads per lane -- so that the arithmetic (and its order) is the
 // plain kernel's.  A wave iteration covers 64 blocks = BS rows: lane b looks after the metadata of
 // block b (one coalesced load per table, as in section 7) and hands pivot / head / position bound
-// to the rows' lanes by shuffles; U = 4 rows are in flight at a time.
+// to the rows' lanes by shuffles; U = 8 rows are in flight at a time (a wave's 64 blocks are
+// contiguous: the TILE form of csrc/kvc_aggregate.hip).  STREAM: a store several times the
+// Infinity Cache (>= 1 GiB of metrics) has its metrics loaded and stored non-temporally, as there.
 struct HvLayout { size_t pivot, claimed, cnt, rec64, total; };
 inline HvLayout hv_layout(int32_t G, int32_t B) {
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
@@ -52,12 +54,12 @@ inline HvLayout hv_layout(int32_t G, int32_t B) {
   return l;
 }
 
-template <int BS, int QV>
+template <int BS, int QV, bool STREAM>
 __global__ __launch_bounds__(256) void aggregate_harvest_kernel(kvc_schedule_params p, SchedWs ws, float* __restrict__ temp,
                                                                 const uint32_t* __restrict__ hv_pivot, int use_l2,
                                                                 int clear_temp) {
   constexpr int ROWS = BS;                           // 64 blocks x BS slots = BS rows of 64 slots
-  constexpr int U = 4;                               // rows in flight
+  constexpr int U = 8;                               // rows in flight
   constexpr int BPR = 64 / BS;                       // blocks per row
   static_assert(ROWS % U == 0, "block sizes 8 / 16 / 32");
   __shared__ uint32_t qk[4][128], qs[4][128], qg[4][128];
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void aggregate_harvest_kernel(kvc_schedule_par
         if (s < num_slots) {
 #pragma unroll
           for (int v = 0; v < QV; ++v) t[u][v] = __builtin_nontemporal_load(temp4 + s * QV + v);
-          m[u] = metrics[s];
+          m[u] = STREAM ? __builtin_nontemporal_load(metrics + s) : metrics[s];
         } else {
 #pragma unroll
           for (int v = 0; v < QV; ++v) t[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256) void aggregate_harvest_kernel(kvc_schedule_par
         }
         const float mn = __fadd_rn(m[u], acc);
         if (in) {
-          metrics[s] = mn;
+          if constexpr (STREAM) __builtin_nontemporal_store(mn, metrics + s); else metrics[s] = mn;
           if (clear_temp) {
 #pragma unroll
             for (int v = 0; v < QV; ++v) temp4[s * QV + v] = f32x4{0.f, 0.f, 0.f, 0.f};
