@@ -297,7 +297,15 @@ typedef struct kvc_schedule_params {
                                                *   leaves: the (1 + harvest_widen) * Tgt-th smallest remaining key,
                                                *   Tgt = k * bs + sum(hang - 1) with this call's k and hang taken as
                                                *   the next step's; extrapolated upwards when fewer are left.
-                                               * Both are ignored (bit 0: an error) unless the call takes the
+                                               * bit 2: this call's own collecting pass takes its pivots from
+                                               *   harvest_buf (left there by the previous call's bit 1, for the same
+                                               *   batch) instead of from a sample: no sampling pass, no pivot kernel,
+                                               *   and half the candidates (an exact count needs no margin for a
+                                               *   sample's error).  For callers that do not harvest; the pivots are
+                                               *   one decode step of attention old either way, and a pass that lists
+                                               *   too little raises the flag as always.  Only the first
+                                               *   kvc_harvest_pivot_bytes() of the buffer are touched.
+                                               * All are ignored (bits 0 and 2: an error) unless the call takes the
                                                * small-eviction schedule in its position-lazy form
                                                * (kvc_harvest_eligible). */
   float harvest_widen;                        /* bit 1: allowance for keys that the next step's attention lifts over
@@ -324,6 +332,7 @@ size_t kvc_schedule_evictions_workspace_bytes(int64_t total_slots, int32_t total
  * Eligible: the small-eviction schedule in its position-lazy form (no use_average, no bias, mode 1
  * or one sequence), block size 8 / 16 / 32, num_queries_per_kv 4 or 8. */
 size_t kvc_harvest_buffer_bytes(int32_t total_heads, int32_t num_seqs);
+size_t kvc_harvest_pivot_bytes(int32_t num_seqs);   /* its leading part: enough for harvest bits 1 and 2 without bit 0 */
 int32_t kvc_harvest_eligible(const kvc_schedule_params* p, int32_t num_queries_per_kv);
 int kvc_aggregate_decode_harvest(const kvc_schedule_params* p, float* temp_metrics,
                                  int32_t num_queries_per_kv, int32_t use_l2, int32_t clear_temp,

@@ -103,7 +103,8 @@ class Loop:
         got = dict(eli=eli.cpu().numpy(), ekc=ekc.cpu().numpy(), ebc=ebc.cpu().numpy())
         for key in KEYS:
             np.testing.assert_array_equal(got[key], want[key], err_msg=f"step {self.step_no} (sel {sel}, k {evicted}): {key}")
-        info = dict(harvested=harvested, used=cm.last_harvest_used, path=cm.last_schedule_path(), evicted=evicted)
+        info = dict(harvested=harvested, used=cm.last_harvest_used, path=cm.last_schedule_path(), evicted=evicted,
+                    remembered=cm.last_pivot_memory_used)
         # ---- carry the host state on (the oracle's compaction; only the selected sequences were compressed)
         st.metrics, st.token_positions = want["metrics"].copy(), want["positions"].copy()
         self.k_np, self.v_np = want["k"], want["v"]
@@ -216,10 +217,11 @@ def test_not_eligible_calls_aggregate_as_before():
 
 def test_switched_off_by_the_environment_variable(monkeypatch):
     monkeypatch.setenv("KVC_HARVEST_AHEAD", "0")
+    monkeypatch.setenv("KVC_PIVOT_MEMORY", "0")
     st = synth.make_state(num_layers=2, num_kv_heads=4, block_size=16, seq_lens=[600, 300], seed=3, protected=17, steady_cap=160)
     ds = hdev.upload(st, DEV, num_queries_per_kv=4, mode="per_sequence")
     cm = ds.cm
-    assert cm.harvest_ahead is False
+    assert cm.harvest_ahead is False and cm.pivot_memory is False
     temp = np.random.default_rng(0).random((st.num_blocks, 16, 4)).astype(np.float32)
     for it in range(3):
         cm.temp_metrics.copy_(torch.from_numpy(temp))
@@ -229,7 +231,7 @@ def test_switched_off_by_the_environment_variable(monkeypatch):
         np.testing.assert_array_equal(cm.metrics.cpu().numpy(), st.metrics)
         want = oracle_pipeline(st, [8, 8], mode="per_sequence")
         eli, ekc, ebc, cmi, cmc = hdev.schedule(ds, st, [8, 8])
-        assert not cm.last_harvest_used and cm._hv is None
+        assert not cm.last_harvest_used and not cm.last_pivot_memory_used and cm._hv is None and cm._hv_buf is None
         np.testing.assert_array_equal(eli.cpu().numpy(), want["eli"])
 
 
@@ -314,3 +316,28 @@ def test_scheduler_that_was_left_the_aggregate_gives_what_the_reference_order_gi
         assert not ra["used"]
         used += bool(rb["used"])
     assert used >= 15, used
+
+
+@pytest.mark.parametrize("bs,stride", [(16, 0), (32, 2), (8, 0)])
+def test_reference_order_takes_its_pivots_from_the_call_before(bs, stride):
+    """no harvest at all -- aggregate_decode at the end of a step, schedule_evictions at the start of the next,
+    as the fork does: from the second call on the collecting pass takes the pivots the call before left behind
+    (kvc_schedule_params.harvest bit 2) instead of sampling; the oracle's schedule every step, and a pass that
+    lists too little is redone on the device"""
+    lp = Loop(L=2, H=4, bs=bs, seq_lens=[40 * bs + 5, 25 * bs, 33 * bs + 9], cap=20 * bs, stride=stride, seed=bs)
+    cm = lp.cm
+    first = lp.step(plain=True)
+    assert not first["remembered"] and first["path"] == "small_eviction"
+    remembered = clean = 0
+    for it in range(30):
+        info = lp.step(plain=True, scale=30.0 if it == 17 else 1.0)      # (once: attention that lifts keys over every pivot)
+        assert not info["used"] and info["path"].startswith("small_eviction")
+        remembered += info["remembered"]
+        clean += info["remembered"] and info["path"] == "small_eviction"
+    assert cm.harvest_ahead is None and cm._hv_buf.numel() == _lib.load().kvc_harvest_pivot_bytes(3)
+    assert remembered >= 24 and clean >= remembered - 3, (remembered, clean)
+    # switched off: every call samples
+    cm.pivot_memory = False
+    for it in range(3):
+        info = lp.step(plain=True)
+        assert not info["remembered"] and info["path"] == "small_eviction"

@@ -47,6 +47,9 @@
 #include "kvc_schedule_fallback.h"
 
 // --------------------------------------------------------------------------- host side
+#ifndef KVC_COLLECT_GRID_CAP
+#define KVC_COLLECT_GRID_CAP 4096                  // (experiment builds: tools/)
+#endif
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // The null padding of the output list is 4 B per candidate slot of pure HBM writes with nobody
@@ -204,6 +207,10 @@ static bool harvest_plan(const kvc_schedule_params& p) {
 extern "C" int32_t kvc_harvest_eligible(const kvc_schedule_params* p, int32_t num_queries_per_kv) {
   if (p == nullptr || !(num_queries_per_kv == 4 || num_queries_per_kv == 8)) return 0;
   return harvest_plan(*p) ? 1 : 0;
+}
+extern "C" size_t kvc_harvest_pivot_bytes(int32_t num_seqs) {
+  if (num_seqs < 1) return 0;
+  return kvc::hv_layout(1, num_seqs).claimed;
 }
 extern "C" size_t kvc_harvest_buffer_bytes(int32_t total_heads, int32_t num_seqs) {
   if (total_heads < 1 || num_seqs < 1) return 0;
@@ -377,13 +384,19 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     const bool hv_ok = p.harvest_buf != nullptr && harvest_plan(p);
     if ((p.harvest & 1) && !hv_ok)
       return fail_invalid("schedule_evictions: harvested lists with a call that is not eligible (kvc_harvest_eligible)");
+    if ((p.harvest & 4) && !hv_ok)
+      return fail_invalid("schedule_evictions: remembered pivots with a call that is not eligible (kvc_harvest_eligible)");
     const bool harvested = (p.harvest & 1) != 0;
+    // the collecting pass with the pivots the previous call left behind instead of a sample's (bit 2)
+    const bool remembered = !harvested && (p.harvest & 4) != 0;
     uint32_t* hv_pivot = nullptr;
-    if (hv_ok && (p.harvest & 3)) {
+    const uint32_t* hv_pivot_in = nullptr;
+    if (hv_ok && (p.harvest & 7)) {
       if ((reinterpret_cast<uintptr_t>(p.harvest_buf) & 15) != 0) return fail_invalid("schedule_evictions: harvest_buf must be 16-byte aligned");
       uint8_t* hb = reinterpret_cast<uint8_t*>(p.harvest_buf);
       const HvLayout hl = hv_layout(G, B);
       if (p.harvest & 2) hv_pivot = reinterpret_cast<uint32_t*>(hb + hl.pivot);
+      hv_pivot_in = reinterpret_cast<const uint32_t*>(hb + hl.pivot);
       if (harvested) {
         ws.st_claimed = reinterpret_cast<uint32_t*>(hb + hl.claimed);
         ws.st_cnt = reinterpret_cast<uint32_t*>(hb + hl.cnt);
@@ -391,7 +404,7 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
       }
     }
     const float hv_widen = p.harvest_widen > 0.0f ? p.harvest_widen : 0.25f;
-    if (!harvested) {
+    if (!harvested && !remembered) {
       int64_t sb = (p.num_blocks + 2047) / 2048;     // >= 8 steps of 64 block indices per wave
       sb = sb < 1 ? 1 : (sb > 4096 ? 4096 : sb);
       const dim3 grid((unsigned)sb), blk(256);
@@ -414,13 +427,14 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
         side = nullptr;
       }
     }
-    if (!harvested) hipLaunchKernelGGL(stream_pivot_kernel, dim3(B), dim3(1024), 0, s, p, ws, sshift);
+    if (remembered) hipLaunchKernelGGL(seqrec_from_pivots_kernel, dim3((B + 255) / 256), dim3(256), 0, s, p, ws, hv_pivot_in);
+    else if (!harvested) hipLaunchKernelGGL(stream_pivot_kernel, dim3(B), dim3(1024), 0, s, p, ws, sshift);
     if (!harvested) {
       // blocks of the batch / blocks of the cache: a dense cache requests the rows before it has
       // looked at the metadata, a sparse one (engine-sized cache, small batch) only the batch's rows
       const bool dense = p.total_slots >= (int64_t)p.num_blocks * p.block_size / 2;
       int64_t cb = dense ? (p.num_blocks + 255) / 256 : (p.num_blocks + kvc::SPARSE_CHUNK - 1) / kvc::SPARSE_CHUNK;
-      cb = cb < 1 ? 1 : (cb > 4096 ? 4096 : cb);
+      cb = cb < 1 ? 1 : (cb > KVC_COLLECT_GRID_CAP ? KVC_COLLECT_GRID_CAP : cb);
       const dim3 grid((unsigned)cb), blk(256);
 #define KVC_COLLECT(BSV)                                                                                  \
       if (lazy) {                                                                                         \
@@ -443,7 +457,8 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     }
     hipLaunchKernelGGL(seq_select_topk_kernel, dim3(B), dim3(1024), (size_t)topk_p2 * 8 + (size_t)LH * 4, s, p, ws, topk_p2, coupled_tk);
     // the pivots for the next decode step's harvest, from what is left of this call's lists (section 10)
-    if (hv_pivot != nullptr) hipLaunchKernelGGL(harvest_pivot_kernel, dim3(B), dim3(1024), 0, s, p, ws, hv_pivot, harvested ? 1 : 0, hv_widen);
+    if (hv_pivot != nullptr)
+      hipLaunchKernelGGL(harvest_pivot_kernel, dim3(B), dim3(1024), 0, s, p, ws, hv_pivot, (harvested || remembered) ? 1 : 0, hv_widen);
     if (side != nullptr && hipStreamWaitEvent(s, side->join, 0) != hipSuccess) {
       (void)hipGetLastError();
       (void)hipStreamSynchronize(side->s2);          // (the emission below must not race the fill)

@@ -178,6 +178,11 @@ class CompressionMetrics:
         env = os.environ.get("KVC_HARVEST_AHEAD", "")
         self.harvest_ahead = None if env == "" else env != "0"
         self.harvest_widen = float(os.environ.get("KVC_HARVEST_WIDEN", "0.25"))
+        # pivot memory (harvest bit 2; on unless KVC_PIVOT_MEMORY=0): without any harvest, a small-eviction call for
+        # the batch of the call before takes the pivots that call left behind instead of sampling the store --
+        # no sampling pass, no pivot kernel, half the candidates in its collecting pass.  Same results.
+        self.pivot_memory = os.environ.get("KVC_PIVOT_MEMORY", "1") not in ("", "0")
+        self.last_pivot_memory_used = False
         self.last_harvest_used = False     # the last schedule_evictions ran on harvested lists
         self.harvest_misses = 0            # harvested calls whose lists fell short (flag raised, redone on device)
         self._hv_buf = None                # pivots + lists (kvc_harvest_buffer_bytes)
@@ -388,7 +393,7 @@ class CompressionMetrics:
         self._hv_lists = None
         stream = _stream(self.metrics)
         ok = (self.harvest_ahead and hv is not None and hv["seqs"] == tuple(int(s) for s in seq_indices)
-              and hv["buf"] is self._hv_buf and hv["stream"] == stream and not self._fb_fault
+              and hv["buf"] is self._hv_buf and hv["full"] and hv["stream"] == stream and not self._fb_fault
               and isinstance(context_lens, torch.Tensor) and context_lens.is_cuda and context_lens.dtype == torch.int32
               and context_lens.is_contiguous()
               and tuple(context_lens.shape) == (self.num_layers, len(seq_indices), self.num_kv_heads)
@@ -422,10 +427,13 @@ class CompressionMetrics:
                 and hl["seqs"] == tuple(int(s) for s in seq_indices)
                 and self._arg_same(hl["seq_pos"], seq_positions) and self._arg_same(hl["prot"], num_protected)
                 and self._arg_same(hl["ctx"], context_lens) and hl["store"] == self._store_versions()
-                and len(k_list) == len(hl["k"])
-                # (the pivots aim at (1 + widen) x what the step before needed: half of that allowance may go to a
-                # sequence that frees more blocks than it did then, the rest is for the keys the attention lifts)
-                and all(a <= b or a <= int(b * (1.0 + 0.5 * self.harvest_widen)) for a, b in zip(k_list, hl["k"])))
+                and self._k_within(k_list, hl["k"]))
+
+    def _k_within(self, k_list, k_then) -> bool:
+        """the pivots aim at (1 + widen) x what the step before needed: half of that allowance may go to a sequence
+        that frees more blocks than it did then, the rest is for the keys the attention lifts"""
+        return (len(k_list) == len(k_then)
+                and all(a <= b or a <= int(b * (1.0 + 0.5 * self.harvest_widen)) for a, b in zip(k_list, k_then)))
 
     def _poll_fallback(self, capturing: bool) -> None:
         """The flag word of an earlier small-eviction / bracket call, copied to pinned memory behind it:
@@ -576,21 +584,28 @@ class CompressionMetrics:
         hl, self._hv_lists = self._hv_lists, None
         p.harvest_buf, p.harvest, p.harvest_widen = None, 0, float(self.harvest_widen)
         stream = _stream(self.metrics)
-        if (self.harvest_ahead and not capturing and p.max_evicted_blocks_hint >= 0
-                and lib.kvc_harvest_eligible(ctypes.byref(p), self.num_queries_per_kv)):
-            need = int(lib.kvc_harvest_buffer_bytes(B * L * H, B))
+        if ((self.harvest_ahead or self.pivot_memory) and not capturing and p.max_evicted_blocks_hint >= 0
+                and lib.kvc_harvest_eligible(ctypes.byref(p), self.num_queries_per_kv if self.harvest_ahead else 4)):
+            # the buffer: pivots only, or pivots + lists once somebody harvests
+            full = bool(self.harvest_ahead)
+            need = int(lib.kvc_harvest_buffer_bytes(B * L * H, B) if full else lib.kvc_harvest_pivot_bytes(B))
             if self._hv_buf is None or self._hv_buf.numel() != need:
                 self._hv_buf = torch.zeros((need,), dtype=torch.uint8, device=dev)
                 self._hv = hl = None
             k_list = [int(v) for v in evicted_blocks_per_seq]
             p.harvest_buf = self._hv_buf.data_ptr()
             p.harvest = 2
+            hv = self._hv
             if self._lists_usable(hl, seq_indices, seq_positions, num_protected, context_lens, k_list, stream):
                 p.harvest |= 1
-            self._hv = dict(seqs=tuple(int(x) for x in seq_indices), k=k_list, N=N, buf=self._hv_buf, stream=stream)
+            elif (self.pivot_memory and hv is not None and hv["buf"] is self._hv_buf and hv["stream"] == stream
+                  and hv["seqs"] == tuple(int(x) for x in seq_indices) and self._k_within(k_list, hv["k"])):
+                p.harvest |= 4
+            self._hv = dict(seqs=tuple(int(x) for x in seq_indices), k=k_list, N=N, buf=self._hv_buf, stream=stream, full=full)
         else:
             self._hv = None
         self.last_harvest_used = bool(p.harvest & 1)
+        self.last_pivot_memory_used = bool(p.harvest & 4)
         p.eli_dirty_map = None
         if (self.reuse_output_buffer and not self.lean_outputs and N > 0
                 and int(lib.kvc_schedule_evictions_plan(ctypes.byref(p))) == 1):
@@ -617,7 +632,7 @@ class CompressionMetrics:
             word = int(ws[off:off + 4].view(torch.int32).item())
             if word & 2:
                 self._raise_fallback_fault("this")
-            self._note_flag(word, bool(p.harvest & 1))
+            self._note_flag(word, bool(p.harvest & 5))
         elif self.last_schedule[2] and not capturing:
             off = self.last_schedule[1]
             if self._fb_pin is None:
@@ -625,7 +640,7 @@ class CompressionMetrics:
             if self._fb_event is None:      # (one copy in flight at a time: the pinned word is read before it is reused)
                 with torch.cuda.device(dev):
                     self._fb_pin.copy_(ws[off:off + 4].view(torch.int32), non_blocking=True)
-                    self._fb_was_harvested = bool(p.harvest & 1)
+                    self._fb_was_harvested = bool(p.harvest & 5)
                     self._fb_event = torch.cuda.Event()
                     self._fb_event.record()
         return out_idx, out_kv, out_blk
