@@ -3,7 +3,9 @@
 with the same attention mass -- one in the reference's order (aggregate_decode at the end of an iteration,
 schedule_evictions' own pass at the start of the next), one that leaves the aggregate to the scheduler
 (CompressionScheduler.schedule_compression(aggregate_decode=True): the harvesting pass) -- must hold the same
-state after every step.  Prints how many steps ran on harvested lists and how many of those fell short.
+state after every step.  Prints how many steps ran on harvested lists and how many of those fell short -- and,
+for the engine in the reference's order, how many collecting passes took their pivots from the call before
+(pivot memory) and how many of those listed too little.
     python tools/soak_harvest.py [steps] [seqs] [layers] [cap] [mass]
 mass: "uniform" | "peaky" (a few keys per head take most of a step's attention, the rest next to nothing)"""
 import copy
@@ -34,7 +36,7 @@ def main():
     b = _Engine(copy.deepcopy(st), seq_lens, cap, qpk, deferred=True)
     g = torch.Generator(device=DEV)
     g.manual_seed(5)
-    used = paths = 0
+    used = paths = remembered = paths_a = 0
     sel = list(range(B))
     for it in range(steps):
         temp = torch.rand((st.num_blocks, bs, qpk), device=DEV, generator=g)
@@ -49,9 +51,13 @@ def main():
                 raise SystemExit(f"step {it}: {key} differs")
         used += bool(rb["used"])
         paths += b.cm.last_schedule_path() == "small_eviction"
+        remembered += bool(a.cm.last_pivot_memory_used)
+        paths_a += a.cm.last_schedule_path() == "small_eviction"
     print(json.dumps({"steps": steps, "sequences": B, "heads_per_sequence": L * H, "cap": cap, "attention_mass": mass,
                       "candidate_slots": st.total_slots, "harvested_steps": used, "harvest_misses": b.cm.harvest_misses,
                       "harvest_widen_at_end": b.cm.harvest_widen, "steps_without_fallback": paths,
+                      "reference_order": {"steps_on_remembered_pivots": remembered, "misses": a.cm.harvest_misses,
+                                          "steps_without_fallback": paths_a},
                       "identical_state_every_step": True}))
 
 

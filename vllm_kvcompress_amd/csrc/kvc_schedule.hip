@@ -365,9 +365,12 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     allow_dynamic_lds(reinterpret_cast<const void*>(seq_prepare_kernel), 160 * 1024 - 1024, prep_done);
   }
   if (topk) {
-    // ---- small-eviction schedule (section 7): one memset of its counters, the output fill (side
-    // stream), 6 launches (+ 2 for the reference's batch > 1 rule); the general pipeline is enqueued
-    // behind it -- one gated launch (section 8) -- and runs only if the flag was raised
+    // ---- small-eviction schedule (section 7): one fill of its counters, the output fill (side
+    // stream), 6 launches (+ 2 for the reference's batch > 1 rule; + 1 that leaves the next call's
+    // pivots, section 10); the general pipeline is enqueued behind it -- one gated launch (section 8)
+    // -- and runs only if the flag was raised.  With the pivots of the call before (harvest bit 2)
+    // the sampling pass and the pivot kernel are not launched; on lists the aggregation pass made
+    // (bit 0) the collecting pass is not either: records | selection | next pivots | emission.
     fill32_async(wb + l.tz_begin, 0u, l.tz_end - l.tz_begin, s);
     SideStream* side = nullptr;
     if (!(p.lean & 1) && p.eli_dirty_map == nullptr) {
