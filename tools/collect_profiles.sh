@@ -107,4 +107,13 @@ for cfg in "--spare-blocks 30" "--spare-blocks 60" "--batch 4" "--batch 16 --ste
   timeout 900 $B $cfg >> "$OUT/${TAG}_configs.jsonl" 2>> "$OUT/configs.err"
 done
 timeout 600 python tools/bench_attention.py > "$OUT/${TAG}_attention_bench.json" 2> "$OUT/attention.err"
+# 5. config 3 as a whole decode step (S0 + S1 + S2 + S3), two sweeps of the store against harvest-ahead: kernel stats
+#    and the comparison itself                                             -> <tag>_decode_step_c3.json, _kernel_stats.csv
+"$REPO/tools/prof_decode_step.sh" "${TAG}_decode_step" > "$OUT/${TAG}_decode_step_stats.txt" 2>&1
+cp "$REPO/gpurun_out/${TAG}_decode_step.json" "$OUT/${TAG}_decode_step_c3.json" 2>/dev/null
+cp "$REPO/gpurun_out/${TAG}_decode_step_kernel_stats.csv" "$OUT/" 2>/dev/null
+cd "$REPO"
+# 6. harvest-ahead / pivot memory over 400 decode steps of an evolving on-device block state    -> <tag>_harvest_soak.txt
+(timeout 500 python tools/soak_harvest.py 400 32 32 1024 uniform; timeout 500 python tools/soak_harvest.py 400 32 32 1024 peaky;
+ timeout 300 python tools/soak_harvest.py 300 4 4 256 peaky) > "$OUT/${TAG}_harvest_soak.txt" 2> "$OUT/soak.err"
 ls "$OUT"
