@@ -305,9 +305,10 @@ typedef struct kvc_schedule_params {
                                                *   one decode step of attention old either way, and a pass that lists
                                                *   too little raises the flag as always.  Only the first
                                                *   kvc_harvest_pivot_bytes() of the buffer are touched.
-                                               * All are ignored (bits 0 and 2: an error) unless the call takes the
-                                               * small-eviction schedule in its position-lazy form
-                                               * (kvc_harvest_eligible). */
+                                               * Bit 0 needs the small-eviction schedule in its position-lazy form
+                                               * (kvc_harvest_eligible; an error otherwise), bits 1 and 2 any
+                                               * small-eviction call (kvc_pivot_memory_eligible; ignored by the
+                                               * other schedules). */
   float harvest_widen;                        /* bit 1: allowance for keys that the next step's attention lifts over
                                                * the pivot, as a fraction of Tgt (<= 0: 0.25) */
   /* outputs */
@@ -332,6 +333,7 @@ size_t kvc_schedule_evictions_workspace_bytes(int64_t total_slots, int32_t total
  * Eligible: the small-eviction schedule in its position-lazy form (no use_average, no bias, mode 1
  * or one sequence), block size 8 / 16 / 32, num_queries_per_kv 4 or 8. */
 size_t kvc_harvest_buffer_bytes(int32_t total_heads, int32_t num_seqs);
+int32_t kvc_pivot_memory_eligible(const kvc_schedule_params* p);
 size_t kvc_harvest_pivot_bytes(int32_t num_seqs);   /* its leading part: enough for harvest bits 1 and 2 without bit 0 */
 int32_t kvc_harvest_eligible(const kvc_schedule_params* p, int32_t num_queries_per_kv);
 int kvc_aggregate_decode_harvest(const kvc_schedule_params* p, float* temp_metrics,

@@ -30,13 +30,13 @@ class Loop:
     """one CompressionMetrics kept over the steps; the host state (oracle side) is copied into its
     tensors in front of every step"""
 
-    def __init__(self, L, H, bs, seq_lens, cap, qpk=4, seed=3, use_l2=True, stride=0):
-        self.L, self.H, self.bs, self.cap, self.qpk, self.use_l2 = L, H, bs, cap, qpk, use_l2
+    def __init__(self, L, H, bs, seq_lens, cap, qpk=4, seed=3, use_l2=True, stride=0, mode="per_sequence"):
+        self.L, self.H, self.bs, self.cap, self.qpk, self.use_l2, self.mode = L, H, bs, cap, qpk, use_l2, mode
         self.seq_lens = list(seq_lens)
         self.st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs, seq_lens=seq_lens, seed=seed,
                                    protected=bs + 1, spare_block_frac=0.6, steady_cap=cap)
         self.sim = EngineSim(self.st, seq_lens)
-        self.ds = hdev.upload(self.st, DEV, num_queries_per_kv=qpk, mode="per_sequence")
+        self.ds = hdev.upload(self.st, DEV, num_queries_per_kv=qpk, mode=mode)
         self.cm = self.ds.cm
         self.cm.use_l2 = use_l2
         assert self.cm.harvest_ahead is None     # (the first aggregate_decode_and_harvest turns it on)
@@ -98,7 +98,7 @@ class Loop:
         evicted = [synth.evict_block_count(context_lens_lh=sub.context_lens[:, b, :], seq_len=int(self.sim.seq_lens[s]),
                                            block_size=bs, protected_window_size=bs + 1, max_cache_tokens=self.cap)
                    for b, s in enumerate(sel)]
-        want = oracle_pipeline(sub, evicted, self.k_np, self.v_np, mode="per_sequence")
+        want = oracle_pipeline(sub, evicted, self.k_np, self.v_np, mode=self.mode)
         eli, ekc, ebc = cm.schedule_evictions(seqs, pos_t, evicted, ctx_t, hang_t, offs_t, prot, total_slots=sub.total_slots)
         got = dict(eli=eli.cpu().numpy(), ekc=ekc.cpu().numpy(), ebc=ebc.cpu().numpy())
         for key in KEYS:
@@ -341,3 +341,17 @@ def test_reference_order_takes_its_pivots_from_the_call_before(bs, stride):
     for it in range(3):
         info = lp.step(plain=True)
         assert not info["remembered"] and info["path"] == "small_eviction"
+
+
+def test_pivot_memory_under_the_batch_rule_of_the_reference():
+    """mode "reference" with three sequences: the reference's batch > 1 rule couples the sequences and keeps the
+    collecting pass that streams the positions (no lazy form, nothing to harvest) -- its pivots still come from the
+    call before"""
+    lp = Loop(L=2, H=4, bs=16, seq_lens=[700, 420, 555], cap=320, mode="reference")
+    lp.step(plain=True)
+    remembered = 0
+    for it in range(12):
+        info = lp.step(plain=it % 2 == 0)            # (aggregate_decode_and_harvest here is the plain pass: not eligible)
+        assert not info["harvested"] and not info["used"] and info["path"].startswith("small_eviction"), info
+        remembered += info["remembered"]
+    assert remembered >= 10, remembered

@@ -110,6 +110,7 @@ SYMBOLS = {
     "kvc_schedule_evictions_fallback_offset": (c_size_t, [c_int64, c_int32, c_int32, c_int32]),
     "kvc_harvest_buffer_bytes": (c_size_t, [c_int32, c_int32]),
     "kvc_harvest_pivot_bytes": (c_size_t, [c_int32]),
+    "kvc_pivot_memory_eligible": (c_int32, [ctypes.POINTER(KvcScheduleParams)]),
     "kvc_harvest_eligible": (c_int32, [ctypes.POINTER(KvcScheduleParams), c_int32]),
     "kvc_aggregate_decode_harvest": (c_int32, [ctypes.POINTER(KvcScheduleParams), c_void_p, c_int32, c_int32,
                                                c_int32, c_void_p]),

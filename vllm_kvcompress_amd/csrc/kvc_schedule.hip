@@ -208,6 +208,13 @@ extern "C" int32_t kvc_harvest_eligible(const kvc_schedule_params* p, int32_t nu
   if (p == nullptr || !(num_queries_per_kv == 4 || num_queries_per_kv == 8)) return 0;
   return harvest_plan(*p) ? 1 : 0;
 }
+// pivot memory (harvest bits 1 and 2 without bit 0) needs no more than the small-eviction schedule itself:
+// whatever its collecting pass streams, its lists are all the evictable keys below the pivots
+extern "C" int32_t kvc_pivot_memory_eligible(const kvc_schedule_params* p) {
+  if (p == nullptr) return 0;
+  int p2 = 0, sshift = 0;
+  return topk_plan(*p, p2, sshift) == KVC_WHY_TAKEN ? 1 : 0;
+}
 extern "C" size_t kvc_harvest_pivot_bytes(int32_t num_seqs) {
   if (num_seqs < 1) return 0;
   return kvc::hv_layout(1, num_seqs).claimed;
@@ -384,11 +391,11 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     // keys that do not depend on the position, sequences that do not need each other's inf counts
     const bool lazy = lazy_plan(p);
     // harvest-ahead (section 10): the lists were made by the aggregation pass / a pivot is wanted for the next one
-    const bool hv_ok = p.harvest_buf != nullptr && harvest_plan(p);
-    if ((p.harvest & 1) && !hv_ok)
+    const bool hv_ok = p.harvest_buf != nullptr;     // (pivots: any small-eviction call; lists: its position-lazy form)
+    if ((p.harvest & 1) && !(hv_ok && harvest_plan(p)))
       return fail_invalid("schedule_evictions: harvested lists with a call that is not eligible (kvc_harvest_eligible)");
     if ((p.harvest & 4) && !hv_ok)
-      return fail_invalid("schedule_evictions: remembered pivots with a call that is not eligible (kvc_harvest_eligible)");
+      return fail_invalid("schedule_evictions: remembered pivots without a harvest buffer");
     const bool harvested = (p.harvest & 1) != 0;
     // the collecting pass with the pivots the previous call left behind instead of a sample's (bit 2)
     const bool remembered = !harvested && (p.harvest & 4) != 0;

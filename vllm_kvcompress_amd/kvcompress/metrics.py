@@ -584,8 +584,9 @@ class CompressionMetrics:
         hl, self._hv_lists = self._hv_lists, None
         p.harvest_buf, p.harvest, p.harvest_widen = None, 0, float(self.harvest_widen)
         stream = _stream(self.metrics)
-        if ((self.harvest_ahead or self.pivot_memory) and not capturing and p.max_evicted_blocks_hint >= 0
-                and lib.kvc_harvest_eligible(ctypes.byref(p), self.num_queries_per_kv if self.harvest_ahead else 4)):
+        if (not capturing and p.max_evicted_blocks_hint >= 0
+                and ((self.harvest_ahead and lib.kvc_harvest_eligible(ctypes.byref(p), self.num_queries_per_kv))
+                     or (self.pivot_memory and lib.kvc_pivot_memory_eligible(ctypes.byref(p))))):
             # the buffer: pivots only, or pivots + lists once somebody harvests
             full = bool(self.harvest_ahead)
             need = int(lib.kvc_harvest_buffer_bytes(B * L * H, B) if full else lib.kvc_harvest_pivot_bytes(B))
