@@ -125,6 +125,102 @@ int main() {
                                         nullptr, s);
     ok = ok && rc == 1 && strstr(kvc_last_error(), "dirty map") != nullptr;
   }
+  // ---- ABI version 5: A2a + A3 with the harvest protocol.  Two decode steps of the same batch: the second one's
+  // schedule once the usual way (aggregate_decode, then schedule_evictions' own pass on remembered pivots) and once on
+  // the lists kvc_aggregate_decode_harvest made -- the same store and the same schedule, no flag raised; the sums
+  // against a plain float loop (metrics.py:429-439: metrics += sum_q temp^2, in index order)
+  {
+    const int qpk = 4, kfree = 4, seq_pos = 400, prot = 32;
+    const int64_t slots = (int64_t)NB * bs;
+    std::vector<int32_t> seq_by(NB, -1), lay_by(NB, 0), head_by(NB, 0), lbn_by(NB, 0), pos2((size_t)slots, 0);
+    for (int l = 0; l < L; ++l)
+      for (int h = 0; h < H; ++h)
+        for (int j = 0; j < nblk; ++j) {
+          const int blk = bt[((l * B + 0) * H + h) * M + j];
+          seq_by[blk] = 0; lay_by[blk] = l; head_by[blk] = h; lbn_by[blk] = j;
+          for (int o = 0; o < bs; ++o) pos2[(size_t)blk * bs + o] = j * bs + o;
+        }
+    std::vector<float> m0((size_t)slots), temp((size_t)slots * qpk);
+    for (size_t i = 0; i < m0.size(); ++i) m0[i] = (float)perm[i / bs] * 64.0f + (float)(rnd() % 64) + (float)(i % bs) * 0.001f;
+    for (auto& t : temp) t = (float)(rnd() % 1000) * 1e-3f;
+    auto aggregate = [&](std::vector<float>& m) {
+      for (int64_t i = 0; i < slots; ++i) {
+        float acc = 0.0f;
+        for (int q = 0; q < qpk; ++q) { volatile float sq = temp[i * qpk + q] * temp[i * qpk + q]; acc = acc + sq; }
+        m[i] = m[i] + acc;
+      }
+    };
+    std::vector<float> m1 = m0, m2;
+    aggregate(m1);
+    m2 = m1;
+    aggregate(m2);
+    std::vector<int32_t> slot_of_seq = {0}, seqpos = {seq_pos}, protv = {prot}, kper = {kfree};
+    std::vector<int32_t> hang2(G), ctx2(L * B * H, ctx);
+    for (int g = 0; g < G; ++g) hang2[g] = ctx % bs == 0 ? bs : ctx % bs;
+    float *d_m = to_dev(m0), *d_mr = to_dev(m1), *d_temp = to_dev(temp);
+    int32_t *d_seq = to_dev(seq_by), *d_lay = to_dev(lay_by), *d_head = to_dev(head_by), *d_lbn = to_dev(lbn_by),
+            *d_pos2 = to_dev(pos2), *d_sos = to_dev(slot_of_seq), *d_sp = to_dev(seqpos), *d_pr = to_dev(protv),
+            *d_kper = to_dev(kper), *d_hang2 = to_dev(hang2), *d_ctx2 = to_dev(ctx2);
+    const size_t wsb2 = kvc_schedule_evictions_workspace_bytes(N, G, B, bs), hvb = kvc_harvest_buffer_bytes(G, B);
+    void *ws2, *hbuf;
+    CK(hipMalloc(&ws2, wsb2)); CK(hipMalloc(&hbuf, hvb)); CK(hipMemset(hbuf, 0, hvb));
+    int32_t* out[3][3];
+    for (auto& o : out) { CK(hipMalloc(&o[0], (size_t)N * 4)); CK(hipMalloc(&o[1], G * 4)); CK(hipMalloc(&o[2], G * 4)); }
+    kvc_schedule_params sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.token_positions = d_pos2; sp.seq_index_by_block = d_seq; sp.layer_index_by_block = d_lay;
+    sp.head_index_by_block = d_head; sp.logical_block_num_by_block = d_lbn; sp.num_blocks = NB;
+    sp.block_size = bs; sp.num_layers = L; sp.num_kv_heads = H; sp.num_seqs = B;
+    sp.seq_slot_of_seq = d_sos; sp.seq_slot_len = 1; sp.seq_positions = d_sp; sp.num_protected = d_pr;
+    sp.evicted_blocks_per_seq = d_kper; sp.context_lens = d_ctx2; sp.hanging_token_count = d_hang2;
+    sp.evicted_kv_offsets = d_offs; sp.total_slots = N; sp.mode = 1; sp.null_value = NUL;
+    sp.max_evicted_blocks_hint = kfree; sp.harvest_buf = hbuf; sp.harvest_widen = 0.25f;
+    auto schedule = [&](float* metrics, int harvest, int32_t** o) {
+      sp.metrics = metrics; sp.harvest = harvest;
+      sp.evicted_logical_indices = o[0]; sp.evicted_kv_count = o[1]; sp.evicted_block_count = o[2];
+      return kvc_schedule_evictions(&sp, ws2, wsb2, s);
+    };
+    auto flag = [&]() {
+      uint32_t w = 99;
+      hipStreamSynchronize(s);
+      hipMemcpy(&w, (uint8_t*)ws2 + kvc_schedule_evictions_fallback_offset(N, G, B, bs), 4, hipMemcpyDeviceToHost);
+      return w;
+    };
+    bool hok = kvc_harvest_eligible(&sp, qpk) == 1 && kvc_pivot_memory_eligible(&sp) == 1 &&
+               kvc_schedule_evictions_plan(&sp) == 1;
+    // step 1: the usual way; the call leaves pivots (bit 1)
+    KV(kvc_aggregate_decode(d_m, d_temp, slots, qpk, 1, 0, s));
+    KV(schedule(d_m, 2, out[0]));
+    hok = hok && flag() == 0 && same(d_m, m1, "metrics after step 1");
+    // step 2, reference run: aggregate_decode on a copy of the store, the call's own pass on the remembered pivots (bits 1 | 2)
+    KV(kvc_aggregate_decode(d_mr, d_temp, slots, qpk, 1, 0, s));
+    void* hbuf2;
+    CK(hipMalloc(&hbuf2, hvb));
+    CK(hipMemcpyAsync(hbuf2, hbuf, hvb, hipMemcpyDeviceToDevice, s));
+    sp.harvest_buf = hbuf2;
+    KV(schedule(d_mr, 2 | 4, out[1]));
+    hok = hok && flag() == 0 && same(d_mr, m2, "metrics after step 2 (aggregate_decode)");
+    // step 2, harvested: the aggregation pass makes the lists, the schedule call runs on them (bits 0 | 1)
+    sp.harvest_buf = hbuf; sp.metrics = d_m;
+    KV(kvc_aggregate_decode_harvest(&sp, d_temp, qpk, 1, 0, s));
+    KV(schedule(d_m, 1 | 2, out[2]));
+    hok = hok && flag() == 0 && same(d_m, m2, "metrics after step 2 (aggregate_decode_harvest)");
+    std::vector<int32_t> r_eli(N), r_cnt(G), r_blk(G);
+    CK(hipMemcpy(r_eli.data(), out[1][0], (size_t)N * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(r_cnt.data(), out[1][1], G * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(r_blk.data(), out[1][2], G * 4, hipMemcpyDeviceToHost));
+    long freed = 0;
+    for (int g = 0; g < G; ++g) freed += r_blk[g];
+    hok = hok && freed == kfree && same(out[2][0], r_eli, "evicted_logical_indices (harvested vs own pass)") &&
+          same(out[2][1], r_cnt, "evicted_kv_count (harvested vs own pass)") &&
+          same(out[2][2], r_blk, "evicted_block_count (harvested vs own pass)");
+    // a call that cannot use lists says so
+    sp.use_average = 1;
+    rc = schedule(d_m, 1, out[2]);
+    hok = hok && rc == 1 && strstr(kvc_last_error(), "not eligible") != nullptr;
+    if (!hok) printf("harvest protocol failed\n");
+    ok = ok && hok;
+  }
   // error convention: unsupported block size -> rc 1 + message
   rc = kvc_count_block_evictions(d_ebc, d_eli, d_offs, d_hang, G, N, 0, NUL, s);
   ok = ok && rc == 1 && strstr(kvc_last_error(), "Unsupported block size") != nullptr;

@@ -1,7 +1,8 @@
 """The drop-in boundary without Python in the loop: a C++ host (tests/cabi/cabi_host.cpp)
 links libkvc_mi355x.so by its header only, runs count -> moves -> compaction and compares
-with the C oracle, then the decode attention through its parameter struct against a plain
-float loop."""
+with the C oracle, two decode steps of aggregation + eviction schedule through the harvest
+protocol of ABI version 5 (lists made by the aggregation pass against the schedule's own pass), then
+the decode attention through its parameter struct against a plain float loop."""
 import os
 import shutil
 import subprocess

@@ -173,7 +173,7 @@ def test_lists_that_fall_short_are_redone_on_the_device():
     assert lp.step()["path"] == "small_eviction"
     lib = _lib.load()
     B, G = 3, 3 * 2 * 4
-    assert cm._hv_buf.numel() == lib.kvc_harvest_buffer_bytes(G, B)
+    assert cm._hv_buf.numel() >= lib.kvc_harvest_buffer_bytes(G, B)
 
     def no_pivots():                       # pivot 0: no key lies below it -> empty lists
         cm._hv_buf[256:256 + 4 * B] = 0

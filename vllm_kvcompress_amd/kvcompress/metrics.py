@@ -590,7 +590,7 @@ class CompressionMetrics:
             # the buffer: pivots only, or pivots + lists once somebody harvests
             full = bool(self.harvest_ahead)
             need = int(lib.kvc_harvest_buffer_bytes(B * L * H, B) if full else lib.kvc_harvest_pivot_bytes(B))
-            if self._hv_buf is None or self._hv_buf.numel() != need:
+            if self._hv_buf is None or self._hv_buf.numel() < need:      # (kept when the batch shrinks: offsets are the call's)
                 self._hv_buf = torch.zeros((need,), dtype=torch.uint8, device=dev)
                 self._hv = hl = None
             k_list = [int(v) for v in evicted_blocks_per_seq]
