@@ -182,8 +182,9 @@ def test_lists_that_fall_short_are_redone_on_the_device():
     info = lp.step(before_harvest=no_pivots)
     assert info["used"] and info["path"] == "small_eviction+fallback", info
     assert cm.harvest_misses == misses + 1 and cm.harvest_widen > widen
-    info = lp.step()                       # the pivots are made anew by a usual pass
-    assert not info["harvested"] and info["path"] == "small_eviction"
+    for _ in range(2):                     # the pivots are made anew by a usual pass; two calls without predictions
+        info = lp.step()
+        assert not info["harvested"] and not info["remembered"] and info["path"] == "small_eviction"
     assert lp.step()["used"]
 
 
@@ -355,3 +356,24 @@ def test_pivot_memory_under_the_batch_rule_of_the_reference():
         assert not info["harvested"] and not info["used"] and info["path"].startswith("small_eviction"), info
         remembered += info["remembered"]
     assert remembered >= 10, remembered
+
+
+def test_pivots_that_never_suffice_stop_being_used():
+    """every call's remembered pivots wiped: each predicted call lists nothing and is redone on the device (the
+    oracle's schedule all the same); the host then leaves predicted pivots alone for 2, 4, 8 ... calls, so redone
+    calls become rare instead of every other one"""
+    lp = Loop(L=2, H=4, bs=16, seq_lens=[700, 420, 555], cap=320)
+    cm = lp.cm
+
+    def wipe():
+        if cm._hv_buf is not None:
+            cm._hv_buf[256:256 + 4 * 3] = 0
+
+    lp.step(plain=True)
+    predicted = []
+    for it in range(40):
+        info = lp.step(plain=True, between=wipe)
+        assert info["path"] == ("small_eviction+fallback" if info["remembered"] else "small_eviction"), info
+        predicted.append(bool(info["remembered"]))
+    assert cm.harvest_misses == sum(predicted) and 3 <= sum(predicted) <= 6, predicted
+    assert not any(predicted[-8:]) or sum(predicted[-20:]) <= 1, predicted

@@ -178,6 +178,10 @@ class CompressionMetrics:
         env = os.environ.get("KVC_HARVEST_AHEAD", "")
         self.harvest_ahead = None if env == "" else env != "0"
         self.harvest_widen = float(os.environ.get("KVC_HARVEST_WIDEN", "0.25"))
+        self._hv_widen0 = self.harvest_widen
+        self._hv_streak = 0                # predicted calls in a row whose lists sufficed
+        self._hv_pause = 0                 # calls still to go without predicted pivots (after a miss)
+        self._hv_pause_len = 0
         # pivot memory (harvest bit 2; on unless KVC_PIVOT_MEMORY=0): without any harvest, a small-eviction call for
         # the batch of the call before takes the pivots that call left behind instead of sampling the store --
         # no sampling pass, no pivot kernel, half the candidates in its collecting pass.  Same results.
@@ -392,7 +396,7 @@ class CompressionMetrics:
         hv = self._hv
         self._hv_lists = None
         stream = _stream(self.metrics)
-        ok = (self.harvest_ahead and hv is not None and hv["seqs"] == tuple(int(s) for s in seq_indices)
+        ok = (self.harvest_ahead and self._hv_pause == 0 and hv is not None and hv["seqs"] == tuple(int(s) for s in seq_indices)
               and hv["buf"] is self._hv_buf and hv["full"] and hv["stream"] == stream and not self._fb_fault
               and isinstance(context_lens, torch.Tensor) and context_lens.is_cuda and context_lens.dtype == torch.int32
               and context_lens.is_contiguous()
@@ -448,11 +452,23 @@ class CompressionMetrics:
 
     def _note_flag(self, word: int, harvested: bool) -> None:
         if harvested:
-            # lists that fell short (the device redid the call): wider pivots, made anew by a usual pass
             if word:
+                # lists that fell short (the device redid the call, at about three times the cost of a call that
+                # samples): wider pivots, made anew by a usual pass -- and predicted pivots are left alone for 2, 4,
+                # ... 256 calls, so that a workload whose attention outruns every allowance costs a redone call
+                # now and then, not every other call
                 self.harvest_misses += 1
                 self.harvest_widen = min(8.0, max(0.5, 2.0 * self.harvest_widen))
                 self._hv = self._hv_lists = None
+                self._hv_streak = 0
+                self._hv_pause_len = min(max(2 * self._hv_pause_len, 2), 256)
+                self._hv_pause = self._hv_pause_len
+            else:
+                self._hv_streak += 1
+                if self._hv_streak >= 64:              # a long run without a miss: back towards the configured allowance
+                    self._hv_streak = 0
+                    self._hv_pause_len = 0
+                    self.harvest_widen = max(self._hv_widen0, 0.5 * self.harvest_widen)
         elif int(self.schedule_path) == 0:
             self._fb_penalty = min(max(2 * self._fb_penalty, 1), 64) if word else 0
             self._fb_backoff = self._fb_penalty
@@ -597,7 +613,9 @@ class CompressionMetrics:
             p.harvest_buf = self._hv_buf.data_ptr()
             p.harvest = 2
             hv = self._hv
-            if self._lists_usable(hl, seq_indices, seq_positions, num_protected, context_lens, k_list, stream):
+            if self._hv_pause > 0:
+                self._hv_pause -= 1
+            elif self._lists_usable(hl, seq_indices, seq_positions, num_protected, context_lens, k_list, stream):
                 p.harvest |= 1
             elif (self.pivot_memory and hv is not None and hv["buf"] is self._hv_buf and hv["stream"] == stream
                   and hv["seqs"] == tuple(int(x) for x in seq_indices) and self._k_within(k_list, hv["k"])):
