@@ -377,3 +377,25 @@ def test_pivots_that_never_suffice_stop_being_used():
         predicted.append(bool(info["remembered"]))
     assert cm.harvest_misses == sum(predicted) and 3 <= sum(predicted) <= 6, predicted
     assert not any(predicted[-8:]) or sum(predicted[-20:]) <= 1, predicted
+
+
+def test_under_inference_mode_no_lists_are_made():
+    """tensors made under torch.inference_mode() (vLLM's workers) keep no version counter: whether somebody wrote to
+    them between the harvest and the schedule call could not be known, so no lists are made -- the plain sums, and the
+    call's own pass (on remembered pivots), with the oracle's result"""
+    with torch.inference_mode():
+        lp = Loop(L=2, H=4, bs=16, seq_lens=[700, 420, 555], cap=320)
+        assert lp.cm.metrics.is_inference()
+        lp.step()
+        for it in range(4):
+            info = lp.step()
+            assert not info["harvested"] and not info["used"] and info["remembered"] and info["path"] == "small_eviction", info
+    # a store made outside, per-step tensors made inside: the same
+    lp = Loop(L=2, H=4, bs=16, seq_lens=[700, 420, 555], cap=320)
+    lp.step()
+    assert lp.step()["used"]
+    with torch.inference_mode():
+        info = lp.step()
+        assert not info["harvested"] and not info["used"] and info["path"] == "small_eviction", info
+    lp.step()
+    assert lp.step()["used"]

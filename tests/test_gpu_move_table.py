@@ -217,3 +217,34 @@ def test_move_scheduler_by_eviction_count(protected):
             np.testing.assert_array_equal(cmi.cpu().numpy(), want["cmi"], err_msg=f"{seq_len} {k} moves")
         counts = sorted(set(int(c) for c in want["ekc"].reshape(-1)))
         assert counts, counts
+
+
+def test_under_inference_mode_nothing_is_assumed_about_tensors_without_a_version_counter():
+    """vLLM's workers run under torch.inference_mode(): tensors made there keep no version counter, so neither the
+    tracked table's map nor the plan can be trusted for them -- the ops take the full fill / plan for themselves,
+    and the results are the oracle's"""
+    st = synth.make_state(num_layers=2, num_kv_heads=4, block_size=16, seq_lens=[600, 300], seed=3, protected=32)
+    evicted = [9, 4]
+    want = oracle_pipeline(st, evicted, mode="per_sequence")
+    with torch.inference_mode():
+        ds = hdev.upload(st, DEV, mode="per_sequence")
+        table = ops.track_move_table(torch.empty((st.total_slots + 77, 2), dtype=torch.int32, device=DEV))
+        assert table.is_inference()
+        k_np, v_np = synth.make_caches_u16(3, st.num_blocks, 32, 16)
+        for rep in range(3):
+            table.fill_(-5)                                   # (nobody can tell: the next call must clear all of it)
+            eli, ekc, ebc = ds.cm.schedule_evictions(list(st.seq_indices), ds.seq_positions, evicted, ds.context_lens,
+                                                     ds.hanging_token_count, ds.evicted_kv_offsets, list(st.protected),
+                                                     total_slots=st.total_slots)
+            cmc = torch.empty_like(ekc)
+            ops.schedule_cache_moves(table, cmc, eli, ekc, ds.evicted_kv_offsets, ds.block_tables, ds.context_lens, 16)
+            got = table.cpu().numpy()
+            np.testing.assert_array_equal(got[:st.total_slots], want["cmi"])
+            assert not got[st.total_slots:].any()
+            np.testing.assert_array_equal(eli.cpu().numpy(), want["eli"])
+            k, v = torch.from_numpy(k_np.copy()).to(DEV), torch.from_numpy(v_np.copy()).to(DEV)
+            m, p = ds.cm.metrics.clone(), ds.cm.token_positions.clone()
+            ops.execute_cache_moves(k, v, m, p, table, cmc, ds.evicted_kv_offsets, 1, 16)
+            w = oracle_pipeline(st, evicted, k_np, v_np, mode="per_sequence")
+            np.testing.assert_array_equal(k.cpu().numpy(), w["k"])
+            np.testing.assert_array_equal(m.cpu().numpy(), w["metrics"])

@@ -34,6 +34,17 @@ def _written(*tensors: torch.Tensor) -> None:
             torch.autograd.graph.increment_version(t)
 
 
+def _version_of(t: torch.Tensor) -> Optional[int]:
+    """a tensor's version counter, or None for a tensor made under torch.inference_mode() (vLLM's workers run
+    under it): those do not keep one, so nothing can be said about who wrote to them -- every "untouched since?"
+    question about them is answered with no"""
+    return None if t.is_inference() else t._version
+
+
+def _same_version(recorded: Optional[int], t: torch.Tensor) -> bool:
+    return recorded is not None and not t.is_inference() and recorded == t._version
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -195,12 +206,12 @@ def _schedule_t1_cache_moves(cache_moves_idx, cache_moves_count, evicted_logical
     mode, dmap, dmap_bytes = (1 if zero_fill else 0), None, 0
     rec = _tracked(cache_moves_idx)
     if rec is not None and not zero_fill:
-        rec.version = -1                  # the bare op leaves rows behind that the map does not know: full fill next time
+        rec.version = None                # the bare op leaves rows behind that the map does not know: full fill next time
         rec = None
     if rec is not None and bs >= 1:
         dmap_bytes = int(lib.kvc_cache_moves_dirty_map_bytes(rows, bs))
         known = (rec.dirty_map is not None and rec.block_size == bs and rec.dirty_map.numel() >= dmap_bytes
-                 and rec.version == cache_moves_idx._version)
+                 and _same_version(rec.version, cache_moves_idx))
         if known:
             mode = 2                      # zero everywhere but where the map says: clear just that
         else:                             # first use, or somebody else wrote to the table: the full fill
@@ -221,11 +232,11 @@ def _schedule_t1_cache_moves(cache_moves_idx, cache_moves_count, evicted_logical
             num_seqs, num_layers, num_kv_heads, block_tables.shape[3], bs,
             mode, _ptr(dmap), dmap_bytes, plan.data_ptr(), _stream(cache_moves_idx)))
     if rec is not None:
-        rec.version = cache_moves_idx._version
+        rec.version = _version_of(cache_moves_idx)
     # the plan belongs to exactly these three tensors as they are now (execute_cache_moves checks)
     index = dev.index if dev.index is not None else torch.cuda.current_device()
     _LAST_PLAN[(index, _stream(cache_moves_idx))] = (
-        plan, tuple((weakref.ref(t), t._version) for t in (cache_moves_idx, cache_moves_count, evicted_kv_offsets)),
+        plan, tuple((weakref.ref(t), _version_of(t)) for t in (cache_moves_idx, cache_moves_count, evicted_kv_offsets)),
         num_seqs * num_layers * num_kv_heads, bs)
 
 
@@ -237,7 +248,7 @@ def _plan_of(k_cache, cmi, cmc, offs, total_heads, block_size):
     if rec is None or rec[2] != total_heads or rec[3] != block_size:
         return None
     for (ref, version), t in zip(rec[1], (cmi, cmc, offs)):
-        if ref() is not t or t._version != version:
+        if ref() is not t or not _same_version(version, t):
             return None
     return rec[0]
 

@@ -319,22 +319,26 @@ class CompressionMetrics:
 
     # ------------------------------------------------------------------ harvest-ahead
     def _store_versions(self):
-        return tuple(t._version for t in (self.metrics, self.token_positions, self.seq_index_by_block,
-                                          self.layer_index_by_block, self.head_index_by_block,
-                                          self.logical_block_num_by_block))
+        """version counters of the six store tensors, or None if one of them was made under torch.inference_mode()
+        (no counter: nothing can be said about who wrote to it, so lists made from it are never trusted)"""
+        store = (self.metrics, self.token_positions, self.seq_index_by_block, self.layer_index_by_block,
+                 self.head_index_by_block, self.logical_block_num_by_block)
+        if any(t.is_inference() for t in store):
+            return None
+        return tuple(t._version for t in store)
 
     @staticmethod
     def _arg_record(x):
         """a batch argument as remembered between the harvest and its schedule call: a tensor by identity
         and version (held, so that neither can be reused), a list by value"""
         if isinstance(x, torch.Tensor):
-            return (x, x._version)
+            return (x, None if x.is_inference() else x._version)
         return (tuple(int(v) for v in x), None)
 
     @staticmethod
     def _arg_same(rec, x) -> bool:
         if isinstance(x, torch.Tensor):
-            return rec[0] is x and rec[1] == x._version
+            return rec[0] is x and rec[1] is not None and not x.is_inference() and rec[1] == x._version
         return not isinstance(rec[0], torch.Tensor) and rec[0] == tuple(int(v) for v in x)
 
     def _store_params(self, p, seq_indices, seq_pos, prot, context_lens, N: int) -> None:
@@ -386,7 +390,8 @@ class CompressionMetrics:
         objects, unmodified; lists: equal values), evictions at most widen / 2 larger than the ones the
         pivots were made for, and the store (metrics, positions, block metadata) not written through this object or torch in
         between -- a writer that goes around both (a custom kernel on ``metrics.data_ptr()``) must not run
-        between the two calls.  In every other case this is ``aggregate_decode`` and the schedule call
+        between the two calls.  Tensors made under ``torch.inference_mode()`` keep no version counter, so with a
+        store or batch arguments of that kind no lists are made (allocate them outside, as an engine's start-up does).  In every other case this is ``aggregate_decode`` and the schedule call
         takes its usual pass.  Returns whether lists were made."""
         if self.random or not self.record_decoding_metrics:
             return False
@@ -401,7 +406,11 @@ class CompressionMetrics:
               and isinstance(context_lens, torch.Tensor) and context_lens.is_cuda and context_lens.dtype == torch.int32
               and context_lens.is_contiguous()
               and tuple(context_lens.shape) == (self.num_layers, len(seq_indices), self.num_kv_heads)
-              and not torch.cuda.is_current_stream_capturing())
+              and not torch.cuda.is_current_stream_capturing()
+              # (tensors made under torch.inference_mode() keep no version counter: lists made from them could never
+              # be trusted by the schedule call, so none are made)
+              and self._store_versions() is not None
+              and not any(isinstance(x, torch.Tensor) and x.is_inference() for x in (seq_positions, num_protected, context_lens)))
         p = None
         if ok:
             lib = _lib.load()
@@ -430,7 +439,7 @@ class CompressionMetrics:
         return (hl is not None and hl["buf"] is self._hv_buf and hl["stream"] == stream
                 and hl["seqs"] == tuple(int(s) for s in seq_indices)
                 and self._arg_same(hl["seq_pos"], seq_positions) and self._arg_same(hl["prot"], num_protected)
-                and self._arg_same(hl["ctx"], context_lens) and hl["store"] == self._store_versions()
+                and self._arg_same(hl["ctx"], context_lens) and hl["store"] is not None and hl["store"] == self._store_versions()
                 and self._k_within(k_list, hl["k"]))
 
     def _k_within(self, k_list, k_then) -> bool:
