@@ -771,6 +771,7 @@ def decode_step_compare(a2, st, ds, evicted, k_cache, v_cache, cmi, cmc, device,
             "stages_ms": {"S0_aggregate_decode": ms(0, 1), "S1_schedule_evictions": ms(1, 2), "S2_schedule_moves": ms(2, 3),
                           "S3_execute_moves": ms(3, 4)},
             "S0_GBps": slots * (4 * qpk + 8) / (ms(0, 1) * 1e-3) / 1e9,
+            "S0_frac_of_hbm_peak": slots * (4 * qpk + 8) / (ms(0, 1) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "S1_schedule": cm.last_schedule_path(), "harvested_steps": used, "harvest_misses": cm.harvest_misses - misses0}
         keep[variant] = (cm.metrics.clone(), eli.clone(), ekc.clone(), ebc.clone(), cmc.clone(),
                          torch.cat([cmi[o:o + int(c)] for o, c in zip(st.evicted_kv_offsets.reshape(-1)[:64].tolist(),
