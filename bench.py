@@ -705,6 +705,18 @@ def measure_workload(a2, seed, device, steps, warmup, probe):
     return res
 
 
+def _committed_s0_traffic(kernel_tag):
+    """HBM bytes per launch of the aggregation kernel from the committed PMC collection (None if absent)"""
+    try:
+        d = json.load(open(os.path.join(REPO, "profiles", "r4_decode_step_pmc.json")))
+        for name, v in d.get("aggregation", {}).items():
+            if kernel_tag in name:
+                return v["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def decode_step_compare(a2, st, ds, evicted, k_cache, v_cache, cmi, cmc, device, steps, warmup):
     """The WHOLE decode step of the continual steady state -- S0 aggregate_decode (reference metrics.py:429-439: the
     whole store, every step; 4 * qpk + 8 B per slot) + S1 + S2 + S3 -- timed twice from the same state with the same
@@ -771,7 +783,14 @@ def decode_step_compare(a2, st, ds, evicted, k_cache, v_cache, cmi, cmc, device,
             "stages_ms": {"S0_aggregate_decode": ms(0, 1), "S1_schedule_evictions": ms(1, 2), "S2_schedule_moves": ms(2, 3),
                           "S3_execute_moves": ms(3, 4)},
             "S0_GBps": slots * (4 * qpk + 8) / (ms(0, 1) * 1e-3) / 1e9,
-            "S0_frac_of_hbm_peak": slots * (4 * qpk + 8) / (ms(0, 1) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "S0_roofline": {"kernel": "kvc::aggregate_harvest_kernel" if cm.harvest_ahead else "kvc::aggregate_decode_q4_kernel",
+                            "bound": "hbm", "achieved": slots * (4 * qpk + 8) / (ms(0, 1) * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                            "unit": "GB/s", "frac": slots * (4 * qpk + 8) / (ms(0, 1) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                            "algorithmic_bytes_per_launch": slots * (4 * qpk + 8),
+                            "traffic": _committed_s0_traffic("aggregate_harvest" if cm.harvest_ahead else "aggregate_decode_q4"),
+                            "traffic_source": "profiles/r4_decode_step_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                                              "passes over tools/decode_step.py; 2 x FETCH + WRITE)",
+                            "timing": "the S0 stage: HIP events on the launch stream around the call (one kernel + the counters' fill)"},
             "S1_schedule": cm.last_schedule_path(), "harvested_steps": used, "harvest_misses": cm.harvest_misses - misses0}
         keep[variant] = (cm.metrics.clone(), eli.clone(), ekc.clone(), ebc.clone(), cmc.clone(),
                          torch.cat([cmi[o:o + int(c)] for o, c in zip(st.evicted_kv_offsets.reshape(-1)[:64].tolist(),
