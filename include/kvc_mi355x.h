@@ -331,7 +331,8 @@ size_t kvc_schedule_evictions_workspace_bytes(int64_t total_slots, int32_t total
  * runs records -> selection -> emission on these lists.  The result is exact or the flag is raised
  * (fallback on device), exactly as when the lists come from the schedule's own collecting pass.
  * Eligible: the small-eviction schedule in its position-lazy form (no use_average, no bias, mode 1
- * or one sequence), block size 8 / 16 / 32, num_queries_per_kv 4 or 8. */
+ * or one sequence), block size 8 / 16 / 32; num_queries_per_kv 4 or 8 read the temp rows as 16-byte
+ * loads, any other value as scalars (as kvc_aggregate_decode does). */
 size_t kvc_harvest_buffer_bytes(int32_t total_heads, int32_t num_seqs);
 int32_t kvc_pivot_memory_eligible(const kvc_schedule_params* p);
 size_t kvc_harvest_pivot_bytes(int32_t num_seqs);   /* its leading part: enough for harvest bits 1 and 2 without bit 0 */

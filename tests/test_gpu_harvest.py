@@ -117,7 +117,7 @@ class Loop:
         return info
 
 
-@pytest.mark.parametrize("bs,qpk,use_l2,stride", [(16, 4, True, 0), (16, 4, False, 2), (32, 8, True, 0), (8, 4, True, 0),
+@pytest.mark.parametrize("bs,qpk,use_l2,stride", [(16, 4, True, 0), (16, 4, False, 2), (32, 8, True, 0), (8, 4, True, 0), (16, 1, True, 0), (16, 7, False, 0),
                                                    (16, 8, True, 4)])
 def test_continual_steps_on_harvested_lists(bs, qpk, use_l2, stride):
     lp = Loop(L=2, H=4, bs=bs, seq_lens=[40 * bs + 5, 25 * bs, 33 * bs + 9], cap=20 * bs, qpk=qpk, use_l2=use_l2,

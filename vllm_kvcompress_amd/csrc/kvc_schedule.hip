@@ -205,7 +205,7 @@ static bool harvest_plan(const kvc_schedule_params& p) {
   return topk_plan(p, p2, sshift) == KVC_WHY_TAKEN && lazy_plan(p);
 }
 extern "C" int32_t kvc_harvest_eligible(const kvc_schedule_params* p, int32_t num_queries_per_kv) {
-  if (p == nullptr || !(num_queries_per_kv == 4 || num_queries_per_kv == 8)) return 0;
+  if (p == nullptr || num_queries_per_kv < 1) return 0;
   return harvest_plan(*p) ? 1 : 0;
 }
 // pivot memory (harvest bits 1 and 2 without bit 0) needs no more than the small-eviction schedule itself:
@@ -668,11 +668,11 @@ extern "C" int kvc_aggregate_decode_harvest(const kvc_schedule_params* pp, float
   const bool big = p.num_blocks * (int64_t)p.block_size >= (int64_t)1 << 28;        // >= 1 GiB of metrics
 #define KVC_HARVEST2(BSV, QVV)                                                                                      \
   if (big)                                                                                                           \
-    hipLaunchKernelGGL((aggregate_harvest_kernel<BSV, QVV, true>), grid, blk, 0, s, p, ws, temp_metrics, hv_pivot, use_l2, clear_temp); \
+    hipLaunchKernelGGL((aggregate_harvest_kernel<BSV, QVV, true>), grid, blk, 0, s, p, ws, temp_metrics, hv_pivot, num_queries_per_kv, use_l2, clear_temp); \
   else                                                                                                               \
-    hipLaunchKernelGGL((aggregate_harvest_kernel<BSV, QVV, false>), grid, blk, 0, s, p, ws, temp_metrics, hv_pivot, use_l2, clear_temp);
+    hipLaunchKernelGGL((aggregate_harvest_kernel<BSV, QVV, false>), grid, blk, 0, s, p, ws, temp_metrics, hv_pivot, num_queries_per_kv, use_l2, clear_temp);
 #define KVC_HARVEST(BSV)                                                                                             \
-  if (num_queries_per_kv == 4) { KVC_HARVEST2(BSV, 1) } else { KVC_HARVEST2(BSV, 2) }
+  if (num_queries_per_kv == 4) { KVC_HARVEST2(BSV, 1) } else if (num_queries_per_kv == 8) { KVC_HARVEST2(BSV, 2) } else { KVC_HARVEST2(BSV, 0) }
   if (p.block_size == 8) { KVC_HARVEST(8); }
   else if (p.block_size == 16) { KVC_HARVEST(16); }
   else { KVC_HARVEST(32); }

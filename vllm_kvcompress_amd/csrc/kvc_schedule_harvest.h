@@ -56,9 +56,11 @@ inline HvLayout hv_layout(int32_t G, int32_t B) {
   return l;
 }
 
+// QV = qpk / 4 (qpk 4 or 8: the temp row as 16-byte loads), or 0: any qpk, the row as scalar loads summed while they
+// arrive (the generic loop of aggregate_decode_kernel: the same additions in the same order)
 template <int BS, int QV, bool STREAM>
 __global__ __launch_bounds__(256) void aggregate_harvest_kernel(kvc_schedule_params p, SchedWs ws, float* __restrict__ temp,
-                                                                const uint32_t* __restrict__ hv_pivot, int use_l2,
+                                                                const uint32_t* __restrict__ hv_pivot, int qpk, int use_l2,
                                                                 int clear_temp) {
   constexpr int ROWS = BS;                           // 64 blocks x BS slots = BS rows of 64 slots
   constexpr int U = 8;                               // rows in flight
@@ -92,19 +94,30 @@ __global__ __launch_bounds__(256) void aggregate_harvest_kernel(kvc_schedule_par
   const int64_t wave = (int64_t)blockIdx.x * 4 + w, nwaves = (int64_t)gridDim.x * 4;
   for (int64_t b0 = wave * 64; b0 < p.num_blocks; b0 += nwaves * 64) {
     const int64_t slot0 = b0 * BS;
-    f32x4 t[U][QV];
-    float m[U];
+    f32x4 t[U][QV > 0 ? QV : 1];
+    float m[U], gsum[U];
     auto load_rows = [&](int r0) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int64_t s = slot0 + (int64_t)(r0 + u) * 64 + lane;
+        gsum[u] = 0.f;
         if (s < num_slots) {
+          if constexpr (QV > 0) {
 #pragma unroll
-          for (int v = 0; v < QV; ++v) t[u][v] = __builtin_nontemporal_load(temp4 + s * QV + v);
+            for (int v = 0; v < QV; ++v) t[u][v] = __builtin_nontemporal_load(temp4 + s * QV + v);
+          } else {
+            float a = 0.0f;
+            for (int q = 0; q < qpk; ++q) {
+              float x = temp[s * qpk + q];
+              if (use_l2) x = __fmul_rn(x, x);
+              a = __fadd_rn(a, x);
+            }
+            gsum[u] = a;
+          }
           m[u] = STREAM ? __builtin_nontemporal_load(metrics + s) : metrics[s];
         } else {
 #pragma unroll
-          for (int v = 0; v < QV; ++v) t[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int v = 0; v < (QV > 0 ? QV : 1); ++v) t[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
           m[u] = 0.f;
         }
       }
@@ -132,18 +145,26 @@ __global__ __launch_bounds__(256) void aggregate_harvest_kernel(kvc_schedule_par
         const int64_t s = slot0 + (int64_t)(r0 + u) * 64 + lane;
         const bool in = s < num_slots;
         float acc = 0.0f;
+        if constexpr (QV > 0) {
 #pragma unroll
-        for (int v = 0; v < QV; ++v) {
-          f32x4 x = t[u][v];
-          if (use_l2) { x.x = __fmul_rn(x.x, x.x); x.y = __fmul_rn(x.y, x.y); x.z = __fmul_rn(x.z, x.z); x.w = __fmul_rn(x.w, x.w); }
-          acc = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(acc, x.x), x.y), x.z), x.w);
+          for (int v = 0; v < QV; ++v) {
+            f32x4 x = t[u][v];
+            if (use_l2) { x.x = __fmul_rn(x.x, x.x); x.y = __fmul_rn(x.y, x.y); x.z = __fmul_rn(x.z, x.z); x.w = __fmul_rn(x.w, x.w); }
+            acc = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(acc, x.x), x.y), x.z), x.w);
+          }
+        } else {
+          acc = gsum[u];
         }
         const float mn = __fadd_rn(m[u], acc);
         if (in) {
           if constexpr (STREAM) __builtin_nontemporal_store(mn, metrics + s); else metrics[s] = mn;
           if (clear_temp) {
+            if constexpr (QV > 0) {
 #pragma unroll
-            for (int v = 0; v < QV; ++v) temp4[s * QV + v] = f32x4{0.f, 0.f, 0.f, 0.f};
+              for (int v = 0; v < QV; ++v) temp4[s * QV + v] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+              for (int q = 0; q < qpk; ++q) temp[s * qpk + q] = 0.0f;
+            }
           }
         }
         const int src = (r0 + u) * BPR + lane / BS;  // the lane that looks after this slot's block
