@@ -192,7 +192,7 @@ class CompressionMetrics:
         self._hv_buf = None                # pivots + lists (kvc_harvest_buffer_bytes)
         self._hv = None                    # pivots in _hv_buf: the batch and eviction sizes they were made for
         self._hv_lists = None              # lists in _hv_buf: the call they were made for
-        self._fb_was_harvested = False     # the flag word in flight belongs to a harvested call
+        self._fb_was_predicted = False     # the flag word in flight belongs to a call on predicted pivots (harvested lists / pivot memory)
 
     # temp_metrics is handed to the attention kernels, which write into it; reading the
     # attribute therefore marks it dirty so that the fused clear in aggregate_decode stays
@@ -457,10 +457,12 @@ class CompressionMetrics:
         self._fb_event = None
         if word & 2:
             self._raise_fallback_fault("an earlier")
-        self._note_flag(word, self._fb_was_harvested)
+        self._note_flag(word, self._fb_was_predicted)
 
-    def _note_flag(self, word: int, harvested: bool) -> None:
-        if harvested:
+    def _note_flag(self, word: int, predicted: bool) -> None:
+        """what a call's flag word means for the calls to come (predicted: it ran on harvested lists or on
+        remembered pivots)"""
+        if predicted:
             if word:
                 # lists that fell short (the device redid the call, at about three times the cost of a call that
                 # samples): wider pivots, made anew by a usual pass -- and predicted pivots are left alone for 2, 4,
@@ -668,7 +670,7 @@ class CompressionMetrics:
             if self._fb_event is None:      # (one copy in flight at a time: the pinned word is read before it is reused)
                 with torch.cuda.device(dev):
                     self._fb_pin.copy_(ws[off:off + 4].view(torch.int32), non_blocking=True)
-                    self._fb_was_harvested = bool(p.harvest & 5)
+                    self._fb_was_predicted = bool(p.harvest & 5)
                     self._fb_event = torch.cuda.Event()
                     self._fb_event.record()
         return out_idx, out_kv, out_blk
