@@ -103,6 +103,10 @@ class Loop:
         got = dict(eli=eli.cpu().numpy(), ekc=ekc.cpu().numpy(), ebc=ebc.cpu().numpy())
         for key in KEYS:
             np.testing.assert_array_equal(got[key], want[key], err_msg=f"step {self.step_no} (sel {sel}, k {evicted}): {key}")
+        if cm.last_schedule[2] == 1:
+            assert cm.last_schedule_reason.endswith("[lists: the aggregation pass]" if cm.last_harvest_used else
+                                                    "[pivots: the call before]" if cm.last_pivot_memory_used else
+                                                    "[pivots: sampled]"), cm.last_schedule_reason
         info = dict(harvested=harvested, used=cm.last_harvest_used, path=cm.last_schedule_path(), evicted=evicted,
                     remembered=cm.last_pivot_memory_used)
         # ---- carry the host state on (the oracle's compaction; only the selected sequences were compressed)

@@ -657,6 +657,10 @@ class CompressionMetrics:
         self.last_schedule_reason = self._describe_plan(
             self.last_schedule[2], int(lib.kvc_schedule_evictions_plan_reason(ctypes.byref(p))),
             backoff=int(p.schedule_path) == 1 and int(self.schedule_path) != 1)
+        if self.last_schedule[2] == 1:
+            # ... and where the small-eviction schedule took its pivots / lists from
+            self.last_schedule_reason += (" [lists: the aggregation pass]" if p.harvest & 1 else
+                                          " [pivots: the call before]" if p.harvest & 4 else " [pivots: sampled]")
         if self.last_schedule[2] and self.strict_fallback and not capturing:
             off = self.last_schedule[1]
             word = int(ws[off:off + 4].view(torch.int32).item())
