@@ -659,6 +659,10 @@ def measure_workload(a2, seed, device, steps, warmup, probe):
         "ms_per_step": step_ms, "value": (evs + moved) / (step_ms * 1e-3),
         "stages_ms": {"S1_schedule_evictions": s1, "S2_schedule_moves": ms(1, 2), "S3_execute_moves": ms(2, 4)},
         "S1_schedule": ds.cm.last_schedule_path(),
+        # (a "[pivots: the call before]" here: the small-eviction schedule did not sample -- on this bench's static store
+        # the pivots of the call before are exact; in an engine they are one decode step of attention old, which
+        # profiles/r4_harvest_soak.txt runs for 400 steps of an evolving state without a pass that listed too little)
+        "S1_schedule_reason": ds.cm.last_schedule_reason,
         # S1 against ITS lower bound (12.75 B per candidate slot)
         "S1_lower_bound_GBps": N * 12.75 / (s1 * 1e-3) / 1e9,
         "S1_frac_of_hbm_peak_at_lower_bound": N * 12.75 / (s1 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
