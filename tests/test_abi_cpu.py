@@ -230,3 +230,41 @@ def test_harvest_eligibility_and_buffer_sizes():
         assert piv % 256 == 0 and 256 + 4 * B <= piv < 256 + 4 * B + 256
         assert full % 256 == 0 and full >= piv + 64 * 128 + G * 4 + G * 256 * 8 and full < piv + 64 * 128 + G * 4 + G * 256 * 8 + 1024
     assert int(lib.kvc_harvest_buffer_bytes(0, 1)) == 0 and int(lib.kvc_harvest_pivot_bytes(0)) == 0
+
+
+def test_host_policy_around_predicted_pivots():
+    """CompressionMetrics' bookkeeping for calls that ran on predicted pivots (harvested lists / the call before's
+    pivots), without a device: a raised flag doubles the allowance, drops the pivots and pauses predictions for
+    2, 4 ... 256 calls; 64 clean predicted calls in a row halve the allowance again; flags of calls that sampled
+    keep their own penalty (the digit rounds for 1, 2, 4 ... 64 calls)"""
+    from vllm_kvcompress_amd.kvcompress.metrics import CompressionMetrics
+    cm = object.__new__(CompressionMetrics)
+    cm.harvest_misses, cm.harvest_widen, cm._hv_widen0 = 0, 0.25, 0.25
+    cm._hv, cm._hv_lists = {"k": [1]}, {"k": [1]}
+    cm._hv_streak = cm._hv_pause = cm._hv_pause_len = 0
+    cm.schedule_path, cm._fb_penalty, cm._fb_backoff = 0, 0, 0
+    pauses, widens = [], []
+    for _ in range(10):
+        cm._hv = {"k": [1]}
+        cm._note_flag(1, True)
+        assert cm._hv is None and cm._hv_lists is None
+        pauses.append(cm._hv_pause)
+        widens.append(cm.harvest_widen)
+    assert pauses == [2, 4, 8, 16, 32, 64, 128, 256, 256, 256] and cm.harvest_misses == 10
+    assert widens[:6] == [0.5, 1.0, 2.0, 4.0, 8.0, 8.0] and cm._fb_penalty == 0
+    for n in range(64 * 5):
+        cm._note_flag(0, True)
+    assert cm._hv_pause_len == 0 and cm.harvest_widen == 0.25          # 8 -> 4 -> 2 -> 1 -> 0.5 -> 0.25
+    cm._note_flag(1, True)
+    assert cm._hv_pause == 2 and cm.harvest_widen == 0.5
+    # the allowance in evictions: a quarter of it may go to a sequence that frees more than it did
+    cm.harvest_widen = 0.25
+    assert cm._k_within([8, 8], [8, 8]) and cm._k_within([9, 1], [8, 8]) and not cm._k_within([10, 8], [8, 8])
+    assert not cm._k_within([8], [8, 8]) and cm._k_within([0, 0], [0, 0]) and not cm._k_within([1, 0], [0, 0])
+    # a call that sampled: the usual penalty
+    cm._note_flag(1, False)
+    assert (cm._fb_penalty, cm._fb_backoff) == (1, 1)
+    cm._note_flag(1, False)
+    assert cm._fb_penalty == 2
+    cm._note_flag(0, False)
+    assert cm._fb_penalty == 0 and cm.harvest_misses == 11
