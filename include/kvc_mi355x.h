@@ -305,10 +305,10 @@ typedef struct kvc_schedule_params {
                                                *   one decode step of attention old either way, and a pass that lists
                                                *   too little raises the flag as always.  Only the first
                                                *   kvc_harvest_pivot_bytes() of the buffer are touched.
-                                               * Bit 0 needs the small-eviction schedule in its position-lazy form
-                                               * (kvc_harvest_eligible; an error otherwise), bits 1 and 2 any
-                                               * small-eviction call (kvc_pivot_memory_eligible; ignored by the
-                                               * other schedules). */
+                                               * All three are for calls that take the small-eviction schedule
+                                               * (kvc_harvest_eligible / kvc_pivot_memory_eligible) and are ignored
+                                               * by the other schedules; bits 0 and 2 without harvest_buf are an
+                                               * error. */
   float harvest_widen;                        /* bit 1: allowance for keys that the next step's attention lifts over
                                                * the pivot, as a fraction of Tgt (<= 0: 0.25) */
   /* outputs */
@@ -330,9 +330,12 @@ size_t kvc_schedule_evictions_workspace_bytes(int64_t total_slots, int32_t total
  * appended to their head's candidate list there.  kvc_schedule_evictions with harvest bit 0 then
  * runs records -> selection -> emission on these lists.  The result is exact or the flag is raised
  * (fallback on device), exactly as when the lists come from the schedule's own collecting pass.
- * Eligible: the small-eviction schedule in its position-lazy form (no use_average, no bias, mode 1
- * or one sequence), block size 8 / 16 / 32; num_queries_per_kv 4 or 8 read the temp rows as 16-byte
- * loads, any other value as scalars (as kvc_aggregate_decode does). */
+ * Eligible: every call that takes the small-eviction schedule (block size 8 / 16 / 32).  In its
+ * position-lazy form (no use_average, no bias, mode 1 or one sequence) the pass reads a position only
+ * for the keys below the pivot; otherwise (averaged metrics, a position bias, the reference's batch > 1
+ * rule) it streams the position rows next to the sums, makes every key in full and counts the masked
+ * slots per head, as that schedule's full collecting pass does.  num_queries_per_kv 4 or 8 read the
+ * temp rows as 16-byte loads, any other value as scalars (as kvc_aggregate_decode does). */
 size_t kvc_harvest_buffer_bytes(int32_t total_heads, int32_t num_seqs);
 int32_t kvc_pivot_memory_eligible(const kvc_schedule_params* p);
 size_t kvc_harvest_pivot_bytes(int32_t num_seqs);   /* its leading part: enough for harvest bits 1 and 2 without bit 0 */

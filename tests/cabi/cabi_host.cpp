@@ -214,10 +214,10 @@ int main() {
     hok = hok && freed == kfree && same(out[2][0], r_eli, "evicted_logical_indices (harvested vs own pass)") &&
           same(out[2][1], r_cnt, "evicted_kv_count (harvested vs own pass)") &&
           same(out[2][2], r_blk, "evicted_block_count (harvested vs own pass)");
-    // a call that cannot use lists says so
-    sp.use_average = 1;
+    // lists without the buffer they would be in: an error
+    sp.harvest_buf = nullptr;
     rc = schedule(d_m, 1, out[2]);
-    hok = hok && rc == 1 && strstr(kvc_last_error(), "not eligible") != nullptr;
+    hok = hok && rc == 1 && strstr(kvc_last_error(), "without a harvest buffer") != nullptr;
     if (!hok) printf("harvest protocol failed\n");
     ok = ok && hok;
   }

@@ -192,8 +192,8 @@ def test_schedule_plan_says_why():
 
 def test_harvest_eligibility_and_buffer_sizes():
     """ABI version 5, the host-side questions (no device needed): which calls may run on lists the aggregation
-    pass made (the small-eviction schedule in its position-lazy form), which may take the pivots of the call
-    before (any small-eviction call), and how large the buffer between them is"""
+    pass made / take the pivots of the call before (any call that takes the small-eviction schedule, whatever its
+    keys depend on), and how large the buffer between them is"""
     import ctypes
     lib = kvc.load()
     keep = []
@@ -217,18 +217,18 @@ def test_harvest_eligibility_and_buffer_sizes():
     assert both() == (1, 1)
     assert both(qpk=8) == (1, 1) and both(qpk=7) == (1, 1) and both(qpk=1) == (1, 1) and both(qpk=0) == (0, 1)
     assert both(B=16) == (1, 1)                                   # per_sequence: sequences do not need each other
-    assert both(B=16, mode=0) == (0, 1)                           # the reference's batch > 1 rule: the full pass, its pivots kept
-    assert both(B=1, mode=0) == (1, 1)                            # ... which a single sequence does not need
-    assert both(use_average=1) == (0, 1) and both(bias=True) == (0, 1)     # keys that depend on the position
-    assert both(path=3) == (0, 1)                                 # the full pass forced (tests)
+    assert both(B=16, mode=0) == (1, 1)                           # the reference's batch > 1 rule: the position rows are streamed too
+    assert both(B=1, mode=0) == (1, 1)
+    assert both(use_average=1) == (1, 1) and both(bias=True) == (1, 1)     # keys that depend on the position: the same
+    assert both(path=3) == (1, 1)                                 # the full pass forced (tests)
     assert both(hint=100000) == (0, 0) and both(hint=-1) == (0, 0)         # bulk / unknown: not the small-eviction schedule
     assert both(path=1) == (0, 0) and both(bs=4) == (0, 0) and both(uniform=1) == (0, 0)
     assert int(lib.kvc_harvest_eligible(None, 4)) == 0 and int(lib.kvc_pivot_memory_eligible(None)) == 0
-    # the buffer: 256 B of header, 4 B per sequence, then (lists) 64 counters a cache line apart, 4 B + 256 x 8 B per head
+    # the buffer: 256 B of header, 4 B per sequence, then (lists) 64 counters a cache line apart, 2 x 4 B + 256 x 8 B per head
     for G, B in ((256, 1), (65536, 256), (4096, 16)):
         piv, full = int(lib.kvc_harvest_pivot_bytes(B)), int(lib.kvc_harvest_buffer_bytes(G, B))
         assert piv % 256 == 0 and 256 + 4 * B <= piv < 256 + 4 * B + 256
-        assert full % 256 == 0 and full >= piv + 64 * 128 + G * 4 + G * 256 * 8 and full < piv + 64 * 128 + G * 4 + G * 256 * 8 + 1024
+        assert full % 256 == 0 and full >= piv + 64 * 128 + G * 8 + G * 256 * 8 and full < piv + 64 * 128 + G * 8 + G * 256 * 8 + 1024
     assert int(lib.kvc_harvest_buffer_bytes(0, 1)) == 0 and int(lib.kvc_harvest_pivot_bytes(0)) == 0
 
 

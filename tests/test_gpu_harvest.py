@@ -200,24 +200,37 @@ def test_attention_mass_that_lifts_every_key_over_the_pivot():
     assert all(p.startswith("small_eviction") for p in paths)
 
 
-def test_not_eligible_calls_aggregate_as_before():
-    """use_average keys depend on the position: no lazy form, no harvest -- the plain sums, the usual schedule"""
-    st = synth.make_state(num_layers=2, num_kv_heads=4, block_size=16, seq_lens=[600, 300], seed=3, protected=17)
+def test_keys_that_depend_on_positions_are_harvested_with_the_position_rows():
+    """use_average: a key is metric / (seq_pos - position) -- no lazy form; the aggregation pass then streams the
+    position rows as well, makes every key in full and counts the masked slots per head, as the full collecting
+    pass does.  A bulk eviction (not the small-eviction schedule) is not eligible: the plain sums, the usual schedule"""
+    st = synth.make_state(num_layers=2, num_kv_heads=4, block_size=16, seq_lens=[600, 300], seed=3, protected=17,
+                          steady_cap=160)
     ds = hdev.upload(st, DEV, num_queries_per_kv=4, mode="per_sequence", use_average=True)
     cm = ds.cm
-    cm.harvest_ahead = True
     temp = np.random.default_rng(0).random((st.num_blocks, 16, 4)).astype(np.float32)
-    for it in range(3):
+    for it in range(4):
         cm.temp_metrics.copy_(torch.from_numpy(temp))
         orc.aggregate_decode(st.metrics, temp, use_l2=True)
-        assert not cm.aggregate_decode_and_harvest(list(st.seq_indices), ds.seq_positions, list(st.protected),
-                                                   ds.context_lens, total_slots=st.total_slots)
+        harvested = cm.aggregate_decode_and_harvest(list(st.seq_indices), ds.seq_positions, list(st.protected),
+                                                    ds.context_lens, total_slots=st.total_slots)
+        assert harvested == (it > 0)
         np.testing.assert_array_equal(cm.metrics.cpu().numpy(), st.metrics)
-        want = oracle_pipeline(st, [2, 1], mode="per_sequence", use_average=True)
-        eli, ekc, ebc, cmi, cmc = hdev.schedule(ds, st, [2, 1])
-        assert not cm.last_harvest_used
+        want = oracle_pipeline(st, [8, 8], mode="per_sequence", use_average=True)
+        eli, ekc, ebc = cm.schedule_evictions(list(st.seq_indices), ds.seq_positions, [8, 8], ds.context_lens,
+                                              ds.hanging_token_count, ds.evicted_kv_offsets, list(st.protected),
+                                              total_slots=st.total_slots)
+        assert cm.last_harvest_used == harvested and cm.last_schedule_path() == "small_eviction"
         np.testing.assert_array_equal(eli.cpu().numpy(), want["eli"])
         np.testing.assert_array_equal(ekc.cpu().numpy(), want["ekc"])
+    # a bulk call in between: nothing to harvest for
+    nblk = ((st.context_lens.astype(np.int64) + 15) // 16).sum(0).sum(-1)
+    bulk = [int(n) // 2 for n in nblk]
+    eli, ekc, ebc, cmi, cmc = hdev.schedule(ds, st, bulk)
+    assert not cm.last_harvest_used and cm._hv is None
+    np.testing.assert_array_equal(ekc.cpu().numpy(), oracle_pipeline(st, bulk, mode="per_sequence", use_average=True)["ekc"])
+    assert not cm.aggregate_decode_and_harvest(list(st.seq_indices), ds.seq_positions, list(st.protected), ds.context_lens,
+                                               total_slots=st.total_slots)
 
 
 def test_switched_off_by_the_environment_variable(monkeypatch):
@@ -348,18 +361,23 @@ def test_reference_order_takes_its_pivots_from_the_call_before(bs, stride):
         assert not info["remembered"] and info["path"] == "small_eviction"
 
 
-def test_pivot_memory_under_the_batch_rule_of_the_reference():
-    """mode "reference" with three sequences: the reference's batch > 1 rule couples the sequences and keeps the
-    collecting pass that streams the positions (no lazy form, nothing to harvest) -- its pivots still come from the
-    call before"""
-    lp = Loop(L=2, H=4, bs=16, seq_lens=[700, 420, 555], cap=320, mode="reference")
+@pytest.mark.parametrize("bs", [16, 32, 8])
+def test_under_the_batch_rule_of_the_reference(bs):
+    """mode "reference" with three sequences -- the fork's default: the reference's batch > 1 rule couples the
+    sequences through their counts of evictable keys, so the collecting pass streams the positions (no lazy form).
+    Its pivots come from the call before; and the harvesting aggregation pass streams the positions too and counts
+    the masked slots per head, after which the schedule call runs on its lists: the oracle's schedule every step"""
+    lp = Loop(L=2, H=4, bs=bs, seq_lens=[44 * bs, 27 * bs + 3, 35 * bs], cap=20 * bs, mode="reference", seed=bs + 1)
     lp.step(plain=True)
-    remembered = 0
-    for it in range(12):
-        info = lp.step(plain=it % 2 == 0)            # (aggregate_decode_and_harvest here is the plain pass: not eligible)
-        assert not info["harvested"] and not info["used"] and info["path"].startswith("small_eviction"), info
+    remembered = used = 0
+    for it in range(16):
+        info = lp.step(plain=it % 4 == 3)
+        # (under that rule later sequences free less than they were asked to, so what they are asked grows from step
+        # to step: lists and pivots made for a smaller request are not used -- the call then samples)
+        assert not info["used"] or info["harvested"], info
         remembered += info["remembered"]
-    assert remembered >= 10, remembered
+        used += info["used"]
+    assert used >= 3 and used + remembered >= 8, (used, remembered)
 
 
 def test_pivots_that_never_suffice_stop_being_used():

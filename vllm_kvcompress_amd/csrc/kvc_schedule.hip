@@ -199,10 +199,11 @@ static int topk_plan(const kvc_schedule_params& p, int& p2_out, int& sshift) {
 static bool lazy_plan(const kvc_schedule_params& p) {
   return !p.use_average && p.bias == nullptr && !(p.mode == 0 && p.num_seqs > 1) && p.schedule_path != 3;
 }
-// harvest-ahead (section 10): the call takes that form, and the aggregation kernel has the shape
+// harvest-ahead (section 10): any call that takes the small-eviction schedule (its position-lazy form costs the
+// aggregation pass nothing but the harvest; the full form streams the position rows as well)
 static bool harvest_plan(const kvc_schedule_params& p) {
   int p2 = 0, sshift = 0;
-  return topk_plan(p, p2, sshift) == KVC_WHY_TAKEN && lazy_plan(p);
+  return topk_plan(p, p2, sshift) == KVC_WHY_TAKEN;
 }
 extern "C" int32_t kvc_harvest_eligible(const kvc_schedule_params* p, int32_t num_queries_per_kv) {
   if (p == nullptr || num_queries_per_kv < 1) return 0;
@@ -391,11 +392,9 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     // keys that do not depend on the position, sequences that do not need each other's inf counts
     const bool lazy = lazy_plan(p);
     // harvest-ahead (section 10): the lists were made by the aggregation pass / a pivot is wanted for the next one
-    const bool hv_ok = p.harvest_buf != nullptr;     // (pivots: any small-eviction call; lists: its position-lazy form)
-    if ((p.harvest & 1) && !(hv_ok && harvest_plan(p)))
-      return fail_invalid("schedule_evictions: harvested lists with a call that is not eligible (kvc_harvest_eligible)");
-    if ((p.harvest & 4) && !hv_ok)
-      return fail_invalid("schedule_evictions: remembered pivots without a harvest buffer");
+    const bool hv_ok = p.harvest_buf != nullptr;
+    if ((p.harvest & 5) && !hv_ok)
+      return fail_invalid("schedule_evictions: harvested lists / remembered pivots without a harvest buffer");
     const bool harvested = (p.harvest & 1) != 0;
     // the collecting pass with the pivots the previous call left behind instead of a sample's (bit 2)
     const bool remembered = !harvested && (p.harvest & 4) != 0;
@@ -410,6 +409,7 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
       if (harvested) {
         ws.st_claimed = reinterpret_cast<uint32_t*>(hb + hl.claimed);
         ws.st_cnt = reinterpret_cast<uint32_t*>(hb + hl.cnt);
+        ws.st_def = reinterpret_cast<uint32_t*>(hb + hl.def);
         ws.rec64 = reinterpret_cast<uint64_t*>(hb + hl.rec64);
       }
     }
@@ -658,25 +658,30 @@ extern "C" int kvc_aggregate_decode_harvest(const kvc_schedule_params* pp, float
   SchedWs ws{};
   ws.st_claimed = reinterpret_cast<uint32_t*>(hb + hl.claimed);
   ws.st_cnt = reinterpret_cast<uint32_t*>(hb + hl.cnt);
+  ws.st_def = reinterpret_cast<uint32_t*>(hb + hl.def);
   ws.rec64 = reinterpret_cast<uint64_t*>(hb + hl.rec64);
   const uint32_t* hv_pivot = reinterpret_cast<const uint32_t*>(hb + hl.pivot);
-  fill32_async(hb + hl.claimed, 0u, hl.rec64 - hl.claimed, s);       // claimed | cnt
+  const bool lazy = lazy_plan(p);
+  fill32_async(hb + hl.claimed, 0u, hl.rec64 - hl.claimed, s);       // claimed | cnt | def
   // a wave iteration covers 64 blocks; at most 16 Ki workgroups of 4 waves (grid-stride beyond)
   int64_t cb = (p.num_blocks + 255) / 256;
   cb = cb < 1 ? 1 : (cb > 16384 ? 16384 : cb);
   const dim3 grid((unsigned)cb), blk(256);
   const bool big = p.num_blocks * (int64_t)p.block_size >= (int64_t)1 << 28;        // >= 1 GiB of metrics
-#define KVC_HARVEST2(BSV, QVV)                                                                                      \
+#define KVC_HARVEST3(BSV, QVV, LZ)                                                                                  \
   if (big)                                                                                                           \
-    hipLaunchKernelGGL((aggregate_harvest_kernel<BSV, QVV, true>), grid, blk, 0, s, p, ws, temp_metrics, hv_pivot, num_queries_per_kv, use_l2, clear_temp); \
+    hipLaunchKernelGGL((aggregate_harvest_kernel<BSV, QVV, true, LZ>), grid, blk, 0, s, p, ws, temp_metrics, hv_pivot, num_queries_per_kv, use_l2, clear_temp); \
   else                                                                                                               \
-    hipLaunchKernelGGL((aggregate_harvest_kernel<BSV, QVV, false>), grid, blk, 0, s, p, ws, temp_metrics, hv_pivot, num_queries_per_kv, use_l2, clear_temp);
+    hipLaunchKernelGGL((aggregate_harvest_kernel<BSV, QVV, false, LZ>), grid, blk, 0, s, p, ws, temp_metrics, hv_pivot, num_queries_per_kv, use_l2, clear_temp);
+#define KVC_HARVEST2(BSV, QVV)                                                                                      \
+  if (lazy) { KVC_HARVEST3(BSV, QVV, true) } else { KVC_HARVEST3(BSV, QVV, false) }
 #define KVC_HARVEST(BSV)                                                                                             \
   if (num_queries_per_kv == 4) { KVC_HARVEST2(BSV, 1) } else if (num_queries_per_kv == 8) { KVC_HARVEST2(BSV, 2) } else { KVC_HARVEST2(BSV, 0) }
   if (p.block_size == 8) { KVC_HARVEST(8); }
   else if (p.block_size == 16) { KVC_HARVEST(16); }
   else { KVC_HARVEST(32); }
 #undef KVC_HARVEST2
+#undef KVC_HARVEST3
 #undef KVC_HARVEST
   return check_launch("aggregate_decode_harvest");
 }

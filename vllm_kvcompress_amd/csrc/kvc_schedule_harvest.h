@@ -43,22 +43,28 @@ namespace kvc {
 // to the rows' lanes by shuffles; U = 8 rows are in flight at a time (a wave's 64 blocks are
 // contiguous: the TILE form of csrc/kvc_aggregate.hip).  STREAM: a store several times the
 // Infinity Cache (>= 1 GiB of metrics) has its metrics loaded and stored non-temporally, as there.
-struct HvLayout { size_t pivot, claimed, cnt, rec64, total; };
+struct HvLayout { size_t pivot, claimed, cnt, def, rec64, total; };
 inline HvLayout hv_layout(int32_t G, int32_t B) {
   auto up = [](size_t v) { return (v + 255) / 256 * 256; };
   HvLayout l;
   size_t o = 256;                                    // (header: reserved)
   l.pivot = o;    o = up(o + (size_t)B * 4);
-  l.claimed = o;  o = up(o + (size_t)CLAIM_SHARDS * 128);   // claimed | cnt: one fill per harvest
+  l.claimed = o;  o = up(o + (size_t)CLAIM_SHARDS * 128);   // claimed | cnt | def: one fill per harvest
   l.cnt = o;      o = up(o + (size_t)G * 4);
+  l.def = o;      o = up(o + (size_t)G * 4);
   l.rec64 = o;    o = up(o + (size_t)G * KREC * 8);
   l.total = o;
   return l;
 }
 
 // QV = qpk / 4 (qpk 4 or 8: the temp row as 16-byte loads), or 0: any qpk, the row as scalar loads summed while they
-// arrive (the generic loop of aggregate_decode_kernel: the same additions in the same order)
-template <int BS, int QV, bool STREAM>
+// arrive (the generic loop of aggregate_decode_kernel: the same additions in the same order).
+// LAZY as in section 7: keys that do not depend on positions and sequences that do not need each other's counts of
+// evictable keys look a position up only for the ~1 % of the slots below the pivot.  Otherwise (averaged metrics, a
+// position bias, the reference's batch > 1 rule) the position rows are streamed next to the sums (+ 4 B per slot),
+// every key is made in full (slot_key) and the masked / non-finite slots of every block are counted for their head
+// (st_def), exactly as the full collecting pass does.
+template <int BS, int QV, bool STREAM, bool LAZY>
 __global__ __launch_bounds__(256) void aggregate_harvest_kernel(kvc_schedule_params p, SchedWs ws, float* __restrict__ temp,
                                                                 const uint32_t* __restrict__ hv_pivot, int qpk, int use_l2,
                                                                 int clear_temp) {
@@ -82,8 +88,12 @@ __global__ __launch_bounds__(256) void aggregate_harvest_kernel(kvc_schedule_par
     if (lane < n) {
       const int e = qn - n + lane;
       const uint32_t g = qg[w][e];
-      const int tp = p.token_positions[qs[w][e]];    // metrics.py:539-544, for the few that matter
-      if (tp <= ql[w][e] && tp >= p.num_sinks) {
+      bool in_range = true;                          // (the full key has the mask in it)
+      if constexpr (LAZY) {                          // metrics.py:539-544, for the few that matter
+        const int tp = p.token_positions[qs[w][e]];
+        in_range = tp <= ql[w][e] && tp >= p.num_sinks;
+      }
+      if (in_range) {
         const uint32_t pos = atomicAdd(&ws.st_cnt[g], 1u);
         if (pos < (uint32_t)KREC) lists[(int64_t)g * KREC + pos] = ((unsigned long long)qk[w][e] << 32) | qs[w][e];
       }
@@ -96,6 +106,7 @@ __global__ __launch_bounds__(256) void aggregate_harvest_kernel(kvc_schedule_par
     const int64_t slot0 = b0 * BS;
     f32x4 t[U][QV > 0 ? QV : 1];
     float m[U], gsum[U];
+    int tpos[U];
     auto load_rows = [&](int r0) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -115,10 +126,12 @@ __global__ __launch_bounds__(256) void aggregate_harvest_kernel(kvc_schedule_par
             gsum[u] = a;
           }
           m[u] = STREAM ? __builtin_nontemporal_load(metrics + s) : metrics[s];
+          tpos[u] = LAZY ? 0 : __builtin_nontemporal_load(p.token_positions + s);
         } else {
 #pragma unroll
           for (int v = 0; v < (QV > 0 ? QV : 1); ++v) t[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
           m[u] = 0.f;
+          tpos[u] = 0;
         }
       }
     };
@@ -134,9 +147,10 @@ __global__ __launch_bounds__(256) void aggregate_harvest_kernel(kvc_schedule_par
     const int ctx = p.context_lens[(l * p.num_seqs + i) * H + h];
     ok = ok && mt.lbn >= 0 && mt.lbn < (ctx + BS - 1) / BS;
     claimed += (uint32_t)__popcll(__ballot(ok));
-    const int g = ok ? (i * L + l) * H + h : 0;
+    const int g = ok ? (i * L + l) * H + h : -1;
     const uint32_t pex = ok ? hv_pivot[i] : 0u;      // (0: no key lies below it)
-    const int bound = p.seq_positions[i] - p.num_protected[i];
+    const int seq_pos = p.seq_positions[i], prot = p.num_protected[i];
+    const int bound = seq_pos - prot;
 #pragma unroll
     for (int r0 = 0; r0 < ROWS; r0 += U) {
       if (r0 > 0) load_rows(r0);
@@ -169,11 +183,26 @@ __global__ __launch_bounds__(256) void aggregate_harvest_kernel(kvc_schedule_par
         }
         const int src = (r0 + u) * BPR + lane / BS;  // the lane that looks after this slot's block
         const uint32_t pvv = (uint32_t)__shfl((int)pex, src, 64);
-        const uint32_t key = float_to_key(mn);
+        uint32_t key;
+        int gg = -1;
+        if constexpr (LAZY) {
+          key = float_to_key(mn);
+        } else {
+          gg = __shfl(g, src, 64);
+          const int spp = __shfl(seq_pos, src, 64), prr = __shfl(prot, src, 64);
+          int ll = 0, hh = 0;
+          if (p.bias != nullptr) { ll = __shfl(l, src, 64); hh = __shfl(h, src, 64); }
+          key = slot_key(p, mn, tpos[u], spp, prr, ll, hh);
+          // masked / non-finite slots of the block (its BS lanes are adjacent) -> the head's deficit
+          int ninf = (gg >= 0 && key >= KEY_INF) ? 1 : 0;
+#pragma unroll
+          for (int d = 1; d < BS; d <<= 1) ninf += __shfl_xor(ninf, d, 64);
+          if (lane % BS == 0 && gg >= 0 && ninf > 0) atomicAdd(&ws.st_def[gg], (uint32_t)ninf);
+        }
         const bool c = in && key < pvv;              // (pvv <= KEY_INF)
         const unsigned long long bal = __ballot(c);
         if (bal) {                                   // wave-uniform
-          const int gg = __shfl(g, src, 64);
+          if constexpr (LAZY) gg = __shfl(g, src, 64);
           const int bb = __shfl(bound, src, 64);
           if (c) {
             const int pos = qn + __popcll(bal & ((1ull << lane) - 1ull));
