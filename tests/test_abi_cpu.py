@@ -268,3 +268,23 @@ def test_host_policy_around_predicted_pivots():
     assert cm._fb_penalty == 2
     cm._note_flag(0, False)
     assert cm._fb_penalty == 0 and cm.harvest_misses == 11
+
+
+def test_c_host_compiles_against_the_header(tmp_path):
+    """tests/cabi/cabi_host.cpp -- the host without Python that tests/test_gpu_cabi.py runs on the GPU -- compiles
+    against include/kvc_mi355x.h and links against the library here as well (no device needed for that): the
+    header, the struct layouts it uses and the exported symbols stay in step"""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    libdir = os.path.join(REPO, "vllm_kvcompress_amd")
+    host_o, orc_o, exe = str(tmp_path / "cabi_host.o"), str(tmp_path / "kvc_oracle.o"), str(tmp_path / "cabi_host")
+    subprocess.check_call(["gcc", "-O1", "-fopenmp", "-c", os.path.join(REPO, "oracle", "kvc_oracle.c"), "-o", orc_o])
+    gomp = subprocess.check_output(["gcc", "-print-file-name=libgomp.so"], text=True).strip()
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-c",
+                           os.path.join(REPO, "tests", "cabi", "cabi_host.cpp"), "-I", os.path.join(REPO, "include"),
+                           "-o", host_o])
+    subprocess.check_call([hipcc, host_o, orc_o, gomp, "-L", libdir, "-lkvc_mi355x", f"-Wl,-rpath,{libdir}", "-o", exe])
+    assert os.path.getsize(exe) > 0
