@@ -697,6 +697,26 @@ def measure_workload(a2, seed, device, steps, warmup, probe):
             "same_counts": same,
             "what": "schedule_evictions(..., block_tables=BlockState.block_tables): an extension of the reference's "
                     "signature (INTEGRATION.md); every other figure of this entry is measured without it"}
+    if res["S1_schedule"] == "small_eviction" and ds.cm.last_pivot_memory_used:
+        # the figures above ran on the pivots of the call before (pivot memory; exact on this bench's static store, one
+        # decode step of attention old in an engine): the same steps with every call sampling the store for its pivots
+        n2 = min(steps, 10)
+        m2 = [[ev(), ev()] for _ in range(n2)]
+        ds.cm.pivot_memory = False
+        eli = ekc = ebc = None
+        for i in range(-2, n2):
+            del eli, ekc, ebc
+            if i >= 0: m2[i][0].record()
+            eli, ekc, ebc = ds.cm.schedule_evictions(seq_idx, ds.seq_positions, evicted, ds.context_lens,
+                                                     ds.hanging_token_count, ds.evicted_kv_offsets, prot, total_slots=N)
+            if i >= 0: m2[i][1].record()
+        torch.cuda.synchronize()
+        ds.cm.pivot_memory = True
+        res["S1_sampled_pivots"] = {
+            "ms": sum(a.elapsed_time(b) for a, b in m2) / n2, "steps": n2, "same_counts": bool(torch.equal(ekc, out["ekc"])),
+            "what": "S1 with CompressionMetrics.pivot_memory = False: every call samples the store for its pivots "
+                    "(sampling pass + pivot kernel, twice the candidates in the collecting pass)"}
+        del eli, ekc, ebc
     if a2.steady_cap and res["S1_schedule"] == "small_eviction" and not a2.lean:
         del wm, wp
         res["decode_step"] = decode_step_compare(a2, st, ds, evicted, k_cache, v_cache, cmi, cmc, device,

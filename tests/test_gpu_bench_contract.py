@@ -140,6 +140,9 @@ def test_default_line_carries_the_other_configurations():
     assert ds["two_sweeps"]["harvested_steps"] == 0 and ds["harvest_ahead"]["harvested_steps"] == 2
     assert ds["harvest_ahead"]["stages_ms"]["S1_schedule_evictions"] < ds["two_sweeps"]["stages_ms"]["S1_schedule_evictions"]
     assert "decode_step" not in oc["c5"]
+    # ... whose S1 ran on the pivots of the call before; the line carries the sampling variant next to it
+    assert oc["c3"]["S1_schedule_reason"].endswith("[pivots: the call before]")
+    assert oc["c3"]["S1_sampled_pivots"]["same_counts"] is True and oc["c3"]["S1_sampled_pivots"]["ms"] > 0
 
 
 def test_engine_leg_traffic_is_measured_live():
