@@ -15,7 +15,6 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
-import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from tests.test_gpu_harvest import DEV, _Engine  # noqa: E402
