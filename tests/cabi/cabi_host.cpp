@@ -77,6 +77,7 @@ int main() {
 
   // ---- device through the C ABI
   printf("kvc abi %d\n", kvc_abi_version());
+  if (kvc_abi_version() != KVC_ABI_VERSION) { printf("library ABI %d, header %d\n", kvc_abi_version(), KVC_ABI_VERSION); return 4; }
   hipStream_t s;
   CK(hipStreamCreate(&s));
   int32_t *d_eli = to_dev(eli), *d_offs = to_dev(offs), *d_hang = to_dev(hang), *d_ekc = to_dev(ekc),
@@ -188,6 +189,20 @@ int main() {
     };
     bool hok = kvc_harvest_eligible(&sp, qpk) == 1 && kvc_pivot_memory_eligible(&sp) == 1 &&
                kvc_schedule_evictions_plan(&sp) == 1;
+    // ABI version 6: N and the eviction counts for a host that holds them as device tensors only (the fork's call form,
+    // vllm/kvcompress/scheduler.py:245-247) -- into page-locked memory the kernel writes itself, and into plain host
+    // memory through the workspace
+    {
+      int64_t *pinned = nullptr, plain[2] = {-1, -1};
+      CK(hipHostMalloc(&pinned, 16, hipHostMallocDefault));
+      pinned[0] = pinned[1] = -1;
+      KV(kvc_schedule_batch_summary(d_ctx2, L * B * H, bs, d_kper, B, pinned, 1, nullptr, 0, s));
+      KV(kvc_schedule_batch_summary(d_ctx2, L * B * H, bs, d_kper, B, plain, 0, ws2, wsb2, s));
+      hok = hok && pinned[0] == N && pinned[1] == kfree && plain[0] == N && plain[1] == kfree;
+      if (!hok) printf("batch summary: %ld %ld / %ld %ld, want %d %d\n", (long)pinned[0], (long)pinned[1], (long)plain[0],
+                       (long)plain[1], N, kfree);
+      CK(hipHostFree(pinned));
+    }
     // step 1: the usual way; the call leaves pivots (bit 1)
     KV(kvc_aggregate_decode(d_m, d_temp, slots, qpk, 1, 0, s));
     KV(schedule(d_m, 2, out[0]));

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
-    assert lib.kvc_abi_version() == 5
+    assert lib.kvc_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define KVC_ABI_VERSION (\d+)", header).group(1))
 
 
 def test_python_surface_matches_reference_signatures():

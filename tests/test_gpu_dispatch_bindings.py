@@ -24,3 +24,16 @@ def test_all_ops_under_each_binding(binding):
     assert res["binding"] == binding and res["ops_ok"] == 7
     # the compiled binding's kernels are registered from C++: no Python frame in the dispatch
     assert res["registered_from"] == ("kvc_torch_binding.cpp" if binding == "compiled" else "python")
+
+
+def test_writes_of_the_compiled_binding_are_seen():
+    """libkvc_torch.so's kernels write through raw pointers; they bump the version counter of every tensor they
+    write, so that harvested lists, the tracked move table and remembered plans made before such a write are not
+    trusted after it (tests/compiled_writes_driver.py: four scenarios, each against the oracle)"""
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tests", "compiled_writes_driver.py")],
+                         capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("COMPILED_WRITES ")][-1]
+    res = json.loads(line[len("COMPILED_WRITES "):])
+    assert set(res) == {"harvest_then_reshape_and_cache", "harvest_then_execute_cache_moves", "tracked_table_and_plan",
+                        "outputs_are_counted"}

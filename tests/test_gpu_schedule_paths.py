@@ -71,23 +71,103 @@ def test_steady_state_takes_the_small_eviction_schedule(L, H, bs, B, cap, mode):
             np.testing.assert_array_equal(gen[key], want[key], err_msg=f"{key} general seed={seed}")
 
 
-def test_hint_decides_and_a_device_tensor_means_unknown():
+def _fork_call_arguments(st, evicted):
+    """the arguments of schedule_evictions built the way the fork's scheduler builds them
+    (reference vllm/kvcompress/scheduler.py:234-280, 491-499): slot indices as a list, last token positions and the
+    eviction counts as fresh device int tensors, context_lens / hanging counts / offsets derived on the device,
+    protected windows as a tuple -- no N, no host copy of the counts, no block tables"""
+    bs = st.block_size
+    slot_indices = [int(s) for s in st.seq_indices]
+    evicted_blocks_per_seq = torch.tensor([int(e) for e in evicted], dtype=torch.int, device=DEV)
+    last_token_positions = torch.tensor([int(x) + 1 for x in st.seq_positions], dtype=torch.int, device=DEV) - 1
+    context_lens = torch.from_numpy(st.context_lens).to(DEV).contiguous()                        # [L, B, H]
+    hanging = torch.from_numpy(st.hanging_token_count).to(DEV).contiguous()                      # [B, L, H]
+    offs = (((context_lens.transpose(0, 1) + bs - 1) // bs) * bs).flatten().cumsum(dim=0)
+    offs = torch.cat([torch.zeros_like(offs[:1]), offs[:-1]]).reshape(*context_lens.transpose(0, 1).shape).type(torch.int)
+    return (slot_indices, last_token_positions, evicted_blocks_per_seq, context_lens, hanging, offs, tuple(st.protected))
+
+
+def test_the_forks_call_form_reaches_every_schedule():
+    """The fork passes evicted_blocks_per_seq as a DEVICE int tensor and neither N nor its maximum
+    (vllm/kvcompress/scheduler.py:245-247, 491-499).  That call must take the schedules the list form takes
+    (one wait brings N and the counts to the host, CompressionMetrics._batch_summary) and give the oracle's result."""
+    # continual steady state: small-eviction schedule, then -- same batch again -- on the pivots of the call before
     st, evicted = _steady(2, 4, 16, 2, 512, 3)
+    want = oracle_pipeline(st, evicted, mode="reference")
     ds = hdev.upload(st, DEV)
     ds.cm.schedule_path = 0                 # (this test is about the automatic choice: KVC_SCHEDULE_PATH must not decide)
-    args = (ds.context_lens, ds.hanging_token_count, ds.evicted_kv_offsets, list(st.protected))
-    a = ds.cm.schedule_evictions(list(st.seq_indices), ds.seq_positions, evicted, *args, total_slots=st.total_slots)
-    assert ds.cm.last_schedule_path() == "small_eviction"
-    b = ds.cm.schedule_evictions(list(st.seq_indices), ds.seq_positions,
-                                 torch.tensor(evicted, dtype=torch.int32, device=DEV), *args,
-                                 total_slots=st.total_slots)
-    assert ds.cm.last_schedule_path() == "general"
-    for x, y in zip(a, b):
-        assert torch.equal(x, y)
-    # bulk eviction (compress_once): the hint sends it to the general pipeline
-    big = [e * 40 for e in evicted]
-    ds.cm.schedule_evictions(list(st.seq_indices), ds.seq_positions, big, *args, total_slots=st.total_slots)
-    assert ds.cm.last_schedule_path() == "general"
+    for call in range(2):
+        eli, ekc, ebc = ds.cm.schedule_evictions(*_fork_call_arguments(st, evicted))
+        assert ds.cm.last_schedule_reason.startswith("small_eviction"), ds.cm.last_schedule_reason
+        assert ds.cm.last_schedule_path() == "small_eviction"
+        assert ds.cm.last_pivot_memory_used == (call == 1)
+        assert tuple(eli.shape) == (st.total_slots,)
+        for got, key in ((eli, "eli"), (ekc, "ekc"), (ebc, "ebc")):
+            np.testing.assert_array_equal(got.cpu().numpy(), want[key], err_msg=f"{key} call {call}")
+    # the list form (the reference's test harnesses) gives the same tensors
+    args = _fork_call_arguments(st, evicted)
+    b = ds.cm.schedule_evictions(args[0], args[1], evicted, *args[3:], total_slots=st.total_slots)
+    for x, key in zip(b, ("eli", "ekc", "ebc")):
+        np.testing.assert_array_equal(x.cpu().numpy(), want[key])
+    # bulk eviction (compress_once): the counts send it to the other schedules, tensor form or list form
+    big = [e * 12 for e in evicted]
+    want = oracle_pipeline(st, big, mode="reference")
+    for form in ("tensor", "list"):
+        args = _fork_call_arguments(st, big)
+        if form == "list":
+            args = args[:2] + (big,) + args[3:]
+        out = ds.cm.schedule_evictions(*args)
+        assert ds.cm.last_schedule_reason.startswith("general (small_eviction: bulk_eviction"), ds.cm.last_schedule_reason
+        for x, key in zip(out, ("eli", "ekc", "ebc")):
+            np.testing.assert_array_equal(x.cpu().numpy(), want[key], err_msg=f"{key} bulk {form}")
+
+
+def test_the_forks_call_form_takes_the_bracket_schedule_for_bulk_evictions():
+    """compress_once of one long sequence (BASELINE configs[1] in small): 64 Ki slots per sequence and 64 blocks per
+    head -- the bracket schedule, from a device tensor of counts"""
+    st = synth.make_state(num_layers=2, num_kv_heads=4, block_size=16, seq_lens=[8193], seed=4, protected=32)
+    nblk = int(((st.context_lens.astype(np.int64) + 15) // 16).sum())
+    evicted = [nblk // 2]
+    want = oracle_pipeline(st, evicted, mode="reference")
+    ds = hdev.upload(st, DEV)
+    ds.cm.schedule_path = 0
+    out = ds.cm.schedule_evictions(*_fork_call_arguments(st, evicted))
+    assert ds.cm.last_schedule_reason.startswith("bracket"), ds.cm.last_schedule_reason
+    assert ds.cm.last_schedule_path() == "bracket"
+    for x, key in zip(out, ("eli", "ekc", "ebc")):
+        np.testing.assert_array_equal(x.cpu().numpy(), want[key], err_msg=key)
+
+
+def test_a_device_tensor_of_counts_under_stream_capture_is_the_only_unknown_hint():
+    """nothing can be read back while a stream is being captured: a captured call with a device tensor of counts takes
+    the digit rounds (hint unknown) and needs total_slots=; its replay gives the oracle's result"""
+    st, evicted = _steady(2, 4, 16, 2, 512, 3)
+    want = oracle_pipeline(st, evicted, mode="reference")
+    ds = hdev.upload(st, DEV)
+    ds.cm.schedule_path = 0
+    args = _fork_call_arguments(st, evicted)
+    ds.cm.schedule_evictions(*args)                       # (warm: workspaces exist before the capture)
+    ds.cm.schedule_path = 1
+    ds.cm.schedule_evictions(*args, total_slots=st.total_slots)
+    ds.cm.schedule_path = 0
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ds.cm.schedule_path = 1
+        ds.cm.schedule_evictions(*args, total_slots=st.total_slots)      # (this stream's workspace)
+        ds.cm.schedule_path = 0
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        out = ds.cm.schedule_evictions(*args, total_slots=st.total_slots)
+        reason = ds.cm.last_schedule_reason
+    assert "hint_unknown" in reason, reason
+    g.replay()
+    torch.cuda.synchronize()
+    for x, key in zip(out, ("eli", "ekc", "ebc")):
+        np.testing.assert_array_equal(x.cpu().numpy(), want[key], err_msg=key)
 
 
 @pytest.mark.parametrize("ties", [1, 3, 6])

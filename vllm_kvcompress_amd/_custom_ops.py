@@ -129,6 +129,7 @@ def count_block_evictions(
             evicted_block_count.data_ptr(), eli.data_ptr(), offs.data_ptr(), hang.data_ptr(),
             evicted_block_count.numel(), eli.numel(), int(block_size), int(null_value),
             _stream(eli)))
+    _written(evicted_block_count, eli)
 
 
 # ---- move tables whose contents the package knows -------------------------------------------
@@ -231,6 +232,7 @@ def _schedule_t1_cache_moves(cache_moves_idx, cache_moves_count, evicted_logical
             _contig(block_tables, keep).data_ptr(), _contig(context_lens, keep).data_ptr(),
             num_seqs, num_layers, num_kv_heads, block_tables.shape[3], bs,
             mode, _ptr(dmap), dmap_bytes, plan.data_ptr(), _stream(cache_moves_idx)))
+    _written(cache_moves_idx, cache_moves_count)      # (before the map and the plan remember the versions they vouch for)
     if rec is not None:
         rec.version = _version_of(cache_moves_idx)
     # the plan belongs to exactly these three tensors as they are now (execute_cache_moves checks)
@@ -301,7 +303,7 @@ def _execute_cache_moves(k_cache, v_cache, kv_metrics, kv_position, cache_moves_
     # along: ONE launch (no planning pass, no claim table); any other list plans for itself
     plan = _plan_of(k_cache, cache_moves_indices, cache_moves_count, evicted_kv_offsets, total_heads, block_size)
     if half != "plan":
-        _written(kv_metrics, kv_position)
+        _written(k_cache, v_cache, kv_metrics, kv_position)
     if plan is not None:
         if half != "plan":
             with torch.cuda.device(k_cache.device):
@@ -353,7 +355,7 @@ def reshape_and_cache_kvc(
     block_size = key_cache.shape[2]
     sm = slot_mapping.contiguous()
     hb = kv_metric_head_bias.contiguous()
-    _written(kv_metrics)
+    _written(key_cache, value_cache, kv_metrics)
     if kv_cache_dtype == "auto":
         if key.dtype != key_cache.dtype or value.dtype != value_cache.dtype:
             raise RuntimeError("reshape_and_cache_kvc: kv_cache_dtype 'auto' needs cache dtype == "
@@ -476,6 +478,7 @@ def _paged_attention_kvc(out, kv_metric_out, exp_sum, max_logits, tmp_out, tmp_k
     p.schedule = _ATTENTION_SCHEDULE
     with torch.cuda.device(query.device):
         _lib.check(lib.kvc_paged_attention_decode(p, _stream(query)))
+    _written(out, kv_metric_out if record_kv_metrics else None)
 
 
 def paged_attention_kvc_v1(out, kv_metric_out, query, key_cache, value_cache, num_kv_heads: int,

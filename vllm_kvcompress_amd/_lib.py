@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KVC_MI355X_LIB", os.path.join(_HERE, "libkvc_mi355x.so"))
 
 MAX_INT = 2147483000  # reference vllm/kvcompress/metrics.py:12
+ABI_VERSION = 6       # KVC_ABI_VERSION of include/kvc_mi355x.h: the struct layouts mirrored below
 
 # KVC_WHY_* of include/kvc_mi355x.h (kvc_schedule_evictions_plan_reason)
 WHY = {0: "taken", 1: "forced_path", 2: "block_size", 3: "hint_unknown", 4: "bulk_eviction",
@@ -103,6 +104,8 @@ SYMBOLS = {
     "kvc_schedule_evictions_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32, c_int32]),
     "kvc_schedule_evictions": (c_int32, [ctypes.POINTER(KvcScheduleParams), c_void_p, c_size_t,
                                          c_void_p]),
+    "kvc_schedule_batch_summary": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32,
+                                             c_void_p, c_size_t, c_void_p]),
     "kvc_schedule_evictions_uses_small_eviction_schedule": (c_int32, [ctypes.POINTER(KvcScheduleParams)]),
     "kvc_schedule_evictions_plan": (c_int32, [ctypes.POINTER(KvcScheduleParams)]),
     "kvc_schedule_evictions_plan_reason": (c_int32, [ctypes.POINTER(KvcScheduleParams)]),
@@ -169,6 +172,11 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    # kvc_schedule_params / kvc_attention_params are mirrored field by field above: a library of another ABI version
+    # (an old build picked up through KVC_MI355X_LIB) would read pointers at the wrong offsets
+    if lib.kvc_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {lib.kvc_abi_version()}, this package mirrors version "
+                          f"{ABI_VERSION} (include/kvc_mi355x.h): rebuild it (vllm_kvcompress_amd/csrc/build.sh)")
     _lib = lib
     return lib
 

@@ -309,6 +309,68 @@ extern "C" size_t kvc_schedule_evictions_workspace_bytes(int64_t total_slots, in
   return ws_layout(total_slots, total_heads, num_seqs, block_size).total;
 }
 
+// ABI version 6: N and the eviction counts of a batch for a host that holds both as device tensors (the
+// fork's call, vllm/kvcompress/scheduler.py:245-247, 491-499).  One workgroup: the [L,B,H] context lengths
+// are at most a few hundred KiB; what the call costs is the launch and the wait, not the sum.
+namespace kvc {
+__global__ __launch_bounds__(1024) void batch_summary_kernel(const int32_t* __restrict__ context_lens, int total_heads,
+                                                             int bs, const int32_t* __restrict__ k_per_seq, int num_seqs,
+                                                             int64_t* __restrict__ out) {
+  __shared__ unsigned long long part[16];
+  unsigned long long blocks = 0;
+  const int n4 = (reinterpret_cast<uintptr_t>(context_lens) & 15) == 0 ? total_heads / 4 : 0;
+  const int4* c4 = reinterpret_cast<const int4*>(context_lens);
+  for (int i = threadIdx.x; i < n4; i += 1024) {
+    const int4 c = c4[i];
+    blocks += (unsigned)((c.x + bs - 1) / bs) + (unsigned)((c.y + bs - 1) / bs) + (unsigned)((c.z + bs - 1) / bs) +
+              (unsigned)((c.w + bs - 1) / bs);
+  }
+  for (int i = n4 * 4 + threadIdx.x; i < total_heads; i += 1024) blocks += (unsigned)((context_lens[i] + bs - 1) / bs);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) blocks += __shfl_xor(blocks, d, 64);
+  if (lane_id() == 0) part[threadIdx.x >> 6] = blocks;
+  for (int i = threadIdx.x; i < num_seqs; i += 1024) out[1 + i] = (int64_t)k_per_seq[i];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += part[w];
+    out[0] = (int64_t)t * bs;
+  }
+}
+}  // namespace kvc
+
+extern "C" int kvc_schedule_batch_summary(const int32_t* context_lens, int32_t total_heads, int32_t block_size,
+                                          const int32_t* evicted_blocks_per_seq, int32_t num_seqs, int64_t* host_out,
+                                          int32_t host_mapped, void* workspace, size_t workspace_bytes,
+                                          kvc_stream_t stream) {
+  using namespace kvc;
+  if (block_size < 1) return fail_invalid("Unsupported block size: " + std::to_string(block_size));
+  if (context_lens == nullptr || total_heads < 0 || num_seqs < 0 || host_out == nullptr ||
+      (num_seqs > 0 && evicted_blocks_per_seq == nullptr))
+    return fail_invalid("schedule_batch_summary: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t bytes = (size_t)(1 + num_seqs) * 8;
+  int64_t* dst = host_out;
+  if (!host_mapped) {
+    if (workspace == nullptr || workspace_bytes < bytes || (reinterpret_cast<uintptr_t>(workspace) & 7) != 0)
+      return fail_invalid("schedule_batch_summary: workspace too small or misaligned");
+    dst = reinterpret_cast<int64_t*>(workspace);
+  }
+  batch_summary_kernel<<<1, 1024, 0, s>>>(context_lens, total_heads, block_size, evicted_blocks_per_seq, num_seqs, dst);
+  if (int rc = check_launch("schedule_batch_summary")) return rc;
+  if (!host_mapped && hipMemcpyAsync(host_out, dst, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) {
+    set_error(std::string("schedule_batch_summary: ") + hipGetErrorString(hipGetLastError()));
+    return KVC_ERR_HIP;
+  }
+  const hipError_t e = hipStreamSynchronize(s);
+  if (e != hipSuccess) {
+    set_error(std::string("schedule_batch_summary: ") + hipGetErrorString(e));
+    return KVC_ERR_HIP;
+  }
+  return KVC_OK;
+}
+
 extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* workspace,
                                       size_t workspace_bytes, kvc_stream_t stream) {
   using namespace kvc;

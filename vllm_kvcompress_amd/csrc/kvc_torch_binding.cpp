@@ -48,6 +48,17 @@ void require(const Tensor& t, const char* name, at::ScalarType dt) {
   TORCH_CHECK(t.scalar_type() == dt, name, ": expected dtype ", dt, ", got ", t.scalar_type());
 }
 
+// The kernels write through raw pointers: neither torch nor the dispatcher counts such a write (a `Tensor!` in a
+// schema is an annotation, not a hook).  Consumers that ask "has anybody written to this tensor since?" --
+// CompressionMetrics' harvested lists and remembered pivots, the tracked move table, the plan a move list brings
+// along -- must get the answer an in-place torch op would give them, whichever binding did the write: every kernel
+// here bumps the version counter of every tensor its launch writes (the Python wrappers do the same,
+// _custom_ops._written).  Tensors made under torch.inference_mode() keep no counter (and every such question
+// about them is answered with "no").
+void written(const Tensor& t) {
+  if (t.defined() && !t.is_inference()) t.unsafeGetTensorImpl()->bump_version();
+}
+
 // persistent per-(device, stream, tag) scratch, grown geometrically; the C ABI never allocates
 Tensor workspace(const Tensor& like, size_t nbytes, const char* tag) {
   static std::mutex mu;
@@ -101,6 +112,8 @@ void count_block_evictions(Tensor& evicted_block_count, Tensor& evicted_logical_
                                   hang.data_ptr<int32_t>(), (int32_t)evicted_block_count.numel(),
                                   evicted_logical_indices.numel(), (int32_t)block_size, (int32_t)null_value,
                                   current_stream(evicted_logical_indices)));
+  written(evicted_block_count);
+  written(evicted_logical_indices);
 }
 
 // The move list schedule_t1_cache_moves made last on a (device, stream) brings its plan along
@@ -182,6 +195,8 @@ void schedule_t1_cache_moves(Tensor& cache_moves_idx, Tensor& cache_moves_count,
                                        ctx.data_ptr<int32_t>(), (int32_t)ekc.size(0), (int32_t)ekc.size(1),
                                        (int32_t)ekc.size(2), (int32_t)bt.size(3), (int32_t)block_size, 0, nullptr, 0,
                                        reinterpret_cast<int32_t*>(plan.data_ptr()), current_stream(cache_moves_idx)));
+  written(cache_moves_idx);               // (before the plan remembers the versions it vouches for)
+  written(cache_moves_count);
   const Tensor* const who[3] = {&cache_moves_idx, &cache_moves_count, &evicted_kv_offsets};
   remember_plan(plan, who, (int32_t)ekc.numel(), (int32_t)block_size);
 }
@@ -209,6 +224,10 @@ void execute_cache_moves(Tensor& k_cache, Tensor& v_cache, Tensor& kv_metrics, T
   c10::DeviceGuard guard(k_cache.device());
   const Tensor* const who[3] = {&cache_moves_idx, &cache_moves_count, &evicted_kv_offsets};
   const Tensor plan = plan_of(k_cache, who, total_heads, (int32_t)block_size);
+  written(k_cache);
+  written(v_cache);
+  written(kv_metrics);
+  written(kv_position);
   if (plan.defined()) {
     check(kvc_execute_cache_moves_planned(k_cache.data_ptr(), v_cache.data_ptr(), kv_metrics.data_ptr<float>(),
                                           kv_position.data_ptr<int32_t>(), cmi.data_ptr<int32_t>(),
@@ -248,7 +267,12 @@ void kvcompress_reshape_and_cache(const Tensor& key, const Tensor& value, Tensor
   const int64_t block_size = key_cache.size(2);
   const Tensor sm = slot_mapping.contiguous(), hb = kv_metric_head_bias.contiguous();
   c10::DeviceGuard guard(key.device());
+  // (the fork's schema does not mark kv_metrics mutable, csrc/torch_bindings.cpp:353-360; the kernel sets
+  // kv_metrics[slot] = bias all the same, csrc/kvcompress_cache_kernels.cu:27-89)
   float* met = const_cast<float*>(kv_metrics.data_ptr<float>());
+  written(key_cache);
+  written(value_cache);
+  written(kv_metrics);
   if (kv_cache_dtype == "auto") {
     TORCH_CHECK(key.scalar_type() == key_cache.scalar_type() && value.scalar_type() == value_cache.scalar_type(),
                 "reshape_and_cache_kvc: kv_cache_dtype 'auto' needs cache dtype == key/value dtype");
@@ -364,6 +388,8 @@ void paged_attention_kvc(Tensor& out, Tensor& kv_metric_out, const Tensor* exp_s
     p.tmp_kv_metric_out = record_kv_metrics ? kv_metric_out.data_ptr<float>() : nullptr;
   }
   check(kvc_paged_attention_decode(&p, current_stream(query)));
+  written(out);
+  if (record_kv_metrics) written(kv_metric_out);
 }
 
 void kvcompress_paged_attention_v1(Tensor& out, Tensor& kv_metric_out, const Tensor& query, const Tensor& key_cache,

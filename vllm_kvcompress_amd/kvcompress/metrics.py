@@ -163,8 +163,10 @@ class CompressionMetrics:
         # does, scheduler.py:492-523); otherwise a new one is made, so a result stays valid for as long
         # as somebody holds it.  False = a fresh tensor and the full padding every call.
         self.reuse_output_buffer = os.environ.get("KVC_REUSE_OUTPUT_BUFFER", "1") not in ("", "0")
-        self._eli_buf = None          # (buffer, dirty map, block size, storage use count when only we hold it, stream)
+        self._eli_buf = None          # (buffer, dirty map, block size, storage use count when only we hold it, stream, version)
         self._small_cache = {}
+        self._summary_pin = None      # page-locked words the batch summary kernel writes (N, evicted_blocks_per_seq)
+        self._summary_np = None
         # harvest-ahead (include/kvc_mi355x.h, ABI version 5): with compression every decode
         # step the metric store is swept twice per step -- by aggregate_decode and, a moment later, by the
         # small-eviction schedule's collecting pass.  ``aggregate_decode_and_harvest`` is the first sweep
@@ -512,6 +514,25 @@ class CompressionMetrics:
             self._small_cache[key] = hit
         return hit
 
+    def _batch_summary(self, context_lens: torch.Tensor, k_per_seq: Optional[torch.Tensor]):
+        """``(N, evicted_blocks_per_seq as a list)`` of a batch the caller describes with device tensors -- what the
+        fork's scheduler passes (reference scheduler.py:245-247, 491-499: a device int tensor, no N).  One launch that
+        writes into page-locked memory and one wait (kvc_schedule_batch_summary); the reference method synchronises
+        for the same reason, many times over (metrics.py:465-489, 709-729)."""
+        lib = _lib.load()
+        B = 0 if k_per_seq is None else int(k_per_seq.numel())
+        if self._summary_pin is None or self._summary_pin.numel() < 1 + B:
+            with torch.inference_mode(False):
+                self._summary_pin = torch.zeros((max(1 + B, 320),), dtype=torch.int64).pin_memory()
+            self._summary_np = self._summary_pin.numpy()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.kvc_schedule_batch_summary(
+                context_lens.data_ptr(), int(context_lens.numel()), int(self.block_size),
+                None if k_per_seq is None else k_per_seq.data_ptr(), B, self._summary_pin.data_ptr(), 1, None, 0,
+                _stream(self.metrics)))
+        vals = self._summary_np[:1 + B].tolist()
+        return int(vals[0]), [int(v) for v in vals[1:]]
+
     def schedule_evictions(
         self,
         seq_indices: List[int],
@@ -530,9 +551,16 @@ class CompressionMetrics:
         """reference metrics.py:441-847.  Returns ``(evicted_logical_indices [N] i32,
         evicted_kv_count [B,L,H] i32, evicted_block_count [B,L,H] i32)``.
 
+        ``evicted_blocks_per_seq``: what the fork's scheduler passes is a device int tensor
+        (scheduler.py:245-247), with no N next to it; the reference's own test harnesses pass lists.
+        Both forms reach every schedule: the tensor form costs one launch and one wait that brings N
+        and the counts to the host together (``_batch_summary``; the reference method waits for the
+        device many times, metrics.py:465-489, 709-729), after which the call is the list form's.
+
         ``total_slots`` (optional, not in the reference signature): N if the caller
-        already knows it; otherwise it is read back from ``context_lens`` (one small
-        device->host copy, the only synchronisation of this method).
+        already knows it.  With it AND a host list of counts the method never waits for the device;
+        under stream capture that is the only form there is (a captured call with a device tensor
+        of counts cannot look at them: digit rounds).
 
         ``block_tables`` (optional, not in the reference signature): ``BlockState.block_tables``
         ``[L, max_num_seqs, H, M]`` (rows indexed by sequence index).  The fork's scheduler has it
@@ -559,13 +587,28 @@ class CompressionMetrics:
         evicted_kv_offsets = evicted_kv_offsets.contiguous()
         assert tuple(context_lens.shape) == (L, B, H)
         assert tuple(evicted_kv_offsets.shape) == (B, L, H)
-        if total_slots is None:
-            total_slots = int((((context_lens + (bs - 1)) // bs).sum(dtype=torch.int64) * bs).item())
-        N = int(total_slots)
-
+        capturing = torch.cuda.is_current_stream_capturing()
         seq_pos = self._as_i32(seq_positions)
         prot = self._as_i32(num_protected)
         k_per_seq = self._as_i32(evicted_blocks_per_seq)
+        # the counts on the host (their maximum picks the schedule, include/kvc_mi355x.h) and N
+        k_list = None
+        if isinstance(evicted_blocks_per_seq, torch.Tensor):
+            if not evicted_blocks_per_seq.is_cuda:
+                k_list = [int(v) for v in evicted_blocks_per_seq.tolist()]
+            elif not capturing:
+                # the fork's call (scheduler.py:245-247, 491-499): a device tensor, no N -- both in one wait
+                n_read, k_list = self._batch_summary(context_lens, k_per_seq)
+                if total_slots is None:
+                    total_slots = n_read
+        else:
+            k_list = [int(v) for v in evicted_blocks_per_seq]
+        if total_slots is None:
+            if capturing:
+                raise RuntimeError("schedule_evictions: under stream capture pass total_slots= (N cannot be read "
+                                   "back from context_lens while the stream is being captured)")
+            total_slots, _ = self._batch_summary(context_lens, None)
+        N = int(total_slots)
 
         out_idx = None                 # (made below, once the schedule is known)
         out_kv = torch.empty((B, L, H), dtype=torch.int32, device=dev)
@@ -576,14 +619,10 @@ class CompressionMetrics:
         p.evicted_blocks_per_seq = k_per_seq.data_ptr()
         p.hanging_token_count = hanging_token_count.data_ptr()
         p.evicted_kv_offsets = evicted_kv_offsets.data_ptr()
-        # the reference scheduler passes a Python list (scheduler.py:184-560): its maximum picks the
-        # schedule (include/kvc_mi355x.h); a device tensor would cost a sync to inspect -> unknown
-        if isinstance(evicted_blocks_per_seq, torch.Tensor) and evicted_blocks_per_seq.is_cuda:
-            p.max_evicted_blocks_hint = -1
-        else:
-            p.max_evicted_blocks_hint = int(max(evicted_blocks_per_seq))
+        # the largest count picks the schedule (include/kvc_mi355x.h); unknown only for a device tensor of counts
+        # under stream capture, where nothing can be read back
+        p.max_evicted_blocks_hint = -1 if k_list is None else int(max(k_list))
         p.schedule_path = int(self.schedule_path)
-        capturing = torch.cuda.is_current_stream_capturing()
         # the reference's other selection rule (metrics.py:639-666; its scheduler never passes it)
         p.uniform_evict = 1 if uniform_evict else 0
         self._poll_fallback(capturing)
@@ -620,7 +659,6 @@ class CompressionMetrics:
             if self._hv_buf is None or self._hv_buf.numel() < need:      # (kept when the batch shrinks: offsets are the call's)
                 self._hv_buf = torch.zeros((need,), dtype=torch.uint8, device=dev)
                 self._hv = hl = None
-            k_list = [int(v) for v in evicted_blocks_per_seq]
             p.harvest_buf = self._hv_buf.data_ptr()
             p.harvest = 2
             hv = self._hv
@@ -637,7 +675,7 @@ class CompressionMetrics:
         self.last_harvest_used = bool(p.harvest & 1)
         self.last_pivot_memory_used = bool(p.harvest & 4)
         p.eli_dirty_map = None
-        if (self.reuse_output_buffer and not self.lean_outputs and N > 0
+        if (self.reuse_output_buffer and not self.lean_outputs and N > 0 and not capturing
                 and int(lib.kvc_schedule_evictions_plan(ctypes.byref(p))) == 1):
             out_idx = self._tracked_output(N, bs, p)
         if out_idx is None:
@@ -680,23 +718,39 @@ class CompressionMetrics:
         return out_idx, out_kv, out_blk
 
     @staticmethod
-    def _storage_refs(t: torch.Tensor) -> int:
-        return int(torch._C._storage_Use_Count(t.untyped_storage()._cdata))
+    def _storage_refs(t: torch.Tensor) -> Optional[int]:
+        """how many tensors share ``t``'s storage, or None when this torch cannot say (``torch._C._storage_Use_Count``
+        is a private API): without it nothing proves that the previous result was dropped, and the kept buffer is
+        never handed out twice"""
+        fn = getattr(torch._C, "_storage_Use_Count", None)
+        if fn is None:
+            return None
+        return int(fn(t.untyped_storage()._cdata))
 
-    def _tracked_output(self, N: int, bs: int, p) -> torch.Tensor:
+    def _tracked_output(self, N: int, bs: int, p) -> Optional[torch.Tensor]:
         """evicted_logical_indices [N] as a view of the buffer this object keeps for the small-eviction
-        schedule (see __init__), with its dirty map in ``p.eli_dirty_map``."""
+        schedule (see __init__), with its dirty map in ``p.eli_dirty_map``; None = no such buffer for this call (a
+        fresh tensor and the full padding).  The buffer is handed out again only when (a) nobody else refers to its
+        storage any more and (b) its version counter is where this object left it: a caller may edit the list the
+        reference returns in place before dropping it (it is a fresh tensor there), which leaves entries the dirty map
+        does not know about -- torch counts such writes, and a buffer that was written to is replaced.  Never under
+        stream capture (the caller decides; a buffer baked into a graph would be overwritten by its replays)."""
         rec = self._eli_buf
         stream = _stream(self.metrics)
         if rec is not None:
-            buf, dmap, rec_bs, refs, rec_stream = rec
-            if buf.numel() < N or rec_bs != bs or rec_stream != stream or self._storage_refs(buf) != refs:
-                rec = None              # too small, another block size / stream, or a previous result is still alive
+            buf, dmap, rec_bs, refs, rec_stream, version = rec
+            if (buf.numel() < N or rec_bs != bs or rec_stream != stream or refs is None
+                    or self._storage_refs(buf) != refs or buf._version != version):
+                rec = None              # too small, another block size / stream, a previous result still alive or edited
         if rec is None:
             cap = (N + N // 16 + 4095) // 4096 * 4096          # the batch grows and shrinks by blocks: some slack
-            buf = torch.full((cap,), MAX_INT, dtype=torch.int32, device=self.device)
-            dmap = torch.zeros(((cap // bs + 31) // 32 + 1,), dtype=torch.int32, device=self.device)
-            rec = self._eli_buf = (buf, dmap, bs, self._storage_refs(buf), stream)
+            with torch.inference_mode(False):                  # (a tensor with a version counter, whoever calls)
+                buf = torch.full((cap,), MAX_INT, dtype=torch.int32, device=self.device)
+                dmap = torch.zeros(((cap // bs + 31) // 32 + 1,), dtype=torch.int32, device=self.device)
+            refs = self._storage_refs(buf)
+            if refs is None:
+                return None
+            rec = self._eli_buf = (buf, dmap, bs, refs, stream, buf._version)
         p.eli_dirty_map = rec[1].data_ptr()
         return rec[0][:N]
 
