@@ -392,6 +392,77 @@ def parity_gate_sampled(args, st, evicted, gpu, k_cache, v_cache, wm, wp, num_sa
 
 
 # --------------------------------------------------------------------------- roofline helpers
+def s1_call_forms(ds, st, evicted, cmi, cmc, k_cache, v_cache, wm, wp, bs, steps=10, warmup=3, ref_counts=None):
+    """S1 through the call the FORK makes -- ``evicted_blocks_per_seq`` a fresh device int tensor, the last token
+    positions a fresh device tensor, the protected windows a tuple, no ``total_slots`` (reference
+    vllm/kvcompress/scheduler.py:245-260, 491-499) -- next to the list form the other figures of this file use
+    (host list of counts + ``total_slots=``: the method never waits for the device).  The tensor form costs one
+    launch and one wait (CompressionMetrics._batch_summary_enqueue / _read) and must take the same schedule.
+    Both forms are timed the same way twice: with HIP events inside the full step loop (S2 and S3 enqueued behind
+    every call, as for ``stages_ms``; the tensor form's wait drains the previous step first, so what the events see
+    on top of the kernels is the host's path from the wait to the first launch), and as host wall-clock from an
+    idle device to the results (``torch.cuda.synchronize()`` on both sides: what an engine that has just read back
+    its sampled tokens sees)."""
+    import gc
+    import time
+    import torch
+    from vllm_kvcompress_amd import _custom_ops as ops
+    cm, dev = ds.cm, ds.cm.device
+    N = st.total_slots
+    seq_idx, prot = list(st.seq_indices), list(st.protected)
+    seq_lens = [int(x) + 1 for x in st.seq_positions]
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+
+    def fork_args():
+        return (seq_idx, torch.tensor(seq_lens, dtype=torch.int, device=dev) - 1,
+                torch.tensor(evicted, dtype=torch.int, device=dev), ds.context_lens, ds.hanging_token_count,
+                ds.evicted_kv_offsets, tuple(prot))
+
+    def call(form, args):
+        if form == "reference_call_form":
+            return cm.schedule_evictions(*args)
+        return cm.schedule_evictions(seq_idx, ds.seq_positions, evicted, ds.context_lens, ds.hanging_token_count,
+                                     ds.evicted_kv_offsets, prot, total_slots=N)
+
+    out = {}
+    gc.collect()
+    gc.disable()
+    for form in ("list_form", "reference_call_form"):
+        marks = [[ev(), ev()] for _ in range(steps)]
+        wall = []
+        eli = ekc = ebc = None
+        for i in range(-warmup, steps):
+            del eli, ekc, ebc
+            args = fork_args()                     # (the scheduler's own work, outside the call that is timed)
+            if i >= 0: marks[i][0].record()
+            eli, ekc, ebc = call(form, args)
+            if i >= 0: marks[i][1].record()
+            ops.schedule_cache_moves(cmi, cmc, eli, ekc, ds.evicted_kv_offsets, ds.block_tables, ds.context_lens, bs)
+            ops.execute_cache_moves(k_cache, v_cache, wm, wp, cmi, cmc, ds.evicted_kv_offsets, 1, 16)
+        torch.cuda.synchronize()
+        rec = {"ms": sum(a.elapsed_time(b) for a, b in marks) / steps, "schedule": cm.last_schedule_reason}
+        if ref_counts is not None:
+            rec["same_counts"] = bool(torch.equal(ekc, ref_counts))
+        for i in range(-warmup, steps):
+            del eli, ekc, ebc
+            args = fork_args()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eli, ekc, ebc = call(form, args)
+            torch.cuda.synchronize()
+            if i >= 0: wall.append(time.perf_counter() - t0)
+        rec["wall_from_idle_ms"] = 1e3 * sorted(wall)[len(wall) // 2]
+        out[form] = rec
+        del eli, ekc, ebc
+    gc.enable()
+    out["delta_ms"] = out["reference_call_form"]["ms"] - out["list_form"]["ms"]
+    out["delta_wall_from_idle_ms"] = out["reference_call_form"]["wall_from_idle_ms"] - out["list_form"]["wall_from_idle_ms"]
+    out["what"] = ("schedule_evictions as the fork calls it (device int tensor of counts, fresh position tensor, no total_slots; "
+                   "scheduler.py:245-260, 491-499) against the list form with total_slots=; ms: HIP events in the full step loop, "
+                   f"{steps} steps; wall_from_idle_ms: median host wall-clock, device idle at entry, results complete at exit")
+    return out
+
+
 def traffic_floor(cmi, cmc, offs, bs, block_bytes):
     """HBM bytes the cache LAYOUT forces for this move list: a destination block is
     rewritten whole (K + V images) and, unless every slot of it is overwritten, read whole first;
@@ -717,6 +788,10 @@ def measure_workload(a2, seed, device, steps, warmup, probe):
             "what": "S1 with CompressionMetrics.pivot_memory = False: every call samples the store for its pivots "
                     "(sampling pass + pivot kernel, twice the candidates in the collecting pass)"}
         del eli, ekc, ebc
+    if not a2.lean:
+        forms = s1_call_forms(ds, st, evicted, cmi, cmc, k_cache, v_cache, wm, wp, bs, steps=min(steps, 10), ref_counts=out["ekc"])
+        res["S1_reference_call_form_ms"] = forms["reference_call_form"]["ms"]
+        res["S1_call_forms"] = forms
     if a2.steady_cap and res["S1_schedule"] == "small_eviction" and not a2.lean:
         del wm, wp
         res["decode_step"] = decode_step_compare(a2, st, ds, evicted, k_cache, v_cache, cmi, cmc, device,
@@ -1314,6 +1389,11 @@ def main():
         }
         if per_rank:
             res["per_rank"] = per_rank
+        if world == 1 and not args.lean:
+            forms = s1_call_forms(ds, st, evicted, cmi, cmc, k_cache, v_cache, work_metrics, work_pos, bs,
+                                  steps=min(args.steps, 10), ref_counts=out["ekc"])
+            res["S1_reference_call_form_ms"] = forms["reference_call_form"]["ms"]
+            res["S1_call_forms"] = forms
         if world == 1 and not args.no_engine_cache and not args.steady_cap and args.spare_blocks == 0.02:
             res["engine_sized_cache"] = engine_sized_cache_run(args, rank, device)
         if world == 1 and not args.no_s0:

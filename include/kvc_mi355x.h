@@ -4,7 +4,7 @@
  * MI355X (gfx950) implementation of the KV-Compress eviction + compaction hot path.
  * Every entry point takes plain device pointers, sizes and a HIP stream (passed as
  * void*, i.e. hipStream_t); no torch types.  All calls are asynchronous on `stream`,
- * never synchronise (one exception, named as such: kvc_schedule_batch_summary), never allocate: scratch memory is passed in by the caller (query
+ * never synchronise (one exception, named as such: kvc_schedule_batch_summary / _wait), never allocate: scratch memory is passed in by the caller (query
  * the size with the matching *_workspace_bytes function).  All index tensors are
  * int32 (reference: vllm/kvcompress/README.md:27, kernels reinterpret_cast<int*>,
  * csrc/kvcompress_eviction_kernels.cu:527-542).
@@ -332,17 +332,20 @@ size_t kvc_schedule_evictions_workspace_bytes(int64_t total_slots, int32_t total
  *                     ceil(ctx / block_size)   (size of evicted_logical_indices, total_slots above)
  *   host_out[1 + i] = evicted_blocks_per_seq[i], i < num_seqs   (evicted_blocks_per_seq may be NULL
  *                     with num_seqs 0: N only)
- * The ONE entry point that waits: a single launch, then the calling thread blocks until the numbers
- * are in host memory (hipStreamSynchronize(stream) -- everything enqueued on `stream` before has run
- * by then as well; not allowed under stream capture).  host_out: 1 + num_seqs int64.  With
+ * The entry point that may wait (the only one, with kvc_schedule_batch_summary_wait): a single launch; with
+ * wait != 0 the calling thread then blocks until the numbers are in host memory (hipStreamSynchronize(stream)
+ * -- everything enqueued on `stream` before has run by then as well; not allowed under stream capture), with
+ * wait == 0 the call returns behind the launch and the caller prepares whatever does not need the numbers
+ * before it calls kvc_schedule_batch_summary_wait(stream).  host_out: 1 + num_seqs int64.  With
  * host_mapped != 0 it must be page-locked host memory the device can write (hipHostMalloc /
  * torch's pin_memory(): the kernel stores into it directly, no copy is enqueued); with
  * host_mapped == 0 it may be any host memory and `workspace` (>= 8 * (1 + num_seqs) bytes of device
  * memory, 8-byte aligned) carries the numbers to a hipMemcpyAsync. */
 int kvc_schedule_batch_summary(const int32_t* context_lens, int32_t total_heads, int32_t block_size,
                                const int32_t* evicted_blocks_per_seq, int32_t num_seqs,
-                               int64_t* host_out, int32_t host_mapped, void* workspace,
+                               int64_t* host_out, int32_t host_mapped, int32_t wait, void* workspace,
                                size_t workspace_bytes, kvc_stream_t stream);
+int kvc_schedule_batch_summary_wait(kvc_stream_t stream);
 /* Harvest-ahead (ABI version 5).  Continual compression streams the whole metric store twice per
  * decode step: aggregate_decode adds the step's attention to it, and a moment later the
  * small-eviction schedule reads it all again to find the ~1 % of the keys that lie below each

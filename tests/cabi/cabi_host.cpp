@@ -196,8 +196,9 @@ int main() {
       int64_t *pinned = nullptr, plain[2] = {-1, -1};
       CK(hipHostMalloc(&pinned, 16, hipHostMallocDefault));
       pinned[0] = pinned[1] = -1;
-      KV(kvc_schedule_batch_summary(d_ctx2, L * B * H, bs, d_kper, B, pinned, 1, nullptr, 0, s));
-      KV(kvc_schedule_batch_summary(d_ctx2, L * B * H, bs, d_kper, B, plain, 0, ws2, wsb2, s));
+      KV(kvc_schedule_batch_summary(d_ctx2, L * B * H, bs, d_kper, B, pinned, 1, 0, nullptr, 0, s));
+      KV(kvc_schedule_batch_summary_wait(s));
+      KV(kvc_schedule_batch_summary(d_ctx2, L * B * H, bs, d_kper, B, plain, 0, 1, ws2, wsb2, s));
       hok = hok && pinned[0] == N && pinned[1] == kfree && plain[0] == N && plain[1] == kfree;
       if (!hok) printf("batch summary: %ld %ld / %ld %ld, want %d %d\n", (long)pinned[0], (long)pinned[1], (long)plain[0],
                        (long)plain[1], N, kfree);

@@ -3,7 +3,10 @@ symbol include/kvc_mi355x.h declares; the Python surface mirrors the reference n
 the ops refuse to run without a HIP device (no silent fallback)."""
 import inspect
 import os
+
 import re
+
+import numpy as np
 
 import pytest
 import torch
@@ -259,8 +262,10 @@ def test_host_policy_around_predicted_pivots():
     assert cm._hv_pause == 2 and cm.harvest_widen == 0.5
     # the allowance in evictions: a quarter of it may go to a sequence that frees more than it did
     cm.harvest_widen = 0.25
-    assert cm._k_within([8, 8], [8, 8]) and cm._k_within([9, 1], [8, 8]) and not cm._k_within([10, 8], [8, 8])
-    assert not cm._k_within([8], [8, 8]) and cm._k_within([0, 0], [0, 0]) and not cm._k_within([1, 0], [0, 0])
+    a = lambda *v: np.asarray(v, dtype=np.int64)
+    assert cm._k_within(a(8, 8), a(8, 8)) and cm._k_within(a(9, 1), a(8, 8)) and not cm._k_within(a(10, 8), a(8, 8))
+    assert not cm._k_within(a(8, 8, 8), a(8, 8))
+    assert not cm._k_within(a(8), a(8, 8)) and cm._k_within(a(0, 0), a(0, 0)) and not cm._k_within(a(1, 0), a(0, 0))
     # a call that sampled: the usual penalty
     cm._note_flag(1, False)
     assert (cm._fb_penalty, cm._fb_backoff) == (1, 1)

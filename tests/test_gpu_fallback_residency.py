@@ -167,9 +167,8 @@ def test_a_timed_out_wait_is_an_error_not_a_schedule():
     ds.cm.schedule_evictions(*args, total_slots=st.total_slots)
     assert ds.cm.last_schedule_path() == "small_eviction"
     torch.cuda.synchronize()
-    ds.cm._fb_pin[0] = 2                           # what the asynchronous copy would bring back after a fault
-    ds.cm._fb_event = torch.cuda.Event()
-    ds.cm._fb_event.record()
+    slot = ds.cm._fb_inflight[-1][0]
+    ds.cm._fb_pin[slot] = 2                        # what the asynchronous copy would bring back after a fault
     torch.cuda.synchronize()
     with pytest.raises(RuntimeError, match="gave up a wait"):
         ds.cm.schedule_evictions(*args, total_slots=st.total_slots)

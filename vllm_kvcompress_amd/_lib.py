@@ -104,8 +104,9 @@ SYMBOLS = {
     "kvc_schedule_evictions_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32, c_int32]),
     "kvc_schedule_evictions": (c_int32, [ctypes.POINTER(KvcScheduleParams), c_void_p, c_size_t,
                                          c_void_p]),
-    "kvc_schedule_batch_summary": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32,
+    "kvc_schedule_batch_summary": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32,
                                              c_void_p, c_size_t, c_void_p]),
+    "kvc_schedule_batch_summary_wait": (c_int32, [c_void_p]),
     "kvc_schedule_evictions_uses_small_eviction_schedule": (c_int32, [ctypes.POINTER(KvcScheduleParams)]),
     "kvc_schedule_evictions_plan": (c_int32, [ctypes.POINTER(KvcScheduleParams)]),
     "kvc_schedule_evictions_plan_reason": (c_int32, [ctypes.POINTER(KvcScheduleParams)]),

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(1024) void batch_summary_kernel(const int32_t* __re
 
 extern "C" int kvc_schedule_batch_summary(const int32_t* context_lens, int32_t total_heads, int32_t block_size,
                                           const int32_t* evicted_blocks_per_seq, int32_t num_seqs, int64_t* host_out,
-                                          int32_t host_mapped, void* workspace, size_t workspace_bytes,
+                                          int32_t host_mapped, int32_t wait, void* workspace, size_t workspace_bytes,
                                           kvc_stream_t stream) {
   using namespace kvc;
   if (block_size < 1) return fail_invalid("Unsupported block size: " + std::to_string(block_size));
@@ -363,9 +363,13 @@ extern "C" int kvc_schedule_batch_summary(const int32_t* context_lens, int32_t t
     set_error(std::string("schedule_batch_summary: ") + hipGetErrorString(hipGetLastError()));
     return KVC_ERR_HIP;
   }
-  const hipError_t e = hipStreamSynchronize(s);
+  return wait ? kvc_schedule_batch_summary_wait(stream) : KVC_OK;
+}
+
+extern "C" int kvc_schedule_batch_summary_wait(kvc_stream_t stream) {
+  const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
   if (e != hipSuccess) {
-    set_error(std::string("schedule_batch_summary: ") + hipGetErrorString(e));
+    kvc::set_error(std::string("schedule_batch_summary: ") + hipGetErrorString(e));
     return KVC_ERR_HIP;
   }
   return KVC_OK;

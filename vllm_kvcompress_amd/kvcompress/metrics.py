@@ -16,6 +16,7 @@ import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple, Union
 
+import numpy as np
 import torch
 
 from .. import _lib
@@ -149,8 +150,8 @@ class CompressionMetrics:
         # call (no synchronisation: a decode step lies in between); after a raised flag the general
         # schedule is taken for 1, 2, 4 ... up to 64 calls before the small-eviction one is tried
         # again.  Results are identical either way.
-        self._fb_pin = None
-        self._fb_event = None
+        self._fb_pin = None           # page-locked flag words, one per call in flight (FB_RING of them)
+        self._fb_inflight = []        # [(word index, event, predicted)] in the order the calls were made
         self._fb_penalty = 0          # general-schedule calls the last raised flag cost
         self._fb_backoff = 0          # of which still to go
         self._fb_fault = False        # a fallback launch gave up a wait (device fault): digit rounds only from now on
@@ -194,7 +195,6 @@ class CompressionMetrics:
         self._hv_buf = None                # pivots + lists (kvc_harvest_buffer_bytes)
         self._hv = None                    # pivots in _hv_buf: the batch and eviction sizes they were made for
         self._hv_lists = None              # lists in _hv_buf: the call they were made for
-        self._fb_was_predicted = False     # the flag word in flight belongs to a call on predicted pivots (harvested lists / pivot memory)
 
     # temp_metrics is handed to the attention kernels, which write into it; reading the
     # attribute therefore marks it dirty so that the fused clear in aggregate_decode stays
@@ -276,6 +276,13 @@ class CompressionMetrics:
         """reference metrics.py:366-370"""
         self._hv_lists = None
         self.seq_index_by_block[physical_blocks] = -1
+
+    def forget_pivots(self) -> None:
+        """Drop the pivots the last ``schedule_evictions`` left behind (and any lists made with them).  They are kept
+        per batch slot: when a slot changes hands -- a sequence finished, another one took its index
+        (CompressionScheduler.complete_seqs calls this) -- the next call samples the store instead of starting from
+        a stranger's pivot (which would still give the right schedule, through a redone call)."""
+        self._hv = self._hv_lists = None
 
     def randomize_metric_slots(self, slot_mapping: torch.Tensor) -> None:
         flat_indices = slot_mapping.flatten().type(torch.long)
@@ -399,12 +406,19 @@ class CompressionMetrics:
             return False
         if self.harvest_ahead is None:
             self.harvest_ahead = True
-        self._poll_fallback(torch.cuda.is_current_stream_capturing())
+        try:
+            self._poll_fallback(torch.cuda.is_current_stream_capturing())
+        except RuntimeError:
+            self._hv_lists = None
+            self.aggregate_decode(fuse_clear)        # (a fault reported by an EARLIER call: this step's sums still happen)
+            raise
         hv = self._hv
         self._hv_lists = None
         stream = _stream(self.metrics)
         ok = (self.harvest_ahead and self._hv_pause == 0 and hv is not None and hv["seqs"] == tuple(int(s) for s in seq_indices)
               and hv["buf"] is self._hv_buf and hv["full"] and hv["stream"] == stream and not self._fb_fault
+              # (after a raised flag the next calls take the digit rounds: lists would be paid for and not used)
+              and not (self._fb_backoff > 0 and int(self.schedule_path) == 0)
               and isinstance(context_lens, torch.Tensor) and context_lens.is_cuda and context_lens.dtype == torch.int32
               and context_lens.is_contiguous()
               and tuple(context_lens.shape) == (self.num_layers, len(seq_indices), self.num_kv_heads)
@@ -419,7 +433,7 @@ class CompressionMetrics:
             seq_pos, prot = self._as_i32(seq_positions), self._as_i32(num_protected)
             p = KvcScheduleParams()
             self._store_params(p, seq_indices, seq_pos, prot, context_lens, int(total_slots) if total_slots else hv["N"])
-            p.max_evicted_blocks_hint = max(hv["k"])
+            p.max_evicted_blocks_hint = int(hv["k"].max())
             p.schedule_path = int(self.schedule_path)
             p.harvest_buf = self._hv_buf.data_ptr()
             ok = bool(lib.kvc_harvest_eligible(ctypes.byref(p), self.num_queries_per_kv))
@@ -447,19 +461,41 @@ class CompressionMetrics:
     def _k_within(self, k_list, k_then) -> bool:
         """the pivots aim at (1 + widen) x what the step before needed: half of that allowance may go to a sequence
         that frees more blocks than it did then, the rest is for the keys the attention lifts"""
-        return (len(k_list) == len(k_then)
-                and all(a <= b or a <= int(b * (1.0 + 0.5 * self.harvest_widen)) for a, b in zip(k_list, k_then)))
+        if k_list.shape != k_then.shape:
+            return False
+        return bool(np.all(k_list <= np.maximum(k_then, (k_then * (1.0 + 0.5 * self.harvest_widen)).astype(np.int64))))
+
+    FB_RING = 16
 
     def _poll_fallback(self, capturing: bool) -> None:
-        """The flag word of an earlier small-eviction / bracket call, copied to pinned memory behind it:
-        looked at (never waited for) by the next call of this object."""
-        if self._fb_event is None or capturing or not self._fb_event.query():
+        """The flag words of earlier small-eviction / bracket calls, each copied to its own page-locked word behind
+        its call: looked at (never waited for) by the next calls of this object, in the order the calls were made --
+        EVERY call's flag is seen (the back-off after a redone call and the pause / widening of predicted pivots
+        count all of them), at the latest FB_RING calls later."""
+        if capturing:
             return
-        word = int(self._fb_pin[0])
-        self._fb_event = None
-        if word & 2:
-            self._raise_fallback_fault("an earlier")
-        self._note_flag(word, self._fb_was_predicted)
+        while self._fb_inflight and self._fb_inflight[0][1].query():
+            slot, _, predicted = self._fb_inflight.pop(0)
+            word = int(self._fb_pin[slot])
+            if word & 2:
+                self._raise_fallback_fault("an earlier")
+            self._note_flag(word, predicted)
+
+    def _watch_flag(self, ws: torch.Tensor, off: int, predicted: bool) -> None:
+        """copy this call's flag word to a free page-locked word behind the call (no synchronisation)"""
+        if self._fb_pin is None:
+            self._fb_pin = torch.zeros(self.FB_RING, dtype=torch.int32).pin_memory()
+        busy = {slot for slot, _, _ in self._fb_inflight}
+        if len(busy) >= self.FB_RING:              # (FB_RING calls enqueued and none has run yet: wait for the oldest)
+            self._fb_inflight[0][1].synchronize()
+            self._poll_fallback(False)
+            busy = {slot for slot, _, _ in self._fb_inflight}
+        slot = next(i for i in range(self.FB_RING) if i not in busy)
+        with torch.cuda.device(self.device):
+            self._fb_pin[slot:slot + 1].copy_(ws[off:off + 4].view(torch.int32), non_blocking=True)
+            event = torch.cuda.Event()
+            event.record()
+        self._fb_inflight.append((slot, event, predicted))
 
     def _note_flag(self, word: int, predicted: bool) -> None:
         """what a call's flag word means for the calls to come (predicted: it ran on harvested lists or on
@@ -514,11 +550,12 @@ class CompressionMetrics:
             self._small_cache[key] = hit
         return hit
 
-    def _batch_summary(self, context_lens: torch.Tensor, k_per_seq: Optional[torch.Tensor]):
-        """``(N, evicted_blocks_per_seq as a list)`` of a batch the caller describes with device tensors -- what the
-        fork's scheduler passes (reference scheduler.py:245-247, 491-499: a device int tensor, no N).  One launch that
-        writes into page-locked memory and one wait (kvc_schedule_batch_summary); the reference method synchronises
-        for the same reason, many times over (metrics.py:465-489, 709-729)."""
+    def _batch_summary_enqueue(self, context_lens: torch.Tensor, k_per_seq: Optional[torch.Tensor], stream: int) -> int:
+        """``N`` and ``evicted_blocks_per_seq`` of a batch the caller describes with device tensors -- what the fork's
+        scheduler passes (reference scheduler.py:245-247, 491-499: a device int tensor of counts, no N) -- on their way
+        to the host: one launch that writes into page-locked memory (kvc_schedule_batch_summary).
+        ``_batch_summary_read`` waits for it; whatever the call can prepare without the numbers is done in between.
+        The reference method waits for the device for the same reason, many times over (metrics.py:465-489, 709-729)."""
         lib = _lib.load()
         B = 0 if k_per_seq is None else int(k_per_seq.numel())
         if self._summary_pin is None or self._summary_pin.numel() < 1 + B:
@@ -528,10 +565,13 @@ class CompressionMetrics:
         with torch.cuda.device(self.device):
             _lib.check(lib.kvc_schedule_batch_summary(
                 context_lens.data_ptr(), int(context_lens.numel()), int(self.block_size),
-                None if k_per_seq is None else k_per_seq.data_ptr(), B, self._summary_pin.data_ptr(), 1, None, 0,
-                _stream(self.metrics)))
-        vals = self._summary_np[:1 + B].tolist()
-        return int(vals[0]), [int(v) for v in vals[1:]]
+                None if k_per_seq is None else k_per_seq.data_ptr(), B, self._summary_pin.data_ptr(), 1, 0, None, 0,
+                stream))
+        return B
+
+    def _batch_summary_read(self, B: int, stream: int):
+        _lib.check(_lib.load().kvc_schedule_batch_summary_wait(stream))
+        return int(self._summary_np[0]), self._summary_np[1:1 + B].copy()
 
     def schedule_evictions(
         self,
@@ -588,40 +628,36 @@ class CompressionMetrics:
         assert tuple(context_lens.shape) == (L, B, H)
         assert tuple(evicted_kv_offsets.shape) == (B, L, H)
         capturing = torch.cuda.is_current_stream_capturing()
-        seq_pos = self._as_i32(seq_positions)
-        prot = self._as_i32(num_protected)
+        stream = _stream(self.metrics)
         k_per_seq = self._as_i32(evicted_blocks_per_seq)
         # the counts on the host (their maximum picks the schedule, include/kvc_mi355x.h) and N
-        k_list = None
+        k_list, pending = None, None
         if isinstance(evicted_blocks_per_seq, torch.Tensor):
             if not evicted_blocks_per_seq.is_cuda:
-                k_list = [int(v) for v in evicted_blocks_per_seq.tolist()]
+                k_list = np.asarray(evicted_blocks_per_seq.tolist(), dtype=np.int64)
             elif not capturing:
-                # the fork's call (scheduler.py:245-247, 491-499): a device tensor, no N -- both in one wait
-                n_read, k_list = self._batch_summary(context_lens, k_per_seq)
-                if total_slots is None:
-                    total_slots = n_read
+                # the fork's call (scheduler.py:245-247, 491-499): a device tensor, no N -- both in one wait, further down
+                pending = self._batch_summary_enqueue(context_lens, k_per_seq, stream)
         else:
-            k_list = [int(v) for v in evicted_blocks_per_seq]
-        if total_slots is None:
+            k_list = np.asarray([int(v) for v in evicted_blocks_per_seq], dtype=np.int64)
+        if total_slots is None and pending is None:
             if capturing:
                 raise RuntimeError("schedule_evictions: under stream capture pass total_slots= (N cannot be read "
                                    "back from context_lens while the stream is being captured)")
-            total_slots, _ = self._batch_summary(context_lens, None)
-        N = int(total_slots)
+            pending = self._batch_summary_enqueue(context_lens, None, stream)
 
+        # ---- everything that does not depend on N or the counts (the device is busy with the summary meanwhile)
+        seq_pos = self._as_i32(seq_positions)
+        prot = self._as_i32(num_protected)
         out_idx = None                 # (made below, once the schedule is known)
         out_kv = torch.empty((B, L, H), dtype=torch.int32, device=dev)
         out_blk = torch.empty((B, L, H), dtype=torch.int32, device=dev)
 
         p = KvcScheduleParams()
-        self._store_params(p, seq_indices, seq_pos, prot, context_lens, N)
+        self._store_params(p, seq_indices, seq_pos, prot, context_lens, 0)
         p.evicted_blocks_per_seq = k_per_seq.data_ptr()
         p.hanging_token_count = hanging_token_count.data_ptr()
         p.evicted_kv_offsets = evicted_kv_offsets.data_ptr()
-        # the largest count picks the schedule (include/kvc_mi355x.h); unknown only for a device tensor of counts
-        # under stream capture, where nothing can be read back
-        p.max_evicted_blocks_hint = -1 if k_list is None else int(max(k_list))
         p.schedule_path = int(self.schedule_path)
         # the reference's other selection rule (metrics.py:639-666; its scheduler never passes it)
         p.uniform_evict = 1 if uniform_evict else 0
@@ -649,7 +685,23 @@ class CompressionMetrics:
         # harvest-ahead: lists made by aggregate_decode_and_harvest for exactly this call / pivots for the next one
         hl, self._hv_lists = self._hv_lists, None
         p.harvest_buf, p.harvest, p.harvest_widen = None, 0, float(self.harvest_widen)
-        stream = _stream(self.metrics)
+        p.eli_dirty_map = None
+        seqs_key = tuple(int(x) for x in seq_indices)
+        p.evicted_kv_count = out_kv.data_ptr()
+        p.evicted_block_count = out_blk.data_ptr()
+
+        # ---- N and the counts are needed from here on
+        if pending is not None:
+            n_read, k_read = self._batch_summary_read(pending, stream)
+            if total_slots is None:
+                total_slots = n_read
+            if k_list is None:
+                k_list = k_read
+        N = int(total_slots)
+        p.total_slots = N
+        # the largest count picks the schedule (include/kvc_mi355x.h); unknown only for a device tensor of counts
+        # under stream capture, where nothing can be read back
+        p.max_evicted_blocks_hint = -1 if k_list is None else int(k_list.max())
         if (not capturing and p.max_evicted_blocks_hint >= 0
                 and ((self.harvest_ahead and lib.kvc_harvest_eligible(ctypes.byref(p), self.num_queries_per_kv))
                      or (self.pivot_memory and lib.kvc_pivot_memory_eligible(ctypes.byref(p))))):
@@ -667,31 +719,26 @@ class CompressionMetrics:
             elif self._lists_usable(hl, seq_indices, seq_positions, num_protected, context_lens, k_list, stream):
                 p.harvest |= 1
             elif (self.pivot_memory and hv is not None and hv["buf"] is self._hv_buf and hv["stream"] == stream
-                  and hv["seqs"] == tuple(int(x) for x in seq_indices) and self._k_within(k_list, hv["k"])):
+                  and hv["seqs"] == seqs_key and self._k_within(k_list, hv["k"])):
                 p.harvest |= 4
-            self._hv = dict(seqs=tuple(int(x) for x in seq_indices), k=k_list, N=N, buf=self._hv_buf, stream=stream, full=full)
+            self._hv = dict(seqs=seqs_key, k=k_list, N=N, buf=self._hv_buf, stream=stream, full=full)
         else:
             self._hv = None
         self.last_harvest_used = bool(p.harvest & 1)
         self.last_pivot_memory_used = bool(p.harvest & 4)
-        p.eli_dirty_map = None
-        if (self.reuse_output_buffer and not self.lean_outputs and N > 0 and not capturing
-                and int(lib.kvc_schedule_evictions_plan(ctypes.byref(p))) == 1):
+        plan = int(lib.kvc_schedule_evictions_plan(ctypes.byref(p)))
+        if self.reuse_output_buffer and not self.lean_outputs and N > 0 and not capturing and plan == 1:
             out_idx = self._tracked_output(N, bs, p)
         if out_idx is None:
             out_idx = torch.empty((N,), dtype=torch.int32, device=dev)
         p.evicted_logical_indices = out_idx.data_ptr()
-        p.evicted_kv_count = out_kv.data_ptr()
-        p.evicted_block_count = out_blk.data_ptr()
 
         ws_bytes = lib.kvc_schedule_evictions_workspace_bytes(N, B * L * H, B, bs)
         ws = workspace(dev, ws_bytes, "schedule_evictions")
         with torch.cuda.device(dev):
-            _lib.check(lib.kvc_schedule_evictions(ctypes.byref(p), ws.data_ptr(), ws.numel(),
-                                                  _stream(self.metrics)))
+            _lib.check(lib.kvc_schedule_evictions(ctypes.byref(p), ws.data_ptr(), ws.numel(), stream))
         self.last_used_block_tables = bool(lib.kvc_schedule_evictions_uses_block_tables(ctypes.byref(p)))
-        self.last_schedule = (ws, int(lib.kvc_schedule_evictions_fallback_offset(N, B * L * H, B, bs)),
-                              int(lib.kvc_schedule_evictions_plan(ctypes.byref(p))))
+        self.last_schedule = (ws, int(lib.kvc_schedule_evictions_fallback_offset(N, B * L * H, B, bs)), plan)
         self.last_schedule_reason = self._describe_plan(
             self.last_schedule[2], int(lib.kvc_schedule_evictions_plan_reason(ctypes.byref(p))),
             backoff=int(p.schedule_path) == 1 and int(self.schedule_path) != 1)
@@ -706,15 +753,7 @@ class CompressionMetrics:
                 self._raise_fallback_fault("this")
             self._note_flag(word, bool(p.harvest & 5))
         elif self.last_schedule[2] and not capturing:
-            off = self.last_schedule[1]
-            if self._fb_pin is None:
-                self._fb_pin = torch.zeros(1, dtype=torch.int32).pin_memory()
-            if self._fb_event is None:      # (one copy in flight at a time: the pinned word is read before it is reused)
-                with torch.cuda.device(dev):
-                    self._fb_pin.copy_(ws[off:off + 4].view(torch.int32), non_blocking=True)
-                    self._fb_was_predicted = bool(p.harvest & 5)
-                    self._fb_event = torch.cuda.Event()
-                    self._fb_event.record()
+            self._watch_flag(ws, self.last_schedule[1], bool(p.harvest & 5))
         return out_idx, out_kv, out_blk
 
     @staticmethod

@@ -85,6 +85,7 @@ class CompressionScheduler:
         self.iteration_count = 0
         self.new_tokens = 0
         self._iters_since_compression: Dict[int, int] = {}
+        self._aggregation_due = False      # schedule_compression(aggregate_decode=True): the step's aggregation has not run yet
         # persistent move workspace (reference scheduler.py:74-86).  Registered with the op surface:
         # the wrapper's per-call fill_(0) of the whole table (vllm/_custom_ops.py:1168) then only
         # clears the rows the previous call wrote -- the table's contents are the same
@@ -126,6 +127,9 @@ class CompressionScheduler:
     def complete_seqs(self, seq_ids: List[int]) -> None:
         for s in seq_ids:
             self._iters_since_compression.pop(s, None)
+        if seq_ids:
+            # a finished sequence's batch slot goes to another sequence: pivots remembered per slot are not that one's
+            self.compression_metrics.forget_pivots()
 
     def increment_new_tokens(self, n: int) -> None:
         self.new_tokens += n
@@ -141,16 +145,23 @@ class CompressionScheduler:
         ``aggregate_decode_and_harvest`` with the batch of the ``schedule_evictions`` right behind it
         (one sweep of the metric store instead of two), or as the plain pass when
         nothing is compressed this iteration.  The sums, and everything computed from them, are the
-        same as with the reference's order."""
-        self.iteration_count += 1
-        if force or (self.iteration_count >= self.compression_interval
-                     or (self.new_token_limit > -1 and self.new_tokens > self.new_token_limit)):
-            self.iteration_count = 0
-            self.new_tokens = 0
-            return self._schedule_compression(requests, block_tables, context_lens, free_mask, aggregate_decode)
-        if aggregate_decode:
-            self.compression_metrics.aggregate_decode()
-        return None
+        same as with the reference's order.  "Exactly once" holds on every way out of this call: if anything
+        raises before the aggregation has run (the policy's assertion, an out-of-budget batch, a device fault
+        reported by an earlier schedule call), the plain pass runs on the way out, so the step's attention is in
+        the store and temp_metrics is cleared before the exception reaches the engine."""
+        self._aggregation_due = bool(aggregate_decode)
+        try:
+            self.iteration_count += 1
+            if force or (self.iteration_count >= self.compression_interval
+                         or (self.new_token_limit > -1 and self.new_tokens > self.new_token_limit)):
+                self.iteration_count = 0
+                self.new_tokens = 0
+                return self._schedule_compression(requests, block_tables, context_lens, free_mask, aggregate_decode)
+            return None
+        finally:
+            if self._aggregation_due:
+                self._aggregation_due = False
+                self.compression_metrics.aggregate_decode()
 
     # ---- reference scheduler.py:184-560 ---------------------------------------------------
     def _schedule_compression(self, requests, block_tables, context_lens, free_mask, aggregate_decode=False):
@@ -170,9 +181,7 @@ class CompressionScheduler:
             chosen.append(req)
             evicted_blocks.append(n)
         if not chosen:
-            if aggregate_decode:
-                self.compression_metrics.aggregate_decode()
-            return None
+            return None                # (schedule_compression runs the plain aggregation on the way out)
         order = sorted(range(len(chosen)), key=lambda i: chosen[i].slot_index)   # :235-238
         chosen = [chosen[i] for i in order]
         evicted_blocks = [evicted_blocks[i] for i in order]
@@ -190,6 +199,7 @@ class CompressionScheduler:
                    .reshape(B, L, H).type(torch.int32).contiguous())
         protected = [r.protected_window_size for r in chosen]
         if aggregate_decode:
+            self._aggregation_due = False            # (the call below aggregates on every path, its own failures included)
             self.compression_metrics.aggregate_decode_and_harvest(slots, last_token_positions, protected, ctx,
                                                                   total_slots=total_slots)
         if total_slots > self.max_kv_per_compression:
