@@ -216,8 +216,8 @@ def parity_gate(args, st, ds, evicted, mode, gpu, snap, k_cache, v_cache, wm, wp
     from oracle import kvc_oracle_c as orc_c
     N = st.total_slots
     if N > PARITY_ORACLE_MAX_SLOTS:
-        if mode == "per_sequence" and st.num_seqs > 1 and not lean:
-            return parity_gate_sampled(args, st, evicted, gpu, k_cache, v_cache, wm, wp)
+        if st.num_seqs > 1 and not lean:
+            return parity_gate_sampled(args, st, evicted, gpu, k_cache, v_cache, wm, wp, mode=mode)
         return {"bit_exact": None, "skipped": f"{N} candidate slots: the oracle's sorts take minutes at this size "
                                               "(this shape is parity-tested at oracle sizes in tests/)"}
     t0 = time.perf_counter()
@@ -306,13 +306,21 @@ def parity_gate(args, st, ds, evicted, mode, gpu, snap, k_cache, v_cache, wm, wp
     return out
 
 
-def parity_gate_sampled(args, st, evicted, gpu, k_cache, v_cache, wm, wp, num_sampled=8, schedule_only=False):
+def parity_gate_sampled(args, st, evicted, gpu, k_cache, v_cache, wm, wp, num_sampled=8, schedule_only=False,
+                        mode="per_sequence"):
     """The gate for a batch too large for the oracle's sorts (configs[2]: 256 sequences, 270 M slots).
     In per_sequence mode every sequence is scheduled as if alone, so the oracle runs on a sub-batch of
     `num_sampled` sequences spread over the batch and every output of THEIR heads -- evicted indices,
     counts, move rows -- must equal the corresponding piece of the full batch's outputs bit for bit;
     the compaction of the WHOLE batch is checked on the device (K / V rows of every moved slot equal
-    their sources; metrics / positions against torch's own scatter of the move list)."""
+    their sources; metrics / positions against torch's own scatter of the move list).
+
+    mode "reference" (the fork's default: the batch > 1 rule of metrics.py:709-729 couples the sequences):
+    the oracle's two-stage form (oracle/kvc_oracle.py, pinned to the reference's b2_* / b3_* fixtures and to the
+    imported reference) -- stage 1 counts every sequence's finite thresholds over the WHOLE batch (no sort),
+    stage 2 is the batch rule on those counts: the number of chunks EVERY sequence really frees, checked
+    against the device's evicted_block_count of every sequence; stage 3 is the per-sequence schedule with
+    those counts, run for the sampled sequences as above."""
     import torch
     from oracle import kvc_oracle as orc
     from oracle import kvc_oracle_c as orc_c
@@ -324,6 +332,20 @@ def parity_gate_sampled(args, st, evicted, gpu, k_cache, v_cache, wm, wp, num_sa
     ctx = np.ascontiguousarray(st.context_lens[:, sel, :])
     offs_s = synth.kv_offsets(ctx, bs)
     hang_s = synth.hanging_tokens(ctx.transpose(1, 0, 2), bs)
+    coupled = None
+    if mode == "reference":
+        fin, nblk = orc.finite_threshold_chunks(
+            metrics=st.metrics, token_positions=st.token_positions, seq_index_by_block=st.seq_index_by_block,
+            layer_index_by_block=st.layer_index_by_block, head_index_by_block=st.head_index_by_block,
+            logical_block_num_by_block=st.logical_block_num_by_block, block_size=bs, num_layers=L, num_kv_heads=H,
+            seq_indices=st.seq_indices, seq_positions=st.seq_positions, context_lens=st.context_lens,
+            hanging_token_count=st.hanging_token_count, num_protected=st.protected)
+        keff = orc.coupled_eviction_counts(evicted, nblk, fin, "reference")
+        got_blocks = gpu["ebc"].reshape(B, -1).sum(1).cpu().numpy().astype(np.int64)
+        coupled = {"sequences": B, "asked_blocks": int(sum(evicted)), "freed_blocks_by_the_batch_rule": int(keff.sum()),
+                   "sequences_that_free_less_than_asked": int((keff < np.asarray(evicted)).sum()),
+                   "every_sequence_frees_what_the_rule_says": bool(np.array_equal(got_blocks, keff))}
+        evicted = [int(x) for x in keff]
     eli, ekc, ebc = orc.schedule_evictions(
         metrics=st.metrics, token_positions=st.token_positions, seq_index_by_block=st.seq_index_by_block,
         layer_index_by_block=st.layer_index_by_block, head_index_by_block=st.head_index_by_block,
@@ -345,6 +367,10 @@ def parity_gate_sampled(args, st, evicted, gpu, k_cache, v_cache, wm, wp, num_sa
             bad.append(name)
 
     idx = torch.tensor(sel, device=dev)
+    if coupled is not None:
+        compared.append("evicted blocks of every sequence == the batch rule on the whole batch's finite-threshold counts")
+        if not coupled["every_sequence_frees_what_the_rule_says"]:
+            bad.append("evicted blocks per sequence (batch rule)")
     cmp("evicted_kv_count", gpu["ekc"][idx].cpu().numpy(), ekc)
     cmp("evicted_block_count", gpu["ebc"][idx].cpu().numpy(), ebc)
     cmp("cache_moves_count", gpu["cmc"][idx].cpu().numpy(), cmc)
@@ -359,8 +385,8 @@ def parity_gate_sampled(args, st, evicted, gpu, k_cache, v_cache, wm, wp, num_sa
     cmp("evicted_logical_indices", gpu["eli"][rows_full].cpu().numpy(), eli[rows_sub])
     cmp("cache_moves_idx", gpu["cmi"][rows_full].cpu().numpy(), cmi[rows_sub])
     if schedule_only:
-        return {"mode": "per_sequence", "bit_exact": not bad, "sampled_sequences": sel, "compared": compared,
-                "mismatched": bad, "seconds": time.perf_counter() - t0}
+        return {"mode": mode, "bit_exact": not bad, "sampled_sequences": sel, "compared": compared,
+                "mismatched": bad, "seconds": time.perf_counter() - t0, **({"batch_rule": coupled} if coupled else {})}
     # the compaction, all sequences, on the device
     cnt = gpu["cmc"].reshape(-1).long()
     o = torch.from_numpy(st.evicted_kv_offsets.reshape(-1).astype(np.int64)).to(dev)
@@ -383,11 +409,15 @@ def parity_gate_sampled(args, st, evicted, gpu, k_cache, v_cache, wm, wp, num_sa
     compared += ["kv_metrics", "kv_position"]
     if not torch.equal(m2, wm): bad.append("kv_metrics")
     if not torch.equal(p2, wp): bad.append("kv_position")
-    return {"workload": "the timed workload itself", "mode": "per_sequence", "bit_exact": not bad,
-            "sampled_sequences": sel,
-            "what": f"the oracle on a sub-batch of {len(sel)} of the {B} sequences (per_sequence: a sequence's schedule does not "
-                    "depend on the others): every output of their heads against the full batch's; the compaction of all "
-                    "sequences checked on the device",
+    return {"workload": "the timed workload itself", "mode": mode, "bit_exact": not bad,
+            "sampled_sequences": sel, **({"batch_rule": coupled} if coupled else {}),
+            "what": (f"the oracle on a sub-batch of {len(sel)} of the {B} sequences (per_sequence: a sequence's schedule does not "
+                     "depend on the others): every output of their heads against the full batch's; the compaction of all "
+                     "sequences checked on the device") if coupled is None else (
+                     f"the oracle's two-stage form of the reference's batch > 1 rule: finite-threshold counts of all {B} sequences "
+                     "-> the rule as arithmetic -> blocks freed per sequence, ALL sequences against the device's; the per-sequence "
+                     f"schedule with those counts for {len(sel)} sampled sequences, every output of their heads against the full "
+                     "batch's; the compaction of all sequences checked on the device"),
             "compared": compared, "mismatched": bad, "seconds": time.perf_counter() - t0}
 
 
@@ -901,23 +931,19 @@ def decode_step_compare(a2, st, ds, evicted, k_cache, v_cache, cmi, cmc, device,
                                                                    y.view(torch.int32) if y.dtype == torch.float32 else y)]
     # the oracle on the final state (the harvested variant ran last: its outputs are the live ones)
     import copy as _copy
-    if a2.mode == "per_sequence":
-        st2 = _copy.copy(st)
-        st2.metrics = cm.metrics.cpu().numpy()
-        parity = parity_gate_sampled(a2, st2, evicted, dict(eli=eli, ekc=ekc, ebc=ebc, cmi=cmi, cmc=cmc), k_cache, v_cache,
-                                     None, None, schedule_only=True)
-        parity["bit_exact"] = bool(parity["bit_exact"]) and not differ
-    else:
-        # (the reference's batch > 1 rule couples the sequences: no sub-batch the oracle could be run on at this size,
-        # as for the step itself; the two variants -- the schedule's own full pass against harvested lists -- must agree)
-        parity = {"mode": a2.mode, "bit_exact": False if differ else None}
+    st2 = _copy.copy(st)
+    st2.metrics = cm.metrics.cpu().numpy()
+    parity = parity_gate_sampled(a2, st2, evicted, dict(eli=eli, ekc=ekc, ebc=ebc, cmi=cmi, cmc=cmc), k_cache, v_cache,
+                                 None, None, schedule_only=True, mode=a2.mode)
+    parity["bit_exact"] = bool(parity["bit_exact"]) and not differ
     parity["variants_agree"] = not differ
     parity["variants_differ_in"] = differ
     parity["what"] = ("both variants from the same store with the same attention mass: the stores and the last step's outputs must "
-                      "be equal (the oracle cannot be run on a sub-batch under the reference's batch > 1 rule)") if a2.mode != "per_sequence" else (
-                      "both variants from the same store with the same attention mass: the stores and the last step's outputs must "
-                      "be equal; the last step of the harvested variant against the oracle's schedule of that store on a sample of "
-                      "the sequences (S0's sums against the oracle: tests/test_gpu_harvest.py, tests/test_gpu_parity.py)")
+                      "be equal; the last step of the harvested variant against the oracle's schedule of that store ("
+                      + ("a sample of the sequences" if a2.mode == "per_sequence" else
+                         "the reference's batch > 1 rule in the oracle's two-stage form: every sequence's freed blocks, and the full "
+                         "schedule of a sample of the sequences")
+                      + "; S0's sums against the oracle: tests/test_gpu_harvest.py, tests/test_gpu_parity.py)")
     cm.metrics.copy_(m0)
     cm.num_queries_per_kv, cm._temp_metrics, cm.harvest_ahead = saved
     cm._hv = cm._hv_lists = None

@@ -46,7 +46,7 @@ def has_ties(st, kw):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     ops, met = gg.import_reference()
-    ok = ties = 0
+    ok = ties = two_stage = 0
     for seed in range(n):
         rng = np.random.default_rng(50_000 + seed)
         L, H = int(rng.integers(1, 4)), int(rng.integers(1, 4))
@@ -105,8 +105,26 @@ def main():
             print(f"MISMATCH seed {seed}: L{L} H{H} bs{bs} B{B} lens {seq_lens} evict {evicted} {list(kw)}")
             sys.exit(1)
         ok += 1
+        if not uniform:
+            # the two-stage form of the oracle (finite-threshold counts -> the batch rule as arithmetic -> one
+            # per-sequence run per sequence) against the REFERENCE's outputs of the same case
+            kw2 = {a: b for a, b in kw.items() if a != "uniform_evict"}
+            t_eli, t_ekc, t_ebc = orc.schedule_evictions_two_stage(
+                metrics=st.metrics, token_positions=st.token_positions,
+                seq_index_by_block=st.seq_index_by_block, layer_index_by_block=st.layer_index_by_block,
+                head_index_by_block=st.head_index_by_block,
+                logical_block_num_by_block=st.logical_block_num_by_block, block_size=bs, num_layers=L,
+                num_kv_heads=H, seq_indices=st.seq_indices, seq_positions=st.seq_positions,
+                evicted_blocks_per_seq=evicted, context_lens=st.context_lens,
+                hanging_token_count=st.hanging_token_count, evicted_kv_offsets=st.evicted_kv_offsets,
+                num_protected=st.protected, mode="reference", **kw2)
+            if not all(np.array_equal(a, b) for a, b in ((eli, t_eli), (ekc, t_ekc), (ebc, t_ebc))):
+                print(f"MISMATCH (two-stage form) seed {seed}: L{L} H{H} bs{bs} B{B} lens {seq_lens} evict {evicted} {list(kw)}")
+                sys.exit(1)
+            two_stage += 1 if B > 1 else 0
     print(f"matched {ok}/{n}; {ties} skipped because the effective metrics contain ties; "
-          f"{n - ok - ties} where the reference's own assertion fired")
+          f"{n - ok - ties} where the reference's own assertion fired; the two-stage form of the batch rule matched the "
+          f"reference on every non-uniform case ({two_stage} of them with batch > 1)")
 
 
 if __name__ == "__main__":

@@ -215,6 +215,139 @@ def schedule_evictions(
 
 
 # --------------------------------------------------------------------------------------
+# The reference's batch > 1 rule in two stages        vllm/kvcompress/metrics.py:671-729
+#
+# ``schedule_evictions(mode="reference")`` above restates the reference literally: ONE sort over the whole
+# batch, then the host loop.  At 256 coupled sequences (BASELINE configs[2]) that sort is minutes of NumPy, so
+# the HIP path's coupled mode had no oracle verdict at size.  The loop couples the sequences through one thing
+# only -- how many chunks with an infinite threshold lie in front of position ``offset_i + k_i`` of the
+# (sequence, threshold)-ordered chunk list (:718, counted from 0: the reference's bug) -- and that needs no sort:
+# a head's thresholds are every bs-th order statistic of its masked metrics, so the number of FINITE ones follows
+# from the number of finite masked metrics of the head.  Hence:
+#   stage 1  finite_threshold_chunks():  per sequence, its chunks with a finite threshold (one counting pass);
+#   stage 2  coupled_eviction_counts():  :709-729 as interval arithmetic on (nblk_i, fin_i, k_i) -> the number of
+#            chunks every sequence REALLY frees, later sequences un-evicting earlier ones included;
+#   stage 3  the per-sequence schedule (mode="per_sequence", a sequence alone) with those counts.
+# ``schedule_evictions_two_stage`` composes them and is pinned to the literal restatement and to the
+# reference-generated b2_* / b3_* fixtures in tests/test_oracle_golden.py (and against the imported reference by
+# oracle/crosscheck_reference.py); bench.py's reference-mode gate and tests/test_gpu_scale.py use stages 1 + 2 on
+# the whole batch and stage 3 on a sample of its sequences.
+# --------------------------------------------------------------------------------------
+def finite_threshold_chunks(
+    *, metrics, token_positions, seq_index_by_block, layer_index_by_block, head_index_by_block,
+    logical_block_num_by_block, block_size, num_layers, num_kv_heads, seq_indices, seq_positions,
+    context_lens, hanging_token_count, num_protected, use_average=False, num_sinks=0, bias=None,
+    position_bins=None, bias_weight=0.0, blocks_per_pass=1 << 20,
+):
+    """Stage 1.  Returns ``(fin [B], nblk [B])``: per sequence of the batch the number of chunks whose threshold
+    (metrics.py:583-596: the ``hang_g``-th entry of every ``bs`` of a head's ascending masked metrics) is finite, and
+    its number of chunks.  Head g has ``R_g`` finite masked metrics (the mask of metrics.py:539-544), so its chunks
+    ``c`` with ``c * bs + hang_g <= R_g`` are the finite ones."""
+    bs, L, H = block_size, num_layers, num_kv_heads
+    seq_indices = [int(s) for s in seq_indices]
+    B = len(seq_indices)
+    seq_positions = np.asarray(seq_positions, dtype=np.int32).reshape(-1)
+    num_protected = np.asarray(num_protected, dtype=np.int32).reshape(-1)
+    slot_of_seq = np.full(max(seq_indices) + 1, -1, dtype=np.int64)
+    slot_of_seq[seq_indices] = np.arange(B)
+    sib = seq_index_by_block.astype(np.int64)
+    cand = (sib >= 0) & (sib <= max(seq_indices))
+    cand &= slot_of_seq[np.clip(sib, 0, max(seq_indices))] >= 0
+    blocks_all = np.nonzero(cand)[0]
+    ctx_blh = context_lens.transpose(1, 0, 2).reshape(-1).astype(np.int64)
+    R = np.zeros(B * L * H, dtype=np.int64)
+    for lo in range(0, blocks_all.shape[0], blocks_per_pass):
+        blocks = blocks_all[lo:lo + blocks_per_pass]
+        m = metrics[blocks].astype(np.float32)
+        pos = token_positions[blocks].astype(np.int32)
+        lay = layer_index_by_block[blocks].astype(np.int64)
+        head = head_index_by_block[blocks].astype(np.int64)
+        lbn = logical_block_num_by_block[blocks].astype(np.int64)
+        bslot = slot_of_seq[sib[blocks]]
+        if use_average:                                              # metrics.py:495-501
+            with np.errstate(divide="ignore", invalid="ignore"):
+                m = (m / (seq_positions[bslot][:, None] - pos).astype(np.float32)).astype(np.float32)
+        if bias is not None:                                         # metrics.py:503-506
+            b = bias_for_position(bias, position_bins, pos, lay, head)
+            m = (m + (b * np.float32(bias_weight)).astype(np.float32)).astype(np.float32)
+        slh = bslot * (L * H) + lay * H + head
+        in_range = ((lbn < (ctx_blh[slh] + bs - 1) // bs)[:, None]
+                    & (pos <= (seq_positions - num_protected)[bslot][:, None])
+                    & (pos >= num_sinks))                            # metrics.py:539-543
+        finite = in_range & (m < INF32)
+        R += np.bincount(slh, weights=finite.sum(1), minlength=B * L * H).astype(np.int64)
+    hang = hanging_token_count.reshape(-1).astype(np.int64)
+    fin_head = np.where(R >= hang, (R - hang) // bs + 1, 0)
+    nblk_head = (ctx_blh + bs - 1) // bs
+    assert np.all(fin_head <= nblk_head)
+    return fin_head.reshape(B, L * H).sum(1), nblk_head.reshape(B, L * H).sum(1)
+
+
+def coupled_eviction_counts(evicted_blocks_per_seq, nblk, fin, mode="reference"):
+    """Stage 2: the host loop of metrics.py:709-729 on counts.  The chunk list is ordered by (sequence, threshold),
+    so inside sequence j's range ``[o_j, o_j + nblk_j)`` the ``fin_j`` finite thresholds come first.  For
+    ``i = 0..B-1``: ``un_i = o_i + k_i - #inf in [0, o_i + k_i)`` (:718 -- from 0, not from ``o_i``) and everything in
+    ``[un_i, o_i + nblk_i)`` is marked kept (:723).  A chunk at position x of sequence j therefore stays evicted iff
+    ``x < un_i`` for every ``i >= j``.  Returns the number of chunks each sequence frees."""
+    k = [int(x) for x in np.asarray(evicted_blocks_per_seq).reshape(-1)]
+    nblk = np.asarray(nblk, dtype=np.int64)
+    fin = np.asarray(fin, dtype=np.int64)
+    B = len(k)
+    o = np.concatenate([[0], np.cumsum(nblk)[:-1]]).astype(np.int64)
+    inf_lo, inf_hi = o + fin, o + nblk                            # the infinite thresholds of each sequence
+    un = np.empty(B, dtype=np.int64)
+    for i in range(B):
+        x = o[i] + k[i]
+        if mode == "reference":
+            ninf = int(np.clip(np.minimum(x, inf_hi) - inf_lo, 0, None).sum())
+        elif mode == "per_sequence":
+            ninf = int(max(0, min(x, inf_hi[i]) - inf_lo[i]))
+        else:
+            raise ValueError(mode)
+        un[i] = x - ninf
+        assert un[i] >= 0                                         # (the literal restatement's assertion)
+        assert un[i] <= o[i] + fin[i], "an infinite threshold inside the evicted range (metrics.py:725)"
+    suffix_min = np.minimum.accumulate(un[::-1])[::-1]
+    return np.clip(suffix_min - o, 0, nblk).astype(np.int64)
+
+
+def schedule_evictions_two_stage(*, seq_indices, seq_positions, evicted_blocks_per_seq, context_lens,
+                                 hanging_token_count, evicted_kv_offsets, num_protected, block_size, num_layers,
+                                 num_kv_heads, mode="reference", only=None, **store):
+    """``schedule_evictions(mode=...)`` of a batch, computed as stage 1 + stage 2 + one per-sequence run per
+    sequence.  ``only``: batch positions to run stage 3 for (default all) -- the return value then holds, per
+    listed position, ``(evicted_logical_indices of the sequence's heads, evicted_kv_count [L,H],
+    evicted_block_count [L,H])``, plus the effective counts of the WHOLE batch; with ``only=None`` the three
+    arrays of ``schedule_evictions`` are returned."""
+    bs, L, H = block_size, num_layers, num_kv_heads
+    seq_indices = [int(s) for s in seq_indices]
+    B = len(seq_indices)
+    seq_positions = np.asarray(seq_positions, dtype=np.int32).reshape(-1)
+    num_protected = np.asarray(num_protected, dtype=np.int32).reshape(-1)
+    common = dict(block_size=bs, num_layers=L, num_kv_heads=H, **store)
+    fin, nblk = finite_threshold_chunks(seq_indices=seq_indices, seq_positions=seq_positions, context_lens=context_lens,
+                                        hanging_token_count=hanging_token_count, num_protected=num_protected, **common)
+    keff = coupled_eviction_counts(evicted_blocks_per_seq, nblk, fin, mode)
+    pieces = {}
+    for j in (range(B) if only is None else only):
+        ctx_j = np.ascontiguousarray(context_lens[:, j:j + 1, :])
+        per_head = (((ctx_j.astype(np.int64) + bs - 1) // bs) * bs).transpose(1, 0, 2).reshape(-1)
+        offs_j = (np.cumsum(per_head) - per_head).astype(np.int32).reshape(1, L, H)
+        pieces[j] = schedule_evictions(
+            seq_indices=[seq_indices[j]], seq_positions=seq_positions[j:j + 1], evicted_blocks_per_seq=[int(keff[j])],
+            context_lens=ctx_j, hanging_token_count=np.ascontiguousarray(hanging_token_count[j:j + 1]),
+            evicted_kv_offsets=offs_j, num_protected=num_protected[j:j + 1], mode="per_sequence", **common)
+    if only is not None:
+        return {j: (e, kc[0], bc[0]) for j, (e, kc, bc) in pieces.items()}, keff
+    eli = np.concatenate([pieces[j][0] for j in range(B)])
+    ekc = np.concatenate([pieces[j][1] for j in range(B)])
+    ebc = np.concatenate([pieces[j][2] for j in range(B)])
+    assert np.array_equal(np.asarray(evicted_kv_offsets).reshape(-1)[::L * H],
+                          np.concatenate([[0], np.cumsum(nblk * bs)[:-1]]))
+    return eli, ekc, ebc
+
+
+# --------------------------------------------------------------------------------------
 # single_tier_schedule_cache_moves_kernel  csrc/kvcompress_eviction_kernels.cu:223-289
 # (Python twin: vllm/_custom_ops.py:1108-1154; wrapper zero-fill :1168)
 # --------------------------------------------------------------------------------------

@@ -377,3 +377,56 @@ def test_one_process_drives_every_visible_device():
             assert ds2.cm.last_schedule_path() == "small_eviction"
             for name, got in zip(("eli", "ekc", "ebc", "cmi", "cmc"), out):
                 np.testing.assert_array_equal(got.cpu().numpy(), want_steady[name], err_msg=f"{name} on {dev}")
+
+
+@pytest.mark.parametrize("kind", ["steady_state", "bulk"])
+def test_coupled_reference_mode_at_64_sequences_of_4k_tokens(kind):
+    """The fork's default mode -- the reference's batch > 1 rule (metrics.py:709-729: the inf count runs from
+    position 0, so a sequence's eviction depends on every sequence in front of it) -- over 64 coupled sequences
+    of 4k tokens, against the oracle in BOTH its forms: the literal restatement (one sort over the 8.4 M slots
+    of the batch) and the two-stage form bench.py's reference-mode gate uses at configs[2] size (finite-threshold
+    counts -> the rule as arithmetic -> per-sequence runs).  "steady_state": every head one token over its cap,
+    a block per head asked for -- the rule lets only the first sequence free anything; "bulk": 4k -> 2k tokens
+    per sequence -- every sequence frees what it asked for less the infinite thresholds in front of it."""
+    Lc, Hc, B, T = 4, 8, 64, 4096
+    if kind == "steady_state":
+        st = synth.make_state(num_layers=Lc, num_kv_heads=Hc, block_size=BS, seq_lens=[3 * T] * B, seed=5,
+                              protected=32, steady_cap=T, spare_block_frac=0.05)
+        evicted = [synth.evict_block_count(context_lens_lh=st.context_lens[:, b, :], seq_len=3 * T, block_size=BS,
+                                           protected_window_size=32, max_cache_tokens=T) for b in range(B)]
+    else:
+        st = synth.make_state(num_layers=Lc, num_kv_heads=Hc, block_size=BS, seq_lens=[T + 1] * B, seed=6,
+                              protected=32, spare_block_frac=0.05)
+        evicted = _evict(st, 0.5, T)
+    kw = dict(metrics=st.metrics, token_positions=st.token_positions, seq_index_by_block=st.seq_index_by_block,
+              layer_index_by_block=st.layer_index_by_block, head_index_by_block=st.head_index_by_block,
+              logical_block_num_by_block=st.logical_block_num_by_block, block_size=BS, num_layers=Lc, num_kv_heads=Hc,
+              seq_indices=st.seq_indices, seq_positions=st.seq_positions, evicted_blocks_per_seq=evicted,
+              context_lens=st.context_lens, hanging_token_count=st.hanging_token_count,
+              evicted_kv_offsets=st.evicted_kv_offsets, num_protected=st.protected)
+    want = orc.schedule_evictions(**kw, mode="reference")
+    two = orc.schedule_evictions_two_stage(**kw, mode="reference")
+    for a, b, name in zip(two, want, ("eli", "ekc", "ebc")):
+        np.testing.assert_array_equal(a, b, err_msg=f"oracle, two-stage form vs literal restatement: {name}")
+    freed = want[2].reshape(B, -1).sum(1)
+    asked = np.asarray(evicted)
+    if kind == "steady_state":
+        assert freed[0] == asked[0] and not freed[1:].any()          # the quirk: only the first sequence frees anything
+    else:
+        assert freed[0] == asked[0] and (freed[1:] < asked[1:]).all() and (freed > 0).sum() > 40
+    ds = hdev.upload(st, DEV, mode="reference")
+    ds.cm.schedule_path = 0
+    for form in ("list", "fork"):
+        if form == "list":
+            got = ds.cm.schedule_evictions(list(st.seq_indices), ds.seq_positions, evicted, ds.context_lens,
+                                           ds.hanging_token_count, ds.evicted_kv_offsets, list(st.protected),
+                                           total_slots=st.total_slots)
+        else:       # the fork's call: counts as a device tensor, no N
+            got = ds.cm.schedule_evictions(list(st.seq_indices), ds.seq_positions.clone(),
+                                           torch.tensor(evicted, dtype=torch.int, device=DEV), ds.context_lens,
+                                           ds.hanging_token_count, ds.evicted_kv_offsets, tuple(st.protected))
+        path = ds.cm.last_schedule_path()
+        assert path.startswith("small_eviction" if kind == "steady_state" else "bracket"), (form, ds.cm.last_schedule_reason)
+        for a, b, name in zip(got, want, ("eli", "ekc", "ebc")):
+            np.testing.assert_array_equal(a.cpu().numpy(), b, err_msg=f"{kind}, {form} form ({path}): {name}")
+        del got

@@ -20,6 +20,63 @@ def test_schedule_evictions_matches_reference(name):
 
 
 @pytest.mark.parametrize("name", golden_cases())
+def test_two_stage_form_matches_reference(name):
+    """oracle.schedule_evictions_two_stage (finite-threshold counts -> the batch rule as interval arithmetic ->
+    per-sequence runs) against every reference-generated fixture, the batch > 1 ones (b2_* / b3_*: the
+    reference's inf-count quirk, metrics.py:718-721) included; uniform_evict is another rule"""
+    g = load_golden(name)
+    kw = sched_kwargs(g)
+    if kw.pop("uniform_evict", False):
+        pytest.skip("uniform_evict: the reference's other selection rule")
+    eli, ekc, ebc = orc.schedule_evictions_two_stage(**kw, mode="reference")
+    np.testing.assert_array_equal(eli, g["ref_evicted_logical_indices"])
+    np.testing.assert_array_equal(ekc, g["ref_evicted_kv_count"])
+    np.testing.assert_array_equal(ebc, g["ref_evicted_block_count"])
+
+
+@pytest.mark.parametrize("mode", ["reference", "per_sequence"])
+def test_two_stage_form_equals_the_literal_restatement_on_coupled_batches(mode):
+    """random batches of 2-7 sequences where the quirk bites (eviction counts around and beyond the finite
+    thresholds of the sequences in front): the two forms of the oracle must agree bit for bit -- or both trip
+    the reference's own assertions (metrics.py:725 / a negative kept range)"""
+    from vllm_kvcompress_amd.harness import synth
+    agreed = tripped = 0
+    for seed in range(40):
+        rng = np.random.default_rng(seed)
+        B = int(rng.integers(2, 8))
+        bs = int(rng.choice([8, 16, 32]))
+        st = synth.make_state(num_layers=2, num_kv_heads=2, block_size=bs,
+                              seq_lens=[int(x) for x in rng.integers(3 * bs, 40 * bs, B)], seed=seed,
+                              protected=[int(x) for x in rng.integers(1, 3 * bs, B)], compressed=bool(seed % 2))
+        nblk = ((st.context_lens.astype(np.int64) + bs - 1) // bs).sum(0).sum(-1)
+        evicted = [int(rng.integers(0, max(1, n // (1 + seed % 3)))) for n in nblk]
+        kw = dict(metrics=st.metrics, token_positions=st.token_positions, seq_index_by_block=st.seq_index_by_block,
+                  layer_index_by_block=st.layer_index_by_block, head_index_by_block=st.head_index_by_block,
+                  logical_block_num_by_block=st.logical_block_num_by_block, block_size=bs, num_layers=2, num_kv_heads=2,
+                  seq_indices=st.seq_indices, seq_positions=st.seq_positions, evicted_blocks_per_seq=evicted,
+                  context_lens=st.context_lens, hanging_token_count=st.hanging_token_count,
+                  evicted_kv_offsets=st.evicted_kv_offsets, num_protected=st.protected)
+        try:
+            want = orc.schedule_evictions(**kw, mode=mode)
+        except AssertionError:
+            with pytest.raises(AssertionError):
+                orc.schedule_evictions_two_stage(**kw, mode=mode)
+            tripped += 1
+            continue
+        got = orc.schedule_evictions_two_stage(**kw, mode=mode)
+        for a, b in zip(got, want):
+            np.testing.assert_array_equal(a, b, err_msg=f"seed {seed}")
+        # ... and the sampled form returns the same pieces
+        pieces, keff = orc.schedule_evictions_two_stage(**kw, mode=mode, only=[B - 1])
+        L_H = 4
+        assert int(want[2].reshape(B, L_H).sum(1)[B - 1]) == int(keff[B - 1])
+        np.testing.assert_array_equal(pieces[B - 1][1], want[1][B - 1])
+        np.testing.assert_array_equal(want[2].reshape(B, L_H).sum(1), keff, err_msg=f"seed {seed}: effective counts")
+        agreed += 1
+    assert agreed >= 20, (agreed, tripped)
+
+
+@pytest.mark.parametrize("name", golden_cases())
 def test_torch_sort_formulation_matches_reference(name):
     """oracle/kvc_oracle_torch.py (the reference's six-sort formulation on torch CPU tensors, what
     bench.py's cpu_baseline times) against the same fixtures; bias cases are not restated there"""
