@@ -310,7 +310,14 @@ typedef struct kvc_schedule_params {
                                                *   one decode step of attention old either way, and a pass that lists
                                                *   too little raises the flag as always.  Only the first
                                                *   kvc_harvest_pivot_bytes() of the buffer are touched.
-                                               * All three are for calls that take the small-eviction schedule
+                                               * bit 3 (ABI version 6, with bit 0): the lists were made by the decode
+                                               *   attention's fused-metric epilogue (kvc_attention_harvest_begin) and
+                                               *   carry what they were made with -- every head's context length, every
+                                               *   sequence's position and protected window; the call compares them with
+                                               *   its own on the device and raises the flag on any difference (lists of
+                                               *   another batch are redone, not trusted).  The caller still vouches for
+                                               *   the store: nothing wrote to it since the last attention launch.
+                                               * All of them are for calls that take the small-eviction schedule
                                                * (kvc_harvest_eligible / kvc_pivot_memory_eligible) and are ignored
                                                * by the other schedules; bits 0 and 2 without harvest_buf are an
                                                * error. */
@@ -600,7 +607,41 @@ typedef struct kvc_attention_params {
   int32_t fused_use_l2;                 /* with fused_metrics: accumulate p^2 (1) or p (0) */
   int32_t schedule;                     /* 0 = automatic, 1 = always partitioned (the reference's v2
                                            shape), 2 = single pass whenever the context fits in LDS */
+  /* ABI version 6, with fused_metrics only: harvest in the epilogue (see kvc_attention_harvest_begin).
+   * harvest_buf NULL = none; every field below is ignored then. */
+  void* harvest_buf;                    /* the buffer kvc_attention_harvest_begin was called with */
+  const int32_t* harvest_seq_slot;      /* [num_seqs]: position of this call's sequence in the compression
+                                           batch the harvest was begun for, or -1 (not part of it) */
+  const int32_t* harvest_seq_positions; /* [harvest_num_seqs]: the schedule call's seq_positions */
+  const int32_t* harvest_num_protected; /* [harvest_num_seqs]: the schedule call's num_protected */
+  int32_t harvest_num_seqs;             /* sequences of the compression batch */
+  int32_t harvest_layer;                /* the layer this call computes */
+  int32_t harvest_num_layers;           /* L of the schedule call (num_kv_heads above is its H) */
+  int32_t harvest_num_sinks;            /* the schedule call's num_sinks */
 } kvc_attention_params;
+
+/* The decode step without a sweep of the metric store (ABI version 6).  With fused_metrics the
+ * attention adds a step's weights straight into the store -- no [NB, bs, qpk] round trip, no
+ * aggregate_decode -- but the small-eviction schedule that follows still streams the whole store to
+ * find the ~1 % of the keys below each sequence's pivot.  The epilogue has every new sum in a
+ * register and the key's position next to it: with harvest_buf set it appends the keys of the NEXT
+ * compression batch that lie below the pivots the previous kvc_schedule_evictions left there
+ * (harvest bit 1) to their heads' candidate lists, as kvc_aggregate_decode_harvest does.  Protocol
+ * of one decode step:
+ *   kvc_attention_harvest_begin(p, stream)        p = the schedule call that will follow (as for
+ *                                                 kvc_aggregate_decode_harvest); clears the counters
+ *   kvc_paged_attention_decode x num_layers       one per layer, each with harvest_layer = its layer,
+ *                                                 over every sequence of the compression batch
+ *   kvc_schedule_evictions(harvest bits 0 | 3 [| 1])  runs records -> selection -> emission on the lists
+ * Eligible (kvc_attention_harvest_eligible): calls that take the small-eviction schedule in its
+ * position-lazy form (no use_average, no bias, mode 1 or one sequence).  Exact or flagged, like every
+ * list of that schedule: a layer that was not launched, a sequence of the batch the attention did not
+ * see, a metric window that ends before the eviction bound (last_position - kv_metric_buffer_len <
+ * seq_position - num_protected) or pivots that were too low leave lists that fall short, and the
+ * schedule call redoes the work on the device.  The caller vouches that nothing else writes to the
+ * store between begin and the schedule call (the Python binding checks version counters). */
+int32_t kvc_attention_harvest_eligible(const kvc_schedule_params* p);
+int kvc_attention_harvest_begin(const kvc_schedule_params* p, kvc_stream_t stream);
 
 int kvc_paged_attention_decode(const kvc_attention_params* p, kvc_stream_t stream);
 /* 1 if a call with these sizes goes through the partition buffers (exp_sums, max_logits, tmp_out,

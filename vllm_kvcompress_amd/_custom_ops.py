@@ -420,7 +420,7 @@ def _paged_attention_kvc(out, kv_metric_out, exp_sum, max_logits, tmp_out, tmp_k
                          query, key_cache, value_cache, num_kv_heads, scale, block_tables,
                          context_lens, kv_position, last_position, kv_metric_buffer_len,
                          block_size, max_context_len, alibi_slopes, kv_cache_dtype, k_scale,
-                         v_scale, record_kv_metrics, fused_metrics=None, use_l2=True) -> None:
+                         v_scale, record_kv_metrics, fused_metrics=None, use_l2=True, harvest=None, layer=0) -> None:
     lib = _lib.load()
     for name, t in (("out", out), ("query", query), ("key_cache", key_cache),
                     ("value_cache", value_cache)):
@@ -476,8 +476,19 @@ def _paged_attention_kvc(out, kv_metric_out, exp_sum, max_logits, tmp_out, tmp_k
     p.dtype, p.kv_cache_dtype = dtypes[query.dtype], kvds[kv_cache_dtype]
     p.record_kv_metrics = int(bool(record_kv_metrics))
     p.schedule = _ATTENTION_SCHEDULE
+    if harvest is not None:
+        # the lists of the next schedule call, made by this launch's epilogue (CompressionMetrics.begin_attention_harvest)
+        harvest.check_call(query, int(num_kv_heads), int(block_size), int(layer), _stream(query))
+        p.harvest_buf = harvest.buf.data_ptr()
+        p.harvest_seq_slot = harvest.seq_slot.data_ptr()
+        p.harvest_seq_positions = harvest.seq_positions.data_ptr()
+        p.harvest_num_protected = harvest.num_protected.data_ptr()
+        p.harvest_num_seqs, p.harvest_layer = harvest.num_seqs, int(layer)
+        p.harvest_num_layers, p.harvest_num_sinks = harvest.num_layers, harvest.num_sinks
     with torch.cuda.device(query.device):
         _lib.check(lib.kvc_paged_attention_decode(p, _stream(query)))
+    if harvest is not None:
+        harvest.layers_done.add(int(layer))
     _written(out, kv_metric_out if record_kv_metrics else None)
 
 
@@ -540,7 +551,8 @@ def paged_attention_kvc_fused_metrics(out, metrics, query, key_cache, value_cach
                                       block_size: int, max_context_len: int, alibi_slopes,
                                       kv_cache_dtype: str, k_scale: float, v_scale: float,
                                       use_l2: bool = True,
-                                      temp_metrics: Optional[torch.Tensor] = None) -> None:
+                                      temp_metrics: Optional[torch.Tensor] = None,
+                                      harvest=None, layer: int = 0) -> None:
     """Extension (the reference lists it as a to-do, vllm/kvcompress/README.md:32,49): the
     attention of ``paged_attention_kvc_v1`` that adds ``sum_q p^2`` (or ``sum_q p``) of every
     key inside the metric window straight into ``metrics [num_blocks, block_size]`` -- what
@@ -549,7 +561,13 @@ def paged_attention_kvc_fused_metrics(out, metrics, query, key_cache, value_cach
     When the call takes the partitioned schedule (long contexts at small batch) the
     unnormalised weights need a ``[num_blocks, block_size, qpk]`` float32 scratch: pass
     ``CompressionMetrics.temp_metrics`` (which this path otherwise leaves unused) as
-    ``temp_metrics``; the op never allocates a buffer of that size itself."""
+    ``temp_metrics``; the op never allocates a buffer of that size itself.
+
+    ``harvest`` / ``layer``: the handle of ``CompressionMetrics.begin_attention_harvest`` and the layer
+    this call computes -- the epilogue then also lists, per head, the keys that fall below the pivots the
+    last ``schedule_evictions`` left behind, and the ``schedule_evictions`` that follows
+    ``end_attention_harvest`` runs on those lists: a decode step of continual compression without a sweep
+    of the metric store (kvc_attention_harvest_begin, include/kvc_mi355x.h)."""
     es, ml, to = _partition_scratch(query, num_kv_heads, max_context_len, "attn_fused")
     tm = None
     if es is not None:
@@ -568,7 +586,7 @@ def paged_attention_kvc_fused_metrics(out, metrics, query, key_cache, value_cach
                          scale, block_tables, context_lens, kv_position, last_position,
                          kv_metric_buffer_len, block_size, max_context_len, alibi_slopes,
                          kv_cache_dtype, k_scale, v_scale, True, fused_metrics=metrics,
-                         use_l2=use_l2)
+                         use_l2=use_l2, harvest=harvest, layer=layer)
 
 
 def paged_attention_kvc_v2(out, kv_metric_out, exp_sum, max_logits, tmp_out, tmp_kv_metric_out,

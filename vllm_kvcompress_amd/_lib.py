@@ -69,6 +69,9 @@ class KvcAttentionParams(ctypes.Structure):
         ("max_num_blocks_per_seq", c_int32), ("max_context_len", c_int32),
         ("dtype", c_int32), ("kv_cache_dtype", c_int32), ("record_kv_metrics", c_int32),
         ("fused_use_l2", c_int32), ("schedule", c_int32),
+        ("harvest_buf", c_void_p), ("harvest_seq_slot", c_void_p), ("harvest_seq_positions", c_void_p),
+        ("harvest_num_protected", c_void_p), ("harvest_num_seqs", c_int32), ("harvest_layer", c_int32),
+        ("harvest_num_layers", c_int32), ("harvest_num_sinks", c_int32),
     ]
 
 
@@ -116,6 +119,8 @@ SYMBOLS = {
     "kvc_harvest_pivot_bytes": (c_size_t, [c_int32]),
     "kvc_pivot_memory_eligible": (c_int32, [ctypes.POINTER(KvcScheduleParams)]),
     "kvc_harvest_eligible": (c_int32, [ctypes.POINTER(KvcScheduleParams), c_int32]),
+    "kvc_attention_harvest_eligible": (c_int32, [ctypes.POINTER(KvcScheduleParams)]),
+    "kvc_attention_harvest_begin": (c_int32, [ctypes.POINTER(KvcScheduleParams), c_void_p]),
     "kvc_aggregate_decode_harvest": (c_int32, [ctypes.POINTER(KvcScheduleParams), c_void_p, c_int32, c_int32,
                                                c_int32, c_void_p]),
     "kvc_aggregate_decode": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,

@@ -51,6 +51,28 @@ extern "C" int kvc_paged_attention_decode(const kvc_attention_params* p, kvc_str
   a.max_blocks = p->max_num_blocks_per_seq; a.record = p->record_kv_metrics ? 1 : 0;
   a.max_ctx = p->max_context_len > 0 ? p->max_context_len : 1;
   a.schedule = p->schedule;
+  a.hv = AttnHarvest{};
+  if (p->harvest_buf != nullptr) {
+    if (a.fused_metrics == nullptr) return fail_invalid("paged_attention_decode: harvest_buf needs fused_metrics");
+    if (p->harvest_seq_slot == nullptr || p->harvest_seq_positions == nullptr || p->harvest_num_protected == nullptr ||
+        p->harvest_num_seqs < 1 || p->harvest_num_layers < 1 || p->harvest_layer < 0 || p->harvest_layer >= p->harvest_num_layers ||
+        (reinterpret_cast<uintptr_t>(p->harvest_buf) & 15) != 0)
+      return fail_invalid("paged_attention_decode: bad harvest arguments");
+    if (p->block_size != 8 && p->block_size != 16 && p->block_size != 32)
+      return fail_invalid("paged_attention_decode: harvest needs block size 8, 16 or 32 (the small-eviction schedule's)");
+    const int G = p->harvest_num_seqs * p->harvest_num_layers * p->num_kv_heads;
+    const HvLayout hl = hv_layout(G, p->harvest_num_seqs);
+    uint8_t* hb = reinterpret_cast<uint8_t*>(p->harvest_buf);
+    a.hv.pivot = reinterpret_cast<const uint32_t*>(hb + hl.pivot);
+    a.hv.cnt = reinterpret_cast<uint32_t*>(hb + hl.cnt);
+    a.hv.lists = reinterpret_cast<unsigned long long*>(hb + hl.rec64);
+    a.hv.claimed = reinterpret_cast<uint32_t*>(hb + hl.claimed);
+    a.hv.seen_ctx = reinterpret_cast<int32_t*>(hb + hl.seen_ctx);
+    a.hv.seq_slot = p->harvest_seq_slot;
+    a.hv.seq_positions = p->harvest_seq_positions;
+    a.hv.num_protected = p->harvest_num_protected;
+    a.hv.layer = p->harvest_layer; a.hv.num_layers = p->harvest_num_layers; a.hv.num_sinks = p->harvest_num_sinks;
+  }
   a.max_parts = (p->max_context_len + ATT_PART - 1) / ATT_PART;
   if (a.max_parts < 1) a.max_parts = 1;
   hipStream_t s = (hipStream_t)stream;

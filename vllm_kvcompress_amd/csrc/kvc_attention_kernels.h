@@ -21,6 +21,7 @@
 // The kernel is HBM-bound: 2*hd*e bytes per cached token and KV head.
 #pragma once
 #include "kvc_common.h"
+#include "kvc_harvest_layout.h"
 #include "../../include/kvc_mi355x.h"
 
 #include <math.h>
@@ -153,6 +154,30 @@ struct KvFrag {
   }
 };
 
+// Harvest in the fused-metric epilogue (the decode step without a sweep of the metric store; the reference author's
+// to-do, vllm/kvcompress/README.md:32, 49, kernel side csrc/attention/kvcompress_attention_kernels.cu:297-313):
+// where the epilogue folds a key's weights into metrics[slot] it has the new sum in a register and the key's
+// position at hand -- a key of a sequence of the NEXT compression batch whose sum lies below that sequence's pivot
+// (left in the harvest buffer by the previous schedule_evictions) is appended to its head's candidate list there,
+// exactly as kvc_schedule_harvest.h's aggregation pass does in its position-lazy form.  After the L launches of a
+// decode step (one per layer) the lists hold every evictable key below the pivots, and the schedule call runs on
+// them: no aggregate_decode, no collecting pass.  Exactness never depends on the pivots: lists that fall short
+// raise the schedule's flag (kvc_schedule_small.h).  A head whose metric window does not reach the eviction bound
+// (kv_metric_buffer_len too large for the protected window) cannot list everything: its count is pushed over the
+// record length, which raises the same flag.
+struct AttnHarvest {
+  const uint32_t* pivot;          // [B]
+  uint32_t* cnt;                  // [G] candidates per head, G = B * L * Hkv, g = (b * L + l) * Hkv + h
+  unsigned long long* lists;      // [G, KREC] (key << 32 | physical slot)
+  uint32_t* claimed;              // [CLAIM_SHARDS x 32] logical blocks the epilogues walked
+  int32_t* seen_ctx;              // [G] the context length each head's list was made with
+  const int32_t* seq_slot;        // [S] this call's sequence -> position in the compression batch, or -1
+  const int32_t* seq_positions;   // [B] the schedule call's (position of the token sampled last, not cached yet)
+  const int32_t* num_protected;   // [B]
+  int32_t layer, num_layers, num_sinks;
+};
+struct HarvestCtx { uint32_t pivot; int g; int bound; };   // pivot 0: nothing of this head is listed
+
 struct AttnArgs {
   void* out;                      // [S, Hq, hd] T
   float* kv_metric_out;           // [NB, bs, qpk]
@@ -173,7 +198,32 @@ struct AttnArgs {
   int64_t q_stride, kv_block_stride;
   float scale, k_scale, v_scale;
   int32_t num_heads, num_kv_heads, max_blocks, max_parts, record, max_ctx, use_l2, schedule;
+  AttnHarvest hv;                 // hv.cnt == nullptr: no harvest
 };
+
+// once per (sequence, KV head) workgroup; `first`: one thread of the ONE workgroup that accounts for the head
+__device__ __forceinline__ HarvestCtx harvest_ctx(const AttnArgs& a, int seq, int hk, int max_pos, int ctx, int bs, bool first) {
+  HarvestCtx h{0u, -1, 0};
+  if (a.hv.cnt == nullptr || a.fused_metrics == nullptr) return h;
+  const int i = a.hv.seq_slot[seq];
+  if (i < 0) return h;
+  h.g = (i * a.hv.num_layers + a.hv.layer) * a.num_kv_heads + hk;
+  h.pivot = a.hv.pivot[i];
+  h.bound = a.hv.seq_positions[i] - a.hv.num_protected[i];
+  if (first) {
+    atomicAdd(&a.hv.claimed[((unsigned)(seq * a.num_kv_heads + hk) % (unsigned)CLAIM_SHARDS) * 32], (uint32_t)((ctx + bs - 1) / bs));
+    if (max_pos < h.bound) atomicAdd(&a.hv.cnt[h.g], (uint32_t)KREC + 1u);
+    a.hv.seen_ctx[h.g] = ctx;
+  }
+  return h;
+}
+__device__ __forceinline__ void harvest_key(const AttnArgs& a, const HarvestCtx& h, int64_t slot, float mn, int pos) {
+  const uint32_t key = float_to_key(mn);
+  if (key < h.pivot && pos <= h.bound && pos >= a.hv.num_sinks) {          // (metrics.py:539-544)
+    const uint32_t at = atomicAdd(&a.hv.cnt[h.g], 1u);
+    if (at < (uint32_t)KREC) a.hv.lists[(int64_t)h.g * KREC + at] = ((unsigned long long)key << 32) | (uint32_t)slot;
+  }
+}
 
 // fused aggregation (what CompressionMetrics.aggregate_decode does with the stored weights,
 // vllm/kvcompress/metrics.py:429-439): metrics[slot] += sum_q p_q^2 (L2) or sum_q p_q, summed in
@@ -188,11 +238,13 @@ __device__ __forceinline__ float metric_term(float acc, float p, int use_l2) {
 // allocates in L2 and costs 15 % of the whole kernel) or are folded into metrics[slot]
 template <typename F>
 __device__ __forceinline__ void put_metric_row(const AttnArgs& a, float* mo, bool fuse, int64_t slot,
-                                               int qpk, int q0, int nq, F val) {
+                                               int qpk, int q0, int nq, F val, const HarvestCtx& hc, int pos) {
   if (fuse) {
     float acc = 0.0f;
     for (int q = 0; q < nq; ++q) acc = metric_term(acc, val(q), a.use_l2);
-    a.fused_metrics[slot] = __fadd_rn(a.fused_metrics[slot], acc);
+    const float mn = __fadd_rn(a.fused_metrics[slot], acc);
+    a.fused_metrics[slot] = mn;
+    if (hc.pivot) harvest_key(a, hc, slot, mn, pos);
   } else if (((qpk | nq) & 3) == 0) {
     for (int q = 0; q < nq; q += 4) {
       f32x4 v;
@@ -433,12 +485,13 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
     if (tid < nq) red_max[0][tid] = __fdividef(1.0f, red_sum[0][tid] + red_sum[1][tid] + red_sum[2][tid] + red_sum[3][tid] + 1e-6f);
     __syncthreads();
     const float* inv_q = red_max[0];
+    const HarvestCtx hc = fuse ? harvest_ctx(a, seq, hk, max_pos, ctx, BS, tid == 0 && q0 == 0) : HarvestCtx{0u, -1, 0};
 #pragma unroll
     for (int k = 0; k < ATT_CHUNK / 64; ++k) {
       const int tl = k * 64 + lane;
       if (mpos[k] > max_pos) continue;                     // .cu:305-312 (also: token >= ctx)
       put_metric_row(a, mo, fuse, mslot[k], qpk, q0, nq,
-                     [&](int q) { return __fmul_rn(pw[q * ROW + tl], inv_q[q]); });
+                     [&](int q) { return __fmul_rn(pw[q * ROW + tl], inv_q[q]); }, hc, mpos[k]);
     }
   }
 }
@@ -689,6 +742,7 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
     }
     __syncthreads();
     const bool fuse = a.fused_metrics != nullptr;
+    const HarvestCtx hc = fuse ? harvest_ctx(a, seq, hk, max_pos, ctx, BS, tid == 0 && q0 == 0) : HarvestCtx{0u, -1, 0};
     for (int it = 0; it < niter; ++it) {
       const int tok_w0 = it * STEP + w * ATT_CHUNK;
       if (tok_w0 >= ctx) break;
@@ -702,9 +756,10 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
         const int tok = tok_w0 + k * 64 + lane;
         if (tok >= ctx) continue;
         const int64_t slot = (int64_t)bt[tok / BS] * BS + (tok % BS);
-        if (a.kv_position[slot] > max_pos) continue;
+        const int kpos = a.kv_position[slot];
+        if (kpos > max_pos) continue;
         put_metric_row(a, a.kv_metric_out, fuse, slot, qpk, q0, nq,
-                       [&](int q) { return __fmul_rn(P[q * prow + tok], fq[q]); });
+                       [&](int q) { return __fmul_rn(P[q * prow + tok], fq[q]); }, hc, kpos);
       }
       __builtin_amdgcn_wave_barrier();               // wfac[w] is rewritten by the next iteration
     }
@@ -815,6 +870,7 @@ __global__ __launch_bounds__(256) void paged_attention_metric_rescale_kernel(Att
   const int32_t* bt = a.block_tables + (int64_t)(seq * a.num_kv_heads + hk) * a.max_blocks;
   constexpr int K = ATT_RS_TOK / 256;
   const bool fuse = a.fused_metrics != nullptr;
+  const HarvestCtx hc = fuse ? harvest_ctx(a, seq, hk, max_pos, ctx, BS, tid == 0 && chunk == 0) : HarvestCtx{0u, -1, 0};
   if ((qpk & 3) == 0 && !(fuse && qpk != 4)) {
     // all address loads, then all position + tmp loads, then the stores: four independent
     // chains per lane keep enough bytes in flight for a pass that is pure streaming; query
@@ -848,7 +904,9 @@ __global__ __launch_bounds__(256) void paged_attention_metric_rescale_kernel(Att
           float acc = 0.0f;
 #pragma unroll
           for (int q = 0; q < 4; ++q) acc = metric_term(acc, v[q], a.use_l2);
-          a.fused_metrics[slot[k]] = __fadd_rn(a.fused_metrics[slot[k]], acc);
+          const float mn = __fadd_rn(a.fused_metrics[slot[k]], acc);
+          a.fused_metrics[slot[k]] = mn;
+          if (hc.pivot) harvest_key(a, hc, slot[k], mn, posv[k]);
         } else {
           *reinterpret_cast<f32x4*>(a.kv_metric_out + slot[k] * qpk + qb) = v;
         }
@@ -859,7 +917,8 @@ __global__ __launch_bounds__(256) void paged_attention_metric_rescale_kernel(Att
       const int i = chunk * ATT_RS_TOK + k * 256 + tid;
       if (i >= ctx) break;
       const int64_t slot = (int64_t)bt[i / BS] * BS + (i % BS);
-      if (a.kv_position[slot] > max_pos) continue;
+      const int kpos = a.kv_position[slot];
+      if (kpos > max_pos) continue;
       const int pj = i / ATT_PART - p0;
       float acc = 0.0f;
       for (int q = 0; q < qpk; ++q) {
@@ -867,7 +926,11 @@ __global__ __launch_bounds__(256) void paged_attention_metric_rescale_kernel(Att
         if (fuse) acc = metric_term(acc, v, a.use_l2);
         else a.kv_metric_out[slot * qpk + q] = v;
       }
-      if (fuse) a.fused_metrics[slot] = __fadd_rn(a.fused_metrics[slot], acc);
+      if (fuse) {
+        const float mn = __fadd_rn(a.fused_metrics[slot], acc);
+        a.fused_metrics[slot] = mn;
+        if (hc.pivot) harvest_key(a, hc, slot, mn, kpos);
+      }
     }
   }
 }

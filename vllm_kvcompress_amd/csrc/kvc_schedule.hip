@@ -209,6 +209,40 @@ extern "C" int32_t kvc_harvest_eligible(const kvc_schedule_params* p, int32_t nu
   if (p == nullptr || num_queries_per_kv < 1) return 0;
   return harvest_plan(*p) ? 1 : 0;
 }
+namespace kvc {
+__global__ __launch_bounds__(256) void harvest_seen_seq_kernel(const int32_t* __restrict__ seq_positions,
+                                                               const int32_t* __restrict__ num_protected, int B,
+                                                               int32_t* __restrict__ seen) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < B) { seen[2 * i] = seq_positions[i]; seen[2 * i + 1] = num_protected[i]; }
+}
+}  // namespace kvc
+
+// harvest in the decode attention's fused-metric epilogue (kvc_attention_kernels.h): the position-lazy form only
+// (the epilogue makes a key from the sum alone and does not count the masked slots of a head)
+extern "C" int32_t kvc_attention_harvest_eligible(const kvc_schedule_params* p) {
+  if (p == nullptr) return 0;
+  return (harvest_plan(*p) && lazy_plan(*p)) ? 1 : 0;
+}
+extern "C" int kvc_attention_harvest_begin(const kvc_schedule_params* pp, kvc_stream_t stream) {
+  using namespace kvc;
+  if (pp == nullptr) return fail_invalid("attention_harvest_begin: null argument");
+  const kvc_schedule_params& p = *pp;
+  if (p.harvest_buf == nullptr || (reinterpret_cast<uintptr_t>(p.harvest_buf) & 15) != 0)
+    return fail_invalid("attention_harvest_begin: harvest_buf must be a 16-byte aligned buffer of kvc_harvest_buffer_bytes()");
+  if (!kvc_attention_harvest_eligible(pp))
+    return fail_invalid("attention_harvest_begin: the call that follows is not eligible (kvc_attention_harvest_eligible)");
+  const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
+  const HvLayout hl = hv_layout(G, p.num_seqs);
+  uint8_t* hb = reinterpret_cast<uint8_t*>(p.harvest_buf);
+  hipStream_t s = (hipStream_t)stream;
+  fill32_async(hb + hl.claimed, 0u, hl.rec64 - hl.claimed, s);                          // claimed | cnt | def
+  fill32_async(hb + hl.seen_ctx, 0xFFFFFFFFu, hl.seen_seq - hl.seen_ctx, s);           // no head has been walked yet
+  hipLaunchKernelGGL(harvest_seen_seq_kernel, dim3((p.num_seqs + 255) / 256), dim3(256), 0, s, p.seq_positions, p.num_protected,
+                     p.num_seqs, reinterpret_cast<int32_t*>(hb + hl.seen_seq));
+  return check_launch("attention_harvest_begin");
+}
+
 // pivot memory (harvest bits 1 and 2 without bit 0) needs no more than the small-eviction schedule itself:
 // whatever its collecting pass streams, its lists are all the evictable keys below the pivots
 extern "C" int32_t kvc_pivot_memory_eligible(const kvc_schedule_params* p) {
@@ -421,6 +455,8 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   ws.blist = reinterpret_cast<uint32_t*>(wb + l.blist);
   ws.bthr = reinterpret_cast<uint32_t*>(wb + l.bthr);
   ws.gate = nullptr;
+  ws.hv_seen_ctx = nullptr;
+  ws.hv_seen_seq = nullptr;
   if (p.total_slots == 0) {
     fill32_async(p.evicted_kv_count, 0u, (size_t)G * 4, s);
     fill32_async(p.evicted_block_count, 0u, (size_t)G * 4, s);
@@ -477,6 +513,11 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
         ws.st_cnt = reinterpret_cast<uint32_t*>(hb + hl.cnt);
         ws.st_def = reinterpret_cast<uint32_t*>(hb + hl.def);
         ws.rec64 = reinterpret_cast<uint64_t*>(hb + hl.rec64);
+        if (p.harvest & 8) {                         // made by the attention's epilogue: verified against this call's batch
+          if (!lazy) return fail_invalid("schedule_evictions: lists made by the attention's epilogue need the position-lazy form");
+          ws.hv_seen_ctx = reinterpret_cast<const int32_t*>(hb + hl.seen_ctx);
+          ws.hv_seen_seq = reinterpret_cast<const int32_t*>(hb + hl.seen_seq);
+        }
       }
     }
     const float hv_widen = p.harvest_widen > 0.0f ? p.harvest_widen : 0.25f;

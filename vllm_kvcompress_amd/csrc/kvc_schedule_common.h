@@ -2,6 +2,7 @@
 // (one translation unit: included by kvc_schedule.hip in this order; see the overview there)
 #pragma once
 #include "kvc_common.h"
+#include "kvc_harvest_layout.h"
 #include "../../include/kvc_mi355x.h"
 
 namespace kvc {
@@ -38,9 +39,10 @@ struct SchedWs {
   uint32_t* fallback;    // [1]      != 0: the small-eviction schedule could not finish exactly
   uint32_t* bar;         // [32+64]  single-launch fallback: phase stamps, then claim / done counters of its phases
   const uint32_t* gate;  // general-path kernels run only if gate == nullptr or *gate != 0
+  const int32_t* hv_seen_ctx;   // [G] lists made by the attention's epilogue: the context length every head's list was made
+  const int32_t* hv_seen_seq;   // [2B] with, every sequence's (position, protected window) -- or nullptr: nothing to verify
 };
 
-constexpr int KREC = 256;   // record length of the small-eviction schedule (keys per head)
 
 __device__ __forceinline__ bool gated_off(const SchedWs& ws) { return ws.gate != nullptr && *ws.gate == 0u; }
 

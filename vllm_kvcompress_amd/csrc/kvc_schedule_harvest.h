@@ -43,19 +43,7 @@ namespace kvc {
 // to the rows' lanes by shuffles; U = 8 rows are in flight at a time (a wave's 64 blocks are
 // contiguous: the TILE form of csrc/kvc_aggregate.hip).  STREAM: a store several times the
 // Infinity Cache (>= 1 GiB of metrics) has its metrics loaded and stored non-temporally, as there.
-struct HvLayout { size_t pivot, claimed, cnt, def, rec64, total; };
-inline HvLayout hv_layout(int32_t G, int32_t B) {
-  auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-  HvLayout l;
-  size_t o = 256;                                    // (header: reserved)
-  l.pivot = o;    o = up(o + (size_t)B * 4);
-  l.claimed = o;  o = up(o + (size_t)CLAIM_SHARDS * 128);   // claimed | cnt | def: one fill per harvest
-  l.cnt = o;      o = up(o + (size_t)G * 4);
-  l.def = o;      o = up(o + (size_t)G * 4);
-  l.rec64 = o;    o = up(o + (size_t)G * KREC * 8);
-  l.total = o;
-  return l;
-}
+// (the buffer's layout: kvc_harvest_layout.h)
 
 // QV = qpk / 4 (qpk 4 or 8: the temp row as 16-byte loads), or 0: any qpk, the row as scalar loads summed while they
 // arrive (the generic loop of aggregate_decode_kernel: the same additions in the same order).

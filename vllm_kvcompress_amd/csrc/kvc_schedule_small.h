@@ -59,7 +59,6 @@ __device__ void wave_bitonic_sort(T* a) {
 }
 
 struct SeqRec { int32_t seq_pos, prot; uint32_t pivot_excl, pad; };   // candidates: key < pivot_excl
-constexpr int CLAIM_SHARDS = 64;     // counters of claimed blocks, 128 B apart
 
 __device__ __forceinline__ uint32_t strat_hash(uint32_t g, uint32_t j) {
   uint32_t x = (g * 0x9E3779B1u) ^ ((j + 0x7F4A7C15u) * 0x85EBCA77u);
@@ -556,6 +555,12 @@ __global__ __launch_bounds__(64 * WAVES) void stream_records_kernel(kvc_schedule
     const uint32_t c = wave_reduce_sum(ws.st_claimed[lane * 32]);
     static_assert(CLAIM_SHARDS == WAVE, "one shard per lane");
     if (lane == 0 && (int64_t)c != p.total_slots / bs) atomicOr(ws.fallback, 1u);
+    if (ws.hv_seen_seq != nullptr) {                 // lists that carry what they were made with (harvest bit 3)
+      bool bad = false;
+      for (int i = lane; i < B; i += WAVE)
+        bad |= ws.hv_seen_seq[2 * i] != p.seq_positions[i] || ws.hv_seen_seq[2 * i + 1] != p.num_protected[i];
+      if (__ballot(bad) && lane == 0) atomicOr(ws.fallback, 1u);
+    }
   }
   // lane q < HPW looks after head g0 + q: finite keys -> finite-threshold chunks of the head
   uint32_t myC = 0;
@@ -565,6 +570,7 @@ __global__ __launch_bounds__(64 * WAVES) void stream_records_kernel(kvc_schedule
     const int ctx = p.context_lens[(l * B + i_seq) * H + h];
     const uint32_t nblk = (uint32_t)((ctx + bs - 1) / bs);
     myC = ws.st_cnt[g];
+    if (ws.hv_seen_ctx != nullptr && ws.hv_seen_ctx[g] != ctx) atomicOr(ws.fallback, 1u);   // another batch's list
     if (!lazy) {                                     // (lazy: nobody counted the masked slots, nobody needs them)
       const uint32_t F = nblk * (uint32_t)bs - ws.st_def[g];
       ws.head_fc[g] = nchunks_freed(F, (uint32_t)p.hanging_token_count[g], (uint32_t)bs);   // finite-threshold chunks

@@ -60,6 +60,26 @@ def _load_kv_head_bias(path: str) -> KVHeadBias:
     raise ValueError(f"Unsupported file format {ext}")
 
 
+class AttentionHarvest:
+    """What ``CompressionMetrics.begin_attention_harvest`` hands to the L attention launches of a decode step
+    (``_custom_ops.paged_attention_kvc_fused_metrics(..., harvest=h, layer=l)``): the harvest buffer with the pivots
+    of the last schedule call, the compression batch the lists are made for, and which layers have run."""
+
+    def __init__(self, cm, buf, seq_slot, seq_positions, num_protected, num_seqs, stream, record):
+        self.cm, self.buf, self.seq_slot = cm, buf, seq_slot
+        self.seq_positions, self.num_protected = seq_positions, num_protected
+        self.num_seqs, self.num_layers, self.num_kv_heads = num_seqs, cm.num_layers, cm.num_kv_heads
+        self.block_size, self.num_sinks = cm.block_size, int(cm.num_sinks)
+        self.stream, self.record = stream, record
+        self.layers_done = set()
+
+    def check_call(self, query, num_kv_heads, block_size, layer, stream) -> None:
+        if (num_kv_heads != self.num_kv_heads or block_size != self.block_size or not 0 <= layer < self.num_layers
+                or stream != self.stream or int(query.shape[0]) != int(self.seq_slot.numel())):
+            raise RuntimeError("paged_attention_kvc_fused_metrics: this call does not belong to the harvest it was given "
+                               "(KV heads / block size / layer / stream / number of sequences differ from begin_attention_harvest's)")
+
+
 class CompressionMetrics:
     """reference metrics.py:94-975"""
 
@@ -195,6 +215,7 @@ class CompressionMetrics:
         self._hv_buf = None                # pivots + lists (kvc_harvest_buffer_bytes)
         self._hv = None                    # pivots in _hv_buf: the batch and eviction sizes they were made for
         self._hv_lists = None              # lists in _hv_buf: the call they were made for
+        self._hv_attention = None          # the handle of begin_attention_harvest while the step's attention runs
 
     # temp_metrics is handed to the attention kernels, which write into it; reading the
     # attribute therefore marks it dirty so that the fused clear in aggregate_decode stays
@@ -451,11 +472,95 @@ class CompressionMetrics:
                               stream=stream, buf=self._hv_buf)
         return True
 
+    def begin_attention_harvest(self, seq_indices: List[int], seq_positions: IntsLike, num_protected: IntsLike,
+                                context_lens: torch.Tensor, attention_seq_indices: Optional[List[int]] = None,
+                                total_slots: Optional[int] = None) -> Optional[AttentionHarvest]:
+        """The decode step WITHOUT a sweep of the metric store (the reference author's to-do,
+        vllm/kvcompress/README.md:32, 49): the fused-metric attention adds a step's weights straight into ``metrics``
+        (``_custom_ops.paged_attention_kvc_fused_metrics``: no temp_metrics, no aggregate_decode) and -- given the
+        handle this method returns -- its epilogue also makes the candidate lists of the ``schedule_evictions(
+        seq_indices, seq_positions, ..., context_lens, ..., num_protected)`` that follows, with the pivots the
+        previous schedule call left behind: that call then runs records -> selection -> emission on the lists, and the
+        store is not streamed at all that step.
+
+            h = cm.begin_attention_harvest(slots, last_token_positions, protected, ctx, attention_seq_indices=...)
+            for l in range(L):      # the model's forward pass
+                ops.paged_attention_kvc_fused_metrics(out, cm.metrics, q[l], k_cache[l], v_cache[l], ..., harvest=h, layer=l)
+            cm.end_attention_harvest(h)
+            cm.schedule_evictions(slots, last_token_positions, evicted_blocks, ctx, hanging, offsets, protected)
+
+        ``seq_positions`` / ``context_lens`` are the SCHEDULE call's (the position of the token sampled this step, the
+        context lengths as they are after this step's append: what the fork's scheduler derives at the start of the
+        next iteration, scheduler.py:256-280).  ``attention_seq_indices``: the sequence index (``seq_index_by_block``
+        value) of every sequence of the attention batch, in its order; default: the compression batch itself.
+        Returns None -- and the caller runs the attention without ``harvest=`` -- when lists cannot be made: no pivots
+        yet (first step, another batch), a schedule that is not the small-eviction one in its position-lazy form
+        (use_average, a position bias, the reference's batch > 1 rule: their keys depend on more than the sum), under
+        stream capture, tensors without version counters.  Same contract as ``aggregate_decode_and_harvest``: the
+        lists are used only by a schedule call with these very arguments and an untouched store in between; anything
+        else, and lists that fall short, take the usual pass / are redone on the device.  Results are identical."""
+        if self.random or not self.record_decoding_metrics:
+            return None
+        if self.harvest_ahead is None:
+            self.harvest_ahead = True
+        capturing = torch.cuda.is_current_stream_capturing()
+        self._poll_fallback(capturing)
+        hv = self._hv
+        self._hv_lists = None
+        stream = _stream(self.metrics)
+        B = len(seq_indices)
+        ok = (self.harvest_ahead and self._hv_pause == 0 and hv is not None and hv["seqs"] == tuple(int(s) for s in seq_indices)
+              and hv["buf"] is self._hv_buf and hv["full"] and hv["stream"] == stream and not self._fb_fault
+              and not (self._fb_backoff > 0 and int(self.schedule_path) == 0)
+              and isinstance(context_lens, torch.Tensor) and context_lens.is_cuda and context_lens.dtype == torch.int32
+              and context_lens.is_contiguous()
+              and tuple(context_lens.shape) == (self.num_layers, B, self.num_kv_heads)
+              and not capturing and self._store_versions() is not None
+              and not any(isinstance(x, torch.Tensor) and x.is_inference() for x in (seq_positions, num_protected, context_lens)))
+        if not ok:
+            return None
+        lib = _lib.load()
+        seq_pos, prot = self._as_i32(seq_positions), self._as_i32(num_protected)
+        p = KvcScheduleParams()
+        self._store_params(p, seq_indices, seq_pos, prot, context_lens, int(total_slots) if total_slots else hv["N"])
+        p.max_evicted_blocks_hint = int(hv["k"].max())
+        p.schedule_path = int(self.schedule_path)
+        p.harvest_buf = self._hv_buf.data_ptr()
+        if not lib.kvc_attention_harvest_eligible(ctypes.byref(p)):
+            return None
+        att = list(seq_indices) if attention_seq_indices is None else [int(x) for x in attention_seq_indices]
+        pos_of = {int(s): i for i, s in enumerate(seq_indices)}
+        seq_slot = self._as_i32([pos_of.get(int(s), -1) for s in att])
+        with torch.cuda.device(self.device):
+            _lib.check(lib.kvc_attention_harvest_begin(ctypes.byref(p), stream))
+        record = dict(seqs=hv["seqs"], attention=True, k=hv["k"], stream=stream, buf=self._hv_buf)
+        self._hv_attention = AttentionHarvest(self, self._hv_buf, seq_slot, seq_pos, prot, B, stream, record)
+        return self._hv_attention
+
+    def end_attention_harvest(self, harvest: Optional[AttentionHarvest]) -> bool:
+        """Behind the last attention launch of the step: the lists belong to the schedule call that follows (see
+        ``begin_attention_harvest``).  Returns whether they will be offered to it -- not if a layer is missing, the
+        handle is not the one of the last ``begin_attention_harvest``, or the stream changed."""
+        ok = (harvest is not None and harvest is getattr(self, "_hv_attention", None) and harvest.cm is self
+              and harvest.layers_done == set(range(self.num_layers)) and harvest.buf is self._hv_buf
+              and harvest.stream == _stream(self.metrics))
+        self._hv_attention = None
+        if not ok:
+            self._hv_lists = None
+            return False
+        self._hv_lists = dict(harvest.record, store=self._store_versions())
+        return True
+
     def _lists_usable(self, hl, seq_indices, seq_positions, num_protected, context_lens, k_list, stream) -> bool:
+        # (lists made by the attention's epilogue carry the context lengths, positions and protected windows they were
+        # made with, and the schedule call checks them on the device -- the fork's scheduler builds these tensors anew
+        # for every call, scheduler.py:256-280; lists made by the aggregation pass are tied to the argument objects)
         return (hl is not None and hl["buf"] is self._hv_buf and hl["stream"] == stream
                 and hl["seqs"] == tuple(int(s) for s in seq_indices)
-                and self._arg_same(hl["seq_pos"], seq_positions) and self._arg_same(hl["prot"], num_protected)
-                and self._arg_same(hl["ctx"], context_lens) and hl["store"] is not None and hl["store"] == self._store_versions()
+                and (hl.get("attention", False)
+                     or (self._arg_same(hl["seq_pos"], seq_positions) and self._arg_same(hl["prot"], num_protected)
+                         and self._arg_same(hl["ctx"], context_lens)))
+                and hl["store"] is not None and hl["store"] == self._store_versions()
                 and self._k_within(k_list, hl["k"]))
 
     def _k_within(self, k_list, k_then) -> bool:
@@ -717,7 +822,7 @@ class CompressionMetrics:
             if self._hv_pause > 0:
                 self._hv_pause -= 1
             elif self._lists_usable(hl, seq_indices, seq_positions, num_protected, context_lens, k_list, stream):
-                p.harvest |= 1
+                p.harvest |= 9 if hl.get("attention", False) else 1
             elif (self.pivot_memory and hv is not None and hv["buf"] is self._hv_buf and hv["stream"] == stream
                   and hv["seqs"] == seqs_key and self._k_within(k_list, hv["k"])):
                 p.harvest |= 4
@@ -744,7 +849,8 @@ class CompressionMetrics:
             backoff=int(p.schedule_path) == 1 and int(self.schedule_path) != 1)
         if self.last_schedule[2] == 1:
             # ... and where the small-eviction schedule took its pivots / lists from
-            self.last_schedule_reason += (" [lists: the aggregation pass]" if p.harvest & 1 else
+            self.last_schedule_reason += (" [lists: the attention's epilogue]" if p.harvest & 8 else
+                                          " [lists: the aggregation pass]" if p.harvest & 1 else
                                           " [pivots: the call before]" if p.harvest & 4 else " [pivots: sampled]")
         if self.last_schedule[2] and self.strict_fallback and not capturing:
             off = self.last_schedule[1]
