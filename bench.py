@@ -947,6 +947,15 @@ def decode_step_compare(a2, st, ds, evicted, k_cache, v_cache, cmi, cmc, device,
     cm.metrics.copy_(m0)
     cm.num_queries_per_kv, cm._temp_metrics, cm.harvest_ahead = saved
     cm._hv = cm._hv_lists = None
+    if a2.mode == "per_sequence" and a2.block_size in (16, 32) and a2.head_size in (64, 128):
+        del wm, wp, keep
+        wm = wp = keep = None
+        out["fused_attention"] = decode_step_fused_attention(a2, st, ds, evicted, k_cache, v_cache, cmi, cmc, temp, m0, device,
+                                                            steps, warmup)
+        fa = out["fused_attention"]
+        if isinstance(fa.get("parity_checked"), dict) and fa["parity_checked"].get("bit_exact") is False:
+            parity["bit_exact"] = False
+            parity["fused_attention_mismatched"] = fa["parity_checked"].get("mismatched")
     out["saved_ms_per_step"] = out["two_sweeps"]["ms_per_step"] - out["harvest_ahead"]["ms_per_step"]
     out["what"] = ("S0 + S1 + S2 + S3 per decode step; num_queries_per_kv 4, aggregate_decode without the fused clear "
                    f"(24 B per slot over {slots} slots); {steps} steps after {warmup} warm-up steps")
@@ -954,6 +963,136 @@ def decode_step_compare(a2, st, ds, evicted, k_cache, v_cache, cmi, cmc, device,
     del temp, m0, wm, wp, keep
     torch.cuda.empty_cache()
     return out
+
+
+def decode_step_fused_attention(a2, st, ds, evicted, k_cache, v_cache, cmi, cmc, temp, m0, device, steps, warmup):
+    """The decode step WITHOUT a sweep of the metric store (the reference author's to-do, vllm/kvcompress/README.md:32, 49):
+    the L launches of the fused-metric decode attention add the step's weights straight into the store (no temp_metrics,
+    no aggregate_decode) and their epilogues make the candidate lists of the schedule call that follows
+    (CompressionMetrics.begin_attention_harvest; include/kvc_mi355x.h ABI version 6) -- S1 then runs on lists, S0 does not
+    exist.  Timed: the attention of one step in three forms (weights to temp_metrics as the reference's kernel writes
+    them | fused into the store | fused + harvest) and S1 + S2 + S3 behind the third.  K / V are overwritten with N(0, 0.5)
+    values (the timed workload's caches hold random bits: NaNs) and the store is scaled so that a step's attention moves
+    a key near the pivot by about as many ranks as the synthetic mass of the other variants does (sum_q p^2 of a
+    softmax over 4 k keys is ~2.4e-7; the stores of this file are permutations of 0 .. slots-per-sequence)."""
+    import gc
+    import torch
+    from vllm_kvcompress_amd import _custom_ops as ops
+    cm = ds.cm
+    L, H, bs, hd, qpk, B, N = st.num_layers, st.num_kv_heads, st.block_size, a2.head_size, 4, st.num_seqs, st.total_slots
+    if k_cache.element_size() != 2:
+        return {"skipped": "fp16 caches only"}
+    try:
+        k_cache.normal_(0.0, 0.5)
+        v_cache.normal_(0.0, 0.5)
+        q = [(torch.randn((B, H * qpk, hd), device=device) * 0.8).to(torch.float16) for _ in range(2)]
+        outb = torch.empty_like(q[0])
+        bt = [ds.block_tables[l].contiguous() for l in range(L)]
+        ctx = [ds.context_lens[l].contiguous() for l in range(L)]
+        wm, wp = cm.metrics.clone(), cm.token_positions.clone()
+    except torch.OutOfMemoryError:
+        torch.cuda.empty_cache()
+        return {"skipped": "does not fit"}
+    scale_store = 1.0e-7
+    last = ds.seq_positions - 1                            # the token being processed (the schedule call's position - 1)
+    buf = torch.zeros((B,), dtype=torch.int32, device=device)
+    max_ctx = int(ds.context_lens.max().item())
+    seq_idx, prot = list(st.seq_indices), list(st.protected)
+    saved = (cm.num_queries_per_kv, cm._temp_metrics, cm.harvest_ahead)
+    cm.num_queries_per_kv, cm._temp_metrics, cm.harvest_ahead = qpk, temp, True
+    cm._hv = cm._hv_lists = None
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+
+    def attention(form, h=None):
+        for l in range(L):
+            args = (q[l & 1], k_cache, v_cache, H, hd ** -0.5, bt[l], ctx[l], cm.token_positions, last, buf, bs, max_ctx, None,
+                    "auto", 1.0, 1.0)
+            if form == "record":
+                ops.paged_attention_kvc_v1(outb, temp, *args, True)
+            else:
+                ops.paged_attention_kvc_fused_metrics(outb, cm.metrics, *args, use_l2=True, temp_metrics=temp, harvest=h, layer=l)
+
+    res = {}
+    # ---- the attention alone, three forms
+    forms = {}
+    for form in ("record", "fused", "fused_harvest"):
+        cm.metrics.copy_(m0).mul_(scale_store)
+        cm.schedule_evictions(seq_idx, ds.seq_positions, evicted, ds.context_lens, ds.hanging_token_count,
+                              ds.evicted_kv_offsets, prot, total_slots=N)         # (leaves the pivots)
+        n = 4
+        marks = [[ev(), ev()] for _ in range(n)]
+        for i in range(-1, n):
+            h = None
+            if form == "fused_harvest":
+                h = cm.begin_attention_harvest(seq_idx, ds.seq_positions, prot, ds.context_lens, total_slots=N)
+                if h is None:
+                    break
+            if i >= 0: marks[i][0].record()
+            attention(form, h)
+            if i >= 0: marks[i][1].record()
+            if h is not None:
+                cm.end_attention_harvest(h)
+        torch.cuda.synchronize()
+        if form == "fused_harvest" and h is None:
+            forms[form] = None
+        else:
+            forms[form] = sum(a.elapsed_time(b) for a, b in marks) / n
+    res["attention_ms_per_step"] = forms
+    kv_bytes = float(sum(int(c.sum().item()) for c in ctx)) * 2 * hd * 2
+    res["attention_GBps_kv_only"] = {k: (kv_bytes / (v * 1e-3) / 1e9 if v else None) for k, v in forms.items()}
+    if forms["fused_harvest"] and forms["record"]:
+        res["harvest_cost_vs_record_kv_metrics"] = forms["fused_harvest"] / forms["record"] - 1.0
+    # ---- the whole step
+    cm.metrics.copy_(m0).mul_(scale_store)
+    cm._hv = cm._hv_lists = None
+    misses0, used = cm.harvest_misses, 0
+    marks = [[ev() for _ in range(5)] for _ in range(steps)]
+    gc.collect()
+    gc.disable()
+    eli = ekc = ebc = None
+    for i in range(-warmup, steps):
+        rec = i >= 0
+        del eli, ekc, ebc
+        h = cm.begin_attention_harvest(seq_idx, ds.seq_positions, prot, ds.context_lens, total_slots=N)
+        if rec: marks[i][0].record()
+        attention("fused_harvest", h)
+        if rec: marks[i][1].record()
+        cm.end_attention_harvest(h)
+        eli, ekc, ebc = cm.schedule_evictions(seq_idx, ds.seq_positions, evicted, ds.context_lens,
+                                              ds.hanging_token_count, ds.evicted_kv_offsets, prot, total_slots=N)
+        used += int(rec and cm.last_harvest_used)
+        if rec: marks[i][2].record()
+        ops.schedule_cache_moves(cmi, cmc, eli, ekc, ds.evicted_kv_offsets, ds.block_tables, ds.context_lens, bs)
+        if rec: marks[i][3].record()
+        ops.execute_cache_moves(k_cache, v_cache, wm, wp, cmi, cmc, ds.evicted_kv_offsets, 1, 16)
+        if rec: marks[i][4].record()
+    torch.cuda.synchronize()
+    gc.enable()
+    ms = lambda a, b: sum(m[a].elapsed_time(m[b]) for m in marks) / steps
+    res.update({
+        "ms_per_step_without_attention": ms(1, 4),
+        "stages_ms": {"attention_L_launches": ms(0, 1), "S0_aggregate_decode": 0.0, "S1_schedule_evictions": ms(1, 2),
+                      "S2_schedule_moves": ms(2, 3), "S3_execute_moves": ms(3, 4)},
+        "S1_schedule": cm.last_schedule_path(), "S1_schedule_reason": cm.last_schedule_reason,
+        "steps_on_the_epilogues_lists": used, "harvest_misses": cm.harvest_misses - misses0,
+        "what": f"{L} launches of paged_attention_kvc_fused_metrics(harvest=) per step over {B} sequences (qpk 4, hd {hd}, "
+                f"contexts of {max_ctx}), then S1 + S2 + S3; no aggregate_decode launch, no collecting pass; {steps} steps after "
+                f"{warmup} warm-up steps"})
+    # the oracle on the final state
+    import copy as _copy
+    st2 = _copy.copy(st)
+    st2.metrics = cm.metrics.cpu().numpy()
+    parity = parity_gate_sampled(a2, st2, evicted, dict(eli=eli, ekc=ekc, ebc=ebc, cmi=cmi, cmc=cmc), k_cache, v_cache,
+                                 None, None, schedule_only=True, mode=a2.mode)
+    parity["what"] = ("the last step's schedule (run on the lists the attention's epilogues made) against the oracle's schedule "
+                      "of the store the attention left, on a sample of the sequences; the sums themselves and an evolving "
+                      "400-step soak against the reference flow: tests/test_gpu_attention_harvest.py, tools/soak_attention_harvest.py")
+    res["parity_checked"] = parity
+    cm.metrics.copy_(m0)
+    cm.num_queries_per_kv, cm._temp_metrics, cm.harvest_ahead = saved
+    cm._hv = cm._hv_lists = None
+    del wm, wp, q, outb
+    return res
 
 
 def engine_sized_cache_run(args, rank, device, steps=20, warmup=3):

@@ -21,7 +21,7 @@ def main():
         raise SystemExit("does not fit")
     print(json.dumps({"stages_ms": res["stages_ms"], "S1_schedule": res["S1_schedule"], "candidate_slots": res["candidate_slots"],
                       "S1_sampled_pivots": res.get("S1_sampled_pivots"), "S1_schedule_reason": res.get("S1_schedule_reason"),
-                      "decode_step": res.get("decode_step")}))
+                      "S1_call_forms": res.get("S1_call_forms"), "decode_step": res.get("decode_step")}))
 
 
 if __name__ == "__main__":

@@ -539,6 +539,10 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
   constexpr int X = KF::X;
   const int32_t* bt = a.block_tables + (int64_t)(seq * a.num_kv_heads + hk) * a.max_blocks;
   const int head0 = hk * qpk + q0;
+  // (what the metric epilogue needs from memory is requested here, a whole kernel ahead of its use)
+  const int max_pos = a.record ? a.last_position[seq] - a.kv_metric_buffer_len[seq] : 0;
+  const HarvestCtx hc = (a.record && a.fused_metrics != nullptr)
+                            ? harvest_ctx(a, seq, hk, max_pos, ctx, BS, tid == 0 && q0 == 0) : HarvestCtx{0u, -1, 0};
   float* P = lds;                                          // [nqr][prow]
   float* Ol = lds + (int64_t)nqr * prow;                   // [4][nqr][HD]
   float* mrec = Ol + (int64_t)4 * nqr * HD;                // [niter_max][NW][16]
@@ -727,7 +731,6 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
 
   // ---- metrics: p = p~ * exp(m_used - M) / (L + 1e-6), one lane per token, written once
   if (a.record) {
-    const int max_pos = a.last_position[seq] - a.kv_metric_buffer_len[seq];
     // per query: global max M and normaliser 1 / (L + 1e-6), once per workgroup, then per wave
     // and iteration the factor exp(m_used - M) / (L + 1e-6) of each query head
     __shared__ float fin_m[ATT_NQ], fin_i[ATT_NQ], wfac[NW][ATT_NQ];
@@ -742,7 +745,57 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
     }
     __syncthreads();
     const bool fuse = a.fused_metrics != nullptr;
-    const HarvestCtx hc = fuse ? harvest_ctx(a, seq, hk, max_pos, ctx, BS, tid == 0 && q0 == 0) : HarvestCtx{0u, -1, 0};
+    if (fuse) {
+      // metrics[slot] += sum_q p^2 is a read-modify-write: with one token after the other every store stands between
+      // the loads behind it (the compiler cannot tell that slots differ) and a wave pays a full memory round trip per
+      // 64 tokens -- measured 6 % of the whole kernel at 256 x 4k contexts.  The block-table entries, positions and
+      // old sums of GI iterations are requested together, before anything is stored.
+      constexpr int GI = 4, K2 = ATT_CHUNK / 64;
+      for (int it0 = 0; it0 < niter; it0 += GI) {
+        if (it0 * STEP + w * ATT_CHUNK >= ctx) break;
+        int64_t slot[GI][K2];
+        int kpos[GI][K2];
+        float mold[GI][K2];
+#pragma unroll
+        for (int j = 0; j < GI; ++j)
+#pragma unroll
+          for (int k = 0; k < K2; ++k) {
+            const int tok = (it0 + j) * STEP + w * ATT_CHUNK + k * 64 + lane;
+            slot[j][k] = (it0 + j < niter && tok < ctx) ? (int64_t)bt[tok / BS] * BS + (tok % BS) : (int64_t)-1;
+          }
+#pragma unroll
+        for (int j = 0; j < GI; ++j)
+#pragma unroll
+          for (int k = 0; k < K2; ++k) kpos[j][k] = slot[j][k] >= 0 ? a.kv_position[slot[j][k]] : 0x7FFFFFFF;
+#pragma unroll
+        for (int j = 0; j < GI; ++j)
+#pragma unroll
+          for (int k = 0; k < K2; ++k) mold[j][k] = kpos[j][k] <= max_pos ? a.fused_metrics[slot[j][k]] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < GI; ++j) {
+          const int it = it0 + j;
+          const int tok_w0 = it * STEP + w * ATT_CHUNK;
+          if (it >= niter || tok_w0 >= ctx) break;
+          const float* mr = mrec + (it * NW + w) * ATT_NQ;
+          if (lane < nq) wfac[w][lane] = __expf(mr[lane] - fin_m[lane]) * fin_i[lane];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          const float* fq = wfac[w];
+#pragma unroll
+          for (int k = 0; k < K2; ++k) {
+            if (kpos[j][k] > max_pos) continue;              // (also: token >= ctx)
+            const int tok = tok_w0 + k * 64 + lane;
+            float acc = 0.0f;
+            for (int q = 0; q < nq; ++q) acc = metric_term(acc, __fmul_rn(P[q * prow + tok], fq[q]), a.use_l2);
+            const float mn = __fadd_rn(mold[j][k], acc);
+            a.fused_metrics[slot[j][k]] = mn;
+            if (hc.pivot) harvest_key(a, hc, slot[j][k], mn, kpos[j][k]);
+          }
+          __builtin_amdgcn_wave_barrier();             // wfac[w] is rewritten by the next iteration
+        }
+      }
+      return;
+    }
     for (int it = 0; it < niter; ++it) {
       const int tok_w0 = it * STEP + w * ATT_CHUNK;
       if (tok_w0 >= ctx) break;
@@ -758,7 +811,7 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
         const int64_t slot = (int64_t)bt[tok / BS] * BS + (tok % BS);
         const int kpos = a.kv_position[slot];
         if (kpos > max_pos) continue;
-        put_metric_row(a, a.kv_metric_out, fuse, slot, qpk, q0, nq,
+        put_metric_row(a, a.kv_metric_out, false, slot, qpk, q0, nq,
                        [&](int q) { return __fmul_rn(P[q * prow + tok], fq[q]); }, hc, kpos);
       }
       __builtin_amdgcn_wave_barrier();               // wfac[w] is rewritten by the next iteration
@@ -886,6 +939,9 @@ __global__ __launch_bounds__(256) void paged_attention_metric_rescale_kernel(Att
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) posv[k] = ok[k] ? a.kv_position[slot[k]] : 0x7FFFFFFF;
+    float mold[K];                                     // (fuse: the old sums, requested with the weights -- see the single-pass kernel)
+#pragma unroll
+    for (int k = 0; k < K; ++k) mold[k] = (fuse && ok[k] && posv[k] <= max_pos) ? a.fused_metrics[slot[k]] : 0.0f;
     for (int qb = 0; qb < qpk; qb += 4) {
       f32x4 t[K];
 #pragma unroll
@@ -904,7 +960,7 @@ __global__ __launch_bounds__(256) void paged_attention_metric_rescale_kernel(Att
           float acc = 0.0f;
 #pragma unroll
           for (int q = 0; q < 4; ++q) acc = metric_term(acc, v[q], a.use_l2);
-          const float mn = __fadd_rn(a.fused_metrics[slot[k]], acc);
+          const float mn = __fadd_rn(mold[k], acc);
           a.fused_metrics[slot[k]] = mn;
           if (hc.pivot) harvest_key(a, hc, slot[k], mn, posv[k]);
         } else {
