@@ -28,6 +28,7 @@
 #include "kvc_common.h"
 #include "../../include/kvc_mi355x.h"
 #include <atomic>
+#include <cstdlib>
 
 // The device code lives in five headers, included here in dependency order (ONE translation unit: the
 // single-launch fallback calls the bodies of every section, and HIP has no cross-module device calls
@@ -36,6 +37,7 @@
 //   kvc_schedule_general.h   sections 0-6: keys, digit rounds, scan + pick, select + emit
 //   kvc_schedule_small.h     section 7: the small-eviction schedule (sample, pivot, collect, records, select, emit)
 //   kvc_schedule_harvest.h   section 10: aggregate_decode that harvests section 7's candidate lists on its way
+//   kvc_schedule_fused.h     section 7b: records + selection + emission + next pivots of section 7 as one launch
 //   kvc_schedule_bracket.h   section 9: the bracket schedule (bracket, count + collect, records, select)
 //   kvc_schedule_fallback.h  section 8: the general pipeline as one gated launch, phases ordered by work counters
 // This file: the host side -- workspace layout, which schedule a call takes (and why), the launches.
@@ -43,6 +45,7 @@
 #include "kvc_schedule_general.h"
 #include "kvc_schedule_small.h"
 #include "kvc_schedule_harvest.h"
+#include "kvc_schedule_fused.h"
 #include "kvc_schedule_bracket.h"
 #include "kvc_schedule_fallback.h"
 
@@ -566,22 +569,49 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
       else { KVC_COLLECT(32); }
 #undef KVC_COLLECT
     }
-    hipLaunchKernelGGL((stream_records_kernel<4, 4>), dim3((G + 15) / 16), dim3(256), 0, s, p, ws, lazy ? 1 : 0);
     const int coupled_tk = (p.mode == 0 && B > 1) ? 1 : (lazy ? 2 : 0);
-    if (coupled_tk == 1) {
-      hipLaunchKernelGGL(seq_sums_topk_kernel, dim3(B), dim3(256), 0, s, p, ws);
-      hipLaunchKernelGGL(seq_prepare_kernel, dim3(1), dim3(1024), prep_lds, s, p, ws);
+    // records + selection + emission as ONE launch (section 7b) where the sequences do not need each other's counts
+    // and a sequence's heads fit one workgroup's waves; KVC_TOPK_CHAIN=1 keeps the launch chain (tests compare the two)
+    static const bool chain_env = [] { const char* e = getenv("KVC_TOPK_CHAIN"); return e != nullptr && e[0] != '\0' && e[0] != '0'; }();
+    const bool fused_tk = coupled_tk != 1 && LH <= 256 && topk_p2 <= 8192 && !chain_env;
+    if (fused_tk) {
+      if (side != nullptr && hipStreamWaitEvent(s, side->join, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(side->s2);        // (the emission must not race the fill)
+        side->failed = true;
+      }
+      const int hpw = LH <= 64 ? 4 : 16;
+      const size_t fl = (size_t)topk_p2 * 8 + (size_t)16 * hpw * 4;
+      static std::atomic<uint64_t> f4_done{0}, f16_done{0};
+      if (hpw == 4) {
+        allow_dynamic_lds(reinterpret_cast<const void*>(topk_fused_kernel<4, false>), 100 * 1024, f4_done);
+        hipLaunchKernelGGL((topk_fused_kernel<4, false>), dim3(B), dim3(1024), fl, s, p, ws, topk_p2, lazy ? 1 : 0, coupled_tk,
+                           hv_pivot != nullptr ? 1 : 0, nullptr, 0, 0.0f);
+      } else {
+        allow_dynamic_lds(reinterpret_cast<const void*>(topk_fused_kernel<16, false>), 100 * 1024, f16_done);
+        hipLaunchKernelGGL((topk_fused_kernel<16, false>), dim3(B), dim3(1024), fl, s, p, ws, topk_p2, lazy ? 1 : 0, coupled_tk,
+                           hv_pivot != nullptr ? 1 : 0, nullptr, 0, 0.0f);
+      }
+      // the pivots for the next decode step's harvest, from what is left of this call's lists (section 10)
+      if (hv_pivot != nullptr)
+        hipLaunchKernelGGL(harvest_pivot_kernel, dim3(B), dim3(1024), 0, s, p, ws, hv_pivot, (harvested || remembered) ? 1 : 0, hv_widen);
+    } else {
+      hipLaunchKernelGGL((stream_records_kernel<4, 4>), dim3((G + 15) / 16), dim3(256), 0, s, p, ws, lazy ? 1 : 0);
+      if (coupled_tk == 1) {
+        hipLaunchKernelGGL(seq_sums_topk_kernel, dim3(B), dim3(256), 0, s, p, ws);
+        hipLaunchKernelGGL(seq_prepare_kernel, dim3(1), dim3(1024), prep_lds, s, p, ws);
+      }
+      hipLaunchKernelGGL(seq_select_topk_kernel, dim3(B), dim3(1024), (size_t)topk_p2 * 8 + (size_t)LH * 4, s, p, ws, topk_p2, coupled_tk);
+      // the pivots for the next decode step's harvest, from what is left of this call's lists (section 10)
+      if (hv_pivot != nullptr)
+        hipLaunchKernelGGL(harvest_pivot_kernel, dim3(B), dim3(1024), 0, s, p, ws, hv_pivot, (harvested || remembered) ? 1 : 0, hv_widen);
+      if (side != nullptr && hipStreamWaitEvent(s, side->join, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(side->s2);          // (the emission below must not race the fill)
+        side->failed = true;
+      }
+      hipLaunchKernelGGL(emit_topk_kernel<4>, dim3((G + 3) / 4), dim3(256), 0, s, p, ws);
     }
-    hipLaunchKernelGGL(seq_select_topk_kernel, dim3(B), dim3(1024), (size_t)topk_p2 * 8 + (size_t)LH * 4, s, p, ws, topk_p2, coupled_tk);
-    // the pivots for the next decode step's harvest, from what is left of this call's lists (section 10)
-    if (hv_pivot != nullptr)
-      hipLaunchKernelGGL(harvest_pivot_kernel, dim3(B), dim3(1024), 0, s, p, ws, hv_pivot, (harvested || remembered) ? 1 : 0, hv_widen);
-    if (side != nullptr && hipStreamWaitEvent(s, side->join, 0) != hipSuccess) {
-      (void)hipGetLastError();
-      (void)hipStreamSynchronize(side->s2);          // (the emission below must not race the fill)
-      side->failed = true;
-    }
-    hipLaunchKernelGGL(emit_topk_kernel<4>, dim3((G + 3) / 4), dim3(256), 0, s, p, ws);
     ws.gate = ws.fallback;
   }
   if (topk && !(p.mode == 0 && B > kvc::FB_MAX_COUPLED)) {

@@ -125,6 +125,35 @@ __device__ __forceinline__ void eli_dirty_update(uint32_t* map, int32_t* eli, in
   }
 }
 
+// eli_dirty_update for an owner of at most 64 map words whose words were loaded beforehand (lane t: word
+// (c0 >> 5) + t, `old_word`; topk_fused_kernel requests the words of all its heads together): the same result
+__device__ __forceinline__ void eli_dirty_apply(uint32_t* map, int32_t* eli, int32_t c0, int32_t c1, int32_t new_chunks,
+                                                int32_t keep_from, int bs_shift, int32_t null_value, uint32_t old_word, int lane) {
+  const int32_t w0 = c0 >> 5, w1 = (c1 - 1) >> 5;
+  const int32_t w = w0 + lane;
+  if (w > w1) return;
+  const int32_t cn = c0 + new_chunks;
+  const int32_t lo = max(c0, w << 5), hi = min(c1, (w + 1) << 5);
+  const uint32_t mask = (hi - lo >= 32) ? 0xFFFFFFFFu : (((1u << (hi - lo)) - 1u) << (lo & 31));
+  const int32_t nh = min(hi, cn);
+  const uint32_t fresh = nh > lo ? ((nh - lo >= 32) ? 0xFFFFFFFFu : (((1u << (nh - lo)) - 1u) << (lo & 31))) : 0u;
+  uint32_t old;
+  if (mask == 0xFFFFFFFFu) {
+    old = old_word;
+    if (old != fresh) map[w] = fresh;
+  } else {
+    old = old_word & mask;
+    if (old & ~fresh) atomicAnd(&map[w], ~(old & ~fresh));
+    if (fresh & ~old) atomicOr(&map[w], fresh & ~old);
+  }
+  while (old) {
+    const int bit = __ffs((int)old) - 1;
+    old &= old - 1u;
+    const int32_t eb = max(((w << 5) + bit) << bs_shift, keep_from), ee = (((w << 5) + bit) + 1) << bs_shift;
+    for (int32_t e = eb; e < ee; ++e) eli[e] = null_value;
+  }
+}
+
 // Fills (`bytes` a multiple of 4, `dst` 4-byte aligned) as KERNEL launches, not hipMemsetAsync: on
 // ROCm 7.2 a memset node recorded into a HIP graph fills its range on the first replay only (later
 // replays leave it partly or wholly untouched: measured, tests/test_gpu_configs.py replays the

@@ -1,0 +1,386 @@
+// kvc_schedule_fused.h -- A3: records + selection + emission (+ the next pivots) of the small-eviction schedule in ONE launch
+// (one translation unit: included by kvc_schedule.hip behind kvc_schedule_harvest.h; see the overview there)
+#pragma once
+#include "kvc_common.h"
+#include "kvc_schedule_common.h"
+#include "kvc_schedule_general.h"
+#include "kvc_schedule_small.h"
+#include "kvc_schedule_harvest.h"
+#include "../../include/kvc_mi355x.h"
+
+namespace kvc {
+
+// ------------------------------------------------------------------ 7b. records + selection + emission in ONE launch
+// On lists somebody else made (the aggregation pass, the attention's epilogue) or with remembered pivots the
+// schedule is a handful of tiny dependent launches -- records 39 us, selection 22, emission 42 at 65 536 heads of
+// ~20 entries.  Those are not latency: rocprofv3 shows the bitonic sorts (42 ds_bpermute per 64-bit list, 21 per
+// emitted list, every wave of a CU through the one LDS crossbar) as the cost.  Nothing here needs a SORTED list:
+//   * a chunk threshold is the entry of RANK hang - 1 + c * bs, the evicted set is the entries of rank < cnt, the
+//     emission wants them at their rank by LOGICAL index -- ranks, not orders;
+//   * a list of C <= 64 entries is one 64-bit value per lane, and a lane's rank is the number of entries below its
+//     own: C steps of v_readlane (a scalar broadcast: no LDS, no cross-lane network) + compare + add.
+// One workgroup per sequence (16 waves, HPW heads per wave): ranks in registers, thresholds into a dense LDS list
+// (~2 per head), the k'-th smallest of them by all-pairs ranking again (a few hundred entries; the radix rounds of
+// seq_select_topk_kernel beyond 1024), and the wave that holds a head's entries emits them: no record is written and
+// read back, no second and third launch.  Lists beyond 64 entries (rare: a head that takes most of a sequence's
+// eviction) are sorted through LDS as in stream_records_kernel / emit_topk_kernel.  For calls whose sequences do not
+// need each other's counts (mode 1, one sequence: `coupled` 0 or 2 as in seq_select_topk_kernel) with at most
+// 16 * HPW heads per sequence; everything else keeps the launch chain.  write_back: the records in rank order to
+// global memory, for harvest_pivot_kernel behind.  PIVOT (measured and NOT used: the host instantiates false): the
+// pivots for the next decode step as this kernel's last phase, from the entries of rank >= cnt staged in the LDS the
+// thresholds have left -- 11 us in the kernel against a 20 us launch, but the ranks and keys that then stay live
+// through the emission cost it 12 us in spills (profiles/r5_topk_fused_phases.txt).
+__device__ __forceinline__ bool less64(uint32_t ahi, uint32_t alo, uint32_t bhi, uint32_t blo) {
+  return ahi < bhi || (ahi == bhi && alo < blo);
+}
+
+template <int HPW, bool PIVOT>
+__global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p, SchedWs ws, int P2, int lazy, int coupled,
+                                                          int write_back, uint32_t* hv_pivot, int from_harvest, float widen) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t sel_lds[];
+  uint64_t* arr = reinterpret_cast<uint64_t*>(sel_lds);                 // [P2] recorded thresholds, dense
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(arr + P2);                // [16 * HPW] freed chunks per head
+  __shared__ __attribute__((aligned(16))) uint64_t sort_s[4][KREC];     // lists beyond a wave (shared by four waves each)
+  __shared__ uint32_t fsum_s, k_s, nthr_s, big_lock[4], flag_s, nrem_s, hangsum_s;
+  __shared__ uint32_t piv_bc[4];
+  __shared__ unsigned long long vstar_s;
+  __shared__ __attribute__((aligned(16))) uint32_t sel_hist[RADIX];
+  __shared__ uint32_t sel_wtot[4];
+  __shared__ uint32_t sel_digit, sel_krem;
+  const int i = blockIdx.x, tid = threadIdx.x, lane = lane_id();
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = p.num_layers, H = p.num_kv_heads, B = p.num_seqs, LH = L * H;
+  const int bs = p.block_size, MCH = KREC / bs;
+  const int64_t gbase = (int64_t)i * LH;
+  const int G = B * LH;
+#ifdef KVC_TOPK_STAMPS
+#define KVC_STAMP(n) do { if (i == 1 && tid == 64) reinterpret_cast<unsigned long long*>(ws.bar)[n] = wall_clock64(); } while (0)
+#else
+#define KVC_STAMP(n) do { } while (0)
+#endif
+  KVC_STAMP(0);
+  if (i == 0 && w == 0) {                            // (as stream_records_kernel: blocks nobody claimed, lists of another batch)
+    const uint32_t c = wave_reduce_sum(ws.st_claimed[lane * 32]);
+    if (lane == 0 && (int64_t)c != p.total_slots / bs) atomicOr(ws.fallback, 1u);
+    if (ws.hv_seen_seq != nullptr) {
+      bool bad = false;
+      for (int b = lane; b < B; b += WAVE)
+        bad |= ws.hv_seen_seq[2 * b] != p.seq_positions[b] || ws.hv_seen_seq[2 * b + 1] != p.num_protected[b];
+      if (__ballot(bad) && lane == 0) atomicOr(ws.fallback, 1u);
+    }
+  }
+  if (tid == 0) { fsum_s = 0; nthr_s = 0; vstar_s = ~0ull; nrem_s = 0; hangsum_s = 0; }
+  const uint32_t used_pivot = (!PIVOT || hv_pivot == nullptr) ? 0u : (from_harvest ? hv_pivot[i] : ws.st_seqrec[i].pivot_excl);
+  if (tid < 4) big_lock[tid] = 0;
+  for (int lh = tid; lh < 16 * HPW; lh += 1024) cnt[lh] = 0;
+  __syncthreads();
+  const int kreq = p.evicted_blocks_per_seq[i];
+  // ---- what lane q < HPW knows about head lh0 + q (all loads requested together)
+  const int lh0 = w * HPW;
+  uint32_t myC = 0, myHang = 0, myFc = 0;
+  int32_t myOff = 0, myEnd = 0;                      // (offsets are int32 end to end: total slots < 2^31)
+  const int sh = __ffs(bs) - 1;                      // block sizes 8 / 16 / 32: shifts, not divisions
+  {
+    const bool mine = lane < HPW && lh0 + lane < LH;
+    const int lh = mine ? lh0 + lane : 0;
+    const int64_t g = gbase + lh;
+    const int l = lh / H, h = lh % H;
+    const int ctx = p.context_lens[(l * B + i) * H + h];
+    const uint32_t c_ = ws.st_cnt[g];
+    const uint32_t hang_ = (uint32_t)p.hanging_token_count[g];
+    const int32_t off_ = p.evicted_kv_offsets[g];
+    const int32_t end_ = (g + 1 < G) ? p.evicted_kv_offsets[g + 1] : (int32_t)p.total_slots;
+    const int seen_ = ws.hv_seen_ctx != nullptr ? ws.hv_seen_ctx[g] : ctx;
+    const uint32_t def_ = lazy ? 0u : ws.st_def[g];
+    if (mine) {
+      myC = c_; myHang = hang_; myOff = off_; myEnd = end_;
+      const uint32_t nblk = (uint32_t)((ctx + bs - 1) >> sh);
+      if (seen_ != ctx) atomicOr(ws.fallback, 1u);   // another batch's list
+      if (!lazy) {
+        myFc = nchunks_freed(nblk * (uint32_t)bs - def_, myHang, (uint32_t)bs);
+        ws.head_fc[g] = myFc;
+        ws.head_fc[(int64_t)G + g] = nblk;
+      }
+      if (myC > (uint32_t)KREC) atomicOr(ws.fallback, 1u);
+    }
+  }
+  if (coupled == 0) {
+    const uint32_t f = wave_reduce_sum(myFc);
+    if (lane == 0 && f) atomicAdd(&fsum_s, f);
+  }
+  KVC_STAMP(1);
+  // ---- records as ranks
+  uint32_t vlo[HPW], vhi[HPW], rk[HPW];
+  uint32_t bigmask = 0;                              // heads of this wave whose list went through LDS (64 < C <= KREC)
+#pragma unroll
+  for (int q = 0; q < HPW; ++q) {
+    const uint32_t C = (uint32_t)__builtin_amdgcn_readlane((int)myC, q);
+    uint64_t x = ~0ull;
+    if (C >= 1u && C <= (uint32_t)WAVE && (uint32_t)lane < C) x = ws.rec64[(gbase + lh0 + q) * KREC + lane];
+    vlo[q] = (uint32_t)x; vhi[q] = (uint32_t)(x >> 32);
+    rk[q] = 0xFFFFu;
+  }
+#pragma unroll
+  for (int q = 0; q < HPW; ++q) {
+    const uint32_t C = (uint32_t)__builtin_amdgcn_readlane((int)myC, q);
+    const uint32_t hang = (uint32_t)__builtin_amdgcn_readlane((int)myHang, q);
+    const int lh = lh0 + q;
+    if (C == 0u || C > (uint32_t)KREC) continue;                                // wave-uniform
+    uint64_t* rec = ws.rec64 + (gbase + lh) * KREC;
+    if (C <= (uint32_t)WAVE) {
+      // the key (high word) decides almost always: rank by it alone (readlane + compare + add with carry), and again
+      // with the slot as tie-break only if two entries of the list share a key -- which shows in the sum of the
+      // ranks: sum_i #{j : key_j < key_i} = C (C - 1) / 2 less the tied pairs
+      uint32_t r = 0;
+      {
+        const uint32_t me = vhi[q];
+        int j = 0;
+        for (; j + 4 <= (int)C; j += 4) {              // (unrolled by hand: the compiler will not unroll around readlane)
+          const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)me, j), a1 = (uint32_t)__builtin_amdgcn_readlane((int)me, j + 1);
+          const uint32_t a2 = (uint32_t)__builtin_amdgcn_readlane((int)me, j + 2), a3 = (uint32_t)__builtin_amdgcn_readlane((int)me, j + 3);
+          r += (a0 < me ? 1u : 0u) + (a1 < me ? 1u : 0u) + (a2 < me ? 1u : 0u) + (a3 < me ? 1u : 0u);
+        }
+        for (; j < (int)C; ++j) r += (uint32_t)__builtin_amdgcn_readlane((int)me, j) < me ? 1u : 0u;
+      }
+      const bool in = (uint32_t)lane < C;
+      if (wave_reduce_sum(in ? r : 0u) != C * (C - 1u) / 2u) {            // wave-uniform
+        r = 0;
+        for (int j = 0; j < (int)C; ++j) {
+          const uint32_t ohi = (uint32_t)__builtin_amdgcn_readlane((int)vhi[q], j);
+          const uint32_t olo = (uint32_t)__builtin_amdgcn_readlane((int)vlo[q], j);
+          r += less64(ohi, olo, vhi[q], vlo[q]) ? 1u : 0u;
+        }
+      }
+      rk[q] = in ? r : 0xFFFFu;
+      if (write_back && in && kreq > 0) rec[r] = ((uint64_t)vhi[q] << 32) | vlo[q];
+      // thresholds sit at ranks hang - 1 + c * bs
+      const bool thr = in && kreq > 0 && hang >= 1u && r + 1u >= hang && ((r + 1u - hang) & (uint32_t)(bs - 1)) == 0u &&
+                       ((r + 1u - hang) >> sh) < (uint32_t)MCH;
+      const unsigned long long tm = __ballot(thr);
+      if (tm) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&nthr_s, (uint32_t)__popcll(tm));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (thr) {
+          const uint32_t e = (uint32_t)lh * (uint32_t)MCH + ((r + 1u - hang) >> sh);
+          arr[base + __popcll(tm & ((1ull << lane) - 1ull))] = ((uint64_t)vhi[q] << 32) | e;
+        }
+      }
+    } else {
+      bigmask |= 1u << q;
+      // (rare) a list beyond a wave: sorted in LDS, one of four buffers, taken with a spin lock by the wave
+      const int bq = w & 3;
+      if (lane == 0) while (atomicCAS(&big_lock[bq], 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(2);
+      wave_lds_sync();
+      uint64_t* a = sort_s[bq];
+      const int SZ = C <= 128u ? 128 : 256;
+      for (int j = lane; j < SZ; j += WAVE) a[j] = (uint32_t)j < C ? rec[j] : ~0ull;
+      wave_lds_sync();
+      if (SZ == 128) wave_bitonic_sort<uint64_t, 128>(a);
+      else wave_bitonic_sort<uint64_t, 256>(a);
+      for (int j0 = 0; j0 < (int)C; j0 += WAVE) {
+        const int j = j0 + lane;
+        const bool in = j < (int)C;
+        if (in) rec[j] = a[j];
+        const bool thr = in && kreq > 0 && hang >= 1u && (uint32_t)j + 1u >= hang && ((uint32_t)j + 1u - hang) % (uint32_t)bs == 0u &&
+                         ((uint32_t)j + 1u - hang) / (uint32_t)bs < (uint32_t)MCH;
+        const unsigned long long tm = __ballot(thr);
+        if (tm) {
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(&nthr_s, (uint32_t)__popcll(tm));
+          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+          if (thr) {
+            const uint32_t e = (uint32_t)lh * (uint32_t)MCH + ((uint32_t)j + 1u - hang) / (uint32_t)bs;
+            arr[base + __popcll(tm & ((1ull << lane) - 1ull))] = (a[j] & 0xFFFFFFFF00000000ull) | e;
+          }
+        }
+      }
+      wave_lds_sync();
+      if (lane == 0) atomicExch(&big_lock[bq], 0u);
+    }
+  }
+  KVC_STAMP(2);
+  __syncthreads();
+  KVC_STAMP(3);
+  // ---- selection: k' and the k'-th smallest recorded threshold by (threshold, head, chunk)
+  const uint32_t nthr = nthr_s;
+  if (tid == 0) {
+    uint32_t kk = kreq <= 0 ? 0u : (uint32_t)kreq;
+    if (coupled == 0 && kk > fsum_s) kk = fsum_s;
+    k_s = kk;
+    ws.seq_k[i] = (int32_t)kk;
+  }
+  __syncthreads();
+  const uint32_t k = k_s;
+  if (k > nthr) {                                    // the records do not list k' thresholds
+    if (tid == 0) atomicOr(ws.fallback, 1u);
+  } else if (k > 0) {
+    // MSB-first radix select over the dense list (a few hundred 64-bit (threshold, head * MCH + chunk) values: one
+    // pass of the workgroup per round); bytes 2 and 3 of the low word are zero (head * MCH + chunk < 2^16): six rounds
+    uint64_t prefix = 0;
+    uint32_t krem = k;
+    for (int round = 0; round < 6; ++round) {
+      const int shift = round < 4 ? 56 - 8 * round : 8 * (5 - round);
+      const int pshift = round < 4 ? shift + 8 : (round == 4 ? 16 : 8);       // bits above the digit = the prefix so far
+      if (tid < RADIX) sel_hist[tid] = 0;
+      __syncthreads();
+      for (uint32_t e0 = 0; e0 < nthr; e0 += 1024u) {      // uniform trip count (ballots inside)
+        const uint32_t e = e0 + (uint32_t)tid;
+        const uint64_t x = e < nthr ? arr[e] : 0ull;
+        const bool in = e < nthr && (round == 0 || (x >> pshift) == prefix);
+        hist_add(sel_hist, in, (uint32_t)(x >> shift) & 0xFFu);
+      }
+      __syncthreads();
+      uint32_t c = 0, inc = 0;
+      if (tid < RADIX) {
+        c = sel_hist[tid];
+        inc = wave_inclusive_scan(c);
+        if ((tid & 63) == 63) sel_wtot[tid >> 6] = inc;
+      }
+      __syncthreads();
+      if (tid < RADIX) {
+        uint32_t off = 0;
+        for (int qq = 0; qq < (tid >> 6); ++qq) off += sel_wtot[qq];
+        const uint32_t incl = off + inc, excl = incl - c;
+        if (krem > excl && krem <= incl) { sel_digit = (uint32_t)tid; sel_krem = krem - excl; }
+      }
+      __syncthreads();
+      prefix = round == 3 ? (((prefix << 8) | sel_digit) << 16) : ((prefix << 8) | sel_digit);   // (skips the two zero bytes)
+      krem = sel_krem;
+    }
+    if (tid == 0) vstar_s = prefix;
+    for (uint32_t e = tid; e < nthr; e += 1024u) {
+      const uint64_t x = arr[e];
+      if (x <= prefix) atomicAdd(&cnt[(uint32_t)x / (uint32_t)MCH], 1u);
+    }
+  }
+  if (tid == 0) flag_s = *reinterpret_cast<volatile uint32_t*>(ws.fallback);
+  __syncthreads();
+  KVC_STAMP(4);
+  if (tid == 0) ws.seq_prefix[i] = (k > 0 && k <= nthr) ? (uint32_t)(vstar_s >> 32) : 0u;
+  // ---- counts and emission: the wave that holds a head's entries emits them
+  const bool flagged = flag_s != 0u;                 // (somebody's lists fell short: the general pipeline behind rewrites everything)
+  uint32_t ce[HPW], u[HPW];
+#pragma unroll
+  for (int q = 0; q < HPW; ++q) {                     // counts out, the evicted entries' logical indices requested
+    const int lh = lh0 + q;
+    ce[q] = 0; u[q] = 0xFFFFFFFFu;
+    if (lh >= LH) continue;                           // wave-uniform
+    const uint32_t hang = (uint32_t)__builtin_amdgcn_readlane((int)myHang, q);
+    const uint32_t n = (k > 0 && k <= nthr) ? cnt[lh] : 0u;
+    ce[q] = n > 0 ? (n - 1u) * (uint32_t)bs + hang : 0u;
+    if (lane == 0) {
+      p.evicted_block_count[gbase + lh] = (int32_t)n;
+      p.evicted_kv_count[gbase + lh] = (int32_t)ce[q];
+    }
+    if (!flagged && !(bigmask & (1u << q)) && rk[q] < ce[q])
+      u[q] = ((uint32_t)p.logical_block_num_by_block[vlo[q] >> sh] << sh) | (vlo[q] & (uint32_t)(bs - 1));
+  }
+  KVC_STAMP(5);
+  if (!flagged) {
+  const bool tracked = p.eli_dirty_map != nullptr && !(p.lean & 1);
+  uint32_t oldw[HPW];
+#pragma unroll
+  for (int q = 0; q < HPW; ++q) {                     // the dirty map's words of every head requested together
+    oldw[q] = 0;
+    if (!tracked || lh0 + q >= LH) continue;
+    const int32_t c0 = __builtin_amdgcn_readlane(myOff, q) >> sh, c1 = __builtin_amdgcn_readlane(myEnd, q) >> sh;
+    if (c0 < c1 && ((c1 - 1) >> 5) - (c0 >> 5) < WAVE && (c0 >> 5) + lane <= ((c1 - 1) >> 5)) oldw[q] = p.eli_dirty_map[(c0 >> 5) + lane];
+  }
+#pragma unroll
+  for (int q = 0; q < HPW; ++q) {
+    const int lh = lh0 + q;
+    if (lh >= LH) break;                              // wave-uniform
+    const int64_t g = gbase + lh;
+    const int32_t off = __builtin_amdgcn_readlane(myOff, q), end = __builtin_amdgcn_readlane(myEnd, q);
+    if (tracked) {
+      const int32_t c0 = off >> sh, c1 = end >> sh;
+      if (c0 < c1 && ((c1 - 1) >> 5) - (c0 >> 5) < WAVE)
+        eli_dirty_apply(p.eli_dirty_map, p.evicted_logical_indices, c0, c1, (int32_t)((ce[q] + (uint32_t)bs - 1u) >> sh), off + (int32_t)ce[q],
+                        sh, p.null_value, oldw[q], lane);
+      else
+        eli_dirty_update(p.eli_dirty_map, p.evicted_logical_indices, c0, c1, (int64_t)((ce[q] + (uint32_t)bs - 1u) >> sh), (int64_t)off + ce[q], bs,
+                         p.null_value, true, lane, WAVE);
+    }
+    if (ce[q] == 0) continue;
+    int32_t* out = p.evicted_logical_indices + off;
+    if (!(bigmask & (1u << q))) {
+      // rank by logical index among the evicted entries: a scalar walk over their lanes
+      const bool ev = rk[q] < ce[q];
+      unsigned long long m = __ballot(ev);
+      uint32_t r2 = 0;
+      while (m) {
+        const int j = __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        r2 += (uint32_t)__builtin_amdgcn_readlane((int)u[q], j) < u[q] ? 1u : 0u;
+      }
+      if (ev) out[r2] = (int32_t)u[q];
+    } else {
+      // (this wave wrote the sorted record to global memory above: read past the L1)
+      const int bq = w & 3;
+      if (lane == 0) while (atomicCAS(&big_lock[bq], 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(2);
+      wave_lds_sync();
+      uint32_t* a = reinterpret_cast<uint32_t*>(sort_s[bq]);
+      const uint64_t* rec = ws.rec64 + g * KREC;
+      for (int j = lane; j < KREC; j += WAVE)
+        a[j] = (uint32_t)j < ce[q] ? logical_of(p, (uint32_t)__atomic_load_n(rec + j, __ATOMIC_RELAXED)) : 0xFFFFFFFFu;
+      wave_lds_sync();
+      wave_bitonic_sort<uint32_t, KREC>(a);
+      for (int j = lane; j < (int)ce[q]; j += WAVE) out[j] = (int32_t)a[j];
+      wave_lds_sync();
+      if (lane == 0) atomicExch(&big_lock[bq], 0u);
+    }
+  }
+  }
+  KVC_STAMP(6);
+  // ---- the pivot for the next decode step's harvest from what is left of the lists (section 10)
+  if (!PIVOT || hv_pivot == nullptr) return;
+  if (kreq <= 0) {                                   // nothing asked of this sequence: lists made for nothing say nothing new
+    if (tid == 0 && !from_harvest) hv_pivot[i] = 0u;
+    return;
+  }
+  __syncthreads();                                   // (the thresholds in arr are not needed any more)
+  uint32_t* keys_s = reinterpret_cast<uint32_t*>(arr);
+  const uint32_t cap = 2u * (uint32_t)P2;
+  {
+    const uint32_t hs = wave_reduce_sum((lane < HPW && lh0 + lane < LH && myHang >= 1u) ? myHang - 1u : 0u);
+    if (lane == 0 && hs) atomicAdd(&hangsum_s, hs);
+  }
+#pragma unroll
+  for (int q = 0; q < HPW; ++q) {
+    const int lh = lh0 + q;
+    if (lh >= LH) break;                              // wave-uniform
+    const uint32_t C = min((uint32_t)__builtin_amdgcn_readlane((int)myC, q), (uint32_t)KREC);
+    if (C == 0u) continue;
+    if (!(bigmask & (1u << q))) {
+      const bool rem = (uint32_t)lane < C && rk[q] >= ce[q] && rk[q] != 0xFFFFu;
+      const unsigned long long m = __ballot(rem);
+      if (m) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&nrem_s, (uint32_t)__popcll(m));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (rem && at < cap) keys_s[at] = vhi[q];
+      }
+    } else {
+      const uint64_t* rec = ws.rec64 + (gbase + lh) * KREC;
+      const uint32_t first = min(ce[q], C);
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&nrem_s, C - first);
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      for (uint32_t j = first + (uint32_t)lane; j < C; j += WAVE)
+        if (base + (j - first) < cap) keys_s[base + (j - first)] = (uint32_t)(__atomic_load_n(rec + j, __ATOMIC_RELAXED) >> 32);
+    }
+  }
+  __syncthreads();
+  const uint32_t R = nrem_s;
+  uint32_t next = used_pivot;
+  if (R <= cap) {
+    auto val = [&](int x) -> uint32_t { return keys_s[x]; };
+    next = next_pivot_from_keys(sel_hist, piv_bc, R, val, kreq, bs, hangsum_s, used_pivot, widen);
+  }
+  if (tid == 0) hv_pivot[i] = next;
+  KVC_STAMP(7);
+}
+
+}  // namespace kvc

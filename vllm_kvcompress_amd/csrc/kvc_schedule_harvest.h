@@ -227,6 +227,38 @@ __device__ __forceinline__ float key_to_float(uint32_t k) {      // inverse of f
   return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k);
 }
 
+// The pivot for the next decode step from the R keys that are left of a sequence's lists (val(x), x < R: any order)
+// once the selection has said what leaves -- see the head of this section.  Called by every thread of the workgroup.
+template <typename ValF>
+__device__ __forceinline__ uint32_t next_pivot_from_keys(uint32_t* hist, uint32_t* bc, uint32_t R, ValF val, int k, int bs,
+                                                         uint32_t hang_sum, uint32_t used, float widen) {
+  auto all = [&](int) { return true; };
+  const double tgt = (double)k * bs + (double)hang_sum;
+  const double want = ceil(tgt * (1.0 + (double)widen)) + 8.0;
+  const uint32_t target = want < 4.0e9 ? (uint32_t)want : 0xFFFFFFFFu;
+  uint32_t next;
+  if (R >= target) {
+    uint32_t P, r2, e2;
+    block_radix_select(hist, bc, (int)R, target, val, all, P, r2, e2);
+    next = P + 1u;                                   // (P < used <= KEY_INF)
+  } else if (used >= KEY_INF) {
+    next = KEY_INF;                                  // every evictable key was a candidate, and they are fewer than the target
+  } else if (R < 2u || used == 0u) {
+    next = used;                                     // (nothing to measure a density on)
+  } else {
+    const uint32_t m = max(R / 4u, 1u);
+    uint32_t Kq, r2, e2;
+    block_radix_select(hist, bc, (int)R, R - m, val, all, Kq, r2, e2);
+    const float fH = key_to_float(used - 1u), fq = key_to_float(Kq);
+    float df = (fH - fq) * ((float)(target - R) / (float)m) * 2.0f;
+    if (!(df > 0.0f)) df = fabsf(fH) * 1e-3f + 1e-30f;           // (ties at the top of the list)
+    const float fn = fH + df;
+    next = (fn == fn && fn < __builtin_inff()) ? min(float_to_key(fn) + 1u, KEY_INF) : KEY_INF;
+    if (next < used) next = used;
+  }
+  return next;
+}
+
 constexpr int HVP_LDS_KEYS = 12288;                  // keys of a sequence staged in LDS (more: read from L2 every round)
 
 // One workgroup per sequence, behind seq_select_topk_kernel: the pivot for the harvest of the next
@@ -291,30 +323,7 @@ __global__ __launch_bounds__(1024) void harvest_pivot_kernel(kvc_schedule_params
     __syncthreads();
   }
   auto val = [&](int x) -> uint32_t { return staged ? keys_s[x] : key_at((uint32_t)x); };
-  auto all = [&](int) { return true; };
-  const double tgt = (double)k * bs + (double)hang_s;
-  const double want = ceil(tgt * (1.0 + (double)widen)) + 8.0;
-  const uint32_t target = want < 4.0e9 ? (uint32_t)want : 0xFFFFFFFFu;
-  uint32_t next;
-  if (R >= target) {
-    uint32_t P, r2, e2;
-    block_radix_select(hist, bc, (int)R, target, val, all, P, r2, e2);
-    next = P + 1u;                                   // (P < used <= KEY_INF)
-  } else if (used >= KEY_INF) {
-    next = KEY_INF;                                  // every evictable key was a candidate, and they are fewer than the target
-  } else if (R < 2u || used == 0u) {
-    next = used;                                     // (nothing to measure a density on)
-  } else {
-    const uint32_t m = max(R / 4u, 1u);
-    uint32_t Kq, r2, e2;
-    block_radix_select(hist, bc, (int)R, R - m, val, all, Kq, r2, e2);
-    const float fH = key_to_float(used - 1u), fq = key_to_float(Kq);
-    float df = (fH - fq) * ((float)(target - R) / (float)m) * 2.0f;
-    if (!(df > 0.0f)) df = fabsf(fH) * 1e-3f + 1e-30f;           // (ties at the top of the list)
-    const float fn = fH + df;
-    next = (fn == fn && fn < __builtin_inff()) ? min(float_to_key(fn) + 1u, KEY_INF) : KEY_INF;
-    if (next < used) next = used;
-  }
+  const uint32_t next = next_pivot_from_keys(hist, bc, R, val, k, bs, hang_s, used, widen);
   if (tid == 0) hv_pivot[i] = next;
 }
 
