@@ -116,3 +116,69 @@ def test_shard_sequences_balances():
     assert sorted(sum(shards, [])) == list(range(6))
     assert abs(loads[0] - loads[1]) <= 1
     assert hdist.shard_sequences([5, 5, 5, 5], 4) == [[0], [1], [2], [3]]
+
+
+# ---- eight ranks: BASELINE configs[3] is 256 sequences over the 8 GPUs of a node ------------------------------------
+SEQ8 = 256            # configs[3]'s batch; ragged toy lengths so that the shards are not trivially equal
+LENS8 = [9 + (7 * i) % 23 for i in range(SEQ8)]
+
+
+def _seq_state8(i):
+    return synth.make_state(num_layers=1, num_kv_heads=2, block_size=BS, seq_lens=[LENS8[i]], seed=500 + i, protected=2)
+
+
+def _worker8(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shards = hdist.shard_sequences([float(n) for n in LENS8], world)
+    res, units = {}, 0
+    for i in shards[rank]:
+        st = _seq_state8(i)
+        nblk = int(((st.context_lens.astype(np.int64) + BS - 1) // BS).sum())
+        out = oracle_pipeline(st, [max(nblk - 2, 0) // 2], mode="per_sequence")
+        res[i] = (out["ekc"], out["cmc"])
+        units += int(out["ekc"].sum()) + int(out["cmc"].sum())
+    red = hdist.reduce_throughput(units, 1.0 + 0.25 * rank)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, res)
+    if rank == 0:
+        q.put((shards, red, gathered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_shard_256_sequences():
+    """configs[3]'s layout -- 256 sequences sharded by sequence over the 8 GPUs of one node, no data-path collective,
+    one all_gather of two scalars -- with eight gloo ranks: every sequence on exactly one rank, 32 per rank, balanced
+    cost, every sequence's schedule equal to its stand-alone run, throughput = sum(units) / max(seconds)"""
+    world = 8
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    shards, red, gathered = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(sum(shards, [])) == list(range(SEQ8)) and [len(x) for x in shards] == [32] * 8
+    loads = [sum(LENS8[i] for i in x) for x in shards]
+    assert max(loads) - min(loads) <= max(LENS8)
+    merged = {}
+    for part in gathered:
+        assert not (set(part) & set(merged))
+        merged.update(part)
+    assert sorted(merged) == list(range(SEQ8))
+    total = 0
+    for i in range(0, SEQ8, 17):                      # (a sample against stand-alone runs; the totals cover the rest)
+        st = _seq_state8(i)
+        nblk = int(((st.context_lens.astype(np.int64) + BS - 1) // BS).sum())
+        want = oracle_pipeline(st, [max(nblk - 2, 0) // 2], mode="per_sequence")
+        np.testing.assert_array_equal(merged[i][0], want["ekc"])
+        np.testing.assert_array_equal(merged[i][1], want["cmc"])
+    total = sum(int(a.sum()) + int(b.sum()) for a, b in merged.values())
+    assert red["units"] == total and len(red["per_rank_seconds"]) == 8
+    assert red["seconds"] == 1.0 + 0.25 * 7 and abs(red["value"] - total / red["seconds"]) < 1e-9

@@ -114,6 +114,32 @@ def test_c4_preset_with_two_ranks_at_toy_size():
     assert d["config"]["freed_blocks"] > 0 and all(r["units"] > 0 for r in d["per_rank"])
 
 
+def test_eight_ranks_share_the_gpu_weak_and_strong():
+    """N = 8 without 8 GPUs: `--gpus 8 --config c4` (BASELINE configs[3]'s shape at toy size) and a fixed batch of 256
+    sequences split over 8 ranks (`--scaling strong --batch 256`), eight gloo ranks sharing the box's one GPU --
+    rank-private caches, per-rank shards, the barrier-bracketed timed region, the all_gather of two scalars and the
+    whole-job value, as the driver will run them over RCCL with one rank per GPU"""
+    env = dict(os.environ, KVC_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--config", "c4",
+                          "--layers", "2", "--seq-len", "256", "--batch", "2", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=1200, cwd=REPO, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and len(d["per_rank"]) == 8
+    assert d["config"]["workload"].startswith("c4:") and all(r["units"] > 0 for r in d["per_rank"])
+    units = sum(r["units"] for r in d["per_rank"])
+    assert abs(d["value"] - units / max(r["seconds"] for r in d["per_rank"])) / d["value"] < 1e-9
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--layers", "1", "--seq-len", "128",
+                          "--batch", "256", "--scaling", "strong", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=1200, cwd=REPO, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and len(d["per_rank"]) == 8
+    u = [r["units"] for r in d["per_rank"]]
+    assert min(u) > 0 and max(u) / min(u) < 1.2          # 256 equal sequences -> 32 per rank (other seeds' metrics)
+    assert "256 sequences split over 8 GPUs" in d["config"]["workload"]
+
+
 def test_default_line_carries_the_other_configurations():
     """the default workload also reports short runs of BASELINE configs[4] and configs[2] (here
     with tiny step counts; bench.py shrinks a configuration that does not fit)"""
@@ -137,6 +163,15 @@ def test_default_line_carries_the_other_configurations():
     # ... and configs[2] as a whole decode step (S0 + S1 + S2 + S3): two sweeps of the store against harvest-ahead
     ds = oc["c3"]["decode_step"]
     assert ds["parity_checked"]["bit_exact"] is True and ds["parity_checked"]["variants_agree"] is True
+    # ... and as the step without a sweep of the store: the attention's epilogues make the lists, no aggregate_decode
+    fa = ds["fused_attention"]
+    assert fa["parity_checked"]["bit_exact"] is True and fa["steps_on_the_epilogues_lists"] == 2, fa
+    assert fa["stages_ms"]["S0_aggregate_decode"] == 0.0 and fa["S1_schedule_reason"].endswith("[lists: the attention's epilogue]")
+    # ... and S1 through the call the fork makes (device tensor of counts, no total_slots) next to the list form
+    for o in oc.values():
+        cf = o["S1_call_forms"]
+        assert cf["reference_call_form"]["same_counts"] is True and cf["reference_call_form"]["schedule"] == cf["list_form"]["schedule"]
+        assert o["S1_reference_call_form_ms"] == cf["reference_call_form"]["ms"] > 0
     assert ds["two_sweeps"]["harvested_steps"] == 0 and ds["harvest_ahead"]["harvested_steps"] == 2
     assert ds["harvest_ahead"]["stages_ms"]["S1_schedule_evictions"] < ds["two_sweeps"]["stages_ms"]["S1_schedule_evictions"]
     assert "decode_step" not in oc["c5"]
