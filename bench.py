@@ -762,7 +762,7 @@ def measure_workload(a2, seed, device, steps, warmup, probe):
         "S1_schedule": ds.cm.last_schedule_path(),
         # (a "[pivots: the call before]" here: the small-eviction schedule did not sample -- on this bench's static store
         # the pivots of the call before are exact; in an engine they are one decode step of attention old, which
-        # profiles/r4_harvest_soak.txt runs for 400 steps of an evolving state without a pass that listed too little)
+        # profiles/r5_harvest_soak.txt runs for 400 steps of an evolving state without a pass that listed too little)
         "S1_schedule_reason": ds.cm.last_schedule_reason,
         # S1 against ITS lower bound (12.75 B per candidate slot)
         "S1_lower_bound_GBps": N * 12.75 / (s1 * 1e-3) / 1e9,
@@ -834,16 +834,21 @@ def measure_workload(a2, seed, device, steps, warmup, probe):
     return res
 
 
+S0_PMC_FILES = ("r5_decode_step_pmc.json", "r4_decode_step_pmc.json")     # newest first
+
+
 def _committed_s0_traffic(kernel_tag):
-    """HBM bytes per launch of the aggregation kernel from the committed PMC collection (None if absent)"""
-    try:
-        d = json.load(open(os.path.join(REPO, "profiles", "r4_decode_step_pmc.json")))
-        for name, v in d.get("aggregation", {}).items():
-            if kernel_tag in name:
-                return v["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+    """(HBM bytes per launch of the aggregation kernel, the file it comes from) from the committed PMC collection --
+    a separately profiled run of tools/decode_step.py (tools/collect_decode_step_pmc.sh), not a measurement of this run"""
+    for name in S0_PMC_FILES:
+        try:
+            d = json.load(open(os.path.join(REPO, "profiles", name)))
+            for kname, v in d.get("aggregation", {}).items():
+                if kernel_tag in kname:
+                    return v["hbm_bytes_per_launch"], name
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
 
 
 def decode_step_compare(a2, st, ds, evicted, k_cache, v_cache, cmi, cmc, device, steps, warmup):
@@ -916,9 +921,10 @@ def decode_step_compare(a2, st, ds, evicted, k_cache, v_cache, cmi, cmc, device,
                             "bound": "hbm", "achieved": slots * (4 * qpk + 8) / (ms(0, 1) * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                             "unit": "GB/s", "frac": slots * (4 * qpk + 8) / (ms(0, 1) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                             "algorithmic_bytes_per_launch": slots * (4 * qpk + 8),
-                            "traffic": _committed_s0_traffic("aggregate_harvest" if cm.harvest_ahead else "aggregate_decode_q4"),
-                            "traffic_source": "profiles/r4_decode_step_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
-                                              "passes over tools/decode_step.py; 2 x FETCH + WRITE)",
+                            "traffic": _committed_s0_traffic("aggregate_harvest" if cm.harvest_ahead else "aggregate_decode_q4")[0],
+                            "traffic_source": f"profiles/{_committed_s0_traffic('aggregate_harvest' if cm.harvest_ahead else 'aggregate_decode_q4')[1]} "
+                                              "(a separately profiled run of tools/decode_step.py, NOT a measurement of this run: rocprofv3 --pmc "
+                                              "FETCH_SIZE / WRITE_SIZE in separate passes; 2 x FETCH + WRITE)",
                             "timing": "the S0 stage: HIP events on the launch stream around the call (one kernel + the counters' fill)"},
             "S1_schedule": cm.last_schedule_path(), "harvested_steps": used, "harvest_misses": cm.harvest_misses - misses0}
         keep[variant] = (cm.metrics.clone(), eli.clone(), ekc.clone(), ebc.clone(), cmc.clone(),

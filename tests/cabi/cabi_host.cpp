@@ -230,6 +230,81 @@ int main() {
     hok = hok && freed == kfree && same(out[2][0], r_eli, "evicted_logical_indices (harvested vs own pass)") &&
           same(out[2][1], r_cnt, "evicted_kv_count (harvested vs own pass)") &&
           same(out[2][2], r_blk, "evicted_block_count (harvested vs own pass)");
+    // ---- ABI version 6: the decode step without a sweep of the store.  Step 3 twice from the same store: (a) the fused-metric
+    // attention of both layers, then the schedule's own pass on remembered pivots; (b) the same attention with the harvest
+    // fields set (kvc_attention_harvest_begin in front), then the schedule on the lists the epilogues made (bits 0 | 3).
+    // The same store and the same schedule, no flag raised; and lists of ANOTHER batch (other positions) are redone, not trusted.
+    {
+      const int Hq = H * qpk;
+      std::vector<_Float16> kc((size_t)NB * hd * bs), vc((size_t)NB * hd * bs), qv((size_t)B * Hq * hd), outv((size_t)B * Hq * hd);
+      for (auto& x : kc) x = (_Float16)(((int)(rnd() % 201) - 100) * 0.004f);
+      for (auto& x : vc) x = (_Float16)(((int)(rnd() % 201) - 100) * 0.004f);
+      for (auto& x : qv) x = (_Float16)(((int)(rnd() % 201) - 100) * 0.01f);
+      _Float16 *d_kc = to_dev(kc), *d_vc = to_dev(vc), *d_q = to_dev(qv), *d_out = to_dev(outv);
+      std::vector<int32_t> lastp = {seq_pos - 1}, bufl = {0}, slot_of_att = {0};
+      int32_t *d_last = to_dev(lastp), *d_bufl = to_dev(bufl), *d_slot = to_dev(slot_of_att);
+      float* d_ma; float* d_mb;
+      CK(hipMalloc(&d_ma, slots * 4)); CK(hipMalloc(&d_mb, slots * 4));
+      CK(hipMemcpyAsync(d_ma, d_m, slots * 4, hipMemcpyDeviceToDevice, s));
+      CK(hipMemcpyAsync(d_mb, d_m, slots * 4, hipMemcpyDeviceToDevice, s));
+      void* hbuf3;
+      CK(hipMalloc(&hbuf3, hvb));
+      CK(hipMemcpyAsync(hbuf3, hbuf, hvb, hipMemcpyDeviceToDevice, s));       // (the pivots step 2 left behind)
+      auto attention = [&](float* metrics, void* harvest) {
+        for (int l = 0; l < L; ++l) {
+          kvc_attention_params ap;
+          memset(&ap, 0, sizeof(ap));
+          ap.out = d_out; ap.fused_metrics = metrics; ap.fused_use_l2 = 1; ap.query = d_q; ap.key_cache = d_kc; ap.value_cache = d_vc;
+          ap.block_tables = d_bt + (size_t)l * B * H * M; ap.context_lens = d_ctx2 + (size_t)l * B * H; ap.kv_position = d_pos2;
+          ap.last_position = d_last; ap.kv_metric_buffer_len = d_bufl; ap.q_stride = (int64_t)Hq * hd;
+          ap.kv_block_stride = (int64_t)hd * bs; ap.scale = 0.088f; ap.k_scale = ap.v_scale = 1.0f; ap.num_seqs = B;
+          ap.num_heads = Hq; ap.num_kv_heads = H; ap.head_size = hd; ap.block_size = bs; ap.max_num_blocks_per_seq = M;
+          ap.max_context_len = ctx; ap.dtype = 0; ap.kv_cache_dtype = 0; ap.record_kv_metrics = 1;
+          if (harvest != nullptr) {
+            ap.harvest_buf = harvest; ap.harvest_seq_slot = d_slot; ap.harvest_seq_positions = d_sp; ap.harvest_num_protected = d_pr;
+            ap.harvest_num_seqs = B; ap.harvest_layer = l; ap.harvest_num_layers = L; ap.harvest_num_sinks = 0;
+          }
+          int rc_ = kvc_paged_attention_decode(&ap, s);
+          if (rc_ != 0) return rc_;
+        }
+        return 0;
+      };
+      bool aok = kvc_attention_harvest_eligible(&sp) == 1;
+      // (a) the fused attention alone, the schedule's own pass
+      KV(attention(d_ma, nullptr));
+      sp.harvest_buf = hbuf3;
+      KV(schedule(d_ma, 2 | 4, out[1]));
+      aok = aok && flag() == 0;
+      // (b) ... with the harvest
+      sp.harvest_buf = hbuf; sp.metrics = d_mb;
+      KV(kvc_attention_harvest_begin(&sp, s));
+      KV(attention(d_mb, hbuf));
+      KV(schedule(d_mb, 1 | 2 | 8, out[2]));
+      aok = aok && flag() == 0;
+      std::vector<float> ma((size_t)slots);
+      std::vector<int32_t> a_eli(N), a_cnt(G), a_blk(G);
+      CK(hipMemcpy(ma.data(), d_ma, slots * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(a_eli.data(), out[1][0], (size_t)N * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(a_cnt.data(), out[1][1], G * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(a_blk.data(), out[1][2], G * 4, hipMemcpyDeviceToHost));
+      long afreed = 0;
+      for (int g = 0; g < G; ++g) afreed += a_blk[g];
+      aok = aok && afreed == kfree && same(d_mb, ma, "metrics (attention with harvest vs without)") &&
+            memcmp(ma.data(), m2.data(), slots * 4) != 0 &&                                      // (the attention did add something)
+            same(out[2][0], a_eli, "evicted_logical_indices (epilogue's lists vs own pass)") &&
+            same(out[2][1], a_cnt, "evicted_kv_count (epilogue's lists vs own pass)") &&
+            same(out[2][2], a_blk, "evicted_block_count (epilogue's lists vs own pass)");
+      // lists made for other positions: the call sees it on the device (bit 3), raises its flag and redoes the work
+      std::vector<int32_t> seqpos_other = {seq_pos + 1};
+      int32_t* d_sp_other = to_dev(seqpos_other);
+      CK(hipMemcpyAsync(d_mb, d_ma, slots * 4, hipMemcpyDeviceToDevice, s));
+      sp.seq_positions = d_sp_other;
+      KV(schedule(d_mb, 1 | 8, out[0]));
+      aok = aok && (flag() & 1u) == 1u;
+      sp.seq_positions = d_sp;
+      if (!aok) printf("attention harvest protocol failed\n");
+      hok = hok && aok;
+    }
     // lists without the buffer they would be in: an error
     sp.harvest_buf = nullptr;
     rc = schedule(d_m, 1, out[2]);

@@ -113,6 +113,12 @@ timeout 600 python tools/bench_attention.py > "$OUT/${TAG}_attention_bench.json"
 cp "$REPO/gpurun_out/${TAG}_decode_step.json" "$OUT/${TAG}_decode_step_c3.json" 2>/dev/null
 cp "$REPO/gpurun_out/${TAG}_decode_step_kernel_stats.csv" "$OUT/" 2>/dev/null
 cd "$REPO"
+"$REPO/tools/collect_decode_step_pmc.sh" "$TAG" > "$OUT/${TAG}_decode_step_pmc.txt" 2>&1
+cp "$REPO/gpurun_out/${TAG}_decode_step_pmc.json" "$OUT/" 2>/dev/null
+# 5b. the decode step in the fork's default mode (the reference's batch > 1 rule), with the oracle's two-stage verdict
+timeout 600 python tools/decode_step.py --mode reference > "$OUT/${TAG}_decode_step_c3_reference_mode.json" 2> "$OUT/ds_ref.err"
+# 5c. the zero-sweep decode step over 400 iterations of an evolving state: fused attention + epilogue harvest against the reference flow
+timeout 600 python tools/soak_attention_harvest.py 400 8 4 512 10 > "$OUT/${TAG}_attention_harvest_soak.json" 2> "$OUT/soak_att.err"
 # 6. harvest-ahead / pivot memory over 400 decode steps of an evolving on-device block state    -> <tag>_harvest_soak.txt
 (timeout 500 python tools/soak_harvest.py 400 32 32 1024 uniform; timeout 500 python tools/soak_harvest.py 400 32 32 1024 peaky;
  timeout 300 python tools/soak_harvest.py 300 4 4 256 peaky) > "$OUT/${TAG}_harvest_soak.txt" 2> "$OUT/soak.err"
