@@ -517,7 +517,7 @@ def traffic_floor(cmi, cmc, offs, bs, block_bytes):
             "dst_blocks": d, "dst_blocks_fully_overwritten": full, "src_blocks": s}
 
 
-PATTERN_CEILING_TYPICAL_GBPS = 5100.0     # random 4 KiB images inside one 64 GiB region (DESIGN.md section 5; 6100 across regions)
+PATTERN_CEILING_TYPICAL_GBPS = 5100.0     # random 4 KiB images inside one 64 GiB region (DESIGN.md section 3.4; 6100 across regions)
 
 
 def frac_ceiling(alg_bytes, floor, ceiling, frac):
@@ -1106,7 +1106,7 @@ def engine_sized_cache_run(args, rank, device, steps=20, warmup=3):
     the GPU's memory (vLLM's gpu_memory_utilization) instead of to the sequence.  Candidate, evicted
     slots are identical to the main run and the moved ones differ by a fraction of a percent (another
     seed's metrics); what changes is the number of (free) blocks in the cache tensor.  Reported next to the main line because random 4 KiB block traffic runs at
-    5.1 or 6.1 TB/s depending on where the blocks lie in HBM (DESIGN.md section 5)."""
+    5.1 or 6.1 TB/s depending on where the blocks lie in HBM (DESIGN.md section 3.4)."""
     import copy
     import torch
     e = 1 if args.kv_dtype == "fp8" else 2

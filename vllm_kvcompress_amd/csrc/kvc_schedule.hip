@@ -51,7 +51,7 @@
 
 // --------------------------------------------------------------------------- host side
 #ifndef KVC_COLLECT_GRID_CAP
-#define KVC_COLLECT_GRID_CAP 4096                  // (experiment builds: tools/)
+#define KVC_COLLECT_GRID_CAP 4096                  // (experiment builds: tools/, profiles/DESIGN_history_r1_r4.md section 6)
 #endif
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

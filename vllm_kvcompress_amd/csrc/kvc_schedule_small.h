@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void stream_sample_kernel(kvc_schedule_params 
 // the registers; a longer one (a sequence far longer than the batch average) is re-read from L2
 // every round.
 #ifndef KVC_PIV_SIGMAS
-#define KVC_PIV_SIGMAS 12.0                          // (experiment builds: tools/)
+#define KVC_PIV_SIGMAS 12.0                          // (experiment builds: tools/, profiles/DESIGN_history_r1_r4.md section 6)
 #endif
 constexpr int PIV_R = 48;
 constexpr int PIV_MAXLH = 1024;                      // heads per sequence (the host checked)

@@ -143,7 +143,7 @@ class CompressionScheduler:
         ``kv_metrics.aggregate_decode()`` (llm_engine.py:1634) has NOT run yet -- the engine left it to
         this call, which is the next reader of the metrics.  It then runs here exactly once: as
         ``aggregate_decode_and_harvest`` with the batch of the ``schedule_evictions`` right behind it
-        (one sweep of the metric store instead of two, DESIGN.md 3.1a), or as the plain pass when
+        (one sweep of the metric store instead of two, DESIGN.md 3.2), or as the plain pass when
         nothing is compressed this iteration.  The sums, and everything computed from them, are the
         same as with the reference's order.  "Exactly once" holds on every way out of this call: if anything
         raises before the aggregation has run (the policy's assertion, an out-of-budget batch, a device fault
