@@ -953,7 +953,7 @@ def decode_step_compare(a2, st, ds, evicted, k_cache, v_cache, cmi, cmc, device,
     cm.metrics.copy_(m0)
     cm.num_queries_per_kv, cm._temp_metrics, cm.harvest_ahead = saved
     cm._hv = cm._hv_lists = None
-    if a2.mode == "per_sequence" and a2.block_size in (16, 32) and a2.head_size in (64, 128):
+    if a2.block_size in (16, 32) and a2.head_size in (64, 128):
         del wm, wp, keep
         wm = wp = keep = None
         out["fused_attention"] = decode_step_fused_attention(a2, st, ds, evicted, k_cache, v_cache, cmi, cmc, temp, m0, device,

@@ -633,8 +633,10 @@ typedef struct kvc_attention_params {
  *   kvc_paged_attention_decode x num_layers       one per layer, each with harvest_layer = its layer,
  *                                                 over every sequence of the compression batch
  *   kvc_schedule_evictions(harvest bits 0 | 3 [| 1])  runs records -> selection -> emission on the lists
- * Eligible (kvc_attention_harvest_eligible): calls that take the small-eviction schedule in its
- * position-lazy form (no use_average, no bias, mode 1 or one sequence).  Exact or flagged, like every
+ * Eligible (kvc_attention_harvest_eligible): calls that take the small-eviction schedule with keys
+ * that are the sum alone (no use_average, no bias).  Under the reference's batch > 1 rule (mode 0,
+ * more than one sequence) the epilogue also counts every head's masked slots, as the schedule's full
+ * collecting pass does (that rule needs every head's count of evictable keys).  Exact or flagged, like every
  * list of that schedule: a layer that was not launched, a sequence of the batch the attention did not
  * see, a metric window that ends before the eviction bound (last_position - kv_metric_buffer_len <
  * seq_position - num_protected) or pivots that were too low leave lists that fall short, and the

@@ -227,10 +227,11 @@ def test_harvest_eligibility_and_buffer_sizes():
     assert both(hint=100000) == (0, 0) and both(hint=-1) == (0, 0)         # bulk / unknown: not the small-eviction schedule
     assert both(path=1) == (0, 0) and both(bs=4) == (0, 0) and both(uniform=1) == (0, 0)
     assert int(lib.kvc_harvest_eligible(None, 4)) == 0 and int(lib.kvc_pivot_memory_eligible(None)) == 0
-    # the attention epilogue's harvest: the position-lazy form only (a key from the sum alone)
+    # the attention epilogue's harvest: keys that are the sum alone (the reference's batch > 1 rule included: the epilogue
+    # counts the masked slots per head); not averaged / biased metrics
     att = lambda **kw: int(lib.kvc_attention_harvest_eligible(ctypes.byref(params(**kw))))
-    assert att() == 1 and att(B=16) == 1 and att(B=1, mode=0) == 1
-    assert att(B=16, mode=0) == 0 and att(use_average=1) == 0 and att(bias=True) == 0 and att(path=3) == 0
+    assert att() == 1 and att(B=16) == 1 and att(B=1, mode=0) == 1 and att(B=16, mode=0) == 1
+    assert att(use_average=1) == 0 and att(bias=True) == 0 and att(path=3) == 0
     assert att(hint=100000) == 0 and att(path=1) == 0 and int(lib.kvc_attention_harvest_eligible(None)) == 0
     # the buffer: 256 B of header, 4 B per sequence, then (lists) 64 counters a cache line apart, 2 x 4 B + 256 x 8 B per head,
     # then what lists made by the attention's epilogue were made with: 4 B per head, 8 B per sequence

@@ -32,9 +32,11 @@ class AttnEngine:
     launches), as LLMEngine.step orders them (llm_engine.py:1556-1634).  ``fused``: the attention folds its weights
     into the store and harvests; else it writes temp_metrics and aggregate_decode runs behind the forward."""
 
-    def __init__(self, st, seq_lens, cap, fused, qpk=4, hd=64, buffer_len=0, protected=None, seed=7, dtype=torch.float16):
+    def __init__(self, st, seq_lens, cap, fused, qpk=4, hd=64, buffer_len=0, protected=None, seed=7, dtype=torch.float16,
+                 mode="per_sequence"):
         self.bs, self.L, self.H, self.cap, self.fused, self.qpk, self.hd = st.block_size, st.num_layers, st.num_kv_heads, cap, fused, qpk, hd
-        self.ds = hdev.upload(st, DEV, num_queries_per_kv=qpk, mode="per_sequence")
+        self.mode = mode
+        self.ds = hdev.upload(st, DEV, num_queries_per_kv=qpk, mode=mode)
         self.cm = self.ds.cm
         self.cm.strict_fallback = True
         self.B = len(seq_lens)
@@ -158,7 +160,7 @@ def _oracle_schedule_of(engine, sel):
     evicted = [synth.evict_block_count(context_lens_lh=ctx[:, b, :], seq_len=int(engine.lens[s]), block_size=bs,
                                        protected_window_size=engine.protected, max_cache_tokens=engine.cap)
                for b, s in enumerate(sel)]
-    return oracle_pipeline(st, evicted, mode="per_sequence"), st
+    return oracle_pipeline(st, evicted, mode=engine.mode), st
 
 
 @pytest.mark.parametrize("bs,cap,qpk,hd,buffer_len,schedule", [
@@ -261,17 +263,47 @@ def test_lists_of_another_batch_or_a_missing_layer_are_not_used():
 
 
 def test_not_offered_where_keys_depend_on_more_than_the_sum():
-    """the reference's batch > 1 rule / averaged metrics: no position-lazy form -> no handle, the plain fused attention"""
+    """averaged metrics: a key is the sum divided by the key's age -> no handle, the plain fused attention"""
     bs, cap = 16, 320
     seq_lens = [cap + 300, cap + 41]
     st = synth.make_state(num_layers=2, num_kv_heads=4, block_size=bs, seq_lens=seq_lens, seed=5, protected=bs + 1,
                           spare_block_frac=0.8, steady_cap=cap)
-    for kw, mode in ((dict(use_average=True), "per_sequence"), ({}, "reference")):
-        ds = hdev.upload(st, DEV, num_queries_per_kv=4, mode=mode, **kw)
-        cm = ds.cm
-        args = (list(st.seq_indices), ds.seq_positions, [8, 8], ds.context_lens, ds.hanging_token_count,
-                ds.evicted_kv_offsets, list(st.protected))
-        cm.harvest_ahead = True
-        cm.schedule_evictions(*args, total_slots=st.total_slots)
-        assert cm.last_schedule_path().startswith("small_eviction")
-        assert cm.begin_attention_harvest(list(st.seq_indices), ds.seq_positions, list(st.protected), ds.context_lens) is None
+    ds = hdev.upload(st, DEV, num_queries_per_kv=4, mode="per_sequence", use_average=True)
+    cm = ds.cm
+    args = (list(st.seq_indices), ds.seq_positions, [8, 8], ds.context_lens, ds.hanging_token_count,
+            ds.evicted_kv_offsets, list(st.protected))
+    cm.harvest_ahead = True
+    cm.schedule_evictions(*args, total_slots=st.total_slots)
+    assert cm.last_schedule_path().startswith("small_eviction")
+    assert cm.begin_attention_harvest(list(st.seq_indices), ds.seq_positions, list(st.protected), ds.context_lens) is None
+
+
+@pytest.mark.parametrize("bs,cap,schedule", [(16, 320, 0), (16, 640, 0), (16, 640, 2), (32, 512, 0)])
+def test_under_the_batch_rule_of_the_reference(bs, cap, schedule):
+    """mode "reference" with several sequences -- the fork's default: the rule couples the sequences through every head's
+    count of evictable keys (metrics.py:709-729), so the epilogue also counts the masked slots of every head (the last
+    block's tail, keys inside the protected window / outside the metric window, non-finite sums), as the schedule's full
+    collecting pass does.  Two engines again, the oracle's schedule (mode "reference") of the store every step."""
+    ops.set_attention_schedule(schedule)
+    try:
+        L, H = 2, 4
+        seq_lens = [cap + 300, cap + 41, cap + 555]
+        st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs, seq_lens=seq_lens, seed=bs + 1, protected=bs + 1,
+                              spare_block_frac=1.5, steady_cap=cap)
+        a = AttnEngine(copy.deepcopy(st), seq_lens, cap, fused=False, mode="reference", hd=64)
+        b = AttnEngine(copy.deepcopy(st), seq_lens, cap, fused=True, mode="reference", hd=64)
+        sel = [0, 1, 2]
+        for it in range(14):
+            want, ost = _oracle_schedule_of(b, sel)
+            ra, rb = a.compress(sel), b.compress(sel)
+            _same({k: v for k, v in ra.items() if k in ("cmc", "cmi")}, rb, f"step {it} (schedule)")
+            np.testing.assert_array_equal(rb["cmc"].cpu().numpy(), want["cmc"], err_msg=f"step {it}: move counts vs oracle")
+            a.append(); b.append()
+            a.forward(sel); b.forward(sel)
+            _same(a.state(), b.state(), f"step {it} (after the forward)")
+        # (under that rule later sequences free less than they were asked to, so what they are asked grows from step to
+        # step: lists made for a smaller request are not used -- the call then takes its own pass)
+        assert b.offered >= 8 and b.used >= 3, (b.offered, b.used, b.paths)
+        assert not a.used
+    finally:
+        ops.set_attention_schedule(0)

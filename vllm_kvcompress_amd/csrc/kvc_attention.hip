@@ -65,6 +65,7 @@ extern "C" int kvc_paged_attention_decode(const kvc_attention_params* p, kvc_str
     uint8_t* hb = reinterpret_cast<uint8_t*>(p->harvest_buf);
     a.hv.pivot = reinterpret_cast<const uint32_t*>(hb + hl.pivot);
     a.hv.cnt = reinterpret_cast<uint32_t*>(hb + hl.cnt);
+    a.hv.def = reinterpret_cast<uint32_t*>(hb + hl.def);
     a.hv.lists = reinterpret_cast<unsigned long long*>(hb + hl.rec64);
     a.hv.claimed = reinterpret_cast<uint32_t*>(hb + hl.claimed);
     a.hv.seen_ctx = reinterpret_cast<int32_t*>(hb + hl.seen_ctx);

@@ -168,6 +168,8 @@ struct KvFrag {
 struct AttnHarvest {
   const uint32_t* pivot;          // [B]
   uint32_t* cnt;                  // [G] candidates per head, G = B * L * Hkv, g = (b * L + l) * Hkv + h
+  uint32_t* def;                  // [G] masked / non-finite slots of the head's blocks (what the full collecting pass counts:
+                                  //     the reference's batch > 1 rule needs every head's count of evictable keys)
   unsigned long long* lists;      // [G, KREC] (key << 32 | physical slot)
   uint32_t* claimed;              // [CLAIM_SHARDS x 32] logical blocks the epilogues walked
   int32_t* seen_ctx;              // [G] the context length each head's list was made with
@@ -176,7 +178,7 @@ struct AttnHarvest {
   const int32_t* num_protected;   // [B]
   int32_t layer, num_layers, num_sinks;
 };
-struct HarvestCtx { uint32_t pivot; int g; int bound; };   // pivot 0: nothing of this head is listed
+struct HarvestCtx { uint32_t pivot; int g; int bound; };   // g < 0: this head is not harvested; pivot 0: nothing of it is listed
 
 struct AttnArgs {
   void* out;                      // [S, Hq, hd] T
@@ -214,15 +216,32 @@ __device__ __forceinline__ HarvestCtx harvest_ctx(const AttnArgs& a, int seq, in
     atomicAdd(&a.hv.claimed[((unsigned)(seq * a.num_kv_heads + hk) % (unsigned)CLAIM_SHARDS) * 32], (uint32_t)((ctx + bs - 1) / bs));
     if (max_pos < h.bound) atomicAdd(&a.hv.cnt[h.g], (uint32_t)KREC + 1u);
     a.hv.seen_ctx[h.g] = ctx;
+    const uint32_t tail = (uint32_t)((ctx + bs - 1) / bs * bs - ctx);     // the last block's slots behind the context: masked
+    if (tail) atomicAdd(&a.hv.def[h.g], tail);
   }
   return h;
 }
-__device__ __forceinline__ void harvest_key(const AttnArgs& a, const HarvestCtx& h, int64_t slot, float mn, int pos) {
+// a key inside the metric window with its new sum: listed if it is evictable and below the pivot.  Returns 1 if the slot
+// is masked or its key not finite -- the head's deficit, as the schedule's full collecting pass counts it
+__device__ __forceinline__ uint32_t harvest_key(const AttnArgs& a, const HarvestCtx& h, int64_t slot, float mn, int pos) {
   const uint32_t key = float_to_key(mn);
-  if (key < h.pivot && pos <= h.bound && pos >= a.hv.num_sinks) {          // (metrics.py:539-544)
+  const bool in_range = pos <= h.bound && pos >= a.hv.num_sinks;          // (metrics.py:539-544)
+  if (in_range && key < h.pivot) {
     const uint32_t at = atomicAdd(&a.hv.cnt[h.g], 1u);
     if (at < (uint32_t)KREC) a.hv.lists[(int64_t)h.g * KREC + at] = ((unsigned long long)key << 32) | (uint32_t)slot;
   }
+  return (!in_range || key >= KEY_INF) ? 1u : 0u;
+}
+// a key of the context OUTSIDE the metric window (no new sum): masked whenever the window reaches the eviction bound
+// (a head whose window does not is poisoned above)
+__device__ __forceinline__ uint32_t harvest_outside(const AttnArgs& a, const HarvestCtx& h, int pos) {
+  return (pos > h.bound || pos < a.hv.num_sinks) ? 1u : 0u;
+}
+// the deficit a wave counted, once per wave (every lane of the wave calls)
+__device__ __forceinline__ void harvest_flush_def(const AttnArgs& a, const HarvestCtx& h, uint32_t ndef) {
+  if (h.g < 0) return;                                                     // wave-uniform
+  const uint32_t n = wave_reduce_sum(ndef);
+  if (lane_id() == 0 && n) atomicAdd(&a.hv.def[h.g], n);
 }
 
 // fused aggregation (what CompressionMetrics.aggregate_decode does with the stored weights,
@@ -237,14 +256,14 @@ __device__ __forceinline__ float metric_term(float acc, float p, int use_l2) {
 // mo[slot, q0 + q] (16-byte non-temporal stores when rows of 4 heads are aligned: a plain store
 // allocates in L2 and costs 15 % of the whole kernel) or are folded into metrics[slot]
 template <typename F>
-__device__ __forceinline__ void put_metric_row(const AttnArgs& a, float* mo, bool fuse, int64_t slot,
-                                               int qpk, int q0, int nq, F val, const HarvestCtx& hc, int pos) {
+__device__ __forceinline__ uint32_t put_metric_row(const AttnArgs& a, float* mo, bool fuse, int64_t slot,
+                                                   int qpk, int q0, int nq, F val, const HarvestCtx& hc, int pos) {
   if (fuse) {
     float acc = 0.0f;
     for (int q = 0; q < nq; ++q) acc = metric_term(acc, val(q), a.use_l2);
     const float mn = __fadd_rn(a.fused_metrics[slot], acc);
     a.fused_metrics[slot] = mn;
-    if (hc.pivot) harvest_key(a, hc, slot, mn, pos);
+    return hc.g >= 0 ? harvest_key(a, hc, slot, mn, pos) : 0u;
   } else if (((qpk | nq) & 3) == 0) {
     for (int q = 0; q < nq; q += 4) {
       f32x4 v;
@@ -254,6 +273,7 @@ __device__ __forceinline__ void put_metric_row(const AttnArgs& a, float* mo, boo
   } else {
     for (int q = 0; q < nq; ++q) __builtin_nontemporal_store(val(q), mo + slot * qpk + q0 + q);
   }
+  return 0u;
 }
 
 __device__ __forceinline__ float group_max(float v) {     // over the 4 lanes sharing lane&15
@@ -486,13 +506,18 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
     __syncthreads();
     const float* inv_q = red_max[0];
     const HarvestCtx hc = fuse ? harvest_ctx(a, seq, hk, max_pos, ctx, BS, tid == 0 && q0 == 0) : HarvestCtx{0u, -1, 0};
+    uint32_t ndef = 0;
 #pragma unroll
     for (int k = 0; k < ATT_CHUNK / 64; ++k) {
       const int tl = k * 64 + lane;
-      if (mpos[k] > max_pos) continue;                     // .cu:305-312 (also: token >= ctx)
-      put_metric_row(a, mo, fuse, mslot[k], qpk, q0, nq,
-                     [&](int q) { return __fmul_rn(pw[q * ROW + tl], inv_q[q]); }, hc, mpos[k]);
+      if (mpos[k] > max_pos) {                             // .cu:305-312 (also: token >= ctx)
+        if (hc.g >= 0 && mpos[k] != 0x7FFFFFFF) ndef += harvest_outside(a, hc, mpos[k]);
+        continue;
+      }
+      ndef += put_metric_row(a, mo, fuse, mslot[k], qpk, q0, nq,
+                             [&](int q) { return __fmul_rn(pw[q * ROW + tl], inv_q[q]); }, hc, mpos[k]);
     }
+    harvest_flush_def(a, hc, ndef);
   }
 }
 
@@ -751,6 +776,7 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
       // 64 tokens -- measured 6 % of the whole kernel at 256 x 4k contexts.  The block-table entries, positions and
       // old sums of GI iterations are requested together, before anything is stored.
       constexpr int GI = 4, K2 = ATT_CHUNK / 64;
+      uint32_t ndef = 0;
       for (int it0 = 0; it0 < niter; it0 += GI) {
         if (it0 * STEP + w * ATT_CHUNK >= ctx) break;
         int64_t slot[GI][K2];
@@ -783,17 +809,21 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
           const float* fq = wfac[w];
 #pragma unroll
           for (int k = 0; k < K2; ++k) {
-            if (kpos[j][k] > max_pos) continue;              // (also: token >= ctx)
+            if (kpos[j][k] > max_pos) {                      // (also: token >= ctx)
+              if (hc.g >= 0 && slot[j][k] >= 0) ndef += harvest_outside(a, hc, kpos[j][k]);
+              continue;
+            }
             const int tok = tok_w0 + k * 64 + lane;
             float acc = 0.0f;
             for (int q = 0; q < nq; ++q) acc = metric_term(acc, __fmul_rn(P[q * prow + tok], fq[q]), a.use_l2);
             const float mn = __fadd_rn(mold[j][k], acc);
             a.fused_metrics[slot[j][k]] = mn;
-            if (hc.pivot) harvest_key(a, hc, slot[j][k], mn, kpos[j][k]);
+            if (hc.g >= 0) ndef += harvest_key(a, hc, slot[j][k], mn, kpos[j][k]);
           }
           __builtin_amdgcn_wave_barrier();             // wfac[w] is rewritten by the next iteration
         }
       }
+      harvest_flush_def(a, hc, ndef);
       return;
     }
     for (int it = 0; it < niter; ++it) {
@@ -942,6 +972,11 @@ __global__ __launch_bounds__(256) void paged_attention_metric_rescale_kernel(Att
     float mold[K];                                     // (fuse: the old sums, requested with the weights -- see the single-pass kernel)
 #pragma unroll
     for (int k = 0; k < K; ++k) mold[k] = (fuse && ok[k] && posv[k] <= max_pos) ? a.fused_metrics[slot[k]] : 0.0f;
+    uint32_t ndef = 0;
+    if (hc.g >= 0)
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        if (ok[k] && posv[k] > max_pos) ndef += harvest_outside(a, hc, posv[k]);
     for (int qb = 0; qb < qpk; qb += 4) {
       f32x4 t[K];
 #pragma unroll
@@ -962,19 +997,24 @@ __global__ __launch_bounds__(256) void paged_attention_metric_rescale_kernel(Att
           for (int q = 0; q < 4; ++q) acc = metric_term(acc, v[q], a.use_l2);
           const float mn = __fadd_rn(mold[k], acc);
           a.fused_metrics[slot[k]] = mn;
-          if (hc.pivot) harvest_key(a, hc, slot[k], mn, posv[k]);
+          if (hc.g >= 0) ndef += harvest_key(a, hc, slot[k], mn, posv[k]);
         } else {
           *reinterpret_cast<f32x4*>(a.kv_metric_out + slot[k] * qpk + qb) = v;
         }
       }
     }
+    harvest_flush_def(a, hc, ndef);
   } else {
+    uint32_t ndef = 0;
     for (int k = 0; k < K; ++k) {
       const int i = chunk * ATT_RS_TOK + k * 256 + tid;
       if (i >= ctx) break;
       const int64_t slot = (int64_t)bt[i / BS] * BS + (i % BS);
       const int kpos = a.kv_position[slot];
-      if (kpos > max_pos) continue;
+      if (kpos > max_pos) {
+        if (hc.g >= 0) ndef += harvest_outside(a, hc, kpos);
+        continue;
+      }
       const int pj = i / ATT_PART - p0;
       float acc = 0.0f;
       for (int q = 0; q < qpk; ++q) {
@@ -985,9 +1025,10 @@ __global__ __launch_bounds__(256) void paged_attention_metric_rescale_kernel(Att
       if (fuse) {
         const float mn = __fadd_rn(a.fused_metrics[slot], acc);
         a.fused_metrics[slot] = mn;
-        if (hc.pivot) harvest_key(a, hc, slot, mn, kpos);
+        if (hc.g >= 0) ndef += harvest_key(a, hc, slot, mn, kpos);
       }
     }
+    harvest_flush_def(a, hc, ndef);
   }
 }
 

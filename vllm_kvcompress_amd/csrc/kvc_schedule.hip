@@ -221,11 +221,15 @@ __global__ __launch_bounds__(256) void harvest_seen_seq_kernel(const int32_t* __
 }
 }  // namespace kvc
 
-// harvest in the decode attention's fused-metric epilogue (kvc_attention_kernels.h): the position-lazy form only
-// (the epilogue makes a key from the sum alone and does not count the masked slots of a head)
+// harvest in the decode attention's fused-metric epilogue (kvc_attention_kernels.h): keys that are the sum alone (no
+// averaged metrics, no position bias: the epilogue does not have the bias table) -- the position-lazy form, or the
+// reference's batch > 1 rule, for which the epilogue counts every head's masked slots as the full collecting pass does
+static bool attention_harvest_plan(const kvc_schedule_params& p) {
+  return harvest_plan(p) && !p.use_average && p.bias == nullptr && p.schedule_path != 3;
+}
 extern "C" int32_t kvc_attention_harvest_eligible(const kvc_schedule_params* p) {
   if (p == nullptr) return 0;
-  return (harvest_plan(*p) && lazy_plan(*p)) ? 1 : 0;
+  return attention_harvest_plan(*p) ? 1 : 0;
 }
 extern "C" int kvc_attention_harvest_begin(const kvc_schedule_params* pp, kvc_stream_t stream) {
   using namespace kvc;
@@ -521,7 +525,8 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
         ws.st_def = reinterpret_cast<uint32_t*>(hb + hl.def);
         ws.rec64 = reinterpret_cast<uint64_t*>(hb + hl.rec64);
         if (p.harvest & 8) {                         // made by the attention's epilogue: verified against this call's batch
-          if (!lazy) return fail_invalid("schedule_evictions: lists made by the attention's epilogue need the position-lazy form");
+          if (!attention_harvest_plan(p))
+            return fail_invalid("schedule_evictions: lists made by the attention's epilogue cannot serve averaged or biased metrics");
           ws.hv_seen_ctx = reinterpret_cast<const int32_t*>(hb + hl.seen_ctx);
           ws.hv_seen_seq = reinterpret_cast<const int32_t*>(hb + hl.seen_seq);
         }

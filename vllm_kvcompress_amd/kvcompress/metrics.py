@@ -494,9 +494,9 @@ class CompressionMetrics:
         next iteration, scheduler.py:256-280).  ``attention_seq_indices``: the sequence index (``seq_index_by_block``
         value) of every sequence of the attention batch, in its order; default: the compression batch itself.
         Returns None -- and the caller runs the attention without ``harvest=`` -- when lists cannot be made: no pivots
-        yet (first step, another batch), a schedule that is not the small-eviction one in its position-lazy form
-        (use_average, a position bias, the reference's batch > 1 rule: their keys depend on more than the sum), under
-        stream capture, tensors without version counters.  Same contract as ``aggregate_decode_and_harvest``: the
+        yet (first step, another batch), a schedule that is not the small-eviction one, keys that are more than the
+        sum (use_average, a position bias), stream capture, tensors without version counters.  The reference's
+        batch > 1 rule (the fork's default mode) is served: the epilogue then also counts every head's masked slots.  Same contract as ``aggregate_decode_and_harvest``: the
         lists are used only by a schedule call with these very arguments and an untouched store in between; anything
         else, and lists that fall short, take the usual pass / are redone on the device.  Results are identical."""
         if self.random or not self.record_decoding_metrics:
