@@ -170,6 +170,22 @@ def test_a_device_tensor_of_counts_under_stream_capture_is_the_only_unknown_hint
         np.testing.assert_array_equal(x.cpu().numpy(), want[key], err_msg=key)
 
 
+@pytest.mark.parametrize("bs,evicted", [(16, [6, 9]), (16, [3, 12]), (32, [4, 5]), (8, [12, 20])])
+def test_lists_longer_than_a_wave(bs, evicted):
+    """few, long heads that free several blocks each: their candidate lists hold 65 ... 256 entries -- the path of the
+    one-launch records / selection / emission kernel that sorts a list through LDS instead of ranking it in registers
+    (and, with KVC_TOPK_CHAIN=1, stream_records_kernel's); one short-listed sequence next to them"""
+    for seed in range(3):
+        st = synth.make_state(num_layers=1, num_kv_heads=2, block_size=bs, seq_lens=[6000, 9000, 700], seed=seed, protected=bs + 1,
+                              steady_cap=2048 // bs * bs)
+        ev = evicted + [1]
+        want = oracle_pipeline(st, ev, mode="per_sequence")
+        got, how = _run(st, ev, 2, "per_sequence")
+        assert how.startswith("small_eviction"), how
+        for key in KEYS:
+            np.testing.assert_array_equal(got[key], want[key], err_msg=f"{key} bs={bs} evicted={ev} seed={seed}")
+
+
 @pytest.mark.parametrize("ties", [1, 3, 6])
 def test_small_eviction_schedule_with_metric_ties(ties):
     """canonical tie order: slots by (metric, physical block, offset), thresholds by (threshold,
