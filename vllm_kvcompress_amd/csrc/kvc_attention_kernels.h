@@ -232,6 +232,24 @@ __device__ __forceinline__ uint32_t harvest_key(const AttnArgs& a, const Harvest
   }
   return (!in_range || key >= KEY_INF) ? 1u : 0u;
 }
+// the same with the candidates staged in LDS (the single-pass kernel: one workgroup owns the head, so ONE returning
+// global atomic per workgroup reserves the list entries of all its candidates instead of one round trip per wave and
+// step -- measured 1 % of the kernel); entries beyond the staging area go straight to the list
+__device__ __forceinline__ uint32_t harvest_key_staged(const AttnArgs& a, const HarvestCtx& h, int64_t slot, float mn, int pos,
+                                                       unsigned long long* cand, uint32_t* cand_n, uint32_t cand_cap) {
+  const uint32_t key = float_to_key(mn);
+  const bool in_range = pos <= h.bound && pos >= a.hv.num_sinks;
+  if (in_range && key < h.pivot) {
+    const unsigned long long e = ((unsigned long long)key << 32) | (uint32_t)slot;
+    const uint32_t i = atomicAdd(cand_n, 1u);
+    if (i < cand_cap) cand[i] = e;
+    else {
+      const uint32_t at = atomicAdd(&a.hv.cnt[h.g], 1u);
+      if (at < (uint32_t)KREC) a.hv.lists[(int64_t)h.g * KREC + at] = e;
+    }
+  }
+  return (!in_range || key >= KEY_INF) ? 1u : 0u;
+}
 // a key of the context OUTSIDE the metric window (no new sum): masked whenever the window reaches the eviction bound
 // (a head whose window does not is poisoned above)
 __device__ __forceinline__ uint32_t harvest_outside(const AttnArgs& a, const HarvestCtx& h, int pos) {
@@ -759,6 +777,7 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
     // per query: global max M and normaliser 1 / (L + 1e-6), once per workgroup, then per wave
     // and iteration the factor exp(m_used - M) / (L + 1e-6) of each query head
     __shared__ float fin_m[ATT_NQ], fin_i[ATT_NQ], wfac[NW][ATT_NQ];
+    __shared__ uint32_t cand_n, cand_base;
     if (tid < nq) {
       const float Mg = wg_max(tid);
       float L = 0.0f;
@@ -768,14 +787,21 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
       fin_m[tid] = Mg;
       fin_i[tid] = __fdividef(1.0f, L + 1e-6f);
     }
+    if (tid == 0) cand_n = 0;
     __syncthreads();
     const bool fuse = a.fused_metrics != nullptr;
+    // harvest: candidates are staged where the waves' partial outputs were (free behind the barrier above)
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(Ol);
+    const uint32_t cand_cap = (uint32_t)(4 * nqr * HD / 2);
     if (fuse) {
       // metrics[slot] += sum_q p^2 is a read-modify-write: with one token after the other every store stands between
       // the loads behind it (the compiler cannot tell that slots differ) and a wave pays a full memory round trip per
       // 64 tokens -- measured 6 % of the whole kernel at 256 x 4k contexts.  The block-table entries, positions and
       // old sums of GI iterations are requested together, before anything is stored.
-      constexpr int GI = 4, K2 = ATT_CHUNK / 64;
+#ifndef KVC_ATT_GI
+#define KVC_ATT_GI 4
+#endif
+      constexpr int GI = KVC_ATT_GI, K2 = ATT_CHUNK / 64;
       uint32_t ndef = 0;
       for (int it0 = 0; it0 < niter; it0 += GI) {
         if (it0 * STEP + w * ATT_CHUNK >= ctx) break;
@@ -818,12 +844,24 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
             for (int q = 0; q < nq; ++q) acc = metric_term(acc, __fmul_rn(P[q * prow + tok], fq[q]), a.use_l2);
             const float mn = __fadd_rn(mold[j][k], acc);
             a.fused_metrics[slot[j][k]] = mn;
-            if (hc.g >= 0) ndef += harvest_key(a, hc, slot[j][k], mn, kpos[j][k]);
+            if (hc.g >= 0) ndef += harvest_key_staged(a, hc, slot[j][k], mn, kpos[j][k], cand, &cand_n, cand_cap);
           }
           __builtin_amdgcn_wave_barrier();             // wfac[w] is rewritten by the next iteration
         }
       }
       harvest_flush_def(a, hc, ndef);
+      if (hc.g >= 0) {                                 // (workgroup-uniform: one head per workgroup)
+        __syncthreads();
+        const uint32_t n = min(cand_n, cand_cap);
+        if (n) {
+          if (tid == 0) cand_base = atomicAdd(&a.hv.cnt[hc.g], n);
+          __syncthreads();
+          for (uint32_t i = tid; i < n; i += 64 * NW) {
+            const uint32_t at = cand_base + i;
+            if (at < (uint32_t)KREC) a.hv.lists[(int64_t)hc.g * KREC + at] = cand[i];
+          }
+        }
+      }
       return;
     }
     for (int it = 0; it < niter; ++it) {
