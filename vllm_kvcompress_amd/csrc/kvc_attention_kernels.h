@@ -803,26 +803,26 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
 #endif
       constexpr int GI = KVC_ATT_GI, K2 = ATT_CHUNK / 64;
       uint32_t ndef = 0;
-      for (int it0 = 0; it0 < niter; it0 += GI) {
-        if (it0 * STEP + w * ATT_CHUNK >= ctx) break;
-        int64_t slot[GI][K2];
-        int kpos[GI][K2];
-        float mold[GI][K2];
+      struct Grp { int64_t slot[GI][K2]; int kpos[GI][K2]; float mold[GI][K2]; };
+      auto has_group = [&](int it0) { return it0 < niter && it0 * STEP + w * ATT_CHUNK < ctx; };      // wave-uniform
+      auto load_group = [&](Grp& G, int it0) {
 #pragma unroll
         for (int j = 0; j < GI; ++j)
 #pragma unroll
           for (int k = 0; k < K2; ++k) {
             const int tok = (it0 + j) * STEP + w * ATT_CHUNK + k * 64 + lane;
-            slot[j][k] = (it0 + j < niter && tok < ctx) ? (int64_t)bt[tok / BS] * BS + (tok % BS) : (int64_t)-1;
+            G.slot[j][k] = (it0 + j < niter && tok < ctx) ? (int64_t)bt[tok / BS] * BS + (tok % BS) : (int64_t)-1;
           }
 #pragma unroll
         for (int j = 0; j < GI; ++j)
 #pragma unroll
-          for (int k = 0; k < K2; ++k) kpos[j][k] = slot[j][k] >= 0 ? a.kv_position[slot[j][k]] : 0x7FFFFFFF;
+          for (int k = 0; k < K2; ++k) G.kpos[j][k] = G.slot[j][k] >= 0 ? a.kv_position[G.slot[j][k]] : 0x7FFFFFFF;
 #pragma unroll
         for (int j = 0; j < GI; ++j)
 #pragma unroll
-          for (int k = 0; k < K2; ++k) mold[j][k] = kpos[j][k] <= max_pos ? a.fused_metrics[slot[j][k]] : 0.0f;
+          for (int k = 0; k < K2; ++k) G.mold[j][k] = G.kpos[j][k] <= max_pos ? a.fused_metrics[G.slot[j][k]] : 0.0f;
+      };
+      auto process_group = [&](const Grp& G, int it0) {
 #pragma unroll
         for (int j = 0; j < GI; ++j) {
           const int it = it0 + j;
@@ -835,19 +835,30 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
           const float* fq = wfac[w];
 #pragma unroll
           for (int k = 0; k < K2; ++k) {
-            if (kpos[j][k] > max_pos) {                      // (also: token >= ctx)
-              if (hc.g >= 0 && slot[j][k] >= 0) ndef += harvest_outside(a, hc, kpos[j][k]);
+            if (G.kpos[j][k] > max_pos) {                    // (also: token >= ctx)
+              if (hc.g >= 0 && G.slot[j][k] >= 0) ndef += harvest_outside(a, hc, G.kpos[j][k]);
               continue;
             }
             const int tok = tok_w0 + k * 64 + lane;
             float acc = 0.0f;
             for (int q = 0; q < nq; ++q) acc = metric_term(acc, __fmul_rn(P[q * prow + tok], fq[q]), a.use_l2);
-            const float mn = __fadd_rn(mold[j][k], acc);
-            a.fused_metrics[slot[j][k]] = mn;
-            if (hc.g >= 0) ndef += harvest_key_staged(a, hc, slot[j][k], mn, kpos[j][k], cand, &cand_n, cand_cap);
+            const float mn = __fadd_rn(G.mold[j][k], acc);
+            a.fused_metrics[G.slot[j][k]] = mn;
+            if (hc.g >= 0) ndef += harvest_key_staged(a, hc, G.slot[j][k], mn, G.kpos[j][k], cand, &cand_n, cand_cap);
           }
           __builtin_amdgcn_wave_barrier();             // wfac[w] is rewritten by the next iteration
         }
+      };
+      // ... and the next group's operands are requested before the current group is worked off (two register sets):
+      // one exposed round trip per wave instead of one per group
+      Grp ga, gb;
+      if (has_group(0)) load_group(ga, 0);
+      for (int it0 = 0; has_group(it0); it0 += 2 * GI) {
+        if (has_group(it0 + GI)) load_group(gb, it0 + GI);
+        process_group(ga, it0);
+        if (!has_group(it0 + GI)) break;
+        if (has_group(it0 + 2 * GI)) load_group(ga, it0 + 2 * GI);
+        process_group(gb, it0 + GI);
       }
       harvest_flush_def(a, hc, ndef);
       if (hc.g >= 0) {                                 // (workgroup-uniform: one head per workgroup)
