@@ -208,6 +208,7 @@ def test_keys_that_depend_on_positions_are_harvested_with_the_position_rows():
                           steady_cap=160)
     ds = hdev.upload(st, DEV, num_queries_per_kv=4, mode="per_sequence", use_average=True)
     cm = ds.cm
+    cm.schedule_path = 0                 # (the bulk call below is about the automatic choice: KVC_SCHEDULE_PATH must not decide)
     temp = np.random.default_rng(0).random((st.num_blocks, 16, 4)).astype(np.float32)
     for it in range(4):
         cm.temp_metrics.copy_(torch.from_numpy(temp))
