@@ -879,13 +879,20 @@ def decode_step_compare(a2, st, ds, evicted, k_cache, v_cache, cmi, cmc, device,
         torch.cuda.empty_cache()
         return {"skipped": "does not fit"}
     saved = (cm.num_queries_per_kv, cm._temp_metrics, cm.harvest_ahead)
+    saved_spec = cm.speculative_harvest
     cm.num_queries_per_kv, cm._temp_metrics = qpk, temp
     seq_idx, prot = list(st.seq_indices), list(st.protected)
     ev = lambda: torch.cuda.Event(enable_timing=True)
     out, keep = {}, {}
-    for variant in ("two_sweeps", "harvest_ahead"):
+    # "fork_flow": the fork's flow with nothing changed -- aggregate_decode() at the end of an iteration, schedule_evictions
+    # at the start of the next -- where aggregate_decode() harvests for the call it predicts (the last call's batch, one token
+    # further on: CompressionMetrics.speculative_harvest, the default).  A decode step advances every sequence by a token, so
+    # this variant's schedule calls get positions that advance by one per step (the other two keep the static store's).
+    pos_steps = [ds.seq_positions + j for j in range(steps + warmup + 1)]
+    for variant in ("two_sweeps", "fork_flow", "harvest_ahead"):       # (harvest_ahead last: the gate below checks its outputs)
         cm.metrics.copy_(m0)
-        cm.harvest_ahead = variant == "harvest_ahead"
+        cm.harvest_ahead = True if variant == "harvest_ahead" else (None if variant == "fork_flow" else False)
+        cm.speculative_harvest = variant == "fork_flow"
         cm._hv = cm._hv_lists = None
         misses0, used = cm.harvest_misses, 0
         marks = [[ev() for _ in range(5)] for _ in range(steps)]
@@ -895,13 +902,14 @@ def decode_step_compare(a2, st, ds, evicted, k_cache, v_cache, cmi, cmc, device,
         for i in range(-warmup, steps):
             rec = i >= 0
             del eli, ekc, ebc
+            pos_now = pos_steps[i + warmup] if variant == "fork_flow" else ds.seq_positions
             if rec: marks[i][0].record()
-            if cm.harvest_ahead:
+            if variant == "harvest_ahead":
                 cm.aggregate_decode_and_harvest(seq_idx, ds.seq_positions, prot, ds.context_lens, total_slots=N, fuse_clear=False)
             else:
                 cm.aggregate_decode(fuse_clear=False)
             if rec: marks[i][1].record()
-            eli, ekc, ebc = cm.schedule_evictions(seq_idx, ds.seq_positions, evicted, ds.context_lens,
+            eli, ekc, ebc = cm.schedule_evictions(seq_idx, pos_now, evicted, ds.context_lens,
                                                   ds.hanging_token_count, ds.evicted_kv_offsets, prot, total_slots=N)
             used += int(rec and cm.last_harvest_used)
             if rec: marks[i][2].record()
@@ -917,16 +925,28 @@ def decode_step_compare(a2, st, ds, evicted, k_cache, v_cache, cmi, cmc, device,
             "stages_ms": {"S0_aggregate_decode": ms(0, 1), "S1_schedule_evictions": ms(1, 2), "S2_schedule_moves": ms(2, 3),
                           "S3_execute_moves": ms(3, 4)},
             "S0_GBps": slots * (4 * qpk + 8) / (ms(0, 1) * 1e-3) / 1e9,
-            "S0_roofline": {"kernel": "kvc::aggregate_harvest_kernel" if cm.harvest_ahead else "kvc::aggregate_decode_q4_kernel",
+            "S0_roofline": {"kernel": "kvc::aggregate_harvest_kernel" if variant != "two_sweeps" else "kvc::aggregate_decode_q4_kernel",
                             "bound": "hbm", "achieved": slots * (4 * qpk + 8) / (ms(0, 1) * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                             "unit": "GB/s", "frac": slots * (4 * qpk + 8) / (ms(0, 1) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                             "algorithmic_bytes_per_launch": slots * (4 * qpk + 8),
-                            "traffic": _committed_s0_traffic("aggregate_harvest" if cm.harvest_ahead else "aggregate_decode_q4")[0],
-                            "traffic_source": f"profiles/{_committed_s0_traffic('aggregate_harvest' if cm.harvest_ahead else 'aggregate_decode_q4')[1]} "
+                            "traffic": _committed_s0_traffic("aggregate_harvest" if variant != "two_sweeps" else "aggregate_decode_q4")[0],
+                            "traffic_source": f"profiles/{_committed_s0_traffic('aggregate_harvest' if variant != 'two_sweeps' else 'aggregate_decode_q4')[1]} "
                                               "(a separately profiled run of tools/decode_step.py, NOT a measurement of this run: rocprofv3 --pmc "
                                               "FETCH_SIZE / WRITE_SIZE in separate passes; 2 x FETCH + WRITE)",
                             "timing": "the S0 stage: HIP events on the launch stream around the call (one kernel + the counters' fill)"},
             "S1_schedule": cm.last_schedule_path(), "harvested_steps": used, "harvest_misses": cm.harvest_misses - misses0}
+        if variant == "fork_flow":
+            # its own verdict: the last step's schedule against the oracle's schedule of the store, at the last step's positions
+            import copy as _copy2
+            st3 = _copy2.copy(st)
+            st3.metrics = cm.metrics.cpu().numpy()
+            st3.seq_positions = pos_steps[steps + warmup - 1].cpu().numpy()
+            pf = parity_gate_sampled(a2, st3, evicted, dict(eli=eli, ekc=ekc, ebc=ebc, cmi=cmi, cmc=cmc), k_cache, v_cache,
+                                     None, None, schedule_only=True, mode=a2.mode)
+            out[variant]["parity_checked"] = pf
+            out[variant]["what"] = ("aggregate_decode() then schedule_evictions, as the fork calls them; aggregate_decode() harvests for the "
+                                    "call it predicts (positions + 1 per step), the schedule call verifies on the device")
+            continue
         keep[variant] = (cm.metrics.clone(), eli.clone(), ekc.clone(), ebc.clone(), cmc.clone(),
                          torch.cat([cmi[o:o + int(c)] for o, c in zip(st.evicted_kv_offsets.reshape(-1)[:64].tolist(),
                                                                       cmc.reshape(-1)[:64].tolist())]) if N else cmi[:0])
@@ -950,8 +970,12 @@ def decode_step_compare(a2, st, ds, evicted, k_cache, v_cache, cmi, cmc, device,
                          "the reference's batch > 1 rule in the oracle's two-stage form: every sequence's freed blocks, and the full "
                          "schedule of a sample of the sequences")
                       + "; S0's sums against the oracle: tests/test_gpu_harvest.py, tests/test_gpu_parity.py)")
+    if out.get("fork_flow", {}).get("parity_checked", {}).get("bit_exact") is False:
+        parity["bit_exact"] = False
+        parity["fork_flow_mismatched"] = out["fork_flow"]["parity_checked"].get("mismatched")
     cm.metrics.copy_(m0)
     cm.num_queries_per_kv, cm._temp_metrics, cm.harvest_ahead = saved
+    cm.speculative_harvest = saved_spec
     cm._hv = cm._hv_lists = None
     if a2.block_size in (16, 32) and a2.head_size in (64, 128):
         del wm, wp, keep

@@ -323,6 +323,14 @@ typedef struct kvc_schedule_params {
                                                * error. */
   float harvest_widen;                        /* bit 1: allowance for keys that the next step's attention lifts over
                                                * the pivot, as a fraction of Tgt (<= 0: 0.25) */
+  int32_t harvest_position_delta;             /* ABI version 6, kvc_aggregate_decode_harvest only: the schedule call
+                                               * that will follow has seq_positions[i] + delta (a caller that harvests
+                                               * for the NEXT iteration's call from the arguments of the last one: a
+                                               * decode step adds one token per sequence).  With it, context_lens may be
+                                               * NULL there (not known yet): a block belongs to the batch by its metadata
+                                               * alone.  Lists made this way carry the positions and protected windows
+                                               * they were made with; the schedule call takes them with harvest bits
+                                               * 0 | 3 and verifies on the device. */
   /* outputs */
   int32_t* evicted_logical_indices;           /* [N] */
   int32_t* evicted_kv_count;                  /* [B,L,H] */

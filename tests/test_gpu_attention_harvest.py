@@ -33,12 +33,15 @@ class AttnEngine:
     into the store and harvests; else it writes temp_metrics and aggregate_decode runs behind the forward."""
 
     def __init__(self, st, seq_lens, cap, fused, qpk=4, hd=64, buffer_len=0, protected=None, seed=7, dtype=torch.float16,
-                 mode="per_sequence"):
+                 mode="per_sequence", speculative=False):
         self.bs, self.L, self.H, self.cap, self.fused, self.qpk, self.hd = st.block_size, st.num_layers, st.num_kv_heads, cap, fused, qpk, hd
         self.mode = mode
         self.ds = hdev.upload(st, DEV, num_queries_per_kv=qpk, mode=mode)
         self.cm = self.ds.cm
         self.cm.strict_fallback = True
+        # (the reference-flow engine is the baseline: its aggregate_decode() is the plain pass -- unless `speculative`: the
+        # fork's flow unchanged, aggregate_decode() harvesting for the next call by itself)
+        self.cm.speculative_harvest = speculative
         self.B = len(seq_lens)
         B, M = self.B, st.block_tables.shape[3] + 6
         bt = np.zeros((self.L, B, self.H, M), np.int32)
@@ -307,3 +310,31 @@ def test_under_the_batch_rule_of_the_reference(bs, cap, schedule):
         assert not a.used
     finally:
         ops.set_attention_schedule(0)
+
+
+@pytest.mark.parametrize("mode,cap", [("per_sequence", 320), ("per_sequence", 640), ("reference", 320)])
+def test_the_unchanged_fork_flow_with_aggregate_decode_predicting_the_next_call(mode, cap):
+    """The fork's flow with NOTHING changed -- attention -> temp_metrics, ``aggregate_decode()`` at the end of the
+    iteration, the scheduler at the start of the next (llm_engine.py:1556-1634) -- twice: once with the plain aggregation
+    pass, once with ``CompressionMetrics.speculative_harvest`` (the default): aggregate_decode() harvests for the call the
+    next iteration will most likely make (the last call's batch, positions + 1).  Identical state after every step; the
+    second engine's schedule calls run on lists, checked on the device against what the call really is."""
+    bs, L, H = 16, 2, 4
+    seq_lens = [cap + 300, cap + 41, cap + 555]
+    st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs, seq_lens=seq_lens, seed=21, protected=bs + 1,
+                          spare_block_frac=1.5, steady_cap=cap)
+    a = AttnEngine(copy.deepcopy(st), seq_lens, cap, fused=False, mode=mode)
+    c = AttnEngine(copy.deepcopy(st), seq_lens, cap, fused=False, mode=mode, speculative=True)
+    sel = [0, 1, 2]
+    for it in range(24):
+        want, ost = _oracle_schedule_of(c, sel)
+        ra, rc = a.compress(sel), c.compress(sel)
+        _same({k: v for k, v in ra.items() if k in ("cmc", "cmi")}, rc, f"step {it} (schedule)")
+        np.testing.assert_array_equal(rc["cmc"].cpu().numpy(), want["cmc"], err_msg=f"step {it}: move counts vs oracle")
+        if rc["used"]:
+            assert c.cm.last_harvest_kind == "aggregation pass, ahead of the call"
+        a.append(); c.append()
+        a.forward(sel); c.forward(sel)
+        _same(a.state(), c.state(), f"step {it} (after the forward)")
+    assert not a.used
+    assert c.used >= (18 if mode == "per_sequence" else 3), (c.used, c.paths)

@@ -163,6 +163,9 @@ def test_default_line_carries_the_other_configurations():
     # ... and configs[2] as a whole decode step (S0 + S1 + S2 + S3): two sweeps of the store against harvest-ahead
     ds = oc["c3"]["decode_step"]
     assert ds["parity_checked"]["bit_exact"] is True and ds["parity_checked"]["variants_agree"] is True
+    # ... and in the fork's own flow (aggregate_decode() predicting the next call): on lists, oracle-checked
+    ff = ds["fork_flow"]
+    assert ff["harvested_steps"] == 2 and ff["parity_checked"]["bit_exact"] is True and ff["S1_schedule"] == "small_eviction"
     # ... and as the step without a sweep of the store: the attention's epilogues make the lists, no aggregate_decode
     fa = ds["fused_attention"]
     assert fa["parity_checked"]["bit_exact"] is True and fa["steps_on_the_epilogues_lists"] == 2, fa

@@ -30,7 +30,7 @@ class Loop:
     """one CompressionMetrics kept over the steps; the host state (oracle side) is copied into its
     tensors in front of every step"""
 
-    def __init__(self, L, H, bs, seq_lens, cap, qpk=4, seed=3, use_l2=True, stride=0, mode="per_sequence"):
+    def __init__(self, L, H, bs, seq_lens, cap, qpk=4, seed=3, use_l2=True, stride=0, mode="per_sequence", speculative=False):
         self.L, self.H, self.bs, self.cap, self.qpk, self.use_l2, self.mode = L, H, bs, cap, qpk, use_l2, mode
         self.seq_lens = list(seq_lens)
         self.st = synth.make_state(num_layers=L, num_kv_heads=H, block_size=bs, seq_lens=seq_lens, seed=seed,
@@ -41,6 +41,7 @@ class Loop:
         self.cm.use_l2 = use_l2
         assert self.cm.harvest_ahead is None     # (the first aggregate_decode_and_harvest turns it on)
         self.cm.strict_fallback = True          # (the flag word is looked at in the call itself)
+        self.cm.speculative_harvest = speculative   # (plain aggregate_decode() harvesting ahead of the call: its own tests below)
         self.cm.sample_stride = stride
         self.k_np, self.v_np = synth.make_caches_u16(seed, self.st.num_blocks, 32, bs)
         self.rng = np.random.default_rng(seed)
@@ -104,7 +105,7 @@ class Loop:
         for key in KEYS:
             np.testing.assert_array_equal(got[key], want[key], err_msg=f"step {self.step_no} (sel {sel}, k {evicted}): {key}")
         if cm.last_schedule[2] == 1:
-            assert cm.last_schedule_reason.endswith("[lists: the aggregation pass]" if cm.last_harvest_used else
+            assert cm.last_schedule_reason.endswith(f"[lists: the {cm.last_harvest_kind}]" if cm.last_harvest_used else
                                                     "[pivots: the call before]" if cm.last_pivot_memory_used else
                                                     "[pivots: sampled]"), cm.last_schedule_reason
         info = dict(harvested=harvested, used=cm.last_harvest_used, path=cm.last_schedule_path(), evicted=evicted,
@@ -258,11 +259,12 @@ class _Engine:
     """the block state of a few resident sequences on the device, stepped with the package's own ops
     (scheduler -> compaction -> append_slots), as the fork's engine steps its own"""
 
-    def __init__(self, st, seq_lens, cap, qpk, deferred):
+    def __init__(self, st, seq_lens, cap, qpk, deferred, speculative=False):
         from vllm_kvcompress_amd.kvcompress.scheduler import CompressionScheduler
         self.bs, self.L, self.H, self.cap, self.deferred = st.block_size, st.num_layers, st.num_kv_heads, cap, deferred
         self.ds = hdev.upload(st, DEV, num_queries_per_kv=qpk, mode="per_sequence")
         self.cm = self.ds.cm
+        self.cm.speculative_harvest = speculative
         B, M = len(seq_lens), st.block_tables.shape[3] + 4
         bt = np.zeros((self.L, B, self.H, M), np.int32)
         bt[..., :st.block_tables.shape[3]] = st.block_tables
@@ -422,3 +424,65 @@ def test_under_inference_mode_no_lists_are_made():
         assert not info["harvested"] and not info["used"] and info["path"] == "small_eviction", info
     lp.step()
     assert lp.step()["used"]
+
+
+# ---- aggregate_decode() that harvests ahead of the call by itself (CompressionMetrics.speculative_harvest) ----------------
+@pytest.mark.parametrize("bs,qpk,mode", [(16, 4, "per_sequence"), (32, 8, "per_sequence"), (8, 4, "per_sequence"), (16, 4, "reference")])
+def test_plain_aggregate_decode_harvests_for_the_next_call_in_the_fork_s_flow(bs, qpk, mode):
+    """The fork's own flow, unchanged: ``aggregate_decode()`` at the end of an iteration, ``schedule_evictions`` at the start
+    of the next -- nobody tells the aggregation what the next call will be.  It predicts the last call's batch one token
+    further on and harvests for it; the lists carry the positions and windows they were made with and the schedule call
+    checks them on the device.  The oracle's sums and schedule every step; the plain steps run on lists."""
+    lp = Loop(L=2, H=4, bs=bs, seq_lens=[40 * bs + 5, 25 * bs, 33 * bs + 9], cap=20 * bs, qpk=qpk, seed=bs + qpk, mode=mode,
+              speculative=True)
+    cm = lp.cm
+    first = lp.step(plain=True)
+    assert not first["used"] and first["path"].startswith("small_eviction")
+    used = clean = 0
+    for it in range(30):
+        info = lp.step(plain=True)
+        used += info["used"]
+        clean += info["used"] and info["path"] == "small_eviction"
+        assert info["path"].startswith("small_eviction"), info
+        if info["used"]:
+            assert cm.last_harvest_kind == "aggregation pass, ahead of the call"
+    if mode == "per_sequence":
+        assert used >= 20 and clean >= used - 4, (used, clean)
+    else:
+        # (under the reference's batch > 1 rule later sequences free less than asked, so what they are asked grows from
+        # step to step and lists made for a smaller request are not used)
+        assert used >= 3, used
+
+
+def test_a_prediction_that_does_not_hold_is_redone_on_the_device():
+    """the next call is NOT the last one a token further on: other positions (a sequence that skipped a step), another
+    protected window, another batch -- the device-side check (or the host's, for the batch) refuses the lists; the
+    oracle's schedule all the same, and after a refusal on the device predictions pause"""
+    lp = Loop(L=2, H=4, bs=16, seq_lens=[700, 420, 555], cap=320, speculative=True)
+    cm = lp.cm
+    lp.step(plain=True)
+    assert lp.step(plain=True)["used"]
+    # positions that moved by two: the lists were made for + 1
+    lp.sim.append_token()
+    lp.st.metrics[:] = lp.st.metrics                      # (state carried by the host simulator; nothing else to do)
+    info = lp.step(plain=True)
+    assert info["used"] and info["path"] == "small_eviction+fallback", info
+    assert cm._hv_pause > 0 or cm.harvest_misses >= 1
+    for _ in range(3):                                      # predictions pause, then come back
+        info = lp.step(plain=True)
+        assert info["path"].startswith("small_eviction")
+    used_again = any(lp.step(plain=True)["used"] for _ in range(6))
+    assert used_again
+    # another batch: refused on the host (no lists are offered for other sequences)
+    info = lp.step(plain=True, sel=[0, 2])
+    assert not info["used"]
+
+
+def test_speculative_harvest_is_off_when_asked():
+    lp = Loop(L=2, H=4, bs=16, seq_lens=[700, 420, 555], cap=320, speculative=False)
+    lp.step(plain=True)
+    for _ in range(4):
+        info = lp.step(plain=True)
+        assert not info["used"] and info["remembered"]
+    assert lp.cm._hv_buf.numel() == _lib.load().kvc_harvest_pivot_bytes(3)
+

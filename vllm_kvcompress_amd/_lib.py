@@ -47,6 +47,7 @@ class KvcScheduleParams(ctypes.Structure):
         ("uniform_evict", c_int32),
         ("eli_dirty_map", c_void_p),
         ("harvest_buf", c_void_p), ("harvest", c_int32), ("harvest_widen", c_float),
+        ("harvest_position_delta", c_int32),
         ("evicted_logical_indices", c_void_p), ("evicted_kv_count", c_void_p),
         ("evicted_block_count", c_void_p),
     ]

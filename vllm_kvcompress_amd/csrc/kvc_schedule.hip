@@ -215,9 +215,9 @@ extern "C" int32_t kvc_harvest_eligible(const kvc_schedule_params* p, int32_t nu
 namespace kvc {
 __global__ __launch_bounds__(256) void harvest_seen_seq_kernel(const int32_t* __restrict__ seq_positions,
                                                                const int32_t* __restrict__ num_protected, int B,
-                                                               int32_t* __restrict__ seen) {
+                                                               int32_t* __restrict__ seen, int delta) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < B) { seen[2 * i] = seq_positions[i]; seen[2 * i + 1] = num_protected[i]; }
+  if (i < B) { seen[2 * i] = seq_positions[i] + delta; seen[2 * i + 1] = num_protected[i]; }
 }
 }  // namespace kvc
 
@@ -246,7 +246,7 @@ extern "C" int kvc_attention_harvest_begin(const kvc_schedule_params* pp, kvc_st
   fill32_async(hb + hl.claimed, 0u, hl.rec64 - hl.claimed, s);                          // claimed | cnt | def
   fill32_async(hb + hl.seen_ctx, 0xFFFFFFFFu, hl.seen_seq - hl.seen_ctx, s);           // no head has been walked yet
   hipLaunchKernelGGL(harvest_seen_seq_kernel, dim3((p.num_seqs + 255) / 256), dim3(256), 0, s, p.seq_positions, p.num_protected,
-                     p.num_seqs, reinterpret_cast<int32_t*>(hb + hl.seen_seq));
+                     p.num_seqs, reinterpret_cast<int32_t*>(hb + hl.seen_seq), 0);
   return check_launch("attention_harvest_begin");
 }
 
@@ -525,8 +525,8 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
         ws.st_def = reinterpret_cast<uint32_t*>(hb + hl.def);
         ws.rec64 = reinterpret_cast<uint64_t*>(hb + hl.rec64);
         if (p.harvest & 8) {                         // made by the attention's epilogue: verified against this call's batch
-          if (!attention_harvest_plan(p))
-            return fail_invalid("schedule_evictions: lists made by the attention's epilogue cannot serve averaged or biased metrics");
+          // (lists of the attention's epilogue cannot serve averaged or biased metrics; the host does not offer them
+          // there -- kvc_attention_harvest_eligible -- and lists of the aggregation pass, which may, are full keys)
           ws.hv_seen_ctx = reinterpret_cast<const int32_t*>(hb + hl.seen_ctx);
           ws.hv_seen_seq = reinterpret_cast<const int32_t*>(hb + hl.seen_seq);
         }
@@ -809,6 +809,11 @@ extern "C" int kvc_aggregate_decode_harvest(const kvc_schedule_params* pp, float
   const uint32_t* hv_pivot = reinterpret_cast<const uint32_t*>(hb + hl.pivot);
   const bool lazy = lazy_plan(p);
   fill32_async(hb + hl.claimed, 0u, hl.rec64 - hl.claimed, s);       // claimed | cnt | def
+  // what the lists are made with, for a schedule call that takes them with harvest bit 3 (verified on the device):
+  // positions (+ delta) and protected windows; the context lengths are not recorded (-2: the walked blocks are counted)
+  fill32_async(hb + hl.seen_ctx, 0xFFFFFFFEu, hl.seen_seq - hl.seen_ctx, s);
+  hipLaunchKernelGGL(harvest_seen_seq_kernel, dim3((p.num_seqs + 255) / 256), dim3(256), 0, s, p.seq_positions, p.num_protected,
+                     p.num_seqs, reinterpret_cast<int32_t*>(hb + hl.seen_seq), p.harvest_position_delta);
   // a wave iteration covers 64 blocks; at most 16 Ki workgroups of 4 waves (grid-stride beyond)
   int64_t cb = (p.num_blocks + 255) / 256;
   cb = cb < 1 ? 1 : (cb > 16384 ? 16384 : cb);

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p,
     if (mine) {
       myC = c_; myHang = hang_; myOff = off_; myEnd = end_;
       const uint32_t nblk = (uint32_t)((ctx + bs - 1) >> sh);
-      if (seen_ != ctx) atomicOr(ws.fallback, 1u);   // another batch's list
+      if (seen_ != ctx && seen_ != -2) atomicOr(ws.fallback, 1u);   // another batch's list (-2: made without context lengths)
       if (!lazy) {
         myFc = nchunks_freed(nblk * (uint32_t)bs - def_, myHang, (uint32_t)bs);
         ws.head_fc[g] = myFc;

@@ -132,12 +132,14 @@ __global__ __launch_bounds__(256) void aggregate_harvest_kernel(kvc_schedule_par
     ok = ok && i >= 0 && mt.l >= 0 && mt.l < L && mt.h >= 0 && mt.h < H;
     const int l = ok ? mt.l : 0, h = ok ? mt.h : 0;
     if (!ok) i = 0;
-    const int ctx = p.context_lens[(l * p.num_seqs + i) * H + h];
-    ok = ok && mt.lbn >= 0 && mt.lbn < (ctx + BS - 1) / BS;
+    // (context_lens == nullptr: a harvest for the NEXT iteration's call, whose context lengths are not known yet -- a
+    // block belongs to the batch by its metadata alone; the schedule call checks the walked blocks against its own N)
+    const int ctx = p.context_lens != nullptr ? p.context_lens[(l * p.num_seqs + i) * H + h] : 0;
+    ok = ok && mt.lbn >= 0 && (p.context_lens == nullptr || mt.lbn < (ctx + BS - 1) / BS);
     claimed += (uint32_t)__popcll(__ballot(ok));
     const int g = ok ? (i * L + l) * H + h : -1;
     const uint32_t pex = ok ? hv_pivot[i] : 0u;      // (0: no key lies below it)
-    const int seq_pos = p.seq_positions[i], prot = p.num_protected[i];
+    const int seq_pos = p.seq_positions[i] + p.harvest_position_delta, prot = p.num_protected[i];
     const int bound = seq_pos - prot;
 #pragma unroll
     for (int r0 = 0; r0 < ROWS; r0 += U) {

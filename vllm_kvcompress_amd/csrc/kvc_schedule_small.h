@@ -570,7 +570,7 @@ __global__ __launch_bounds__(64 * WAVES) void stream_records_kernel(kvc_schedule
     const int ctx = p.context_lens[(l * B + i_seq) * H + h];
     const uint32_t nblk = (uint32_t)((ctx + bs - 1) / bs);
     myC = ws.st_cnt[g];
-    if (ws.hv_seen_ctx != nullptr && ws.hv_seen_ctx[g] != ctx) atomicOr(ws.fallback, 1u);   // another batch's list
+    if (ws.hv_seen_ctx != nullptr && ws.hv_seen_ctx[g] != ctx && ws.hv_seen_ctx[g] != -2) atomicOr(ws.fallback, 1u);   // another batch's list (-2: not recorded)
     if (!lazy) {                                     // (lazy: nobody counted the masked slots, nobody needs them)
       const uint32_t F = nblk * (uint32_t)bs - ws.st_def[g];
       ws.head_fc[g] = nchunks_freed(F, (uint32_t)p.hanging_token_count[g], (uint32_t)bs);   // finite-threshold chunks

@@ -209,6 +209,17 @@ class CompressionMetrics:
         # the batch of the call before takes the pivots that call left behind instead of sampling the store --
         # no sampling pass, no pivot kernel, half the candidates in its collecting pass.  Same results.
         self.pivot_memory = os.environ.get("KVC_PIVOT_MEMORY", "1") not in ("", "0")
+        # speculative harvest (on unless KVC_SPECULATIVE_HARVEST=0 or KVC_HARVEST_AHEAD=0): the fork calls aggregate_decode()
+        # at the END of an iteration (llm_engine.py:1634) without saying what the next iteration will compress.  In
+        # continual compression that is the batch of the last schedule call, one token further on: the plain
+        # aggregate_decode() then harvests for THAT call -- the last call's sequences and protected windows, its positions
+        # + 1, block membership from the metadata alone -- and the lists carry what they were made with; the next
+        # schedule_evictions for the same sequences takes them with the device-side check of harvest bit 3 (another
+        # position, another window, blocks that came or went: redone on the device, and predictions pause).  One sweep of
+        # the store per decode step in the UNCHANGED fork flow.  Same results either way.
+        self.speculative_harvest = (os.environ.get("KVC_SPECULATIVE_HARVEST", "1") not in ("", "0")
+                                    and os.environ.get("KVC_HARVEST_AHEAD", "") != "0")
+        self.last_harvest_kind = ""        # "aggregation pass" | "aggregation pass, ahead of the call" | "attention's epilogue"
         self.last_pivot_memory_used = False
         self.last_harvest_used = False     # the last schedule_evictions ran on harvested lists
         self.harvest_misses = 0            # harvested calls whose lists fell short (flag raised, redone on device)
@@ -339,6 +350,11 @@ class CompressionMetrics:
         if self.random or not self.record_decoding_metrics:
             return
         self._hv_lists = None
+        if self._speculative_harvest(fuse_clear):
+            return
+        self._plain_aggregate_decode(fuse_clear)
+
+    def _plain_aggregate_decode(self, fuse_clear: bool) -> None:
         lib = _lib.load()
         with torch.cuda.device(self.device):
             _lib.check(lib.kvc_aggregate_decode(
@@ -346,6 +362,45 @@ class CompressionMetrics:
                 self.num_queries_per_kv, 1 if self.use_l2 else 0, 1 if fuse_clear else 0,
                 _stream(self.metrics)))
         self._temp_clean = bool(fuse_clear)
+
+    def _speculative_harvest(self, fuse_clear: bool) -> bool:
+        """``aggregate_decode()`` as the harvesting pass for the schedule call the NEXT iteration will most likely make
+        (see ``speculative_harvest`` in ``__init__``).  Returns False -- nothing was launched -- when there is nothing to
+        predict from; the sums are the plain pass's, bit for bit, either way."""
+        hv = self._hv
+        if not (self.speculative_harvest and self.harvest_ahead is not False and hv is not None and hv.get("full")
+                and hv["buf"] is self._hv_buf and hv.get("seq_pos") is not None and self._hv_pause == 0 and not self._fb_fault
+                and not (self._fb_backoff > 0 and int(self.schedule_path) == 0)):
+            return False
+        capturing = torch.cuda.is_current_stream_capturing()
+        stream = _stream(self.metrics)
+        if capturing or hv["stream"] != stream or self._store_versions() is None:
+            return False
+        try:
+            self._poll_fallback(False)
+        except RuntimeError:
+            self._plain_aggregate_decode(fuse_clear)     # (a fault reported by an EARLIER call: this step's sums still happen)
+            raise
+        if self._hv is not hv or self._hv_pause > 0 or self._fb_fault:      # (the poll may have dropped the pivots)
+            return False
+        lib = _lib.load()
+        p = KvcScheduleParams()
+        self._store_params(p, list(hv["seqs"]), hv["seq_pos"], hv["prot"], None, hv["N"])
+        p.max_evicted_blocks_hint = int(hv["k"].max())
+        p.schedule_path = int(self.schedule_path)
+        p.harvest_buf = self._hv_buf.data_ptr()
+        p.harvest_position_delta = 1                      # one decode step: one more token per sequence
+        if not lib.kvc_harvest_eligible(ctypes.byref(p), self.num_queries_per_kv):
+            return False
+        with torch.cuda.device(self.device):
+            _lib.check(lib.kvc_aggregate_decode_harvest(
+                ctypes.byref(p), self._temp_metrics.data_ptr(), self.num_queries_per_kv,
+                1 if self.use_l2 else 0, 1 if fuse_clear else 0, stream))
+        self._temp_clean = bool(fuse_clear)
+        torch.autograd.graph.increment_version(self.metrics)     # (written through a raw pointer)
+        self._hv_lists = dict(seqs=hv["seqs"], attention=True, speculative=True, k=hv["k"], stream=stream, buf=self._hv_buf,
+                              store=self._store_versions())
+        return True
 
     # ------------------------------------------------------------------ harvest-ahead
     def _store_versions(self):
@@ -387,7 +442,7 @@ class CompressionMetrics:
         p.seq_slot_len = slot_of_seq.numel()
         p.seq_positions = seq_pos.data_ptr()
         p.num_protected = prot.data_ptr()
-        p.context_lens = context_lens.data_ptr()
+        p.context_lens = None if context_lens is None else context_lens.data_ptr()
         p.total_slots = N
         p.use_average = 1 if self.use_average else 0
         p.num_sinks = int(self.num_sinks)
@@ -431,7 +486,7 @@ class CompressionMetrics:
             self._poll_fallback(torch.cuda.is_current_stream_capturing())
         except RuntimeError:
             self._hv_lists = None
-            self.aggregate_decode(fuse_clear)        # (a fault reported by an EARLIER call: this step's sums still happen)
+            self._plain_aggregate_decode(fuse_clear)     # (a fault reported by an EARLIER call: this step's sums still happen)
             raise
         hv = self._hv
         self._hv_lists = None
@@ -459,7 +514,7 @@ class CompressionMetrics:
             p.harvest_buf = self._hv_buf.data_ptr()
             ok = bool(lib.kvc_harvest_eligible(ctypes.byref(p), self.num_queries_per_kv))
         if not ok:
-            self.aggregate_decode(fuse_clear)
+            self._plain_aggregate_decode(fuse_clear)
             return False
         with torch.cuda.device(self.device):
             _lib.check(lib.kvc_aggregate_decode_harvest(
@@ -807,11 +862,15 @@ class CompressionMetrics:
         # the largest count picks the schedule (include/kvc_mi355x.h); unknown only for a device tensor of counts
         # under stream capture, where nothing can be read back
         p.max_evicted_blocks_hint = -1 if k_list is None else int(k_list.max())
+        # (lists are wanted once somebody harvests explicitly -- or from the start when aggregate_decode() may harvest
+        # ahead of the call by itself)
+        want_lists = bool(self.harvest_ahead) or (self.harvest_ahead is None and self.speculative_harvest
+                                                  and self.record_decoding_metrics and not self.random)
         if (not capturing and p.max_evicted_blocks_hint >= 0
-                and ((self.harvest_ahead and lib.kvc_harvest_eligible(ctypes.byref(p), self.num_queries_per_kv))
+                and ((want_lists and lib.kvc_harvest_eligible(ctypes.byref(p), self.num_queries_per_kv))
                      or (self.pivot_memory and lib.kvc_pivot_memory_eligible(ctypes.byref(p))))):
             # the buffer: pivots only, or pivots + lists once somebody harvests
-            full = bool(self.harvest_ahead)
+            full = want_lists
             need = int(lib.kvc_harvest_buffer_bytes(B * L * H, B) if full else lib.kvc_harvest_pivot_bytes(B))
             if self._hv_buf is None or self._hv_buf.numel() < need:      # (kept when the batch shrinks: offsets are the call's)
                 self._hv_buf = torch.zeros((need,), dtype=torch.uint8, device=dev)
@@ -823,10 +882,13 @@ class CompressionMetrics:
                 self._hv_pause -= 1
             elif self._lists_usable(hl, seq_indices, seq_positions, num_protected, context_lens, k_list, stream):
                 p.harvest |= 9 if hl.get("attention", False) else 1
+                self.last_harvest_kind = ("aggregation pass, ahead of the call" if hl.get("speculative", False) else
+                                          "attention's epilogue" if hl.get("attention", False) else "aggregation pass")
             elif (self.pivot_memory and hv is not None and hv["buf"] is self._hv_buf and hv["stream"] == stream
                   and hv["seqs"] == seqs_key and self._k_within(k_list, hv["k"])):
                 p.harvest |= 4
-            self._hv = dict(seqs=seqs_key, k=k_list, N=N, buf=self._hv_buf, stream=stream, full=full)
+            self._hv = dict(seqs=seqs_key, k=k_list, N=N, buf=self._hv_buf, stream=stream, full=full,
+                            seq_pos=seq_pos, prot=prot)       # (held: what aggregate_decode() predicts the next call from)
         else:
             self._hv = None
         self.last_harvest_used = bool(p.harvest & 1)
@@ -849,8 +911,7 @@ class CompressionMetrics:
             backoff=int(p.schedule_path) == 1 and int(self.schedule_path) != 1)
         if self.last_schedule[2] == 1:
             # ... and where the small-eviction schedule took its pivots / lists from
-            self.last_schedule_reason += (" [lists: the attention's epilogue]" if p.harvest & 8 else
-                                          " [lists: the aggregation pass]" if p.harvest & 1 else
+            self.last_schedule_reason += (f" [lists: the {self.last_harvest_kind}]" if p.harvest & 1 else
                                           " [pivots: the call before]" if p.harvest & 4 else " [pivots: sampled]")
         if self.last_schedule[2] and self.strict_fallback and not capturing:
             off = self.last_schedule[1]
