@@ -294,6 +294,31 @@ int main() {
             same(out[2][0], a_eli, "evicted_logical_indices (epilogue's lists vs own pass)") &&
             same(out[2][1], a_cnt, "evicted_kv_count (epilogue's lists vs own pass)") &&
             same(out[2][2], a_blk, "evicted_block_count (epilogue's lists vs own pass)");
+      // (c) the aggregation pass harvesting for a call it PREDICTS (the fork's flow: aggregate_decode() at the end of an
+      // iteration, the schedule call at the start of the next): the last call's positions + 1, context lengths not known
+      // (NULL) -- against the plain pass + the schedule's own pass on the same pivots
+      {
+        std::vector<int32_t> seqpos_prev = {seq_pos - 1};
+        int32_t* d_sp_prev = to_dev(seqpos_prev);
+        CK(hipMemcpyAsync(hbuf3, hbuf, hvb, hipMemcpyDeviceToDevice, s));     // (the pivots (b)'s call left behind)
+        KV(kvc_aggregate_decode(d_ma, d_temp, slots, qpk, 1, 0, s));
+        sp.harvest_buf = hbuf3;
+        KV(schedule(d_ma, 2 | 4, out[1]));
+        aok = aok && flag() == 0;
+        sp.harvest_buf = hbuf; sp.metrics = d_mb; sp.seq_positions = d_sp_prev; sp.context_lens = nullptr;
+        sp.harvest_position_delta = 1;
+        KV(kvc_aggregate_decode_harvest(&sp, d_temp, qpk, 1, 0, s));
+        sp.seq_positions = d_sp; sp.context_lens = d_ctx2; sp.harvest_position_delta = 0;
+        KV(schedule(d_mb, 1 | 2 | 8, out[2]));
+        aok = aok && flag() == 0;
+        CK(hipMemcpy(ma.data(), d_ma, slots * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(a_eli.data(), out[1][0], (size_t)N * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(a_cnt.data(), out[1][1], G * 4, hipMemcpyDeviceToHost));
+        aok = aok && same(d_mb, ma, "metrics (predicting aggregation pass vs plain)") &&
+              same(out[2][0], a_eli, "evicted_logical_indices (predicted lists vs own pass)") &&
+              same(out[2][1], a_cnt, "evicted_kv_count (predicted lists vs own pass)");
+        if (!aok) printf("predicted harvest failed\n");
+      }
       // lists made for other positions: the call sees it on the device (bit 3), raises its flag and redoes the work
       std::vector<int32_t> seqpos_other = {seq_pos + 1};
       int32_t* d_sp_other = to_dev(seqpos_other);
