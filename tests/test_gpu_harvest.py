@@ -486,3 +486,38 @@ def test_speculative_harvest_is_off_when_asked():
         assert not info["used"] and info["remembered"]
     assert lp.cm._hv_buf.numel() == _lib.load().kvc_harvest_pivot_bytes(3)
 
+
+
+def test_prediction_with_several_decode_steps_between_two_schedule_calls():
+    """compression_interval = 3: three aggregate_decode() calls (three tokens) lie between two schedule calls.  The first
+    gap teaches the pattern; from then on the LAST aggregation of a gap harvests for positions + 3, and the schedule call
+    runs on its lists -- the oracle's schedule of the store every time"""
+    bs, cap = 16, 320
+    seq_lens = [cap + 200, cap + 90]
+    st = synth.make_state(num_layers=2, num_kv_heads=4, block_size=bs, seq_lens=seq_lens, seed=13, protected=bs + 1,
+                          steady_cap=cap)
+    ds = hdev.upload(st, DEV, num_queries_per_kv=4, mode="per_sequence")
+    cm = ds.cm
+    cm.strict_fallback = True
+    rng = np.random.default_rng(2)
+    seqs, prot = list(st.seq_indices), list(st.protected)
+    used = []
+    for call in range(6):
+        for agg in range(3):                                     # three decode steps: the sums, no change of the block state
+            temp = rng.random((st.num_blocks, bs, 4)).astype(np.float32)
+            cm.temp_metrics.copy_(torch.from_numpy(temp))
+            orc.aggregate_decode(st.metrics, temp, use_l2=True)
+            cm.aggregate_decode()
+            st.seq_positions = st.seq_positions + 1
+        np.testing.assert_array_equal(cm.metrics.cpu().numpy(), st.metrics)
+        want = oracle_pipeline(st, [8, 8], mode="per_sequence")
+        pos_t = torch.from_numpy(st.seq_positions.astype(np.int32)).to(DEV)
+        eli, ekc, ebc = cm.schedule_evictions(seqs, pos_t, [8, 8], ds.context_lens, ds.hanging_token_count,
+                                              ds.evicted_kv_offsets, prot, total_slots=st.total_slots)
+        assert cm.last_schedule_path() == "small_eviction", (call, cm.last_schedule_path())
+        np.testing.assert_array_equal(eli.cpu().numpy(), want["eli"], err_msg=f"call {call}")
+        np.testing.assert_array_equal(ekc.cpu().numpy(), want["ekc"], err_msg=f"call {call}")
+        used.append(bool(cm.last_harvest_used))
+    # call 0: no pivots yet; call 1: the gap was not known (assumed 1: the first aggregation harvested, the next two dropped
+    # its lists); from call 2 on the third aggregation harvests for positions + 3
+    assert used[0] is False and all(used[2:]), used

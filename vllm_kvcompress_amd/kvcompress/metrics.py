@@ -220,6 +220,10 @@ class CompressionMetrics:
         self.speculative_harvest = (os.environ.get("KVC_SPECULATIVE_HARVEST", "1") not in ("", "0")
                                     and os.environ.get("KVC_HARVEST_AHEAD", "") != "0")
         self.last_harvest_kind = ""        # "aggregation pass" | "aggregation pass, ahead of the call" | "attention's epilogue"
+        # (compression_interval > 1: several aggregate_decode() calls lie between two schedule calls.  The prediction is made
+        # by the LAST of them -- the gap seen last time says which one that is -- for positions + that many tokens)
+        self._aggs_since_schedule = 0
+        self._last_gap = 1
         self.last_pivot_memory_used = False
         self.last_harvest_used = False     # the last schedule_evictions ran on harvested lists
         self.harvest_misses = 0            # harvested calls whose lists fell short (flag raised, redone on device)
@@ -350,7 +354,8 @@ class CompressionMetrics:
         if self.random or not self.record_decoding_metrics:
             return
         self._hv_lists = None
-        if self._speculative_harvest(fuse_clear):
+        self._aggs_since_schedule += 1
+        if self._aggs_since_schedule == self._last_gap and self._speculative_harvest(fuse_clear, self._last_gap):
             return
         self._plain_aggregate_decode(fuse_clear)
 
@@ -363,7 +368,7 @@ class CompressionMetrics:
                 _stream(self.metrics)))
         self._temp_clean = bool(fuse_clear)
 
-    def _speculative_harvest(self, fuse_clear: bool) -> bool:
+    def _speculative_harvest(self, fuse_clear: bool, tokens_ahead: int = 1) -> bool:
         """``aggregate_decode()`` as the harvesting pass for the schedule call the NEXT iteration will most likely make
         (see ``speculative_harvest`` in ``__init__``).  Returns False -- nothing was launched -- when there is nothing to
         predict from; the sums are the plain pass's, bit for bit, either way."""
@@ -389,7 +394,7 @@ class CompressionMetrics:
         p.max_evicted_blocks_hint = int(hv["k"].max())
         p.schedule_path = int(self.schedule_path)
         p.harvest_buf = self._hv_buf.data_ptr()
-        p.harvest_position_delta = 1                      # one decode step: one more token per sequence
+        p.harvest_position_delta = int(tokens_ahead)      # a decode step: one more token per sequence
         if not lib.kvc_harvest_eligible(ctypes.byref(p), self.num_queries_per_kv):
             return False
         with torch.cuda.device(self.device):
@@ -482,6 +487,7 @@ class CompressionMetrics:
             return False
         if self.harvest_ahead is None:
             self.harvest_ahead = True
+        self._aggs_since_schedule += 1
         try:
             self._poll_fallback(torch.cuda.is_current_stream_capturing())
         except RuntimeError:
@@ -789,6 +795,7 @@ class CompressionMetrics:
         assert tuple(evicted_kv_offsets.shape) == (B, L, H)
         capturing = torch.cuda.is_current_stream_capturing()
         stream = _stream(self.metrics)
+        self._last_gap, self._aggs_since_schedule = max(self._aggs_since_schedule, 1), 0
         k_per_seq = self._as_i32(evicted_blocks_per_seq)
         # the counts on the host (their maximum picks the schedule, include/kvc_mi355x.h) and N
         k_list, pending = None, None
