@@ -64,6 +64,33 @@ __device__ __forceinline__ uint32_t wave_reduce_sum(uint32_t v) {
   return v;
 }
 
+// The same two for a wave whose 64 lanes are ALL active: DPP row operations (the adds themselves permute: no trip
+// through the LDS crossbar, no address arithmetic) and, for the sum, four scalar reads of the rows' totals.  A lane
+// that is switched off would neither be added nor hold a row's total: only where control flow is wave-uniform.
+//   quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror 0x141, row_mirror 0x140, row_shr:n 0x110 + n,
+//   row_bcast:15 0x142 (rows 1, 3: row_mask 0xA), row_bcast:31 0x143 (rows 2, 3: row_mask 0xC)
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_reduce_sum_full(uint32_t v) {
+  v += dpp_or_zero<0xB1>(v);
+  v += dpp_or_zero<0x4E>(v);
+  v += dpp_or_zero<0x141>(v);
+  v += dpp_or_zero<0x140>(v);
+  return (uint32_t)(__builtin_amdgcn_readlane((int)v, 0) + __builtin_amdgcn_readlane((int)v, 16) +
+                    __builtin_amdgcn_readlane((int)v, 32) + __builtin_amdgcn_readlane((int)v, 48));
+}
+__device__ __forceinline__ uint32_t wave_inclusive_scan_full(uint32_t v) {
+  v += dpp_or_zero<0x111>(v);
+  v += dpp_or_zero<0x112>(v);
+  v += dpp_or_zero<0x114>(v);
+  v += dpp_or_zero<0x118>(v);
+  v += dpp_or_zero<0x142, 0xA>(v);
+  v += dpp_or_zero<0x143, 0xC>(v);
+  return v;
+}
+
 // last index g in [0,n) with a[g] <= x  (a ascending, a[0] <= x assumed)
 __device__ __forceinline__ int upper_bound_minus1(const int32_t* __restrict__ a, int n, int64_t x) {
   int lo = 0, hi = n;                      // invariant: a[lo] <= x, (hi==n or a[hi] > x)

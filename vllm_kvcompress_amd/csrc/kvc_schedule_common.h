@@ -129,29 +129,91 @@ __device__ __forceinline__ void eli_dirty_update(uint32_t* map, int32_t* eli, in
 // (c0 >> 5) + t, `old_word`; topk_fused_kernel requests the words of all its heads together): the same result
 __device__ __forceinline__ void eli_dirty_apply(uint32_t* map, int32_t* eli, int32_t c0, int32_t c1, int32_t new_chunks,
                                                 int32_t keep_from, int bs_shift, int32_t null_value, uint32_t old_word, int lane) {
+  // (called by all 64 lanes of the wave: the words are per lane, the entries that go back to null are the wave's)
   const int32_t w0 = c0 >> 5, w1 = (c1 - 1) >> 5;
   const int32_t w = w0 + lane;
-  if (w > w1) return;
-  const int32_t cn = c0 + new_chunks;
-  const int32_t lo = max(c0, w << 5), hi = min(c1, (w + 1) << 5);
-  const uint32_t mask = (hi - lo >= 32) ? 0xFFFFFFFFu : (((1u << (hi - lo)) - 1u) << (lo & 31));
-  const int32_t nh = min(hi, cn);
-  const uint32_t fresh = nh > lo ? ((nh - lo >= 32) ? 0xFFFFFFFFu : (((1u << (nh - lo)) - 1u) << (lo & 31))) : 0u;
-  uint32_t old;
-  if (mask == 0xFFFFFFFFu) {
-    old = old_word;
-    if (old != fresh) map[w] = fresh;
-  } else {
-    old = old_word & mask;
-    if (old & ~fresh) atomicAnd(&map[w], ~(old & ~fresh));
-    if (fresh & ~old) atomicOr(&map[w], fresh & ~old);
+  uint32_t old = 0;
+  if (w <= w1) {
+    const int32_t cn = c0 + new_chunks;
+    const int32_t lo = max(c0, w << 5), hi = min(c1, (w + 1) << 5);
+    const uint32_t mask = (hi - lo >= 32) ? 0xFFFFFFFFu : (((1u << (hi - lo)) - 1u) << (lo & 31));
+    const int32_t nh = min(hi, cn);
+    const uint32_t fresh = nh > lo ? ((nh - lo >= 32) ? 0xFFFFFFFFu : (((1u << (nh - lo)) - 1u) << (lo & 31))) : 0u;
+    if (mask == 0xFFFFFFFFu) {
+      old = old_word;
+      if (old != fresh) map[w] = fresh;
+    } else {
+      old = old_word & mask;
+      if (old & ~fresh) atomicAnd(&map[w], ~(old & ~fresh));
+      if (fresh & ~old) atomicOr(&map[w], fresh & ~old);
+    }
   }
-  while (old) {
-    const int bit = __ffs((int)old) - 1;
-    old &= old - 1u;
-    const int32_t eb = max(((w << 5) + bit) << bs_shift, keep_from), ee = (((w << 5) + bit) + 1) << bs_shift;
-    for (int32_t e = eb; e < ee; ++e) eli[e] = null_value;
+  // everything from keep_from to the end of the owner's last dirty chunk goes back to null: a chunk that is not dirty
+  // in between holds nulls already (that is what its bit says), so one strided fill by the wave does what a walk over
+  // the dirty bits would -- one lane, one entry at a time
+  const unsigned long long any = __ballot(old != 0u);
+  if (any) {                                         // wave-uniform
+    const int top = 63 - __clzll((long long)any);
+    const uint32_t tw = (uint32_t)__builtin_amdgcn_readlane((int)old, top);
+    const int32_t last = ((w0 + top) << 5) + (31 - __clz((int)tw));
+    const int32_t ee = (last + 1) << bs_shift;
+    for (int32_t e = keep_from + lane; e < ee; e += WAVE) eli[e] = null_value;
   }
+}
+
+// The same for up to 64 owners at once, by ONE wave with all its lanes active: lane q < n_owners of off_v / end_v / ce_v
+// holds owner q's first entry, end and number of fresh entries.  A lane per (owner, map word) -- 64 / Wp owners per
+// pass, Wp = the owners' largest word count rounded up to a power of two -- instead of a pass per owner with a
+// handful of lanes at work (topk_fused_kernel: 16 heads of 8 words each are two passes, not sixteen).  The entries that
+// go back to null: from the owner's fresh entries' end to the end of its last dirty chunk, filled by the owner's Wp
+// lanes (chunks in between that are not dirty hold nulls already).  false (nothing done): an owner of more than 64 words.
+__device__ __forceinline__ bool eli_dirty_apply_owners(uint32_t* map, int32_t* eli, int32_t off_v, int32_t end_v, uint32_t ce_v,
+                                                       int n_owners, int bs_shift, int32_t null_value, int lane) {
+  uint32_t nw = 0;
+  if (lane < n_owners) {
+    const int32_t c0 = off_v >> bs_shift, c1 = end_v >> bs_shift;
+    nw = c0 < c1 ? (uint32_t)(((c1 - 1) >> 5) - (c0 >> 5) + 1) : 0u;
+  }
+  uint32_t W = 0;
+  for (int d = 32; d > 0; d >>= 1) nw = max(nw, (uint32_t)__shfl_xor((int)nw, d, 64));
+  W = (uint32_t)__builtin_amdgcn_readfirstlane((int)nw);
+  if (W == 0u) return true;
+  if (W > (uint32_t)WAVE) return false;
+  const int lg = W <= 1u ? 0 : 32 - __clz((int)(W - 1u));
+  const int per_pass = WAVE >> lg;
+  const int t = lane & ((1 << lg) - 1);
+  for (int q0 = 0; q0 < n_owners; q0 += per_pass) {    // wave-uniform
+    const int q = q0 + (lane >> lg);
+    const int qs = min(q, n_owners - 1);
+    const int32_t off = __shfl(off_v, qs, 64), end = __shfl(end_v, qs, 64);
+    const int32_t fresh_n = (int32_t)__shfl((int)ce_v, qs, 64);
+    const int32_t c0 = off >> bs_shift, c1 = end >> bs_shift;
+    const int32_t w = (c0 >> 5) + t;
+    uint32_t old = 0;
+    if (q < n_owners && c0 < c1 && w <= ((c1 - 1) >> 5)) {
+      const int32_t cn = c0 + ((fresh_n + (1 << bs_shift) - 1) >> bs_shift);
+      const int32_t lo = max(c0, w << 5), hi = min(c1, (w + 1) << 5);
+      const uint32_t mask = (hi - lo >= 32) ? 0xFFFFFFFFu : (((1u << (hi - lo)) - 1u) << (lo & 31));
+      const int32_t nh = min(hi, cn);
+      const uint32_t fresh = nh > lo ? ((nh - lo >= 32) ? 0xFFFFFFFFu : (((1u << (nh - lo)) - 1u) << (lo & 31))) : 0u;
+      const uint32_t old_word = map[w];
+      if (mask == 0xFFFFFFFFu) {
+        old = old_word;
+        if (old != fresh) map[w] = fresh;
+      } else {
+        old = old_word & mask;
+        if (old & ~fresh) atomicAnd(&map[w], ~(old & ~fresh));
+        if (fresh & ~old) atomicOr(&map[w], fresh & ~old);
+      }
+    }
+    int32_t last = old ? (w << 5) + 31 - __clz((int)old) : -1;      // the owner's highest dirty chunk: max over its lanes
+    for (int d = 1; d < (1 << lg); d <<= 1) last = max(last, __shfl_xor(last, d, 64));
+    if (q < n_owners && last >= 0) {
+      const int32_t ee = (last + 1) << bs_shift;
+      for (int32_t e = off + fresh_n + t; e < ee; e += 1 << lg) eli[e] = null_value;
+    }
+  }
+  return true;
 }
 
 // Fills (`bytes` a multiple of 4, `dst` 4-byte aligned) as KERNEL launches, not hipMemsetAsync: on

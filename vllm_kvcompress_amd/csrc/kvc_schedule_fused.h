@@ -30,6 +30,9 @@ namespace kvc {
 // pivots for the next decode step as this kernel's last phase, from the entries of rank >= cnt staged in the LDS the
 // thresholds have left -- 11 us in the kernel against a 20 us launch, but the ranks and keys that then stay live
 // through the emission cost it 12 us in spills (profiles/r5_topk_fused_phases.txt).
+// s_waitcnt vmcnt(0) (gfx9 encoding: vmcnt = bits 3:0 and 15:14; expcnt 6:4 and lgkmcnt 11:8 left at their maxima)
+#define KVC_WAIT_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)
+
 __device__ __forceinline__ bool less64(uint32_t ahi, uint32_t alo, uint32_t bhi, uint32_t blo) {
   return ahi < bhi || (ahi == bhi && alo < blo);
 }
@@ -55,12 +58,15 @@ __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p,
   const int G = B * LH;
 #ifdef KVC_TOPK_STAMPS
 #define KVC_STAMP(n) do { if (i == 1 && tid == 64) reinterpret_cast<unsigned long long*>(ws.bar)[n] = wall_clock64(); } while (0)
+#define KVC_LAP(acc, t0) do { const unsigned long long t_ = wall_clock64(); acc += t_ - t0; t0 = t_; } while (0)
+  unsigned long long lap_a = 0, lap_b = 0, lap_c = 0, lap_t = 0;
 #else
 #define KVC_STAMP(n) do { } while (0)
+#define KVC_LAP(acc, t0) do { } while (0)
 #endif
   KVC_STAMP(0);
   if (i == 0 && w == 0) {                            // (as stream_records_kernel: blocks nobody claimed, lists of another batch)
-    const uint32_t c = wave_reduce_sum(ws.st_claimed[lane * 32]);
+    const uint32_t c = wave_reduce_sum_full(ws.st_claimed[lane * 32]);
     if (lane == 0 && (int64_t)c != p.total_slots / bs) atomicOr(ws.fallback, 1u);
     if (ws.hv_seen_seq != nullptr) {
       bool bad = false;
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p,
     }
   }
   if (coupled == 0) {
-    const uint32_t f = wave_reduce_sum(myFc);
+    const uint32_t f = wave_reduce_sum_full(myFc);
     if (lane == 0 && f) atomicAdd(&fsum_s, f);
   }
   KVC_STAMP(1);
@@ -120,6 +126,11 @@ __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p,
     vlo[q] = (uint32_t)x; vhi[q] = (uint32_t)(x >> 32);
     rk[q] = 0xFFFFu;
   }
+  // every list has arrived before the first head's write-back leaves: the stores below are counted by the same vmcnt
+  // as the loads above, their number is not known at compile time, and the compiler would wait for ALL of them -- that
+  // is, for the previous head's stores to be acknowledged -- before it touches the next head's list: sixteen store
+  // round trips in a row (profiles/r5_topk_fused_phases.txt)
+  KVC_WAIT_VMEM();
 #pragma unroll
   for (int q = 0; q < HPW; ++q) {
     const uint32_t C = (uint32_t)__builtin_amdgcn_readlane((int)myC, q);
@@ -143,7 +154,7 @@ __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p,
         for (; j < (int)C; ++j) r += (uint32_t)__builtin_amdgcn_readlane((int)me, j) < me ? 1u : 0u;
       }
       const bool in = (uint32_t)lane < C;
-      if (wave_reduce_sum(in ? r : 0u) != C * (C - 1u) / 2u) {            // wave-uniform
+      if (wave_reduce_sum_full(in ? r : 0u) != C * (C - 1u) / 2u) {            // wave-uniform
         r = 0;
         for (int j = 0; j < (int)C; ++j) {
           const uint32_t ohi = (uint32_t)__builtin_amdgcn_readlane((int)vhi[q], j);
@@ -234,7 +245,7 @@ __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p,
       uint32_t c = 0, inc = 0;
       if (tid < RADIX) {
         c = sel_hist[tid];
-        inc = wave_inclusive_scan(c);
+        inc = wave_inclusive_scan_full(c);
         if ((tid & 63) == 63) sel_wtot[tid >> 6] = inc;
       }
       __syncthreads();
@@ -261,60 +272,67 @@ __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p,
   // ---- counts and emission: the wave that holds a head's entries emits them
   const bool flagged = flag_s != 0u;                 // (somebody's lists fell short: the general pipeline behind rewrites everything)
   uint32_t ce[HPW], u[HPW];
-#pragma unroll
-  for (int q = 0; q < HPW; ++q) {                     // counts out, the evicted entries' logical indices requested
-    const int lh = lh0 + q;
-    ce[q] = 0; u[q] = 0xFFFFFFFFu;
-    if (lh >= LH) continue;                           // wave-uniform
-    const uint32_t hang = (uint32_t)__builtin_amdgcn_readlane((int)myHang, q);
-    const uint32_t n = (k > 0 && k <= nthr) ? cnt[lh] : 0u;
-    ce[q] = n > 0 ? (n - 1u) * (uint32_t)bs + hang : 0u;
-    if (lane == 0) {
-      p.evicted_block_count[gbase + lh] = (int32_t)n;
-      p.evicted_kv_count[gbase + lh] = (int32_t)ce[q];
+  uint32_t ceV = 0;                                  // lane q < HPW: head lh0 + q's number of evicted entries
+  {                                                  // counts out: a lane per head, two coalesced stores per wave
+    const bool mine = lane < HPW && lh0 + lane < LH;
+    uint32_t n = 0;
+    if (mine && k > 0 && k <= nthr) n = cnt[lh0 + lane];
+    ceV = n > 0 ? (n - 1u) * (uint32_t)bs + myHang : 0u;
+    if (mine) {
+      p.evicted_block_count[gbase + lh0 + lane] = (int32_t)n;
+      p.evicted_kv_count[gbase + lh0 + lane] = (int32_t)ceV;
     }
+  }
+#pragma unroll
+  for (int q = 0; q < HPW; ++q) {                     // the evicted entries' logical indices requested
+    ce[q] = (uint32_t)__builtin_amdgcn_readlane((int)ceV, q);
+    u[q] = 0xFFFFFFFFu;
+    if (lh0 + q >= LH) continue;                      // wave-uniform
     if (!flagged && !(bigmask & (1u << q)) && rk[q] < ce[q])
       u[q] = ((uint32_t)p.logical_block_num_by_block[vlo[q] >> sh] << sh) | (vlo[q] & (uint32_t)(bs - 1));
   }
   KVC_STAMP(5);
   if (!flagged) {
   const bool tracked = p.eli_dirty_map != nullptr && !(p.lean & 1);
-  uint32_t oldw[HPW];
-#pragma unroll
-  for (int q = 0; q < HPW; ++q) {                     // the dirty map's words of every head requested together
-    oldw[q] = 0;
-    if (!tracked || lh0 + q >= LH) continue;
-    const int32_t c0 = __builtin_amdgcn_readlane(myOff, q) >> sh, c1 = __builtin_amdgcn_readlane(myEnd, q) >> sh;
-    if (c0 < c1 && ((c1 - 1) >> 5) - (c0 >> 5) < WAVE && (c0 >> 5) + lane <= ((c1 - 1) >> 5)) oldw[q] = p.eli_dirty_map[(c0 >> 5) + lane];
-  }
+  // the dirty map's words of all the wave's heads, a lane per (head, word); false: a head of more than 64 words
+  // (2048 blocks) -- those take the per-head form below
+  const int nheads = min(HPW, LH - lh0);
+  const bool dirty_done = !tracked || nheads <= 0 ||
+                          eli_dirty_apply_owners(p.eli_dirty_map, p.evicted_logical_indices, myOff, myEnd, ceV, nheads, sh, p.null_value, lane);
 #pragma unroll
   for (int q = 0; q < HPW; ++q) {
     const int lh = lh0 + q;
     if (lh >= LH) break;                              // wave-uniform
     const int64_t g = gbase + lh;
     const int32_t off = __builtin_amdgcn_readlane(myOff, q), end = __builtin_amdgcn_readlane(myEnd, q);
-    if (tracked) {
-      const int32_t c0 = off >> sh, c1 = end >> sh;
-      if (c0 < c1 && ((c1 - 1) >> 5) - (c0 >> 5) < WAVE)
-        eli_dirty_apply(p.eli_dirty_map, p.evicted_logical_indices, c0, c1, (int32_t)((ce[q] + (uint32_t)bs - 1u) >> sh), off + (int32_t)ce[q],
-                        sh, p.null_value, oldw[q], lane);
-      else
-        eli_dirty_update(p.eli_dirty_map, p.evicted_logical_indices, c0, c1, (int64_t)((ce[q] + (uint32_t)bs - 1u) >> sh), (int64_t)off + ce[q], bs,
-                         p.null_value, true, lane, WAVE);
-    }
+#ifdef KVC_TOPK_STAMPS
+    if (q == 0) lap_t = wall_clock64();
+#endif
+    if (!dirty_done)
+      eli_dirty_update(p.eli_dirty_map, p.evicted_logical_indices, off >> sh, end >> sh, (int64_t)((ce[q] + (uint32_t)bs - 1u) >> sh),
+                       (int64_t)off + ce[q], bs, p.null_value, true, lane, WAVE);
+    KVC_LAP(lap_a, lap_t);
     if (ce[q] == 0) continue;
     int32_t* out = p.evicted_logical_indices + off;
     if (!(bigmask & (1u << q))) {
-      // rank by logical index among the evicted entries: a scalar walk over their lanes
-      const bool ev = rk[q] < ce[q];
-      unsigned long long m = __ballot(ev);
+      // rank by logical index among the evicted entries.  Their ranks by metric are 0 .. ce - 1: pushed to the lane of
+      // that rank (one ds_permute) they sit in the first ce lanes, and all pairs is ce steps, not C (the pushed
+      // 0xFFFFFFFF of the entries that stay land behind them)
+      const uint32_t C = (uint32_t)__builtin_amdgcn_readlane((int)myC, q);
+      uint32_t me = 0xFFFFFFFFu;
+      if ((uint32_t)lane < C) me = (uint32_t)__builtin_amdgcn_ds_permute((int)(rk[q] << 2), (int)u[q]);
+      const int n = (int)min(ce[q], C);
       uint32_t r2 = 0;
-      while (m) {
-        const int j = __ffsll((long long)m) - 1;
-        m &= m - 1ull;
-        r2 += (uint32_t)__builtin_amdgcn_readlane((int)u[q], j) < u[q] ? 1u : 0u;
+      int j = 0;
+      for (; j + 4 <= n; j += 4) {
+        const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)me, j), a1 = (uint32_t)__builtin_amdgcn_readlane((int)me, j + 1);
+        const uint32_t a2 = (uint32_t)__builtin_amdgcn_readlane((int)me, j + 2), a3 = (uint32_t)__builtin_amdgcn_readlane((int)me, j + 3);
+        r2 += (a0 < me ? 1u : 0u) + (a1 < me ? 1u : 0u) + (a2 < me ? 1u : 0u) + (a3 < me ? 1u : 0u);
       }
-      if (ev) out[r2] = (int32_t)u[q];
+      for (; j < n; ++j) r2 += (uint32_t)__builtin_amdgcn_readlane((int)me, j) < me ? 1u : 0u;
+      KVC_LAP(lap_b, lap_t);
+      if (lane < n) out[r2] = (int32_t)me;
+      KVC_LAP(lap_c, lap_t);
     } else {
       // (this wave wrote the sorted record to global memory above: read past the L1)
       const int bq = w & 3;
@@ -333,6 +351,12 @@ __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p,
   }
   }
   KVC_STAMP(6);
+#ifdef KVC_TOPK_STAMPS
+  if (i == 1 && tid == 64) {
+    unsigned long long* st_ = reinterpret_cast<unsigned long long*>(ws.bar);
+    st_[8] = lap_a; st_[9] = lap_b; st_[10] = lap_c;
+  }
+#endif
   // ---- the pivot for the next decode step's harvest from what is left of the lists (section 10)
   if (!PIVOT || hv_pivot == nullptr) return;
   if (kreq <= 0) {                                   // nothing asked of this sequence: lists made for nothing say nothing new
@@ -343,7 +367,7 @@ __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p,
   uint32_t* keys_s = reinterpret_cast<uint32_t*>(arr);
   const uint32_t cap = 2u * (uint32_t)P2;
   {
-    const uint32_t hs = wave_reduce_sum((lane < HPW && lh0 + lane < LH && myHang >= 1u) ? myHang - 1u : 0u);
+    const uint32_t hs = wave_reduce_sum_full((lane < HPW && lh0 + lane < LH && myHang >= 1u) ? myHang - 1u : 0u);
     if (lane == 0 && hs) atomicAdd(&hangsum_s, hs);
   }
 #pragma unroll

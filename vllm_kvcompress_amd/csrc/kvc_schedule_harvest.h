@@ -291,9 +291,9 @@ __global__ __launch_bounds__(1024) void harvest_pivot_kernel(kvc_schedule_params
       const uint32_t hang = (uint32_t)p.hanging_token_count[g];
       hs = hang >= 1u ? hang - 1u : 0u;
     }
-    const uint32_t inc = wave_inclusive_scan(r);
+    const uint32_t inc = wave_inclusive_scan_full(r);
     if (lane == WAVE - 1) wsum_s[w] = inc;
-    hs = wave_reduce_sum(hs);
+    hs = wave_reduce_sum_full(hs);
     if (lane == 0 && hs) atomicAdd(&hang_s, hs);
     __syncthreads();
     uint32_t woff = 0;
