@@ -4,6 +4,8 @@ small-eviction schedule of the continual-compression steady state (the metric st
 physical order, per-head records of the keys below a sampled pivot), which raises a device flag and lets the general pipeline redo the work when it cannot
 finish exactly.  Both must give the oracle's result bit for bit; these tests also pin WHICH one
 produced it."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -635,3 +637,31 @@ def test_block_tables_debug_check(monkeypatch):
         ds.cm.check_block_tables(bad, list(st.seq_indices), ds.context_lens)
     monkeypatch.delenv("KVC_DEBUG_TABLES")
     ds.cm.schedule_evictions(*args, total_slots=st.total_slots, block_tables=bad)                     # (not checked without the switch)
+
+
+def test_next_pivots_are_the_same_wherever_they_are_made():
+    """the pivots a call leaves for the next decode step's harvest: topk_fused_kernel's last phase (default),
+    harvest_pivot_kernel launched behind it (KVC_TOPK_PIVOT_LAUNCH=1), the launch chain (KVC_TOPK_CHAIN=1) -- one
+    function over the same remaining keys, so the same words, step after step (tests/pivot_phase_driver.py)"""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = {}
+    for name, env in (("phase", {}), ("launch", {"KVC_TOPK_PIVOT_LAUNCH": "1"}), ("chain", {"KVC_TOPK_CHAIN": "1"})):
+        e = dict(os.environ)
+        e.pop("KVC_TOPK_PIVOT_LAUNCH", None)
+        e.pop("KVC_TOPK_CHAIN", None)
+        e.update(env)
+        out = subprocess.run([sys.executable, os.path.join(repo, "tests", "pivot_phase_driver.py")], capture_output=True, text=True,
+                             timeout=600, cwd=repo, env=e)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+        line = [l for l in out.stdout.splitlines() if l.startswith("PIVOT_PHASE ")][-1]
+        runs[name] = json.loads(line[len("PIVOT_PHASE "):])
+    for case in runs["phase"]:
+        a = runs["phase"][case]
+        assert all(p is not None for p in a["pivots"]) and any("the call before" in h or "lists" in h for h in a["how"]), a["how"]
+        for other in ("launch", "chain"):
+            b = runs[other][case]
+            assert a["pivots"] == b["pivots"], (case, other, a["pivots"], b["pivots"])
+            assert a["digests"] == b["digests"], (case, other)

@@ -31,7 +31,6 @@ def main():
         ws, off, plan = cm.last_schedule
         stamps = ws[off + 128:off + 128 + 96].view(torch.int64).cpu().numpy()
         d = np.diff(stamps[:8]) / 100.0          # 100 MHz -> us
-        print("emit laps (dirty map | rank by logical index | store), us:", np.round(stamps[8:11] / 100.0, 2))
         print(cm.last_schedule_reason, "us per phase (loads | ranks | barrier | select | counts | emit | next pivot):", np.round(d, 2), "total", round(float((stamps[7] - stamps[0]) / 100.0), 2))
         del out
 

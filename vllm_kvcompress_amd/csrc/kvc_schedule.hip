@@ -590,20 +590,26 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
         side->failed = true;
       }
       const int hpw = LH <= 64 ? 4 : 16;
-      const size_t fl = (size_t)topk_p2 * 8 + (size_t)16 * hpw * 4;
-      static std::atomic<uint64_t> f4_done{0}, f16_done{0};
-      if (hpw == 4) {
-        allow_dynamic_lds(reinterpret_cast<const void*>(topk_fused_kernel<4, false>), 100 * 1024, f4_done);
-        hipLaunchKernelGGL((topk_fused_kernel<4, false>), dim3(B), dim3(1024), fl, s, p, ws, topk_p2, lazy ? 1 : 0, coupled_tk,
-                           hv_pivot != nullptr ? 1 : 0, nullptr, 0, 0.0f);
-      } else {
-        allow_dynamic_lds(reinterpret_cast<const void*>(topk_fused_kernel<16, false>), 100 * 1024, f16_done);
-        hipLaunchKernelGGL((topk_fused_kernel<16, false>), dim3(B), dim3(1024), fl, s, p, ws, topk_p2, lazy ? 1 : 0, coupled_tk,
-                           hv_pivot != nullptr ? 1 : 0, nullptr, 0, 0.0f);
-      }
-      // the pivots for the next decode step's harvest, from what is left of this call's lists (section 10)
-      if (hv_pivot != nullptr)
-        hipLaunchKernelGGL(harvest_pivot_kernel, dim3(B), dim3(1024), 0, s, p, ws, hv_pivot, (harvested || remembered) ? 1 : 0, hv_widen);
+      // the pivots for the next decode step's harvest, from what is left of this call's lists (section 10): the kernel's
+      // last phase (KVC_TOPK_PIVOT_LAUNCH=1: harvest_pivot_kernel behind it, as on the launch chain -- tests compare)
+      static const bool piv_env = [] { const char* e = getenv("KVC_TOPK_PIVOT_LAUNCH"); return e != nullptr && e[0] != '\0' && e[0] != '0'; }();
+      const bool piv_in = hv_pivot != nullptr && !piv_env;
+      const int lds_keys = piv_in ? (LH * WAVE < kvc::HVP_LDS_KEYS ? LH * WAVE : kvc::HVP_LDS_KEYS) : 0;
+      const size_t fl_sel = (size_t)topk_p2 * 8 + (size_t)16 * hpw * 4;
+      const size_t fl = fl_sel > (size_t)lds_keys * 4 ? fl_sel : (size_t)lds_keys * 4;
+      const int fh = (harvested || remembered) ? 1 : 0;
+      static std::atomic<uint64_t> f4_done{0}, f16_done{0}, f4p_done{0}, f16p_done{0};
+#define KVC_FUSED(HPWV, PIVV, DONE)                                                                                        \
+      do {                                                                                                                 \
+        allow_dynamic_lds(reinterpret_cast<const void*>(topk_fused_kernel<HPWV, PIVV>), 100 * 1024, DONE);                 \
+        hipLaunchKernelGGL((topk_fused_kernel<HPWV, PIVV>), dim3(B), dim3(1024), fl, s, p, ws, topk_p2, lazy ? 1 : 0,      \
+                           coupled_tk, lds_keys, piv_in ? hv_pivot : nullptr, fh, hv_widen);                               \
+      } while (0)
+      if (hpw == 4) { if (piv_in) KVC_FUSED(4, true, f4p_done); else KVC_FUSED(4, false, f4_done); }
+      else { if (piv_in) KVC_FUSED(16, true, f16p_done); else KVC_FUSED(16, false, f16_done); }
+#undef KVC_FUSED
+      if (hv_pivot != nullptr && !piv_in)
+        hipLaunchKernelGGL(harvest_pivot_kernel, dim3(B), dim3(1024), 0, s, p, ws, hv_pivot, fh, hv_widen);
     } else {
       hipLaunchKernelGGL((stream_records_kernel<4, 4>), dim3((G + 15) / 16), dim3(256), 0, s, p, ws, lazy ? 1 : 0);
       if (coupled_tk == 1) {

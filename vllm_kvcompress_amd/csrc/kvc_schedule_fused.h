@@ -39,13 +39,12 @@ __device__ __forceinline__ bool less64(uint32_t ahi, uint32_t alo, uint32_t bhi,
 
 template <int HPW, bool PIVOT>
 __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p, SchedWs ws, int P2, int lazy, int coupled,
-                                                          int write_back, uint32_t* hv_pivot, int from_harvest, float widen) {
+                                                          int lds_keys, uint32_t* hv_pivot, int from_harvest, float widen) {
   extern __shared__ __attribute__((aligned(16))) uint8_t sel_lds[];
   uint64_t* arr = reinterpret_cast<uint64_t*>(sel_lds);                 // [P2] recorded thresholds, dense
   uint32_t* cnt = reinterpret_cast<uint32_t*>(arr + P2);                // [16 * HPW] freed chunks per head
   __shared__ __attribute__((aligned(16))) uint64_t sort_s[4][KREC];     // lists beyond a wave (shared by four waves each)
-  __shared__ uint32_t fsum_s, k_s, nthr_s, big_lock[4], flag_s, nrem_s, hangsum_s;
-  __shared__ uint32_t piv_bc[4];
+  __shared__ uint32_t fsum_s, k_s, nthr_s, big_lock[4], flag_s;
   __shared__ unsigned long long vstar_s;
   __shared__ __attribute__((aligned(16))) uint32_t sel_hist[RADIX];
   __shared__ uint32_t sel_wtot[4];
@@ -58,11 +57,8 @@ __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p,
   const int G = B * LH;
 #ifdef KVC_TOPK_STAMPS
 #define KVC_STAMP(n) do { if (i == 1 && tid == 64) reinterpret_cast<unsigned long long*>(ws.bar)[n] = wall_clock64(); } while (0)
-#define KVC_LAP(acc, t0) do { const unsigned long long t_ = wall_clock64(); acc += t_ - t0; t0 = t_; } while (0)
-  unsigned long long lap_a = 0, lap_b = 0, lap_c = 0, lap_t = 0;
 #else
 #define KVC_STAMP(n) do { } while (0)
-#define KVC_LAP(acc, t0) do { } while (0)
 #endif
   KVC_STAMP(0);
   if (i == 0 && w == 0) {                            // (as stream_records_kernel: blocks nobody claimed, lists of another batch)
@@ -75,8 +71,7 @@ __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p,
       if (__ballot(bad) && lane == 0) atomicOr(ws.fallback, 1u);
     }
   }
-  if (tid == 0) { fsum_s = 0; nthr_s = 0; vstar_s = ~0ull; nrem_s = 0; hangsum_s = 0; }
-  const uint32_t used_pivot = (!PIVOT || hv_pivot == nullptr) ? 0u : (from_harvest ? hv_pivot[i] : ws.st_seqrec[i].pivot_excl);
+  if (tid == 0) { fsum_s = 0; nthr_s = 0; vstar_s = ~0ull; }
   if (tid < 4) big_lock[tid] = 0;
   for (int lh = tid; lh < 16 * HPW; lh += 1024) cnt[lh] = 0;
   __syncthreads();
@@ -115,55 +110,71 @@ __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p,
     if (lane == 0 && f) atomicAdd(&fsum_s, f);
   }
   KVC_STAMP(1);
-  // ---- records as ranks
-  uint32_t vlo[HPW], vhi[HPW], rk[HPW];
+  // ---- records as ranks, two heads at a time; the lists are requested a pair ahead and nothing of them stays in
+  // registers: the record goes back to global memory in rank order (what harvest_pivot_kernel behind reads, and what
+  // the emission below reads its first entries from), the thresholds into LDS
   uint32_t bigmask = 0;                              // heads of this wave whose list went through LDS (64 < C <= KREC)
-#pragma unroll
-  for (int q = 0; q < HPW; ++q) {
+  auto load_list = [&](int q) -> uint64_t {
     const uint32_t C = (uint32_t)__builtin_amdgcn_readlane((int)myC, q);
-    uint64_t x = ~0ull;
+    uint64_t x = ~0ull;                              // (a lane beyond the list's end: a key below nobody)
     if (C >= 1u && C <= (uint32_t)WAVE && (uint32_t)lane < C) x = ws.rec64[(gbase + lh0 + q) * KREC + lane];
-    vlo[q] = (uint32_t)x; vhi[q] = (uint32_t)(x >> 32);
-    rk[q] = 0xFFFFu;
-  }
-  // every list has arrived before the first head's write-back leaves: the stores below are counted by the same vmcnt
-  // as the loads above, their number is not known at compile time, and the compiler would wait for ALL of them -- that
-  // is, for the previous head's stores to be acknowledged -- before it touches the next head's list: sixteen store
-  // round trips in a row (profiles/r5_topk_fused_phases.txt)
-  KVC_WAIT_VMEM();
+    return x;
+  };
+  static_assert(HPW % 2 == 0, "heads are ranked two at a time");
+  uint64_t xcur[2] = {load_list(0), load_list(1)};
 #pragma unroll
-  for (int q = 0; q < HPW; ++q) {
+  for (int q2 = 0; q2 < HPW; q2 += 2) {
+    uint64_t xnext[2] = {~0ull, ~0ull};
+    if (q2 + 2 < HPW) { xnext[0] = load_list(q2 + 2); xnext[1] = load_list(q2 + 3); }
+    const uint32_t plo[2] = {(uint32_t)xcur[0], (uint32_t)xcur[1]};
+    const uint32_t phi[2] = {(uint32_t)(xcur[0] >> 32), (uint32_t)(xcur[1] >> 32)};
+    // ranks by key of TWO heads in one loop: two independent chains of readlane -> compare -> add for the in-order
+    // issue of a wave that shares its SIMD with three others (the loop runs to the longer list: a lane beyond a list's
+    // end holds 0xFFFFFFFF, which is below nobody)
+    uint32_t rpair[2] = {0u, 0u};
+    {
+      const uint32_t Ca = (uint32_t)__builtin_amdgcn_readlane((int)myC, q2), Cb = (uint32_t)__builtin_amdgcn_readlane((int)myC, q2 + 1);
+      const int n = (int)max(Ca <= (uint32_t)WAVE ? Ca : 0u, Cb <= (uint32_t)WAVE ? Cb : 0u);
+      const uint32_t ma = phi[0], mb = phi[1];
+      uint32_t ra = 0, rb = 0;
+      int j = 0;
+      for (; j + 4 <= n; j += 4) {                     // (unrolled by hand: the compiler will not unroll around readlane)
+        const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)ma, j), a1 = (uint32_t)__builtin_amdgcn_readlane((int)ma, j + 1);
+        const uint32_t a2 = (uint32_t)__builtin_amdgcn_readlane((int)ma, j + 2), a3 = (uint32_t)__builtin_amdgcn_readlane((int)ma, j + 3);
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)mb, j), b1 = (uint32_t)__builtin_amdgcn_readlane((int)mb, j + 1);
+        const uint32_t b2 = (uint32_t)__builtin_amdgcn_readlane((int)mb, j + 2), b3 = (uint32_t)__builtin_amdgcn_readlane((int)mb, j + 3);
+        ra += (a0 < ma ? 1u : 0u) + (a1 < ma ? 1u : 0u) + (a2 < ma ? 1u : 0u) + (a3 < ma ? 1u : 0u);
+        rb += (b0 < mb ? 1u : 0u) + (b1 < mb ? 1u : 0u) + (b2 < mb ? 1u : 0u) + (b3 < mb ? 1u : 0u);
+      }
+      for (; j < n; ++j) {
+        ra += (uint32_t)__builtin_amdgcn_readlane((int)ma, j) < ma ? 1u : 0u;
+        rb += (uint32_t)__builtin_amdgcn_readlane((int)mb, j) < mb ? 1u : 0u;
+      }
+      rpair[0] = ra; rpair[1] = rb;
+    }
+#pragma unroll
+    for (int hq = 0; hq < 2; ++hq) {
+    const int q = q2 + hq;
     const uint32_t C = (uint32_t)__builtin_amdgcn_readlane((int)myC, q);
     const uint32_t hang = (uint32_t)__builtin_amdgcn_readlane((int)myHang, q);
     const int lh = lh0 + q;
     if (C == 0u || C > (uint32_t)KREC) continue;                                // wave-uniform
     uint64_t* rec = ws.rec64 + (gbase + lh) * KREC;
     if (C <= (uint32_t)WAVE) {
-      // the key (high word) decides almost always: rank by it alone (readlane + compare + add with carry), and again
-      // with the slot as tie-break only if two entries of the list share a key -- which shows in the sum of the
-      // ranks: sum_i #{j : key_j < key_i} = C (C - 1) / 2 less the tied pairs
-      uint32_t r = 0;
-      {
-        const uint32_t me = vhi[q];
-        int j = 0;
-        for (; j + 4 <= (int)C; j += 4) {              // (unrolled by hand: the compiler will not unroll around readlane)
-          const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)me, j), a1 = (uint32_t)__builtin_amdgcn_readlane((int)me, j + 1);
-          const uint32_t a2 = (uint32_t)__builtin_amdgcn_readlane((int)me, j + 2), a3 = (uint32_t)__builtin_amdgcn_readlane((int)me, j + 3);
-          r += (a0 < me ? 1u : 0u) + (a1 < me ? 1u : 0u) + (a2 < me ? 1u : 0u) + (a3 < me ? 1u : 0u);
-        }
-        for (; j < (int)C; ++j) r += (uint32_t)__builtin_amdgcn_readlane((int)me, j) < me ? 1u : 0u;
-      }
+      // the key (high word) decides almost always: ranked by it alone above, and again with the slot as tie-break only
+      // if two entries of the list share a key -- which shows in the sum of the ranks:
+      // sum_i #{j : key_j < key_i} = C (C - 1) / 2 less the tied pairs
+      uint32_t r = rpair[hq];
       const bool in = (uint32_t)lane < C;
       if (wave_reduce_sum_full(in ? r : 0u) != C * (C - 1u) / 2u) {            // wave-uniform
         r = 0;
         for (int j = 0; j < (int)C; ++j) {
-          const uint32_t ohi = (uint32_t)__builtin_amdgcn_readlane((int)vhi[q], j);
-          const uint32_t olo = (uint32_t)__builtin_amdgcn_readlane((int)vlo[q], j);
-          r += less64(ohi, olo, vhi[q], vlo[q]) ? 1u : 0u;
+          const uint32_t ohi = (uint32_t)__builtin_amdgcn_readlane((int)phi[hq], j);
+          const uint32_t olo = (uint32_t)__builtin_amdgcn_readlane((int)plo[hq], j);
+          r += less64(ohi, olo, phi[hq], plo[hq]) ? 1u : 0u;
         }
       }
-      rk[q] = in ? r : 0xFFFFu;
-      if (write_back && in && kreq > 0) rec[r] = ((uint64_t)vhi[q] << 32) | vlo[q];
+      if (in && kreq > 0) rec[r] = xcur[hq];           // (a sequence nothing is asked of emits nothing and leaves no pivot)
       // thresholds sit at ranks hang - 1 + c * bs
       const bool thr = in && kreq > 0 && hang >= 1u && r + 1u >= hang && ((r + 1u - hang) & (uint32_t)(bs - 1)) == 0u &&
                        ((r + 1u - hang) >> sh) < (uint32_t)MCH;
@@ -174,7 +185,7 @@ __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p,
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         if (thr) {
           const uint32_t e = (uint32_t)lh * (uint32_t)MCH + ((r + 1u - hang) >> sh);
-          arr[base + __popcll(tm & ((1ull << lane) - 1ull))] = ((uint64_t)vhi[q] << 32) | e;
+          arr[base + __popcll(tm & ((1ull << lane) - 1ull))] = ((uint64_t)phi[hq] << 32) | e;
         }
       }
     } else {
@@ -209,6 +220,8 @@ __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p,
       wave_lds_sync();
       if (lane == 0) atomicExch(&big_lock[bq], 0u);
     }
+    }
+    xcur[0] = xnext[0]; xcur[1] = xnext[1];
   }
   KVC_STAMP(2);
   __syncthreads();
@@ -283,13 +296,22 @@ __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p,
       p.evicted_kv_count[gbase + lh0 + lane] = (int32_t)ceV;
     }
   }
+  // the evicted entries are the first ce of the head's record, which the ranks phase left in rank order (written by
+  // this wave before the barriers above; read past the L1 all the same).  Two loops: every head's slots requested,
+  // then every head's logical block numbers -- two round trips to the L2 for the wave, not two per head
 #pragma unroll
-  for (int q = 0; q < HPW; ++q) {                     // the evicted entries' logical indices requested
+  for (int q = 0; q < HPW; ++q) {
     ce[q] = (uint32_t)__builtin_amdgcn_readlane((int)ceV, q);
     u[q] = 0xFFFFFFFFu;
-    if (lh0 + q >= LH) continue;                      // wave-uniform
-    if (!flagged && !(bigmask & (1u << q)) && rk[q] < ce[q])
-      u[q] = ((uint32_t)p.logical_block_num_by_block[vlo[q] >> sh] << sh) | (vlo[q] & (uint32_t)(bs - 1));
+    if (lh0 + q < LH && !flagged && !(bigmask & (1u << q)) && (uint32_t)lane < ce[q])
+      u[q] = __atomic_load_n(reinterpret_cast<const uint32_t*>(ws.rec64 + (gbase + lh0 + q) * KREC + lane), __ATOMIC_RELAXED);
+  }
+#pragma unroll
+  for (int q = 0; q < HPW; ++q) {
+    if (lh0 + q < LH && !flagged && !(bigmask & (1u << q)) && (uint32_t)lane < ce[q]) {
+      const uint32_t slot = u[q];
+      u[q] = ((uint32_t)p.logical_block_num_by_block[slot >> sh] << sh) | (slot & (uint32_t)(bs - 1));
+    }
   }
   KVC_STAMP(5);
   if (!flagged) {
@@ -300,39 +322,46 @@ __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p,
   const bool dirty_done = !tracked || nheads <= 0 ||
                           eli_dirty_apply_owners(p.eli_dirty_map, p.evicted_logical_indices, myOff, myEnd, ceV, nheads, sh, p.null_value, lane);
 #pragma unroll
-  for (int q = 0; q < HPW; ++q) {
+  for (int q2 = 0; q2 < HPW; q2 += 2) {
+    if (lh0 + q2 >= LH) break;                        // wave-uniform
+    // ranks by logical index among the evicted entries of TWO heads in one loop (as the ranks by key above): the evicted
+    // sit in lanes 0 .. ce - 1, the others hold 0xFFFFFFFF (a head whose list went through LDS: everywhere)
+    uint32_t r2p[2] = {0u, 0u};
+    const int nev[2] = {(bigmask >> q2 & 1u) ? 0 : (int)min(ce[q2], (uint32_t)WAVE),
+                        (bigmask >> (q2 + 1) & 1u) ? 0 : (int)min(ce[q2 + 1], (uint32_t)WAVE)};
+    {
+      const int n = max(nev[0], nev[1]);
+      const uint32_t ma = u[q2], mb = u[q2 + 1];
+      uint32_t ra = 0, rb = 0;
+      int j = 0;
+      for (; j + 4 <= n; j += 4) {
+        const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)ma, j), a1 = (uint32_t)__builtin_amdgcn_readlane((int)ma, j + 1);
+        const uint32_t a2 = (uint32_t)__builtin_amdgcn_readlane((int)ma, j + 2), a3 = (uint32_t)__builtin_amdgcn_readlane((int)ma, j + 3);
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)mb, j), b1 = (uint32_t)__builtin_amdgcn_readlane((int)mb, j + 1);
+        const uint32_t b2 = (uint32_t)__builtin_amdgcn_readlane((int)mb, j + 2), b3 = (uint32_t)__builtin_amdgcn_readlane((int)mb, j + 3);
+        ra += (a0 < ma ? 1u : 0u) + (a1 < ma ? 1u : 0u) + (a2 < ma ? 1u : 0u) + (a3 < ma ? 1u : 0u);
+        rb += (b0 < mb ? 1u : 0u) + (b1 < mb ? 1u : 0u) + (b2 < mb ? 1u : 0u) + (b3 < mb ? 1u : 0u);
+      }
+      for (; j < n; ++j) {
+        ra += (uint32_t)__builtin_amdgcn_readlane((int)ma, j) < ma ? 1u : 0u;
+        rb += (uint32_t)__builtin_amdgcn_readlane((int)mb, j) < mb ? 1u : 0u;
+      }
+      r2p[0] = ra; r2p[1] = rb;
+    }
+#pragma unroll
+    for (int hq = 0; hq < 2; ++hq) {
+    const int q = q2 + hq;
     const int lh = lh0 + q;
     if (lh >= LH) break;                              // wave-uniform
     const int64_t g = gbase + lh;
     const int32_t off = __builtin_amdgcn_readlane(myOff, q), end = __builtin_amdgcn_readlane(myEnd, q);
-#ifdef KVC_TOPK_STAMPS
-    if (q == 0) lap_t = wall_clock64();
-#endif
     if (!dirty_done)
       eli_dirty_update(p.eli_dirty_map, p.evicted_logical_indices, off >> sh, end >> sh, (int64_t)((ce[q] + (uint32_t)bs - 1u) >> sh),
                        (int64_t)off + ce[q], bs, p.null_value, true, lane, WAVE);
-    KVC_LAP(lap_a, lap_t);
     if (ce[q] == 0) continue;
     int32_t* out = p.evicted_logical_indices + off;
     if (!(bigmask & (1u << q))) {
-      // rank by logical index among the evicted entries.  Their ranks by metric are 0 .. ce - 1: pushed to the lane of
-      // that rank (one ds_permute) they sit in the first ce lanes, and all pairs is ce steps, not C (the pushed
-      // 0xFFFFFFFF of the entries that stay land behind them)
-      const uint32_t C = (uint32_t)__builtin_amdgcn_readlane((int)myC, q);
-      uint32_t me = 0xFFFFFFFFu;
-      if ((uint32_t)lane < C) me = (uint32_t)__builtin_amdgcn_ds_permute((int)(rk[q] << 2), (int)u[q]);
-      const int n = (int)min(ce[q], C);
-      uint32_t r2 = 0;
-      int j = 0;
-      for (; j + 4 <= n; j += 4) {
-        const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)me, j), a1 = (uint32_t)__builtin_amdgcn_readlane((int)me, j + 1);
-        const uint32_t a2 = (uint32_t)__builtin_amdgcn_readlane((int)me, j + 2), a3 = (uint32_t)__builtin_amdgcn_readlane((int)me, j + 3);
-        r2 += (a0 < me ? 1u : 0u) + (a1 < me ? 1u : 0u) + (a2 < me ? 1u : 0u) + (a3 < me ? 1u : 0u);
-      }
-      for (; j < n; ++j) r2 += (uint32_t)__builtin_amdgcn_readlane((int)me, j) < me ? 1u : 0u;
-      KVC_LAP(lap_b, lap_t);
-      if (lane < n) out[r2] = (int32_t)me;
-      KVC_LAP(lap_c, lap_t);
+      if (lane < nev[hq]) out[r2p[hq]] = (int32_t)u[q];
     } else {
       // (this wave wrote the sorted record to global memory above: read past the L1)
       const int bq = w & 3;
@@ -348,62 +377,24 @@ __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p,
       wave_lds_sync();
       if (lane == 0) atomicExch(&big_lock[bq], 0u);
     }
+    }
   }
   }
   KVC_STAMP(6);
-#ifdef KVC_TOPK_STAMPS
-  if (i == 1 && tid == 64) {
-    unsigned long long* st_ = reinterpret_cast<unsigned long long*>(ws.bar);
-    st_[8] = lap_a; st_[9] = lap_b; st_[10] = lap_c;
-  }
-#endif
-  // ---- the pivot for the next decode step's harvest from what is left of the lists (section 10)
-  if (!PIVOT || hv_pivot == nullptr) return;
-  if (kreq <= 0) {                                   // nothing asked of this sequence: lists made for nothing say nothing new
-    if (tid == 0 && !from_harvest) hv_pivot[i] = 0u;
-    return;
-  }
-  __syncthreads();                                   // (the thresholds in arr are not needed any more)
-  uint32_t* keys_s = reinterpret_cast<uint32_t*>(arr);
-  const uint32_t cap = 2u * (uint32_t)P2;
-  {
-    const uint32_t hs = wave_reduce_sum_full((lane < HPW && lh0 + lane < LH && myHang >= 1u) ? myHang - 1u : 0u);
-    if (lane == 0 && hs) atomicAdd(&hangsum_s, hs);
-  }
-#pragma unroll
-  for (int q = 0; q < HPW; ++q) {
-    const int lh = lh0 + q;
-    if (lh >= LH) break;                              // wave-uniform
-    const uint32_t C = min((uint32_t)__builtin_amdgcn_readlane((int)myC, q), (uint32_t)KREC);
-    if (C == 0u) continue;
-    if (!(bigmask & (1u << q))) {
-      const bool rem = (uint32_t)lane < C && rk[q] >= ce[q] && rk[q] != 0xFFFFu;
-      const unsigned long long m = __ballot(rem);
-      if (m) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&nrem_s, (uint32_t)__popcll(m));
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (rem && at < cap) keys_s[at] = vhi[q];
-      }
-    } else {
-      const uint64_t* rec = ws.rec64 + (gbase + lh) * KREC;
-      const uint32_t first = min(ce[q], C);
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(&nrem_s, C - first);
-      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-      for (uint32_t j = first + (uint32_t)lane; j < C; j += WAVE)
-        if (base + (j - first) < cap) keys_s[base + (j - first)] = (uint32_t)(__atomic_load_n(rec + j, __ATOMIC_RELAXED) >> 32);
+  // ---- the pivots for the next decode step's harvest from what is left of the lists (section 10): harvest_pivot_kernel's
+  // body as this kernel's last phase -- the records are in rank order in global memory, the counts are out, and the
+  // LDS of the thresholds is free for the keys (lds_keys: what the host sized the dynamic region for)
+  if constexpr (PIVOT) {
+    if (hv_pivot != nullptr) {
+      __shared__ uint32_t piv_pre_s[16 * HPW + 1];
+      __shared__ uint16_t piv_start_s[16 * HPW];
+      __shared__ uint32_t piv_wsum_s[16], piv_hang_s;
+      __syncthreads();                               // (every wave is done with the thresholds' counts; the counts and records are out)
+      const PivotLds S{sel_hist, sel_wtot, piv_pre_s, piv_start_s, piv_wsum_s, &piv_hang_s, reinterpret_cast<uint32_t*>(sel_lds),
+                       (uint32_t)lds_keys};
+      harvest_pivot_body(p, ws, hv_pivot, from_harvest, widen, i, S);
     }
   }
-  __syncthreads();
-  const uint32_t R = nrem_s;
-  uint32_t next = used_pivot;
-  if (R <= cap) {
-    auto val = [&](int x) -> uint32_t { return keys_s[x]; };
-    next = next_pivot_from_keys(sel_hist, piv_bc, R, val, kreq, bs, hangsum_s, used_pivot, widen);
-  }
-  if (tid == 0) hv_pivot[i] = next;
   KVC_STAMP(7);
 }
 

@@ -267,18 +267,22 @@ constexpr int HVP_LDS_KEYS = 12288;                  // keys of a sequence stage
 // decode step from what is left of this call's lists (see the head of this section).
 //   used_pivot: the pivots the lists were made with (the harvest buffer's own for harvested lists
 //   -- read before they are overwritten -- or nullptr: st_seqrec's, this call's collecting pass)
-__global__ __launch_bounds__(1024) void harvest_pivot_kernel(kvc_schedule_params p, SchedWs ws, uint32_t* hv_pivot,
-                                                              int from_harvest, float widen) {
-  __shared__ __attribute__((aligned(16))) uint32_t hist[RADIX];
-  __shared__ uint32_t bc[4];
-  __shared__ uint32_t pre_s[PIV_MAXLH + 1];          // exclusive prefix of the heads' remaining entries
-  __shared__ uint16_t start_s[PIV_MAXLH];            // first remaining entry of a head's record (= its evicted count)
-  __shared__ uint32_t wsum_s[16];
-  __shared__ uint32_t hang_s;
-  __shared__ __attribute__((aligned(16))) uint32_t keys_s[HVP_LDS_KEYS];
-  const int i = blockIdx.x, tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
+// (the body: harvest_pivot_kernel's, and topk_fused_kernel's last phase -- the LDS is the caller's)
+struct PivotLds {
+  uint32_t* hist;                                    // [RADIX], 16-byte aligned
+  uint32_t* bc;                                      // [4]
+  uint32_t* pre_s;                                   // [LH + 1] exclusive prefix of the heads' remaining entries
+  uint16_t* start_s;                                 // [LH] first remaining entry of a head's record (= its evicted count)
+  uint32_t* wsum_s;                                  // [16]
+  uint32_t* hang_s;                                  // [1]
+  uint32_t* keys_s;                                  // [keys_cap] a sequence's remaining keys (more: read from L2 every round)
+  uint32_t keys_cap;
+};
+__device__ __forceinline__ void harvest_pivot_body(const kvc_schedule_params& p, const SchedWs& ws, uint32_t* hv_pivot, int from_harvest,
+                                                   float widen, int i, const PivotLds& S) {
+  const int tid = threadIdx.x, lane = lane_id(), w = tid >> 6;
   const int LH = p.num_layers * p.num_kv_heads, bs = p.block_size;
-  if (tid == 0) hang_s = 0;
+  if (tid == 0) *S.hang_s = 0;
   __syncthreads();
   {
     uint32_t r = 0, hs = 0;
@@ -287,22 +291,22 @@ __global__ __launch_bounds__(1024) void harvest_pivot_kernel(kvc_schedule_params
       const uint32_t C = min(ws.st_cnt[g], (uint32_t)KREC);
       const uint32_t cnt = min((uint32_t)max(p.evicted_kv_count[g], 0), C);
       r = C - cnt;
-      start_s[tid] = (uint16_t)cnt;
+      S.start_s[tid] = (uint16_t)cnt;
       const uint32_t hang = (uint32_t)p.hanging_token_count[g];
       hs = hang >= 1u ? hang - 1u : 0u;
     }
     const uint32_t inc = wave_inclusive_scan_full(r);
-    if (lane == WAVE - 1) wsum_s[w] = inc;
+    if (lane == WAVE - 1) S.wsum_s[w] = inc;
     hs = wave_reduce_sum_full(hs);
-    if (lane == 0 && hs) atomicAdd(&hang_s, hs);
+    if (lane == 0 && hs) atomicAdd(S.hang_s, hs);
     __syncthreads();
     uint32_t woff = 0;
-    for (int q = 0; q < w; ++q) woff += wsum_s[q];
-    if (tid < LH) pre_s[tid] = woff + inc - r;
-    if (tid == LH - 1) pre_s[LH] = woff + inc;
+    for (int q = 0; q < w; ++q) woff += S.wsum_s[q];
+    if (tid < LH) S.pre_s[tid] = woff + inc - r;
+    if (tid == LH - 1) S.pre_s[LH] = woff + inc;
   }
   __syncthreads();
-  const uint32_t R = pre_s[LH];
+  const uint32_t R = S.pre_s[LH];
   const int k = p.evicted_blocks_per_seq[i];
   const uint32_t used = from_harvest ? hv_pivot[i] : ws.st_seqrec[i].pivot_excl;
   if (k <= 0) {                                      // nothing asked of this sequence: lists made for nothing say nothing new
@@ -310,6 +314,8 @@ __global__ __launch_bounds__(1024) void harvest_pivot_kernel(kvc_schedule_params
     return;
   }
   __syncthreads();                                   // (everybody has read the old pivot before it is written below)
+  const uint32_t* pre_s = S.pre_s;
+  const uint16_t* start_s = S.start_s;
   auto key_at = [&](uint32_t x) -> uint32_t {        // flat index x < R -> the key of that remaining entry
     int lo = 0, hi = LH;                             // pre_s[lo] <= x < pre_s[hi]
     while (hi - lo > 1) {
@@ -317,16 +323,31 @@ __global__ __launch_bounds__(1024) void harvest_pivot_kernel(kvc_schedule_params
       if (pre_s[mid] <= x) lo = mid; else hi = mid;
     }
     const int64_t e = ((int64_t)i * LH + lo) * KREC + start_s[lo] + (x - pre_s[lo]);
-    return (uint32_t)(ws.rec64[e] >> 32);
+    // (past the L1: inside topk_fused_kernel the records were put in rank order by this very workgroup)
+    return (uint32_t)(__atomic_load_n(ws.rec64 + e, __ATOMIC_RELAXED) >> 32);
   };
-  const bool staged = R <= (uint32_t)HVP_LDS_KEYS;
+  uint32_t* keys_s = S.keys_s;
+  const bool staged = R <= S.keys_cap;
   if (staged) {
     for (uint32_t x = tid; x < R; x += 1024u) keys_s[x] = key_at(x);
     __syncthreads();
   }
   auto val = [&](int x) -> uint32_t { return staged ? keys_s[x] : key_at((uint32_t)x); };
-  const uint32_t next = next_pivot_from_keys(hist, bc, R, val, k, bs, hang_s, used, widen);
+  const uint32_t next = next_pivot_from_keys(S.hist, S.bc, R, val, k, bs, *S.hang_s, used, widen);
   if (tid == 0) hv_pivot[i] = next;
+}
+
+__global__ __launch_bounds__(1024) void harvest_pivot_kernel(kvc_schedule_params p, SchedWs ws, uint32_t* hv_pivot,
+                                                              int from_harvest, float widen) {
+  __shared__ __attribute__((aligned(16))) uint32_t hist[RADIX];
+  __shared__ uint32_t bc[4];
+  __shared__ uint32_t pre_s[PIV_MAXLH + 1];
+  __shared__ uint16_t start_s[PIV_MAXLH];
+  __shared__ uint32_t wsum_s[16];
+  __shared__ uint32_t hang_s;
+  __shared__ __attribute__((aligned(16))) uint32_t keys_s[HVP_LDS_KEYS];
+  const PivotLds S{hist, bc, pre_s, start_s, wsum_s, &hang_s, keys_s, (uint32_t)HVP_LDS_KEYS};
+  harvest_pivot_body(p, ws, hv_pivot, from_harvest, widen, blockIdx.x, S);
 }
 
 }  // namespace kvc
