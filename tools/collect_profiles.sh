@@ -115,6 +115,11 @@ cp "$REPO/gpurun_out/${TAG}_decode_step_kernel_stats.csv" "$OUT/" 2>/dev/null
 cd "$REPO"
 "$REPO/tools/collect_decode_step_pmc.sh" "$TAG" > "$OUT/${TAG}_decode_step_pmc.txt" 2>&1
 cp "$REPO/gpurun_out/${TAG}_decode_step_pmc.json" "$OUT/" 2>/dev/null
+# 5a. the launches of one decode step in order (S1 on the lists the aggregation pass / the attention's epilogue made)  -> <tag>_s1_timeline.txt
+(cd /tmp && rm -rf /tmp/tl_$TAG && timeout 600 rocprofv3 --kernel-trace -d /tmp/tl_$TAG --output-format csv -- python "$REPO/tools/decode_step.py" > /dev/null 2> "$OUT/timeline.err";
+ cd "$REPO" && (echo "# fork flow: aggregate_decode() harvests for the next call, schedule_evictions on its lists"; python tools/s1_timeline.py /tmp/tl_$TAG aggregate_harvest_kernel;
+                echo "# zero-sweep step: the last layer's attention launch with the harvesting epilogue, then the schedule"; python tools/s1_timeline.py /tmp/tl_$TAG paged_attention | tail -9)) > "$OUT/${TAG}_s1_timeline.txt" 2>> "$OUT/timeline.err"
+cd "$REPO"
 # 5b. the decode step in the fork's default mode (the reference's batch > 1 rule), with the oracle's two-stage verdict
 timeout 600 python tools/decode_step.py --mode reference > "$OUT/${TAG}_decode_step_c3_reference_mode.json" 2> "$OUT/ds_ref.err"
 # 5c. the zero-sweep decode step over 400 iterations of an evolving state: fused attention + epilogue harvest against the reference flow
