@@ -10,29 +10,33 @@
 
 namespace kvc {
 
-// ------------------------------------------------------------------ 7b. records + selection + emission in ONE launch
+// ------------------------------------------------------------------ 7b. records + selection + emission (+ next pivots) in ONE launch
 // On lists somebody else made (the aggregation pass, the attention's epilogue) or with remembered pivots the
-// schedule is a handful of tiny dependent launches -- records 39 us, selection 22, emission 42 at 65 536 heads of
-// ~20 entries.  Those are not latency: rocprofv3 shows the bitonic sorts (42 ds_bpermute per 64-bit list, 21 per
-// emitted list, every wave of a CU through the one LDS crossbar) as the cost.  Nothing here needs a SORTED list:
+// schedule is a handful of tiny dependent launches -- records 39 us, selection 22, emission 42, next pivots 20 at
+// 65 536 heads of ~20 entries.  Those are not latency: rocprofv3 shows the bitonic sorts (42 ds_bpermute per 64-bit
+// list, 21 per emitted list, every wave of a CU through the one LDS crossbar) as the cost.  Nothing here needs a SORTED
+// list:
 //   * a chunk threshold is the entry of RANK hang - 1 + c * bs, the evicted set is the entries of rank < cnt, the
 //     emission wants them at their rank by LOGICAL index -- ranks, not orders;
 //   * a list of C <= 64 entries is one 64-bit value per lane, and a lane's rank is the number of entries below its
 //     own: C steps of v_readlane (a scalar broadcast: no LDS, no cross-lane network) + compare + add.
-// One workgroup per sequence (16 waves, HPW heads per wave): ranks in registers, thresholds into a dense LDS list
-// (~2 per head), the k'-th smallest of them by all-pairs ranking again (a few hundred entries; the radix rounds of
-// seq_select_topk_kernel beyond 1024), and the wave that holds a head's entries emits them: no record is written and
-// read back, no second and third launch.  Lists beyond 64 entries (rare: a head that takes most of a sequence's
-// eviction) are sorted through LDS as in stream_records_kernel / emit_topk_kernel.  For calls whose sequences do not
-// need each other's counts (mode 1, one sequence: `coupled` 0 or 2 as in seq_select_topk_kernel) with at most
-// 16 * HPW heads per sequence; everything else keeps the launch chain.  write_back: the records in rank order to
-// global memory, for harvest_pivot_kernel behind.  PIVOT (measured and NOT used: the host instantiates false): the
-// pivots for the next decode step as this kernel's last phase, from the entries of rank >= cnt staged in the LDS the
-// thresholds have left -- 11 us in the kernel against a 20 us launch, but the ranks and keys that then stay live
-// through the emission cost it 12 us in spills (profiles/r5_topk_fused_phases.txt).
-// s_waitcnt vmcnt(0) (gfx9 encoding: vmcnt = bits 3:0 and 15:14; expcnt 6:4 and lgkmcnt 11:8 left at their maxima)
-#define KVC_WAIT_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)
-
+// One workgroup per sequence (16 waves, HPW heads per wave).  Phases:
+//   ranks     two heads per loop (two independent chains for a wave's in-order issue), the lists requested a pair
+//             ahead; the record goes back to global memory in RANK order (lane -> rec[rank]) and nothing of it stays
+//             in registers; thresholds into a dense LDS list (~2 per head)
+//   select    the k'-th smallest threshold by six radix rounds of the workgroup
+//   counts    a lane per head (two coalesced stores per wave); the evicted entries are rec[0 .. ce): their slots,
+//             then their logical block numbers, two rounds of loads for all the wave's heads
+//   emit      rank by logical index among the evicted (lanes 0 .. ce - 1, all pairs, two heads per loop); the kept
+//             output list's dirty map a lane per (head, map word) (eli_dirty_apply_owners)
+//   pivots    (PIVOT) harvest_pivot_kernel's body: the next decode step's pivots from rec[ce .. C), staged in the
+//             LDS the thresholds have left
+// Lists beyond 64 entries (rare: a head that takes most of a sequence's eviction) are sorted through LDS as in
+// stream_records_kernel / emit_topk_kernel.  For calls whose sequences do not need each other's counts (mode 1, one
+// sequence: `coupled` 0 or 2 as in seq_select_topk_kernel) with at most 16 * HPW heads per sequence; everything else
+// keeps the launch chain.  The kernel is bound by instruction issue, not by memory, LDS or the instruction cache
+// (profiles/r5_topk_fused_phases.txt has the stamps of every version and the counters): what counts is instructions
+// per head.
 __device__ __forceinline__ bool less64(uint32_t ahi, uint32_t alo, uint32_t bhi, uint32_t blo) {
   return ahi < bhi || (ahi == bhi && alo < blo);
 }
