@@ -521,3 +521,37 @@ def test_prediction_with_several_decode_steps_between_two_schedule_calls():
     # call 0: no pivots yet; call 1: the gap was not known (assumed 1: the first aggregation harvested, the next two dropped
     # its lists); from call 2 on the third aggregation harvests for positions + 3
     assert used[0] is False and all(used[2:]), used
+
+
+def test_predictions_nobody_takes_are_paused():
+    """an engine that writes to the store between aggregate_decode() and schedule_evictions() (here: a no-op write to
+    the position table, which bumps its version counter) voids every prediction: after three in a row the predictions
+    pause -- aggregate_decode() is the plain pass again -- and the schedules stay the oracle's throughout"""
+    bs, cap = 16, 320
+    seq_lens = [cap + 120, cap + 70]
+    st = synth.make_state(num_layers=2, num_kv_heads=4, block_size=bs, seq_lens=seq_lens, seed=17, protected=bs + 1,
+                          steady_cap=cap)
+    ds = hdev.upload(st, DEV, num_queries_per_kv=4, mode="per_sequence")
+    cm = ds.cm
+    cm.strict_fallback = True
+    rng = np.random.default_rng(4)
+    seqs, prot = list(st.seq_indices), list(st.protected)
+    made = []
+    for call in range(9):
+        temp = rng.random((st.num_blocks, bs, 4)).astype(np.float32)
+        cm.temp_metrics.copy_(torch.from_numpy(temp))
+        orc.aggregate_decode(st.metrics, temp, use_l2=True)
+        cm.aggregate_decode()
+        made.append(cm._hv_lists is not None)
+        cm.token_positions.add_(0)                                  # somebody writes to the store
+        st.seq_positions = st.seq_positions + 1
+        want = oracle_pipeline(st, [8, 8], mode="per_sequence")
+        pos_t = torch.from_numpy(st.seq_positions.astype(np.int32)).to(DEV)
+        eli, ekc, ebc = cm.schedule_evictions(seqs, pos_t, [8, 8], ds.context_lens, ds.hanging_token_count,
+                                              ds.evicted_kv_offsets, prot, total_slots=st.total_slots)
+        assert not cm.last_harvest_used
+        np.testing.assert_array_equal(eli.cpu().numpy(), want["eli"], err_msg=f"call {call}")
+        np.testing.assert_array_equal(ekc.cpu().numpy(), want["ekc"], err_msg=f"call {call}")
+    np.testing.assert_array_equal(cm.metrics.cpu().numpy(), st.metrics)
+    # call 0: nothing to predict from; calls 1-3: predictions made and void; then four schedule calls without
+    assert made == [False, True, True, True, False, False, False, False, True], made

@@ -224,6 +224,13 @@ class CompressionMetrics:
         # by the LAST of them -- the gap seen last time says which one that is -- for positions + that many tokens)
         self._aggs_since_schedule = 0
         self._last_gap = 1
+        # (an engine whose order of calls makes every prediction void -- say, one that writes to the store between the
+        # aggregation and the schedule call -- would pay for lists it never uses: three predictions in a row that no
+        # call took pause the predictions for 4, 8 ... 256 schedule calls)
+        self._spec_made = False
+        self._spec_unused = 0
+        self._spec_pause = 0
+        self._spec_pause_len = 0
         self.last_pivot_memory_used = False
         self.last_harvest_used = False     # the last schedule_evictions ran on harvested lists
         self.harvest_misses = 0            # harvested calls whose lists fell short (flag raised, redone on device)
@@ -375,6 +382,7 @@ class CompressionMetrics:
         hv = self._hv
         if not (self.speculative_harvest and self.harvest_ahead is not False and hv is not None and hv.get("full")
                 and hv["buf"] is self._hv_buf and hv.get("seq_pos") is not None and self._hv_pause == 0 and not self._fb_fault
+                and self._spec_pause == 0
                 and not (self._fb_backoff > 0 and int(self.schedule_path) == 0)):
             return False
         capturing = torch.cuda.is_current_stream_capturing()
@@ -405,6 +413,7 @@ class CompressionMetrics:
         torch.autograd.graph.increment_version(self.metrics)     # (written through a raw pointer)
         self._hv_lists = dict(seqs=hv["seqs"], attention=True, speculative=True, k=hv["k"], stream=stream, buf=self._hv_buf,
                               store=self._store_versions())
+        self._spec_made = True
         return True
 
     # ------------------------------------------------------------------ harvest-ahead
@@ -900,6 +909,18 @@ class CompressionMetrics:
             self._hv = None
         self.last_harvest_used = bool(p.harvest & 1)
         self.last_pivot_memory_used = bool(p.harvest & 4)
+        made, self._spec_made = self._spec_made, False
+        if self._spec_pause > 0:
+            self._spec_pause -= 1
+        if made:
+            if (p.harvest & 1) and hl is not None and hl.get("speculative", False):
+                self._spec_unused = self._spec_pause_len = 0
+            else:
+                self._spec_unused += 1
+                if self._spec_unused >= 3:
+                    self._spec_unused = 0
+                    self._spec_pause_len = min(max(2 * self._spec_pause_len, 4), 256)
+                    self._spec_pause = self._spec_pause_len
         plan = int(lib.kvc_schedule_evictions_plan(ctypes.byref(p)))
         if self.reuse_output_buffer and not self.lean_outputs and N > 0 and not capturing and plan == 1:
             out_idx = self._tracked_output(N, bs, p)
