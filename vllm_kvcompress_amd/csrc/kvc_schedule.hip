@@ -492,7 +492,9 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     // -- and runs only if the flag was raised.  With the pivots of the call before (harvest bit 2)
     // the sampling pass and the pivot kernel are not launched; on lists the aggregation pass made
     // (bit 0) the collecting pass is not either: records | selection | next pivots | emission.
-    fill32_async(wb + l.tz_begin, 0u, l.tz_end - l.tz_begin, s);
+    // (on harvested lists the claims, counts and deficits are the harvest buffer's, zeroed where they were made, and
+    // nothing is sampled: only the flag block is this call's to clear)
+    fill32_async(wb + l.tz_begin, 0u, (p.harvest & 1) != 0 && p.harvest_buf != nullptr ? l.st_claimed - l.tz_begin : l.tz_end - l.tz_begin, s);
     SideStream* side = nullptr;
     if (!(p.lean & 1) && p.eli_dirty_map == nullptr) {
       if (p.total_slots >= (1 << 22)) side = side_stream(s);
