@@ -37,6 +37,32 @@ namespace kvc {
 // keeps the launch chain.  The kernel is bound by instruction issue, not by memory, LDS or the instruction cache
 // (profiles/r5_topk_fused_phases.txt has the stamps of every version and the counters): what counts is instructions
 // per head.
+// Ranks against the entries of a lane's own ROW of 16, without a scalar broadcast: step J adds [src of the row's lane J <
+// me] -- v_sub_co_u32 with a DPP row_newbcast operand leaves the borrow (= the comparison) in VCC, v_addc adds it: two
+// VALU instructions per step and no scalar one (v_readlane + compare + add and the lane arithmetic around them are
+// five).  Steps in groups of four while J < cnt (wave-uniform); all 64 lanes active.  (s_nop: a DPP operand written by
+// the instruction before, and VCC written by a VALU instruction and read by the next, want two wait states on gfx950.)
+#define KVC_DPP_STEP(J) "v_sub_co_u32_dpp %1, vcc, %2, %3 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t" \
+                        "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+#define KVC_DPP_STEP4(A, B, C, D)                                                                             \
+  asm volatile("s_nop 1\n\t" KVC_DPP_STEP(A) KVC_DPP_STEP(B) KVC_DPP_STEP(C) KVC_DPP_STEP(D)                \
+               : "+v"(r), "=&v"(tmp) : "v"(src), "v"(me) : "vcc")
+__device__ __forceinline__ uint32_t rank_in_rows(uint32_t src, uint32_t me, int cnt, uint32_t r) {
+  uint32_t tmp;
+  if (cnt > 0) KVC_DPP_STEP4(0, 1, 2, 3);
+  if (cnt > 4) KVC_DPP_STEP4(4, 5, 6, 7);
+  if (cnt > 8) KVC_DPP_STEP4(8, 9, 10, 11);
+  if (cnt > 12) KVC_DPP_STEP4(12, 13, 14, 15);
+  return r;
+}
+// ... and against the 32 lanes of a lane's HALF of the wave (two lists of at most 32 entries in one register, one per
+// half; the entries beyond a list's end hold 0xFFFFFFFF, below nobody): the own row, then the half's other row
+__device__ __forceinline__ uint32_t rank_in_halves(uint32_t v, int n) {
+  uint32_t r = rank_in_rows(v, v, n < 16 ? n : 16, 0u);
+  if (n > 16) r = rank_in_rows((uint32_t)__shfl_xor((int)v, 16, 64), v, 16, r);
+  return r;
+}
+
 __device__ __forceinline__ bool less64(uint32_t ahi, uint32_t alo, uint32_t bhi, uint32_t blo) {
   return ahi < bhi || (ahi == bhi && alo < blo);
 }
@@ -125,11 +151,57 @@ __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p,
     return x;
   };
   static_assert(HPW % 2 == 0, "heads are ranked two at a time");
-  uint64_t xcur[2] = {load_list(0), load_list(1)};
+  // two lists of at most 32 entries share ONE register: head q2 in lanes 0 .. 31, head q2 + 1 in lanes 32 .. 63
+  auto load_pair = [&](int q2, uint64_t& x0, uint64_t& x1) {
+    const uint32_t Ca = (uint32_t)__builtin_amdgcn_readlane((int)myC, q2), Cb = (uint32_t)__builtin_amdgcn_readlane((int)myC, q2 + 1);
+    if (Ca <= 32u && Cb <= 32u) {                     // wave-uniform
+      const int hqv = lane >> 5;
+      x0 = ~0ull; x1 = ~0ull;
+      if ((uint32_t)(lane & 31) < (hqv ? Cb : Ca)) x0 = ws.rec64[(gbase + lh0 + q2 + hqv) * KREC + (lane & 31)];
+    } else {
+      x0 = load_list(q2); x1 = load_list(q2 + 1);
+    }
+  };
+  uint64_t xcur[2];
+  load_pair(0, xcur[0], xcur[1]);
 #pragma unroll
   for (int q2 = 0; q2 < HPW; q2 += 2) {
     uint64_t xnext[2] = {~0ull, ~0ull};
-    if (q2 + 2 < HPW) { xnext[0] = load_list(q2 + 2); xnext[1] = load_list(q2 + 3); }
+    if (q2 + 2 < HPW) load_pair(q2 + 2, xnext[0], xnext[1]);
+    bool pair_done = false;
+    {
+      const uint32_t Ca = (uint32_t)__builtin_amdgcn_readlane((int)myC, q2), Cb = (uint32_t)__builtin_amdgcn_readlane((int)myC, q2 + 1);
+      if (Ca <= 32u && Cb <= 32u) {                   // the packed pair: ranks through DPP row broadcasts
+        const uint32_t hqv = (uint32_t)lane >> 5, e = (uint32_t)lane & 31u;
+        const uint32_t C = hqv ? Cb : Ca;
+        const uint32_t key = (uint32_t)(xcur[0] >> 32);
+        const bool in = e < C;
+        uint32_t r = 0;
+        if ((Ca | Cb) != 0u) r = rank_in_halves(key, (int)max(Ca, Cb));
+        if (wave_reduce_sum_full(in ? r : 0u) == Ca * (Ca - 1u) / 2u + Cb * (Cb - 1u) / 2u) {    // wave-uniform: no two keys tie
+          pair_done = true;
+          const uint32_t hang = hqv ? (uint32_t)__builtin_amdgcn_readlane((int)myHang, q2 + 1) : (uint32_t)__builtin_amdgcn_readlane((int)myHang, q2);
+          const uint32_t lh = (uint32_t)(lh0 + q2) + hqv;
+          if (in && kreq > 0) ws.rec64[(gbase + lh) * KREC + r] = xcur[0];
+          const bool thr = in && kreq > 0 && hang >= 1u && r + 1u >= hang && ((r + 1u - hang) & (uint32_t)(bs - 1)) == 0u &&
+                           ((r + 1u - hang) >> sh) < (uint32_t)MCH;
+          const unsigned long long tm = __ballot(thr);
+          if (tm) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&nthr_s, (uint32_t)__popcll(tm));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (thr) arr[base + __popcll(tm & ((1ull << lane) - 1ull))] = ((uint64_t)key << 32) | (lh * (uint32_t)MCH + ((r + 1u - hang) >> sh));
+          }
+        } else {
+          // (two entries share a key: the pair goes through the general form below, a list per register)
+          const uint32_t lo = (uint32_t)xcur[0], hi = (uint32_t)(xcur[0] >> 32);
+          const uint32_t lo2 = (uint32_t)__shfl((int)lo, lane + 32, 64), hi2 = (uint32_t)__shfl((int)hi, lane + 32, 64);
+          xcur[1] = lane < 32 ? (((uint64_t)hi2 << 32) | lo2) : ~0ull;
+          if (lane >= 32) xcur[0] = ~0ull;
+        }
+      }
+    }
+    if (!pair_done) {
     const uint32_t plo[2] = {(uint32_t)xcur[0], (uint32_t)xcur[1]};
     const uint32_t phi[2] = {(uint32_t)(xcur[0] >> 32), (uint32_t)(xcur[1] >> 32)};
     // ranks by key of TWO heads in one loop: two independent chains of readlane -> compare -> add for the in-order
@@ -223,6 +295,7 @@ __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p,
       }
       wave_lds_sync();
       if (lane == 0) atomicExch(&big_lock[bq], 0u);
+    }
     }
     }
     xcur[0] = xnext[0]; xcur[1] = xnext[1];
