@@ -361,7 +361,6 @@ __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p,
   if (tid == 0) ws.seq_prefix[i] = (k > 0 && k <= nthr) ? (uint32_t)(vstar_s >> 32) : 0u;
   // ---- counts and emission: the wave that holds a head's entries emits them
   const bool flagged = flag_s != 0u;                 // (somebody's lists fell short: the general pipeline behind rewrites everything)
-  uint32_t ce[HPW], u[HPW];
   uint32_t ceV = 0;                                  // lane q < HPW: head lh0 + q's number of evicted entries
   {                                                  // counts out: a lane per head, two coalesced stores per wave
     const bool mine = lane < HPW && lh0 + lane < LH;
@@ -373,22 +372,29 @@ __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p,
       p.evicted_kv_count[gbase + lh0 + lane] = (int32_t)ceV;
     }
   }
-  // the evicted entries are the first ce of the head's record, which the ranks phase left in rank order (written by
-  // this wave before the barriers above; read past the L1 all the same).  Two loops: every head's slots requested,
-  // then every head's logical block numbers -- two round trips to the L2 for the wave, not two per head
+  // The evicted entries are the first ce of the head's record, which the ranks phase left in rank order (written by
+  // this wave before the barriers above; read past the L1 all the same).  Two heads that evict at most 32 entries each
+  // (nearly all) share ONE register, as the lists did: head q2 in lanes 0 .. 31 of u2[q2 / 2], head q2 + 1 in lanes
+  // 32 .. 63; 0xFFFFFFFF = no entry.  Two loops: every pair's slots requested, then every pair's logical block numbers
+  // -- two round trips to the L2 for the wave, not two per head.  The other pairs (more than 32 evicted entries of a
+  // head, a list that went through LDS) are emitted head by head below.
+  constexpr int NP = HPW / 2;
+  uint32_t u2[NP];
+  uint32_t packmask = 0;                             // bit pr: pair pr is packed
+  const uint32_t hqv = (uint32_t)lane >> 5, el = (uint32_t)lane & 31u;
 #pragma unroll
-  for (int q = 0; q < HPW; ++q) {
-    ce[q] = (uint32_t)__builtin_amdgcn_readlane((int)ceV, q);
-    u[q] = 0xFFFFFFFFu;
-    if (lh0 + q < LH && !flagged && !(bigmask & (1u << q)) && (uint32_t)lane < ce[q])
-      u[q] = __atomic_load_n(reinterpret_cast<const uint32_t*>(ws.rec64 + (gbase + lh0 + q) * KREC + lane), __ATOMIC_RELAXED);
+  for (int pr = 0; pr < NP; ++pr) {
+    u2[pr] = 0xFFFFFFFFu;
+    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)ceV, 2 * pr), c1 = (uint32_t)__builtin_amdgcn_readlane((int)ceV, 2 * pr + 1);
+    if (flagged || (bigmask & (3u << (2 * pr))) || c0 > 32u || c1 > 32u) continue;        // wave-uniform
+    packmask |= 1u << pr;
+    if (lh0 + 2 * pr + (int)hqv < LH && el < (hqv ? c1 : c0))
+      u2[pr] = __atomic_load_n(reinterpret_cast<const uint32_t*>(ws.rec64 + (gbase + lh0 + 2 * pr + hqv) * KREC + el), __ATOMIC_RELAXED);
   }
 #pragma unroll
-  for (int q = 0; q < HPW; ++q) {
-    if (lh0 + q < LH && !flagged && !(bigmask & (1u << q)) && (uint32_t)lane < ce[q]) {
-      const uint32_t slot = u[q];
-      u[q] = ((uint32_t)p.logical_block_num_by_block[slot >> sh] << sh) | (slot & (uint32_t)(bs - 1));
-    }
+  for (int pr = 0; pr < NP; ++pr) {
+    const uint32_t slot = u2[pr];
+    if (slot != 0xFFFFFFFFu) u2[pr] = ((uint32_t)p.logical_block_num_by_block[slot >> sh] << sh) | (slot & (uint32_t)(bs - 1));
   }
   KVC_STAMP(5);
   if (!flagged) {
@@ -399,61 +405,55 @@ __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p,
   const bool dirty_done = !tracked || nheads <= 0 ||
                           eli_dirty_apply_owners(p.eli_dirty_map, p.evicted_logical_indices, myOff, myEnd, ceV, nheads, sh, p.null_value, lane);
 #pragma unroll
-  for (int q2 = 0; q2 < HPW; q2 += 2) {
+  for (int pr = 0; pr < NP; ++pr) {
+    const int q2 = 2 * pr;
     if (lh0 + q2 >= LH) break;                        // wave-uniform
-    // ranks by logical index among the evicted entries of TWO heads in one loop (as the ranks by key above): the evicted
-    // sit in lanes 0 .. ce - 1, the others hold 0xFFFFFFFF (a head whose list went through LDS: everywhere)
-    uint32_t r2p[2] = {0u, 0u};
-    const int nev[2] = {(bigmask >> q2 & 1u) ? 0 : (int)min(ce[q2], (uint32_t)WAVE),
-                        (bigmask >> (q2 + 1) & 1u) ? 0 : (int)min(ce[q2 + 1], (uint32_t)WAVE)};
-    {
-      const int n = max(nev[0], nev[1]);
-      const uint32_t ma = u[q2], mb = u[q2 + 1];
-      uint32_t ra = 0, rb = 0;
-      int j = 0;
-      for (; j + 4 <= n; j += 4) {
-        const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)ma, j), a1 = (uint32_t)__builtin_amdgcn_readlane((int)ma, j + 1);
-        const uint32_t a2 = (uint32_t)__builtin_amdgcn_readlane((int)ma, j + 2), a3 = (uint32_t)__builtin_amdgcn_readlane((int)ma, j + 3);
-        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)mb, j), b1 = (uint32_t)__builtin_amdgcn_readlane((int)mb, j + 1);
-        const uint32_t b2 = (uint32_t)__builtin_amdgcn_readlane((int)mb, j + 2), b3 = (uint32_t)__builtin_amdgcn_readlane((int)mb, j + 3);
-        ra += (a0 < ma ? 1u : 0u) + (a1 < ma ? 1u : 0u) + (a2 < ma ? 1u : 0u) + (a3 < ma ? 1u : 0u);
-        rb += (b0 < mb ? 1u : 0u) + (b1 < mb ? 1u : 0u) + (b2 < mb ? 1u : 0u) + (b3 < mb ? 1u : 0u);
+    if (packmask >> pr & 1u) {
+      // both heads' evicted entries in one register: ranks by logical index through DPP row broadcasts, one store
+      const uint32_t me = u2[pr];
+      const unsigned long long vm = __ballot(me != 0xFFFFFFFFu);
+      const int n = max(__popc((uint32_t)vm), __popc((uint32_t)(vm >> 32)));
+      if (n > 0) {
+        const uint32_t r2 = rank_in_halves(me, n);
+        const int32_t off2 = hqv ? __builtin_amdgcn_readlane(myOff, q2 + 1) : __builtin_amdgcn_readlane(myOff, q2);
+        if (me != 0xFFFFFFFFu) p.evicted_logical_indices[off2 + (int32_t)r2] = (int32_t)me;
       }
-      for (; j < n; ++j) {
-        ra += (uint32_t)__builtin_amdgcn_readlane((int)ma, j) < ma ? 1u : 0u;
-        rb += (uint32_t)__builtin_amdgcn_readlane((int)mb, j) < mb ? 1u : 0u;
-      }
-      r2p[0] = ra; r2p[1] = rb;
     }
 #pragma unroll
     for (int hq = 0; hq < 2; ++hq) {
-    const int q = q2 + hq;
-    const int lh = lh0 + q;
-    if (lh >= LH) break;                              // wave-uniform
-    const int64_t g = gbase + lh;
-    const int32_t off = __builtin_amdgcn_readlane(myOff, q), end = __builtin_amdgcn_readlane(myEnd, q);
-    if (!dirty_done)
-      eli_dirty_update(p.eli_dirty_map, p.evicted_logical_indices, off >> sh, end >> sh, (int64_t)((ce[q] + (uint32_t)bs - 1u) >> sh),
-                       (int64_t)off + ce[q], bs, p.null_value, true, lane, WAVE);
-    if (ce[q] == 0) continue;
-    int32_t* out = p.evicted_logical_indices + off;
-    if (!(bigmask & (1u << q))) {
-      if (lane < nev[hq]) out[r2p[hq]] = (int32_t)u[q];
-    } else {
-      // (this wave wrote the sorted record to global memory above: read past the L1)
-      const int bq = w & 3;
-      if (lane == 0) while (atomicCAS(&big_lock[bq], 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(2);
-      wave_lds_sync();
-      uint32_t* a = reinterpret_cast<uint32_t*>(sort_s[bq]);
+      const int q = q2 + hq;
+      const int lh = lh0 + q;
+      if (lh >= LH) break;                            // wave-uniform
+      const int64_t g = gbase + lh;
+      const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)ceV, q);
+      const int32_t off = __builtin_amdgcn_readlane(myOff, q), end = __builtin_amdgcn_readlane(myEnd, q);
+      if (!dirty_done)
+        eli_dirty_update(p.eli_dirty_map, p.evicted_logical_indices, off >> sh, end >> sh, (int64_t)((ce + (uint32_t)bs - 1u) >> sh),
+                         (int64_t)off + ce, bs, p.null_value, true, lane, WAVE);
+      if (ce == 0 || (packmask >> pr & 1u)) continue;
+      int32_t* out = p.evicted_logical_indices + off;
       const uint64_t* rec = ws.rec64 + g * KREC;
-      for (int j = lane; j < KREC; j += WAVE)
-        a[j] = (uint32_t)j < ce[q] ? logical_of(p, (uint32_t)__atomic_load_n(rec + j, __ATOMIC_RELAXED)) : 0xFFFFFFFFu;
-      wave_lds_sync();
-      wave_bitonic_sort<uint32_t, KREC>(a);
-      for (int j = lane; j < (int)ce[q]; j += WAVE) out[j] = (int32_t)a[j];
-      wave_lds_sync();
-      if (lane == 0) atomicExch(&big_lock[bq], 0u);
-    }
+      if (!(bigmask & (1u << q))) {
+        // (rare) a head that evicts 33 .. 64 entries: its slots, their logical block numbers, ranks by readlane
+        uint32_t me = 0xFFFFFFFFu;
+        if ((uint32_t)lane < ce) me = logical_of(p, __atomic_load_n(reinterpret_cast<const uint32_t*>(rec + lane), __ATOMIC_RELAXED));
+        uint32_t r2 = 0;
+        for (int j = 0; j < (int)min(ce, (uint32_t)WAVE); ++j) r2 += (uint32_t)__builtin_amdgcn_readlane((int)me, j) < me ? 1u : 0u;
+        if ((uint32_t)lane < ce) out[r2] = (int32_t)me;
+      } else {
+        // (this wave wrote the sorted record to global memory above: read past the L1)
+        const int bq = w & 3;
+        if (lane == 0) while (atomicCAS(&big_lock[bq], 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(2);
+        wave_lds_sync();
+        uint32_t* a = reinterpret_cast<uint32_t*>(sort_s[bq]);
+        for (int j = lane; j < KREC; j += WAVE)
+          a[j] = (uint32_t)j < ce ? logical_of(p, (uint32_t)__atomic_load_n(rec + j, __ATOMIC_RELAXED)) : 0xFFFFFFFFu;
+        wave_lds_sync();
+        wave_bitonic_sort<uint32_t, KREC>(a);
+        for (int j = lane; j < (int)ce; j += WAVE) out[j] = (int32_t)a[j];
+        wave_lds_sync();
+        if (lane == 0) atomicExch(&big_lock[bq], 0u);
+      }
     }
   }
   }
