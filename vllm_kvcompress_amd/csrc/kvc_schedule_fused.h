@@ -74,7 +74,7 @@ __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p,
   uint64_t* arr = reinterpret_cast<uint64_t*>(sel_lds);                 // [P2] recorded thresholds, dense
   uint32_t* cnt = reinterpret_cast<uint32_t*>(arr + P2);                // [16 * HPW] freed chunks per head
   __shared__ __attribute__((aligned(16))) uint64_t sort_s[4][KREC];     // lists beyond a wave (shared by four waves each)
-  __shared__ uint32_t fsum_s, k_s, nthr_s, big_lock[4], flag_s;
+  __shared__ uint32_t fsum_s, k_s, nthr_s, big_lock[4], flag_s, piv_total_s, piv_hs_s, piv_n_s;
   __shared__ unsigned long long vstar_s;
   __shared__ __attribute__((aligned(16))) uint32_t sel_hist[RADIX];
   __shared__ uint32_t sel_wtot[4];
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p,
       if (__ballot(bad) && lane == 0) atomicOr(ws.fallback, 1u);
     }
   }
-  if (tid == 0) { fsum_s = 0; nthr_s = 0; vstar_s = ~0ull; }
+  if (tid == 0) { fsum_s = 0; nthr_s = 0; vstar_s = ~0ull; piv_total_s = 0; piv_hs_s = 0; piv_n_s = 0; }
   if (tid < 4) big_lock[tid] = 0;
   for (int lh = tid; lh < 16 * HPW; lh += 1024) cnt[lh] = 0;
   __syncthreads();
@@ -466,10 +466,76 @@ __global__ __launch_bounds__(1024) void topk_fused_kernel(kvc_schedule_params p,
       __shared__ uint32_t piv_pre_s[16 * HPW + 1];
       __shared__ uint16_t piv_start_s[16 * HPW];
       __shared__ uint32_t piv_wsum_s[16], piv_hang_s;
+      // what is left of the wave's lists, and its heads' hanging tokens (hang - 1 each), summed for the workgroup
+      {
+        const bool mine = lane < HPW && lh0 + lane < LH;
+        const uint32_t Cc = min(myC, (uint32_t)KREC);
+        const uint32_t rem = wave_reduce_sum_full(mine ? Cc - min(ceV, Cc) : 0u);
+        const uint32_t hs = wave_reduce_sum_full(mine && myHang >= 1u ? myHang - 1u : 0u);
+        if (lane == 0) { atomicAdd(&piv_total_s, rem); atomicAdd(&piv_hs_s, hs); }
+      }
+      const uint32_t used = from_harvest ? hv_pivot[i] : ws.st_seqrec[i].pivot_excl;
       __syncthreads();                               // (every wave is done with the thresholds' counts; the counts and records are out)
-      const PivotLds S{sel_hist, sel_wtot, piv_pre_s, piv_start_s, piv_wsum_s, &piv_hang_s, reinterpret_cast<uint32_t*>(sel_lds),
-                       (uint32_t)lds_keys};
-      harvest_pivot_body(p, ws, hv_pivot, from_harvest, widen, i, S);
+      const uint32_t R = piv_total_s;
+      if (kreq <= 0) {                               // nothing asked of this sequence: lists made for nothing say nothing new
+        if (tid == 0 && !from_harvest) hv_pivot[i] = 0u;
+      } else if (R <= (uint32_t)lds_keys) {
+        // every wave stages what is left of ITS heads' records (rank order: the entries from the evicted count on) in the
+        // LDS the thresholds have left -- the lists of a pair of short heads through one load, as they were ranked
+        uint32_t* keys_s = reinterpret_cast<uint32_t*>(sel_lds);
+        auto put = [&](bool valid, uint32_t key) {
+          const unsigned long long m = __ballot(valid);
+          if (m) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&piv_n_s, (uint32_t)__popcll(m));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (valid) keys_s[base + __popcll(m & ((1ull << lane) - 1ull))] = key;
+          }
+        };
+        const uint32_t hq5 = (uint32_t)lane >> 5, e5 = (uint32_t)lane & 31u;
+        uint32_t kq[HPW / 2];
+        uint32_t shortmask = 0;
+#pragma unroll
+        for (int pr = 0; pr < HPW / 2; ++pr) {         // the pairs of short lists: all their loads in flight together
+          kq[pr] = 0xFFFFFFFFu;
+          const uint32_t Ca = (uint32_t)__builtin_amdgcn_readlane((int)myC, 2 * pr), Cb = (uint32_t)__builtin_amdgcn_readlane((int)myC, 2 * pr + 1);
+          if (Ca > 32u || Cb > 32u) continue;          // wave-uniform
+          shortmask |= 1u << pr;
+          const uint32_t c0 = min((uint32_t)__builtin_amdgcn_readlane((int)ceV, 2 * pr), Ca), c1 = min((uint32_t)__builtin_amdgcn_readlane((int)ceV, 2 * pr + 1), Cb);
+          if (e5 >= (hq5 ? c1 : c0) && e5 < (hq5 ? Cb : Ca))
+            kq[pr] = (uint32_t)(__atomic_load_n(ws.rec64 + (gbase + lh0 + 2 * pr + hq5) * KREC + e5, __ATOMIC_RELAXED) >> 32);
+        }
+#pragma unroll
+        for (int pr = 0; pr < HPW / 2; ++pr) {
+          if (shortmask >> pr & 1u) {
+            // (a remaining key is never 0xFFFFFFFF: candidates lie below a pivot <= KEY_INF)
+            put(kq[pr] != 0xFFFFFFFFu, kq[pr]);
+          } else {
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) {
+              const int q = 2 * pr + hq;
+              const uint32_t C = min((uint32_t)__builtin_amdgcn_readlane((int)myC, q), (uint32_t)KREC);
+              const uint32_t c = min((uint32_t)__builtin_amdgcn_readlane((int)ceV, q), C);
+              for (uint32_t j0 = 0; j0 < C; j0 += WAVE) {      // wave-uniform
+                const uint32_t j = j0 + (uint32_t)lane;
+                const bool valid = j >= c && j < C;
+                uint32_t key = 0;
+                if (valid) key = (uint32_t)(__atomic_load_n(ws.rec64 + (gbase + lh0 + q) * KREC + j, __ATOMIC_RELAXED) >> 32);
+                put(valid, key);
+              }
+            }
+          }
+        }
+        __syncthreads();
+        auto val = [&](int x) -> uint32_t { return keys_s[x]; };
+        const uint32_t next = next_pivot_from_keys(sel_hist, sel_wtot, R, val, kreq, bs, piv_hs_s, used, widen);
+        if (tid == 0) hv_pivot[i] = next;
+      } else {
+        // (more keys than the LDS holds: harvest_pivot_kernel's body, which reads them from the L2 every round)
+        const PivotLds S{sel_hist, sel_wtot, piv_pre_s, piv_start_s, piv_wsum_s, &piv_hang_s, reinterpret_cast<uint32_t*>(sel_lds),
+                         (uint32_t)lds_keys};
+        harvest_pivot_body(p, ws, hv_pivot, from_harvest, widen, i, S);
+      }
     }
   }
   KVC_STAMP(7);
