@@ -1,6 +1,7 @@
-"""Device helpers that every schedule kernel leans on, checked on their own: the wave-level sums and scans of
-csrc/kvc_common.h -- the shuffle forms and the DPP forms for full waves -- against a host loop
-(tests/device/wave_helpers_check.hip, compiled here with hipcc)."""
+"""Device helpers that the schedule kernels lean on, checked on their own against host loops
+(tests/device/wave_helpers_check.hip, compiled here with hipcc): the wave-level sums and scans of csrc/kvc_common.h --
+the shuffle forms and the DPP forms for full waves -- and rank_in_halves of csrc/kvc_schedule_fused.h (two lists per
+wave ranked through DPP row broadcasts) for every pair of list lengths."""
 import os
 import shutil
 import subprocess
