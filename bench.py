@@ -21,7 +21,10 @@ is not already running under torch.distributed.run; sequences are sharded, every
 a private cache (weak scaling: the same per-rank workload; ``--scaling strong`` splits a
 fixed batch); the only collective is the reduction of the throughput scalars.
 
-Prints ONE JSON line (rank 0).
+Prints ONE compact JSON line (rank 0, < 4 KB, the last line of stdout): the contract's keys, `roofline`,
+`cpu_baseline`, the parity verdict.  The legs that do not fit it (other configurations, engine-sized cache, call
+forms, S0 stages, adjacent attention) go to ``--detail-json`` (default bench_detail.json), named in the line.
+The timed step calls the path exactly as the fork's scheduler does (``--call-form fork``).
 """
 from __future__ import annotations
 
@@ -86,6 +89,25 @@ def parse_args(argv=None):
     ap.add_argument("--pass-block-tables", action="store_true",
                     help="hand BlockState.block_tables to schedule_evictions (optional argument: bulk evictions of a batch "
                          "that is sparse in its cache build their keys through it; the streaming schedule ignores it)")
+    ap.add_argument("--call-form", default="fork", choices=["fork", "hinted"],
+                    help="how the timed step calls the path.  fork (default, the headline): exactly the fork's scheduler "
+                         "(reference vllm/kvcompress/scheduler.py:74-86, 245-260, 491-529) -- evicted_blocks_per_seq and the "
+                         "last token positions as FRESH device int tensors, protected windows as a tuple, no total_slots=, "
+                         "no block_tables=, a plain persistent move workspace, a fresh cache_moves_count.  hinted: host list "
+                         "of counts + total_slots= (the method never waits for the device) and a workspace registered with "
+                         "track_move_table (`stages_ms_hinted` of the default line)")
+    ap.add_argument("--block-layout", default="reference", choices=["reference", "slot_major"],
+                    help="how the bytes inside a cache block are laid out (include/kvc_mi355x.h KVC_LAYOUT_*).  reference "
+                         "(default, the headline): the fork's K [hd/x][bs][x] / V [hd][bs].  slot_major: K [bs][hd] / V [bs][hd], "
+                         "the package's opt-in MI355X-native layout (KVC_BLOCK_LAYOUT=slot_major) -- the default run measures "
+                         "it in a child process and reports it as `roofline_native_layout`")
+    ap.add_argument("--no-native-layout", action="store_true", help="skip the slot-major leg of the default run")
+    ap.add_argument("--headline-only", action="store_true", default=None,
+                    help="only the timed loop, the parity gate and (N = 1) roofline + cpu_baseline: none of the other legs "
+                         "(other configs, engine-sized cache, S0 stages, call forms, adjacent attention, native layout).  "
+                         "The default for --gpus N > 1")
+    ap.add_argument("--detail-json", default=os.path.join(REPO, "bench_detail.json"),
+                    help="where everything that does not fit the compact line goes (named in the line as `detail`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true",
                     help="skip the oracle comparison of the timed workload's results (profiling passes that "
@@ -654,10 +676,11 @@ def workload_flags(args):
         f.append("--contiguous-blocks")
     if args.lean:
         f.append("--lean")
+    f += ["--block-layout", args.block_layout, "--call-form", args.call_form]
     return f
 
 
-def live_pmc_traffic(extra_flags, timeout=240):
+def live_pmc_traffic(extra_flags, timeout=240, kernel="compact_runs_kernel"):
     """HBM bytes per launch of the compaction kernel from the TCC counters, measured NOW: two short
     runs of this same script under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate
     passes, no trace domain, as MI355X_MICROARCH.md prescribes; FETCH doubled for a wide streaming
@@ -688,7 +711,7 @@ def live_pmc_traffic(extra_flags, timeout=240):
             if r.returncode != 0 or not files:
                 return None
             v = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
-                 if row["Counter_Name"] == counter and "compact_runs_kernel" in row["Kernel_Name"]]
+                 if row["Counter_Name"] == counter and kernel in row["Kernel_Name"]]
             if not v:
                 return None
             vals[counter] = sum(v) / len(v)
@@ -713,11 +736,13 @@ def measure_workload(a2, seed, device, steps, warmup, probe):
         return None
     N = st.total_slots
     wm, wp = ds.cm.metrics.clone(), ds.cm.token_positions.clone()
-    # the move workspace, held the way CompressionScheduler holds its own (reference scheduler.py:74-86: one
-    # persistent table; registered, so that the wrapper's per-call fill_(0) clears only what the previous call wrote)
-    cmi = ops.track_move_table(torch.empty((N, 2), dtype=torch.int32, device=device))
-    cmc = torch.empty((st.num_seqs, st.num_layers, st.num_kv_heads), dtype=torch.int32, device=device)
+    # the fork's own call form, like the headline (main()): a plain persistent move workspace (reference
+    # scheduler.py:74-86), fresh device tensors of counts and positions and a fresh cache_moves_count per step
+    # (:245-260, 508-512), no total_slots=
+    cmi = torch.empty((N, 2), dtype=torch.int32, device=device)
     seq_idx, prot = list(st.seq_indices), list(st.protected)
+    prot_t, seq_lens = tuple(prot), [int(x) + 1 for x in st.seq_positions]
+    BLH = (st.num_seqs, st.num_layers, st.num_kv_heads)
     snap = parity_snapshot(k_cache, v_cache) if N <= PARITY_ORACLE_MAX_SLOTS else None
     ev = lambda: torch.cuda.Event(enable_timing=True)
     marks = [[ev() for _ in range(5)] for _ in range(steps)]
@@ -730,10 +755,13 @@ def measure_workload(a2, seed, device, steps, warmup, probe):
         rec = i >= 0
         out.clear()
         del eli, ekc, ebc              # (the previous step's results go out of scope, as in the engine's loop)
+        k_t = torch.tensor(evicted, dtype=torch.int, device=device)
+        pos_t = torch.tensor(seq_lens, dtype=torch.int, device=device) - 1
         if rec: marks[i][0].record()
-        eli, ekc, ebc = ds.cm.schedule_evictions(seq_idx, ds.seq_positions, evicted, ds.context_lens,
-                                                 ds.hanging_token_count, ds.evicted_kv_offsets, prot, total_slots=N)
+        eli, ekc, ebc = ds.cm.schedule_evictions(seq_idx, pos_t, k_t, ds.context_lens,
+                                                 ds.hanging_token_count, ds.evicted_kv_offsets, prot_t)
         if rec: marks[i][1].record()
+        cmc = torch.empty(BLH, dtype=torch.int32, device=device)
         ops.schedule_cache_moves(cmi, cmc, eli, ekc, ds.evicted_kv_offsets, ds.block_tables, ds.context_lens, bs)
         if rec: marks[i][2].record()
         ops._execute_cache_moves(k_cache, v_cache, wm, wp, cmi, cmc, ds.evicted_kv_offsets, "plan")
@@ -773,6 +801,8 @@ def measure_workload(a2, seed, device, steps, warmup, probe):
                      "frac_of_floor": floor["bytes"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "pattern_ceiling_GBps": pattern_ceiling(k_cache, v_cache, block_bytes) if probe else None},
         "timing": f"{steps} steps after {warmup} warm-up steps, HIP events on the launch stream",
+        "call_form": "fork (fresh device tensors of counts / positions, no total_slots=, plain move workspace); "
+                     "S1_call_forms has the hinted form next to it",
         "parity_checked": parity,
     }
     res["roofline"].update(frac_ceiling(alg, floor, res["roofline"]["pattern_ceiling_GBps"], res["roofline"]["frac"]))
@@ -1338,6 +1368,118 @@ def cpu_baseline(args):
     }
 
 
+def native_layout_run(args, timeout=900):
+    """The same workload with slot-major cache blocks (KVC_BLOCK_LAYOUT=slot_major: K [bs][hd], V [bs][hd] inside every
+    block; tensor shapes, op signatures, slot numbers unchanged), measured by this same script in a child process
+    (`--block-layout slot_major --headline-only`): the compaction kernel's roofline object, the step's stage times and the
+    parity verdict (the compacted cache, permuted back, against the oracle).  None if the child fails."""
+    import copy
+    a2 = copy.copy(args)
+    a2.block_layout = "slot_major"
+    cmd = ([sys.executable, os.path.abspath(__file__), "--steps", str(min(args.steps, 20)), "--warmup", "3",
+            "--headline-only", "--no-cpu-baseline", "--no-probe", "--detail-json", "", "--spare-blocks", str(args.spare_blocks)]
+           + workload_flags(a2) + (["--no-live-traffic"] if args.no_live_traffic else []))
+    try:
+        r = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=timeout)
+    except (subprocess.TimeoutExpired, OSError) as e:
+        return {"failed": str(e)[:200]}
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"failed": (r.stderr or r.stdout)[-400:]}
+    d = json.loads(lines[-1])
+    out = dict(d["roofline"])
+    out.update({"value": d["value"], "ms_per_step": d["ms_per_step"], "stages_ms": d["stages_ms"],
+                "parity_checked": d["parity_checked"], "steps": d["steps"],
+                "what": "python bench.py --block-layout slot_major: the package's opt-in in-block layout "
+                        "(KVC_BLOCK_LAYOUT=slot_major), same workload, same call form, same oracle"})
+    return out
+
+
+# --------------------------------------------------------------------------- output
+LINE_MAX_BYTES = 4096           # the driver parses the LAST stdout line; round 5's 22 KB line was not parsed
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
+def _round(x, sig=6):
+    """floats at 6 significant digits, recursively (the line is for parsers and readers, the detail file keeps all)"""
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}")
+    if isinstance(x, dict):
+        return {k: _round(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_round(v, sig) for v in x]
+    return x
+
+
+def compact_line(res, detail_path):
+    """The ONE line the driver parses: the contract's keys, `roofline`, `cpu_baseline`, the parity verdict and the
+    stage times -- everything else (other configs, the engine-sized cache, call forms, S0 stages, the adjacent
+    attention, prose) lives in the detail file this line names."""
+    line = _pick(res, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                       "scaling", "vs_baseline", "dtype", "data"))
+    line["config"] = _pick(res["config"], ("workload", "candidate_slots", "evicted_slots", "moved_slots", "freed_blocks"))
+    line["call_form"] = res.get("call_form", "").split(":")[0]
+    line["stages_ms"] = res["stages_ms"]
+    if "stages_ms_hinted" in res:
+        line["stages_ms_hinted"] = res["stages_ms_hinted"]
+    line["S1_schedule"] = res.get("S1_schedule")
+    r = res["roofline"]
+    line["roofline"] = _pick(r, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+                                 "algorithmic_bytes_per_launch", "avg_launch_ms", "layout_amplification",
+                                 "alg_frac_ceiling", "frac_of_ceiling", "traffic_frac_of_peak"))
+    if line["roofline"].get("traffic_source"):
+        line["roofline"]["traffic_source"] = line["roofline"]["traffic_source"].split(":")[0].split(" (")[0][:120]
+    if res.get("roofline_native_layout"):
+        line["roofline_native_layout"] = res["roofline_native_layout"]
+    c = res.get("cpu_baseline")
+    if c:
+        line["cpu_baseline"] = _pick(c, ("value", "unit", "cores", "kind", "cpu_model", "host_cpus", "threads_by_stage",
+                                         "stage_seconds"))
+        line["cpu_baseline"]["sample"] = c["sample"].split(";")[0][:200]
+    pc = res.get("parity_checked")
+    line["parity_checked"] = None if pc is None else _pick(pc, ("bit_exact", "mismatched", "skipped", "kv_bytes"))
+    if isinstance(line["parity_checked"], dict) and "skipped" in line["parity_checked"]:
+        line["parity_checked"]["skipped"] = line["parity_checked"]["skipped"][:100]
+    oc = res.get("other_configs")
+    if oc:      # one number per configuration; the legs themselves are in the detail file
+        line["other_configs"] = {
+            v["config"]: (_pick(v, ("value", "ms_per_step", "skipped"))
+                          | {"frac": (v.get("roofline") or {}).get("frac"),
+                             "bit_exact": (v.get("parity_checked") or {}).get("bit_exact")})
+            for v in oc}
+    if "per_rank" in res:
+        line["per_rank"] = res["per_rank"]
+    line["detail"] = os.path.relpath(detail_path, REPO) if detail_path else None
+    line = _round(line)
+    txt = json.dumps(line, separators=(",", ":"))
+    for drop in ("other_configs", "stages_ms_hinted", "per_rank"):      # (never the contract's keys)
+        if len(txt) < LINE_MAX_BYTES:
+            break
+        if drop == "per_rank" and "per_rank" in line and len(line["per_rank"]) <= 8:
+            continue
+        line.pop(drop, None)
+        txt = json.dumps(line, separators=(",", ":"))
+    assert len(txt) < LINE_MAX_BYTES, f"bench line is {len(txt)} bytes"
+    return txt
+
+
+def emit(res, detail_path):
+    """detail file first (everything), then the compact line as the last thing on stdout"""
+    if detail_path:
+        try:
+            with open(detail_path, "w") as f:
+                json.dump(res, f, indent=1)
+                f.write("\n")
+        except OSError as e:
+            print(f"bench.py: could not write {detail_path}: {e}", file=sys.stderr)
+            detail_path = None
+    sys.stdout.flush()
+    print(compact_line(res, detail_path), flush=True)
+
+
 # --------------------------------------------------------------------------- main
 def main():
     args = parse_args()
@@ -1369,6 +1511,9 @@ def main():
         else:
             dist.init_process_group(backend=backend)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # N > 1: the driver's scaling run is the timed loop + the all_gather, nothing else
+    headline_only = bool(args.headline_only) if args.headline_only is not None else (world > 1 or args.block_layout != "reference")
+    extras = world == 1 and not headline_only
 
     # sequences of this rank: weak = --batch each; strong = --batch split by harness.dist
     from vllm_kvcompress_amd.harness import dist as hdist
@@ -1383,14 +1528,27 @@ def main():
     N = st.total_slots
     work_metrics = ds.cm.metrics.clone()
     work_pos = ds.cm.token_positions.clone()
-    # the move workspace, held the way CompressionScheduler holds its own (reference scheduler.py:74-86: one
-    # persistent table; registered, so that the wrapper's per-call fill_(0) clears only what the previous call wrote)
-    cmi = ops.track_move_table(torch.empty((N, 2), dtype=torch.int32, device=device))
-    cmc = torch.empty((st.num_seqs, st.num_layers, st.num_kv_heads), dtype=torch.int32, device=device)
+    # the cache as it is before the first step (the reference's layout), for the parity gate behind the timed region
+    snap = parity_snapshot(k_cache, v_cache) if (rank == 0 and N <= PARITY_ORACLE_MAX_SLOTS and not args.no_parity_gate) else None
+    slot_major = args.block_layout == "slot_major"
+    if slot_major:
+        # the package's opt-in layout: the same cache contents, every block re-laid-out K [bs][hd] / V [bs][hd]; the
+        # three ops that interpret a block follow the package's switch
+        from vllm_kvcompress_amd import layout as kvc_layout
+        vllm_kvcompress_amd.set_block_layout("slot_major")
+        kvc_layout.convert_block_layout(k_cache, v_cache, "reference", "slot_major")
+    # the move workspace, held the way CompressionScheduler holds its own (reference scheduler.py:74-86: ONE persistent
+    # [max_kv_per_compression, 2] int table, torch.empty).  --call-form hinted registers it (track_move_table: the wrapper's
+    # per-call fill_(0) then clears only what the previous call wrote); the fork's form leaves it a plain tensor
+    fork = args.call_form == "fork"
+    cmi = torch.empty((N, 2), dtype=torch.int32, device=device)
+    if not fork:
+        cmi = ops.track_move_table(cmi)
     seq_idx = list(st.seq_indices)
     prot = list(st.protected)
-    # the cache as it is before the first step, for the parity gate behind the timed region
-    snap = parity_snapshot(k_cache, v_cache) if (rank == 0 and N <= PARITY_ORACLE_MAX_SLOTS and not args.no_parity_gate) else None
+    prot_t = tuple(prot)
+    seq_lens = [int(x) + 1 for x in st.seq_positions]
+    BLH = (st.num_seqs, st.num_layers, st.num_kv_heads)
 
     ev = lambda: torch.cuda.Event(enable_timing=True)
     # marks: S1 start, S2 start, S3 start (plan half), data kernel start, end.  All events are
@@ -1400,16 +1558,26 @@ def main():
 
     host_t = []
 
-    def step(i=None):
+    def step(i=None, fork=fork, cmi=cmi, marks=marks):
         out.clear()                    # (the previous step's results go out of scope, as in the engine's loop)
+        if fork:
+            # what CompressionScheduler._schedule_compression builds anew every call (scheduler.py:245-260): part of
+            # the step's wall time, outside the S1 marks (they bracket the method the fork calls)
+            k_t = torch.tensor(evicted, dtype=torch.int, device=device)
+            pos_t = torch.tensor(seq_lens, dtype=torch.int, device=device) - 1
         if i is not None: marks[i][0].record()
         host_t.append(time.perf_counter())
-        eli, ekc, ebc = ds.cm.schedule_evictions(seq_idx, ds.seq_positions, evicted,
-                                                 ds.context_lens, ds.hanging_token_count,
-                                                 ds.evicted_kv_offsets, prot, total_slots=N,
-                                                 block_tables=ds.block_tables if args.pass_block_tables else None)
+        if fork:
+            eli, ekc, ebc = ds.cm.schedule_evictions(seq_idx, pos_t, k_t, ds.context_lens, ds.hanging_token_count,
+                                                     ds.evicted_kv_offsets, prot_t)          # (scheduler.py:491-499)
+        else:
+            eli, ekc, ebc = ds.cm.schedule_evictions(seq_idx, ds.seq_positions, evicted,
+                                                     ds.context_lens, ds.hanging_token_count,
+                                                     ds.evicted_kv_offsets, prot, total_slots=N,
+                                                     block_tables=ds.block_tables if args.pass_block_tables else None)
         host_t.append(time.perf_counter())
         if i is not None: marks[i][1].record()
+        cmc = torch.empty(BLH, dtype=torch.int32, device=device)                              # (scheduler.py:508-512)
         if args.lean:
             ops._schedule_t1_cache_moves(cmi, cmc, eli, ekc, ds.evicted_kv_offsets, ds.block_tables,
                                          ds.context_lens, bs, zero_fill=False)
@@ -1425,7 +1593,7 @@ def main():
         ops._execute_cache_moves(k_cache, v_cache, work_metrics, work_pos, cmi, cmc,
                                  ds.evicted_kv_offsets, "apply")
         if i is not None: marks[i][4].record()
-        out["ekc"], out["ebc"], out["eli"] = ekc, ebc, eli
+        out["ekc"], out["ebc"], out["eli"], out["cmc"], out["cmi"] = ekc, ebc, eli, cmc, cmi
 
     for _ in range(args.warmup):
         step()
@@ -1457,6 +1625,7 @@ def main():
     kernel_ms = sum(m[3].elapsed_time(m[4]) for m in marks) / args.steps
 
     evicted_slots = int(out["ekc"].sum().item())
+    cmc, ekc_ref = out["cmc"], out["ekc"]
     moved_slots = int(cmc.sum().item())
     freed_blocks = int(out["ebc"].sum().item())
     if args.mode == "per_sequence" or batch == 1:   # the reference's batch>1 quirk frees fewer
@@ -1484,6 +1653,8 @@ def main():
     parity = None
     if rank == 0 and not args.no_parity_gate:
         # parity gates before any number is reported
+        if slot_major:       # (the oracle computes in the reference's layout: the compacted cache goes back through the permutation)
+            kvc_layout.convert_block_layout(k_cache, v_cache, "slot_major", "reference")
         parity = parity_gate(args, st, ds, evicted, args.mode, dict(eli=out["eli"], ekc=out["ekc"], ebc=out["ebc"], cmi=cmi, cmc=cmc),
                              snap, k_cache, v_cache, work_metrics, work_pos, lean=bool(args.lean))
         del snap
@@ -1492,6 +1663,10 @@ def main():
             if world > 1:
                 dist.destroy_process_group()
             sys.exit(3)
+        if slot_major:
+            parity["layout"] = ("the compacted slot-major cache, permuted back to the reference's layout "
+                                "(vllm_kvcompress_amd.layout.convert_block_layout), against the oracle's")
+            kvc_layout.convert_block_layout(k_cache, v_cache, "reference", "slot_major")
     if rank == 0:
         e = 1 if args.kv_dtype == "fp8" else 2
         block_bytes = args.head_size * bs * e
@@ -1499,6 +1674,9 @@ def main():
         alg_bytes = moved_slots * bpm + 8 * st.total_heads
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         floor = traffic_floor(cmi, cmc, ds.evicted_kv_offsets, bs, block_bytes)
+        if slot_major:       # a move is two contiguous copies: the layout forces nothing beyond the algorithmic bytes
+            floor = {"bytes": alg_bytes, "dst_blocks": floor["dst_blocks"], "dst_blocks_fully_overwritten": floor["dst_blocks"],
+                     "src_blocks": floor["src_blocks"], "note": "slot-major blocks: floor == algorithmic bytes"}
         floor_gbps = floor["bytes"] / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_source = None, None
         default_workload = (args.layers, args.kv_heads, args.head_size, bs, args.seq_len, batch,
@@ -1507,7 +1685,8 @@ def main():
                                 32, 8, 128, 16, 32768, 1, 0.5, 32, "perm", "fp16", 0, False, 0.02)
         # the committed PMC figure belongs to the default workload only; it is a separately
         # profiled run of the same kernel and workload, not a measurement of this run
-        live = (live_pmc_traffic(workload_flags(args) + ["--spare-blocks", str(args.spare_blocks)])
+        live = (live_pmc_traffic(workload_flags(args) + ["--spare-blocks", str(args.spare_blocks)],
+                                 kernel="compact_slots_kernel" if slot_major else "compact_runs_kernel")
                 if (world == 1 and not args.no_live_traffic) else None)
         if live is not None:
             traffic = live["hbm_bytes_per_launch"]
@@ -1546,6 +1725,7 @@ def main():
                                else f"compress_once keep={args.keep}, ")
                             + f"protected_window={args.protected}, "
                             f"metrics={args.metric_shape}, schedule mode={args.mode}"
+                            + (", slot-major cache blocks (KVC_BLOCK_LAYOUT=slot_major)" if slot_major else "")
                             + (", lean outputs (extension)" if args.lean else "")
                             + (", block_tables passed to schedule_evictions (read only when the batch is sparse in its cache)" if args.pass_block_tables else "")
                             + ", physical blocks "
@@ -1564,7 +1744,9 @@ def main():
                 "S3_moved_slots_per_s": moved_slots / (s3 * 1e-3),
             },
             "roofline": {
-                "kernel": f"kvc::compact_runs_kernel<{args.head_size},{bs},{e},4> (execute_cache_moves)",
+                "kernel": (f"kvc::compact_slots_kernel<{args.head_size * e // 16}> (execute_cache_moves, slot-major blocks)"
+                           if slot_major else f"kvc::compact_runs_kernel<{args.head_size},{bs},{e},4> (execute_cache_moves)"),
+                "block_layout": args.block_layout,
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_move": bpm,
@@ -1584,23 +1766,44 @@ def main():
         }
         if per_rank:
             res["per_rank"] = per_rank
-        if world == 1 and not args.lean:
+        res["call_form"] = (
+            "fork: schedule_evictions(slot_indices, FRESH device int tensor of last token positions, FRESH device int tensor "
+            "of evicted_blocks_per_seq, context_lens, hanging_token_count, evicted_kv_offsets, tuple of protected windows) -- "
+            "no total_slots=, no block_tables= -- then schedule_cache_moves on a plain persistent [N, 2] workspace with a fresh "
+            "cache_moves_count, then execute_cache_moves (reference scheduler.py:74-86, 245-260, 491-529)" if fork else
+            "hinted: host list of counts + total_slots=, move workspace registered with track_move_table")
+        if extras and fork and not args.lean:
+            # the same step through the hinted form (host list + total_slots=: the method never waits; tracked table)
+            hsteps = min(args.steps, 20)
+            hmarks = [[ev() for _ in range(5)] for _ in range(hsteps)]
+            hcmi = ops.track_move_table(torch.empty((N, 2), dtype=torch.int32, device=device))
+            for i in range(-3, hsteps):
+                step(i if i >= 0 else None, fork=False, cmi=hcmi, marks=hmarks)
+            torch.cuda.synchronize()
+            hs = [sum(m[a].elapsed_time(m[b]) for m in hmarks) / hsteps for a, b in ((0, 1), (1, 2), (2, 4))]
+            res["stages_ms_hinted"] = {"S1_schedule_evictions": hs[0], "S2_schedule_moves": hs[1], "S3_execute_moves": hs[2],
+                                       "same_counts": bool(torch.equal(out["ekc"], ekc_ref))}
+            del hcmi
+        if extras and not slot_major and not args.no_native_layout and not args.steady_cap:
+            res["roofline_native_layout"] = native_layout_run(args)
+        if extras and not args.lean:
             forms = s1_call_forms(ds, st, evicted, cmi, cmc, k_cache, v_cache, work_metrics, work_pos, bs,
-                                  steps=min(args.steps, 10), ref_counts=out["ekc"])
+                                  steps=min(args.steps, 10), ref_counts=ekc_ref)
             res["S1_reference_call_form_ms"] = forms["reference_call_form"]["ms"]
             res["S1_call_forms"] = forms
-        if world == 1 and not args.no_engine_cache and not args.steady_cap and args.spare_blocks == 0.02:
+        if extras and not args.no_engine_cache and not args.steady_cap and args.spare_blocks == 0.02:
             res["engine_sized_cache"] = engine_sized_cache_run(args, rank, device)
-        if world == 1 and not args.no_s0:
+        if extras and not args.no_s0:
             del cmi, work_metrics, work_pos
+            out.clear()
             res["stages_ms_S0"] = s0_stages(args, device)
-        if world == 1 and default_workload and not args.no_other_configs:
+        if extras and default_workload and not args.no_other_configs:
             # (the main workload's K/V are not needed any more: the big configurations want the HBM)
             del k_cache, v_cache
             ds.cm.metrics = ds.cm.token_positions = None
             torch.cuda.empty_cache()
             res["other_configs"] = other_configs_run(args, rank, device)
-        if world == 1 and not args.no_adjacent:
+        if extras and not args.no_adjacent:
             # the producer of the metrics (row F3), one layer step at the continual-compression
             # shape; not part of `value`
             from vllm_kvcompress_amd.harness.attention_bench import run as attn_run
@@ -1610,7 +1813,7 @@ def main():
                 for r in (True, False)]
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(res))
+        emit(res, args.detail_json)
     if world > 1:
         dist.destroy_process_group()
 

@@ -36,10 +36,31 @@ typedef void* kvc_stream_t; /* hipStream_t */
 /* The ABI this header describes; kvc_abi_version() of the library loaded at run time must return it
  * (kvc_schedule_params grew fields in the middle between versions: a host built against another
  * version must not call in).  The Python binding and tests/cabi/cabi_host.cpp check it at start-up. */
-#define KVC_ABI_VERSION 6
+#define KVC_ABI_VERSION 7
 
 int kvc_abi_version(void);
 const char* kvc_last_error(void);
+
+/* ---------------------------------------------------------------------------------
+ * ABI version 7: the layout of the bytes INSIDE a cache block.
+ * The fork allocates the KV cache as an opaque [2, num_blocks, block_size * head_size] tensor and hands the
+ * ops views of it (vllm/attention/ops/paged_attn.py:262-284: K [NB, hd/x, bs, x], V [NB, hd, bs]); a block
+ * belongs to one (sequence, layer, KV head); swap_blocks / copy_blocks move whole blocks.  What a block's
+ * head_size * block_size elements MEAN is known to exactly three ops -- the cache write
+ * (kvcompress_reshape_and_cache), the decode attention (kvcompress_paged_attention_v1 / _v2) and
+ * execute_cache_moves -- and all three are this library's.  Two layouts, chosen per call:
+ *   KVC_LAYOUT_REFERENCE   the reference's: K [hd/x][bs][x] (x = 16 B of elements), V [hd][bs]
+ *                          (csrc/kvcompress_cache_kernels.cu:57-77).  A slot is 16 B pieces at a 16 * bs B
+ *                          stride in K and single elements at a bs * e B stride in V: moving ONE slot
+ *                          into a block rewrites the block's whole V image.
+ *   KVC_LAYOUT_SLOT_MAJOR  K [bs][hd], V [bs][hd]: a slot's K (and V) is ONE contiguous run of
+ *                          head_size * elem_bytes bytes at byte offset slot * head_size * elem_bytes of
+ *                          the K (V) plane.  A move is two contiguous copies; nothing else is touched.
+ * Tensor shapes, op signatures, block tables, slot numbers and the metric store are the same in both;
+ * a cache must be written, attended to and compacted in ONE layout (the library cannot tell them apart).
+ * --------------------------------------------------------------------------------- */
+#define KVC_LAYOUT_REFERENCE 0
+#define KVC_LAYOUT_SLOT_MAJOR 1
 
 /* ---------------------------------------------------------------------------------
  * A4  count_block_evictions
@@ -167,6 +188,24 @@ int kvc_execute_cache_moves_planned(void* k_cache, void* v_cache, float* kv_metr
                                     int64_t num_blocks, int32_t block_size, int32_t head_size,
                                     int32_t elem_bytes, int32_t vec_size, const int32_t* plan,
                                     kvc_stream_t stream);
+
+/* execute_cache_moves on a KVC_LAYOUT_SLOT_MAJOR cache (ABI version 7): same move list, same semantics
+ * (csrc/kvcompress_eviction_kernels.cu:359-435), but a move is 2 contiguous copies of head_size * elem_bytes
+ * bytes + 8 B of metric / position: no destination image is read, nothing but the moved bytes is written.
+ * head_size * elem_bytes must be a multiple of 16.  `plan`: the plan kvc_schedule_t1_cache_moves_ex left for
+ * exactly this list (caller vouches, as for _planned), or the workspace after kvc_execute_cache_moves_slot_major_plan
+ * on the same stream; NULL = the call plans for itself into `workspace` (kvc_cache_moves_plan_bytes() bytes,
+ * 16-byte aligned; one small launch more).  No claim table: slots are copied independently, any independent
+ * move list is handled the same way. */
+int kvc_execute_cache_moves_slot_major_plan(const int32_t* cache_moves_count, int32_t total_heads,
+                                            void* workspace, size_t workspace_bytes, kvc_stream_t stream);
+int kvc_execute_cache_moves_slot_major(void* k_cache, void* v_cache, float* kv_metrics,
+                                       int32_t* kv_position, const int32_t* cache_moves_idx,
+                                       const int32_t* cache_moves_count,
+                                       const int32_t* evicted_kv_offsets, int32_t total_heads,
+                                       int64_t num_blocks, int32_t block_size, int32_t head_size,
+                                       int32_t elem_bytes, const int32_t* plan, void* workspace,
+                                       size_t workspace_bytes, kvc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * A3  CompressionMetrics.schedule_evictions  (mask -> select -> count -> emit)
@@ -361,6 +400,14 @@ int kvc_schedule_batch_summary(const int32_t* context_lens, int32_t total_heads,
                                int64_t* host_out, int32_t host_mapped, int32_t wait, void* workspace,
                                size_t workspace_bytes, kvc_stream_t stream);
 int kvc_schedule_batch_summary_wait(kvc_stream_t stream);
+/* ABI version 7: the same launch for a host that polls instead of waiting for the stream.  host_mapped_out:
+ * 2 + num_seqs int64 of page-locked, device-mapped host memory; the kernel stores N and the counts, then
+ * (system-scope release) `ticket` (any non-zero value the caller has not used for this buffer before) into
+ * host_mapped_out[1 + num_seqs].  A host that reads the ticket (acquire) sees the numbers; it never has to
+ * call _wait.  Never waits itself. */
+int kvc_schedule_batch_summary_ticket(const int32_t* context_lens, int32_t total_heads, int32_t block_size,
+                                      const int32_t* evicted_blocks_per_seq, int32_t num_seqs,
+                                      int64_t* host_mapped_out, int64_t ticket, kvc_stream_t stream);
 /* Harvest-ahead (ABI version 5).  Continual compression streams the whole metric store twice per
  * decode step: aggregate_decode adds the step's attention to it, and a moment later the
  * small-eviction schedule reads it all again to find the ~1 % of the keys that lie below each
@@ -504,6 +551,22 @@ int kvc_reshape_and_cache_fp8(const void* key, const void* value, void* key_cach
                               int64_t value_stride, float k_scale, float v_scale,
                               kvc_stream_t stream);
 
+/* A7 into a cache of either block layout (ABI version 7; block_layout = KVC_LAYOUT_*): the two entry points
+ * above are these with KVC_LAYOUT_REFERENCE. */
+int kvc_reshape_and_cache_layout(const void* key, const void* value, void* key_cache,
+                                 void* value_cache, float* kv_metrics, const int64_t* slot_mapping,
+                                 const float* kv_metric_head_bias, int64_t num_tokens,
+                                 int32_t num_heads, int32_t head_size, int32_t block_size,
+                                 int32_t elem_bytes, int64_t key_stride, int64_t value_stride,
+                                 int32_t block_layout, kvc_stream_t stream);
+int kvc_reshape_and_cache_fp8_layout(const void* key, const void* value, void* key_cache,
+                                     void* value_cache, float* kv_metrics, const int64_t* slot_mapping,
+                                     const float* kv_metric_head_bias, int64_t num_tokens,
+                                     int32_t num_heads, int32_t head_size, int32_t block_size,
+                                     int32_t src_dtype, int32_t fp8_kind, int64_t key_stride,
+                                     int64_t value_stride, float k_scale, float v_scale,
+                                     int32_t block_layout, kvc_stream_t stream);
+
 /* ---------------------------------------------------------------------------------
  * F2  the block-state side of a compression step
  * replaces BlockSpaceManagerKVC.free_compressed_blocks and what it calls
@@ -626,6 +689,9 @@ typedef struct kvc_attention_params {
   int32_t harvest_layer;                /* the layer this call computes */
   int32_t harvest_num_layers;           /* L of the schedule call (num_kv_heads above is its H) */
   int32_t harvest_num_sinks;            /* the schedule call's num_sinks */
+  /* ABI version 7 */
+  int32_t block_layout;                 /* KVC_LAYOUT_REFERENCE (0) / KVC_LAYOUT_SLOT_MAJOR: how key_cache and
+                                           value_cache blocks are laid out inside (block_size 16 or 32 for slot-major) */
 } kvc_attention_params;
 
 /* The decode step without a sweep of the metric store (ABI version 6).  With fused_metrics the

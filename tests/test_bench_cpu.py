@@ -69,3 +69,28 @@ def test_self_launch_command(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_compact_line_of_a_full_result_stays_under_4k():
+    """round 5's driver record had `parsed: null`: the line had grown to 22 KB.  The full result of that run
+    (profiles/r5_bench.json) through compact_line: the contract's keys, roofline and cpu_baseline survive, the
+    line stays under 4 KB, the rest is what the detail file is for"""
+    import json
+    res = json.load(open(os.path.join(REPO, "profiles", "r5_bench.json")))
+    assert len(json.dumps(res)) > 20000
+    txt = bench.compact_line(res, os.path.join(REPO, "bench_detail.json"))
+    assert len(txt) < bench.LINE_MAX_BYTES and "\n" not in txt
+    d = json.loads(txt)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity_checked", "stages_ms"):
+        assert k in d, k
+    assert d["detail"] == "bench_detail.json" and d["config"]["workload"].startswith("c2:")
+    r = d["roofline"]
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+              "algorithmic_bytes_per_launch", "avg_launch_ms", "layout_amplification", "alg_frac_ceiling"):
+        assert k in r, k
+    assert abs(r["frac"] - res["roofline"]["frac"]) < 1e-5 and abs(r["traffic"] / res["roofline"]["traffic"] - 1) < 1e-5
+    c = d["cpu_baseline"]
+    assert {"value", "unit", "cores", "kind", "cpu_model", "threads_by_stage", "stage_seconds", "sample"} <= set(c)
+    assert d["parity_checked"] == {"bit_exact": True, "mismatched": [], "kv_bytes": res["parity_checked"]["kv_bytes"]}
+    assert set(d["other_configs"]) == {"c5", "c3"} and d["other_configs"]["c3"]["value"] > 0

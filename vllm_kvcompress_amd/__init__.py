@@ -10,6 +10,6 @@ Drop-in for the reference fork's op surface for this path only:
 
 See DESIGN.md / INTEGRATION.md at the repository root.
 """
-from ._lib import LIB_PATH, MAX_INT, load  # noqa: F401
+from ._lib import LIB_PATH, MAX_INT, block_layout, load, set_block_layout  # noqa: F401
 
-__all__ = ["LIB_PATH", "MAX_INT", "load"]
+__all__ = ["LIB_PATH", "MAX_INT", "load", "block_layout", "set_block_layout"]

@@ -10,6 +10,7 @@ raises instead of silently reading garbage.
 """
 from __future__ import annotations
 
+import os
 import weakref
 from typing import Optional
 
@@ -172,6 +173,24 @@ def _tracked(table: torch.Tensor):
     return rec
 
 
+# The fork never calls track_move_table: its scheduler just passes the same persistent tensor to schedule_cache_moves
+# step after step (reference scheduler.py:74-86, 513-522).  A table seen by schedule_cache_moves is therefore
+# registered by the call itself (the first call pays the reference's full fill_(0), every later one clears only what
+# the call before wrote) -- the guards are track_move_table's: the very tensor object, its storage pointer and its
+# version counter (a tensor without one, e.g. made under torch.inference_mode(), is filled whole every call).
+# KVC_AUTO_TRACK_MOVE_TABLE=0: only tables registered explicitly.  What a registration costs: a dirty map of
+# kvc_cache_moves_dirty_map_bytes(rows, bs) (1 bit per block_size rows).
+AUTO_TRACK_MOVE_TABLE = os.environ.get("KVC_AUTO_TRACK_MOVE_TABLE", "1") not in ("", "0")
+
+
+def _auto_track(table: torch.Tensor):
+    if (not AUTO_TRACK_MOVE_TABLE or table.dim() != 2 or table.shape[1] != 2 or not table.is_contiguous()
+            or _version_of(table) is None or torch.cuda.is_current_stream_capturing()):
+        return None
+    track_move_table(table)
+    return _tracked(table)
+
+
 def schedule_cache_moves(
     out_cache_moves_indices: torch.Tensor,
     out_cache_moves_count: torch.Tensor,
@@ -206,6 +225,8 @@ def _schedule_t1_cache_moves(cache_moves_idx, cache_moves_count, evicted_logical
     rows, bs = cache_moves_idx.shape[0], int(block_size)
     mode, dmap, dmap_bytes = (1 if zero_fill else 0), None, 0
     rec = _tracked(cache_moves_idx)
+    if rec is None and zero_fill:
+        rec = _auto_track(cache_moves_idx)
     if rec is not None and not zero_fill:
         rec.version = None                # the bare op leaves rows behind that the map does not know: full fill next time
         rec = None
@@ -304,6 +325,21 @@ def _execute_cache_moves(k_cache, v_cache, kv_metrics, kv_position, cache_moves_
     plan = _plan_of(k_cache, cache_moves_indices, cache_moves_count, evicted_kv_offsets, total_heads, block_size)
     if half != "plan":
         _written(k_cache, v_cache, kv_metrics, kv_position)
+    if _lib.block_layout_id() == _lib.LAYOUTS["slot_major"]:
+        # a slot is two contiguous runs of hd * e bytes: the kernel copies exactly the moved bytes (no block images,
+        # no claim table); without a plan of the list's own, one small launch makes one
+        ws = workspace(k_cache.device, int(lib.kvc_cache_moves_plan_bytes()), "execute_cache_moves_slot_major")
+        with torch.cuda.device(k_cache.device):
+            if plan is None and half in ("plan", "both"):
+                _lib.check(lib.kvc_execute_cache_moves_slot_major_plan(cmc.data_ptr(), total_heads, ws.data_ptr(),
+                                                                       ws.numel(), _stream(k_cache)))
+            if half != "plan":
+                _lib.check(lib.kvc_execute_cache_moves_slot_major(
+                    k_cache.data_ptr(), v_cache.data_ptr(), kv_metrics.data_ptr(), kv_position.data_ptr(),
+                    cmi.data_ptr(), cmc.data_ptr(), offs.data_ptr(), total_heads, num_blocks, block_size, head_size,
+                    k_cache.element_size(), (plan if plan is not None else ws).data_ptr(), ws.data_ptr(), ws.numel(),
+                    _stream(k_cache)))
+        return
     if plan is not None:
         if half != "plan":
             with torch.cuda.device(k_cache.device):
@@ -361,11 +397,11 @@ def reshape_and_cache_kvc(
             raise RuntimeError("reshape_and_cache_kvc: kv_cache_dtype 'auto' needs cache dtype == "
                                "key/value dtype")
         with torch.cuda.device(key.device):
-            _lib.check(lib.kvc_reshape_and_cache(
+            _lib.check(lib.kvc_reshape_and_cache_layout(
                 key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
                 kv_metrics.data_ptr(), sm.data_ptr(), hb.data_ptr(), num_tokens, num_heads,
                 head_size, block_size, key.element_size(), key.stride(0), value.stride(0),
-                _stream(key)))
+                _lib.block_layout_id(), _stream(key)))
         return
     kinds = {"fp8": 0, "fp8_e4m3": 0, "fp8_e5m2": 1}
     if kv_cache_dtype not in kinds:
@@ -376,11 +412,11 @@ def reshape_and_cache_kvc(
     if key_cache.element_size() != 1 or value_cache.element_size() != 1:
         raise RuntimeError("reshape_and_cache_kvc: an fp8 kv cache must have 1-byte elements")
     with torch.cuda.device(key.device):
-        _lib.check(lib.kvc_reshape_and_cache_fp8(
+        _lib.check(lib.kvc_reshape_and_cache_fp8_layout(
             key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
             kv_metrics.data_ptr(), sm.data_ptr(), hb.data_ptr(), num_tokens, num_heads, head_size,
             block_size, srcs[key.dtype], kinds[kv_cache_dtype], key.stride(0), value.stride(0),
-            float(k_scale), float(v_scale), _stream(key)))
+            float(k_scale), float(v_scale), _lib.block_layout_id(), _stream(key)))
 
 
 V1_DEAD_MESSAGE = ("schedule_cache_evictions (V1) is dead code in the reference; use "
@@ -476,6 +512,7 @@ def _paged_attention_kvc(out, kv_metric_out, exp_sum, max_logits, tmp_out, tmp_k
     p.dtype, p.kv_cache_dtype = dtypes[query.dtype], kvds[kv_cache_dtype]
     p.record_kv_metrics = int(bool(record_kv_metrics))
     p.schedule = _ATTENTION_SCHEDULE
+    p.block_layout = _lib.block_layout_id()
     if harvest is not None:
         # the lists of the next schedule call, made by this launch's epilogue (CompressionMetrics.begin_attention_harvest)
         harvest.check_call(query, int(num_kv_heads), int(block_size), int(layer), _stream(query))

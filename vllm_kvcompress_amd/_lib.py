@@ -15,7 +15,43 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KVC_MI355X_LIB", os.path.join(_HERE, "libkvc_mi355x.so"))
 
 MAX_INT = 2147483000  # reference vllm/kvcompress/metrics.py:12
-ABI_VERSION = 6       # KVC_ABI_VERSION of include/kvc_mi355x.h: the struct layouts mirrored below
+ABI_VERSION = 7       # KVC_ABI_VERSION of include/kvc_mi355x.h: the struct layouts mirrored below
+
+# KVC_LAYOUT_* of include/kvc_mi355x.h: how the bytes INSIDE a cache block are laid out.  The fork hands the ops
+# views of an opaque [2, NB, bs * hd] tensor (reference vllm/attention/ops/paged_attn.py:262-284); the three ops that
+# interpret a block -- reshape_and_cache_kvc, paged_attention_kvc_*, execute_cache_moves -- are all this package's,
+# so the layout is a switch of the package: "reference" (default: K [hd/x][bs][x], V [hd][bs], byte for byte the
+# fork's) or "slot_major" (K [bs][hd], V [bs][hd]: a slot is two contiguous runs, a move two contiguous copies).
+# One layout per process, chosen before the first cache write: KVC_BLOCK_LAYOUT=slot_major or set_block_layout().
+LAYOUTS = {"reference": 0, "slot_major": 1}
+_block_layout = os.environ.get("KVC_BLOCK_LAYOUT", "reference") or "reference"
+if _block_layout not in LAYOUTS:
+    raise ImportError(f"KVC_BLOCK_LAYOUT={_block_layout!r}: expected one of {sorted(LAYOUTS)}")
+
+
+def set_block_layout(name: str) -> None:
+    """``"reference"`` or ``"slot_major"`` for every cache op of this process from now on (a cache written in one
+    layout must be read and compacted in the same one: switch before the first write, or convert with
+    ``vllm_kvcompress_amd.layout.convert_block_layout``)."""
+    global _block_layout
+    if name not in LAYOUTS:
+        raise ValueError(f"block layout {name!r}: expected one of {sorted(LAYOUTS)}")
+    _block_layout = name
+    try:                                   # the compiled dispatcher binding keeps its own copy
+        import torch
+        if hasattr(torch.ops, "_kvc_mi355x") and hasattr(torch.ops._kvc_mi355x, "set_block_layout"):
+            torch.ops._kvc_mi355x.set_block_layout(LAYOUTS[name])
+    except (ImportError, RuntimeError):
+        pass
+
+
+def block_layout() -> str:
+    return _block_layout
+
+
+def block_layout_id() -> int:
+    return LAYOUTS[_block_layout]
+
 
 # KVC_WHY_* of include/kvc_mi355x.h (kvc_schedule_evictions_plan_reason)
 WHY = {0: "taken", 1: "forced_path", 2: "block_size", 3: "hint_unknown", 4: "bulk_eviction",
@@ -73,6 +109,7 @@ class KvcAttentionParams(ctypes.Structure):
         ("harvest_buf", c_void_p), ("harvest_seq_slot", c_void_p), ("harvest_seq_positions", c_void_p),
         ("harvest_num_protected", c_void_p), ("harvest_num_seqs", c_int32), ("harvest_layer", c_int32),
         ("harvest_num_layers", c_int32), ("harvest_num_sinks", c_int32),
+        ("block_layout", c_int32),
     ]
 
 
@@ -105,12 +142,17 @@ SYMBOLS = {
                                                 c_void_p, c_void_p, c_int32, c_int64, c_int32,
                                                 c_int32, c_int32, c_int32, c_void_p, c_size_t,
                                                 c_void_p]),
+    "kvc_execute_cache_moves_slot_major_plan": (c_int32, [c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
+    "kvc_execute_cache_moves_slot_major": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                     c_void_p, c_void_p, c_int32, c_int64, c_int32,
+                                                     c_int32, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
     "kvc_schedule_evictions_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32, c_int32]),
     "kvc_schedule_evictions": (c_int32, [ctypes.POINTER(KvcScheduleParams), c_void_p, c_size_t,
                                          c_void_p]),
     "kvc_schedule_batch_summary": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32,
                                              c_void_p, c_size_t, c_void_p]),
     "kvc_schedule_batch_summary_wait": (c_int32, [c_void_p]),
+    "kvc_schedule_batch_summary_ticket": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
     "kvc_schedule_evictions_uses_small_eviction_schedule": (c_int32, [ctypes.POINTER(KvcScheduleParams)]),
     "kvc_schedule_evictions_plan": (c_int32, [ctypes.POINTER(KvcScheduleParams)]),
     "kvc_schedule_evictions_plan_reason": (c_int32, [ctypes.POINTER(KvcScheduleParams)]),
@@ -139,6 +181,13 @@ SYMBOLS = {
                                             c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
                                             c_int32, c_int32, c_int64, c_int64, c_float, c_float,
                                             c_void_p]),
+    "kvc_reshape_and_cache_layout": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
+                                               c_int32, c_int64, c_int64, c_int32, c_void_p]),
+    "kvc_reshape_and_cache_fp8_layout": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                   c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32,
+                                                   c_int32, c_int32, c_int64, c_int64, c_float, c_float,
+                                                   c_int32, c_void_p]),
     "kvc_free_compressed_blocks_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "kvc_free_compressed_blocks": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_int32,

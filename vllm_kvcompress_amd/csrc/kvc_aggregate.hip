@@ -421,6 +421,37 @@ __global__ __launch_bounds__(256) void reshape_and_cache_blocks_kernel(
   }
 }
 
+// ------------------------------------------------------------------ A7 (slot-major blocks)
+// KVC_LAYOUT_SLOT_MAJOR (include/kvc_mi355x.h): a (token, head)'s K and V rows go, unchanged, to the
+// hd * e contiguous bytes of their slot -- one thread per 16 B piece of K and of V
+__global__ __launch_bounds__(256) void reshape_and_cache_slots_kernel(
+    const uint8_t* __restrict__ key, const uint8_t* __restrict__ value,
+    uint8_t* __restrict__ key_cache, uint8_t* __restrict__ value_cache,
+    float* __restrict__ kv_metrics, const int64_t* __restrict__ slot_mapping,
+    const float* __restrict__ bias, int64_t items, int num_heads, int pieces, int64_t key_stride_bytes,
+    int64_t value_stride_bytes, int aligned) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= items * pieces) return;
+  const int64_t item = i / pieces;
+  const int pc = (int)(i % pieces);
+  const int64_t slot = slot_mapping[item];
+  if (slot < 0) return;                                          // padding token
+  const int64_t token = item / num_heads;
+  const int head = (int)(item % num_heads);
+  if (pc == 0) kv_metrics[slot] = bias[head];
+  const int64_t sb = (int64_t)pieces * 16;
+  const uint8_t* ks = key + token * key_stride_bytes + (int64_t)head * sb + pc * 16;
+  const uint8_t* vs = value + token * value_stride_bytes + (int64_t)head * sb + pc * 16;
+  uint8_t* kd = key_cache + slot * sb + pc * 16;
+  uint8_t* vd = value_cache + slot * sb + pc * 16;
+  if (aligned) {
+    *reinterpret_cast<u32x4a*>(kd) = *reinterpret_cast<const u32x4a*>(ks);
+    *reinterpret_cast<u32x4a*>(vd) = *reinterpret_cast<const u32x4a*>(vs);
+  } else {
+    for (int b = 0; b < 16; ++b) { kd[b] = ks[b]; vd[b] = vs[b]; }
+  }
+}
+
 // ------------------------------------------------------------------ A7 (fp8 cache)
 // fp8 = cvt(float(x) / scale) with round-to-nearest-even and saturation to the largest
 // finite value, OCP e4m3fn / e5m2 -- what the reference computes with
@@ -454,7 +485,7 @@ __global__ __launch_bounds__(512) void reshape_and_cache_fp8_kernel(
     uint8_t* __restrict__ key_cache, uint8_t* __restrict__ value_cache,
     float* __restrict__ kv_metrics, const int64_t* __restrict__ slot_mapping,
     const float* __restrict__ bias, int num_heads, int head_size, int bs, int64_t key_stride,
-    int64_t value_stride, float k_scale, float v_scale) {
+    int64_t value_stride, float k_scale, float v_scale, int slot_major) {
   const int64_t token = blockIdx.x;
   const int n = num_heads * head_size;
   auto load = [&](const uint8_t* base, int64_t idx) -> float {
@@ -475,6 +506,11 @@ __global__ __launch_bounds__(512) void reshape_and_cache_fp8_kernel(
     const int64_t blk = slot / bs;
     const int off = (int)(slot % bs);
     const int64_t block_bytes = (int64_t)head_size * bs;        // 1 byte per element
+    if (slot_major) {                                           // KVC_LAYOUT_SLOT_MAJOR: [bs][hd] in both planes
+      value_cache[slot * head_size + d] = cvt(load(value, token * value_stride + i), v_scale);
+      key_cache[slot * head_size + d] = cvt(load(key, token * key_stride + i), k_scale);
+      continue;
+    }
     value_cache[blk * block_bytes + (int64_t)d * bs + off] = cvt(load(value, token * value_stride + i), v_scale);
     key_cache[blk * block_bytes + ((int64_t)(d / 16) * bs + off) * 16 + d % 16] = cvt(load(key, token * key_stride + i), k_scale);
   }
@@ -579,14 +615,38 @@ extern "C" int kvc_reshape_and_cache(const void* key, const void* value, void* k
                                      int64_t num_tokens, int32_t num_heads, int32_t head_size,
                                      int32_t block_size, int32_t elem_bytes, int64_t key_stride,
                                      int64_t value_stride, kvc_stream_t stream) {
+  return kvc_reshape_and_cache_layout(key, value, key_cache, value_cache, kv_metrics, slot_mapping, kv_metric_head_bias,
+                                      num_tokens, num_heads, head_size, block_size, elem_bytes, key_stride, value_stride,
+                                      KVC_LAYOUT_REFERENCE, stream);
+}
+
+extern "C" int kvc_reshape_and_cache_layout(const void* key, const void* value, void* key_cache,
+                                            void* value_cache, float* kv_metrics,
+                                            const int64_t* slot_mapping, const float* kv_metric_head_bias,
+                                            int64_t num_tokens, int32_t num_heads, int32_t head_size,
+                                            int32_t block_size, int32_t elem_bytes, int64_t key_stride,
+                                            int64_t value_stride, int32_t block_layout, kvc_stream_t stream) {
   using namespace kvc;
   if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4)
     return fail_invalid("Unsupported cache element size: " + std::to_string(elem_bytes));
   if (head_size % (16 / elem_bytes) != 0)
     return fail_invalid("Unsupported head size: " + std::to_string(head_size));
+  if (block_layout != KVC_LAYOUT_REFERENCE && block_layout != KVC_LAYOUT_SLOT_MAJOR)
+    return fail_invalid("Unsupported block layout: " + std::to_string(block_layout));
   if (num_tokens <= 0) return KVC_OK;
   hipStream_t s = (hipStream_t)stream;
   const int64_t items = num_tokens * num_heads;
+  if (block_layout == KVC_LAYOUT_SLOT_MAJOR) {
+    const int pieces = head_size * elem_bytes / 16;
+    const int aligned = (((uintptr_t)key | (uintptr_t)value | (uintptr_t)key_cache | (uintptr_t)value_cache) % 16 == 0) &&
+                        ((key_stride * elem_bytes) % 16 == 0) && ((value_stride * elem_bytes) % 16 == 0);
+    const int64_t threads = items * pieces;
+    hipLaunchKernelGGL(reshape_and_cache_slots_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s,
+                       (const uint8_t*)key, (const uint8_t*)value, (uint8_t*)key_cache, (uint8_t*)value_cache, kv_metrics,
+                       slot_mapping, kv_metric_head_bias, items, num_heads, pieces, key_stride * elem_bytes,
+                       value_stride * elem_bytes, aligned);
+    return check_launch("kvcompress_reshape_and_cache (slot-major)");
+  }
 #define KVC_RCB(HD, BS, E)                                                                          \
   hipLaunchKernelGGL((reshape_and_cache_blocks_kernel<HD, BS, E>), dim3((unsigned)((items + 255) / 256)), \
                      dim3(256), 0, s, (const uint8_t*)key, (const uint8_t*)value, (uint8_t*)key_cache, \
@@ -617,7 +677,22 @@ extern "C" int kvc_reshape_and_cache_fp8(const void* key, const void* value, voi
                                          int32_t block_size, int32_t src_dtype, int32_t fp8_kind,
                                          int64_t key_stride, int64_t value_stride, float k_scale,
                                          float v_scale, kvc_stream_t stream) {
+  return kvc_reshape_and_cache_fp8_layout(key, value, key_cache, value_cache, kv_metrics, slot_mapping, kv_metric_head_bias,
+                                          num_tokens, num_heads, head_size, block_size, src_dtype, fp8_kind, key_stride,
+                                          value_stride, k_scale, v_scale, KVC_LAYOUT_REFERENCE, stream);
+}
+
+extern "C" int kvc_reshape_and_cache_fp8_layout(const void* key, const void* value, void* key_cache,
+                                                void* value_cache, float* kv_metrics,
+                                                const int64_t* slot_mapping, const float* kv_metric_head_bias,
+                                                int64_t num_tokens, int32_t num_heads, int32_t head_size,
+                                                int32_t block_size, int32_t src_dtype, int32_t fp8_kind,
+                                                int64_t key_stride, int64_t value_stride, float k_scale,
+                                                float v_scale, int32_t block_layout, kvc_stream_t stream) {
   using namespace kvc;
+  if (block_layout != KVC_LAYOUT_REFERENCE && block_layout != KVC_LAYOUT_SLOT_MAJOR)
+    return fail_invalid("Unsupported block layout: " + std::to_string(block_layout));
+  const int slot_major = block_layout == KVC_LAYOUT_SLOT_MAJOR ? 1 : 0;
   if (src_dtype < 0 || src_dtype > 2) return fail_invalid("Unsupported input type of kv cache");
   if (fp8_kind < 0 || fp8_kind > 1) return fail_invalid("Unsupported data type of kv cache");
   if (head_size % 16 != 0) return fail_invalid("Unsupported head size: " + std::to_string(head_size));
@@ -630,7 +705,7 @@ extern "C" int kvc_reshape_and_cache_fp8(const void* key, const void* value, voi
                      dim3(threads), 0, s, (const uint8_t*)key, (const uint8_t*)value,                \
                      (uint8_t*)key_cache, (uint8_t*)value_cache, kv_metrics, slot_mapping,            \
                      kv_metric_head_bias, num_heads, head_size, block_size, key_stride, value_stride, \
-                     k_scale, v_scale)
+                     k_scale, v_scale, slot_major)
   switch (src_dtype * 2 + fp8_kind) {
     case 0: KVC_RC8(0, 0); break;
     case 1: KVC_RC8(0, 1); break;

@@ -51,6 +51,9 @@ extern "C" int kvc_paged_attention_decode(const kvc_attention_params* p, kvc_str
   a.max_blocks = p->max_num_blocks_per_seq; a.record = p->record_kv_metrics ? 1 : 0;
   a.max_ctx = p->max_context_len > 0 ? p->max_context_len : 1;
   a.schedule = p->schedule;
+  if (p->block_layout != KVC_LAYOUT_REFERENCE && p->block_layout != KVC_LAYOUT_SLOT_MAJOR)
+    return fail_invalid("Unsupported block layout: " + std::to_string(p->block_layout));
+  a.layout = p->block_layout;
   a.hv = AttnHarvest{};
   if (p->harvest_buf != nullptr) {
     if (a.fused_metrics == nullptr) return fail_invalid("paged_attention_decode: harvest_buf needs fused_metrics");

@@ -200,8 +200,101 @@ struct AttnArgs {
   int64_t q_stride, kv_block_stride;
   float scale, k_scale, v_scale;
   int32_t num_heads, num_kv_heads, max_blocks, max_parts, record, max_ctx, use_l2, schedule;
+  int32_t layout;                 // KVC_LAYOUT_REFERENCE / KVC_LAYOUT_SLOT_MAJOR
   AttnHarvest hv;                 // hv.cnt == nullptr: no harvest
 };
+
+// ---------------------------------------------------------------- KVC_LAYOUT_SLOT_MAJOR: P.V
+// In slot-major blocks (K [bs][hd], V [bs][hd]) a token's K row is still 16-byte pieces of 8 dims -- QK^T keeps its
+// MFMA form with other addresses.  V is the problem: an MFMA operand wants 8 TOKENS of one dim in a lane, and a
+// slot-major V piece is 8 DIMS of one token.  P.V therefore runs on the vector ALUs: a lane owns 8 dims of the
+// output (PPT = hd / 8 lanes per token, TPI = 64 / PPT tokens per wave instruction, each instruction hd * e
+// contiguous bytes per token) and accumulates acc[q][8] += p[q][token] * v[8] in fp32 for its NI = 32 / TPI tokens
+// of every 32-token group -- 8 conversions + 4 packed FMAs per query head and 16 bytes, ~10 % of the issue slots
+// at qpk 4 of a kernel that is bound by HBM.  P is rounded to the cache type first, like the MFMA operand
+// (.cu:332-420).  NQM = accumulator rows (4 or 8 query heads per KV head; more are refused by the launcher).
+template <typename T, int HD, int BS, int KVD, int NQM>
+struct PvSlots {
+  using KF = KvFrag<T, KVD>;
+  using V8 = typename Mma<T>::V8;
+  static constexpr int PPT = HD / 8;            // lanes per token
+  static constexpr int TPI = 64 / PPT;          // tokens per wave instruction
+  static constexpr int GT = HD <= 128 ? 32 : 16;   // tokens per group (what a lane holds of it: NI x 16 bytes)
+  static constexpr int NI = GT / TPI;           // instructions (= tokens per lane) per group
+  static constexpr int NG = ATT_CHUNK / GT;     // groups per wave chunk
+  static_assert(HD == 64 || HD == 128 || HD == 256, "slot-major attention: head sizes 64, 128, 256");
+  static_assert(NI % 4 == 0 && BS % NI == 0 && BS >= NI, "a lane's tokens of a group lie in one block");
+  struct Group { typename KF::Raw v[NI]; };
+  float acc[NQM][8];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int q = 0; q < NQM; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[q][e] = 0.0f;
+  }
+  // requests the V pieces of the group of GT tokens at t0 (a multiple of GT)
+  __device__ __forceinline__ void load(Group& G, const AttnArgs& a, const int32_t* bt, int t0, int ctx, int lane) const {
+    const int tsub = lane / PPT, pc = lane % PPT;
+    const int tok0 = t0 + tsub * NI;
+    const int64_t phys = tok0 < ctx ? bt[tok0 / BS] : 0;
+    const int64_t base = phys * a.kv_block_stride + (int64_t)(tok0 % BS) * HD + 8 * pc;
+#pragma unroll
+    for (int it = 0; it < NI; ++it)
+      G.v[it] = tok0 + it < ctx ? KF::load(a.v_cache, base + (int64_t)it * HD) : KF::zero();
+  }
+  // p_t0: the P tile at token t0, row stride rs floats ([query][token] fp32, 16-byte aligned rows).  Both factors go
+  // into the FMA as cache-type values widened on the fly (v_fma_mix_f32 for fp16): nothing converted is kept
+  __device__ __forceinline__ void fma(const Group& G, const float* p_t0, int rs, int nq, float v_scale, int lane) {
+    const int tsub = lane / PPT;
+#pragma unroll
+    for (int i4 = 0; i4 < NI / 4; ++i4) {
+      V8 vt[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) vt[j] = KF::convert(G.v[4 * i4 + j], v_scale);
+#pragma unroll
+      for (int q = 0; q < NQM; ++q) {
+        if (q >= nq) break;                                 // wave-uniform
+        const f32x4 p4 = *reinterpret_cast<const f32x4*>(p_t0 + q * rs + tsub * NI + 4 * i4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const T ph = (T)p4[j];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[q][e] = fmaf((float)ph, (float)vt[j][e], acc[q][e]);
+        }
+      }
+    }
+  }
+  // acc[q][*] *= alpha of query head q, which sits in lane q of `alpha` (lane & 15 = query)
+  __device__ __forceinline__ void rescale(float alpha, int nq) {
+#pragma unroll
+    for (int q = 0; q < NQM; ++q) {
+      if (q >= nq) break;
+      const float aq = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(alpha), q));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[q][e] *= aq;
+    }
+  }
+  // sums the TPI token groups of the wave and writes out[q * rs + dim], dims 8 pc .. 8 pc + 7 from lane pc
+  __device__ __forceinline__ void reduce_store(float* out, int rs, int nq, int lane) {
+#pragma unroll
+    for (int q = 0; q < NQM; ++q) {
+      if (q >= nq) break;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = acc[q][e];
+#pragma unroll
+        for (int d = PPT; d < 64; d <<= 1) v += __shfl_xor(v, d, 64);
+        acc[q][e] = v;
+      }
+      if (lane < PPT) {
+        *reinterpret_cast<f32x4*>(out + q * rs + 8 * lane) = f32x4{acc[q][0], acc[q][1], acc[q][2], acc[q][3]};
+        *reinterpret_cast<f32x4*>(out + q * rs + 8 * lane + 4) = f32x4{acc[q][4], acc[q][5], acc[q][6], acc[q][7]};
+      }
+    }
+  }
+};
+template <int HD, int BS>
+constexpr bool slot_major_shape() { return (HD == 64 || HD == 128 || HD == 256) && (BS == 16 || BS == 32); }
 
 // once per (sequence, KV head) workgroup; `first`: one thread of the ONE workgroup that accounts for the head
 __device__ __forceinline__ HarvestCtx harvest_ctx(const AttnArgs& a, int seq, int hk, int max_pos, int ctx, int bs, bool first) {
@@ -304,8 +397,9 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 // dynamic LDS: 2 x [ATT_WAVES][nqr][max(ATT_CHUNK, HD)] floats (P tiles | per-wave outputs)
-template <typename T, int HD, int BS, int KVD>
+template <typename T, int HD, int BS, int KVD, int NQM = 0>      // NQM > 0: KVC_LAYOUT_SLOT_MAJOR with <= NQM query heads
 __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a) {
+  constexpr bool SLOTS = NQM > 0;
   using M = Mma<T>;
   using V8 = typename M::V8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -384,11 +478,13 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
       // looks its own block up (tokens past the context are clamped onto the last one and masked below)
       const int tk = BS >= 16 ? t0 + c : min(t0 + c, ctx - 1);
       const int64_t phys = BS >= 16 ? bt[t0 / BS] : bt[tk / BS];
-      const int64_t kb = phys * a.kv_block_stride + (int64_t)(tk % BS) * X;
+      // (slot-major: the token's K row is hd contiguous elements)
+      const int64_t kb = phys * a.kv_block_stride + (int64_t)(tk % BS) * (SLOTS ? HD : X);
       typename KF::Raw kk[KS];
 #pragma unroll
       for (int s = 0; s < KS; ++s)
-        kk[s] = KF::load(a.k_cache, kb + (int64_t)((32 * s + 8 * g) / X) * BS * X + (32 * s + 8 * g) % X);
+        kk[s] = KF::load(a.k_cache, SLOTS ? kb + 32 * s + 8 * g
+                                          : kb + (int64_t)((32 * s + 8 * g) / X) * BS * X + (32 * s + 8 * g) % X);
 #pragma unroll
       for (int s = 0; s < KS; ++s) acc = M::mma(KF::convert(kk[s], a.k_scale), qf[s], acc);
     }
@@ -434,8 +530,24 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
   f32x4 O[DT];
 #pragma unroll
   for (int i = 0; i < DT; ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  PvSlots<T, SLOTS ? HD : 128, SLOTS ? BS : 16, KVD, SLOTS ? NQM : 1> pv;
+  if constexpr (SLOTS) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // (this wave's P tile, written above, is read by other lanes)
+    __builtin_amdgcn_wave_barrier();
+    pv.init();
+    using PV = decltype(pv);
+    typename PV::Group gv[2];
+    pv.load(gv[0], a, bt, tok_w0, ctx, lane);
 #pragma unroll
-  for (int pr = 0; pr < ATT_NSUB / 2; ++pr) {
+    for (int pr = 0; pr < PV::NG; ++pr) {
+      const int t0 = tok_w0 + pr * PV::GT;
+      if (t0 >= ctx) break;                               // wave-uniform
+      if (pr + 1 < PV::NG) pv.load(gv[(pr + 1) & 1], a, bt, t0 + PV::GT, ctx, lane);
+      pv.fma(gv[pr & 1], pw + pr * PV::GT, ROW, nq, a.v_scale, lane);
+    }
+  }
+#pragma unroll
+  for (int pr = 0; pr < (SLOTS ? 0 : ATT_NSUB / 2); ++pr) {
     const int t0 = tok_w0 + pr * 32;
     if (t0 >= ctx) break;                                 // wave-uniform
     // B operand: P[query c][tokens t0 + 8 g .. + 7], rounded to the cache type (.cu:332-420)
@@ -481,7 +593,9 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
 
   // ---- combine the four waves (same max, so a plain sum), normalise, store
   float* ow = lds + (int64_t)(ATT_WAVES + w) * nqr * ROW;   // second LDS region
-  if (c < nq) {
+  if constexpr (SLOTS) {
+    pv.reduce_store(ow, ROW, nq, lane);
+  } else if (c < nq) {
 #pragma unroll
     for (int i = 0; i < DT; ++i) *reinterpret_cast<f32x4*>(ow + c * ROW + 16 * i + 4 * g) = O[i];
   }
@@ -547,8 +661,9 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
 // (two workgroups per CU: qpk * max_context * 4 B <= ~68 KiB - the continual-compression
 // regime, e.g. 4k-token caps at qpk 4) and there are enough (sequence, KV head) pairs to fill the chip.
 // dynamic LDS: P [nqr][prow] | O [4][nqr][HD] | mrec [niter][4][16]
-template <typename T, int HD, int BS, int KVD, int NW>
+template <typename T, int HD, int BS, int KVD, int NW, int NQM = 0>
 __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode_whole_kernel(AttnArgs a, int prow, int niter_max) {
+  constexpr bool SLOTS = NQM > 0;
   using M = Mma<T>;
   using V8 = typename M::V8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -605,6 +720,8 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
   f32x4 O[DT];
 #pragma unroll
   for (int i = 0; i < DT; ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  PvSlots<T, SLOTS ? HD : 128, SLOTS ? BS : 16, KVD, SLOTS ? NQM : 1> pv;
+  if constexpr (SLOTS) pv.init();
   float m_run = -INFINITY, l_run = 0.0f;
   const int niter = (ctx + STEP - 1) / STEP;
   for (int it = 0; it < niter; ++it) {
@@ -622,10 +739,11 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
       if (t0 < ctx) {
         const int tk = BS >= 16 ? t0 + c : min(t0 + c, ctx - 1);
         const int64_t phys = BS >= 16 ? bt[t0 / BS] : bt[tk / BS];
-        const int64_t kb = phys * a.kv_block_stride + (int64_t)(tk % BS) * X;
+        const int64_t kb = phys * a.kv_block_stride + (int64_t)(tk % BS) * (SLOTS ? HD : X);
 #pragma unroll
         for (int s = 0; s < KS; ++s)
-          kk[sb][s] = KF::load(a.k_cache, kb + (int64_t)((32 * s + 8 * g) / X) * BS * X + (32 * s + 8 * g) % X);
+          kk[sb][s] = KF::load(a.k_cache, SLOTS ? kb + 32 * s + 8 * g
+                                                : kb + (int64_t)((32 * s + 8 * g) / X) * BS * X + (32 * s + 8 * g) % X);
       } else {
 #pragma unroll
         for (int s = 0; s < KS; ++s) kk[sb][s] = KF::zero();
@@ -671,10 +789,28 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
     l_run = l_run * alpha + group_sum(lsum);
     m_run = m_new;
     if (g == 0) mrec[(it * NW + w) * ATT_NQ + c] = m_new;
+    constexpr int NPR = ATT_NSUB / 2;
+    if constexpr (SLOTS) {
+      // (alpha of query head q sits in the lanes with lane & 15 == q; 0 on the first chunk, where acc is 0 too)
+      pv.rescale(alpha, nq);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (this wave's P rows, written above, are read by other lanes)
+      __builtin_amdgcn_wave_barrier();
+      using PV = decltype(pv);
+      typename PV::Group gv[2];
+      pv.load(gv[0], a, bt, tok_w0, ctx, lane);
+#pragma unroll
+      for (int pr = 0; pr < PV::NG; ++pr) {
+        const int t0 = tok_w0 + pr * PV::GT;
+        if (t0 >= ctx) break;
+        if (pr + 1 < PV::NG) pv.load(gv[(pr + 1) & 1], a, bt, t0 + PV::GT, ctx, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        pv.fma(gv[pr & 1], pw + pr * PV::GT, prow, nq, a.v_scale, lane);
+      }
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < DT; ++i) O[i] *= alpha;
     // ---- P.V, V fragments one 32-token pair ahead
-    constexpr int NPR = ATT_NSUB / 2;
     typename KF::Raw vv[2][DT];
     auto load_v = [&](int pr, int bufi) {
       const int tok = tok_w0 + pr * 32 + 8 * g;
@@ -735,7 +871,9 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
   for (int k = 0; k < OUTS; ++k) oacc[k] = 0.0f;
 #pragma unroll
   for (int hlf = 0; hlf < NW / 4; ++hlf) {
-    if (w / 4 == hlf && c < nq) {
+    if constexpr (SLOTS) {
+      if (w / 4 == hlf) pv.reduce_store(Ol + (int64_t)(w % 4) * nqr * HD, HD, nq, lane);
+    } else if (w / 4 == hlf && c < nq) {
 #pragma unroll
       for (int i = 0; i < DT; ++i)
         *reinterpret_cast<f32x4*>(Ol + ((int64_t)(w % 4) * nqr + c) * HD + 16 * i + 4 * g) = O[i];
@@ -1107,8 +1245,28 @@ inline AttnPlan attention_plan(int num_seqs, int num_heads, int num_kv_heads, in
   return p;
 }
 
+template <typename T, int HD, int BS, int KVD, int NQM>
+int launch_attention_layout(const AttnArgs& a, int num_seqs, hipStream_t s);
+
 template <typename T, int HD, int BS, int KVD>
 int launch_attention(const AttnArgs& a, int num_seqs, hipStream_t s) {
+  if (a.layout == KVC_LAYOUT_SLOT_MAJOR) {
+    if constexpr (slot_major_shape<HD, BS>()) {
+      const int qpk = a.num_heads / a.num_kv_heads;
+      if (qpk > 8)
+        return fail_invalid("paged_attention_decode: slot-major blocks support <= 8 query heads per KV head (got " +
+                            std::to_string(qpk) + ")");
+      return qpk <= 4 ? launch_attention_layout<T, HD, BS, KVD, 4>(a, num_seqs, s)
+                      : launch_attention_layout<T, HD, BS, KVD, 8>(a, num_seqs, s);
+    } else {
+      return fail_invalid("paged_attention_decode: slot-major blocks support head sizes 64 / 128 / 256 with block sizes 16 / 32");
+    }
+  }
+  return launch_attention_layout<T, HD, BS, KVD, 0>(a, num_seqs, s);
+}
+
+template <typename T, int HD, int BS, int KVD, int NQM>
+int launch_attention_layout(const AttnArgs& a, int num_seqs, hipStream_t s) {
   const int qpk = a.num_heads / a.num_kv_heads;
   const int ngroups = (qpk + ATT_NQ - 1) / ATT_NQ;
   const int nqr = qpk < ATT_NQ ? qpk : ATT_NQ;
@@ -1120,14 +1278,14 @@ int launch_attention(const AttnArgs& a, int num_seqs, hipStream_t s) {
     const int niter = (a.max_ctx + nw * ATT_CHUNK - 1) / (nw * ATT_CHUNK);
     if (nw == 4) {
       if (whole_lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(paged_attention_decode_whole_kernel<T, HD, BS, KVD, 4>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(paged_attention_decode_whole_kernel<T, HD, BS, KVD, 4, NQM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)whole_lds);
-      hipLaunchKernelGGL((paged_attention_decode_whole_kernel<T, HD, BS, KVD, 4>), dim3(a.num_kv_heads * ngroups, num_seqs),
+      hipLaunchKernelGGL((paged_attention_decode_whole_kernel<T, HD, BS, KVD, 4, NQM>), dim3(a.num_kv_heads * ngroups, num_seqs),
                          dim3(256), whole_lds, s, a, prow, niter);
     } else {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(paged_attention_decode_whole_kernel<T, HD, BS, KVD, 8>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(paged_attention_decode_whole_kernel<T, HD, BS, KVD, 8, NQM>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)whole_lds);
-      hipLaunchKernelGGL((paged_attention_decode_whole_kernel<T, HD, BS, KVD, 8>), dim3(a.num_kv_heads * ngroups, num_seqs),
+      hipLaunchKernelGGL((paged_attention_decode_whole_kernel<T, HD, BS, KVD, 8, NQM>), dim3(a.num_kv_heads * ngroups, num_seqs),
                          dim3(512), whole_lds, s, a, prow, niter);
     }
     return check_launch("paged_attention_decode");
@@ -1138,9 +1296,9 @@ int launch_attention(const AttnArgs& a, int num_seqs, hipStream_t s) {
   constexpr int ROW = ATT_CHUNK > HD ? ATT_CHUNK : HD;
   const size_t lds_bytes = (size_t)2 * ATT_WAVES * nqr * ROW * sizeof(float);
   if (lds_bytes > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(paged_attention_decode_kernel<T, HD, BS, KVD>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(paged_attention_decode_kernel<T, HD, BS, KVD, NQM>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  hipLaunchKernelGGL((paged_attention_decode_kernel<T, HD, BS, KVD>),
+  hipLaunchKernelGGL((paged_attention_decode_kernel<T, HD, BS, KVD, NQM>),
                      dim3(a.max_parts, a.num_kv_heads * ngroups, num_seqs), dim3(256), lds_bytes, s, a);
   if (a.max_parts > 1) {
     hipLaunchKernelGGL((paged_attention_reduce_kernel<T, HD, BS>), dim3(a.num_heads, num_seqs), dim3(256),

@@ -585,6 +585,131 @@ __global__ __launch_bounds__(256) void compact_generic_kernel(
   }
 }
 
+// ------------------------------------------------------------------------- slot-major layout
+// KVC_LAYOUT_SLOT_MAJOR (include/kvc_mi355x.h): K and V of physical slot s are the SB = hd * e bytes at
+// byte s * SB of their planes.  A move is two contiguous copies of SB bytes + 8 B of metric / position --
+// randomly placed chunks of >= 128 B copy at the speed of a linear copy (tools/gather_bw.hip), so this
+// kernel is the algorithmic traffic and nothing else: no destination image is read, no claim table.
+//   * LPS = SB / 16 lanes hold one slot image; a wave instruction moves 64 / LPS slots (1 KiB);
+//   * a wave owns a contiguous range of the plan's 32-move tiles (the byte-wise half of the plan that
+//     schedule_t1_cache_moves leaves behind, or compact_plan_kernel's).  Its moves go through a queue in
+//     LDS so that heads with one or two moves (the continual steady state: 65 536 heads, ~1 move each)
+//     fill whole batches: a batch = MB moves, ALL of whose loads (K, V, metric, position: <= 18 per lane)
+//     are requested before the first store;
+//   * loads and stores are non-temporal: every byte is touched once.
+template <int LPS>
+__global__ __launch_bounds__(256) void compact_slots_kernel(
+    uint8_t* __restrict__ k_cache, uint8_t* __restrict__ v_cache, float* __restrict__ metrics,
+    int32_t* __restrict__ positions, const int32_t* __restrict__ moves,
+    const int32_t* __restrict__ count, const int32_t* __restrict__ offs,
+    const int32_t* __restrict__ wg_tiles, int nwg, int heads_per_wg, int G) {
+  constexpr int TM = KVC_TM_GENERIC;                      // moves per tile of the plan
+  constexpr int MB = LPS <= 16 ? 32 : 512 / LPS;          // moves per batch
+  constexpr int SPI = 64 / LPS;                           // slots per wave instruction
+  constexpr int NIT = MB / SPI;                           // instructions per plane and batch (<= 8)
+  constexpr int64_t SB = (int64_t)LPS * 16;               // bytes of a slot image
+  __shared__ int2 queue[4][TM + MB];
+  const int lane = lane_id(), w = threadIdx.x / WAVE;
+  const int nw = gridDim.x * 4, wv = blockIdx.x * 4 + w;
+  int tb, te, g, g_first;
+  if (!locate_tiles(wg_tiles, nwg, heads_per_wg, count, G, TM, wv, nw, lane, tb, te, g, g_first)) return;
+  int2* q = queue[w];
+  const int sub = lane / LPS, piece = lane % LPS;
+  int qn = 0;
+  auto copy_batch = [&](int n) {                          // q[0, n), n <= MB (wave-uniform)
+    u32x4 kr[NIT], vr[NIT];
+    int2 mv[NIT];
+    float m = 0.0f;
+    int32_t pos = 0;
+    const int2 mine = lane < n ? q[lane] : int2{0, 0};
+    if (lane < n) { m = __builtin_nontemporal_load(metrics + mine.y); pos = __builtin_nontemporal_load(positions + mine.y); }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = it * SPI + sub;
+      mv[it] = idx < n ? q[idx] : int2{-1, -1};
+      if (it * SPI < n && mv[it].x >= 0) {
+        kr[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(k_cache + (int64_t)mv[it].y * SB) + piece);
+        vr[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(v_cache + (int64_t)mv[it].y * SB) + piece);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      if (it * SPI < n && mv[it].x >= 0) {
+        __builtin_nontemporal_store(kr[it], reinterpret_cast<u32x4*>(k_cache + (int64_t)mv[it].x * SB) + piece);
+        __builtin_nontemporal_store(vr[it], reinterpret_cast<u32x4*>(v_cache + (int64_t)mv[it].x * SB) + piece);
+      }
+    }
+    if (lane < n) { metrics[mine.x] = m; positions[mine.x] = pos; }
+  };
+  int cnt = count[g];
+  int g_next = g_first + (cnt + TM - 1) / TM;
+  for (int t = tb; t < te; ++t) {
+    while (t >= g_next && g + 1 < G) { ++g; g_first = g_next; cnt = count[g]; g_next = g_first + (cnt + TM - 1) / TM; }
+    const int j = (t - g_first) * TM + lane;
+    const bool in = lane < TM && j < cnt;
+    int2 m = {0, 0};
+    if (in) m = reinterpret_cast<const int2*>(moves)[(int64_t)offs[g] + j];
+    const unsigned long long mask = __ballot(in);
+    if (in) q[qn + __popcll(mask & ((1ull << lane) - 1ull))] = m;
+    qn += __popcll(mask);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    while (qn >= MB) {
+      copy_batch(MB);
+      // what is left moves to the front (< TM entries: one read and one write per lane)
+      const int rest = qn - MB;
+      const int2 keep = lane < rest ? q[MB + lane] : int2{0, 0};
+      __builtin_amdgcn_wave_barrier();
+      if (lane < rest) q[lane] = keep;
+      qn = rest;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (qn > 0) copy_batch(qn);
+}
+
+// slot images that are not a power-of-two number of 16 B pieces <= 64 (e.g. head size 96): 16 B pieces one by one
+__global__ __launch_bounds__(256) void compact_slots_generic_kernel(
+    uint8_t* __restrict__ k_cache, uint8_t* __restrict__ v_cache, float* __restrict__ metrics,
+    int32_t* __restrict__ positions, const int32_t* __restrict__ moves,
+    const int32_t* __restrict__ count, const int32_t* __restrict__ offs,
+    const int32_t* __restrict__ wg_tiles, int nwg, int heads_per_wg, int G, int pieces) {
+  __shared__ int loc_s[5];
+  const int tid = threadIdx.x;
+  if (tid < WAVE) {
+    int tb = 0, te = 0, g0 = 0, gf = 0;
+    const bool any = locate_tiles(wg_tiles, nwg, heads_per_wg, count, G, KVC_TM_GENERIC, blockIdx.x, gridDim.x, tid,
+                                  tb, te, g0, gf);
+    if (tid == 0) { loc_s[0] = any ? 1 : 0; loc_s[1] = tb; loc_s[2] = te; loc_s[3] = g0; loc_s[4] = gf; }
+  }
+  __syncthreads();
+  if (!loc_s[0]) return;
+  int g = loc_s[3], g_first = loc_s[4];
+  int cnt = count[g];
+  int g_next = g_first + (cnt + KVC_TM_GENERIC - 1) / KVC_TM_GENERIC;
+  const int64_t sb = (int64_t)pieces * 16;
+  for (int t = loc_s[1]; t < loc_s[2]; ++t) {
+    while (t >= g_next && g + 1 < G) { ++g; g_first = g_next; cnt = count[g]; g_next = g_first + (cnt + KVC_TM_GENERIC - 1) / KVC_TM_GENERIC; }
+    const int j0 = (t - g_first) * KVC_TM_GENERIC;
+    const int j1 = min(cnt, j0 + KVC_TM_GENERIC);
+    const int2* __restrict__ mv = reinterpret_cast<const int2*>(moves) + offs[g];
+    for (int j = j0 + tid; j < j1; j += blockDim.x) {
+      const int2 m = mv[j];
+      metrics[m.x] = metrics[m.y];
+      positions[m.x] = positions[m.y];
+    }
+    const int n = (j1 - j0) * 2 * pieces;
+    for (int idx = tid; idx < n; idx += blockDim.x) {
+      const int2 m = mv[j0 + idx / (2 * pieces)];
+      const int r = idx % (2 * pieces);
+      uint8_t* base = r < pieces ? k_cache : v_cache;
+      const int pc = r < pieces ? r : r - pieces;
+      reinterpret_cast<u32x4*>(base + (int64_t)m.x * sb)[pc] = reinterpret_cast<const u32x4*>(base + (int64_t)m.y * sb)[pc];
+    }
+  }
+}
+
 }  // namespace kvc
 
 // one byte per block, in whole 16 B vectors
@@ -782,4 +907,88 @@ extern "C" int kvc_execute_cache_moves(void* k_cache, void* v_cache, float* kv_m
                                        cache_moves_count, evicted_kv_offsets, total_heads, num_blocks,
                                        block_size, head_size, elem_bytes, vec_size, workspace,
                                        workspace_bytes, stream);
+}
+
+// ---- KVC_LAYOUT_SLOT_MAJOR (ABI version 7)
+namespace kvc {
+template <int LPS>
+static int compact_slots_grid() {
+  static std::atomic<int> grid[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (grid[dev].load(std::memory_order_relaxed) == 0) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, compact_slots_kernel<LPS>, 256, 0) != hipSuccess || per_cu < 1)
+      per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+      cus = 256;
+    grid[dev].store(per_cu * cus, std::memory_order_relaxed);
+  }
+  return grid[dev].load(std::memory_order_relaxed);
+}
+}  // namespace kvc
+
+extern "C" int kvc_execute_cache_moves_slot_major_plan(const int32_t* cache_moves_count, int32_t total_heads,
+                                                       void* workspace, size_t workspace_bytes, kvc_stream_t stream) {
+  using namespace kvc;
+  if (total_heads <= 0) return KVC_OK;
+  if (cache_moves_count == nullptr || workspace == nullptr || workspace_bytes < claims_offset() ||
+      (reinterpret_cast<uintptr_t>(workspace) & 15) != 0)
+    return fail_invalid("execute_cache_moves (slot-major plan): bad arguments");
+  int nwg, hpw;
+  moves_plan_shape(total_heads, nwg, hpw);
+  const int plan_blocks = hpw >= 16 ? (nwg + 3) / 4 : (nwg + 255) / 256;
+  // (the byte-wise half of the plan: 32-move tiles; no claim table in this layout)
+  hipLaunchKernelGGL(compact_plan_kernel, dim3(plan_blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<int32_t*>(workspace) + MOVES_PLAN_WGS, cache_moves_count, total_heads,
+                     KVC_TM_GENERIC, nwg, hpw, plan_blocks, (u32x4*)nullptr, (int64_t)0);
+  return check_launch("execute_cache_moves (slot-major plan)");
+}
+
+extern "C" int kvc_execute_cache_moves_slot_major(void* k_cache, void* v_cache, float* kv_metrics,
+                                                  int32_t* kv_position, const int32_t* cache_moves_idx,
+                                                  const int32_t* cache_moves_count,
+                                                  const int32_t* evicted_kv_offsets, int32_t total_heads,
+                                                  int64_t num_blocks, int32_t block_size, int32_t head_size,
+                                                  int32_t elem_bytes, const int32_t* plan, void* workspace,
+                                                  size_t workspace_bytes, kvc_stream_t stream) {
+  using namespace kvc;
+  (void)num_blocks;
+  if (block_size < 1) return fail_invalid("Unsupported block size: " + std::to_string(block_size));
+  if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4)
+    return fail_invalid("Unsupported cache element size: " + std::to_string(elem_bytes));
+  if (head_size < 1 || (head_size * elem_bytes) % 16 != 0)
+    return fail_invalid("Unsupported head size: " + std::to_string(head_size) + " (slot-major blocks hold slots of whole 16-byte pieces)");
+  if (total_heads <= 0) return KVC_OK;
+  if (plan == nullptr) {
+    if (int rc = kvc_execute_cache_moves_slot_major_plan(cache_moves_count, total_heads, workspace, workspace_bytes, stream))
+      return rc;
+    plan = reinterpret_cast<const int32_t*>(workspace);
+  } else if ((reinterpret_cast<uintptr_t>(plan) & 15) != 0) {
+    return fail_invalid("execute_cache_moves: plan must be 16-byte aligned");
+  }
+  const int32_t* tiles = plan + MOVES_PLAN_WGS;
+  int nwg, hpw;
+  moves_plan_shape(total_heads, nwg, hpw);
+  hipStream_t s = (hipStream_t)stream;
+  uint8_t* k = reinterpret_cast<uint8_t*>(k_cache);
+  uint8_t* v = reinterpret_cast<uint8_t*>(v_cache);
+  const int pieces = head_size * elem_bytes / 16;
+#define KVC_SLOTS(LPS)                                                                               \
+  hipLaunchKernelGGL(compact_slots_kernel<LPS>, dim3(compact_slots_grid<LPS>()), dim3(256), 0, s, k, v, \
+                     kv_metrics, kv_position, cache_moves_idx, cache_moves_count, evicted_kv_offsets, tiles, nwg, hpw, total_heads)
+  switch (pieces) {
+    case 4: KVC_SLOTS(4); break;
+    case 8: KVC_SLOTS(8); break;
+    case 16: KVC_SLOTS(16); break;
+    case 32: KVC_SLOTS(32); break;
+    case 64: KVC_SLOTS(64); break;
+    default:
+      hipLaunchKernelGGL(compact_slots_generic_kernel, dim3(256 * 8), dim3(256), 0, s, k, v, kv_metrics, kv_position,
+                         cache_moves_idx, cache_moves_count, evicted_kv_offsets, tiles, nwg, hpw, total_heads, pieces);
+  }
+#undef KVC_SLOTS
+  return check_launch("execute_cache_moves (slot-major)");
 }

@@ -356,7 +356,7 @@ extern "C" size_t kvc_schedule_evictions_workspace_bytes(int64_t total_slots, in
 namespace kvc {
 __global__ __launch_bounds__(1024) void batch_summary_kernel(const int32_t* __restrict__ context_lens, int total_heads,
                                                              int bs, const int32_t* __restrict__ k_per_seq, int num_seqs,
-                                                             int64_t* __restrict__ out) {
+                                                             int64_t* __restrict__ out, int64_t ticket) {
   __shared__ unsigned long long part[16];
   unsigned long long blocks = 0;
   const int n4 = (reinterpret_cast<uintptr_t>(context_lens) & 15) == 0 ? total_heads / 4 : 0;
@@ -375,12 +375,19 @@ __global__ __launch_bounds__(1024) void batch_summary_kernel(const int32_t* __re
   for (int d = 32; d > 0; d >>= 1) blocks += __shfl_xor(blocks, d, 64);
   if (lane_id() == 0) part[threadIdx.x >> 6] = blocks;
   for (int i = threadIdx.x; i < num_seqs; i += 1024) out[1 + i] = (int64_t)k_per_seq[i];
+  if (ticket) __threadfence_system();             // (the counts are on their way before the ticket is)
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned long long t = 0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) t += part[w];
     out[0] = (int64_t)t * bs;
+    if (ticket) {
+      // a host that polls the ticket word sees the numbers a memory round trip after this store, without waiting
+      // for the kernel's end-of-grid signal to travel through the runtime
+      __threadfence_system();
+      __hip_atomic_store(out + 1 + num_seqs, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 }  // namespace kvc
@@ -402,13 +409,26 @@ extern "C" int kvc_schedule_batch_summary(const int32_t* context_lens, int32_t t
       return fail_invalid("schedule_batch_summary: workspace too small or misaligned");
     dst = reinterpret_cast<int64_t*>(workspace);
   }
-  batch_summary_kernel<<<1, 1024, 0, s>>>(context_lens, total_heads, block_size, evicted_blocks_per_seq, num_seqs, dst);
+  batch_summary_kernel<<<1, 1024, 0, s>>>(context_lens, total_heads, block_size, evicted_blocks_per_seq, num_seqs, dst, (int64_t)0);
   if (int rc = check_launch("schedule_batch_summary")) return rc;
   if (!host_mapped && hipMemcpyAsync(host_out, dst, bytes, hipMemcpyDeviceToHost, s) != hipSuccess) {
     set_error(std::string("schedule_batch_summary: ") + hipGetErrorString(hipGetLastError()));
     return KVC_ERR_HIP;
   }
   return wait ? kvc_schedule_batch_summary_wait(stream) : KVC_OK;
+}
+
+extern "C" int kvc_schedule_batch_summary_ticket(const int32_t* context_lens, int32_t total_heads, int32_t block_size,
+                                                 const int32_t* evicted_blocks_per_seq, int32_t num_seqs,
+                                                 int64_t* host_mapped_out, int64_t ticket, kvc_stream_t stream) {
+  using namespace kvc;
+  if (block_size < 1) return fail_invalid("Unsupported block size: " + std::to_string(block_size));
+  if (context_lens == nullptr || total_heads < 0 || num_seqs < 0 || host_mapped_out == nullptr || ticket == 0 ||
+      (num_seqs > 0 && evicted_blocks_per_seq == nullptr))
+    return fail_invalid("schedule_batch_summary: bad arguments");
+  batch_summary_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(context_lens, total_heads, block_size, evicted_blocks_per_seq,
+                                                            num_seqs, host_mapped_out, ticket);
+  return check_launch("schedule_batch_summary");
 }
 
 extern "C" int kvc_schedule_batch_summary_wait(kvc_stream_t stream) {

@@ -17,6 +17,7 @@
 #include <torch/library.h>
 
 #include <atomic>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <optional>
@@ -79,6 +80,21 @@ Tensor workspace(const Tensor& like, size_t nbytes, const char* tag) {
 // _kvc_mi355x::set_attention_schedule, like vllm_kvcompress_amd._custom_ops.set_attention_schedule
 // does for the Python-registered ops
 std::atomic<int> g_attention_schedule{0};
+
+// KVC_LAYOUT_* of every cache op registered here (include/kvc_mi355x.h, ABI version 7): the environment's
+// KVC_BLOCK_LAYOUT at load time, or _kvc_mi355x::set_block_layout (what vllm_kvcompress_amd.set_block_layout calls)
+static int layout_from_env() {
+  const char* e = std::getenv("KVC_BLOCK_LAYOUT");
+  if (e == nullptr || *e == 0 || std::string(e) == "reference") return KVC_LAYOUT_REFERENCE;
+  if (std::string(e) == "slot_major") return KVC_LAYOUT_SLOT_MAJOR;
+  TORCH_CHECK(false, "KVC_BLOCK_LAYOUT=", e, ": expected reference or slot_major");
+}
+std::atomic<int> g_block_layout{layout_from_env()};
+void set_block_layout_op(int64_t layout) {
+  TORCH_CHECK(layout == KVC_LAYOUT_REFERENCE || layout == KVC_LAYOUT_SLOT_MAJOR, "block layout must be 0 (reference) or 1 (slot-major)");
+  g_block_layout.store((int)layout);
+}
+int64_t block_layout_op() { return g_block_layout.load(); }
 
 // start-up hooks of this binding (vllm_kvcompress_amd._custom_ops.reserve_workspace /
 // reserve_attention_scratch / set_attention_schedule call them when this library is the one
@@ -228,6 +244,18 @@ void execute_cache_moves(Tensor& k_cache, Tensor& v_cache, Tensor& kv_metrics, T
   written(v_cache);
   written(kv_metrics);
   written(kv_position);
+  if (g_block_layout.load() == KVC_LAYOUT_SLOT_MAJOR) {
+    // a slot is two contiguous runs: the moved bytes and nothing else; the list's own plan or one small launch
+    Tensor ws = workspace(k_cache, kvc_cache_moves_plan_bytes(), "execute_cache_moves_slot_major");
+    check(kvc_execute_cache_moves_slot_major(k_cache.data_ptr(), v_cache.data_ptr(), kv_metrics.data_ptr<float>(),
+                                             kv_position.data_ptr<int32_t>(), cmi.data_ptr<int32_t>(),
+                                             cmc.data_ptr<int32_t>(), offs.data_ptr<int32_t>(), total_heads, num_blocks,
+                                             (int32_t)block_size, (int32_t)head_size, (int32_t)k_cache.element_size(),
+                                             plan.defined() ? reinterpret_cast<const int32_t*>(plan.data_ptr()) : nullptr,
+                                             ws.data_ptr(), (size_t)ws.numel(), current_stream(k_cache)));
+    if (plan.defined()) g_planned_compactions.fetch_add(1);
+    return;
+  }
   if (plan.defined()) {
     check(kvc_execute_cache_moves_planned(k_cache.data_ptr(), v_cache.data_ptr(), kv_metrics.data_ptr<float>(),
                                           kv_position.data_ptr<int32_t>(), cmi.data_ptr<int32_t>(),
@@ -276,10 +304,11 @@ void kvcompress_reshape_and_cache(const Tensor& key, const Tensor& value, Tensor
   if (kv_cache_dtype == "auto") {
     TORCH_CHECK(key.scalar_type() == key_cache.scalar_type() && value.scalar_type() == value_cache.scalar_type(),
                 "reshape_and_cache_kvc: kv_cache_dtype 'auto' needs cache dtype == key/value dtype");
-    check(kvc_reshape_and_cache(key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
-                                met, sm.data_ptr<int64_t>(), hb.data_ptr<float>(), num_tokens,
-                                (int32_t)num_heads, (int32_t)head_size, (int32_t)block_size,
-                                (int32_t)key.element_size(), key.stride(0), value.stride(0), current_stream(key)));
+    check(kvc_reshape_and_cache_layout(key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+                                       met, sm.data_ptr<int64_t>(), hb.data_ptr<float>(), num_tokens,
+                                       (int32_t)num_heads, (int32_t)head_size, (int32_t)block_size,
+                                       (int32_t)key.element_size(), key.stride(0), value.stride(0),
+                                       g_block_layout.load(), current_stream(key)));
     return;
   }
   int kind = 0;
@@ -294,11 +323,11 @@ void kvcompress_reshape_and_cache(const Tensor& key, const Tensor& value, Tensor
   TORCH_CHECK(value.scalar_type() == key.scalar_type(), "Unsupported input type of kv cache: ", value.scalar_type());
   TORCH_CHECK(key_cache.element_size() == 1 && value_cache.element_size() == 1,
               "reshape_and_cache_kvc: an fp8 kv cache must have 1-byte elements");
-  check(kvc_reshape_and_cache_fp8(key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
-                                  met, sm.data_ptr<int64_t>(), hb.data_ptr<float>(), num_tokens,
-                                  (int32_t)num_heads, (int32_t)head_size, (int32_t)block_size, src, kind,
-                                  key.stride(0), value.stride(0), (float)k_scale, (float)v_scale,
-                                  current_stream(key)));
+  check(kvc_reshape_and_cache_fp8_layout(key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+                                         met, sm.data_ptr<int64_t>(), hb.data_ptr<float>(), num_tokens,
+                                         (int32_t)num_heads, (int32_t)head_size, (int32_t)block_size, src, kind,
+                                         key.stride(0), value.stride(0), (float)k_scale, (float)v_scale,
+                                         g_block_layout.load(), current_stream(key)));
 }
 
 // ------------------------------------------------------------------ _C (decode attention)
@@ -365,6 +394,7 @@ void paged_attention_kvc(Tensor& out, Tensor& kv_metric_out, const Tensor* exp_s
   p.max_context_len = (int32_t)max_context_len;
   p.dtype = dt; p.kv_cache_dtype = kvd; p.record_kv_metrics = record_kv_metrics ? 1 : 0;
   p.schedule = g_attention_schedule.load();
+  p.block_layout = g_block_layout.load();
   c10::DeviceGuard guard(query.device());
   Tensor scratch;                                   // v1: the small partition buffers the signature does not carry
   if (exp_sums != nullptr) {
@@ -497,6 +527,8 @@ TORCH_LIBRARY_FRAGMENT(_C, m) {
 TORCH_LIBRARY_FRAGMENT(_kvc_mi355x, m) {
   m.def("reserve_workspace(Tensor like, int nbytes, str tag) -> ()", &reserve_workspace_op);
   m.def("set_attention_schedule(int schedule) -> ()", &set_attention_schedule_op);
+  m.def("set_block_layout(int layout) -> ()", &set_block_layout_op);
+  m.def("block_layout() -> int", &block_layout_op);
   // how many execute_cache_moves calls ran on the plan of the schedule_t1_cache_moves before them (tests)
   m.def("planned_compactions() -> int", &planned_compactions_op);
 }
