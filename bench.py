@@ -694,9 +694,8 @@ def live_pmc_traffic(extra_flags, timeout=240, kernel="compact_runs_kernel"):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None
-    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-           "--no-adjacent", "--no-s0", "--no-probe", "--no-engine-cache", "--no-other-configs",
-           "--no-live-traffic", "--no-parity-gate"] + list(extra_flags)
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--headline-only", "--no-cpu-baseline",
+           "--no-probe", "--no-live-traffic", "--no-parity-gate", "--detail-json", ""] + list(extra_flags)
     env = dict(os.environ, TMPDIR="/tmp")
     vals = {}
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:

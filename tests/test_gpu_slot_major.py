@@ -93,9 +93,9 @@ def test_reshape_and_cache_slot_major(dtype, hd, bs, slot_major):
     kd = torch.from_numpy(ks).to(DEV).view(tdt)
     vd = torch.from_numpy(vs).to(DEV).view(tdt)
     md = torch.from_numpy(m0.copy()).to(DEV)
-    # a key that is a strided view (the fork's qkv split), a contiguous value
-    kv = torch.from_numpy(np.concatenate([key, val], axis=2)).to(DEV).view(tdt)
-    ops.reshape_and_cache_kvc(kv[:, :, :hd], torch.from_numpy(val).to(DEV).view(tdt), kd, vd, md,
+    # a key that is a view with a token stride of its own (the fork's qkv split), a contiguous value
+    kv = torch.from_numpy(np.stack([key, val], axis=1)).to(DEV).view(tdt)          # [T, 2, H, hd]
+    ops.reshape_and_cache_kvc(kv[:, 0], torch.from_numpy(val).to(DEV).view(tdt), kd, vd, md,
                               torch.from_numpy(slots).to(DEV), torch.from_numpy(bias).to(DEV), "auto", 1.0, 1.0)
     torch.cuda.synchronize()
     gk, gv = to_reference(kd.view(it).cpu().numpy(), vd.view(it).cpu().numpy())

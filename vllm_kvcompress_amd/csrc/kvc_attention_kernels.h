@@ -314,6 +314,13 @@ __device__ __forceinline__ HarvestCtx harvest_ctx(const AttnArgs& a, int seq, in
   }
   return h;
 }
+// a head with nothing cached returns before harvest_ctx: its (empty) list still says which context length it was made
+// with -- the schedule call compares seen_ctx with its own context_lens and would otherwise redo every step's call
+__device__ __forceinline__ void harvest_empty_head(const AttnArgs& a, int seq, int hk) {
+  if (a.hv.cnt == nullptr || a.fused_metrics == nullptr || !a.record) return;
+  const int i = a.hv.seq_slot[seq];
+  if (i >= 0) a.hv.seen_ctx[(i * a.hv.num_layers + a.hv.layer) * a.num_kv_heads + hk] = 0;
+}
 // a key inside the metric window with its new sum: listed if it is evictable and below the pivot.  Returns 1 if the slot
 // is masked or its key not finite -- the head's deficit, as the schedule's full collecting pass counts it
 __device__ __forceinline__ uint32_t harvest_key(const AttnArgs& a, const HarvestCtx& h, int64_t slot, float mn, int pos) {
@@ -422,6 +429,7 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
       const int q0e = qg * ATT_NQ, nqe = min(ATT_NQ, qpk - q0e);
       for (int idx = threadIdx.x; idx < nqe * HD; idx += 256)
         reinterpret_cast<T*>(a.out)[((int64_t)seq * a.num_heads + hk * qpk + q0e + idx / HD) * HD + idx % HD] = (T)0.0f;
+      if (threadIdx.x == 0 && qg == 0) harvest_empty_head(a, seq, hk);
     }
     return;
   }
@@ -686,6 +694,7 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
     const int q0e = qg * ATT_NQ, nqe = min(ATT_NQ, qpk - q0e);
     for (int idx = threadIdx.x; idx < nqe * HD; idx += 64 * NW)
       reinterpret_cast<T*>(a.out)[((int64_t)seq * a.num_heads + hk * qpk + q0e + idx / HD) * HD + idx % HD] = (T)0.0f;
+    if (threadIdx.x == 0 && qg == 0) harvest_empty_head(a, seq, hk);
     return;
   }
   const int q0 = qg * ATT_NQ;

@@ -109,7 +109,11 @@ __device__ __forceinline__ bool locate_tiles(const int32_t* __restrict__ wg_tile
   const uint32_t s2 = (lane < per && eb + lane < nwg) ? (uint32_t)wg_tiles[eb + lane] : 0u;
   const uint32_t inc2 = wave_inclusive_scan(s2);
   const unsigned long long m2 = __ballot(base + (int)inc2 > t_begin);
-  if (!m2) return false;                             // (a plan that does not belong to these counts)
+  // a plan that does not belong to these counts (the caller's contract, include/kvc_mi355x.h: both bindings make it
+  // impossible through version checks; a raw C-ABI caller vouches): dropping the wave's moves quietly would leave
+  // a cache that is neither the old nor the new one -- the launch faults instead (the next call on the stream
+  // reports the error)
+  if (!m2) __builtin_trap();
   const int l2 = __ffsll((long long)m2) - 1;
   base += __shfl((int)(inc2 - s2), l2, 64);
   const int gb0 = (eb + l2) * heads_per_wg, ge = min(G, gb0 + heads_per_wg);
@@ -125,6 +129,7 @@ __device__ __forceinline__ bool locate_tiles(const int32_t* __restrict__ wg_tile
     }
     base += __shfl((int)inc3, 63, 64);
   }
+  __builtin_trap();                                  // (the plan lists more tiles than the counts hold: see above)
   return false;
 }
 

@@ -658,7 +658,9 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     const int sparse = p.total_slots < (int64_t)p.num_blocks * p.block_size / 2 ? 1 : 0;
     const unsigned vgrid = (unsigned)fallback_grid();
     hipLaunchKernelGGL(fallback_general_kernel, dim3(p.fallback_grid > 0 ? (unsigned)p.fallback_grid : vgrid), dim3(256), 0, s,
-                       p, ws, sparse, z16, zv, 0, vgrid);
+                       p, ws, sparse, z16, zv, 0, vgrid,
+                       (p.harvest_buf != nullptr && (p.harvest & 2))
+                           ? reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(p.harvest_buf) + hv_layout(G, B).pivot) : nullptr);
     return check_launch("schedule_evictions");
   }
   // ---- general pipeline
@@ -756,7 +758,7 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     const int64_t zv = (int64_t)((l.zero_end - l.zero_begin) / 16);
     const unsigned vgrid = (unsigned)fallback_grid();
     hipLaunchKernelGGL(fallback_general_kernel, dim3(p.fallback_grid > 0 ? (unsigned)p.fallback_grid : vgrid), dim3(256), 0, s,
-                       p, ws, 0, z16, zv, 1, vgrid);
+                       p, ws, 0, z16, zv, 1, vgrid, (uint32_t*)nullptr);
     return check_launch("schedule_evictions");
   }
   if (p.uniform_evict) {

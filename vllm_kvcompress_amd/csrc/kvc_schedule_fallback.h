@@ -92,9 +92,15 @@ constexpr int FB_MAX_COUPLED = 256;                  // sequences whose batch > 
 // vgrid: virtual workgroups of the streaming phases (the grid the host would like to be resident)
 __global__ __launch_bounds__(256, 2) void fallback_general_kernel(kvc_schedule_params p, SchedWs ws, int sparse,
                                                                uint4* zero16, int64_t zero_vecs, int have_keys,
-                                                               unsigned vgrid) {
+                                                               unsigned vgrid, uint32_t* hv_pivot) {
   const uint32_t flag0 = __hip_atomic_load(ws.fallback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (flag0 == 0u) return;                           // flag down: this launch is all the fallback costs
+  // The pivots this call left for the next one were computed from lists that just turned out not to be trustworthy
+  // (a workgroup of topk_fused_kernel reads the flag once, before its emission: it may have written next pivots while
+  // another one was raising it).  The host drops them when it sees the flag, up to a ring of calls later; until then
+  // the next call would start from them.  Pivot 0 lists nothing: that call falls short, is redone here, and stays exact.
+  if (hv_pivot != nullptr && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < p.num_seqs; i += 256) hv_pivot[i] = 0u;
   __shared__ __attribute__((aligned(16))) uint8_t prep_s[FB_MAX_COUPLED * 24];
   __shared__ uint32_t word_s;
   const bool coupled = p.mode == 0 && p.num_seqs > 1;

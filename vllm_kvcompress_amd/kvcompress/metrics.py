@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import time
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple, Union
 
@@ -78,6 +79,17 @@ class AttentionHarvest:
                 or stream != self.stream or int(query.shape[0]) != int(self.seq_slot.numel())):
             raise RuntimeError("paged_attention_kvc_fused_metrics: this call does not belong to the harvest it was given "
                                "(KV heads / block size / layer / stream / number of sequences differ from begin_attention_harvest's)")
+
+
+@dataclass
+class SortedMetricOutputs:
+    """reference metrics.py:83-90 (what the dead V1 front end ``sort_seq_metrics`` returned)"""
+    sorted_indices: torch.Tensor
+    seq_block_offsets: torch.Tensor
+    layer_by_block: torch.Tensor
+    head_by_block: torch.Tensor
+    logical_block_num_by_block: torch.Tensor
+    token_positions: torch.Tensor
 
 
 class CompressionMetrics:
@@ -187,6 +199,7 @@ class CompressionMetrics:
         self._eli_buf = None          # (buffer, dirty map, block size, storage use count when only we hold it, stream, version)
         self._small_cache = {}
         self._summary_pin = None      # page-locked words the batch summary kernel writes (N, evicted_blocks_per_seq)
+        self._summary_ticket = 0      # ... and the ticket of the last launch (the word behind the counts)
         self._summary_np = None
         # harvest-ahead (include/kvc_mi355x.h, ABI version 5): with compression every decode
         # step the metric store is swept twice per step -- by aggregate_decode and, a moment later, by the
@@ -219,6 +232,14 @@ class CompressionMetrics:
         # the store per decode step in the UNCHANGED fork flow.  Same results either way.
         self.speculative_harvest = (os.environ.get("KVC_SPECULATIVE_HARVEST", "1") not in ("", "0")
                                     and os.environ.get("KVC_HARVEST_AHEAD", "") != "0")
+        # What the lists cost in HBM: kvc_harvest_buffer_bytes(G, B) ~ 2 KiB per head of the compression batch (256 u64
+        # entries + counters; 134 MB at 256 sequences x 32 layers x 8 KV heads).  The buffer is RESERVED when the store
+        # is (init_kv_metadata: the engine's start-up, where its memory profiling sees it), sized for the heads the store
+        # can hold and capped by this budget (KVC_HARVEST_BUFFER_MAX_MB, default 192); a batch whose lists would not fit
+        # the budget keeps the pivots only -- its schedule call makes its lists in its own collecting pass, as without
+        # speculative harvest.  Nothing is allocated while serving unless a batch outgrows a reservation smaller than
+        # the budget (a store initialised with few blocks).
+        self.harvest_buffer_max_bytes = int(float(os.environ.get("KVC_HARVEST_BUFFER_MAX_MB", "192")) * (1 << 20))
         self.last_harvest_kind = ""        # "aggregation pass" | "aggregation pass, ahead of the call" | "attention's epilogue"
         # (compression_interval > 1: several aggregate_decode() calls lie between two schedule calls.  The prediction is made
         # by the LAST of them -- the gap seen last time says which one that is -- for positions + that many tokens)
@@ -290,12 +311,69 @@ class CompressionMetrics:
         self.logical_block_num_by_block = torch.zeros((num_blocks,), dtype=torch.int, device=dev)
         self.token_positions = torch.zeros((num_blocks, self.block_size), dtype=torch.int,
                                            device=dev)
+        self._reserve_harvest_buffer()
         self.validate_metadata()
+
+    def _wants_lists(self) -> bool:
+        """lists are wanted once somebody harvests explicitly -- or from the start when aggregate_decode() may harvest
+        ahead of the call by itself"""
+        return bool(self.harvest_ahead) or (self.harvest_ahead is None and self.speculative_harvest
+                                            and self.record_decoding_metrics and not self.random)
+
+    def _reserve_harvest_buffer(self) -> None:
+        """The harvest buffer (pivots + per-head candidate lists) next to the store, at start-up: sized for as many
+        heads as the store can hold blocks (a head of a compression batch owns at least one), capped by
+        ``harvest_buffer_max_bytes``.  See ``__init__``."""
+        if self.num_blocks is None or not (self._wants_lists() or self.pivot_memory):
+            return
+        lib = _lib.load()
+        heads_per_seq = self.num_layers * self.num_kv_heads
+        B = max(1, min(self.num_blocks // heads_per_seq, 6500))
+        if self._wants_lists():
+            G = max(heads_per_seq, min(self.num_blocks, B * heads_per_seq))
+            size = min(int(lib.kvc_harvest_buffer_bytes(G, B)), max(self.harvest_buffer_max_bytes, 0))
+        else:
+            size = 0
+        size = max(size, int(lib.kvc_harvest_pivot_bytes(B)))
+        if self._hv_buf is None or self._hv_buf.numel() < size:
+            self._hv_buf = torch.zeros((size,), dtype=torch.uint8, device=self.device)
+            self._hv = self._hv_lists = None
 
     def validate_metadata(self) -> None:
         """reference metrics.py:372-376"""
         allocated_mask = self.seq_index_by_block >= 0
         assert (self.head_index_by_block[allocated_mask] < self.num_kv_heads).all()
+
+    def validate_metadata_even_layer_evict(self) -> None:
+        """reference metrics.py:380-389 (a debug check, commented out at its only call site :372): with
+        ``even_layer_evict`` every layer holds the same number of allocated blocks.  The reference samples ONE random
+        layer per call; here every layer is checked (deterministic; fails whenever the reference's could)."""
+        if self.even_layer_evict:
+            allocated_mask = self.seq_index_by_block >= 0
+            per_layer = torch.bincount(self.layer_index_by_block[allocated_mask].long(), minlength=self.num_layers)
+            per_layer_count = int(allocated_mask.sum().item()) / self.num_layers
+            for check_idx in range(self.num_layers):
+                check_idx_count = int(per_layer[check_idx].item())
+                assert check_idx_count == per_layer_count, (
+                    f'{check_idx_count=}, {per_layer_count=} (are you using control_layers?)')
+
+    def sort_seq_metrics(self, seq_indices: List[int], seq_positions: List[int], checkpoint: bool = True):
+        """reference metrics.py:850-966: the global-sort front end of the V1 scheduler (``schedule_cache_evictions``),
+        which is dead code in the fork (vllm/kvcompress/scheduler.py:285 ``if False:``).  The live path is
+        ``schedule_evictions``; like the V1 ops this raises with a pointer to it instead of an AttributeError."""
+        from .._custom_ops import V1_DEAD_MESSAGE
+        raise NotImplementedError("sort_seq_metrics feeds the V1 scheduler: " + V1_DEAD_MESSAGE)
+
+    def checkpoint(self, sink=None) -> None:
+        """reference metrics.py:968-975: hands the store and its metadata to the fork's debugging CHECKPOINTER
+        (vllm/debug.py, disabled unless a developer switches it on: a no-op in every run of the fork's own scripts).
+        ``sink(name, tensor)`` receives the same six (name, tensor) pairs; without one this is the disabled
+        checkpointer's no-op."""
+        if sink is None:
+            return
+        for name in ("metrics", "seq_index_by_block", "layer_index_by_block", "head_index_by_block",
+                     "logical_block_num_by_block", "token_positions"):
+            sink("metrics__" + name, getattr(self, name))
 
     def clear_temp_metrics(self) -> None:
         """reference metrics.py:337-342.  A no-op when the last aggregate_decode already
@@ -354,15 +432,18 @@ class CompressionMetrics:
                                                  sm.data_ptr(), seq_len, self.num_kv_heads, qpk,
                                                  _stream(self.metrics)))
 
-    def aggregate_decode(self, fuse_clear: bool = True) -> None:
+    def aggregate_decode(self, fuse_clear: bool = True, predict: bool = True) -> None:
         """reference metrics.py:429-439: metrics += sum_q temp^2 (L2) or sum_q temp (L1).
         With ``fuse_clear`` the same pass also zeroes temp_metrics, which makes the next
-        ``clear_temp_metrics()`` free."""
+        ``clear_temp_metrics()`` free.  ``predict=False`` (not in the reference's signature): the
+        plain pass only -- no lists for the call the next iteration will probably make (a step that is being
+        aborted, CompressionScheduler.schedule_compression)."""
         if self.random or not self.record_decoding_metrics:
             return
         self._hv_lists = None
         self._aggs_since_schedule += 1
-        if self._aggs_since_schedule == self._last_gap and self._speculative_harvest(fuse_clear, self._last_gap):
+        if (predict and self._aggs_since_schedule == self._last_gap
+                and self._speculative_harvest(fuse_clear, self._last_gap)):
             return
         self._plain_aggregate_decode(fuse_clear)
 
@@ -733,19 +814,32 @@ class CompressionMetrics:
         The reference method waits for the device for the same reason, many times over (metrics.py:465-489, 709-729)."""
         lib = _lib.load()
         B = 0 if k_per_seq is None else int(k_per_seq.numel())
-        if self._summary_pin is None or self._summary_pin.numel() < 1 + B:
+        if self._summary_pin is None or self._summary_pin.numel() < 2 + B:
             with torch.inference_mode(False):
-                self._summary_pin = torch.zeros((max(1 + B, 320),), dtype=torch.int64).pin_memory()
+                self._summary_pin = torch.zeros((max(2 + B, 320),), dtype=torch.int64).pin_memory()
             self._summary_np = self._summary_pin.numpy()
+        # the kernel stores the numbers and then a ticket (system-scope release) into the page-locked buffer: the host
+        # polls the ticket word instead of waiting for the stream's end-of-kernel signal (ABI version 7)
+        self._summary_ticket += 1
         with torch.cuda.device(self.device):
-            _lib.check(lib.kvc_schedule_batch_summary(
+            _lib.check(lib.kvc_schedule_batch_summary_ticket(
                 context_lens.data_ptr(), int(context_lens.numel()), int(self.block_size),
-                None if k_per_seq is None else k_per_seq.data_ptr(), B, self._summary_pin.data_ptr(), 1, 0, None, 0,
-                stream))
+                None if k_per_seq is None else k_per_seq.data_ptr(), B, self._summary_pin.data_ptr(),
+                self._summary_ticket, stream))
         return B
 
     def _batch_summary_read(self, B: int, stream: int):
-        _lib.check(_lib.load().kvc_schedule_batch_summary_wait(stream))
+        word, ticket = self._summary_np[1 + B:2 + B], self._summary_ticket
+        deadline = None
+        spins = 0
+        while int(word[0]) != ticket:
+            spins += 1
+            if spins & 0x3FFF == 0:             # (a launch that failed never writes the ticket: ask the runtime now and then)
+                if deadline is None:
+                    deadline = time.monotonic() + 30.0
+                _lib.check(_lib.load().kvc_schedule_batch_summary_wait(stream))
+                if int(word[0]) != ticket and time.monotonic() > deadline:
+                    raise RuntimeError("schedule_evictions: the batch summary never arrived")
         return int(self._summary_np[0]), self._summary_np[1:1 + B].copy()
 
     def schedule_evictions(
@@ -880,14 +974,18 @@ class CompressionMetrics:
         p.max_evicted_blocks_hint = -1 if k_list is None else int(k_list.max())
         # (lists are wanted once somebody harvests explicitly -- or from the start when aggregate_decode() may harvest
         # ahead of the call by itself)
-        want_lists = bool(self.harvest_ahead) or (self.harvest_ahead is None and self.speculative_harvest
-                                                  and self.record_decoding_metrics and not self.random)
+        want_lists = self._wants_lists()
         if (not capturing and p.max_evicted_blocks_hint >= 0
                 and ((want_lists and lib.kvc_harvest_eligible(ctypes.byref(p), self.num_queries_per_kv))
                      or (self.pivot_memory and lib.kvc_pivot_memory_eligible(ctypes.byref(p))))):
             # the buffer: pivots only, or pivots + lists once somebody harvests
             full = want_lists
             need = int(lib.kvc_harvest_buffer_bytes(B * L * H, B) if full else lib.kvc_harvest_pivot_bytes(B))
+            have = 0 if self._hv_buf is None else self._hv_buf.numel()
+            if full and need > max(have, self.harvest_buffer_max_bytes):
+                # lists for this batch would not fit the reservation or the budget (__init__): pivots only, the call
+                # makes its lists in its own collecting pass
+                full, need = False, int(lib.kvc_harvest_pivot_bytes(B))
             if self._hv_buf is None or self._hv_buf.numel() < need:      # (kept when the batch shrinks: offsets are the call's)
                 self._hv_buf = torch.zeros((need,), dtype=torch.uint8, device=dev)
                 self._hv = hl = None

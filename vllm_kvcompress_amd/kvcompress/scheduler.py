@@ -152,16 +152,27 @@ class CompressionScheduler:
         self._aggregation_due = bool(aggregate_decode)
         try:
             self.iteration_count += 1
+            out = None
             if force or (self.iteration_count >= self.compression_interval
                          or (self.new_token_limit > -1 and self.new_tokens > self.new_token_limit)):
                 self.iteration_count = 0
                 self.new_tokens = 0
-                return self._schedule_compression(requests, block_tables, context_lens, free_mask, aggregate_decode)
-            return None
-        finally:
+                out = self._schedule_compression(requests, block_tables, context_lens, free_mask, aggregate_decode)
+        except BaseException as first:
+            # an aborted step: the PLAIN pass (no prediction for a next call, no lists) so that the step's attention is
+            # in the store and temp_metrics is cleared; a second failure on the way out (a device fault the poll
+            # reports, a launch error) is chained to the first, never put in its place
             if self._aggregation_due:
                 self._aggregation_due = False
-                self.compression_metrics.aggregate_decode()
+                try:
+                    self.compression_metrics.aggregate_decode(predict=False)
+                except Exception as second:
+                    raise first from second
+            raise
+        if self._aggregation_due:                       # nothing was compressed this iteration: the normal way out
+            self._aggregation_due = False
+            self.compression_metrics.aggregate_decode()
+        return out
 
     # ---- reference scheduler.py:184-560 ---------------------------------------------------
     def _schedule_compression(self, requests, block_tables, context_lens, free_mask, aggregate_decode=False):
