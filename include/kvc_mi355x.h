@@ -624,6 +624,30 @@ int kvc_append_slots(int32_t* context_lens, int32_t* block_tables, uint8_t* free
                      int32_t write_token_position, void* workspace, size_t workspace_bytes,
                      kvc_stream_t stream);
 
+/* F2, the prefill side (ABI version 7): a new sequence's FIRST allocation
+ * replaces BlockSpaceManagerKVC._add_sequence and what it calls
+ *   (vllm/kvcompress/block_manager.py:196-222 -> :103-110 ParallelBlockAllocator.allocate,
+ *    block.py:414-446 get_allocated_block_metadata, vllm/kvcompress/metrics.py:344-361 insert_metadata)
+ * and BlockStateView.get_prefill_slot_mapping (block.py:275-303).
+ * cnt = ceil(seq_len / block_size) blocks for every (layer, head): the L * H * cnt lowest-numbered free blocks
+ * (free_mask, cleared for them), block r of that list to (l, h, j) = (r / (H cnt), r / cnt % H, r % cnt);
+ * context_lens[l, seq_slot, h] = seq_len; block_tables[l, seq_slot, h, j]; the blocks' metadata rows
+ * (sequence = seq_slot, layer, head, logical block j) and position rows j * bs + arange(bs); slot_mapping
+ * (may be NULL) [L, seq_len, H] int64 = block[l, h, t / bs] * bs + t % bs -- what reshape_and_cache_kvc takes
+ * for layer l.  status[0] = blocks needed, status[1] = free blocks before the call, or -1 when cnt exceeds
+ * max_num_blocks_per_seq; when status[1] < status[0] NOTHING has been modified (the reference raises
+ * "Out of memory!" before touching anything, block_manager.py:104-106). */
+size_t kvc_add_sequence_workspace_bytes(int32_t num_layers, int32_t num_kv_heads, int32_t seq_len,
+                                        int32_t block_size, int64_t num_blocks);
+int kvc_add_sequence(int32_t* context_lens, int32_t* block_tables, uint8_t* free_mask,
+                     int32_t* seq_index_by_block, int32_t* layer_index_by_block,
+                     int32_t* head_index_by_block, int32_t* logical_block_num_by_block,
+                     int32_t* token_positions, int64_t* slot_mapping, int32_t* status,
+                     int32_t num_layers, int32_t max_num_seqs, int32_t num_kv_heads,
+                     int32_t max_num_blocks_per_seq, int64_t num_blocks, int32_t block_size,
+                     int32_t seq_slot, int32_t seq_len, void* workspace, size_t workspace_bytes,
+                     kvc_stream_t stream);
+
 /* ---------------------------------------------------------------------------------
  * F3  single-query paged attention with KV-metric output (decode step)
  * replaces torch.ops._C.kvcompress_paged_attention_v1 / _v2

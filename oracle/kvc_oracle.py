@@ -640,6 +640,48 @@ def append_slots(block_tables, context_lens, seq_indices, last_token_position, f
     return n
 
 
+def add_sequence(block_tables, context_lens, seq_slot, seq_len, free_mask, seq_index_by_block,
+                 layer_index_by_block, head_index_by_block, logical_block_num_by_block, token_positions,
+                 block_size):
+    """A prefill sequence's first allocation, in place on every argument; returns its prefill slot mapping
+    ``[L, seq_len, H]`` int64.
+
+    BlockSpaceManagerKVC._add_sequence                vllm/kvcompress/block_manager.py:196-222
+    ParallelBlockAllocator.allocate                   vllm/kvcompress/block_manager.py:103-110
+    BlockStateView.get_allocated_block_metadata       vllm/kvcompress/block.py:414-446
+    CompressionMetrics.insert_metadata                vllm/kvcompress/metrics.py:344-361
+    BlockStateView.get_prefill_slot_mapping           vllm/kvcompress/block.py:275-303
+    ``ceil(seq_len / bs)`` blocks for every (layer, head): the lowest-numbered free blocks, reshaped
+    ``[L, H, nblk]``; every head's context length becomes ``seq_len``; the blocks' metadata rows are written and
+    their position rows are ``logical block * bs + arange(bs)`` (positions == logical indices: nothing was
+    compressed yet); token t of (layer, head) goes to slot ``block[l, h, t // bs] * bs + t % bs``."""
+    bs = block_size
+    L, S, H, M = block_tables.shape
+    cnt = (int(seq_len) + bs - 1) // bs
+    total = L * H * cnt
+    free = np.nonzero(free_mask)[0]
+    if free.shape[0] < total:
+        raise ValueError(f"Out of memory! Requested {total} out of {int(free.shape[0])} available blocks.")
+    assert cnt <= M, "block table too short for the sequence"
+    blocks = free[:total].reshape(L, H, cnt)
+    free_mask[free[:total]] = False
+    context_lens[:, seq_slot, :] = seq_len
+    block_tables[:, seq_slot, :, :cnt] = blocks
+    ar = np.arange(bs, dtype=token_positions.dtype)
+    for l in range(L):
+        for h in range(H):
+            for j in range(cnt):
+                blk = int(blocks[l, h, j])
+                seq_index_by_block[blk] = seq_slot
+                layer_index_by_block[blk] = l
+                head_index_by_block[blk] = h
+                logical_block_num_by_block[blk] = j
+                token_positions[blk] = j * bs + ar
+    t = np.arange(int(seq_len))
+    slot_mapping = blocks.transpose(0, 2, 1)[:, t // bs, :].astype(np.int64) * bs + (t % bs)[None, :, None]
+    return slot_mapping
+
+
 # --------------------------------------------------------------------------------------
 # F3  single-query paged attention with per-key metric output
 #     csrc/attention/kvcompress_attention_kernels.cu:97-455 (main), :532-651 (v2 reduce);

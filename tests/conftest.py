@@ -16,7 +16,7 @@ def pytest_configure(config):
 
 def golden_cases():
     return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR)
-                  if f.endswith(".npz") and not f.startswith(("blockstate_", "append_", "agg_", "policy_", "attn_")))
+                  if f.endswith(".npz") and not f.startswith(("blockstate_", "append_", "prefill_alloc_", "agg_", "policy_", "attn_")))
 
 
 @pytest.fixture(scope="session")

@@ -115,7 +115,7 @@ def test_reshape_and_cache_fp8_slot_major(kind, src, slot_major):
     wk = np.zeros((NB, hd // 16, bs, 16), np.uint8)
     wv = np.zeros((NB, hd, bs), np.uint8)
     wm = np.zeros((NB, bs), np.float32)
-    orc.reshape_and_cache_kvc_fp8(key.float().numpy(), val.float().numpy(), wk, wv, wm, slots, bias, kind, 0.5, 2.0)
+    orc.reshape_and_cache_kvc_fp8(key.float().numpy(), val.float().numpy(), wk, wv, wm, slots, bias, kind[4:], 0.5, 2.0)
     kd = torch.zeros((NB, hd // 16, bs, 16), dtype=torch.uint8, device=DEV)
     vd = torch.zeros((NB, hd, bs), dtype=torch.uint8, device=DEV)
     md = torch.zeros((NB, bs), dtype=torch.float32, device=DEV)

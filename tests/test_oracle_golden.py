@@ -396,3 +396,31 @@ def test_append_slots_out_of_memory_like_the_reference():
                          g["last_token_position"], fm, g["seq_index_by_block"].copy(),
                          g["layer_index_by_block"].copy(), g["head_index_by_block"].copy(),
                          g["logical_block_num_by_block"].copy(), g["token_positions"].copy(), int(g["block_size"]))
+
+
+PREFILL_ALLOC_CASES = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.startswith("prefill_alloc_"))
+
+
+@pytest.mark.parametrize("name", PREFILL_ALLOC_CASES)
+def test_add_sequence_matches_reference(name):
+    """fixtures produced by the reference's own _add_sequence + ParallelBlockAllocator + BlockState +
+    get_allocated_block_metadata + insert_metadata + get_prefill_slot_mapping (oracle/gen_golden_prefill_alloc.py)"""
+    g = load_golden(name)
+    w = {k: g[k].copy() for k, _ in APPEND_KEYS}
+    sm = orc.add_sequence(w["block_tables"], w["context_lens"], int(g["seq_slot"]), int(g["seq_len"]), w["free_mask"],
+                          w["seq_index_by_block"], w["layer_index_by_block"], w["head_index_by_block"],
+                          w["logical_block_num_by_block"], w["token_positions"], int(g["block_size"]))
+    for k, r in APPEND_KEYS:
+        np.testing.assert_array_equal(w[k], g[r], err_msg=k)
+    np.testing.assert_array_equal(sm, g["ref_slot_mapping"])
+    assert sm.dtype == np.int64 and int(w["free_mask"].sum()) == int(g["ref_free_count"])
+
+
+def test_add_sequence_out_of_memory_like_the_reference():
+    g = load_golden(PREFILL_ALLOC_CASES[0])
+    fm = g["free_mask"].copy()
+    fm[np.nonzero(fm)[0][3:]] = False                 # three free blocks left
+    with pytest.raises(ValueError, match="Out of memory"):
+        orc.add_sequence(g["block_tables"].copy(), g["context_lens"].copy(), int(g["seq_slot"]), int(g["seq_len"]), fm,
+                         g["seq_index_by_block"].copy(), g["layer_index_by_block"].copy(), g["head_index_by_block"].copy(),
+                         g["logical_block_num_by_block"].copy(), g["token_positions"].copy(), int(g["block_size"]))

@@ -19,7 +19,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--json", default=None)
     ap.add_argument("--only", default=None, help="S,ctx: run a single configuration")
+    ap.add_argument("--block-layout", default=None, choices=["reference", "slot_major"],
+                    help="in-block cache layout (default: KVC_BLOCK_LAYOUT or reference); the cache holds random bits, "
+                         "so the same buffers serve either layout")
     args = ap.parse_args()
+    if args.block_layout:
+        import vllm_kvcompress_amd
+        vllm_kvcompress_amd.set_block_layout(args.block_layout)
     res = []
     cfgs = [(256, 4097), (64, 4097), (16, 32769), (1, 32769), (256, 512)]
     if args.only:

@@ -197,6 +197,10 @@ SYMBOLS = {
     "kvc_append_slots": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                    c_int32, c_int32, c_int64, c_int32, c_int32, c_void_p, c_size_t, c_void_p]),
+    "kvc_add_sequence_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32, c_int64]),
+    "kvc_add_sequence": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int64, c_int32,
+                                   c_int32, c_int32, c_void_p, c_size_t, c_void_p]),
     "kvc_prefill_metric_fused_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "kvc_prefill_metric_fused": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                            c_int32, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64,

@@ -245,6 +245,49 @@ __global__ __launch_bounds__(256) void append_apply_kernel(
   context_lens[lsh] = ctx + 1;
 }
 
+// ------------------------------------------------------------------------- prefill side
+// A new sequence's first allocation:
+//   BlockSpaceManagerKVC._add_sequence                vllm/kvcompress/block_manager.py:196-222
+//   ParallelBlockAllocator.allocate                   vllm/kvcompress/block_manager.py:103-110
+//   BlockStateView.get_allocated_block_metadata       vllm/kvcompress/block.py:414-446
+//   CompressionMetrics.insert_metadata                vllm/kvcompress/metrics.py:344-361
+//   BlockStateView.get_prefill_slot_mapping           vllm/kvcompress/block.py:275-303
+// ceil(T / bs) blocks for every (layer, head): the L * H * cnt lowest-numbered free blocks (the tiled rank of the
+// append side), block r to (l, h, j) = (r / (H cnt), r / cnt % H, r % cnt); context lengths, table rows, metadata
+// rows, position rows (j * bs + o: positions are logical indices before any compression) and the prefill slot
+// mapping [L, T, H] in one pass.
+// the scan's first element holds the request (n_heads = 0 for free_tile_scan / free_pick): need, and whether the table fits
+__global__ void prefill_request_kernel(AppendWs ws, int need, int fits) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { ws.prefix[0] = need; *ws.ok = fits; }
+}
+
+// one thread per allocated block
+__global__ __launch_bounds__(256) void prefill_apply_kernel(
+    AppendWs ws, int32_t* __restrict__ context_lens, int32_t* __restrict__ block_tables,
+    int32_t* __restrict__ seq_index_by_block, int32_t* __restrict__ layer_index_by_block,
+    int32_t* __restrict__ head_index_by_block, int32_t* __restrict__ logical_block_num_by_block,
+    int32_t* __restrict__ token_positions, int64_t* __restrict__ slot_mapping, int L, int S, int H, int M, int bs,
+    int slot, int seq_len, int cnt) {
+  if (*ws.ok == 0) return;                           // nothing is modified when the sequence does not fit
+  const int need = L * H * cnt;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= need) return;
+  const int l = r / (H * cnt), h = (r / cnt) % H, j = r % cnt;
+  const int blk = ws.alloc[r];
+  const int64_t lsh = ((int64_t)l * S + slot) * H + h;
+  block_tables[lsh * M + j] = blk;
+  if (j == 0) context_lens[lsh] = seq_len;
+  seq_index_by_block[blk] = slot;                    // insert_metadata
+  layer_index_by_block[blk] = l;
+  head_index_by_block[blk] = h;
+  logical_block_num_by_block[blk] = j;
+  for (int o = 0; o < bs; ++o) {
+    const int t = j * bs + o;
+    token_positions[(int64_t)blk * bs + o] = t;
+    if (slot_mapping != nullptr && t < seq_len) slot_mapping[((int64_t)l * seq_len + t) * H + h] = (int64_t)blk * bs + o;
+  }
+}
+
 }  // namespace kvc
 
 extern "C" size_t kvc_free_compressed_blocks_workspace_bytes(int32_t num_layers, int32_t batch,
@@ -320,4 +363,50 @@ extern "C" int kvc_append_slots(int32_t* context_lens, int32_t* block_tables, ui
                      token_positions, seq_slots, last_token_position, num_layers, batch, max_num_seqs,
                      num_kv_heads, max_num_blocks_per_seq, block_size, write_token_position);
   return check_launch("append_slots");
+}
+
+extern "C" size_t kvc_add_sequence_workspace_bytes(int32_t num_layers, int32_t num_kv_heads, int32_t seq_len,
+                                                   int32_t block_size, int64_t num_blocks) {
+  if (block_size < 1 || seq_len < 0) return 0;
+  const size_t need = (size_t)num_layers * num_kv_heads * (size_t)((seq_len + block_size - 1) / block_size);
+  return (1 + (append_tiles(num_blocks) + 1) + need + 4) * sizeof(int32_t);
+}
+
+extern "C" int kvc_add_sequence(int32_t* context_lens, int32_t* block_tables, uint8_t* free_mask,
+                                int32_t* seq_index_by_block, int32_t* layer_index_by_block,
+                                int32_t* head_index_by_block, int32_t* logical_block_num_by_block,
+                                int32_t* token_positions, int64_t* slot_mapping, int32_t* status,
+                                int32_t num_layers, int32_t max_num_seqs, int32_t num_kv_heads,
+                                int32_t max_num_blocks_per_seq, int64_t num_blocks, int32_t block_size,
+                                int32_t seq_slot, int32_t seq_len, void* workspace, size_t workspace_bytes,
+                                kvc_stream_t stream) {
+  using namespace kvc;
+  if (block_size < 1) return fail_invalid("Unsupported block size: " + std::to_string(block_size));
+  if (num_layers < 1 || num_kv_heads < 1 || seq_len < 0 || seq_slot < 0 || seq_slot >= max_num_seqs)
+    return fail_invalid("add_sequence: bad arguments");
+  if (num_blocks < 1) return fail_invalid("add_sequence: no blocks");
+  if (workspace_bytes < kvc_add_sequence_workspace_bytes(num_layers, num_kv_heads, seq_len, block_size, num_blocks))
+    return fail_invalid("add_sequence: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int cnt = (seq_len + block_size - 1) / block_size;
+  const int64_t need64 = (int64_t)num_layers * num_kv_heads * cnt;
+  if (need64 > 0x7FFFFFFF) return fail_invalid("add_sequence: too many blocks");
+  const int need = (int)need64;
+  const int tiles = (int)append_tiles(num_blocks);
+  AppendWs ws;
+  ws.prefix = reinterpret_cast<int32_t*>(workspace);
+  ws.tile_off = ws.prefix + 1;
+  ws.alloc = ws.tile_off + tiles + 1;
+  ws.ok = ws.alloc + need;
+  hipLaunchKernelGGL(prefill_request_kernel, dim3(1), dim3(64), 0, s, ws, need, cnt <= max_num_blocks_per_seq ? 1 : 0);
+  hipLaunchKernelGGL(free_tile_count_kernel, dim3(tiles), dim3(256), 0, s, ws, free_mask, num_blocks);
+  hipLaunchKernelGGL(free_tile_scan_kernel, dim3(1), dim3(1024), 0, s, ws, tiles, 0, status);
+  hipLaunchKernelGGL(free_pick_kernel, dim3(tiles), dim3(256), 0, s, ws, free_mask, num_blocks, 0);
+  // (a sequence of no tokens allocates nothing but still takes its batch slot: context lengths 0)
+  if (need > 0)
+    hipLaunchKernelGGL(prefill_apply_kernel, dim3((need + 255) / 256), dim3(256), 0, s, ws, context_lens, block_tables,
+                       seq_index_by_block, layer_index_by_block, head_index_by_block, logical_block_num_by_block,
+                       token_positions, slot_mapping, num_layers, max_num_seqs, num_kv_heads, max_num_blocks_per_seq,
+                       block_size, seq_slot, seq_len, cnt);
+  return check_launch("add_sequence");
 }

@@ -65,7 +65,8 @@ def run(S, ctx_len, Hq=32, Hkv=8, hd=128, bs=16, iters=20, record=True, dtype="f
     tokens = S * Hkv * ctx_len
     # fused: position read + metrics read-modify-write instead of the qpk-wide store
     alg = tokens * (2 * hd * kc.element_size() + ((4 + 8) if fused else (4 * record + 4 * qpk * record)))
-    return {"num_seqs": S, "context_len": ctx_len, "num_heads": Hq, "num_kv_heads": Hkv,
+    from vllm_kvcompress_amd import _lib
+    return {"block_layout": _lib.block_layout(), "num_seqs": S, "context_len": ctx_len, "num_heads": Hq, "num_kv_heads": Hkv,
             "head_size": hd, "block_size": bs, "dtype": dtype, "kv_cache_dtype": kv_dtype, "k_scale": k_scale, "record_kv_metrics": record, "fused_metric_aggregation": fused,
             "ms_per_layer_step": ms, "algorithmic_bytes": alg, "GBps": alg / ms / 1e6,
             "frac_of_8TBps": alg / ms / 1e6 / 8000.0, "cached_tokens_per_s": tokens / ms * 1e3}

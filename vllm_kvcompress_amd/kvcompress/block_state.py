@@ -117,3 +117,54 @@ def append_slots(
     if need > free:
         raise ValueError(f"Out of memory! Requested {need} out of {free} available blocks.")
     return need
+
+
+def add_sequence(
+    block_tables: torch.Tensor,          # [L, max_num_seqs, H, M] i32   (BlockState.block_tables, updated)
+    context_lens: torch.Tensor,          # [L, max_num_seqs, H]    i32   (updated)
+    seq_slot: int,                       # the batch slot the sequence takes
+    seq_len: int,                        # its prompt length in tokens
+    free_mask: torch.Tensor,             # [NB] bool (ParallelBlockAllocator.free_mask, updated)
+    kv_metrics,                          # CompressionMetrics: metadata rows + token_positions (updated)
+    block_size: int,
+    slot_mapping: bool = True,
+):
+    """``BlockSpaceManagerKVC._add_sequence`` (vllm/kvcompress/block_manager.py:196-222: allocate ``ceil(T / bs)``
+    blocks per (layer, head) from the low end of the free list, wire them into the tables, set the context lengths,
+    ``get_allocated_block_metadata`` + ``CompressionMetrics.insert_metadata``) and, in the same pass,
+    ``BlockStateView.get_prefill_slot_mapping`` (block.py:275-303) on device.  Returns ``(blocks allocated,
+    slot_mapping [L, T, H] int64 or None)`` -- ``slot_mapping[l]`` is what ``reshape_and_cache_kvc`` takes for layer
+    ``l``.  One host sync (the reference's allocator keeps its free count on the host); raises
+    ``ValueError("Out of memory! ...")`` like ``ParallelBlockAllocator.allocate`` -- nothing has been modified then."""
+    lib = _lib.load()
+    cm = kv_metrics
+    for n, t in (("block_tables", block_tables), ("context_lens", context_lens),
+                 ("seq_index_by_block", cm.seq_index_by_block), ("token_positions", cm.token_positions)):
+        if not t.is_cuda or t.dtype != torch.int32 or not t.is_contiguous():
+            raise RuntimeError(f"add_sequence: {n} must be a contiguous int32 HIP tensor")
+    if free_mask.dtype not in (torch.bool, torch.uint8) or not free_mask.is_cuda or not free_mask.is_contiguous():
+        raise RuntimeError("add_sequence: free_mask must be a contiguous bool/uint8 HIP tensor")
+    L, S, H, M = block_tables.shape
+    dev = block_tables.device
+    NB, T, bs = int(free_mask.numel()), int(seq_len), int(block_size)
+    status = torch.zeros((2,), dtype=torch.int32, device=dev)
+    sm = torch.empty((L, T, H), dtype=torch.int64, device=dev) if slot_mapping else None
+    ws = workspace(dev, int(lib.kvc_add_sequence_workspace_bytes(L, H, T, bs, NB)), "add_sequence")
+    for t in (cm.seq_index_by_block, cm.layer_index_by_block, cm.head_index_by_block, cm.logical_block_num_by_block,
+              cm.token_positions, context_lens, block_tables):
+        torch.autograd.graph.increment_version(t)
+    cm._hv_lists = None                   # (insert_metadata: lists made before it do not know the new blocks)
+    with torch.cuda.device(dev):
+        _lib.check(lib.kvc_add_sequence(
+            context_lens.data_ptr(), block_tables.data_ptr(), free_mask.data_ptr(),
+            cm.seq_index_by_block.data_ptr(), cm.layer_index_by_block.data_ptr(), cm.head_index_by_block.data_ptr(),
+            cm.logical_block_num_by_block.data_ptr(), cm.token_positions.data_ptr(),
+            None if sm is None else sm.data_ptr(), status.data_ptr(), L, S, H, M, NB, bs, int(seq_slot), T,
+            ws.data_ptr(), ws.numel(), _stream(block_tables)))
+    need, free = (int(x) for x in status.tolist())
+    if free < 0:
+        raise RuntimeError("add_sequence: the sequence needs more blocks per head than the block table holds "
+                           "(max_num_blocks_per_head)")
+    if need > free:
+        raise ValueError(f"Out of memory! Requested {need} out of {free} available blocks.")
+    return need, sm
