@@ -749,6 +749,13 @@ int kvc_paged_attention_decode(const kvc_attention_params* p, kvc_stream_t strea
 int32_t kvc_paged_attention_decode_uses_partitions(int32_t num_seqs, int32_t num_heads,
                                                    int32_t num_kv_heads, int32_t head_size,
                                                    int32_t max_context_len, int32_t schedule);
+/* The same question for a cache of the given in-block layout (KVC_LAYOUT_*): slot-major blocks keep one K tile
+ * per wave in the LDS, so the longest context that finishes in one kernel is slightly shorter.  The function above
+ * answers for KVC_LAYOUT_REFERENCE. */
+int32_t kvc_paged_attention_decode_uses_partitions_in(int32_t num_seqs, int32_t num_heads,
+                                                      int32_t num_kv_heads, int32_t head_size,
+                                                      int32_t max_context_len, int32_t schedule,
+                                                      int32_t block_layout);
 
 #ifdef __cplusplus
 }

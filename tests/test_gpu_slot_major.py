@@ -293,7 +293,7 @@ def test_attention_matches_reference_twin_slot_major(case, version, attn_mode, s
     qpk = Hq // int(g["num_kv_heads"])
     pos = np.zeros((NB, bs), np.int32)
     run = lambda: _attn(g, c, pos, np.full(S, 10, np.int32), np.zeros(S, np.int32), version)
-    if hd not in (64, 128, 256) or bs not in (16, 32) or qpk > 8:
+    if hd not in (64, 128, 256) or bs not in (16, 32):
         with pytest.raises(RuntimeError, match="slot-major"):
             run()
         return
@@ -315,6 +315,8 @@ def test_attention_matches_reference_twin_slot_major(case, version, attn_mode, s
     (1, 16, 2, 128, 16, 3000, 4100, "f16", False),       # qpk 8 at a 4k cap: 8-wave single pass
     (1, 4, 1, 128, 16, 6000, 8300, "bf16", False),       # qpk 4 at 8k
     (2, 6, 2, 64, 32, 5, 1100, "f16", True),             # qpk 3
+    (2, 24, 2, 128, 16, 40, 1300, "f16", False),         # qpk 12: all query heads of a KV head in one MFMA operand
+    (1, 40, 2, 128, 32, 300, 800, "bf16", False),        # qpk 20: two query groups per KV head
 ])
 def test_attention_matches_oracle_slot_major(shape, attn_mode, slot_major):
     S, Hq, Hkv, hd, bs, lo, hi, dt, alibi = shape
@@ -333,7 +335,7 @@ def test_attention_matches_oracle_slot_major(shape, attn_mode, slot_major):
 
 def test_attention_unsupported_shapes_raise_slot_major(slot_major):
     rng = np.random.default_rng(1)
-    for shape in ((1, 40, 2, 128, 16), (2, 6, 2, 96, 32), (2, 8, 2, 128, 8)):      # qpk 20, head size 96, block size 8
+    for shape in ((2, 6, 2, 96, 32), (2, 8, 2, 128, 8)):      # head size 96, block size 8
         S, Hq, Hkv, hd, bs = shape
         g, c, pos, last = make_state(rng, S, Hq, Hkv, hd, bs, 10, 100)
         with pytest.raises(RuntimeError, match="slot-major"):
@@ -429,7 +431,7 @@ def test_written_cache_is_attended_to_in_the_same_layout(slot_major):
     # the written cache, in the reference's layout, holds the state's tokens (slots past the contexts stay zero)
     gk, gv = to_reference(kd.view(torch.int16).cpu().numpy(), vd.view(torch.int16).cpu().numpy())
     g2 = dict(g, key_cache_bits=gk, value_cache_bits=gv)
-    c2 = decode_golden(g2)
+    c2 = dict(c, kc=gk.view(np.float16), vc=gv.view(np.float16))
     buf = np.zeros(S, np.int32)
     ref_out, ref_km = oracle_decode(c2, g2, pos, last, buf)
     out, km = _attn(g2, c2, pos, last, buf, "v2")

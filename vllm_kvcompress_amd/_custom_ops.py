@@ -569,9 +569,9 @@ def reserve_attention_scratch(device, num_seqs: int, num_heads: int, head_size: 
 def _partition_scratch(query, num_kv_heads, max_context_len, tag):
     num_seqs, num_heads, head_size = query.shape
     parts = (int(max_context_len) + _ATTN_PARTITION - 1) // _ATTN_PARTITION
-    if parts <= 1 or not _lib.load().kvc_paged_attention_decode_uses_partitions(
+    if parts <= 1 or not _lib.load().kvc_paged_attention_decode_uses_partitions_in(
             num_seqs, num_heads, int(num_kv_heads), head_size, int(max_context_len),
-            _ATTENTION_SCHEDULE):
+            _ATTENTION_SCHEDULE, _lib.block_layout_id()):
         return None, None, None            # one kernel finishes the call: no scratch at all
     n, nbytes = _partition_scratch_bytes(num_seqs, num_heads, head_size, query.element_size(),
                                          max_context_len)

@@ -208,6 +208,8 @@ SYMBOLS = {
                                            c_size_t, c_void_p]),
     "kvc_paged_attention_decode_uses_partitions": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32,
                                                              c_int32]),
+    "kvc_paged_attention_decode_uses_partitions_in": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32,
+                                                                c_int32, c_int32]),
     "kvc_paged_attention_decode": (c_int32, [ctypes.POINTER(KvcAttentionParams), c_void_p]),
 }
 

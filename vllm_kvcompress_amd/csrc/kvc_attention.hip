@@ -28,6 +28,15 @@ extern "C" int32_t kvc_paged_attention_decode_uses_partitions(int32_t num_seqs, 
   return kvc::attention_plan(num_seqs, num_heads, num_kv_heads, head_size, max_context_len, schedule).whole ? 0 : 1;
 }
 
+extern "C" int32_t kvc_paged_attention_decode_uses_partitions_in(int32_t num_seqs, int32_t num_heads,
+                                                                 int32_t num_kv_heads, int32_t head_size,
+                                                                 int32_t max_context_len, int32_t schedule,
+                                                                 int32_t block_layout) {
+  if (num_kv_heads < 1 || num_heads < num_kv_heads || max_context_len <= kvc::ATT_PART) return 0;
+  return kvc::attention_plan(num_seqs, num_heads, num_kv_heads, head_size, max_context_len, schedule,
+                             kvc::attention_stage_bytes(head_size, block_layout)).whole ? 0 : 1;
+}
+
 extern "C" int kvc_paged_attention_decode(const kvc_attention_params* p, kvc_stream_t stream) {
   using namespace kvc;
   if (p == nullptr) return fail_invalid("paged_attention_decode: null params");

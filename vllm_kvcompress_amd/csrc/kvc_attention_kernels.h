@@ -25,6 +25,7 @@
 #include "../../include/kvc_mi355x.h"
 
 #include <math.h>
+#include <algorithm>
 #include <type_traits>
 
 #ifndef KVC_WHOLE_ATTR
@@ -32,6 +33,11 @@
 #endif
 #ifndef KVC_PF
 #define KVC_PF 3
+#endif
+// experiment builds only (tools/, timing): 1 = slot-major K addressing with the reference P.V, 2 = reference K
+// addressing with the slot-major P.V -- which half of the layout costs what.  Results are wrong for 1 and 2.
+#ifndef KVC_SM_EXP
+#define KVC_SM_EXP 0
 #endif
 // K and V are streamed exactly once per call: non-temporal loads (measured +8 % at batch 256)
 #define KVC_LD(p) __builtin_nontemporal_load(p)
@@ -206,90 +212,158 @@ struct AttnArgs {
 
 // ---------------------------------------------------------------- KVC_LAYOUT_SLOT_MAJOR: P.V
 // In slot-major blocks (K [bs][hd], V [bs][hd]) a token's K row is still 16-byte pieces of 8 dims -- QK^T keeps its
-// MFMA form with other addresses.  V is the problem: an MFMA operand wants 8 TOKENS of one dim in a lane, and a
-// slot-major V piece is 8 DIMS of one token.  P.V therefore runs on the vector ALUs: a lane owns 8 dims of the
-// output (PPT = hd / 8 lanes per token, TPI = 64 / PPT tokens per wave instruction, each instruction hd * e
-// contiguous bytes per token) and accumulates acc[q][8] += p[q][token] * v[8] in fp32 for its NI = 32 / TPI tokens
-// of every 32-token group -- 8 conversions + 4 packed FMAs per query head and 16 bytes, ~10 % of the issue slots
-// at qpk 4 of a kernel that is bound by HBM.  P is rounded to the cache type first, like the MFMA operand
-// (.cu:332-420).  NQM = accumulator rows (4 or 8 query heads per KV head; more are refused by the launcher).
-template <typename T, int HD, int BS, int KVD, int NQM>
+// MFMA form with other addresses.  V is the other way round: the 16x16x32 A operand wants 8 TOKENS of one dim in a
+// lane, a slot-major piece is consecutive DIMS of one token.  The operand is therefore assembled inside the lane:
+// lane (c, g) owns EPL = hd / 16 consecutive dims (piece c of a token's row) and requests that piece of ITS 8 tokens
+// t0 + 8 g .. + 7 -- an 8 x EPL matrix [token][dim] in its own registers, every wave instruction reading the whole
+// hd * e contiguous bytes of four tokens.  MFMA e of the group takes column e of that matrix (8 tokens of dim
+// EPL c + e: one v_perm_b32 per operand dword, nothing crosses lanes, nothing goes through the LDS) against the same P
+// operand as the reference layout: accumulator e holds out(dim EPL (4 g + j) + e, query c) in element j.  As many
+// MFMAs and bytes in flight as the reference layout's P.V; the dims are merely numbered differently, which only the
+// final store sees.
+template <typename T, int HD, int KVD>
 struct PvSlots {
   using KF = KvFrag<T, KVD>;
   using V8 = typename Mma<T>::V8;
-  static constexpr int PPT = HD / 8;            // lanes per token
-  static constexpr int TPI = 64 / PPT;          // tokens per wave instruction
-  static constexpr int GT = HD <= 128 ? 32 : 16;   // tokens per group (what a lane holds of it: NI x 16 bytes)
-  static constexpr int NI = GT / TPI;           // instructions (= tokens per lane) per group
-  static constexpr int NG = ATT_CHUNK / GT;     // groups per wave chunk
+  static constexpr int EPL = HD / 16;                     // dims per lane (= MFMAs per 32-token group = output tiles)
+  static constexpr int NB = EPL * (KVD == 0 ? 2 : 1);     // bytes per token and lane: 4, 8, 16, 32
+  static constexpr int ND = NB / 4;                       // raw dwords
+  static constexpr int NH = EPL / 2;                      // dwords of T pairs
   static_assert(HD == 64 || HD == 128 || HD == 256, "slot-major attention: head sizes 64, 128, 256");
-  static_assert(NI % 4 == 0 && BS % NI == 0 && BS >= NI, "a lane's tokens of a group lie in one block");
-  struct Group { typename KF::Raw v[NI]; };
-  float acc[NQM][8];
-  __device__ __forceinline__ void init() {
+  struct Group { uint32_t r[8][ND]; };
+  // requests the lane's piece of tokens t0 + 8 g .. + 7 (t0 a multiple of 32: one block); tokens past the context: 0
+  static __device__ __forceinline__ void load(Group& G, const AttnArgs& a, const int32_t* bt, int t0, int ctx, int c, int g,
+                                              int64_t blk_stride, int bs) {
+    const int tok = t0 + 8 * g;
+    const int64_t phys = tok < ctx ? bt[tok / bs] : 0;
+    const uint8_t* base = reinterpret_cast<const uint8_t*>(a.v_cache) +
+                          ((phys * blk_stride + (int64_t)(tok % bs) * HD) * (KVD == 0 ? 2 : 1) + (int64_t)c * NB);
 #pragma unroll
-    for (int q = 0; q < NQM; ++q)
+    for (int i = 0; i < 8; ++i) {
+      const uint8_t* p = base + (int64_t)i * HD * (KVD == 0 ? 2 : 1);
+      const bool live = tok + i < ctx;
+      if constexpr (ND == 1) {
+        G.r[i][0] = live ? KVC_LD(reinterpret_cast<const uint32_t*>(p)) : 0u;
+      } else if constexpr (ND == 2) {
+        const au32x2 v = live ? KVC_LD(reinterpret_cast<const au32x2*>(p)) : au32x2{0u, 0u};
+        G.r[i][0] = v[0]; G.r[i][1] = v[1];
+      } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[q][e] = 0.0f;
-  }
-  // requests the V pieces of the group of GT tokens at t0 (a multiple of GT)
-  __device__ __forceinline__ void load(Group& G, const AttnArgs& a, const int32_t* bt, int t0, int ctx, int lane) const {
-    const int tsub = lane / PPT, pc = lane % PPT;
-    const int tok0 = t0 + tsub * NI;
-    const int64_t phys = tok0 < ctx ? bt[tok0 / BS] : 0;
-    const int64_t base = phys * a.kv_block_stride + (int64_t)(tok0 % BS) * HD + 8 * pc;
+        for (int k = 0; k < ND / 4; ++k) {
+          const au32x4 v = live ? KVC_LD(reinterpret_cast<const au32x4*>(p) + k) : au32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int it = 0; it < NI; ++it)
-      G.v[it] = tok0 + it < ctx ? KF::load(a.v_cache, base + (int64_t)it * HD) : KF::zero();
-  }
-  // p_t0: the P tile at token t0, row stride rs floats ([query][token] fp32, 16-byte aligned rows).  Both factors go
-  // into the FMA as cache-type values widened on the fly (v_fma_mix_f32 for fp16): nothing converted is kept
-  __device__ __forceinline__ void fma(const Group& G, const float* p_t0, int rs, int nq, float v_scale, int lane) {
-    const int tsub = lane / PPT;
-#pragma unroll
-    for (int i4 = 0; i4 < NI / 4; ++i4) {
-      V8 vt[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) vt[j] = KF::convert(G.v[4 * i4 + j], v_scale);
-#pragma unroll
-      for (int q = 0; q < NQM; ++q) {
-        if (q >= nq) break;                                 // wave-uniform
-        const f32x4 p4 = *reinterpret_cast<const f32x4*>(p_t0 + q * rs + tsub * NI + 4 * i4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const T ph = (T)p4[j];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[q][e] = fmaf((float)ph, (float)vt[j][e], acc[q][e]);
+          for (int d = 0; d < 4; ++d) G.r[i][4 * k + d] = v[d];
         }
       }
     }
   }
-  // acc[q][*] *= alpha of query head q, which sits in lane q of `alpha` (lane & 15 = query)
-  __device__ __forceinline__ void rescale(float alpha, int nq) {
+  // O[e] += V^T(dims EPL c' + e of the 16 lanes c', 32 tokens) . P(32 tokens, 16 queries)
+  static __device__ __forceinline__ void mma(const Group& G, V8 pb, f32x4 (&O)[EPL], float v_scale) {
+    uint32_t h[8][NH];                                    // [token][pair of dims] as T
 #pragma unroll
-    for (int q = 0; q < NQM; ++q) {
-      if (q >= nq) break;
-      const float aq = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(alpha), q));
+    for (int i = 0; i < 8; ++i) {
+      if constexpr (KVD == 0) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[q][e] *= aq;
+        for (int d = 0; d < NH; ++d) h[i][d] = G.r[i][d];
+      } else if constexpr (EPL == 4) {
+        typename KF::Raw raw; raw.v = au32x2{G.r[i][0], 0u};
+        const au32x4 v = __builtin_bit_cast(au32x4, KF::convert(raw, v_scale));
+        h[i][0] = v[0]; h[i][1] = v[1];
+      } else {
+#pragma unroll
+        for (int k = 0; k < EPL / 8; ++k) {
+          typename KF::Raw raw; raw.v = au32x2{G.r[i][2 * k], G.r[i][2 * k + 1]};
+          const au32x4 v = __builtin_bit_cast(au32x4, KF::convert(raw, v_scale));
+#pragma unroll
+          for (int d = 0; d < 4; ++d) h[i][4 * k + d] = v[d];
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      au32x4 av;
+#pragma unroll
+      for (int tp = 0; tp < 4; ++tp)                      // tokens 2 tp (low half), 2 tp + 1 (high half) of dim e
+        av[tp] = __builtin_amdgcn_perm(h[2 * tp + 1][e / 2], h[2 * tp][e / 2], (e & 1) ? 0x07060302u : 0x05040100u);
+      O[e] = Mma<T>::mma(__builtin_bit_cast(V8, av), pb, O[e]);
     }
   }
-  // sums the TPI token groups of the wave and writes out[q * rs + dim], dims 8 pc .. 8 pc + 7 from lane pc
-  __device__ __forceinline__ void reduce_store(float* out, int rs, int nq, int lane) {
+  // row: the [hd] fp32 output row of query c; lane (c, g) holds dims EPL (4 g + j) + e in O[e][j]
+  static __device__ __forceinline__ void store(float* row, const f32x4 (&O)[EPL], int g) {
 #pragma unroll
-    for (int q = 0; q < NQM; ++q) {
-      if (q >= nq) break;
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float v = acc[q][e];
+      for (int e4 = 0; e4 < EPL / 4; ++e4)
+        *reinterpret_cast<f32x4*>(row + EPL * (4 * g + j) + 4 * e4) =
+            f32x4{O[4 * e4][j], O[4 * e4 + 1][j], O[4 * e4 + 2][j], O[4 * e4 + 3][j]};
+  }
+};
+// ---------------------------------------------------------------- KVC_LAYOUT_SLOT_MAJOR: K
+// The QK^T operand is the same 8 dims of one token as in the reference layout, but the MFMA wants 16 TOKENS in 16
+// consecutive lanes and slot-major tokens are a whole row (hd * e bytes) apart: read as operands, four neighbouring
+// lanes ask for four different rows (16 bytes each) where the reference layout has them side by side -- measured
+// +5..10 % (fp16) / +17 % (fp8) on the whole kernel.  The wave therefore reads a 16-token tile the way it lies in
+// memory -- per instruction 8 tokens x 128 contiguous bytes (whole cache lines, neighbouring lanes on neighbouring
+// bytes) -- parks 128 bytes per token at a time ("phase": 64 fp16 dims, 128 fp8 dims) in its own 2 KiB of LDS and
+// takes the operands from there.  The 16-byte units of a parked row are XOR-swizzled by the token so that the lane
+// groups of ds_read_b128 / ds_read_b64 / ds_write_b128 each cover all banks once.  Wave-private: no barrier, the LDS
+// executes a wave's instructions in order.
+constexpr int KSLOTS_STAGE = 2048;                        // LDS bytes per wave
+template <typename T, int HD, int KVD>
+struct KSlots {
+  using KF = KvFrag<T, KVD>;
+  static constexpr int ES = KVD == 0 ? 2 : 1;
+  static constexpr int RB = HD * ES;                      // bytes per token row: 64 .. 512
+  static constexpr int PB = RB < 128 ? RB : 128;          // bytes per token and phase
+  static constexpr int NPH = RB / PB;                     // phases per tile
+  static constexpr int NI = 16 * PB / 1024;               // wave loads per phase: 2 (1 for 64-byte rows)
+  static constexpr int U = PB / 16;                       // 16-byte units per parked row: 8 (4)
+  static constexpr int R = 256 / PB;                      // parked rows per 256-byte bank row: 2 (4)
+  static constexpr int SPP = PB / (32 * ES);              // MFMA k-steps per phase
+  static_assert(HD == 64 || HD == 128 || HD == 256, "slot-major attention: head sizes 64, 128, 256");
+  static_assert(16 * PB <= KSLOTS_STAGE && NPH * SPP == HD / 32, "KSlots");
+  static __device__ __forceinline__ int swz(int tok) { return (tok / R) % U; }
+  struct Raw { au32x4 v[NPH][NI]; };
+  // tile: element offset of the tile's first token row in the K cache
+  static __device__ __forceinline__ void load(Raw& r, const void* k_cache, int64_t tile, int lane) {
+    const uint8_t* base = reinterpret_cast<const uint8_t*>(k_cache) + tile * ES;
 #pragma unroll
-        for (int d = PPT; d < 64; d <<= 1) v += __shfl_xor(v, d, 64);
-        acc[q][e] = v;
+    for (int ph = 0; ph < NPH; ++ph)
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int u = 64 * k + lane, tok = u / U, j = u % U;
+        r.v[ph][k] = KVC_LD(reinterpret_cast<const au32x4*>(base + tok * RB + ph * PB + j * 16));
       }
-      if (lane < PPT) {
-        *reinterpret_cast<f32x4*>(out + q * rs + 8 * lane) = f32x4{acc[q][0], acc[q][1], acc[q][2], acc[q][3]};
-        *reinterpret_cast<f32x4*>(out + q * rs + 8 * lane + 4) = f32x4{acc[q][4], acc[q][5], acc[q][6], acc[q][7]};
-      }
+  }
+  static __device__ __forceinline__ void stage(const Raw& r, int ph, uint8_t* kst, int lane) {
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+      const int u = 64 * k + lane, tok = u / U, j = u % U;
+      *reinterpret_cast<au32x4*>(kst + tok * PB + ((j ^ swz(tok)) << 4)) = r.v[ph][k];
+    }
+  }
+  // dims 32 (ph SPP + sp) + 8 g .. + 7 of token c, out of the parked phase ph
+  static __device__ __forceinline__ typename KF::Raw frag(const uint8_t* kst, int sp, int c, int g) {
+    const int off = (32 * sp + 8 * g) * ES;
+    const uint8_t* p = kst + c * PB + (((off >> 4) ^ swz(c)) << 4) + (off & 15);
+    typename KF::Raw r;
+    if constexpr (KVD == 0) r.v = *reinterpret_cast<const au32x4*>(p);
+    else r.v = *reinterpret_cast<const au32x2*>(p);
+    return r;
+  }
+  // the tile's MFMA operands kf[HD / 32], through the wave's LDS tile
+  template <int KS>
+  static __device__ __forceinline__ void operands(const Raw& r, uint8_t* kst, typename KF::Raw (&kf)[KS], int lane) {
+    const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+      stage(r, ph, kst, lane);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // (read by other lanes of this wave)
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int sp = 0; sp < SPP; ++sp) kf[ph * SPP + sp] = frag(kst, sp, c, g);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // (and overwritten by the next phase)
+      __builtin_amdgcn_wave_barrier();
     }
   }
 };
@@ -404,9 +478,10 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 // dynamic LDS: 2 x [ATT_WAVES][nqr][max(ATT_CHUNK, HD)] floats (P tiles | per-wave outputs)
-template <typename T, int HD, int BS, int KVD, int NQM = 0>      // NQM > 0: KVC_LAYOUT_SLOT_MAJOR with <= NQM query heads
+template <typename T, int HD, int BS, int KVD, int NQM = 0>      // NQM > 0: KVC_LAYOUT_SLOT_MAJOR
 __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a) {
   constexpr bool SLOTS = NQM > 0;
+  constexpr bool SLOTS_K = SLOTS && KVC_SM_EXP != 2, SLOTS_V = SLOTS && KVC_SM_EXP != 1;
   using M = Mma<T>;
   using V8 = typename M::V8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -476,23 +551,42 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
   // ---- QK^T: S[sb][j] = logit(token tok_w0 + 16 sb + 4 g + j, query c)
   f32x4 S[ATT_NSUB];
   float mloc = -INFINITY;
+  using KSL = KSlots<T, SLOTS ? HD : 128, KVD>;
+  constexpr int KPF = 2;                                  // slot-major: tiles requested ahead
+  typename KSL::Raw kraw[SLOTS_K ? KPF : 1];
+  uint8_t* kst = reinterpret_cast<uint8_t*>(lds + (int64_t)2 * ATT_WAVES * nqr * ROW) + w * KSLOTS_STAGE;
+  auto load_tile = [&](int sb, typename KSL::Raw& r) {
+    const int t0 = tok_w0 + sb * 16;
+    if (t0 < ctx)                                         // wave-uniform; (a tile lies inside one block: bs >= 16)
+      KSL::load(r, a.k_cache, (int64_t)bt[t0 / BS] * a.kv_block_stride + (int64_t)(t0 % BS) * HD, lane);
+  };
+  if constexpr (SLOTS_K) {
+#pragma unroll
+    for (int d = 0; d < KPF; ++d) load_tile(d, kraw[d]);
+  }
 #pragma unroll
   for (int sb = 0; sb < ATT_NSUB; ++sb) {
     const int t0 = tok_w0 + sb * 16;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (t0 < ctx) {                                       // wave-uniform
+    if constexpr (SLOTS_K) {
+      if (t0 < ctx) {                                     // wave-uniform
+        typename KF::Raw kk[KS];
+        KSL::operands(kraw[sb % KPF], kst, kk, lane);
+        if (sb + KPF < ATT_NSUB) load_tile(sb + KPF, kraw[sb % KPF]);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = M::mma(KF::convert(kk[s], a.k_scale), qf[s], acc);
+      }
+    } else if (t0 < ctx) {                                // wave-uniform
       // dims 32 s + 8 g .. + 7 of token t0 + c: vector (dim / X), element (dim % X).  A 16-token
       // sub-block lies inside one cache block for BS >= 16; for BS = 8 it spans two (16 for BS = 1), so every lane
       // looks its own block up (tokens past the context are clamped onto the last one and masked below)
       const int tk = BS >= 16 ? t0 + c : min(t0 + c, ctx - 1);
       const int64_t phys = BS >= 16 ? bt[t0 / BS] : bt[tk / BS];
-      // (slot-major: the token's K row is hd contiguous elements)
-      const int64_t kb = phys * a.kv_block_stride + (int64_t)(tk % BS) * (SLOTS ? HD : X);
+      const int64_t kb = phys * a.kv_block_stride + (int64_t)(tk % BS) * X;
       typename KF::Raw kk[KS];
 #pragma unroll
       for (int s = 0; s < KS; ++s)
-        kk[s] = KF::load(a.k_cache, SLOTS ? kb + 32 * s + 8 * g
-                                          : kb + (int64_t)((32 * s + 8 * g) / X) * BS * X + (32 * s + 8 * g) % X);
+        kk[s] = KF::load(a.k_cache, kb + (int64_t)((32 * s + 8 * g) / X) * BS * X + (32 * s + 8 * g) % X);
 #pragma unroll
       for (int s = 0; s < KS; ++s) acc = M::mma(KF::convert(kk[s], a.k_scale), qf[s], acc);
     }
@@ -538,24 +632,9 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
   f32x4 O[DT];
 #pragma unroll
   for (int i = 0; i < DT; ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  PvSlots<T, SLOTS ? HD : 128, SLOTS ? BS : 16, KVD, SLOTS ? NQM : 1> pv;
-  if constexpr (SLOTS) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // (this wave's P tile, written above, is read by other lanes)
-    __builtin_amdgcn_wave_barrier();
-    pv.init();
-    using PV = decltype(pv);
-    typename PV::Group gv[2];
-    pv.load(gv[0], a, bt, tok_w0, ctx, lane);
+  using PV = PvSlots<T, SLOTS ? HD : 128, KVD>;
 #pragma unroll
-    for (int pr = 0; pr < PV::NG; ++pr) {
-      const int t0 = tok_w0 + pr * PV::GT;
-      if (t0 >= ctx) break;                               // wave-uniform
-      if (pr + 1 < PV::NG) pv.load(gv[(pr + 1) & 1], a, bt, t0 + PV::GT, ctx, lane);
-      pv.fma(gv[pr & 1], pw + pr * PV::GT, ROW, nq, a.v_scale, lane);
-    }
-  }
-#pragma unroll
-  for (int pr = 0; pr < (SLOTS ? 0 : ATT_NSUB / 2); ++pr) {
+  for (int pr = 0; pr < ATT_NSUB / 2; ++pr) {
     const int t0 = tok_w0 + pr * 32;
     if (t0 >= ctx) break;                                 // wave-uniform
     // B operand: P[query c][tokens t0 + 8 g .. + 7], rounded to the cache type (.cu:332-420)
@@ -568,6 +647,13 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) { pb[e] = (T)lo[e]; pb[4 + e] = (T)hi[e]; }
+    }
+    if constexpr (SLOTS_V) {
+      // A operand assembled in the lane from its 8 tokens' pieces (PvSlots)
+      typename PV::Group gv;
+      PV::load(gv, a, bt, t0, ctx, c, g, a.kv_block_stride, BS);
+      PV::mma(gv, pb, O, a.v_scale);
+      continue;
     }
     // A operand: V[dim 16 i + c][tokens t0 + 8 g .. + 7]
     const int tok = t0 + 8 * g;
@@ -601,8 +687,8 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
 
   // ---- combine the four waves (same max, so a plain sum), normalise, store
   float* ow = lds + (int64_t)(ATT_WAVES + w) * nqr * ROW;   // second LDS region
-  if constexpr (SLOTS) {
-    pv.reduce_store(ow, ROW, nq, lane);
+  if constexpr (SLOTS_V) {
+    if (c < nq) PV::store(ow + c * ROW, O, g);
   } else if (c < nq) {
 #pragma unroll
     for (int i = 0; i < DT; ++i) *reinterpret_cast<f32x4*>(ow + c * ROW + 16 * i + 4 * g) = O[i];
@@ -672,6 +758,7 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
 template <typename T, int HD, int BS, int KVD, int NW, int NQM = 0>
 __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode_whole_kernel(AttnArgs a, int prow, int niter_max) {
   constexpr bool SLOTS = NQM > 0;
+  constexpr bool SLOTS_K = SLOTS && KVC_SM_EXP != 2, SLOTS_V = SLOTS && KVC_SM_EXP != 1;
   using M = Mma<T>;
   using V8 = typename M::V8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -712,7 +799,11 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
                             ? harvest_ctx(a, seq, hk, max_pos, ctx, BS, tid == 0 && q0 == 0) : HarvestCtx{0u, -1, 0};
   float* P = lds;                                          // [nqr][prow]
   float* Ol = lds + (int64_t)nqr * prow;                   // [4][nqr][HD]
-  float* mrec = Ol + (int64_t)4 * nqr * HD;                // [niter_max][NW][16]
+  // (slot-major blocks: the waves' K tiles, KSlots, live in the O region until the loop over the context is over)
+  const int o_floats = SLOTS_K ? max(4 * nqr * HD, NW * KSLOTS_STAGE / 4) : 4 * nqr * HD;
+  float* mrec = Ol + o_floats;                             // [niter_max][NW][16]
+  using KSL = KSlots<T, SLOTS ? HD : 128, KVD>;
+  uint8_t* kst = reinterpret_cast<uint8_t*>(Ol) + w * KSLOTS_STAGE;
 
   V8 qf[KS];
   {
@@ -729,8 +820,7 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
   f32x4 O[DT];
 #pragma unroll
   for (int i = 0; i < DT; ++i) O[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  PvSlots<T, SLOTS ? HD : 128, SLOTS ? BS : 16, KVD, SLOTS ? NQM : 1> pv;
-  if constexpr (SLOTS) pv.init();
+  using PV = PvSlots<T, SLOTS ? HD : 128, KVD>;
   float m_run = -INFINITY, l_run = 0.0f;
   const int niter = (ctx + STEP - 1) / STEP;
   for (int it = 0; it < niter; ++it) {
@@ -743,16 +833,19 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
     float mloc = -INFINITY;
     constexpr int PF = KVC_PF;
     typename KF::Raw kk[ATT_NSUB][KS];
+    typename KSL::Raw kraw[SLOTS_K ? PF : 1];            // slot-major: whole tiles, operands through the wave's LDS tile (KSlots)
     auto load_k = [&](int sb) {
       const int t0 = tok_w0 + sb * 16;
-      if (t0 < ctx) {
+      if constexpr (SLOTS_K) {
+        if (t0 < ctx)
+          KSL::load(kraw[sb % PF], a.k_cache, (int64_t)bt[t0 / BS] * a.kv_block_stride + (int64_t)(t0 % BS) * HD, lane);
+      } else if (t0 < ctx) {
         const int tk = BS >= 16 ? t0 + c : min(t0 + c, ctx - 1);
         const int64_t phys = BS >= 16 ? bt[t0 / BS] : bt[tk / BS];
-        const int64_t kb = phys * a.kv_block_stride + (int64_t)(tk % BS) * (SLOTS ? HD : X);
+        const int64_t kb = phys * a.kv_block_stride + (int64_t)(tk % BS) * X;
 #pragma unroll
         for (int s = 0; s < KS; ++s)
-          kk[sb][s] = KF::load(a.k_cache, SLOTS ? kb + 32 * s + 8 * g
-                                                : kb + (int64_t)((32 * s + 8 * g) / X) * BS * X + (32 * s + 8 * g) % X);
+          kk[sb][s] = KF::load(a.k_cache, kb + (int64_t)((32 * s + 8 * g) / X) * BS * X + (32 * s + 8 * g) % X);
       } else {
 #pragma unroll
         for (int s = 0; s < KS; ++s) kk[sb][s] = KF::zero();
@@ -762,12 +855,22 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
     for (int sb = 0; sb < PF && sb < ATT_NSUB; ++sb) load_k(sb);
 #pragma unroll
     for (int sb = 0; sb < ATT_NSUB; ++sb) {
-      if (sb + PF < ATT_NSUB) load_k(sb + PF);
-      __builtin_amdgcn_sched_barrier(0);
       const int t0 = tok_w0 + sb * 16;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (SLOTS_K) {
+        if (t0 < ctx) {                                     // wave-uniform
+          typename KF::Raw kf[KS];
+          KSL::operands(kraw[sb % PF], kst, kf, lane);
+          if (sb + PF < ATT_NSUB) load_k(sb + PF);
 #pragma unroll
-      for (int s = 0; s < KS; ++s) acc = M::mma(KF::convert(kk[sb][s], a.k_scale), qf[s], acc);
+          for (int s = 0; s < KS; ++s) acc = M::mma(KF::convert(kf[s], a.k_scale), qf[s], acc);
+        }
+      } else {
+        if (sb + PF < ATT_NSUB) load_k(sb + PF);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = M::mma(KF::convert(kk[sb][s], a.k_scale), qf[s], acc);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int tok = t0 + 4 * g + j;
@@ -799,32 +902,20 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
     m_run = m_new;
     if (g == 0) mrec[(it * NW + w) * ATT_NQ + c] = m_new;
     constexpr int NPR = ATT_NSUB / 2;
-    if constexpr (SLOTS) {
-      // (alpha of query head q sits in the lanes with lane & 15 == q; 0 on the first chunk, where acc is 0 too)
-      pv.rescale(alpha, nq);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (this wave's P rows, written above, are read by other lanes)
-      __builtin_amdgcn_wave_barrier();
-      using PV = decltype(pv);
-      typename PV::Group gv[2];
-      pv.load(gv[0], a, bt, tok_w0, ctx, lane);
-#pragma unroll
-      for (int pr = 0; pr < PV::NG; ++pr) {
-        const int t0 = tok_w0 + pr * PV::GT;
-        if (t0 >= ctx) break;
-        if (pr + 1 < PV::NG) pv.load(gv[(pr + 1) & 1], a, bt, t0 + PV::GT, ctx, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        pv.fma(gv[pr & 1], pw + pr * PV::GT, prow, nq, a.v_scale, lane);
-      }
-      continue;
-    }
 #pragma unroll
     for (int i = 0; i < DT; ++i) O[i] *= alpha;
     // ---- P.V, V fragments one 32-token pair ahead
     typename KF::Raw vv[2][DT];
+    typename PV::Group gv[SLOTS_V ? 2 : 1];
     auto load_v = [&](int pr, int bufi) {
+      if constexpr (SLOTS_V) {
+        PV::load(gv[bufi], a, bt, tok_w0 + pr * 32, ctx, c, g, a.kv_block_stride, BS);
+        return;
+      }
       const int tok = tok_w0 + pr * 32 + 8 * g;
       const bool live = tok < ctx;
-      if constexpr (BS >= 8) {
+      if constexpr (SLOTS_V) {
+      } else if constexpr (BS >= 8) {
         const int64_t phys = live ? bt[tok / BS] : 0;
         const int64_t vb = phys * a.kv_block_stride + (int64_t)c * BS + (tok % BS);
 #pragma unroll
@@ -856,6 +947,10 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
 #pragma unroll
         for (int e = 0; e < 4; ++e) { pb[e] = (T)lo[e]; pb[4 + e] = (T)hi[e]; }
       }
+      if constexpr (SLOTS_V) {
+        PV::mma(gv[pr & 1], pb, O, a.v_scale);
+        continue;
+      }
       const int tok = t0 + 8 * g;
       const bool tail = t0 + 32 > ctx;                     // wave-uniform: mask stale tokens
 #pragma unroll
@@ -871,6 +966,7 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
     }
   }
 
+  if constexpr (SLOTS_K) __syncthreads();                  // (the O region held the waves' K tiles until here)
   // ---- combine the waves (each has its own running max), four at a time through the
   // [4][nqr][HD] output region so that the 8-wave variant needs no more LDS than the 4-wave one
   if (g == 0) { red_max[w][c] = m_run; red_sum[w][c] = l_run; }
@@ -880,8 +976,8 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
   for (int k = 0; k < OUTS; ++k) oacc[k] = 0.0f;
 #pragma unroll
   for (int hlf = 0; hlf < NW / 4; ++hlf) {
-    if constexpr (SLOTS) {
-      if (w / 4 == hlf) pv.reduce_store(Ol + (int64_t)(w % 4) * nqr * HD, HD, nq, lane);
+    if constexpr (SLOTS_V) {
+      if (w / 4 == hlf && c < nq) PV::store(Ol + ((int64_t)(w % 4) * nqr + c) * HD, O, g);
     } else if (w / 4 == hlf && c < nq) {
 #pragma unroll
       for (int i = 0; i < DT; ++i)
@@ -1231,7 +1327,11 @@ __global__ __launch_bounds__(256) void paged_attention_metric_rescale_kernel(Att
 // which schedule a call takes (shared by the launcher and kvc_paged_attention_decode_uses_partitions)
 struct AttnPlan { bool whole; int nw, prow; size_t whole_lds; };
 // schedule: 0 automatic, 1 always partitioned, 2 single pass whenever it fits (kvc_attention_params.schedule)
-inline AttnPlan attention_plan(int num_seqs, int num_heads, int num_kv_heads, int head_size, int max_ctx, int schedule) {
+// LDS per WAVE for slot-major blocks: the K tile in flight (KSlots).  The single-pass kernel keeps it where the
+// waves' partial outputs go afterwards.
+inline int attention_stage_bytes(int head_size, int layout) { (void)head_size; return layout == KVC_LAYOUT_SLOT_MAJOR ? KSLOTS_STAGE : 0; }
+inline AttnPlan attention_plan(int num_seqs, int num_heads, int num_kv_heads, int head_size, int max_ctx, int schedule,
+                               int stage_bytes = 0) {
   const int qpk = num_heads / num_kv_heads;
   const int ngroups = (qpk + ATT_NQ - 1) / ATT_NQ;
   const int nqr = qpk < ATT_NQ ? qpk : ATT_NQ;
@@ -1243,7 +1343,8 @@ inline AttnPlan attention_plan(int num_seqs, int num_heads, int num_kv_heads, in
   p.prow = (max_ctx + ATT_CHUNK - 1) / ATT_CHUNK * ATT_CHUNK + 4;
   auto whole_bytes = [&](int nw) {
     const int niter = (max_ctx + nw * ATT_CHUNK - 1) / (nw * ATT_CHUNK);
-    return ((size_t)nqr * p.prow + (size_t)4 * nqr * head_size + (size_t)niter * nw * ATT_NQ) * sizeof(float);
+    const size_t o_bytes = std::max((size_t)4 * nqr * head_size * sizeof(float), (size_t)nw * stage_bytes);
+    return ((size_t)nqr * p.prow + (size_t)niter * nw * ATT_NQ) * sizeof(float) + o_bytes;
   };
   p.nw = whole_bytes(4) <= 79 * 1024 ? 4 : 8;
   p.whole_lds = whole_bytes(p.nw);
@@ -1261,12 +1362,7 @@ template <typename T, int HD, int BS, int KVD>
 int launch_attention(const AttnArgs& a, int num_seqs, hipStream_t s) {
   if (a.layout == KVC_LAYOUT_SLOT_MAJOR) {
     if constexpr (slot_major_shape<HD, BS>()) {
-      const int qpk = a.num_heads / a.num_kv_heads;
-      if (qpk > 8)
-        return fail_invalid("paged_attention_decode: slot-major blocks support <= 8 query heads per KV head (got " +
-                            std::to_string(qpk) + ")");
-      return qpk <= 4 ? launch_attention_layout<T, HD, BS, KVD, 4>(a, num_seqs, s)
-                      : launch_attention_layout<T, HD, BS, KVD, 8>(a, num_seqs, s);
+      return launch_attention_layout<T, HD, BS, KVD, 1>(a, num_seqs, s);
     } else {
       return fail_invalid("paged_attention_decode: slot-major blocks support head sizes 64 / 128 / 256 with block sizes 16 / 32");
     }
@@ -1279,7 +1375,8 @@ int launch_attention_layout(const AttnArgs& a, int num_seqs, hipStream_t s) {
   const int qpk = a.num_heads / a.num_kv_heads;
   const int ngroups = (qpk + ATT_NQ - 1) / ATT_NQ;
   const int nqr = qpk < ATT_NQ ? qpk : ATT_NQ;
-  const AttnPlan plan = attention_plan(num_seqs, a.num_heads, a.num_kv_heads, HD, a.max_ctx, a.schedule);
+  const int STAGE = attention_stage_bytes(HD, NQM > 0 ? KVC_LAYOUT_SLOT_MAJOR : KVC_LAYOUT_REFERENCE);
+  const AttnPlan plan = attention_plan(num_seqs, a.num_heads, a.num_kv_heads, HD, a.max_ctx, a.schedule, STAGE);
   const int prow = plan.prow, nw = plan.nw;
   const size_t whole_lds = plan.whole_lds;
   const bool whole = plan.whole;
@@ -1303,7 +1400,7 @@ int launch_attention_layout(const AttnArgs& a, int num_seqs, hipStream_t s) {
                           (a.record && a.tmp_kv_metric_out == nullptr)))
     return fail_invalid("paged_attention_decode: this shape needs the partition buffers");
   constexpr int ROW = ATT_CHUNK > HD ? ATT_CHUNK : HD;
-  const size_t lds_bytes = (size_t)2 * ATT_WAVES * nqr * ROW * sizeof(float);
+  const size_t lds_bytes = (size_t)2 * ATT_WAVES * nqr * ROW * sizeof(float) + (size_t)ATT_WAVES * STAGE;
   if (lds_bytes > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(paged_attention_decode_kernel<T, HD, BS, KVD, NQM>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

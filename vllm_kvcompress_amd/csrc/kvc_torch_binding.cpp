@@ -404,8 +404,8 @@ void paged_attention_kvc(Tensor& out, Tensor& kv_metric_out, const Tensor* exp_s
     p.max_logits = max_logits->data_ptr<float>();
     p.tmp_out = tmp_out->data_ptr();
     p.tmp_kv_metric_out = tmp_kv_metric_out->data_ptr<float>();
-  } else if (kvc_paged_attention_decode_uses_partitions(p.num_seqs, p.num_heads, p.num_kv_heads, p.head_size,
-                                                        p.max_context_len, p.schedule)) {
+  } else if (kvc_paged_attention_decode_uses_partitions_in(p.num_seqs, p.num_heads, p.num_kv_heads, p.head_size,
+                                                           p.max_context_len, p.schedule, p.block_layout)) {
     const int64_t parts = (max_context_len + 511) / 512;
     const int64_t n = (int64_t)p.num_seqs * p.num_heads * parts;
     const size_t nbytes = (size_t)n * 8 + (size_t)n * p.head_size * query.element_size() + 256;
