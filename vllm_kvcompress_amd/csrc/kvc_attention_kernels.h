@@ -479,7 +479,8 @@ __device__ __forceinline__ float group_sum(float v) {
 
 // dynamic LDS: 2 x [ATT_WAVES][nqr][max(ATT_CHUNK, HD)] floats (P tiles | per-wave outputs)
 template <typename T, int HD, int BS, int KVD, int NQM = 0>      // NQM > 0: KVC_LAYOUT_SLOT_MAJOR
-__global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a) {
+// (slot-major operands cost ~30 registers more when left to the compiler: held to four waves per SIMD up to hd 128)
+__global__ __launch_bounds__(256, (NQM > 0 && HD <= 128) ? 4 : 1) void paged_attention_decode_kernel(AttnArgs a) {
   constexpr bool SLOTS = NQM > 0;
   constexpr bool SLOTS_K = SLOTS && KVC_SM_EXP != 2, SLOTS_V = SLOTS && KVC_SM_EXP != 1;
   using M = Mma<T>;
@@ -552,7 +553,10 @@ __global__ __launch_bounds__(256) void paged_attention_decode_kernel(AttnArgs a)
   f32x4 S[ATT_NSUB];
   float mloc = -INFINITY;
   using KSL = KSlots<T, SLOTS ? HD : 128, KVD>;
-  constexpr int KPF = 2;                                  // slot-major: tiles requested ahead
+#ifndef KVC_KPF
+#define KVC_KPF 2
+#endif
+  constexpr int KPF = KVC_KPF;                            // slot-major: tiles requested ahead
   typename KSL::Raw kraw[SLOTS_K ? KPF : 1];
   uint8_t* kst = reinterpret_cast<uint8_t*>(lds + (int64_t)2 * ATT_WAVES * nqr * ROW) + w * KSLOTS_STAGE;
   auto load_tile = [&](int sb, typename KSL::Raw& r) {
@@ -906,7 +910,8 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
     for (int i = 0; i < DT; ++i) O[i] *= alpha;
     // ---- P.V, V fragments one 32-token pair ahead
     typename KF::Raw vv[2][DT];
-    typename PV::Group gv[SLOTS_V ? 2 : 1];
+    constexpr int VBUF = (SLOTS_V && HD > 128) ? 1 : 2;   // (hd 256: a group is 64 registers -- one at a time)
+    typename PV::Group gv[SLOTS_V ? VBUF : 1];
     auto load_v = [&](int pr, int bufi) {
       if constexpr (SLOTS_V) {
         PV::load(gv[bufi], a, bt, tok_w0 + pr * 32, ctx, c, g, a.kv_block_stride, BS);
@@ -935,7 +940,7 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
     for (int pr = 0; pr < NPR; ++pr) {
       const int t0 = tok_w0 + pr * 32;
       if (t0 >= ctx) break;
-      if (pr + 1 < NPR) load_v(pr + 1, (pr + 1) & 1);
+      if (VBUF == 2 && pr + 1 < NPR) load_v(pr + 1, (pr + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
       V8 pb;
       {
@@ -948,7 +953,8 @@ __global__ __launch_bounds__(64 * NW) KVC_WHOLE_ATTR void paged_attention_decode
         for (int e = 0; e < 4; ++e) { pb[e] = (T)lo[e]; pb[4 + e] = (T)hi[e]; }
       }
       if constexpr (SLOTS_V) {
-        PV::mma(gv[pr & 1], pb, O, a.v_scale);
+        PV::mma(gv[pr & (VBUF - 1)], pb, O, a.v_scale);
+        if (VBUF == 1 && pr + 1 < NPR) load_v(pr + 1, 0);
         continue;
       }
       const int tok = t0 + 8 * g;
