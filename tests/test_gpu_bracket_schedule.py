@@ -157,10 +157,19 @@ def test_batch_rule_with_a_chunk_nobody_claims():
     assert how_a == "bracket+fallback" and how_b == "general", how_a
     for key in KEYS:
         np.testing.assert_array_equal(a[key], b[key], err_msg=key)
-    # sequences that do not couple need no count of the evictable keys: no fallback, the same answer
+    # sequences that do not couple: the key pass (which no longer has a 0xFF fill in front of it) counts the
+    # logical blocks it finds, bracket_kernel sees one missing -> the fallback builds keys and holes anew: the same answer
     c, how_c = _run(st, evicted, 4, mode="per_sequence")
     d, _ = _run(st, evicted, 1, mode="per_sequence")
-    assert how_c == "bracket", how_c
+    assert how_c == "bracket+fallback", how_c
+    for key in KEYS:
+        np.testing.assert_array_equal(c[key], d[key], err_msg=key)
+    # ... and the call after it starts from clean counters again
+    st2 = synth.make_state(num_layers=2, num_kv_heads=4, block_size=16, seq_lens=[4100, 3000], seed=15, protected=32)
+    e, how_e = _run(st2, evicted, 4, mode="per_sequence")
+    f, _ = _run(st2, evicted, 1, mode="per_sequence")
+    assert how_e == "bracket", how_e
+    c, d = e, f
     for key in KEYS:
         np.testing.assert_array_equal(c[key], d[key], err_msg=key)
 

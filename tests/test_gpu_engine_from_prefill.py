@@ -145,6 +145,9 @@ def test_engine_from_prefill_all_state_on_device(mode, layout):
             assert n_o == n_d, f"iteration {it}"
             same(f"iteration {it}: decode")
         assert compressions >= 25, compressions
-        assert int(o.ctx.max()) <= cap + bs
+        # (the reference's batch > 1 rule hands a sequence fewer evictions than it asked for when another one's
+        # heads hold few evictable keys -- metrics.py:718's count -- so only the per-sequence mode holds the cap)
+        if mode == "per_sequence":
+            assert int(o.ctx.max()) <= cap + bs
     finally:
         _lib.set_block_layout("reference")

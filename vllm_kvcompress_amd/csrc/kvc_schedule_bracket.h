@@ -228,6 +228,16 @@ __global__ __launch_bounds__(1024) void bracket_kernel(kvc_schedule_params p, Sc
   if (tid < 3) red_s[tid] = 0;
   if (i == 0 && tid < 128) ws.fallback[tid] = 0u;    // the flag, the stamps and the phase counters of the fallback
   __syncthreads();
+  if (i == 0 && ws.bclaim != nullptr && tid < WAVE) {
+    // no 0xFF fill in front of the key pass: it counted the logical blocks it found instead.  Every slot of keys,
+    // chunk table and sample was written iff the count is N / bs -- else (a hole in the metadata, or counters some
+    // other schedule left dirty) the flag goes up and the fallback builds everything anew.  The counters are left
+    // zero for the next call.
+    static_assert(CLAIM_SHARDS == WAVE, "one shard per lane");
+    const uint32_t c = wave_reduce_sum(ws.bclaim[tid * 32]);
+    ws.bclaim[tid * 32] = 0u;
+    if (tid == 0 && (int64_t)c != p.total_slots / bs) atomicOr(ws.fallback, 1u | FB_HOLES_BIT);
+  }
   {
     uint32_t hs = 0, la = 0;                         // sum of hang, heads that hold anything
     for (int lh = tid; lh < LH; lh += blockDim.x) {

@@ -32,6 +32,9 @@ struct SchedWs {
   uint32_t* bsample;     // [B, BR_CELLS] bracket schedule: the sample build_keys leaves behind (nullptr: none wanted)
   uint32_t* bnonfin;     // [G] bracket schedule under the batch > 1 rule: build_keys counts the head's keys that are
                          //     not evictable here (= st_samp; nullptr: not wanted)
+  uint32_t* bclaim;      // [64 x 32] bracket schedule without the 0xFF fill: the key pass counts the logical blocks it
+                         //     finds a physical block for here (= st_claimed; nullptr: not wanted); bracket_kernel checks
+                         //     the sum against N / bs and leaves the counters zero for the next call
   const int32_t* bk;     // [B] bracket schedule: chunks a sequence frees -- the caller's k (k' = min(k, finite) is found
                          //     on the way) or, under the batch > 1 rule, seq_k = k' itself
   uint32_t* bthr;        // [N / bs] bracket schedule: per head (from its first chunk on) its listed thresholds, ascending
@@ -43,6 +46,10 @@ struct SchedWs {
   const int32_t* hv_seen_seq;   // [2B] with, every sequence's (position, protected window) -- or nullptr: nothing to verify
 };
 
+
+// flag word bit: the bracket schedule's key pass did not find every logical block (or its counters were not clean):
+// the fallback makes keys, chunk table and holes anew instead of starting from the keys that exist
+constexpr uint32_t FB_HOLES_BIT = 8u;
 
 __device__ __forceinline__ bool gated_off(const SchedWs& ws) { return ws.gate != nullptr && *ws.gate == 0u; }
 

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void fallback_general_kernel(kvc_schedule_p
   const int B = p.num_seqs, G = B * p.num_layers * p.num_kv_heads;
   const uint32_t VS = (uint32_t)B < 4u * vgrid ? (uint32_t)B : 4u * vgrid;     // per-sequence phases
   const uint32_t VH = (uint32_t)G < 8u * vgrid ? (uint32_t)G : 8u * vgrid;     // the per-head phase
-  if (have_keys) {
+  if (have_keys && !(flag0 & FB_HOLES_BIT)) {
     run(vgrid, [&](unsigned v, unsigned V) { zero_body(zero16, zero_vecs, v, V); });
   } else {
     // every logical block of the batch has a physical block (the collecting pass counted them:

@@ -55,10 +55,24 @@ __device__ __forceinline__ void sample_key(const kvc_schedule_params& p, SchedWs
 
 // (bodies take the workgroup's index and the number of workgroups as arguments: the kernels below
 // pass blockIdx / gridDim, the single-launch fallback of the small-eviction schedule its own)
-template <int VEC>
+// one add per workgroup on one of CLAIM_SHARDS counters a cache line apart (what the workgroup's threads counted)
+__device__ __forceinline__ void claim_flush(uint32_t* shards, uint32_t mine, unsigned bid) {
+  __shared__ uint32_t claim_s;
+  if (threadIdx.x == 0) claim_s = 0u;
+  __syncthreads();
+  const uint32_t w = wave_reduce_sum(mine);
+  if (lane_id() == 0 && w) atomicAdd(&claim_s, w);
+  __syncthreads();
+  if (threadIdx.x == 0 && claim_s) atomicAdd(&shards[(bid % (unsigned)CLAIM_SHARDS) * 32], claim_s);
+}
+
+// COUNT: the logical blocks that found their physical block are counted into ws.bclaim (the bracket schedule's
+// stand-in for the 0xFF fill: every slot was written if the count is N / bs)
+template <int VEC, bool COUNT = false>
 __device__ __forceinline__ void build_keys_body(const kvc_schedule_params& p, SchedWs& ws, unsigned bid, unsigned data_blocks) {
   const int bs = p.block_size;
   const int per_blk = bs / VEC;
+  uint32_t claimed = 0;
   // (grid-stride: behind the small-eviction schedule this kernel is launched gated, with a small grid)
   for (int64_t tid = (int64_t)bid * blockDim.x + threadIdx.x; tid < p.num_blocks * per_blk;
        tid += (int64_t)data_blocks * blockDim.x) {
@@ -107,8 +121,9 @@ __device__ __forceinline__ void build_keys_body(const kvc_schedule_params& p, Sc
     if (ws.bsample != nullptr) sample_key(p, ws, i, dst, k1);
     if (ws.bnonfin != nullptr && k1 >= KEY_INF) atomicAdd(&ws.bnonfin[g], 1u);
   }
-  if (off == 0) ws.chunk_phys[base / bs + lbn] = (int32_t)blk;
+  if (off == 0) { ws.chunk_phys[base / bs + lbn] = (int32_t)blk; claimed += 1u; }
   }
+  if constexpr (COUNT) claim_flush(ws.bclaim, claimed, bid);
 }
 
 template <int VEC>
@@ -119,7 +134,8 @@ __global__ __launch_bounds__(256) void build_keys_kernel(kvc_schedule_params p, 
     zero_body(zero16, zero_vecs, blockIdx.x - data_blocks, gridDim.x - data_blocks);
     return;
   }
-  build_keys_body<VEC>(p, ws, blockIdx.x, data_blocks);
+  if (ws.bclaim != nullptr) build_keys_body<VEC, true>(p, ws, blockIdx.x, data_blocks);
+  else build_keys_body<VEC>(p, ws, blockIdx.x, data_blocks);
 }
 
 // The same pass for bs in {4, 8, 16, 32, 64} (16 B per thread), organised so that blocks OUTSIDE the
@@ -133,7 +149,9 @@ __global__ __launch_bounds__(256) void build_keys_kernel(kvc_schedule_params p, 
 // batch blocks a wave finds; this form 0.07 ms.)
 constexpr int SPARSE_SCAN = 16;                       // index loads in flight per thread
 constexpr int SPARSE_CHUNK = 256 * SPARSE_SCAN;       // blocks per workgroup sweep
+template <bool COUNT = false>
 __device__ __forceinline__ void build_keys_sparse_body(const kvc_schedule_params& p, SchedWs& ws, unsigned bid, unsigned data_blocks) {
+  uint32_t claimed = 0;
   __shared__ uint32_t list_s[SPARSE_CHUNK];           // (batch position of the sequence << 12) | block - chunk base
   static_assert(SPARSE_CHUNK <= 4096, "12 bits of block offset");
   __shared__ uint32_t n_s;
@@ -193,10 +211,11 @@ __device__ __forceinline__ void build_keys_sparse_body(const kvc_schedule_params
         const uint32_t c = (kq.x >= KEY_INF) + (kq.y >= KEY_INF) + (kq.z >= KEY_INF) + (kq.w >= KEY_INF);
         if (c) atomicAdd(&ws.bnonfin[g], c);
       }
-      if (off == 0) ws.chunk_phys[base_g / bs + lbn] = (int32_t)blk;
+      if (off == 0) { ws.chunk_phys[base_g / bs + lbn] = (int32_t)blk; claimed += 1u; }
     }
     __syncthreads();
   }
+  if constexpr (COUNT) claim_flush(ws.bclaim, claimed, bid);
 }
 
 __global__ __launch_bounds__(256) void build_keys_sparse_kernel(kvc_schedule_params p, SchedWs ws,
@@ -206,7 +225,8 @@ __global__ __launch_bounds__(256) void build_keys_sparse_kernel(kvc_schedule_par
     zero_body(zero16, zero_vecs, blockIdx.x - data_blocks, gridDim.x - data_blocks);
     return;
   }
-  build_keys_sparse_body(p, ws, blockIdx.x, data_blocks);
+  if (ws.bclaim != nullptr) build_keys_sparse_body<true>(p, ws, blockIdx.x, data_blocks);
+  else build_keys_sparse_body(p, ws, blockIdx.x, data_blocks);
 }
 
 // The same keys in LOGICAL order through the caller's block tables (kvc_schedule_params.block_tables,
