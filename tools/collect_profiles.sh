@@ -90,6 +90,46 @@ if dom:
 json.dump(summary, open(f"{out}/{tag}_traffic_engine.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if k != "kernels"}))
 PY
+# 3b'. the opt-in slot-major in-block layout (KVC_BLOCK_LAYOUT=slot_major): the same step, kernel stats and the two PMC
+#      passes of compact_slots_kernel                         -> <tag>_native_kernel_stats.csv, <tag>_native_traffic.json
+cd /tmp
+BENCH_N="$BENCH --block-layout slot_major"
+timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_n" --output-format csv -- $BENCH_N > "$OUT/${TAG}_native_bench_under_rocprof.json" 2> "$OUT/stats_n.log"
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch_n" --output-format csv -- $BENCH_N > /dev/null 2> "$OUT/fetch_n.log"
+timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write_n" --output-format csv -- $BENCH_N > /dev/null 2> "$OUT/write_n.log"
+python - "$OUT" "$TAG" <<'PY'
+import csv, glob, json, sys, collections
+out, tag = sys.argv[1], sys.argv[2]
+stats = glob.glob(f"{out}/stats_n/*/*_kernel_stats.csv")[0]
+rows = list(csv.DictReader(open(stats)))
+with open(f"{out}/{tag}_native_kernel_stats.csv", "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+    for r in rows:
+        if "kvc::" in r["Name"] or "rocclr" in r["Name"]:
+            w.writerow([r["Name"][:120], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+def pmc(kind, counter):
+    f = glob.glob(f"{out}/{kind}/*/*_counter_collection.csv")[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in agg.items()}
+fetch, write = pmc("fetch_n", "FETCH_SIZE"), pmc("write_n", "WRITE_SIZE")
+res = {}
+for k in sorted(set(fetch) | set(write)):
+    if "kvc::" in k:
+        fkb, wkb = fetch.get(k, 0.0), write.get(k, 0.0)
+        res[k[:100]] = {"FETCH_SIZE_KB_per_launch": fkb, "WRITE_SIZE_KB_per_launch": wkb,
+                        "hbm_bytes_per_launch": (2.0 * fkb + wkb) * 1024.0}
+dom = [k for k in res if "compact_slots_kernel" in k]
+summary = {"tag": tag, "command": "bench.py --steps 10 --warmup 2 --block-layout slot_major (default workload, slot-major blocks)", "kernels": res}
+if dom:
+    summary["dominant_kernel"] = dom[0]
+    summary["hbm_bytes_per_launch"] = res[dom[0]]["hbm_bytes_per_launch"]
+json.dump(summary, open(f"{out}/{tag}_native_traffic.json", "w"), indent=1)
+print(json.dumps({k: v for k, v in summary.items() if k != "kernels"}))
+PY
 # 3c. config 3 at full size: kernel stats and PMC traffic of the small-eviction schedule
 "$REPO/tools/prof_bench.sh" "${TAG}_c3" --config c3 > "$OUT/${TAG}_c3_stats.txt" 2>&1
 cp "$REPO/gpurun_out/${TAG}_c3_kernel_stats.csv" "$OUT/" 2>/dev/null
@@ -107,6 +147,8 @@ for cfg in "--spare-blocks 30" "--spare-blocks 60" "--batch 4" "--batch 16 --ste
   timeout 900 $B $cfg >> "$OUT/${TAG}_configs.jsonl" 2>> "$OUT/configs.err"
 done
 timeout 600 python tools/bench_attention.py > "$OUT/${TAG}_attention_bench.json" 2> "$OUT/attention.err"
+timeout 600 python tools/bench_attention.py --block-layout slot_major > "$OUT/${TAG}_attention_bench_slot_major.json" 2>> "$OUT/attention.err"
+(python tools/cmp_attention_layouts.py "$OUT/${TAG}_attention_bench.json" "$OUT/${TAG}_attention_bench_slot_major.json" > "$OUT/${TAG}_attention_layouts.txt") 2>> "$OUT/attention.err"
 # 5. config 3 as a whole decode step (S0 + S1 + S2 + S3), two sweeps of the store against harvest-ahead: kernel stats
 #    and the comparison itself                                             -> <tag>_decode_step_c3.json, _kernel_stats.csv
 "$REPO/tools/prof_decode_step.sh" "${TAG}_decode_step" > "$OUT/${TAG}_decode_step_stats.txt" 2>&1
