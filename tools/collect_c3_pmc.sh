@@ -10,7 +10,7 @@ OUT="$REPO/gpurun_out/pmc_$TAG"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $REPO/bench.py --config c3 --steps 6 --warmup 1 --no-cpu-baseline --no-adjacent --no-s0 --no-probe --no-other-configs --no-live-traffic --no-parity-gate $*"
+BENCH="python $REPO/bench.py --config c3 --steps 6 --warmup 1 --no-cpu-baseline --no-adjacent --no-s0 --no-probe --no-other-configs --no-native-layout --no-live-traffic --no-parity-gate $*"
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" --output-format csv -- $BENCH > "$OUT/bench_fetch.json" 2> "$OUT/fetch.log"
 timeout 600 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" --output-format csv -- $BENCH > /dev/null 2> "$OUT/write.log"
 python - "$OUT" "$TAG" "$REPO" "$*" <<'PY'

@@ -18,7 +18,7 @@ export TMPDIR=/tmp
 cd "$REPO"
 timeout 900 python bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
 cd /tmp
-BENCH="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-adjacent --no-s0 --no-probe --no-engine-cache --no-other-configs --no-live-traffic --no-parity-gate"
+BENCH="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-adjacent --no-s0 --no-probe --no-engine-cache --no-other-configs --no-native-layout --no-live-traffic --no-parity-gate"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats" --output-format csv -- $BENCH > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/stats.log"
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" --output-format csv -- $BENCH > /dev/null 2> "$OUT/fetch.log"
 timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$OUT/write" --output-format csv -- $BENCH > /dev/null 2> "$OUT/write.log"
@@ -146,8 +146,8 @@ done
 for cfg in "--spare-blocks 30" "--spare-blocks 60" "--batch 4" "--batch 16 --steady-cap 4096" "--batch 64 --steady-cap 4096" "--config c3" "--config c3 --mode reference" "--config c3 --lean" "--config c3i" "--config c4" "--config c5" "--layers 80 --seq-len 16384 --batch 4"; do
   timeout 900 $B $cfg >> "$OUT/${TAG}_configs.jsonl" 2>> "$OUT/configs.err"
 done
-timeout 600 python tools/bench_attention.py > "$OUT/${TAG}_attention_bench.json" 2> "$OUT/attention.err"
-timeout 600 python tools/bench_attention.py --block-layout slot_major > "$OUT/${TAG}_attention_bench_slot_major.json" 2>> "$OUT/attention.err"
+timeout 600 python tools/bench_attention.py --json "$OUT/${TAG}_attention_bench.json" > /dev/null 2> "$OUT/attention.err"
+timeout 600 python tools/bench_attention.py --block-layout slot_major --json "$OUT/${TAG}_attention_bench_slot_major.json" > /dev/null 2>> "$OUT/attention.err"
 (python tools/cmp_attention_layouts.py "$OUT/${TAG}_attention_bench.json" "$OUT/${TAG}_attention_bench_slot_major.json" > "$OUT/${TAG}_attention_layouts.txt") 2>> "$OUT/attention.err"
 # 5. config 3 as a whole decode step (S0 + S1 + S2 + S3), two sweeps of the store against harvest-ahead: kernel stats
 #    and the comparison itself                                             -> <tag>_decode_step_c3.json, _kernel_stats.csv

@@ -7,7 +7,7 @@ OUT="$REPO/gpurun_out/pmc_$TAG"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $REPO/bench.py --config c3 --steps 3 --warmup 1 --no-cpu-baseline --no-adjacent --no-s0 --no-probe --no-other-configs --no-live-traffic"
+BENCH="python $REPO/bench.py --config c3 --steps 3 --warmup 1 --no-cpu-baseline --no-adjacent --no-s0 --no-probe --no-other-configs --no-native-layout --no-live-traffic"
 timeout 600 rocprofv3 --pmc $CTRS -d "$OUT/pmc" --output-format csv -- $BENCH > /dev/null 2> "$OUT/pmc.log"
 python - "$OUT" "$TAG" "$REPO" <<'PY'
 import csv, glob, sys, collections, json

@@ -8,7 +8,7 @@ OUT="$REPO/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-adjacent --no-s0 --no-probe --no-other-configs --no-live-traffic --no-engine-cache $*"
+BENCH="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-adjacent --no-s0 --no-probe --no-other-configs --no-native-layout --no-live-traffic --no-engine-cache $*"
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/stats" --output-format csv -- $BENCH > "$REPO/gpurun_out/${TAG}.json" 2> "$OUT/stats.log"
 python - "$OUT" "$TAG" "$REPO" <<'PY'
 import csv, glob, sys, json
