@@ -789,7 +789,7 @@ def measure_workload(a2, seed, device, steps, warmup, probe):
         "S1_schedule": ds.cm.last_schedule_path(),
         # (a "[pivots: the call before]" here: the small-eviction schedule did not sample -- on this bench's static store
         # the pivots of the call before are exact; in an engine they are one decode step of attention old, which
-        # profiles/r5_harvest_soak.txt runs for 400 steps of an evolving state without a pass that listed too little)
+        # profiles/r6_harvest_soak.txt runs for 400 steps of an evolving state without a pass that listed too little)
         "S1_schedule_reason": ds.cm.last_schedule_reason,
         # S1 against ITS lower bound (12.75 B per candidate slot)
         "S1_lower_bound_GBps": N * 12.75 / (s1 * 1e-3) / 1e9,
@@ -863,7 +863,7 @@ def measure_workload(a2, seed, device, steps, warmup, probe):
     return res
 
 
-S0_PMC_FILES = ("r5_decode_step_pmc.json", "r4_decode_step_pmc.json")     # newest first
+S0_PMC_FILES = ("r6_decode_step_pmc.json", "r5_decode_step_pmc.json", "r4_decode_step_pmc.json")     # newest first
 
 
 def _committed_s0_traffic(kernel_tag):
