@@ -376,11 +376,10 @@ __global__ __launch_bounds__(256) void count_collect_kernel(kvc_schedule_params 
   static_assert(U >= 1 && HTILE % (4 * CC_RUN) == 0, "a tile is U steps of four waves");
   // heads change rarely: the head of the last step, its slot range and its sequence's bracket stay in
   // (scalar) registers
-  int g = upper_bound_minus1(p.evicted_kv_offsets, G, tb * HTILE);
-  int64_t g_beg = p.evicted_kv_offsets[g];
-  int64_t g_end = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : N;
-  BrRec rc = recs[g / LH];
-  const int g0 = g;                                  // (the same in every wave)
+  // (found below, behind the request for the first tile: what the workgroup takes is a chain of dependent loads)
+  int g = 0, g0 = 0;                                 // g0: the same in every wave
+  int64_t g_beg = 0, g_end = 0;
+  BrRec rc{};
   int acc_g = -1;
   uint32_t acc_b = 0;                                // (per lane)
   auto flush = [&]() {
@@ -433,6 +432,11 @@ __global__ __launch_bounds__(256) void count_collect_kernel(kvc_schedule_params 
     }
   };
   load_tile(kn, tb);
+  g = wave_upper_bound_minus1(p.evicted_kv_offsets, G, tb * HTILE);
+  g_beg = p.evicted_kv_offsets[g];
+  g_end = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : N;
+  rc = recs[g / LH];
+  g0 = g;
   for (int64_t t = tb; t < te; ++t) {
     const int64_t t0 = t * HTILE;
 #pragma unroll

@@ -295,7 +295,7 @@ __device__ __forceinline__ void hist_round_body(const kvc_schedule_params& p, Sc
   const int64_t ntiles = (N + HTILE - 1) / HTILE;
   const int64_t tb = ntiles * bid / nb, te = ntiles * (bid + 1) / nb;
   if (tb >= te) return;
-  int g = upper_bound_minus1(p.evicted_kv_offsets, G, tb * HTILE);
+  int g = wave_upper_bound_minus1(p.evicted_kv_offsets, G, tb * HTILE);
   int64_t g_end = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : N;
   int cur_g = -1;                                   // head whose counts sit in sh
   auto flush = [&]() {                              // uniform call sites only
