@@ -2,7 +2,8 @@
 """Soak: random decode-attention shapes (GQA group sizes 1..16, head sizes 64/128, block sizes
 16/32, contexts from 1 to 9000 tokens, fp16/bf16, metric windows, ALiBi, both kernel
 schedules incl. the 8-wave single-pass variant) against the oracle.
-Run on the GPU box:  python tools/soak_attention.py [ncases]"""
+Run on the GPU box:  python tools/soak_attention.py [ncases] [--layout slot_major]
+(--layout slot_major: the caches permuted into slot-major blocks and the package switched to that layout)"""
 import os
 import sys
 import time
@@ -17,7 +18,15 @@ from tests.test_gpu_attention import _run_gpu, _set_mode             # noqa: E40
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    layout = "slot_major" if "slot_major" in sys.argv[1:] else "reference"
+    n = int(argv[0]) if argv and argv[0].isdigit() else 100
+    run = _run_gpu
+    if layout == "slot_major":
+        from vllm_kvcompress_amd import _lib
+        from tests.test_gpu_slot_major import _attn
+        _lib.set_block_layout("slot_major")
+        run = _attn
     t0 = time.time()
     worst_w, worst_o = 0.0, 0.0
     for seed in range(n):
@@ -36,7 +45,7 @@ def main():
         ref_out, ref_km = oracle_decode(c, g, pos, last, buf)
         for mode in (1, 2):
             _set_mode(mode)
-            out, km = _run_gpu(g, c, pos, last, buf, "v1" if seed % 2 else "v2")
+            out, km = run(g, c, pos, last, buf, "v1" if seed % 2 else "v2")
             same = ((ref_km == -1.0) == (km == -1.0)).all()
             rec = ref_km != -1.0
             ew = float(np.max(np.abs(km[rec] - ref_km[rec]) / (np.abs(ref_km[rec]) + 1e-9))) if rec.any() else 0.0
@@ -50,7 +59,7 @@ def main():
                 _set_mode(0)
                 sys.exit(1)
     _set_mode(0)
-    print(f"soak ok: {n} attention cases x 2 schedules within tolerance in {time.time() - t0:.1f} s "
+    print(f"soak ok ({layout} blocks): {n} attention cases x 2 schedules within tolerance in {time.time() - t0:.1f} s "
           f"(worst weight rel err {worst_w:.2g}, worst output err {worst_o:.2g} of tolerance)")
 
 
