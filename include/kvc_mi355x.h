@@ -36,7 +36,7 @@ typedef void* kvc_stream_t; /* hipStream_t */
 /* The ABI this header describes; kvc_abi_version() of the library loaded at run time must return it
  * (kvc_schedule_params grew fields in the middle between versions: a host built against another
  * version must not call in).  The Python binding and tests/cabi/cabi_host.cpp check it at start-up. */
-#define KVC_ABI_VERSION 7
+#define KVC_ABI_VERSION 8
 
 int kvc_abi_version(void);
 const char* kvc_last_error(void);
@@ -374,6 +374,20 @@ typedef struct kvc_schedule_params {
   int32_t* evicted_logical_indices;           /* [N] */
   int32_t* evicted_kv_count;                  /* [B,L,H] */
   int32_t* evicted_block_count;               /* [B,L,H] */
+  const int64_t* total_slots_dev;             /* ABI version 8, optional (NULL: total_slots is N).  A host that holds its batch
+                                               * as device tensors only (the fork's scheduler) learns N from the device; with
+                                               * this field it does not have to WAIT for it before it launches: total_slots is
+                                               * then an UPPER BOUND (a multiple of block_size) that sizes the scratch layout,
+                                               * the grids and evicted_logical_indices ([total_slots]; entries from N on are
+                                               * left untouched), and the kernels take the true N from total_slots_dev[0] --
+                                               * device memory written EARLIER ON THE SAME STREAM by
+                                               * kvc_schedule_batch_summary_deferred.  total_slots_dev[1] != 0 (N exceeded
+                                               * the bound) voids the call: every kernel returns at once, the outputs are
+                                               * unspecified and the caller repeats the call with the N it has read meanwhile.
+                                               * For the digit rounds and the bracket schedule without the reference's batch > 1
+                                               * rule: max_evicted_blocks_hint must be -1 (the small-eviction schedule is chosen
+                                               * from host-side counts), mode 0 with num_seqs > 1, uniform_evict, block_tables
+                                               * and harvest bits are refused. */
 } kvc_schedule_params;
 
 size_t kvc_schedule_evictions_workspace_bytes(int64_t total_slots, int32_t total_heads,
@@ -408,6 +422,14 @@ int kvc_schedule_batch_summary_wait(kvc_stream_t stream);
 int kvc_schedule_batch_summary_ticket(const int32_t* context_lens, int32_t total_heads, int32_t block_size,
                                       const int32_t* evicted_blocks_per_seq, int32_t num_seqs,
                                       int64_t* host_mapped_out, int64_t ticket, kvc_stream_t stream);
+/* ABI version 8: the same launch, which also leaves N where the schedule's kernels can read it:
+ * total_slots_dev[0] = N, total_slots_dev[1] = (N > total_slots_bound) -- two int64 of DEVICE memory, read by a
+ * kvc_schedule_evictions call enqueued behind it with kvc_schedule_params.total_slots_dev.  The host enqueues both
+ * back to back and polls the ticket while the device works. */
+int kvc_schedule_batch_summary_deferred(const int32_t* context_lens, int32_t total_heads, int32_t block_size,
+                                        const int32_t* evicted_blocks_per_seq, int32_t num_seqs,
+                                        int64_t* host_mapped_out, int64_t ticket, int64_t* total_slots_dev,
+                                        int64_t total_slots_bound, kvc_stream_t stream);
 /* Harvest-ahead (ABI version 5).  Continual compression streams the whole metric store twice per
  * decode step: aggregate_decode adds the step's attention to it, and a moment later the
  * small-eviction schedule reads it all again to find the ~1 % of the keys that lie below each

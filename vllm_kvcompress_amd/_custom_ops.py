@@ -23,7 +23,35 @@ _WORKSPACES = {}
 
 
 def _stream(t: torch.Tensor) -> int:
-    return torch.cuda.current_stream(t.device).cuda_stream
+    # (the raw handle straight from the binding: torch.cuda.current_stream() builds a Stream object per call, and with a
+    # device that has no index it walks through torch.cuda.is_available() -- an os.getenv -- every time)
+    index = t.device.index
+    return torch._C._cuda_getCurrentRawStream(index if index is not None else torch._C._cuda_getDevice())
+
+
+class on_device:
+    """``with torch.cuda.device(d):`` for launches through the C ABI, without that context manager's bookkeeping when
+    ``d`` is the current device already -- one process per GPU: always -- (a few microseconds in front of the first launch
+    of every op, on a host path that an idle device waits for)"""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, device):
+        if isinstance(device, int):
+            self.idx = device
+        else:
+            idx = device.index if isinstance(device, torch.device) else torch.device(device).index
+            self.idx = idx if idx is not None else torch._C._cuda_getDevice()
+
+    def __enter__(self):
+        self.prev = torch._C._cuda_getDevice()
+        if self.prev != self.idx:
+            torch.cuda.set_device(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev != self.idx:
+            torch.cuda.set_device(self.prev)
+        return False
 
 
 def _written(*tensors: torch.Tensor) -> None:
@@ -63,13 +91,12 @@ def workspace(device: torch.device, nbytes: int, tag: str) -> torch.Tensor:
     different streams never share scratch; a buffer that is outgrown stays referenced by the
     caching allocator's stream ordering until the kernels already enqueued on it have run
     (``record_stream``)."""
-    index = device.index if device.index is not None else torch.cuda.current_device()
-    stream = torch.cuda.current_stream(index)
-    key = (index, stream.cuda_stream, tag)
+    index = device.index if device.index is not None else torch._C._cuda_getDevice()
+    key = (index, torch._C._cuda_getCurrentRawStream(index), tag)
     buf = _WORKSPACES.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:
-            buf.record_stream(stream)
+            buf.record_stream(torch.cuda.current_stream(index))
         buf = torch.empty(max(int(nbytes * 1.25), 4096), dtype=torch.uint8,
                           device=torch.device("cuda", index))
         _WORKSPACES[key] = buf
@@ -90,7 +117,7 @@ def reserve_workspace(device: torch.device, nbytes: int, tag: str) -> None:
     workspace(device, nbytes, tag)
     if _compiled_binding():
         like = torch.empty(0, dtype=torch.uint8, device=device)
-        with torch.cuda.device(device):
+        with on_device(device):
             torch.ops._kvc_mi355x.reserve_workspace(like, int(nbytes), tag)
 
 
@@ -125,7 +152,7 @@ def count_block_evictions(
     eli = evicted_logical_indices
     offs = evicted_kv_offsets.contiguous()
     hang = hanging_token_count.contiguous()
-    with torch.cuda.device(eli.device):
+    with on_device(eli.device):
         _lib.check(lib.kvc_count_block_evictions(
             evicted_block_count.data_ptr(), eli.data_ptr(), offs.data_ptr(), hang.data_ptr(),
             evicted_block_count.numel(), eli.numel(), int(block_size), int(null_value),
@@ -244,7 +271,7 @@ def _schedule_t1_cache_moves(cache_moves_idx, cache_moves_count, evicted_logical
             rec.block_size = bs
         dmap = rec.dirty_map
     plan = workspace(dev, int(lib.kvc_cache_moves_plan_bytes()), "cache_moves_plan")
-    with torch.cuda.device(dev):
+    with on_device(dev):
         _lib.check(lib.kvc_schedule_t1_cache_moves_ex(
             cache_moves_idx.data_ptr(), rows, cache_moves_count.data_ptr(),
             _contig(evicted_logical_indices, keep).data_ptr(),
@@ -329,7 +356,7 @@ def _execute_cache_moves(k_cache, v_cache, kv_metrics, kv_position, cache_moves_
         # a slot is two contiguous runs of hd * e bytes: the kernel copies exactly the moved bytes (no block images,
         # no claim table); without a plan of the list's own, one small launch makes one
         ws = workspace(k_cache.device, int(lib.kvc_cache_moves_plan_bytes()), "execute_cache_moves_slot_major")
-        with torch.cuda.device(k_cache.device):
+        with on_device(k_cache.device):
             if plan is None and half in ("plan", "both"):
                 _lib.check(lib.kvc_execute_cache_moves_slot_major_plan(cmc.data_ptr(), total_heads, ws.data_ptr(),
                                                                        ws.numel(), _stream(k_cache)))
@@ -342,7 +369,7 @@ def _execute_cache_moves(k_cache, v_cache, kv_metrics, kv_position, cache_moves_
         return
     if plan is not None:
         if half != "plan":
-            with torch.cuda.device(k_cache.device):
+            with on_device(k_cache.device):
                 _lib.check(lib.kvc_execute_cache_moves_planned(
                     k_cache.data_ptr(), v_cache.data_ptr(), kv_metrics.data_ptr(), kv_position.data_ptr(),
                     cmi.data_ptr(), cmc.data_ptr(), offs.data_ptr(), total_heads, num_blocks, block_size,
@@ -352,7 +379,7 @@ def _execute_cache_moves(k_cache, v_cache, kv_metrics, kv_position, cache_moves_
     ws = workspace(k_cache.device, ws_bytes, "execute_cache_moves")
     shape = (total_heads, num_blocks, block_size, head_size, k_cache.element_size(), vec,
              ws.data_ptr(), ws.numel(), _stream(k_cache))
-    with torch.cuda.device(k_cache.device):
+    with on_device(k_cache.device):
         if half == "plan":
             _lib.check(lib.kvc_execute_cache_moves_plan(cmi.data_ptr(), cmc.data_ptr(),
                                                         offs.data_ptr(), *shape))
@@ -396,7 +423,7 @@ def reshape_and_cache_kvc(
         if key.dtype != key_cache.dtype or value.dtype != value_cache.dtype:
             raise RuntimeError("reshape_and_cache_kvc: kv_cache_dtype 'auto' needs cache dtype == "
                                "key/value dtype")
-        with torch.cuda.device(key.device):
+        with on_device(key.device):
             _lib.check(lib.kvc_reshape_and_cache_layout(
                 key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
                 kv_metrics.data_ptr(), sm.data_ptr(), hb.data_ptr(), num_tokens, num_heads,
@@ -411,7 +438,7 @@ def reshape_and_cache_kvc(
         raise RuntimeError(f"Unsupported input type of kv cache: {key.dtype}")
     if key_cache.element_size() != 1 or value_cache.element_size() != 1:
         raise RuntimeError("reshape_and_cache_kvc: an fp8 kv cache must have 1-byte elements")
-    with torch.cuda.device(key.device):
+    with on_device(key.device):
         _lib.check(lib.kvc_reshape_and_cache_fp8_layout(
             key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
             kv_metrics.data_ptr(), sm.data_ptr(), hb.data_ptr(), num_tokens, num_heads, head_size,
@@ -522,7 +549,7 @@ def _paged_attention_kvc(out, kv_metric_out, exp_sum, max_logits, tmp_out, tmp_k
         p.harvest_num_protected = harvest.num_protected.data_ptr()
         p.harvest_num_seqs, p.harvest_layer = harvest.num_seqs, int(layer)
         p.harvest_num_layers, p.harvest_num_sinks = harvest.num_layers, harvest.num_sinks
-    with torch.cuda.device(query.device):
+    with on_device(query.device):
         _lib.check(lib.kvc_paged_attention_decode(p, _stream(query)))
     if harvest is not None:
         harvest.layers_done.add(int(layer))

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KVC_MI355X_LIB", os.path.join(_HERE, "libkvc_mi355x.so"))
 
 MAX_INT = 2147483000  # reference vllm/kvcompress/metrics.py:12
-ABI_VERSION = 7       # KVC_ABI_VERSION of include/kvc_mi355x.h: the struct layouts mirrored below
+ABI_VERSION = 8       # KVC_ABI_VERSION of include/kvc_mi355x.h: the struct layouts mirrored below
 
 # KVC_LAYOUT_* of include/kvc_mi355x.h: how the bytes INSIDE a cache block are laid out.  The fork hands the ops
 # views of an opaque [2, NB, bs * hd] tensor (reference vllm/attention/ops/paged_attn.py:262-284); the three ops that
@@ -86,6 +86,7 @@ class KvcScheduleParams(ctypes.Structure):
         ("harvest_position_delta", c_int32),
         ("evicted_logical_indices", c_void_p), ("evicted_kv_count", c_void_p),
         ("evicted_block_count", c_void_p),
+        ("total_slots_dev", c_void_p),
     ]
 
 
@@ -152,6 +153,8 @@ SYMBOLS = {
     "kvc_schedule_batch_summary": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32,
                                              c_void_p, c_size_t, c_void_p]),
     "kvc_schedule_batch_summary_wait": (c_int32, [c_void_p]),
+    "kvc_schedule_batch_summary_deferred": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int64,
+                                                      c_void_p, c_int64, c_void_p]),
     "kvc_schedule_batch_summary_ticket": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
     "kvc_schedule_evictions_uses_small_eviction_schedule": (c_int32, [ctypes.POINTER(KvcScheduleParams)]),
     "kvc_schedule_evictions_plan": (c_int32, [ctypes.POINTER(KvcScheduleParams)]),

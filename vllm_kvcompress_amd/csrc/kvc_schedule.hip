@@ -364,7 +364,8 @@ extern "C" size_t kvc_schedule_evictions_workspace_bytes(int64_t total_slots, in
 namespace kvc {
 __global__ __launch_bounds__(1024) void batch_summary_kernel(const int32_t* __restrict__ context_lens, int total_heads,
                                                              int bs, const int32_t* __restrict__ k_per_seq, int num_seqs,
-                                                             int64_t* __restrict__ out, int64_t ticket) {
+                                                             int64_t* __restrict__ out, int64_t ticket,
+                                                             int64_t* __restrict__ n_dev = nullptr, int64_t n_bound = 0) {
   __shared__ unsigned long long part[16];
   unsigned long long blocks = 0;
   const int n4 = (reinterpret_cast<uintptr_t>(context_lens) & 15) == 0 ? total_heads / 4 : 0;
@@ -390,6 +391,8 @@ __global__ __launch_bounds__(1024) void batch_summary_kernel(const int32_t* __re
 #pragma unroll
     for (int w = 0; w < 16; ++w) t += part[w];
     out[0] = (int64_t)t * bs;
+    // ABI version 8: N for the schedule's kernels behind this launch (and whether the host's bound holds)
+    if (n_dev != nullptr) { n_dev[0] = (int64_t)t * bs; n_dev[1] = (int64_t)t * bs > n_bound ? 1 : 0; }
     if (ticket) {
       // a host that polls the ticket word sees the numbers a memory round trip after this store, without waiting
       // for the kernel's end-of-grid signal to travel through the runtime
@@ -439,6 +442,20 @@ extern "C" int kvc_schedule_batch_summary_ticket(const int32_t* context_lens, in
   return check_launch("schedule_batch_summary");
 }
 
+extern "C" int kvc_schedule_batch_summary_deferred(const int32_t* context_lens, int32_t total_heads, int32_t block_size,
+                                                   const int32_t* evicted_blocks_per_seq, int32_t num_seqs,
+                                                   int64_t* host_mapped_out, int64_t ticket, int64_t* total_slots_dev,
+                                                   int64_t total_slots_bound, kvc_stream_t stream) {
+  using namespace kvc;
+  if (block_size < 1) return fail_invalid("Unsupported block size: " + std::to_string(block_size));
+  if (context_lens == nullptr || total_heads < 0 || num_seqs < 0 || host_mapped_out == nullptr || ticket == 0 ||
+      total_slots_dev == nullptr || total_slots_bound < 0 || (num_seqs > 0 && evicted_blocks_per_seq == nullptr))
+    return fail_invalid("schedule_batch_summary: bad arguments");
+  batch_summary_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(context_lens, total_heads, block_size, evicted_blocks_per_seq,
+                                                            num_seqs, host_mapped_out, ticket, total_slots_dev, total_slots_bound);
+  return check_launch("schedule_batch_summary");
+}
+
 extern "C" int kvc_schedule_batch_summary_wait(kvc_stream_t stream) {
   const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
   if (e != hipSuccess) {
@@ -461,6 +478,14 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
     return fail_invalid("schedule_evictions: total slots must stay below 2^31 (int32 offsets)");
   if (p.total_slots % p.block_size != 0)
     return fail_invalid("schedule_evictions: total_slots must be a multiple of block_size");
+  if (p.total_slots_dev != nullptr) {
+    // ABI version 8: total_slots is a bound, N is on the device.  The schedules that take their decisions from N on the
+    // device take it (digit rounds, bracket); the rest is the host's to avoid.
+    if (p.max_evicted_blocks_hint >= 0 || (p.mode == 0 && p.num_seqs > 1) || p.uniform_evict || p.block_tables != nullptr ||
+        (p.harvest & 5) != 0 || p.eli_dirty_map != nullptr || p.total_slots == 0)
+      return fail_invalid("schedule_evictions: total_slots_dev goes with max_evicted_blocks_hint = -1, mode 1 or one sequence, "
+                          "no uniform_evict, no block_tables, no harvested lists / remembered pivots, no dirty map, a bound > 0");
+  }
   const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
   const int B = p.num_seqs;
   const WsLayout l = ws_layout(p.total_slots, G, B, p.block_size);
@@ -495,6 +520,7 @@ extern "C" int kvc_schedule_evictions(const kvc_schedule_params* pp, void* works
   ws.blist = reinterpret_cast<uint32_t*>(wb + l.blist);
   ws.bthr = reinterpret_cast<uint32_t*>(wb + l.bthr);
   ws.gate = nullptr;
+  ws.n_dev = p.total_slots_dev;
   ws.hv_seen_ctx = nullptr;
   ws.hv_seen_seq = nullptr;
   if (p.total_slots == 0) {

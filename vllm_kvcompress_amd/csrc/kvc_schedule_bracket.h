@@ -183,6 +183,7 @@ __device__ __forceinline__ void reg_rank_select2(uint32_t (&key)[R], uint32_t fi
 // (A chunk no physical block claims keeps its 0xFFFFFFFF keys, which nobody counted: count_collect
 // raises the flag when it meets one, and the digit rounds redo the call.)
 __global__ __launch_bounds__(256) void bracket_totals_kernel(kvc_schedule_params p, SchedWs ws) {
+  if (voided(ws)) return;
   __shared__ uint32_t red_s[2];
   const int i = blockIdx.x, tid = threadIdx.x, lane = lane_id();
   const int B = p.num_seqs, H = p.num_kv_heads, LH = p.num_layers * H, bs = p.block_size;
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void bracket_totals_kernel(kvc_schedule_params
   for (int lh = tid; lh < LH; lh += blockDim.x) {
     const int g = i * LH + lh;
     const int64_t b = p.evicted_kv_offsets[g];
-    const int64_t e = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : p.total_slots;
+    const int64_t e = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : true_n(p, ws);
     const uint32_t slots = (uint32_t)(e - b), nonfin = ws.bnonfin[g];
     const int ctx = p.context_lens[((lh / H) * B + i) * H + (lh % H)];
     f += nchunks_freed(slots > nonfin ? slots - nonfin : 0u, (uint32_t)p.hanging_token_count[g], (uint32_t)bs);
@@ -215,6 +216,7 @@ __global__ __launch_bounds__(256) void bracket_totals_kernel(kvc_schedule_params
 // behind it (the heads' three, the flag and the barrier words).
 constexpr int BR_R = BR_CELLS / 1024;                // sample keys per thread
 __global__ __launch_bounds__(1024) void bracket_kernel(kvc_schedule_params p, SchedWs ws) {
+  if (voided(ws)) return;
   __shared__ __attribute__((aligned(16))) uint32_t priv[2 * PRIV_WORDS];
   __shared__ __attribute__((aligned(16))) uint32_t hist[2 * RADIX];
   __shared__ uint32_t bc[6];
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(1024) void bracket_kernel(kvc_schedule_params p, Sc
   const int i = blockIdx.x, tid = threadIdx.x, lane = lane_id();
   const int B = p.num_seqs, H = p.num_kv_heads, LH = p.num_layers * H, bs = p.block_size;
   const int64_t base = p.evicted_kv_offsets[i * LH];
-  const int64_t end = i + 1 < B ? (int64_t)p.evicted_kv_offsets[(i + 1) * LH] : p.total_slots;
+  const int64_t end = i + 1 < B ? (int64_t)p.evicted_kv_offsets[(i + 1) * LH] : true_n(p, ws);
   const uint32_t n = (uint32_t)(end - base);
   BR_STAMP(0);
   if (tid < 3) red_s[tid] = 0;
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(1024) void bracket_kernel(kvc_schedule_params p, Sc
     static_assert(CLAIM_SHARDS == WAVE, "one shard per lane");
     const uint32_t c = wave_reduce_sum(ws.bclaim[tid * 32]);
     ws.bclaim[tid * 32] = 0u;
-    if (tid == 0 && (int64_t)c != p.total_slots / bs) atomicOr(ws.fallback, 1u | FB_HOLES_BIT);
+    if (tid == 0 && (int64_t)c != true_n(p, ws) / bs) atomicOr(ws.fallback, 1u | FB_HOLES_BIT);
   }
   {
     uint32_t hs = 0, la = 0;                         // sum of hang, heads that hold anything
@@ -307,11 +309,12 @@ __global__ __launch_bounds__(1024) void bracket_kernel(kvc_schedule_params p, Sc
 constexpr int CC_RUN = 256;                          // keys per wave step
 constexpr int CC_QUEUE = 64 + CC_RUN;
 __global__ __launch_bounds__(256) void count_collect_kernel(kvc_schedule_params p, SchedWs ws) {
+  if (voided(ws)) return;
   __shared__ uint32_t qk[4][CC_QUEUE], qg[4][CC_QUEUE];
   __shared__ uint32_t wg_below[8];                   // the workgroup's first eight heads: one global add each
   const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
   const int LH = p.num_layers * p.num_kv_heads;
-  const int64_t N = p.total_slots;
+  const int64_t N = true_n(p, ws);
   const int lane = lane_id(), w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const BrRec* recs = reinterpret_cast<const BrRec*>(ws.st_seqrec);
   const int64_t ntiles = (N + HTILE - 1) / HTILE;
@@ -547,13 +550,14 @@ __device__ __forceinline__ void bracket_thresholds(uint32_t below, uint32_t m, u
 // kernel is one workgroup per sequence and would fetch a 64-byte line per threshold otherwise
 // (9 us at config 2's 13.8 k thresholds)
 __global__ __launch_bounds__(512) void bracket_records_kernel(kvc_schedule_params p, SchedWs ws) {
+  if (voided(ws)) return;
   __shared__ uint32_t a[BR_SORT_MAX], tmp[BR_SORT_MAX], cnt[BR_SORT_MAX + 1];
   __shared__ uint32_t wtot[8];
   const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
   const int g = blockIdx.x;
   BR_STAMP(16);
   const int64_t base = p.evicted_kv_offsets[g];
-  const int64_t end = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : p.total_slots;
+  const int64_t end = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : true_n(p, ws);
   const uint32_t m = ws.st_cnt[g];
   const uint32_t below = ws.st_def[g];
   const uint32_t hang = (uint32_t)p.hanging_token_count[g];
@@ -586,6 +590,7 @@ __global__ __launch_bounds__(512) void bracket_records_kernel(kvc_schedule_param
 // k' -- finalize_body's rule.                                        metrics.py:671-729, 773-792
 // dynamic LDS: arr[P] thresholds, head-major; tpre[LH + 1]
 __global__ __launch_bounds__(1024) void bracket_select_kernel(kvc_schedule_params p, SchedWs ws, int P) {
+  if (voided(ws)) return;
   extern __shared__ __attribute__((aligned(16))) uint8_t sel_lds[];
   uint32_t* arr = reinterpret_cast<uint32_t*>(sel_lds);
   uint32_t* tpre = arr + P;                                             // [LH + 1] exclusive prefix of the heads' listed thresholds
@@ -608,7 +613,7 @@ __global__ __launch_bounds__(1024) void bracket_select_kernel(kvc_schedule_param
   if (tid < LH) {
     const int g = i * LH + tid;
     const int64_t b = p.evicted_kv_offsets[g];
-    const int64_t e = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : p.total_slots;
+    const int64_t e = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : true_n(p, ws);
     const uint32_t below = ws.st_def[g];
     const uint32_t m = min(ws.st_cnt[g], bracket_cap((uint32_t)(e - b)));
     hang = (uint32_t)p.hanging_token_count[g];

@@ -42,6 +42,7 @@ struct SchedWs {
   uint32_t* fallback;    // [1]      != 0: the small-eviction schedule could not finish exactly
   uint32_t* bar;         // [32+64]  single-launch fallback: phase stamps, then claim / done counters of its phases
   const uint32_t* gate;  // general-path kernels run only if gate == nullptr or *gate != 0
+  const int64_t* n_dev;  // kvc_schedule_params.total_slots_dev (ABI 8): [0] the true N, [1] != 0: the call is void; nullptr: total_slots is N
   const int32_t* hv_seen_ctx;   // [G] lists made by the attention's epilogue: the context length every head's list was made
   const int32_t* hv_seen_seq;   // [2B] with, every sequence's (position, protected window) -- or nullptr: nothing to verify
 };
@@ -51,7 +52,15 @@ struct SchedWs {
 // the fallback makes keys, chunk table and holes anew instead of starting from the keys that exist
 constexpr uint32_t FB_HOLES_BIT = 8u;
 
-__device__ __forceinline__ bool gated_off(const SchedWs& ws) { return ws.gate != nullptr && *ws.gate == 0u; }
+// N as the kernels see it: a host that launches before it knows N passes an upper bound in total_slots (the layout,
+// the grids) and the number itself through device memory (kvc_schedule_params.total_slots_dev, ABI version 8)
+__device__ __forceinline__ int64_t true_n(const kvc_schedule_params& p, const SchedWs& ws) {
+  return ws.n_dev != nullptr ? ws.n_dev[0] : p.total_slots;
+}
+// ... and a bound that turned out too small voids the call: nothing is read or written
+__device__ __forceinline__ bool voided(const SchedWs& ws) { return ws.n_dev != nullptr && ws.n_dev[1] != 0; }
+
+__device__ __forceinline__ bool gated_off(const SchedWs& ws) { return voided(ws) || (ws.gate != nullptr && *ws.gate == 0u); }
 
 // bracket schedule (section 9): the bracket list of head g (its slots start at off_g) lives at
 // blist + off_g / BR_DIV + g * BR_PAD and holds an eighth of the head's slots plus BR_PAD entries,

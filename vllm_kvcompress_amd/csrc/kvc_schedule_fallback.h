@@ -77,13 +77,14 @@ __device__ __forceinline__ bool fb_phase(const FbSync& fs, uint32_t phase, uint3
 }
 
 // the schedule that evicts nothing (what a call leaves behind when a wait was given up)
-__device__ __forceinline__ void fb_void_outputs(const kvc_schedule_params& p, unsigned bid, unsigned nb) {
+__device__ __forceinline__ void fb_void_outputs(const kvc_schedule_params& p, const SchedWs& ws, unsigned bid, unsigned nb) {
   const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
   for (int64_t g = (int64_t)bid * 256 + threadIdx.x; g < G; g += (int64_t)nb * 256) {
     p.evicted_kv_count[g] = 0;
     p.evicted_block_count[g] = 0;
   }
-  for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < p.total_slots; i += (int64_t)nb * 256)
+  const int64_t N = true_n(p, ws);
+  for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < N; i += (int64_t)nb * 256)
     p.evicted_logical_indices[i] = p.null_value;
 }
 
@@ -93,6 +94,7 @@ constexpr int FB_MAX_COUPLED = 256;                  // sequences whose batch > 
 __global__ __launch_bounds__(256, 2) void fallback_general_kernel(kvc_schedule_params p, SchedWs ws, int sparse,
                                                                uint4* zero16, int64_t zero_vecs, int have_keys,
                                                                unsigned vgrid, uint32_t* hv_pivot) {
+  if (voided(ws)) return;
   const uint32_t flag0 = __hip_atomic_load(ws.fallback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (flag0 == 0u) return;                           // flag down: this launch is all the fallback costs
   // The pivots this call left for the next one were computed from lists that just turned out not to be trustworthy
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void fallback_general_kernel(kvc_schedule_p
   __shared__ uint32_t word_s;
   const bool coupled = p.mode == 0 && p.num_seqs > 1;
   const unsigned bid = blockIdx.x, nb = gridDim.x;
-  if (flag0 & FB_TIMEOUT_BIT) { fb_void_outputs(p, bid, nb); return; }
+  if (flag0 & FB_TIMEOUT_BIT) { fb_void_outputs(p, ws, bid, nb); return; }
   FbSync fs;
   fs.claim = ws.bar + 32;
   fs.done = ws.bar + 32 + FB_PHASES;
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void fallback_general_kernel(kvc_schedule_p
     // the same for all workgroups) -> nothing to clear, nothing to fix: two phases less
     uint32_t claimed = 0;
     for (int q = 0; q < CLAIM_SHARDS; ++q) claimed += ws.st_claimed[q * 32];
-    const bool holes = (int64_t)claimed != p.total_slots / p.block_size && !(p.lean & 2);
+    const bool holes = (int64_t)claimed != true_n(p, ws) / p.block_size && !(p.lean & 2);
     auto keys = [&](unsigned v, unsigned V) {
       if (sparse) build_keys_sparse_body(p, ws, v, V);
       else build_keys_body<4>(p, ws, v, V);
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void fallback_general_kernel(kvc_schedule_p
       });
     }
   }
-  if (!alive) { fb_void_outputs(p, bid, nb); return; }
+  if (!alive) { fb_void_outputs(p, ws, bid, nb); return; }
   // the last phase: nobody waits for it (the kernel's end does)
   for (;;) {
     __syncthreads();

@@ -36,7 +36,7 @@ __device__ __forceinline__ void zero_body(uint4* zero16, int64_t zero_vecs, unsi
 __device__ __forceinline__ void sample_keys(const kvc_schedule_params& p, SchedWs& ws, int i, int64_t dst, const uint4& k) {
   const int LH = p.num_layers * p.num_kv_heads;
   const int64_t sb = p.evicted_kv_offsets[i * LH];
-  const int64_t se = i + 1 < p.num_seqs ? (int64_t)p.evicted_kv_offsets[(i + 1) * LH] : p.total_slots;
+  const int64_t se = i + 1 < p.num_seqs ? (int64_t)p.evicted_kv_offsets[(i + 1) * LH] : true_n(p, ws);
   const int lg = bracket_stride_log2((uint32_t)(se - sb));
   const uint32_t at0 = (uint32_t)(dst - sb);
   const uint32_t cell = at0 >> lg;
@@ -46,7 +46,7 @@ __device__ __forceinline__ void sample_keys(const kvc_schedule_params& p, SchedW
 __device__ __forceinline__ void sample_key(const kvc_schedule_params& p, SchedWs& ws, int i, int64_t dst, uint32_t k) {
   const int LH = p.num_layers * p.num_kv_heads;
   const int64_t sb = p.evicted_kv_offsets[i * LH];
-  const int64_t se = i + 1 < p.num_seqs ? (int64_t)p.evicted_kv_offsets[(i + 1) * LH] : p.total_slots;
+  const int64_t se = i + 1 < p.num_seqs ? (int64_t)p.evicted_kv_offsets[(i + 1) * LH] : true_n(p, ws);
   const int lg = bracket_stride_log2((uint32_t)(se - sb));
   const uint32_t at = (uint32_t)(dst - sb);
   const uint32_t cell = at >> lg;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void build_keys_tables_kernel(kvc_schedule_par
     return;
   }
   const int H = p.num_kv_heads, LH = p.num_layers * H, G = p.num_seqs * LH, bs = p.block_size;
-  const int64_t N = p.total_slots;
+  const int64_t N = true_n(p, ws);
   for (int64_t t0 = (int64_t)blockIdx.x * 1024; t0 < N; t0 += (int64_t)data_blocks * 1024) {
     const int64_t idx0 = t0 + 4 * threadIdx.x;
     if (idx0 >= N) continue;
@@ -290,7 +290,7 @@ __device__ __forceinline__ void hist_round_body(const kvc_schedule_params& p, Sc
   __shared__ uint32_t sh[RADIX];
   const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
   const int LH = p.num_layers * p.num_kv_heads;
-  const int64_t N = p.total_slots;
+  const int64_t N = true_n(p, ws);
   const int shift = 24 - 8 * round;
   const int64_t ntiles = (N + HTILE - 1) / HTILE;
   const int64_t tb = ntiles * bid / nb, te = ntiles * (bid + 1) / nb;
@@ -732,7 +732,7 @@ __device__ __forceinline__ void select_emit_head(const kvc_schedule_params& p, S
   const int G = p.num_seqs * p.num_layers * p.num_kv_heads;
   const int bs = p.block_size;
   const int64_t base = p.evicted_kv_offsets[g];
-  const int64_t end = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : p.total_slots;
+  const int64_t end = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : true_n(p, ws);
   const int n = (int)(end - base);
   const uint32_t cnt = (uint32_t)p.evicted_kv_count[g];
   const uint32_t* gkeys = ws.keys + base;

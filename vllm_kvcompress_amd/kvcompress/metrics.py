@@ -12,6 +12,7 @@ calls into ``libkvc_mi355x.so``.
 from __future__ import annotations
 
 import ctypes
+import math
 import os
 import time
 from dataclasses import dataclass
@@ -21,7 +22,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from .._custom_ops import _stream, workspace
+from .._custom_ops import _stream, on_device, workspace
 from .._lib import MAX_INT, KvcScheduleParams
 
 _BIAS_KEY = "bias"                 # reference metrics.py:13-14
@@ -198,6 +199,19 @@ class CompressionMetrics:
         self.reuse_output_buffer = os.environ.get("KVC_REUSE_OUTPUT_BUFFER", "1") not in ("", "0")
         self._eli_buf = None          # (buffer, dirty map, block size, storage use count when only we hold it, stream, version)
         self._small_cache = {}
+        # The fork's call (device tensor of counts, no N) without a wait in front of the launches (ABI version 8): the
+        # schedule is enqueued on an upper bound of N -- 1.25 x the largest N a batch of this size has had -- right behind
+        # the summary launch that leaves the true N on the device; the host reads N while the device works and hands out
+        # evicted_logical_indices[:N].  A bound that turns out too small voids the call on the device and it is repeated
+        # the waiting way.  For the digit rounds and the bracket schedule (the small-eviction schedule is chosen from the
+        # host-side counts); results are the same either way.  KVC_DEFERRED_N=0 / cm.deferred_n = False turns it off.
+        self.deferred_n = os.environ.get("KVC_DEFERRED_N", "1") not in ("", "0")
+        self._dn_bound = {}            # batch size -> bound on N (a multiple of 64 Ki slots)
+        self._dn_plan = {}             # batch size -> the schedule the last call's true N and counts pick (0 / 1 / 2)
+        self._dn_dev = None            # [2] int64 on the device: N, void
+        self._dn_sizes = {}            # (bound, B, path) -> plan, workspace bytes, flag offset
+        self.deferred_calls = 0        # calls that went this way / that were voided
+        self.deferred_voided = 0
         self._summary_pin = None      # page-locked words the batch summary kernel writes (N, evicted_blocks_per_seq)
         self._summary_ticket = 0      # ... and the ticket of the last launch (the word behind the counts)
         self._summary_np = None
@@ -427,7 +441,7 @@ class CompressionMetrics:
         sm = slot_mapping.contiguous()
         if pm.dtype != torch.float32 or sm.dtype != torch.int64 or not pm.is_cuda:
             raise RuntimeError("aggregate_prefill: need float32 metrics and int64 slots on a HIP device")
-        with torch.cuda.device(self.device):
+        with on_device(self.device):
             _lib.check(lib.kvc_aggregate_prefill(self.metrics.data_ptr(), pm.data_ptr(),
                                                  sm.data_ptr(), seq_len, self.num_kv_heads, qpk,
                                                  _stream(self.metrics)))
@@ -449,7 +463,7 @@ class CompressionMetrics:
 
     def _plain_aggregate_decode(self, fuse_clear: bool) -> None:
         lib = _lib.load()
-        with torch.cuda.device(self.device):
+        with on_device(self.device):
             _lib.check(lib.kvc_aggregate_decode(
                 self.metrics.data_ptr(), self._temp_metrics.data_ptr(), self.metrics.numel(),
                 self.num_queries_per_kv, 1 if self.use_l2 else 0, 1 if fuse_clear else 0,
@@ -486,7 +500,7 @@ class CompressionMetrics:
         p.harvest_position_delta = int(tokens_ahead)      # a decode step: one more token per sequence
         if not lib.kvc_harvest_eligible(ctypes.byref(p), self.num_queries_per_kv):
             return False
-        with torch.cuda.device(self.device):
+        with on_device(self.device):
             _lib.check(lib.kvc_aggregate_decode_harvest(
                 ctypes.byref(p), self._temp_metrics.data_ptr(), self.num_queries_per_kv,
                 1 if self.use_l2 else 0, 1 if fuse_clear else 0, stream))
@@ -612,7 +626,7 @@ class CompressionMetrics:
         if not ok:
             self._plain_aggregate_decode(fuse_clear)
             return False
-        with torch.cuda.device(self.device):
+        with on_device(self.device):
             _lib.check(lib.kvc_aggregate_decode_harvest(
                 ctypes.byref(p), self._temp_metrics.data_ptr(), self.num_queries_per_kv,
                 1 if self.use_l2 else 0, 1 if fuse_clear else 0, stream))
@@ -682,7 +696,7 @@ class CompressionMetrics:
         att = list(seq_indices) if attention_seq_indices is None else [int(x) for x in attention_seq_indices]
         pos_of = {int(s): i for i, s in enumerate(seq_indices)}
         seq_slot = self._as_i32([pos_of.get(int(s), -1) for s in att])
-        with torch.cuda.device(self.device):
+        with on_device(self.device):
             _lib.check(lib.kvc_attention_harvest_begin(ctypes.byref(p), stream))
         record = dict(seqs=hv["seqs"], attention=True, k=hv["k"], stream=stream, buf=self._hv_buf)
         self._hv_attention = AttentionHarvest(self, self._hv_buf, seq_slot, seq_pos, prot, B, stream, record)
@@ -747,10 +761,10 @@ class CompressionMetrics:
             self._poll_fallback(False)
             busy = {slot for slot, _, _ in self._fb_inflight}
         slot = next(i for i in range(self.FB_RING) if i not in busy)
-        with torch.cuda.device(self.device):
+        with on_device(self.device):
             self._fb_pin[slot:slot + 1].copy_(ws[off:off + 4].view(torch.int32), non_blocking=True)
             event = torch.cuda.Event()
-            event.record()
+            event.record(torch.cuda.current_stream(ws.device.index))     # (an explicit index: see _custom_ops._stream)
         self._fb_inflight.append((slot, event, predicted))
 
     def _note_flag(self, word: int, predicted: bool) -> None:
@@ -806,7 +820,8 @@ class CompressionMetrics:
             self._small_cache[key] = hit
         return hit
 
-    def _batch_summary_enqueue(self, context_lens: torch.Tensor, k_per_seq: Optional[torch.Tensor], stream: int) -> int:
+    def _batch_summary_enqueue(self, context_lens: torch.Tensor, k_per_seq: Optional[torch.Tensor], stream: int,
+                               bound: Optional[int] = None) -> int:
         """``N`` and ``evicted_blocks_per_seq`` of a batch the caller describes with device tensors -- what the fork's
         scheduler passes (reference scheduler.py:245-247, 491-499: a device int tensor of counts, no N) -- on their way
         to the host: one launch that writes into page-locked memory (kvc_schedule_batch_summary).
@@ -821,11 +836,19 @@ class CompressionMetrics:
         # the kernel stores the numbers and then a ticket (system-scope release) into the page-locked buffer: the host
         # polls the ticket word instead of waiting for the stream's end-of-kernel signal (ABI version 7)
         self._summary_ticket += 1
-        with torch.cuda.device(self.device):
-            _lib.check(lib.kvc_schedule_batch_summary_ticket(
-                context_lens.data_ptr(), int(context_lens.numel()), int(self.block_size),
-                None if k_per_seq is None else k_per_seq.data_ptr(), B, self._summary_pin.data_ptr(),
-                self._summary_ticket, stream))
+        with on_device(self.device):
+            if bound is None:
+                _lib.check(lib.kvc_schedule_batch_summary_ticket(
+                    context_lens.data_ptr(), int(context_lens.numel()), int(self.block_size),
+                    None if k_per_seq is None else k_per_seq.data_ptr(), B, self._summary_pin.data_ptr(),
+                    self._summary_ticket, stream))
+            else:       # (ABI version 8: N also where the kernels behind this launch read it)
+                if self._dn_dev is None:
+                    self._dn_dev = torch.zeros((2,), dtype=torch.int64, device=self.device)
+                _lib.check(lib.kvc_schedule_batch_summary_deferred(
+                    context_lens.data_ptr(), int(context_lens.numel()), int(self.block_size),
+                    None if k_per_seq is None else k_per_seq.data_ptr(), B, self._summary_pin.data_ptr(),
+                    self._summary_ticket, self._dn_dev.data_ptr(), int(bound), stream))
         return B
 
     def _batch_summary_read(self, B: int, stream: int):
@@ -841,6 +864,87 @@ class CompressionMetrics:
                 if int(word[0]) != ticket and time.monotonic() > deadline:
                     raise RuntimeError("schedule_evictions: the batch summary never arrived")
         return int(self._summary_np[0]), self._summary_np[1:1 + B].copy()
+
+    _DN_GRAIN = 1 << 16
+
+    def _dn_note(self, B: int, N: int, p) -> None:
+        """what a call's true N and counts say for the next call of a batch of this size (deferred N, __init__)"""
+        # (a quarter over N, in steps that are fine where the schedules' thresholds are: the library picks the schedule
+        # from the bound, and a bracket schedule on a batch that is too small for it is redone by its fallback)
+        grain = self._DN_GRAIN if N >= (1 << 20) else 1024
+        grain = grain // math.gcd(grain, self.block_size) * self.block_size
+        want = (N + N // 4 + grain - 1) // grain * grain
+        if want > self._dn_bound.get(B, 0):
+            self._dn_bound[B] = want
+        if int(p.max_evicted_blocks_hint) >= 0:
+            self._dn_plan[B] = int(_lib.load().kvc_schedule_evictions_plan(ctypes.byref(p)))
+
+    def _schedule_evictions_deferred(self, seq_indices, seq_positions, k_per_seq, context_lens, hanging_token_count,
+                                     evicted_kv_offsets, num_protected, stream: int):
+        """``schedule_evictions`` for the fork's call without a wait in front of the launches (see ``deferred_n``).
+        Returns the three outputs -- or ``(N, counts)`` when the bound did not hold and the device did nothing."""
+        lib = _lib.load()
+        bs, L, H, B = self.block_size, self.num_layers, self.num_kv_heads, len(seq_indices)
+        dev = self.device
+        bound = int(self._dn_bound[B])
+        if bound >= 2147483647 - self._DN_GRAIN:
+            bound = (2147483646 // bs) * bs
+        pending = self._batch_summary_enqueue(context_lens, k_per_seq, stream, bound=bound)
+        seq_pos = self._as_i32(seq_positions)
+        prot = self._as_i32(num_protected)
+        out_idx = torch.empty((bound,), dtype=torch.int32, device=dev)
+        out_two = torch.empty((2, B, L, H), dtype=torch.int32, device=dev)       # (one allocation for the two count tensors)
+        out_kv, out_blk = out_two[0], out_two[1]
+        p = KvcScheduleParams()
+        self._store_params(p, seq_indices, seq_pos, prot, context_lens, bound)
+        p.evicted_blocks_per_seq = k_per_seq.data_ptr()
+        p.hanging_token_count = hanging_token_count.data_ptr()
+        p.evicted_kv_offsets = evicted_kv_offsets.data_ptr()
+        p.schedule_path = int(self.schedule_path)
+        p.uniform_evict = 0
+        if p.schedule_path == 0 and self._fb_backoff > 0:
+            self._fb_backoff -= 1
+            p.schedule_path = 1
+        p.block_tables, p.seq_index_of_slot, p.max_num_seqs, p.block_tables_width = None, None, 0, 0
+        p.harvest_buf, p.harvest, p.harvest_widen, p.eli_dirty_map = None, 0, float(self.harvest_widen), None
+        p.max_evicted_blocks_hint = -1
+        p.total_slots_dev = self._dn_dev.data_ptr()
+        p.evicted_logical_indices = out_idx.data_ptr()
+        p.evicted_kv_count = out_kv.data_ptr()
+        p.evicted_block_count = out_blk.data_ptr()
+        self._hv_lists = None          # (lists made for this call belong to the small-eviction schedule: not used here)
+        self._hv = None
+        self.last_harvest_used = self.last_pivot_memory_used = False
+        self._spec_made = False
+        key = (bound, B, int(p.schedule_path))
+        known = self._dn_sizes.get(key)
+        if known is None:
+            known = self._dn_sizes[key] = (int(lib.kvc_schedule_evictions_plan(ctypes.byref(p))),
+                                           int(lib.kvc_schedule_evictions_workspace_bytes(bound, B * L * H, B, bs)),
+                                           int(lib.kvc_schedule_evictions_fallback_offset(bound, B * L * H, B, bs)))
+        plan, ws_bytes, fb_off = known
+        ws = workspace(dev, ws_bytes, "schedule_evictions")
+        with on_device(dev):
+            _lib.check(lib.kvc_schedule_evictions(ctypes.byref(p), ws.data_ptr(), ws.numel(), stream))
+        # ---- the device is at work; N and the counts arrive meanwhile
+        self._poll_fallback(False)
+        n_read, k_read = self._batch_summary_read(pending, stream)
+        self.deferred_calls += 1
+        p.total_slots_dev = None
+        p.total_slots, p.max_evicted_blocks_hint = int(n_read), int(k_read.max())
+        self._dn_note(B, int(n_read), p)
+        if n_read > bound:
+            self.deferred_voided += 1
+            return int(n_read), k_read
+        self.last_used_block_tables = False
+        self.last_schedule = (ws, fb_off, plan)
+        p.total_slots, p.max_evicted_blocks_hint = bound, -1
+        self.last_schedule_reason = self._describe_plan(
+            plan, int(lib.kvc_schedule_evictions_plan_reason(ctypes.byref(p))),
+            backoff=int(p.schedule_path) == 1 and int(self.schedule_path) != 1) + " [N on the device]"
+        if plan:
+            self._watch_flag(ws, self.last_schedule[1], False)
+        return out_idx[:int(n_read)], out_kv, out_blk
 
     def schedule_evictions(
         self,
@@ -902,7 +1006,19 @@ class CompressionMetrics:
         k_per_seq = self._as_i32(evicted_blocks_per_seq)
         # the counts on the host (their maximum picks the schedule, include/kvc_mi355x.h) and N
         k_list, pending = None, None
-        if isinstance(evicted_blocks_per_seq, torch.Tensor):
+        if (self.deferred_n and not capturing and total_slots is None and block_tables is None and not uniform_evict
+                and isinstance(evicted_blocks_per_seq, torch.Tensor) and evicted_blocks_per_seq.is_cuda
+                and (self.schedule_mode == "per_sequence" or B == 1) and self._dn_plan.get(B, 1) != 1
+                and self._dn_bound.get(B, 0) > 0 and not self._fb_fault and not self.strict_fallback
+                and int(self.schedule_path) in (0, 1, 4) and not self.lean_outputs):
+            done = self._schedule_evictions_deferred(seq_indices, seq_positions, k_per_seq, context_lens, hanging_token_count,
+                                                     evicted_kv_offsets, num_protected, stream)
+            if isinstance(done, tuple) and len(done) == 3:
+                return done
+            total_slots, k_list = done         # (voided: N and the counts are known now -- the usual way, without a wait)
+        if k_list is not None:
+            pass
+        elif isinstance(evicted_blocks_per_seq, torch.Tensor):
             if not evicted_blocks_per_seq.is_cuda:
                 k_list = np.asarray(evicted_blocks_per_seq.tolist(), dtype=np.int64)
             elif not capturing:
@@ -972,6 +1088,7 @@ class CompressionMetrics:
         # the largest count picks the schedule (include/kvc_mi355x.h); unknown only for a device tensor of counts
         # under stream capture, where nothing can be read back
         p.max_evicted_blocks_hint = -1 if k_list is None else int(k_list.max())
+        self._dn_note(B, N, p)
         # (lists are wanted once somebody harvests explicitly -- or from the start when aggregate_decode() may harvest
         # ahead of the call by itself)
         want_lists = self._wants_lists()
@@ -1028,7 +1145,7 @@ class CompressionMetrics:
 
         ws_bytes = lib.kvc_schedule_evictions_workspace_bytes(N, B * L * H, B, bs)
         ws = workspace(dev, ws_bytes, "schedule_evictions")
-        with torch.cuda.device(dev):
+        with on_device(dev):
             _lib.check(lib.kvc_schedule_evictions(ctypes.byref(p), ws.data_ptr(), ws.numel(), stream))
         self.last_used_block_tables = bool(lib.kvc_schedule_evictions_uses_block_tables(ctypes.byref(p)))
         self.last_schedule = (ws, int(lib.kvc_schedule_evictions_fallback_offset(N, B * L * H, B, bs)), plan)
