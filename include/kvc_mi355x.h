@@ -388,6 +388,16 @@ typedef struct kvc_schedule_params {
                                                * rule: max_evicted_blocks_hint must be -1 (the small-eviction schedule is chosen
                                                * from host-side counts), mode 0 with num_seqs > 1, uniform_evict, block_tables
                                                * and harvest bits are refused. */
+  uint32_t* flag_mirror;                      /* ABI version 8, optional (NULL: none).  One word of page-locked, device-mapped
+                                               * host memory: the single gated launch at the end of a small-eviction / bracket
+                                               * call stores (flag_ticket << 8) | (the call's flag word & 0xFF) there (system
+                                               * scope) -- bit 0: the schedule could not finish exactly and the call was redone
+                                               * on the device, bit 1: that launch gave up a wait (outputs void), bit 3: keys
+                                               * and holes were made anew.  A host that wants to know reads the word some time
+                                               * later instead of enqueueing a copy behind every call.  Not written by calls
+                                               * that take the digit rounds directly (they have no flag) nor under the
+                                               * reference's batch > 1 rule with more than 256 sequences (a launch chain). */
+  uint32_t flag_ticket;                       /* (24 bits) */
 } kvc_schedule_params;
 
 size_t kvc_schedule_evictions_workspace_bytes(int64_t total_slots, int32_t total_heads,

@@ -167,8 +167,9 @@ def test_a_timed_out_wait_is_an_error_not_a_schedule():
     ds.cm.schedule_evictions(*args, total_slots=st.total_slots)
     assert ds.cm.last_schedule_path() == "small_eviction"
     torch.cuda.synchronize()
-    slot = ds.cm._fb_inflight[-1][0]
-    ds.cm._fb_pin[slot] = 2                        # what the asynchronous copy would bring back after a fault
+    slot, _, _, ticket = ds.cm._fb_inflight[-1]
+    # what the call's last launch would have left in its page-locked word after a fault: (ticket << 8) | flag word
+    ds.cm._fb_pin[slot] = (ticket << 8) | 2
     torch.cuda.synchronize()
     with pytest.raises(RuntimeError, match="gave up a wait"):
         ds.cm.schedule_evictions(*args, total_slots=st.total_slots)

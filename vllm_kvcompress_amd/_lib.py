@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int32, c_int64, c_size_t, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # KVC_MI355X_LIB: alternative build of the same library (kernel experiments)
@@ -86,7 +86,7 @@ class KvcScheduleParams(ctypes.Structure):
         ("harvest_position_delta", c_int32),
         ("evicted_logical_indices", c_void_p), ("evicted_kv_count", c_void_p),
         ("evicted_block_count", c_void_p),
-        ("total_slots_dev", c_void_p),
+        ("total_slots_dev", c_void_p), ("flag_mirror", c_void_p), ("flag_ticket", c_uint32),
     ]
 
 

@@ -38,7 +38,12 @@ struct FbSync {
   uint32_t* claim;       // [FB_PHASES] virtual workgroups handed out
   uint32_t* done;        // [FB_PHASES] ... finished
   uint32_t* flag;        // the schedule's flag word (bit 1: a wait timed out, results void)
+  uint32_t* mirror;      // kvc_schedule_params.flag_mirror (page-locked host word) or nullptr
+  uint32_t ticket;
 };
+__device__ __forceinline__ void fb_mirror(uint32_t* mirror, uint32_t ticket, uint32_t flag) {
+  if (mirror != nullptr) __hip_atomic_store(mirror, (ticket << 8) | (flag & 0xFFu), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // runs body(v, V) for the virtual workgroups v this workgroup can claim, then waits for all V;
 // false = the wait was given up (or somebody else gave up): stop
@@ -67,7 +72,12 @@ __device__ __forceinline__ bool fb_phase(const FbSync& fs, uint32_t phase, uint3
     while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < V) {
       __builtin_amdgcn_s_sleep(16);
       if (__hip_atomic_load(fs.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & FB_TIMEOUT_BIT) { ok = 0u; break; }
-      if (wall_clock64() - t0 > 1000000000ull) { atomicOr(fs.flag, FB_TIMEOUT_BIT); ok = 0u; break; }
+      if (wall_clock64() - t0 > 1000000000ull) {
+        const uint32_t was = atomicOr(fs.flag, FB_TIMEOUT_BIT);
+        fb_mirror(fs.mirror, fs.ticket, was | FB_TIMEOUT_BIT);      // (the host hears of a fault whoever notices it)
+        ok = 0u;
+        break;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     *word_s = ok;
@@ -96,6 +106,8 @@ __global__ __launch_bounds__(256, 2) void fallback_general_kernel(kvc_schedule_p
                                                                unsigned vgrid, uint32_t* hv_pivot) {
   if (voided(ws)) return;
   const uint32_t flag0 = __hip_atomic_load(ws.fallback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // the call's flag word for the host, in page-locked memory (what the schedule in front raised is final here)
+  if (blockIdx.x == 0 && threadIdx.x == 0) fb_mirror(p.flag_mirror, p.flag_ticket, flag0);
   if (flag0 == 0u) return;                           // flag down: this launch is all the fallback costs
   // The pivots this call left for the next one were computed from lists that just turned out not to be trustworthy
   // (a workgroup of topk_fused_kernel reads the flag once, before its emission: it may have written next pivots while
@@ -112,6 +124,8 @@ __global__ __launch_bounds__(256, 2) void fallback_general_kernel(kvc_schedule_p
   fs.claim = ws.bar + 32;
   fs.done = ws.bar + 32 + FB_PHASES;
   fs.flag = ws.fallback;
+  fs.mirror = p.flag_mirror;
+  fs.ticket = p.flag_ticket;
   uint32_t phase = 0;
   bool alive = true;
   // (workgroup 0 leaves the 100 MHz wall clock of every phase end behind the counter: tools/fallback_cost.py)

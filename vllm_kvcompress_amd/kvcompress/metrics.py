@@ -184,7 +184,9 @@ class CompressionMetrics:
         # schedule is taken for 1, 2, 4 ... up to 64 calls before the small-eviction one is tried
         # again.  Results are identical either way.
         self._fb_pin = None           # page-locked flag words, one per call in flight (FB_RING of them)
-        self._fb_inflight = []        # [(word index, event, predicted)] in the order the calls were made
+        self._fb_inflight = []        # [(word index, event or None, predicted, ticket or None)] in the order the calls were made
+        self._fb_np = None
+        self._fb_ticket = 0
         self._fb_penalty = 0          # general-schedule calls the last raised flag cost
         self._fb_backoff = 0          # of which still to go
         self._fb_fault = False        # a fallback launch gave up a wait (device fault): digit rounds only from now on
@@ -738,34 +740,60 @@ class CompressionMetrics:
     FB_RING = 16
 
     def _poll_fallback(self, capturing: bool) -> None:
-        """The flag words of earlier small-eviction / bracket calls, each copied to its own page-locked word behind
-        its call: looked at (never waited for) by the next calls of this object, in the order the calls were made --
-        EVERY call's flag is seen (the back-off after a redone call and the pause / widening of predicted pivots
-        count all of them), at the latest FB_RING calls later."""
+        """The flag words of earlier small-eviction / bracket calls, each in its own page-locked word -- stored there by
+        the call's last launch itself (kvc_schedule_params.flag_mirror, ABI version 8: (ticket << 8) | flag) or, for the one
+        chain that does not end in that launch, copied there behind the call: looked at (never waited for) by the next
+        calls of this object, in the order the calls were made -- EVERY call's flag is seen (the back-off after a redone
+        call and the pause / widening of predicted pivots count all of them), at the latest FB_RING calls later."""
         if capturing:
             return
-        while self._fb_inflight and self._fb_inflight[0][1].query():
-            slot, _, predicted = self._fb_inflight.pop(0)
-            word = int(self._fb_pin[slot])
+        while self._fb_inflight and self._flag_arrived(self._fb_inflight[0]):
+            slot, _, predicted, ticket = self._fb_inflight.pop(0)
+            word = int(self._fb_np[slot])
+            if ticket is not None:
+                word &= 0xFF
             if word & 2:
                 self._raise_fallback_fault("an earlier")
             self._note_flag(word, predicted)
 
+    def _flag_arrived(self, entry) -> bool:
+        slot, event, _, ticket = entry
+        if ticket is None:
+            return event.query()
+        return (int(self._fb_np[slot]) >> 8) & 0xFFFFFF == ticket
+
+    def _flag_slot(self) -> int:
+        """a page-locked word nobody is waiting on"""
+        if self._fb_pin is None:
+            with torch.inference_mode(False):
+                self._fb_pin = torch.zeros(self.FB_RING, dtype=torch.int32).pin_memory()
+            self._fb_np = self._fb_pin.numpy()
+        busy = {e[0] for e in self._fb_inflight}
+        if len(busy) >= self.FB_RING:              # (FB_RING calls enqueued and none has run yet: wait for the oldest)
+            if self._fb_inflight[0][3] is None:
+                self._fb_inflight[0][1].synchronize()
+            else:
+                torch.cuda.synchronize(self.device)
+            self._poll_fallback(False)
+            busy = {e[0] for e in self._fb_inflight}
+        return next(i for i in range(self.FB_RING) if i not in busy)
+
+    def _mirror_flag(self, p) -> Tuple[int, int]:
+        """the call `p` describes reports its flag word itself: slot and ticket for ``_fb_inflight`` once it is enqueued"""
+        slot = self._flag_slot()
+        self._fb_ticket = (self._fb_ticket % 0xFFFFFF) + 1
+        p.flag_mirror = self._fb_pin.data_ptr() + 4 * slot
+        p.flag_ticket = self._fb_ticket
+        return slot, self._fb_ticket
+
     def _watch_flag(self, ws: torch.Tensor, off: int, predicted: bool) -> None:
         """copy this call's flag word to a free page-locked word behind the call (no synchronisation)"""
-        if self._fb_pin is None:
-            self._fb_pin = torch.zeros(self.FB_RING, dtype=torch.int32).pin_memory()
-        busy = {slot for slot, _, _ in self._fb_inflight}
-        if len(busy) >= self.FB_RING:              # (FB_RING calls enqueued and none has run yet: wait for the oldest)
-            self._fb_inflight[0][1].synchronize()
-            self._poll_fallback(False)
-            busy = {slot for slot, _, _ in self._fb_inflight}
-        slot = next(i for i in range(self.FB_RING) if i not in busy)
+        slot = self._flag_slot()
         with on_device(self.device):
             self._fb_pin[slot:slot + 1].copy_(ws[off:off + 4].view(torch.int32), non_blocking=True)
             event = torch.cuda.Event()
             event.record(torch.cuda.current_stream(ws.device.index))     # (an explicit index: see _custom_ops._stream)
-        self._fb_inflight.append((slot, event, predicted))
+        self._fb_inflight.append((slot, event, predicted, None))
 
     def _note_flag(self, word: int, predicted: bool) -> None:
         """what a call's flag word means for the calls to come (predicted: it ran on harvested lists or on
@@ -909,6 +937,7 @@ class CompressionMetrics:
         p.harvest_buf, p.harvest, p.harvest_widen, p.eli_dirty_map = None, 0, float(self.harvest_widen), None
         p.max_evicted_blocks_hint = -1
         p.total_slots_dev = self._dn_dev.data_ptr()
+        mirror = self._mirror_flag(p)
         p.evicted_logical_indices = out_idx.data_ptr()
         p.evicted_kv_count = out_kv.data_ptr()
         p.evicted_block_count = out_blk.data_ptr()
@@ -943,7 +972,7 @@ class CompressionMetrics:
             plan, int(lib.kvc_schedule_evictions_plan_reason(ctypes.byref(p))),
             backoff=int(p.schedule_path) == 1 and int(self.schedule_path) != 1) + " [N on the device]"
         if plan:
-            self._watch_flag(ws, self.last_schedule[1], False)
+            self._fb_inflight.append((mirror[0], None, False, mirror[1]))
         return out_idx[:int(n_read)], out_kv, out_blk
 
     def schedule_evictions(
@@ -1145,6 +1174,10 @@ class CompressionMetrics:
 
         ws_bytes = lib.kvc_schedule_evictions_workspace_bytes(N, B * L * H, B, bs)
         ws = workspace(dev, ws_bytes, "schedule_evictions")
+        # (the call's last launch reports its flag word itself -- except the one chain that does not end in it)
+        mirror = None
+        if plan and not capturing and not self.strict_fallback and not (plan == 1 and int(p.mode) == 0 and B > 256):
+            mirror = self._mirror_flag(p)
         with on_device(dev):
             _lib.check(lib.kvc_schedule_evictions(ctypes.byref(p), ws.data_ptr(), ws.numel(), stream))
         self.last_used_block_tables = bool(lib.kvc_schedule_evictions_uses_block_tables(ctypes.byref(p)))
@@ -1162,6 +1195,8 @@ class CompressionMetrics:
             if word & 2:
                 self._raise_fallback_fault("this")
             self._note_flag(word, bool(p.harvest & 5))
+        elif mirror is not None:
+            self._fb_inflight.append((mirror[0], None, bool(p.harvest & 5), mirror[1]))
         elif self.last_schedule[2] and not capturing:
             self._watch_flag(ws, self.last_schedule[1], bool(p.harvest & 5))
         return out_idx, out_kv, out_blk
