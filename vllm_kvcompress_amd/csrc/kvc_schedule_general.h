@@ -82,6 +82,10 @@ __device__ __forceinline__ void build_keys_body(const kvc_schedule_params& p, Sc
   // their 4 B of sequence index and nothing else; for the others the wide loads do not depend on
   // the rest of the metadata chain below and are issued first
   const int s = p.seq_index_by_block[blk];
+  // (this kernel runs when most blocks belong to the batch -- a sparse cache takes build_keys_sparse_body --: the other
+  // three metadata rows are requested with the first, not behind the two tests below: one round trip less per thread)
+  const int l = p.layer_index_by_block[blk], h = p.head_index_by_block[blk];
+  const int lbn = p.logical_block_num_by_block[blk];
   if (s < 0 || s >= p.seq_slot_len) continue;
   float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f);
   int4 q4 = make_int4(0, 0, 0, 0);
@@ -92,14 +96,15 @@ __device__ __forceinline__ void build_keys_body(const kvc_schedule_params& p, Sc
   const int i = p.seq_slot_of_seq[s];
   if (i < 0) continue;
   const int L = p.num_layers, H = p.num_kv_heads, B = p.num_seqs;
-  const int l = p.layer_index_by_block[blk], h = p.head_index_by_block[blk];
-  const int lbn = p.logical_block_num_by_block[blk];
+  // (a block whose rows do not name a head of the batch is inconsistent metadata: skipped like a free one)
+  if (l < 0 || l >= L || h < 0 || h >= H) continue;
   const int g = (i * L + l) * H + h;
+  // (requested together, in front of the test that needs only the first)
   const int ctx = p.context_lens[(l * B + i) * H + h];
-  const int nblk = (ctx + bs - 1) / bs;
-  if (lbn < 0 || lbn >= nblk) continue;        // not part of the head's slot range
   const int seq_pos = p.seq_positions[i], prot = p.num_protected[i];
   const int64_t base = p.evicted_kv_offsets[g];
+  const int nblk = (ctx + bs - 1) / bs;
+  if (lbn < 0 || lbn >= nblk) continue;        // not part of the head's slot range
   const int64_t src = blk * bs + off, dst = base + (int64_t)lbn * bs + off;
   if constexpr (VEC == 4) {
     const float4 m = m4;
@@ -748,6 +753,16 @@ __device__ __forceinline__ void select_emit_head(const kvc_schedule_params& p, S
       for (int idx = tid; idx < n; idx += blockDim.x) out[idx] = p.null_value;
     return;
   }
+  // (bracket schedule: the head's count below the bracket, its list length and the list entry that is M are requested
+  // here, in front of the staging pass and its barrier -- two dependent round trips that the staging hides)
+  uint32_t br_below = 0, br_m = 0, br_M = 0;
+  bool br_listed = false;
+  if (bracket == 1) {
+    br_below = ws.st_def[g];
+    br_m = min(ws.st_cnt[g], bracket_cap((uint32_t)n));
+    br_listed = cnt > br_below && cnt - 1u - br_below < br_m;
+    if (br_listed) br_M = (ws.blist + bracket_list_at(base, g))[cnt - 1u - br_below];
+  }
   // stage the head's keys in LDS once; every later pass (4 select rounds + emit) reads LDS
   const bool staged = n <= lds_cap;
   if (staged) {
@@ -775,12 +790,12 @@ __device__ __forceinline__ void select_emit_head(const kvc_schedule_params& p, S
   } else if (bracket) {
     // the cnt-th smallest key of the head lies in its bracket list (keys in [lo, hi], sorted; `below`
     // keys of the head are smaller than lo) unless the head frees only chunks below the bracket
-    const uint32_t below = ws.st_def[g];
-    const uint32_t m = min(ws.st_cnt[g], bracket_cap((uint32_t)n));
+    const uint32_t below = br_below;
+    const uint32_t m = br_m;
     const uint32_t* list = ws.blist + bracket_list_at(base, g);
-    if (cnt > below && cnt - 1u - below < m) {
+    if (br_listed) {
       from_list = true;
-      M = list[cnt - 1u - below];
+      M = br_M;
       uint32_t lt = 0, eq = 0;                       // entries below M / equal to M: one parallel pass over the list
       for (uint32_t j = tid; j < m; j += SEL_THREADS) { const uint32_t v = list[j]; lt += v < M; eq += v == M; }
       lt = wave_reduce_sum(lt); eq = wave_reduce_sum(eq);
