@@ -210,7 +210,7 @@ class CompressionMetrics:
         self.deferred_n = os.environ.get("KVC_DEFERRED_N", "1") not in ("", "0")
         self._dn_bound = {}            # batch size -> bound on N (a multiple of 64 Ki slots)
         self._dn_plan = {}             # batch size -> the schedule the last call's true N and counts pick (0 / 1 / 2)
-        self._dn_dev = None            # [2] int64 on the device: N, void
+        self._dn_dev = None            # stream -> [2] int64 on the device: N, void
         self._dn_sizes = {}            # (bound, B, path) -> plan, workspace bytes, flag offset
         self.deferred_calls = 0        # calls that went this way / that were voided
         self.deferred_voided = 0
@@ -871,12 +871,10 @@ class CompressionMetrics:
                     None if k_per_seq is None else k_per_seq.data_ptr(), B, self._summary_pin.data_ptr(),
                     self._summary_ticket, stream))
             else:       # (ABI version 8: N also where the kernels behind this launch read it)
-                if self._dn_dev is None:
-                    self._dn_dev = torch.zeros((2,), dtype=torch.int64, device=self.device)
                 _lib.check(lib.kvc_schedule_batch_summary_deferred(
                     context_lens.data_ptr(), int(context_lens.numel()), int(self.block_size),
                     None if k_per_seq is None else k_per_seq.data_ptr(), B, self._summary_pin.data_ptr(),
-                    self._summary_ticket, self._dn_dev.data_ptr(), int(bound), stream))
+                    self._summary_ticket, self._dn_words(stream).data_ptr(), int(bound), stream))
         return B
 
     def _batch_summary_read(self, B: int, stream: int):
@@ -894,6 +892,15 @@ class CompressionMetrics:
         return int(self._summary_np[0]), self._summary_np[1:1 + B].copy()
 
     _DN_GRAIN = 1 << 16
+
+    def _dn_words(self, stream: int) -> torch.Tensor:
+        """the two device words (N, void) of calls enqueued on `stream` (stream order keeps one call's apart from the next's)"""
+        if self._dn_dev is None:
+            self._dn_dev = {}
+        t = self._dn_dev.get(stream)
+        if t is None:
+            t = self._dn_dev[stream] = torch.zeros((2,), dtype=torch.int64, device=self.device)
+        return t
 
     def _dn_note(self, B: int, N: int, p) -> None:
         """what a call's true N and counts say for the next call of a batch of this size (deferred N, __init__)"""
@@ -936,7 +943,7 @@ class CompressionMetrics:
         p.block_tables, p.seq_index_of_slot, p.max_num_seqs, p.block_tables_width = None, None, 0, 0
         p.harvest_buf, p.harvest, p.harvest_widen, p.eli_dirty_map = None, 0, float(self.harvest_widen), None
         p.max_evicted_blocks_hint = -1
-        p.total_slots_dev = self._dn_dev.data_ptr()
+        p.total_slots_dev = self._dn_words(stream).data_ptr()
         mirror = self._mirror_flag(p)
         p.evicted_logical_indices = out_idx.data_ptr()
         p.evicted_kv_count = out_kv.data_ptr()
