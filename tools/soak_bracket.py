@@ -72,6 +72,25 @@ def soak(n):
                 print(f"MISMATCH seed={seed} key={name} mode={mode} L={L} H={H} bs={bs} B={B} T={T} ties={ties} "
                       f"compressed={compressed} frac={frac} evicted={evicted} how={key}")
                 sys.exit(1)
+        # the fork's call form with N on the device (ABI version 8; sequences that do not couple): the same answer whether
+        # the bound holds (the call before learnt it), is far too generous, or does not hold (voided on the device, repeated)
+        if mode == "per_sequence" or B == 1:
+            cm = ds.cm
+            cm.schedule_path = int(rng.choice([0, 1, 4]))
+            cm._dn_plan[B] = 2
+            cm._dn_bound[B] = int(rng.choice([st.total_slots, st.total_slots + bs * int(rng.integers(1, 5000)),
+                                              4 * st.total_slots, max(bs, (st.total_slots // 2) // bs * bs)]))
+            voided0 = cm.deferred_voided
+            got2 = cm.schedule_evictions(list(st.seq_indices), ds.seq_positions.clone(),
+                                         torch.tensor(evicted, dtype=torch.int, device=DEV), ds.context_lens,
+                                         ds.hanging_token_count, ds.evicted_kv_offsets, tuple(st.protected))
+            key2 = "N on the device: " + ("voided, repeated" if cm.deferred_voided > voided0 else cm.last_schedule_path())
+            how[key2] = how.get(key2, 0) + 1
+            for i, name in enumerate(("eli", "ekc", "ebc")):
+                if not np.array_equal(got2[i].cpu().numpy(), want[i].cpu().numpy()):
+                    print(f"MISMATCH (N on the device) seed={seed} key={name} mode={mode} L={L} H={H} bs={bs} B={B} T={T} "
+                          f"bound={cm._dn_bound[B]} N={st.total_slots} evicted={evicted} how={key2}")
+                    sys.exit(1)
     print(f"soak ok: {n} states, bracket schedule identical to the digit rounds (and the oracle where small) "
           f"in {time.time() - t0:.1f} s; {how}")
 
