@@ -121,6 +121,14 @@ __device__ __forceinline__ int wave_upper_bound_minus1(const int32_t* __restrict
   return lo + (c > 0 ? c - 1 : 0);
 }
 
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global load and store the wave
+// has in flight (s_waitcnt vmcnt(0) in front of s_barrier): in a loop whose steps exchange a few words through LDS and
+// then walk a chain of dependent global loads, every step then pays the whole chain's latency before the next one may
+// even request its loads (schedule_moves_heads_kernel: 16 steps x ~2 us).  Only for barriers that publish LDS data.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // order LDS traffic between the lanes of one wave (no other wave shares the buffer)
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -14,6 +14,7 @@
 //    of the [rows,2] move table, so the kernel also produces the zero fill of the
 //    reference wrapper (vllm/_custom_ops.py:1168) in the same pass, writing each row once.
 #include "kvc_common.h"
+#include <atomic>
 #include "../../include/kvc_mi355x.h"
 
 namespace kvc {
@@ -182,14 +183,62 @@ constexpr int MOVE_BITMAP_WORDS = 15000;             // 480 k tail slots per hea
 constexpr int WAVE_HEAD_MAX = 2048;                  // evictions a single wave takes (64 words of bitmap)
 constexpr int LANE_HEAD_MAX = 32;                    // evictions a single lane walks serially
 
-template <int THREADS, int BITMAP_WORDS>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void schedule_moves_heads_kernel(MovesArgs a) {
+// -DKVC_S2_STAMPS (experiment builds): workgroup 0 prints the 100 MHz wall clock of its phases
+#ifdef KVC_S2_STAMPS
+#define S2_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) s2_t[k] = wall_clock64(); } while (0)
+#else
+#define S2_STAMP(k) do { } while (0)
+#endif
+// compute units of the current device (asked once per device)
+static int cu_count() {
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  int c = cus[dev].load(std::memory_order_relaxed);
+  if (c == 0) {
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c < 1) c = 256;
+    cus[dev].store(c, std::memory_order_relaxed);
+  }
+  return c;
+}
+
+// logical slot -> (logical block, offset): the block size is a kernel argument, and a 32-bit division by a run-time value
+// is ~35 VALU instructions -- four of them per move were what the kernel's main loop took (17 of its 23 us at 16 Ki
+// evictions per head, by its stamps).  One division per thread instead: m = floor((2^32 - 1) / bs); for 0 <= x < 2^31 the
+// quotient mulhi(x, m) is x / bs or one less (x (1 / bs - m / 2^32) < 1), which the remainder tells.  Any block size.
+struct BlockDiv {
+  uint32_t bs, m;
+  __device__ __forceinline__ explicit BlockDiv(int b) : bs((uint32_t)b), m(0xFFFFFFFFu / (uint32_t)b) {}
+  __device__ __forceinline__ void divmod(int x, int& q, int& r) const {
+    uint32_t qq = __umulhi((uint32_t)x, m);
+    uint32_t rr = (uint32_t)x - qq * bs;
+    if (rr >= bs) { ++qq; rr -= bs; }
+    q = (int)qq; r = (int)rr;
+  }
+  __device__ __forceinline__ int blk(int x) const { int q, r; divmod(x, q, r); return q; }
+  __device__ __forceinline__ int off(int x) const { int q, r; divmod(x, q, r); return r; }
+  // physical slot of logical slot x through the head's block table
+  __device__ __forceinline__ int phys(const int32_t* bt, int x) const { int q, r; divmod(x, q, r); return bt[q] * (int)bs + r; }
+};
+
+// WIDE: the form for a launch of at most one workgroup per CU (a few hundred heads of thousands of evictions each:
+// configs[1], [4]) -- compiled for four waves per SIMD, its main loop keeps four chains of dependent loads in flight per
+// thread (95 registers).  With more workgroups than CUs two of them share a CU at eight waves per SIMD (64 registers), and
+// that occupancy is worth more than the chains (measured: configs[3] 1.13 ms against 1.41 in the wide form).
+template <int THREADS, int BITMAP_WORDS, bool WIDE = false>
+__global__ __launch_bounds__(THREADS, (WIDE ? 4 : 8)) void schedule_moves_heads_kernel(MovesArgs a) {
+#ifdef KVC_S2_STAMPS
+  unsigned long long s2_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  S2_STAMP(0);
   constexpr int NWAVES = THREADS / WAVE;
   __shared__ uint32_t bitmap[BITMAP_WORDS];       // 64 KiB for long heads, 4 KiB for short ones (occupancy)
   __shared__ uint32_t wbitmap[NWAVES][WAVE_HEAD_MAX / 32];
   __shared__ uint32_t wave_tot[2][NWAVES];
   __shared__ uint32_t tiles_s[2];
   const int B = a.B, L = a.L, H = a.H, M = a.M, bs = a.bs;
+  const BlockDiv bd(bs);
   const int G = B * L * H;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   int2* mv2 = reinterpret_cast<int2*>(a.moves);
@@ -251,6 +300,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
     }
   }
 
+  S2_STAMP(1);
   // ---- heads a single lane takes: the reference's own serial walk (kvcompress_eviction_kernels.cu:
   // 256-272), one head per lane -- in the continual-compression steady state a head evicts a block's
   // hanging tokens (a handful of indices) and what a step costs is the chain of dependent loads,
@@ -271,12 +321,13 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
       if (dst >= src) break;
       if (src <= stop) { ++ec; continue; }
       if (off + mc < rows)
-        mv2[off + mc] = make_int2(bt[dst / bs] * bs + dst % bs, bt[src / bs] * bs + src % bs);
+        mv2[off + mc] = make_int2(bd.phys(bt, dst), bd.phys(bt, src));
       ++mc;
     }
     finish_head(g, off, seg_end, cnt, mc, 0, 1);
   }
 
+  S2_STAMP(2);
   // ---- heads a wave takes
   for (int g = g_begin + w; g < g_end; g += NWAVES) {
     const int cnt = a.ekc[g];
@@ -314,7 +365,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
           if (surv && j < nmoves) {
             const int dst = E[j];
             if (off + j < rows)
-              mv2[off + j] = make_int2(bt[dst / bs] * bs + dst % bs, bt[slot / bs] * bs + slot % bs);
+              mv2[off + j] = make_int2(bd.phys(bt, dst), bd.phys(bt, slot));
           }
           carry += __popcll(bal);
         }
@@ -326,7 +377,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
         if (i >= 0) {
           const int src = ctx - 1 - i, dst = E[j];
           if (off + j < rows)
-            mv2[off + j] = make_int2(bt[dst / bs] * bs + dst % bs, bt[src / bs] * bs + src % bs);
+            mv2[off + j] = make_int2(bd.phys(bt, dst), bd.phys(bt, src));
         }
       }
       int lo = 0, hi = cnt;                                    // first j that is not a move
@@ -336,6 +387,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
     finish_head(g, off, seg_end, cnt, nmoves, lane, WAVE);
   }
 
+  S2_STAMP(3);
   // ---- heads the whole workgroup takes, one after the other
   for (int g = g_begin; g < g_end; ++g) {
     const int cnt = a.ekc[g];
@@ -349,43 +401,65 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const bool regular = E[cnt - 1] < ctx && (cnt + 31) / 32 <= BITMAP_WORDS;
     if (regular) {
       const int new_len = ctx - cnt;
-      // holes below new_len = lower_bound(E, new_len)
-      int lo = 0, hi = cnt;
-      while (lo < hi) { const int mid = (lo + hi) >> 1; if (E[mid] < new_len) lo = mid + 1; else hi = mid; }
-      nmoves = lo;
+      // holes below new_len = lower_bound(E, new_len): 64 probes per step by every wave (the same answer in each) --
+      // three dependent loads for 16 Ki entries where the bisection took fourteen
+      S2_STAMP(4);
+      nmoves = wave_lower_bound(E, cnt, new_len, lane);
+      S2_STAMP(5);
       const int words = (cnt + 31) / 32;
       __syncthreads();                               // (the bitmap of the head before)
       for (int i = tid; i < words; i += THREADS) bitmap[i] = 0;
       __syncthreads();
-      for (int k = nmoves + tid; k < cnt; k += THREADS) {       // evicted slots inside the tail
-        const int t = E[k] - new_len;
-        atomicOr(&bitmap[t >> 5], 1u << (t & 31));
+      for (int k0 = nmoves + tid; k0 < cnt; k0 += THREADS * 4) {   // evicted slots inside the tail, four requested at once
+        int t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int k = k0 + u * THREADS; t[u] = k < cnt ? E[k] - new_len : -1; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (t[u] >= 0) atomicOr(&bitmap[t[u] >> 5], 1u << (t[u] & 31));
       }
       __syncthreads();
+      S2_STAMP(6);
       uint32_t carry = 0;
       int buf = 0;
-      for (int base = 0; base < cnt; base += THREADS) {         // i-th slot from the top
-        const int i = base + tid;
-        bool surv = false;
-        int slot = 0;
-        if (i < cnt) {
-          slot = ctx - 1 - i;
-          const int t = slot - new_len;
-          surv = !((bitmap[t >> 5] >> (t & 31)) & 1u);
+      // Q consecutive slots from the top per thread and step.  A step is one barrier and, per move, a chain of two
+      // dependent loads (E[j], then the block table): the wave executes in order, so a step costs both round trips
+      // (1.45 us x 16 steps of the kernel's 39 us at 16 Ki evictions per head, by its stamps) -- Q chains in flight per
+      // thread instead of one, 1 / Q of the steps: the loop 24 -> 14 us at Q = 4 (which needs more than the 64 registers of
+      // eight waves per SIMD: the WIDE form only).
+      constexpr int Q = WIDE ? 4 : 1;
+      for (int base = 0; base < cnt; base += THREADS * Q) {
+        const int i0 = base + tid * Q;                          // my slots: the i0-th .. (i0 + Q - 1)-th from the top
+        uint32_t sm = 0;                                        // ... and which of them survive
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          const int i = i0 + q;
+          if (i < cnt) {
+            const int t = ctx - 1 - i - new_len;
+            if (!((bitmap[t >> 5] >> (t & 31)) & 1u)) sm |= 1u << q;
+          }
         }
-        const unsigned long long bal = __ballot(surv);
-        const uint32_t lane_ex = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_tot[buf][w] = (uint32_t)__popcll(bal);
-        __syncthreads();
+        const uint32_t c = (uint32_t)__popc(sm);
+        const uint32_t inc = wave_inclusive_scan(c);
+        if (lane == WAVE - 1) wave_tot[buf][w] = inc;
+        lds_barrier();                                          // (the moves of the step before stay in flight)
         uint32_t woff = 0, tot = 0;
 #pragma unroll
-        for (int q = 0; q < NWAVES; ++q) { const uint32_t c = wave_tot[buf][q]; if (q < w) woff += c; tot += c; }
-        if (surv) {
-          const int j = (int)(carry + woff + lane_ex);
-          const int dst = E[j];
-          if (off + j < rows)
-            mv2[off + j] = make_int2(bt[dst / bs] * bs + dst % bs, bt[slot / bs] * bs + slot % bs);
-        }
+        for (int q = 0; q < NWAVES; ++q) { const uint32_t cq = wave_tot[buf][q]; if (q < w) woff += cq; tot += cq; }
+        const int j0 = (int)(carry + woff + inc - c);           // my first survivor is the j0-th of the head
+        int dst[Q], pd[Q], ps[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+          if ((sm >> q) & 1u) dst[q] = E[j0 + __popc(sm & ((1u << q) - 1u))];
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+          if ((sm >> q) & 1u) { pd[q] = bt[bd.blk(dst[q])]; ps[q] = bt[bd.blk(ctx - 1 - i0 - q)]; }
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+          if ((sm >> q) & 1u) {
+            const int j = j0 + __popc(sm & ((1u << q) - 1u)), slot = ctx - 1 - i0 - q;
+            if (off + j < rows) mv2[off + j] = make_int2(pd[q] * bs + bd.off(dst[q]), ps[q] * bs + bd.off(slot));
+          }
         carry += tot;
         buf ^= 1;
       }
@@ -396,19 +470,29 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
         if (i >= 0) {
           const int src = ctx - 1 - i, dst = E[j];
           if (off + j < rows)
-            mv2[off + j] = make_int2(bt[dst / bs] * bs + dst % bs, bt[src / bs] * bs + src % bs);
+            mv2[off + j] = make_int2(bd.phys(bt, dst), bd.phys(bt, src));
         }
       }
       int lo = 0, hi = cnt;                                    // first j that is not a move
       while (lo < hi) { const int mid = (lo + hi) >> 1; if (move_iteration(h, mid) >= 0) lo = mid + 1; else hi = mid; }
       nmoves = lo;
     }
+    S2_STAMP(7);
     finish_head(g, off, seg_end, cnt, nmoves, tid, THREADS);
+    S2_STAMP(8);
   }
   if (a.plan != nullptr) {
     __syncthreads();
     if (tid < 2) a.plan[tid * MOVES_PLAN_WGS + blockIdx.x] = (int32_t)tiles_s[tid];
   }
+#ifdef KVC_S2_STAMPS
+  S2_STAMP(9);
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    printf("S2 stamps (us): zero %.2f lane %.2f wave %.2f geom %.2f lb %.2f mark %.2f loop %.2f finish %.2f plan %.2f\n",
+           (s2_t[1] - s2_t[0]) * 0.01, (s2_t[2] - s2_t[1]) * 0.01, (s2_t[3] - s2_t[2]) * 0.01, (s2_t[4] - s2_t[3]) * 0.01,
+           (s2_t[5] - s2_t[4]) * 0.01, (s2_t[6] - s2_t[5]) * 0.01, (s2_t[7] - s2_t[6]) * 0.01, (s2_t[8] - s2_t[7]) * 0.01,
+           (s2_t[9] - s2_t[8]) * 0.01);
+#endif
 }
 
 }  // namespace kvc
@@ -462,7 +546,9 @@ extern "C" int kvc_schedule_t1_cache_moves_ex(
   // extra workgroups see to the rows behind the last head's segment
   const int tail_wgs = zero_fill ? 64 : 0;
   const int64_t rows_per_head = cache_moves_rows / G;
-  if (rows_per_head >= 8192)
+  if (rows_per_head >= 8192 && a.nwg <= kvc::cu_count())
+    hipLaunchKernelGGL((kvc::schedule_moves_heads_kernel<1024, kvc::MOVE_BITMAP_WORDS, true>), dim3(a.nwg + tail_wgs), dim3(1024), 0, s, a);
+  else if (rows_per_head >= 8192)
     hipLaunchKernelGGL((kvc::schedule_moves_heads_kernel<1024, kvc::MOVE_BITMAP_WORDS>), dim3(a.nwg + tail_wgs), dim3(1024), 0, s, a);
   else
     hipLaunchKernelGGL((kvc::schedule_moves_heads_kernel<256, 1024>), dim3(a.nwg + tail_wgs), dim3(256), 0, s, a);
