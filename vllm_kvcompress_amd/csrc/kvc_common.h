@@ -121,6 +121,24 @@ __device__ __forceinline__ int wave_upper_bound_minus1(const int32_t* __restrict
   return lo + (c > 0 ? c - 1 : 0);
 }
 
+// x -> (x / d, x % d) for a divisor that is a kernel argument (block sizes, slots per block): a 32-bit division by a
+// run-time value is ~35 VALU instructions.  One division per thread instead: m = floor((2^32 - 1) / bs); for 0 <= x < 2^31 the
+// quotient mulhi(x, m) is x / bs or one less (x (1 / bs - m / 2^32) < 1), which the remainder tells.  Any block size.
+struct BlockDiv {
+  uint32_t bs, m;
+  __device__ __forceinline__ explicit BlockDiv(int b) : bs((uint32_t)b), m(0xFFFFFFFFu / (uint32_t)b) {}
+  __device__ __forceinline__ void divmod(int x, int& q, int& r) const {
+    uint32_t qq = __umulhi((uint32_t)x, m);
+    uint32_t rr = (uint32_t)x - qq * bs;
+    if (rr >= bs) { ++qq; rr -= bs; }
+    q = (int)qq; r = (int)rr;
+  }
+  __device__ __forceinline__ int blk(int x) const { int q, r; divmod(x, q, r); return q; }
+  __device__ __forceinline__ int off(int x) const { int q, r; divmod(x, q, r); return r; }
+  // physical slot of logical slot x through the head's block table
+  __device__ __forceinline__ int phys(const int32_t* bt, int x) const { int q, r; divmod(x, q, r); return bt[q] * (int)bs + r; }
+};
+
 // A workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global load and store the wave
 // has in flight (s_waitcnt vmcnt(0) in front of s_barrier): in a loop whose steps exchange a few words through LDS and
 // then walk a chain of dependent global loads, every step then pays the whole chain's latency before the next one may

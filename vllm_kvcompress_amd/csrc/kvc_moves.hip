@@ -203,25 +203,6 @@ static int cu_count() {
   return c;
 }
 
-// logical slot -> (logical block, offset): the block size is a kernel argument, and a 32-bit division by a run-time value
-// is ~35 VALU instructions -- four of them per move were what the kernel's main loop took (17 of its 23 us at 16 Ki
-// evictions per head, by its stamps).  One division per thread instead: m = floor((2^32 - 1) / bs); for 0 <= x < 2^31 the
-// quotient mulhi(x, m) is x / bs or one less (x (1 / bs - m / 2^32) < 1), which the remainder tells.  Any block size.
-struct BlockDiv {
-  uint32_t bs, m;
-  __device__ __forceinline__ explicit BlockDiv(int b) : bs((uint32_t)b), m(0xFFFFFFFFu / (uint32_t)b) {}
-  __device__ __forceinline__ void divmod(int x, int& q, int& r) const {
-    uint32_t qq = __umulhi((uint32_t)x, m);
-    uint32_t rr = (uint32_t)x - qq * bs;
-    if (rr >= bs) { ++qq; rr -= bs; }
-    q = (int)qq; r = (int)rr;
-  }
-  __device__ __forceinline__ int blk(int x) const { int q, r; divmod(x, q, r); return q; }
-  __device__ __forceinline__ int off(int x) const { int q, r; divmod(x, q, r); return r; }
-  // physical slot of logical slot x through the head's block table
-  __device__ __forceinline__ int phys(const int32_t* bt, int x) const { int q, r; divmod(x, q, r); return bt[q] * (int)bs + r; }
-};
-
 // WIDE: the form for a launch of at most one workgroup per CU (a few hundred heads of thousands of evictions each:
 // configs[1], [4]) -- compiled for four waves per SIMD, its main loop keeps four chains of dependent loads in flight per
 // thread (95 registers).  With more workgroups than CUs two of them share a CU at eight waves per SIMD (64 registers), and

@@ -73,11 +73,15 @@ __device__ __forceinline__ void build_keys_body(const kvc_schedule_params& p, Sc
   const int bs = p.block_size;
   const int per_blk = bs / VEC;
   uint32_t claimed = 0;
+  const BlockDiv pd(per_blk);                         // (thread -> block, offset without a run-time division per thread)
+  const bool narrow = p.num_blocks * per_blk < ((int64_t)1 << 31);
   // (grid-stride: behind the small-eviction schedule this kernel is launched gated, with a small grid)
   for (int64_t tid = (int64_t)bid * blockDim.x + threadIdx.x; tid < p.num_blocks * per_blk;
        tid += (int64_t)data_blocks * blockDim.x) {
-  const int64_t blk = tid / per_blk;
-  const int off = (int)(tid % per_blk) * VEC;
+  int64_t blk;
+  int off;
+  if (narrow) { int q, r; pd.divmod((int)tid, q, r); blk = q; off = r * VEC; }
+  else { blk = tid / per_blk; off = (int)(tid % per_blk) * VEC; }
   // free blocks (an engine's cache is sized to HBM: most blocks do not belong to the batch) cost
   // their 4 B of sequence index and nothing else; for the others the wide loads do not depend on
   // the rest of the metadata chain below and are issued first
