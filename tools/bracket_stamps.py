@@ -38,7 +38,8 @@ def main():
     names = {0: "bracket: start", 1: "heads, counters", 2: "sample loaded", 3: "order statistics",
              8: "select: start", 9: "head geometry, prefix", 10: "thresholds in LDS", 11: "T*", 12: "head counts",
              13: "written", 16: "records: start", 17: "list in LDS", 18: "sorted", 19: "written"}
-    for grp in ((0, 1, 2, 3), (16, 17, 18, 19), (8, 9, 10, 11, 12, 13)):
+    names.update({4: "select + emit: start", 5: "keys staged in LDS", 6: "M known", 7: "emitted", 20: "padded"})
+    for grp in ((0, 1, 2, 3), (16, 17, 18, 19), (8, 9, 10, 11, 12, 13), (4, 5, 6, 7, 20)):
         for a, b in zip(grp, grp[1:]):
             print(f"  {names[b]:28s} {(int(w[b]) - int(w[a])) * 0.01:7.2f} us")
         print()

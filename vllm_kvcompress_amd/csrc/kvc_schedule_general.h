@@ -730,6 +730,11 @@ __device__ __forceinline__ void block_radix_select(uint32_t* hist, uint32_t* bc,
   out_rank_in_eq = rank;
 }
 
+#ifdef KVC_BR_STAMPS
+#define SE_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && bracket == 1) ws.head_fc[k] = (uint32_t)wall_clock64(); } while (0)
+#else
+#define SE_STAMP(k) do { } while (0)
+#endif
 // lds_cap = number of keys the dynamic LDS buffer can stage (0 = read keys from global/L2)
 // bracket = 1 (section 9): M comes from the head's sorted bracket list instead of the digit rounds
 template <int SEL_THREADS>
@@ -757,6 +762,7 @@ __device__ __forceinline__ void select_emit_head(const kvc_schedule_params& p, S
       for (int idx = tid; idx < n; idx += blockDim.x) out[idx] = p.null_value;
     return;
   }
+  SE_STAMP(4);
   // (bracket schedule: the head's count below the bracket, its list length and the list entry that is M are requested
   // here, in front of the staging pass and its barrier -- two dependent round trips that the staging hides)
   uint32_t br_below = 0, br_m = 0, br_M = 0;
@@ -779,6 +785,7 @@ __device__ __forceinline__ void select_emit_head(const kvc_schedule_params& p, S
     }
     __syncthreads();
   }
+  SE_STAMP(5);
   auto key_at = [&](int idx) { return staged ? lds_keys[idx] : gkeys[idx]; };
   // Warm start from the sequence-level rounds: cum[r][g][d] counts this head's keys that share
   // T*'s top r digits and have digit r <= d.  The cnt-th smallest key M is at most T* and at
@@ -864,6 +871,7 @@ __device__ __forceinline__ void select_emit_head(const kvc_schedule_params& p, S
                          rstar + 1, prefix);
     }
   }
+  SE_STAMP(6);
   // ties on the metric: the `take` entries with the smallest (physical block, offset)
   uint32_t Fstar = 0xFFFFFFFFu;
   const int32_t* cphys = ws.chunk_phys + base / bs;
@@ -917,8 +925,10 @@ __device__ __forceinline__ void select_emit_head(const kvc_schedule_params& p, S
     carry += scan_buf[U * NWAVES];
     __syncthreads();                                // scan_buf is rewritten by the next batch
   }
+  SE_STAMP(7);
   if (!(p.lean & 1))
     for (int idx = (int)cnt + tid; idx < n; idx += blockDim.x) out[idx] = p.null_value;
+  SE_STAMP(20);
 }
 
 // one workgroup per head; behind the small-eviction schedule (gated: a launch that normally finds
