@@ -39,7 +39,8 @@ def main():
              8: "select: start", 9: "head geometry, prefix", 10: "thresholds in LDS", 11: "T*", 12: "head counts",
              13: "written", 16: "records: start", 17: "list in LDS", 18: "sorted", 19: "written"}
     names.update({4: "select + emit: start", 5: "keys staged in LDS", 6: "M known", 7: "emitted", 20: "padded"})
-    for grp in ((0, 1, 2, 3), (16, 17, 18, 19), (8, 9, 10, 11, 12, 13), (4, 5, 6, 7, 20)):
+    names.update({21: "count + collect: start", 22: "first head found", 23: "tiles done", 14: "last batch reserved", 15: "stored"})
+    for grp in ((0, 1, 2, 3), (21, 22, 23, 14, 15), (16, 17, 18, 19), (8, 9, 10, 11, 12, 13), (4, 5, 6, 7, 20)):
         for a, b in zip(grp, grp[1:]):
             print(f"  {names[b]:28s} {(int(w[b]) - int(w[a])) * 0.01:7.2f} us")
         print()

@@ -434,12 +434,14 @@ __global__ __launch_bounds__(256) void count_collect_kernel(kvc_schedule_params 
       }
     }
   };
+  BR_STAMP(21);
   load_tile(kn, tb);
   g = wave_upper_bound_minus1(p.evicted_kv_offsets, G, tb * HTILE);
   g_beg = p.evicted_kv_offsets[g];
   g_end = (g + 1 < G) ? (int64_t)p.evicted_kv_offsets[g + 1] : N;
   rc = recs[g / LH];
   g0 = g;
+  BR_STAMP(22);
   for (int64_t t = tb; t < te; ++t) {
     const int64_t t0 = t * HTILE;
 #pragma unroll
@@ -473,10 +475,13 @@ __global__ __launch_bounds__(256) void count_collect_kernel(kvc_schedule_params 
       }
     }
   }
+  BR_STAMP(23);
   flush();
   if (qn > 0) drain(qn);
+  BR_STAMP(14);
   complete();
   __syncthreads();
+  BR_STAMP(15);
   if (threadIdx.x < 8 && wg_below[threadIdx.x]) atomicAdd(&ws.st_def[g0 + threadIdx.x], wg_below[threadIdx.x]);
 }
 
