@@ -900,7 +900,10 @@ extern "C" int kvc_aggregate_decode_harvest(const kvc_schedule_params* pp, float
                      p.num_seqs, reinterpret_cast<int32_t*>(hb + hl.seen_seq), p.harvest_position_delta);
   // a wave iteration covers 64 blocks; at most 16 Ki workgroups of 4 waves (grid-stride beyond)
   int64_t cb = (p.num_blocks + 255) / 256;
-  cb = cb < 1 ? 1 : (cb > 16384 ? 16384 : cb);
+#ifndef KVC_HV_GRID
+#define KVC_HV_GRID 16384
+#endif
+  cb = cb < 1 ? 1 : (cb > KVC_HV_GRID ? KVC_HV_GRID : cb);
   const dim3 grid((unsigned)cb), blk(256);
   const bool big = p.num_blocks * (int64_t)p.block_size >= (int64_t)1 << 28;        // >= 1 GiB of metrics
 #define KVC_HARVEST3(BSV, QVV, LZ)                                                                                  \

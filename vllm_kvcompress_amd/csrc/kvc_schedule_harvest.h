@@ -57,7 +57,10 @@ __global__ __launch_bounds__(256) void aggregate_harvest_kernel(kvc_schedule_par
                                                                 const uint32_t* __restrict__ hv_pivot, int qpk, int use_l2,
                                                                 int clear_temp) {
   constexpr int ROWS = BS;                           // 64 blocks x BS slots = BS rows of 64 slots
-  constexpr int U = 8;                               // rows in flight
+#ifndef KVC_HV_U
+#define KVC_HV_U 8
+#endif
+  constexpr int U = KVC_HV_U;                        // rows in flight
   constexpr int BPR = 64 / BS;                       // blocks per row
   static_assert(ROWS % U == 0, "block sizes 8 / 16 / 32");
   __shared__ uint32_t qk[4][128], qs[4][128], qg[4][128];
