@@ -230,6 +230,64 @@ int main() {
     hok = hok && freed == kfree && same(out[2][0], r_eli, "evicted_logical_indices (harvested vs own pass)") &&
           same(out[2][1], r_cnt, "evicted_kv_count (harvested vs own pass)") &&
           same(out[2][2], r_blk, "evicted_block_count (harvested vs own pass)");
+    // ---- ABI version 8: the same call without a wait in front of the launches -- N on the device, a bound on the host
+    // (digit rounds / bracket schedule: max_evicted_blocks_hint = -1), the flag word stored by the call's last launch
+    // itself; and a bound that does not hold: voided on the device, nothing written
+    {
+      int64_t* pinned = nullptr;
+      uint32_t* mirror = nullptr;
+      int64_t* n_dev = nullptr;
+      CK(hipHostMalloc(&pinned, 8 * (2 + B), hipHostMallocDefault));
+      CK(hipHostMalloc(&mirror, 4, hipHostMallocDefault));
+      CK(hipMalloc(&n_dev, 16));
+      const int64_t bound = N + 64 * bs;
+      const size_t wsb8 = kvc_schedule_evictions_workspace_bytes(bound, G, B, bs);
+      void* ws8;
+      CK(hipMalloc(&ws8, wsb8));
+      int32_t *o_ref[3], *o_def[3];
+      for (auto& o : {o_ref, o_def}) { CK(hipMalloc(&o[0], (size_t)bound * 4)); CK(hipMalloc(&o[1], G * 4)); CK(hipMalloc(&o[2], G * 4)); }
+      kvc_schedule_params p8 = sp;
+      p8.metrics = d_m; p8.harvest = 0; p8.harvest_buf = nullptr; p8.max_evicted_blocks_hint = -1; p8.schedule_path = 4;
+      // the waiting way (reference for this leg): N known, the bracket schedule forced
+      p8.total_slots = N; p8.total_slots_dev = nullptr;
+      p8.evicted_logical_indices = o_ref[0]; p8.evicted_kv_count = o_ref[1]; p8.evicted_block_count = o_ref[2];
+      KV(kvc_schedule_evictions(&p8, ws8, wsb8, s));
+      std::vector<int32_t> w_eli(N), w_cnt(G), w_blk(G);
+      CK(hipStreamSynchronize(s));
+      CK(hipMemcpy(w_eli.data(), o_ref[0], (size_t)N * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(w_cnt.data(), o_ref[1], G * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(w_blk.data(), o_ref[2], G * 4, hipMemcpyDeviceToHost));
+      // the deferred way: summary + schedule back to back, then the host reads
+      *mirror = 0; pinned[1 + B] = 0;
+      KV(kvc_schedule_batch_summary_deferred(d_ctx2, L * B * H, bs, d_kper, B, pinned, 7, n_dev, bound, s));
+      p8.total_slots = bound; p8.total_slots_dev = n_dev; p8.flag_mirror = mirror; p8.flag_ticket = 41;
+      p8.evicted_logical_indices = o_def[0]; p8.evicted_kv_count = o_def[1]; p8.evicted_block_count = o_def[2];
+      KV(kvc_schedule_evictions(&p8, ws8, wsb8, s));
+      while (__atomic_load_n(&pinned[1 + B], __ATOMIC_ACQUIRE) != 7) { }
+      bool ok8 = pinned[0] == N && pinned[1] == kfree;
+      CK(hipStreamSynchronize(s));
+      ok8 = ok8 && (*mirror >> 8) == 41u && (*mirror & 2u) == 0u;
+      std::vector<int32_t> g_eli(N);
+      CK(hipMemcpy(g_eli.data(), o_def[0], (size_t)N * 4, hipMemcpyDeviceToHost));
+      ok8 = ok8 && g_eli == w_eli && same(o_def[1], w_cnt, "evicted_kv_count (N on the device)") &&
+            same(o_def[2], w_blk, "evicted_block_count (N on the device)");
+      // a bound below N: the summary sets the void word, every kernel returns, outputs and mirror stay as they were
+      CK(hipMemsetAsync(o_def[1], 0x5A, G * 4, s));
+      *mirror = 0;
+      KV(kvc_schedule_batch_summary_deferred(d_ctx2, L * B * H, bs, d_kper, B, pinned, 8, n_dev, (int64_t)N - bs, s));
+      p8.total_slots = N - bs; p8.flag_ticket = 42;
+      KV(kvc_schedule_evictions(&p8, ws8, wsb8, s));
+      CK(hipStreamSynchronize(s));
+      std::vector<int32_t> v_cnt(G);
+      CK(hipMemcpy(v_cnt.data(), o_def[1], G * 4, hipMemcpyDeviceToHost));
+      bool untouched = true;
+      for (int g = 0; g < G; ++g) untouched = untouched && v_cnt[g] == 0x5A5A5A5A;
+      ok8 = ok8 && pinned[1 + B] == 8 && pinned[0] == N && untouched && *mirror == 0u;
+      if (!ok8) printf("ABI 8 leg failed: N %ld mirror %08x untouched %d\n", (long)pinned[0], *mirror, (int)untouched);
+      printf("schedule with N on the device (ABI 8): %s\n", ok8 ? "ok" : "MISMATCH");
+      hok = hok && ok8;
+      CK(hipHostFree(pinned)); CK(hipHostFree(mirror)); CK(hipFree(n_dev)); CK(hipFree(ws8));
+    }
     // ---- ABI version 6: the decode step without a sweep of the store.  Step 3 twice from the same store: (a) the fused-metric
     // attention of both layers, then the schedule's own pass on remembered pivots; (b) the same attention with the harvest
     // fields set (kvc_attention_harvest_begin in front), then the schedule on the lists the epilogues made (bits 0 | 3).
