@@ -240,18 +240,7 @@ __global__ __launch_bounds__(1024) void bracket_kernel(kvc_schedule_params p, Sc
     ws.bclaim[tid * 32] = 0u;
     if (tid == 0 && (int64_t)c != true_n(p, ws) / bs) atomicOr(ws.fallback, 1u | FB_HOLES_BIT);
   }
-  {
-    uint32_t hs = 0, la = 0;                         // sum of hang, heads that hold anything
-    for (int lh = tid; lh < LH; lh += blockDim.x) {
-      const int g = i * LH + lh;
-      ws.st_cnt[g] = 0u; ws.st_def[g] = 0u;
-      const int ctx = p.context_lens[((lh / H) * B + i) * H + (lh % H)];
-      if (ctx > 0) { hs += (uint32_t)p.hanging_token_count[g]; la += 1u; }
-    }
-    hs = wave_reduce_sum(hs); la = wave_reduce_sum(la);
-    if (lane == 0) { atomicAdd(&red_s[0], hs); atomicAdd(&red_s[1], la); }
-  }
-  BR_STAMP(1);
+  // (the sample's 32 keys per thread are requested first: the walk over the heads below does not depend on them)
   const int lg = bracket_stride_log2(n);
   const uint32_t stride = 1u << lg;
   const uint32_t* samp = ws.bsample + (int64_t)i * BR_CELLS;
@@ -265,6 +254,18 @@ __global__ __launch_bounds__(1024) void bracket_kernel(kvc_schedule_params p, Sc
     const bool have = c0 + stride <= n || (c0 < n && bracket_cell_slot(x, (uint32_t)i, lg) < n);
     key[r] = have ? samp[x] : 0xFFFFFFFFu;
   }
+  {
+    uint32_t hs = 0, la = 0;                         // sum of hang, heads that hold anything
+    for (int lh = tid; lh < LH; lh += blockDim.x) {
+      const int g = i * LH + lh;
+      ws.st_cnt[g] = 0u; ws.st_def[g] = 0u;
+      const int ctx = p.context_lens[((lh / H) * B + i) * H + (lh % H)];
+      if (ctx > 0) { hs += (uint32_t)p.hanging_token_count[g]; la += 1u; }
+    }
+    hs = wave_reduce_sum(hs); la = wave_reduce_sum(la);
+    if (lane == 0) { atomicAdd(&red_s[0], hs); atomicAdd(&red_s[1], la); }
+  }
+  BR_STAMP(1);
 #pragma unroll
   for (int r = 0; r < BR_R; ++r)
     if (key[r] < KEY_INF) { finmask |= 1u << r; kmin = min(kmin, key[r]); kmax = max(kmax, key[r]); }
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(256) void count_collect_kernel(kvc_schedule_params 
     const int64_t t0 = t * HTILE;
 #pragma unroll
     for (int u = 0; u < U; ++u) kv[u] = kn[u];
-    if (t + 1 < te) load_tile(kn, t + 1);            // the next tile's keys are on their way meanwhile
+    if (t + 1 < te) load_tile(kn, t + 1);            // the next tile's keys are on their way meanwhile (two ahead: no gain)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t r0 = t0 + (int64_t)(u * 4 + w) * CC_RUN;             // the step's first key
