@@ -18,6 +18,9 @@
 //    P comes back from LDS in the B-operand layout;
 //  * partition results are combined by a small second kernel (same maths as the reference's
 //    v2 reduce); heads that fit one partition are finished by the first kernel.
+//  * KVC_LAYOUT_SLOT_MAJOR blocks (K [bs][hd], V [bs][hd]: include/kvc_mi355x.h) run through the same two MFMA products;
+//    only the way the operands reach the lanes differs -- K tiles are read as the contiguous lines they are and parked in
+//    a wave-private LDS tile (KSlots), the P.V operand is assembled inside the lane from whole token rows (PvSlots).
 // The kernel is HBM-bound: 2*hd*e bytes per cached token and KV head.
 #pragma once
 #include "kvc_common.h"
